@@ -1,0 +1,496 @@
+"""
+CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+A NumPy restatement of the ADMM hot path of fabian-sp/GGLasso (reference @ /root/reference,
+v0.2.1).  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+may import this module; ``gglasso_amd`` never does (the product path fails loudly without the HIP
+library instead of falling back to anything in here).
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the real reference in the build
+container and stores inputs + reference outputs in ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
+checks every function below against those vectors (operators <= 1e-12, 10-iteration trajectories
+<= 1e-10, converged Theta <= 1e-8) plus the reference's own known-answer test (lambda1_mask = 0
+=> Theta = inv(S), tests/test_solvers.py:191-216).
+
+Third-party arithmetic: the reference calls ``numpy.linalg.eigh`` (LAPACK dsyevd via NumPy; pin
+``numpy>=1.17.3,<2.0.0`` in pyproject.toml:37, NumPy 2.2.6/OpenBLAS 0.3.29 in this image) at
+admm_solver.py:181,199 and single_admm_solver.py:164,174.  The oracle calls the same routine, so the
+only thing restated is what the reference does around it.  Eigenvectors are never compared (sign /
+order / degenerate-subspace ambiguity); only Q f(D) Q^T is.
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference/src/gglasso/).
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CLIB = None
+
+
+def _clib():
+    """C restatement of prox_p (oracle/ggl_oracle.c), used for sizes where Python loops are too slow."""
+    global _CLIB
+    if _CLIB is None:
+        path = os.path.join(_HERE, "libggl_oracle.so")
+        if not os.path.exists(path):
+            return None
+        lib = ctypes.CDLL(path)
+        dp = ctypes.POINTER(ctypes.c_double)
+        lib.oracle_prox_p.argtypes = [dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_int]
+        lib.oracle_prox_p.restype = ctypes.c_int
+        lib.oracle_condat.argtypes = [dp, dp, ctypes.c_int, ctypes.c_double]
+        lib.oracle_condat.restype = None
+        _CLIB = lib
+    return _CLIB
+
+
+# ---------------------------------------------------------------------------------------------
+# elementwise / group / fused prox operators
+# ---------------------------------------------------------------------------------------------
+
+def prox_1norm(v, l):
+    """solver/ggl_helper.py:12-14 -- soft threshold."""
+    return np.sign(v) * np.maximum(np.abs(v) - l, 0.)
+
+
+def prox_od_1norm(A, l):
+    """solver/ggl_helper.py:16-27 -- soft threshold everywhere, diagonal restored from the input.
+    ``l`` is a scalar or a (p,p) array (lambda1 * lambda1_mask, single_admm_solver.py:114)."""
+    res = np.sign(A) * np.maximum(np.abs(A) - l, 0.)
+    d = np.arange(min(A.shape))
+    res[d, d] = A[d, d]
+    return res
+
+
+def prox_2norm(v, l):
+    """solver/ggl_helper.py:38-43 -- prox of the Euclidean (Frobenius) norm."""
+    a = np.maximum(np.linalg.norm(v), l)
+    return v * (a - l) / a
+
+
+def prox_phi_ggl(v, l1, l2):
+    """solver/ggl_helper.py:68-71."""
+    return prox_2norm(prox_1norm(v, l1), l2)
+
+
+def condat_method(y, lam):
+    """solver/fgl_helper.py:11-68 -- Condat's direct 1-D total-variation prox (pure-Python loop;
+    small cases only, the C twin in ggl_oracle.c handles the rest)."""
+    y = np.asarray(y, dtype=np.float64)
+    N = len(y)
+    x = np.zeros(N)
+    k = k0 = kplus = kminus = 0
+    vmin = y[0] - lam
+    vmax = y[0] + lam
+    umin = lam
+    umax = -lam
+    while True:
+        while k == N - 1:
+            if umin < 0:
+                x[k0:kminus + 1] = vmin
+                kminus += 1
+                k = k0 = kminus
+                umin = lam
+                vmin = y[k]
+                umax = y[k] + lam - vmax
+            elif umax > 0:
+                x[k0:kplus + 1] = vmax
+                kplus += 1
+                k = k0 = kplus
+                umax = -lam
+                vmax = y[k]
+                umin = y[k] - lam - vmin
+            else:
+                x[k0:] = vmin + umin / (k - k0 + 1)
+                return x
+            if k == N - 1:
+                x[k] = vmin + umin
+                return x
+        if y[k + 1] + umin - vmin < -lam:
+            x[k0:kminus + 1] = vmin
+            kminus += 1
+            k = kplus = k0 = kminus
+            vmin = y[k]
+            vmax = y[k] + 2 * lam
+            umin = lam
+            umax = -lam
+        elif y[k + 1] + umax - vmax > lam:
+            x[k0:kplus + 1] = vmax
+            kplus += 1
+            k = kminus = k0 = kplus
+            vmin = y[k] - 2 * lam
+            vmax = y[k]
+            umin = lam
+            umax = -lam
+        else:
+            k += 1
+            umin = umin + y[k] - vmin
+            umax = umax + y[k] - vmax
+            if umin >= lam:
+                vmin += (umin - lam) / (k - k0 + 1)
+                umin = lam
+                kminus = k
+            if umax <= -lam:
+                vmax += (umax + lam) / (k - k0 + 1)
+                umax = -lam
+                kplus = k
+
+
+def prox_tv(v, l):
+    """solver/ggl_helper.py:126-129."""
+    return condat_method(v, l)
+
+
+def prox_phi_fgl(v, l1, l2):
+    """solver/ggl_helper.py:131-134 -- TV prox first, then soft threshold."""
+    return prox_1norm(prox_tv(v, l2), l1)
+
+
+def prox_p_loops(X, l1, l2, reg):
+    """solver/ggl_helper.py:190-207 restated pair by pair (pure Python; small cases)."""
+    assert np.abs(X - X.transpose(0, 2, 1)).max() <= 1e-5, "input X is not symmetric"
+    assert min(l1, l2) > 0
+    assert reg in ('GGL', 'FGL')
+    K, p, _ = X.shape
+    M = np.zeros((K, p, p))
+    for i in range(p):
+        for j in range(i, p):
+            if i == j:
+                M[:, i, j] = 0.5 * X[:, i, j]
+            elif reg == 'GGL':
+                M[:, i, j] = prox_phi_ggl(X[:, i, j], l1, l2)
+            else:
+                M[:, i, j] = prox_phi_fgl(X[:, i, j], l1, l2)
+    return M + M.transpose(0, 2, 1)
+
+
+def prox_p(X, l1, l2, reg):
+    """solver/ggl_helper.py:190-207.  Upper triangle (i<j) decides, output is exactly symmetric,
+    the diagonal passes through.  GGL is vectorised over all pairs; FGL uses the C restatement of
+    Condat's scan when it is built, the Python loop otherwise."""
+    assert np.abs(X - X.transpose(0, 2, 1)).max() <= 1e-5, "input X is not symmetric"
+    assert min(l1, l2) > 0, "lambda 1 and lambda2 have to be positive"
+    assert reg in ('GGL', 'FGL')
+    K, p, _ = X.shape
+    if reg == 'GGL':
+        iu = np.triu_indices(p, 1)
+        U = prox_1norm(X[:, iu[0], iu[1]], l1)                  # (K, npairs)
+        a = np.maximum(np.sqrt(np.sum(U * U, axis=0)), l2)
+        U = U * ((a - l2) / a)
+        M = np.zeros((K, p, p))
+        M[:, iu[0], iu[1]] = U
+        M = M + M.transpose(0, 2, 1)
+        d = np.arange(p)
+        M[:, d, d] = X[:, d, d]
+        return M
+    lib = _clib()
+    if lib is None:
+        return prox_p_loops(X, l1, l2, reg)
+    Xc = np.ascontiguousarray(X, dtype=np.float64)
+    out = np.empty_like(Xc)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib.oracle_prox_p(Xc.ctypes.data_as(dp), out.ctypes.data_as(dp), K, p, l1, l2, 2)
+    assert rc == 0
+    return out
+
+
+def prox_p_c(X, l1, l2, reg):
+    """prox_p through the C restatement for both penalties (cross-check of the two oracles)."""
+    lib = _clib()
+    assert lib is not None, "oracle/libggl_oracle.so not built (run oracle/build.sh)"
+    K, p, _ = X.shape
+    Xc = np.ascontiguousarray(X, dtype=np.float64)
+    out = np.empty_like(Xc)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib.oracle_prox_p(Xc.ctypes.data_as(dp), out.ctypes.data_as(dp), K, p, l1, l2,
+                           1 if reg == 'GGL' else 2)
+    assert rc == 0
+    return out
+
+
+def P_val(X, l1, l2, reg):
+    """solver/ggl_helper.py:162-176 -- value of the regulariser (off-diagonal only)."""
+    K, p, _ = X.shape
+    iu = np.triu_indices(p, 1)
+    V = X[:, iu[0], iu[1]]
+    res = l1 * np.abs(V).sum()
+    if reg == 'GGL':
+        res += l2 * np.sqrt((V * V).sum(axis=0)).sum()
+    else:
+        res += l2 * np.abs(V[1:] - V[:-1]).sum()
+    return 2 * res
+
+
+# ---------------------------------------------------------------------------------------------
+# log-det prox and low-rank prox (eigenvalue maps)
+# ---------------------------------------------------------------------------------------------
+
+def phip(d, beta):
+    """solver/ggl_helper.py:272-274."""
+    return 0.5 * (np.sqrt(d ** 2 + 4 * beta) + d)
+
+
+def phiplus(beta, D, Q):
+    """solver/ggl_helper.py:280-303 -- B = Q diag(phip(D)) Q^T."""
+    return (Q * phip(D, beta)) @ Q.T
+
+
+def prox_rank_norm(A, beta, D=np.array([]), Q=np.array([])):
+    """solver/ggl_helper.py:29-36 -- B = Q diag(max(D-beta,0)) Q^T (eigh recomputed if D is absent)."""
+    if len(D) != A.shape[0]:
+        D, Q = np.linalg.eigh(A)
+    return (Q * np.maximum(D - beta, 0.)) @ Q.T
+
+
+def phiplus_stack(W, beta):
+    """Omega-step of admm_solver.py:180-187 for a whole (K,p,p) stack; beta scalar or (K,)."""
+    D, Q = np.linalg.eigh(W)
+    beta = np.broadcast_to(np.asarray(beta, dtype=np.float64), (W.shape[0],))
+    return (Q * phip(D, beta[:, None])[:, None, :]) @ Q.transpose(0, 2, 1), D
+
+
+def rank_stack(C, beta):
+    """L-step of admm_solver.py:197-205 for a whole stack."""
+    D, Q = np.linalg.eigh(C)
+    beta = np.broadcast_to(np.asarray(beta, dtype=np.float64), (C.shape[0],))
+    return (Q * np.maximum(D - beta[:, None], 0.)[:, None, :]) @ Q.transpose(0, 2, 1)
+
+
+def f_obj(Omega, S):
+    """solver/ggl_helper.py:266-270 -- sum_k -log det Omega_k + <Omega, S>."""
+    return (-np.log(np.linalg.det(Omega))).sum() + np.sum(Omega * S)
+
+
+# ---------------------------------------------------------------------------------------------
+# stopping criteria
+# ---------------------------------------------------------------------------------------------
+
+def ADMM_stopping_criterion(Omega, Omega_t_1, Theta, L, X, S, rho, eps_abs, eps_rel, latent=False):
+    """solver/admm_solver.py:316-331 (K,p,p) and solver/single_admm_solver.py:277-291 (p,p).
+    Note dim*eps_abs with dim = K(p^2+p)/2, not sqrt(dim)."""
+    if S.ndim == 3:
+        K, p, _ = S.shape
+    else:
+        K, p = 1, S.shape[0]
+    dim = K * ((p ** 2 + p) / 2)
+    e_pri = dim * eps_abs + eps_rel * np.maximum(np.linalg.norm(Omega), np.linalg.norm(Theta - L))
+    e_dual = dim * eps_abs + eps_rel * rho * np.linalg.norm(X)
+    r = np.linalg.norm(Omega - Theta + L)
+    s = rho * np.linalg.norm(Omega - Omega_t_1)
+    return r, s, e_pri, e_dual
+
+
+def kkt_stopping_criterion_mgl(Omega, Theta, L, X, S, lambda1, lambda2, nk, reg, latent=False, mu1=None):
+    """solver/admm_solver.py:333-371 (X is the UNscaled dual here: the caller passes rho*X)."""
+    term1 = np.linalg.norm(Theta - prox_p(Theta + X, lambda1, lambda2, reg)) / (1 + np.linalg.norm(Theta))
+    term2 = np.linalg.norm(Theta - Omega - L) / (1 + np.linalg.norm(Theta))
+    proxK, _ = phiplus_stack(Omega - nk * S - X, nk[:, 0, 0])
+    term3 = np.linalg.norm(Omega - proxK) / (1 + np.linalg.norm(Omega))
+    term4 = 0
+    if latent:
+        proxL = rank_stack(L - X, mu1)
+        term4 = np.linalg.norm(L - proxL) / (1 + np.linalg.norm(L))
+    return max(term1, term2, term3, term4)
+
+
+def kkt_stopping_criterion_sgl(Omega, Theta, L, X, S, lambda1, latent=False, mu1=None):
+    """solver/single_admm_solver.py:293-320."""
+    term1 = np.linalg.norm(Theta - prox_od_1norm(Theta + X, l=lambda1)) / (1 + np.linalg.norm(Theta))
+    term2 = np.linalg.norm(Omega - Theta + L) / (1 + np.linalg.norm(Theta))
+    D, Q = np.linalg.eigh(Omega - S - X)
+    term3 = np.linalg.norm(Omega - phiplus(1, D, Q)) / (1 + np.linalg.norm(Omega))
+    term4 = 0
+    if latent:
+        D, Q = np.linalg.eigh(L - X)
+        term4 = np.linalg.norm(L - prox_rank_norm(L - X, mu1, D, Q)) / (1 + np.linalg.norm(L))
+    return max(term1, term2, term3, term4)
+
+
+# ---------------------------------------------------------------------------------------------
+# full host loops (control flow of the reference, operators from above)
+# ---------------------------------------------------------------------------------------------
+
+def ADMM_MGL(S, lambda1, lambda2, reg, Omega_0, Theta_0=np.array([]), X_0=np.array([]),
+             n_samples=None, tol=1e-5, rtol=1e-4, stopping_criterion='boyd', update_rho=True,
+             rho=1., max_iter=1000, verbose=False, measure=False, latent=False, mu1=None,
+             history=None):
+    """solver/admm_solver.py:13-313.  ``history`` (a list) receives (r,s,e_pri,e_dual,rho) per
+    iteration; it is an oracle-only extra for trajectory tests."""
+    assert Omega_0.shape == S.shape
+    assert S.shape[1] == S.shape[2]
+    assert reg in ['GGL', 'FGL']
+    assert min(lambda1, lambda2) > 0
+    K, p, _ = S.shape
+    assert rho > 0
+    if latent:
+        if isinstance(mu1, float):
+            mu1 = mu1 * np.ones(K)
+        assert mu1 is not None
+        assert np.all(mu1 > 0)
+    if n_samples is None:
+        nk = np.ones((K, 1, 1))
+    elif isinstance(n_samples, int):
+        nk = n_samples * np.ones((K, 1, 1))
+    else:
+        nk = np.asarray(n_samples, dtype=np.float64).reshape(K, 1, 1)
+
+    Omega_t = Omega_0.copy()
+    if len(Theta_0) == 0:
+        Theta_0 = Omega_0.copy()
+    if len(X_0) == 0:
+        X_0 = np.zeros((K, p, p))
+    Theta_t = Theta_0.copy()
+    L_t = np.zeros((K, p, p))
+    X_t = X_0.copy()
+    residual = np.zeros(max_iter)
+    objective = np.zeros(max_iter)
+    status = ''
+
+    for iter_t in range(max_iter):
+        Omega_t_1 = Omega_t
+        W_t = Theta_t - L_t - X_t - (nk / rho) * S
+        Omega_t, _ = phiplus_stack(W_t, nk[:, 0, 0] / rho)
+        Theta_t = prox_p(Omega_t + L_t + X_t, (1 / rho) * lambda1, (1 / rho) * lambda2, reg)
+        if latent:
+            L_t = rank_stack(Theta_t - X_t - Omega_t, mu1 / rho)
+        X_t = X_t + Omega_t - Theta_t + L_t
+        if measure:
+            objective[iter_t] = f_obj(Omega_t, S) + P_val(Theta_t, lambda1, lambda2, reg)
+
+        if stopping_criterion == 'boyd':
+            r_t, s_t, e_pri, e_dual = ADMM_stopping_criterion(Omega_t, Omega_t_1, Theta_t, L_t, X_t,
+                                                              S, rho, tol, rtol, latent)
+            if history is not None:
+                history.append((r_t, s_t, e_pri, e_dual, rho))
+            if update_rho:
+                if r_t >= 10 * s_t:
+                    rho_new = 2 * rho
+                elif s_t >= 10 * r_t:
+                    rho_new = 0.5 * rho
+                else:
+                    rho_new = 1. * rho
+                X_t = (rho / rho_new) * X_t
+                rho = rho_new
+            residual[iter_t] = max(r_t, s_t)
+            if (r_t <= e_pri) and (s_t <= e_dual):
+                status = 'optimal'
+                break
+        else:
+            eta_A = kkt_stopping_criterion_mgl(Omega_t, Theta_t, L_t, rho * X_t, S, lambda1, lambda2,
+                                               nk, reg, latent, mu1)
+            residual[iter_t] = eta_A
+            if eta_A <= tol:
+                status = 'optimal'
+                break
+
+    if status != 'optimal':
+        if stopping_criterion == 'boyd':
+            if r_t <= e_pri:
+                status = 'primal optimal'
+            elif s_t <= e_dual:
+                status = 'dual optimal'
+            else:
+                status = 'max iterations reached'
+        else:
+            status = 'max iterations reached'
+
+    sol = {'Omega': Omega_t, 'Theta': Theta_t, 'L': L_t, 'X': X_t}
+    info = {'status': status, 'iterations': iter_t + 1, 'rho': rho}
+    if measure:
+        info['residual'] = residual[:iter_t + 1]
+        info['objective'] = objective[:iter_t + 1]
+    return sol, info
+
+
+def ADMM_SGL(S, lambda1, Omega_0, Theta_0=np.array([]), X_0=np.array([]), rho=1., max_iter=1000,
+             tol=1e-7, rtol=1e-4, stopping_criterion='boyd', update_rho=True, verbose=False,
+             measure=False, latent=False, mu1=None, lambda1_mask=None, history=None):
+    """solver/single_admm_solver.py:15-275."""
+    assert Omega_0.shape == S.shape
+    assert S.shape[0] == S.shape[1]
+    p = S.shape[0]
+    assert lambda1 > 0
+    if lambda1_mask is not None:
+        assert lambda1_mask.shape == (p, p)
+        assert np.all(lambda1_mask >= 0)
+        assert np.all(np.abs(lambda1_mask.T - lambda1_mask) <= 1e-5)
+        lambda1 = lambda1 * lambda1_mask
+    assert np.all(lambda1 >= 0)
+    assert stopping_criterion in ["boyd", "kkt"]
+    if latent:
+        assert mu1 is not None
+        assert mu1 > 0
+    assert rho > 0
+
+    Omega_t = Omega_0.copy()
+    if len(Theta_0) == 0:
+        Theta_0 = Omega_0.copy()
+    if len(X_0) == 0:
+        X_0 = np.zeros((p, p))
+    Theta_t = Theta_0.copy()
+    L_t = np.zeros((p, p))
+    X_t = X_0.copy()
+    residual = np.zeros(max_iter)
+    status = ''
+
+    for iter_t in range(max_iter):
+        W_t = Theta_t - L_t - X_t - (1 / rho) * S
+        eigD, eigQ = np.linalg.eigh(W_t)
+        Omega_t_1 = Omega_t
+        Omega_t = phiplus(beta=1 / rho, D=eigD, Q=eigQ)
+        Theta_t = prox_od_1norm(Omega_t + L_t + X_t, (1 / rho) * lambda1)
+        if latent:
+            C_t = Theta_t - X_t - Omega_t
+            eigD1, eigQ1 = np.linalg.eigh(C_t)
+            L_t = prox_rank_norm(C_t, mu1 / rho, D=eigD1, Q=eigQ1)
+        X_t = X_t + Omega_t - Theta_t + L_t
+
+        if stopping_criterion == 'boyd':
+            r_t, s_t, e_pri, e_dual = ADMM_stopping_criterion(Omega_t, Omega_t_1, Theta_t, L_t, X_t,
+                                                              S, rho, tol, rtol, latent)
+            if history is not None:
+                history.append((r_t, s_t, e_pri, e_dual, rho))
+            if update_rho:
+                if r_t >= 10 * s_t:
+                    rho_new = 2 * rho
+                elif s_t >= 10 * r_t:
+                    rho_new = 0.5 * rho
+                else:
+                    rho_new = 1. * rho
+                X_t = (rho / rho_new) * X_t
+                rho = rho_new
+            residual[iter_t] = max(r_t, s_t)
+            if (r_t <= e_pri) and (s_t <= e_dual):
+                status = 'optimal'
+                break
+        else:
+            eta_A = kkt_stopping_criterion_sgl(Omega_t, Theta_t, L_t, rho * X_t, S, lambda1, latent, mu1)
+            residual[iter_t] = eta_A
+            if eta_A <= tol:
+                status = 'optimal'
+                break
+
+    if status != 'optimal':
+        if stopping_criterion == 'boyd':
+            if r_t <= e_pri:
+                status = 'primal optimal'
+            elif s_t <= e_dual:
+                status = 'dual optimal'
+            else:
+                status = 'max iterations reached'
+        else:
+            status = 'max iterations reached'
+
+    if latent:
+        sol = {'Omega': Omega_t, 'Theta': Theta_t, 'L': L_t, 'X': X_t}
+    else:
+        sol = {'Omega': Omega_t, 'Theta': Theta_t, 'X': X_t}
+    info = {'status': status, 'iterations': iter_t + 1, 'rho': rho}
+    if measure:
+        info['residual'] = residual[:iter_t + 1]
+    return sol, info
