@@ -1,0 +1,106 @@
+"""ctypes binding of libggl_hip.so (include/ggl_hip.h).  There is no fallback: if the library is
+missing, fails to load, or sees no GPU when one is required, this module raises."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libggl_hip.so")
+
+# mirrors include/ggl_hip.h
+REG_SGL, REG_GGL, REG_FGL = 0, 1, 2
+EIG_AUTO, EIG_JACOBI, EIG_ROCSOLVER = 0, 1, 2
+JACOBI_MAX_P = 128
+BUF_S, BUF_OMEGA, BUF_THETA, BUF_L, BUF_X, BUF_GROUPSQ, BUF_NORMS, BUF_OMEGA_PREV = range(8)
+E_ARG, E_HIP, E_SOLVER, E_ALLOC = -1, -2, -3, -4
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_d = ctypes.c_double
+
+_SIGNATURES = {
+    "ggl_version": ([], _i),
+    "ggl_last_error": ([], ctypes.c_char_p),
+    "ggl_device_count": ([], _i),
+    "ggl_ctx_create": ([_i, _i, _i, _i, _vp, ctypes.POINTER(_vp)], _i),
+    "ggl_ctx_destroy": ([_vp], _i),
+    "ggl_ctx_sync": ([_vp], _i),
+    "ggl_device_ptr": ([_vp, _i], _vp),
+    "ggl_set_S": ([_vp, _dp], _i),
+    "ggl_set_state": ([_vp, _dp, _dp, _dp, _dp], _i),
+    "ggl_get_state": ([_vp, _dp, _dp, _dp, _dp], _i),
+    "ggl_set_lambda1_mask": ([_vp, _dp], _i),
+    "ggl_admm_step": ([_vp, _d, _d, _d, _i, _i, _dp, _dp, _dp], _i),
+    "ggl_step_omega": ([_vp, _d, _i, _dp], _i),
+    "ggl_step_group_partial": ([_vp, _d, _d], _i),
+    "ggl_step_finish": ([_vp, _d, _d, _d, _i, _i, _dp, _i, _dp], _i),
+    "ggl_scale_X": ([_vp, _d], _i),
+    "ggl_exit_checks": ([_vp, _i, _dp], _i),
+    "ggl_objective": ([_vp, _d, _d, _i, _dp], _i),
+    "ggl_kkt_residual": ([_vp, _d, _d, _d, _i, _i, _dp, _dp, _dp], _i),
+    "ggl_eigh_batched": ([_i, _i, _dp, _dp, _dp, _i], _i),
+    "ggl_phiplus": ([_i, _i, _dp, _dp, _dp, _dp], _i),
+    "ggl_prox_rank_norm": ([_i, _i, _dp, _dp, _dp, _dp], _i),
+    "ggl_phiplus_matrix": ([_i, _i, _dp, _dp, _dp, _i], _i),
+    "ggl_rank_matrix": ([_i, _i, _dp, _dp, _dp, _i], _i),
+    "ggl_prox_od_1norm": ([_i, _dp, _d, _dp, _dp], _i),
+    "ggl_prox_p": ([_i, _i, _dp, _d, _d, _i, _dp], _i),
+    "ggl_prox_tv": ([_i, _i, _dp, _d, _dp], _i),
+    "ggl_prox_2norm": ([_i, _i, _dp, _d, _dp], _i),
+    "ggl_prox_phi": ([_i, _i, _dp, _d, _d, _i, _dp], _i),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+def load():
+    """Load libggl_hip.so (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m gglasso_amd.build` "
+            "(gglasso_amd has no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in _SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().ggl_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Map a C return code to the exception the reference would raise (AssertionError for bad
+    arguments, solver/admm_solver.py:113-127) or RuntimeError."""
+    if rc >= 0:
+        return rc
+    msg = last_error()
+    if rc == E_ARG:
+        raise AssertionError(msg)
+    raise RuntimeError(f"libggl_hip error {rc}: {msg}")
+
+
+def require_gpu():
+    n = load().ggl_device_count()
+    if n <= 0:
+        raise RuntimeError("gglasso_amd needs an AMD GPU (MI355X / gfx950); none is visible "
+                           f"(ggl_device_count() = {n}: {last_error()})")
+    return n
+
+
+def as_c(a):
+    """C-contiguous float64 view/copy of a NumPy array (the ABI's only data type)."""
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)

@@ -1,0 +1,56 @@
+// Shared device helpers for libggl_hip (gfx950 only; wavefront = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.hpp"
+
+#define GGL_WAVE 64
+
+namespace ggl {
+
+// soft threshold, solver/ggl_helper.py:12-14 (sign(v) * max(|v| - l, 0))
+__device__ __forceinline__ double soft(double v, double l)
+{
+    double a = fmax(fabs(v) - l, 0.0);
+    return v > 0.0 ? a : (v < 0.0 ? -a : 0.0);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Deterministic block reduction of NV running sums; result valid in thread 0.
+// scratch: NV * (blockDim/64) doubles of LDS.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scratch[wid * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double s = 0.0;
+            for (int w = 0; w < nw; ++w) s += scratch[w * NV + i];
+            v[i] = s;
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace ggl

@@ -1,0 +1,344 @@
+// HBM-streaming kernels of the ADMM iteration: W formation, SGL Theta-step, dual update,
+// stopping-test norms, small utilities.  grid = (chunks of p*p, K); every block writes its
+// five partial sums to a fixed slot so the reduction order (and the result) is deterministic.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace ggl {
+
+static constexpr int EW_THREADS = 256;
+static constexpr int EW_EPT = 4;   // elements per thread
+static constexpr int EW_CHUNK = EW_THREADS * EW_EPT;
+
+int elementwise_blocks(int p)
+{
+    size_t pp = (size_t)p * p;
+    return (int)((pp + EW_CHUNK - 1) / EW_CHUNK);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_L>
+__global__ __launch_bounds__(EW_THREADS) void k_form_W(double* __restrict__ W, const double* __restrict__ Theta,
+                                                       const double* __restrict__ L, const double* __restrict__ X,
+                                                       const double* __restrict__ S, const double* __restrict__ betaK,
+                                                       size_t pp)
+{
+    const int k = blockIdx.y;
+    const double beta = betaK[k];
+    const size_t base = (size_t)k * pp;
+    size_t i = (size_t)blockIdx.x * EW_CHUNK + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < EW_EPT; ++e, i += EW_THREADS) {
+        if (i < pp) {
+            double t = Theta[base + i];
+            if (HAS_L) t -= L[base + i];
+            W[base + i] = (t - X[base + i]) - beta * S[base + i];
+        }
+    }
+}
+
+void launch_form_W(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
+                   const double* S, const double* betaK, int K, int p)
+{
+    size_t pp = (size_t)p * p;
+    dim3 grid(elementwise_blocks(p), K);
+    if (L)
+        hipLaunchKernelGGL(k_form_W<true>, grid, dim3(EW_THREADS), 0, st, W, Theta, L, X, S, betaK, pp);
+    else
+        hipLaunchKernelGGL(k_form_W<false>, grid, dim3(EW_THREADS), 0, st, W, Theta, L, X, S, betaK, pp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SGL Theta-step.  single_admm_solver.py:169 (Theta), :178 (X), :277-291 (norms).
+template <bool LATENT, bool MASK>
+__global__ __launch_bounds__(EW_THREADS) void k_theta_sgl(double* __restrict__ Theta, double* __restrict__ X,
+                                                          double* __restrict__ C, const double* __restrict__ Omega,
+                                                          const double* __restrict__ OmegaPrev,
+                                                          const double* __restrict__ L, const double* __restrict__ l1K,
+                                                          const double* __restrict__ mask, double inv_rho,
+                                                          double* __restrict__ partials, int p)
+{
+    __shared__ double scratch[GGL_NNORM * (EW_THREADS / 64)];
+    const int k = blockIdx.y;
+    const size_t pp = (size_t)p * p;
+    const size_t base = (size_t)k * pp;
+    const double lk = MASK ? 0.0 : l1K[k];
+    double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
+    size_t i = (size_t)blockIdx.x * EW_CHUNK + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < EW_EPT; ++e, i += EW_THREADS) {
+        if (i < pp) {
+            const int r = (int)(i / p), c = (int)(i - (size_t)r * p);
+            const double om = Omega[base + i];
+            const double x = X[base + i];
+            const double l = LATENT ? L[base + i] : 0.0;
+            const double v = (om + l) + x;
+            const double thr = MASK ? inv_rho * mask[i] : lk;
+            const double th = (r == c) ? v : soft(v, thr);
+            Theta[base + i] = th;
+            if (LATENT) {
+                C[base + i] = (th - x) - om;
+            } else {
+                const double xn = (x + om) - th;   // single_admm_solver.py:178
+                X[base + i] = xn;
+                const double dp = om - OmegaPrev[base + i];
+                acc[0] += om * om;
+                acc[1] += th * th;
+                acc[2] += xn * xn;
+                acc[3] += (om - th) * (om - th);
+                acc[4] += dp * dp;
+            }
+        }
+    }
+    if (!LATENT) {
+        block_sum<GGL_NNORM>(acc, scratch);
+        if (threadIdx.x == 0) {
+            double* o = partials + ((size_t)k * gridDim.x + blockIdx.x) * GGL_NNORM;
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) o[v] = acc[v];
+        }
+    }
+}
+
+void launch_theta_sgl(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
+                      const double* OmegaPrev, const double* L, const double* l1K, const double* mask,
+                      double inv_rho, int latent, double* partials, int K, int p)
+{
+    dim3 grid(elementwise_blocks(p), K), blk(EW_THREADS);
+#define GGL_TS(LAT, MSK)                                                                              \
+    hipLaunchKernelGGL((k_theta_sgl<LAT, MSK>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1K, \
+                       mask, inv_rho, partials, p)
+    if (latent) {
+        if (mask) GGL_TS(true, true); else GGL_TS(true, false);
+    } else {
+        if (mask) GGL_TS(false, true); else GGL_TS(false, false);
+    }
+#undef GGL_TS
+}
+
+// ---------------------------------------------------------------------------------------------
+// X += (Omega - Theta) + L ; norms (admm_solver.py:208, 316-331)
+template <bool HAS_L>
+__global__ __launch_bounds__(EW_THREADS) void k_dual_update(double* __restrict__ X, const double* __restrict__ Omega,
+                                                            const double* __restrict__ OmegaPrev,
+                                                            const double* __restrict__ Theta,
+                                                            const double* __restrict__ L,
+                                                            double* __restrict__ partials, size_t pp)
+{
+    __shared__ double scratch[GGL_NNORM * (EW_THREADS / 64)];
+    const int k = blockIdx.y;
+    const size_t base = (size_t)k * pp;
+    double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
+    size_t i = (size_t)blockIdx.x * EW_CHUNK + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < EW_EPT; ++e, i += EW_THREADS) {
+        if (i < pp) {
+            const double om = Omega[base + i], th = Theta[base + i];
+            const double l = HAS_L ? L[base + i] : 0.0;
+            const double res = (om - th) + l;
+            const double xn = X[base + i] + res;
+            X[base + i] = xn;
+            const double dp = om - OmegaPrev[base + i];
+            acc[0] += om * om;
+            acc[1] += (th - l) * (th - l);
+            acc[2] += xn * xn;
+            acc[3] += res * res;
+            acc[4] += dp * dp;
+        }
+    }
+    block_sum<GGL_NNORM>(acc, scratch);
+    if (threadIdx.x == 0) {
+        double* o = partials + ((size_t)k * gridDim.x + blockIdx.x) * GGL_NNORM;
+#pragma unroll
+        for (int v = 0; v < GGL_NNORM; ++v) o[v] = acc[v];
+    }
+}
+
+void launch_dual_update(hipStream_t st, double* X, const double* Omega, const double* OmegaPrev,
+                        const double* Theta, const double* L, double* partials, int K, int p)
+{
+    size_t pp = (size_t)p * p;
+    dim3 grid(elementwise_blocks(p), K), blk(EW_THREADS);
+    if (L)
+        hipLaunchKernelGGL(k_dual_update<true>, grid, blk, 0, st, X, Omega, OmegaPrev, Theta, L, partials, pp);
+    else
+        hipLaunchKernelGGL(k_dual_update<false>, grid, blk, 0, st, X, Omega, OmegaPrev, Theta, L, partials, pp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[k][v] = sum_b partials[k][b][v]; one block per k, fixed summation tree.
+__global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partials, int nblk, int nv,
+                                                         double* __restrict__ out)
+{
+    __shared__ double sh[256];
+    const int k = blockIdx.x;
+    for (int v = 0; v < nv; ++v) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += 256) s += partials[((size_t)k * nblk + b) * nv + v];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[(size_t)k * nv + v] = sh[0];
+        __syncthreads();
+    }
+}
+
+void launch_reduce_partials(hipStream_t st, const double* partials, int K, int nblk, int nv, double* out)
+{
+    hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(256), 0, st, partials, nblk, nv, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scale(double* __restrict__ X, double f, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) X[i] *= f;
+}
+
+void launch_scale(hipStream_t st, double* X, double f, size_t n)
+{
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_scale, dim3(blocks), dim3(256), 0, st, X, f, n);
+}
+
+__global__ __launch_bounds__(256) void k_sub(double* __restrict__ D, const double* __restrict__ A,
+                                             const double* __restrict__ B, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        D[i] = B ? A[i] - B[i] : A[i];
+}
+
+void launch_sub(hipStream_t st, double* D, const double* A, const double* B, size_t n)
+{
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_sub, dim3(blocks), dim3(256), 0, st, D, A, B, n);
+}
+
+// out[k] = max |A[k,i,j] - A[k,j,i]|   (exit check admm_solver.py:284-291; runs once per solve)
+__global__ __launch_bounds__(256) void k_asym_max(const double* __restrict__ A, int p, double* __restrict__ out)
+{
+    __shared__ double sh[4];
+    const int k = blockIdx.x;
+    const double* a = A + (size_t)k * p * p;
+    double m = 0.0;
+    const size_t pp = (size_t)p * p;
+    for (size_t i = threadIdx.x; i < pp; i += 256) {
+        const int r = (int)(i / p), c = (int)(i - (size_t)r * p);
+        if (c > r) m = fmax(m, fabs(a[i] - a[(size_t)c * p + r]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[k] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+void launch_asym_max(hipStream_t st, const double* A, int K, int p, double* out)
+{
+    hipLaunchKernelGGL(k_asym_max, dim3(K), dim3(256), 0, st, A, p, out);
+}
+
+// partials[k][b][0] = sum_chunk A*B
+__global__ __launch_bounds__(EW_THREADS) void k_dot(const double* __restrict__ A, const double* __restrict__ B,
+                                                    size_t pp, double* __restrict__ partials)
+{
+    __shared__ double scratch[EW_THREADS / 64];
+    const int k = blockIdx.y;
+    const size_t base = (size_t)k * pp;
+    double acc[1] = {0.0};
+    size_t i = (size_t)blockIdx.x * EW_CHUNK + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < EW_EPT; ++e, i += EW_THREADS)
+        if (i < pp) acc[0] += A[base + i] * B[base + i];
+    block_sum<1>(acc, scratch);
+    if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = acc[0];
+}
+
+void launch_dot(hipStream_t st, const double* A, const double* B, int K, int p, double* partials)
+{
+    size_t pp = (size_t)p * p;
+    hipLaunchKernelGGL(k_dot, dim3(elementwise_blocks(p), K), dim3(EW_THREADS), 0, st, A, B, pp, partials);
+}
+
+__global__ __launch_bounds__(256) void k_axpy(double* __restrict__ out, const double* __restrict__ A, double c,
+                                              const double* __restrict__ B, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = A[i] + c * B[i];
+}
+
+void launch_axpy(hipStream_t st, double* out, const double* A, double c, const double* B, size_t n)
+{
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_axpy, dim3(blocks), dim3(256), 0, st, out, A, c, B, n);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void k_kkt_w(double* __restrict__ out, const double* __restrict__ Omega,
+                                                      const double* __restrict__ S, const double* __restrict__ X,
+                                                      const double* __restrict__ nkK, double rho, size_t pp)
+{
+    const int k = blockIdx.y;
+    const double nk = nkK[k];
+    const size_t base = (size_t)k * pp;
+    size_t i = (size_t)blockIdx.x * EW_CHUNK + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < EW_EPT; ++e, i += EW_THREADS)
+        if (i < pp) out[base + i] = (Omega[base + i] - nk * S[base + i]) - rho * X[base + i];
+}
+
+void launch_kkt_w(hipStream_t st, double* out, const double* Omega, const double* S, const double* X,
+                  const double* nkK, double rho, int K, int p)
+{
+    size_t pp = (size_t)p * p;
+    hipLaunchKernelGGL(k_kkt_w, dim3(elementwise_blocks(p), K), dim3(EW_THREADS), 0, st, out, Omega, S, X, nkK, rho, pp);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void k_sqdiff(const double* __restrict__ A, const double* __restrict__ B,
+                                                       size_t pp, double* __restrict__ partials)
+{
+    __shared__ double scratch[EW_THREADS / 64];
+    const int k = blockIdx.y;
+    const size_t base = (size_t)k * pp;
+    double acc[1] = {0.0};
+    size_t i = (size_t)blockIdx.x * EW_CHUNK + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < EW_EPT; ++e, i += EW_THREADS)
+        if (i < pp) {
+            const double d = B ? A[base + i] - B[base + i] : A[base + i];
+            acc[0] += d * d;
+        }
+    block_sum<1>(acc, scratch);
+    if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = acc[0];
+}
+
+void launch_sqdiff(hipStream_t st, const double* A, const double* B, int K, int p, double* partials)
+{
+    size_t pp = (size_t)p * p;
+    hipLaunchKernelGGL(k_sqdiff, dim3(elementwise_blocks(p), K), dim3(EW_THREADS), 0, st, A, B, pp, partials);
+}
+
+// stateless prox_od_1norm (ggl_helper.py:16-27)
+__global__ __launch_bounds__(256) void k_prox_od(double* __restrict__ out, const double* __restrict__ A, double lam,
+                                                 const double* __restrict__ lam_pp, int p)
+{
+    const size_t pp = (size_t)p * p;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pp; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / p), c = (int)(i - (size_t)r * p);
+        const double v = A[i];
+        out[i] = (r == c) ? v : soft(v, lam_pp ? lam_pp[i] : lam);
+    }
+}
+
+void launch_prox_od(hipStream_t st, double* out, const double* A, double lam, const double* lam_pp, int p)
+{
+    size_t pp = (size_t)p * p;
+    int blocks = (int)((pp + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_prox_od, dim3(blocks), dim3(256), 0, st, out, A, lam, lam_pp, p);
+}
+
+}  // namespace ggl

@@ -1,0 +1,755 @@
+// C ABI of libggl_hip.so (include/ggl_hip.h): context, state movement, the ADMM iteration and the
+// stateless operator entry points.  Everything here is host code that sequences the gfx950 kernels
+// of elementwise.hip / theta_pair.hip / eig_jacobi.hip / recon_gemm.hip on one HIP stream.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../../include/ggl_hip.h"
+#include "kernels.hpp"
+
+using namespace ggl;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(GGL_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define ARGCHK(cond, msg)                                       \
+    do {                                                        \
+        if (!(cond)) return fail(GGL_E_ARG, "bad argument: %s", msg); \
+    } while (0)
+
+struct ggl_ctx {
+    int device = 0, K = 0, p = 0, flags = 0, eig = 0;
+    size_t n = 0;   // K*p*p
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    rocblas_handle blas = nullptr;
+    double *S = nullptr, *Om[2] = {nullptr, nullptr}, *Theta = nullptr, *L = nullptr, *X = nullptr, *W = nullptr;
+    int cur = 0;              // Om[cur] is Omega_t, Om[cur^1] is Omega_{t-1}
+    double *DvO = nullptr, *DvL = nullptr, *scale = nullptr, *E = nullptr;   // (K,p), (K,p), (2,K,p), (K,p)
+    int* info = nullptr;      // (K)
+    double* par = nullptr;    // device: beta[K] | l1[K] | mu[K] | nk[K]
+    double* par_h = nullptr;  // pinned mirror
+    double *mask = nullptr, *groupsq = nullptr;   // (p,p)
+    bool has_mask = false;
+    double* partials = nullptr;
+    size_t partials_len = 0;
+    double *norms = nullptr, *norms_h = nullptr;  // (K,8) device / pinned
+    int* info_h = nullptr;                        // pinned (K)
+    bool nk_valid = false;
+};
+
+static bool use_jacobi(const ggl_ctx* c)
+{
+    if (c->eig == GGL_EIG_JACOBI) return true;
+    if (c->eig == GGL_EIG_ROCSOLVER) return false;
+    return jacobi_fits(c->p);
+}
+
+extern "C" int ggl_version(void) { return GGL_VERSION; }
+extern "C" const char* ggl_last_error(void) { return g_err; }
+
+extern "C" int ggl_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(GGL_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+static int ctx_alloc(ggl_ctx* c)
+{
+    const size_t nb = c->n * sizeof(double);
+    const size_t kp = (size_t)c->K * c->p;
+    HIPCHK(hipMalloc(&c->S, nb));
+    HIPCHK(hipMalloc(&c->Om[0], nb));
+    HIPCHK(hipMalloc(&c->Om[1], nb));
+    HIPCHK(hipMalloc(&c->Theta, nb));
+    HIPCHK(hipMalloc(&c->L, nb));
+    HIPCHK(hipMalloc(&c->X, nb));
+    HIPCHK(hipMalloc(&c->W, nb));
+    HIPCHK(hipMalloc(&c->DvO, kp * sizeof(double)));
+    HIPCHK(hipMalloc(&c->DvL, kp * sizeof(double)));
+    HIPCHK(hipMalloc(&c->scale, 2 * kp * sizeof(double)));
+    HIPCHK(hipMalloc(&c->E, kp * sizeof(double)));
+    HIPCHK(hipMalloc(&c->info, c->K * sizeof(int)));
+    HIPCHK(hipMalloc(&c->par, 4 * (size_t)c->K * sizeof(double)));
+    HIPCHK(hipHostMalloc(&c->par_h, 4 * (size_t)c->K * sizeof(double)));
+    HIPCHK(hipMalloc(&c->mask, (size_t)c->p * c->p * sizeof(double)));
+    HIPCHK(hipMalloc(&c->groupsq, (size_t)c->p * c->p * sizeof(double)));
+    HIPCHK(hipMemsetAsync(c->groupsq, 0, (size_t)c->p * c->p * sizeof(double), c->stream));
+    size_t pl = (size_t)c->K * elementwise_blocks(c->p) * GGL_NNORM;
+    pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_GGL, c->K) * GGL_NNORM);
+    pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_FGL, c->K) * GGL_NNORM);
+    c->partials_len = pl;
+    HIPCHK(hipMalloc(&c->partials, pl * sizeof(double)));
+    HIPCHK(hipMalloc(&c->norms, (size_t)c->K * 8 * sizeof(double)));
+    HIPCHK(hipHostMalloc(&c->norms_h, (size_t)c->K * 8 * sizeof(double)));
+    HIPCHK(hipHostMalloc(&c->info_h, (size_t)c->K * sizeof(int)));
+    HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
+    HIPCHK(hipMemsetAsync(c->X, 0, nb, c->stream));
+    HIPCHK(hipMemsetAsync(c->Om[1], 0, nb, c->stream));
+    return GGL_OK;
+}
+
+extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream, ggl_ctx** out)
+{
+    ARGCHK(out != nullptr, "out");
+    ARGCHK(K >= 1 && p >= 1, "K, p must be positive");
+    const int eig = flags & 0xff;
+    ARGCHK(eig == GGL_EIG_AUTO || eig == GGL_EIG_JACOBI || eig == GGL_EIG_ROCSOLVER, "eigensolver selector");
+    ARGCHK(eig != GGL_EIG_JACOBI || jacobi_fits(p), "GGL_EIG_JACOBI needs p <= GGL_JACOBI_MAX_P");
+    HIPCHK(hipSetDevice(device));
+    ggl_ctx* c = new ggl_ctx();
+    c->device = device;
+    c->K = K;
+    c->p = p;
+    c->flags = flags;
+    c->eig = eig;
+    c->n = (size_t)K * p * p;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(GGL_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    int rc = ctx_alloc(c);
+    if (rc != GGL_OK) { ggl_ctx_destroy(c); return rc; }
+    if (!use_jacobi(c)) {
+        if (rocblas_create_handle(&c->blas) != rocblas_status_success) {
+            ggl_ctx_destroy(c);
+            return fail(GGL_E_SOLVER, "rocblas_create_handle failed");
+        }
+        rocblas_set_stream(c->blas, c->stream);
+    }
+    *out = c;
+    return GGL_OK;
+}
+
+extern "C" int ggl_ctx_destroy(ggl_ctx* c)
+{
+    if (!c) return GGL_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->blas) rocblas_destroy_handle(c->blas);
+    double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
+                      c->E, c->par, c->mask, c->groupsq, c->partials, c->norms};
+    for (double* b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->info) (void)hipFree(c->info);
+    if (c->par_h) (void)hipHostFree(c->par_h);
+    if (c->norms_h) (void)hipHostFree(c->norms_h);
+    if (c->info_h) (void)hipHostFree(c->info_h);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GGL_OK;
+}
+
+extern "C" int ggl_ctx_sync(ggl_ctx* c)
+{
+    ARGCHK(c, "ctx");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GGL_OK;
+}
+
+extern "C" void* ggl_device_ptr(ggl_ctx* c, int which)
+{
+    if (!c) return nullptr;
+    switch (which) {
+        case GGL_BUF_S: return c->S;
+        case GGL_BUF_OMEGA: return c->Om[c->cur];
+        case GGL_BUF_OMEGA_PREV: return c->Om[c->cur ^ 1];
+        case GGL_BUF_THETA: return c->Theta;
+        case GGL_BUF_L: return c->L;
+        case GGL_BUF_X: return c->X;
+        case GGL_BUF_GROUPSQ: return c->groupsq;
+        case GGL_BUF_NORMS: return c->norms;
+        default: return nullptr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// state
+// ---------------------------------------------------------------------------------------------
+extern "C" int ggl_set_S(ggl_ctx* c, const double* S)
+{
+    ARGCHK(c && S, "ctx, S");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->S, S, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GGL_OK;
+}
+
+extern "C" int ggl_set_state(ggl_ctx* c, const double* Omega, const double* Theta, const double* L, const double* X)
+{
+    ARGCHK(c, "ctx");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nb = c->n * sizeof(double);
+    if (Omega) HIPCHK(hipMemcpyAsync(c->Om[c->cur], Omega, nb, hipMemcpyHostToDevice, c->stream));
+    if (Theta) HIPCHK(hipMemcpyAsync(c->Theta, Theta, nb, hipMemcpyHostToDevice, c->stream));
+    if (L) HIPCHK(hipMemcpyAsync(c->L, L, nb, hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
+    if (X) HIPCHK(hipMemcpyAsync(c->X, X, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GGL_OK;
+}
+
+extern "C" int ggl_get_state(ggl_ctx* c, double* Omega, double* Theta, double* L, double* X)
+{
+    ARGCHK(c, "ctx");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nb = c->n * sizeof(double);
+    if (Omega) HIPCHK(hipMemcpyAsync(Omega, c->Om[c->cur], nb, hipMemcpyDeviceToHost, c->stream));
+    if (Theta) HIPCHK(hipMemcpyAsync(Theta, c->Theta, nb, hipMemcpyDeviceToHost, c->stream));
+    if (L) HIPCHK(hipMemcpyAsync(L, c->L, nb, hipMemcpyDeviceToHost, c->stream));
+    if (X) HIPCHK(hipMemcpyAsync(X, c->X, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GGL_OK;
+}
+
+extern "C" int ggl_set_lambda1_mask(ggl_ctx* c, const double* lam)
+{
+    ARGCHK(c, "ctx");
+    HIPCHK(hipSetDevice(c->device));
+    c->has_mask = (lam != nullptr);
+    if (lam) {
+        HIPCHK(hipMemcpyAsync(c->mask, lam, (size_t)c->p * c->p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return GGL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// eigen-decomposition + eigenvalue map + reconstruction of a device stack (in: A, destroyed when
+// the rocSOLVER path is taken; out may alias nothing).  Dv receives the eigenvalues.
+// ---------------------------------------------------------------------------------------------
+static int eig_recon(ggl_ctx* c, double* A, double* out, double* Dv, int map, const double* betaK)
+{
+    if (use_jacobi(c)) {
+        HIPCHK(launch_jacobi(c->stream, A, Dv, nullptr, out, map, betaK, c->info, c->K, c->p));
+        return GGL_OK;
+    }
+    // row-major symmetric == column-major symmetric; the row-major LOWER triangle (what numpy's
+    // eigh reads) is the column-major UPPER one.  Eigenvectors come back in column-major columns
+    // == row-major ROWS, the layout launch_recon wants.
+    rocblas_status st = rocsolver_dsyevd_strided_batched(c->blas, rocblas_evect_original, rocblas_fill_upper, c->p, A,
+                                                         c->p, (rocblas_stride)c->p * c->p, Dv, c->p, c->E, c->p,
+                                                         c->info, c->K);
+    if (st != rocblas_status_success) return fail(GGL_E_SOLVER, "rocsolver_dsyevd_strided_batched: status %d", (int)st);
+    launch_recon(c->stream, out, A, Dv, betaK, map, c->K, c->p, c->scale);
+    HIPCHK(hipGetLastError());
+    return GGL_OK;
+}
+
+static int eigvals_only(ggl_ctx* c, double* A, double* Dv)
+{
+    if (use_jacobi(c)) {
+        HIPCHK(launch_jacobi(c->stream, A, Dv, nullptr, nullptr, MAP_IDENT, nullptr, c->info, c->K, c->p));
+        return GGL_OK;
+    }
+    rocblas_status st = rocsolver_dsyevd_strided_batched(c->blas, rocblas_evect_none, rocblas_fill_upper, c->p, A, c->p,
+                                                         (rocblas_stride)c->p * c->p, Dv, c->p, c->E, c->p, c->info,
+                                                         c->K);
+    if (st != rocblas_status_success) return fail(GGL_E_SOLVER, "rocsolver_dsyevd (values): status %d", (int)st);
+    return GGL_OK;
+}
+
+static int check_info(ggl_ctx* c, const char* what)
+{
+    const bool jac = use_jacobi(c);
+    for (int k = 0; k < c->K; ++k) {
+        const int v = c->info_h[k];
+        if (jac ? (v < 0) : (v != 0))
+            return fail(GGL_E_SOLVER, "%s: eigensolver did not converge for instance %d (info=%d)", what, k, v);
+    }
+    return GGL_OK;
+}
+
+static int upload_par(ggl_ctx* c, int slot, const double* vals, double scalar, double div)
+{
+    // par[slot][k] = (vals ? vals[k] : scalar) / div
+    double* h = c->par_h + (size_t)slot * c->K;
+    for (int k = 0; k < c->K; ++k) h[k] = (vals ? vals[k] : scalar) / div;
+    HIPCHK(hipMemcpyAsync(c->par + (size_t)slot * c->K, h, c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return GGL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the iteration
+// ---------------------------------------------------------------------------------------------
+extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* nk)
+{
+    ARGCHK(c, "ctx");
+    ARGCHK(rho > 0, "rho must be positive");
+    HIPCHK(hipSetDevice(c->device));
+    // the previous step's pinned parameters are consumed: every step ends with a stream sync
+    int rc = upload_par(c, 0, nk, 1.0, rho);   // beta_k = nk/rho    (admm_solver.py:180,184)
+    if (rc) return rc;
+    const double* beta = c->par;
+    launch_form_W(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->K, c->p);
+    HIPCHK(hipGetLastError());
+    const int nxt = c->cur ^ 1;
+    rc = eig_recon(c, c->W, c->Om[nxt], c->DvO, MAP_PHIPLUS, beta);
+    if (rc) return rc;
+    c->cur = nxt;
+    return GGL_OK;
+}
+
+extern "C" int ggl_step_group_partial(ggl_ctx* c, double rho, double lambda1)
+{
+    ARGCHK(c, "ctx");
+    ARGCHK(rho > 0, "rho must be positive");
+    HIPCHK(hipSetDevice(c->device));
+    launch_group_partial(c->stream, c->groupsq, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
+    HIPCHK(hipGetLastError());
+    return GGL_OK;
+}
+
+static int finish_norms(ggl_ctx* c, int rows, double out_norms[5])
+{
+    HIPCHK(hipMemcpyAsync(c->norms_h, c->norms, (size_t)rows * GGL_NNORM * sizeof(double), hipMemcpyDeviceToHost,
+                          c->stream));
+    HIPCHK(hipMemcpyAsync(c->info_h, c->info, c->K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = check_info(c, "ADMM step");
+    if (rc) return rc;
+    for (int v = 0; v < GGL_NNORM; ++v) {
+        double s = 0.0;
+        for (int r = 0; r < rows; ++r) s += c->norms_h[(size_t)r * GGL_NNORM + v];
+        out_norms[v] = s;
+    }
+    return GGL_OK;
+}
+
+extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double lambda2, int reg, int latent,
+                               const double* mu1, int groupsq_ready, double out_norms[5])
+{
+    ARGCHK(c && out_norms, "ctx, out_norms");
+    ARGCHK(rho > 0, "rho must be positive");
+    ARGCHK(reg == GGL_REG_SGL || reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
+    ARGCHK(!latent || mu1, "latent needs mu1");
+    ARGCHK(!(groupsq_ready && latent), "K-sharded GGL with latent variables is not supported");
+    HIPCHK(hipSetDevice(c->device));
+    const double inv_rho = 1.0 / rho;
+    const double l1 = inv_rho * lambda1, l2 = inv_rho * lambda2;   // admm_solver.py:191-192
+    double* Om = c->Om[c->cur];
+    double* OmPrev = c->Om[c->cur ^ 1];
+    int rows = 1;
+    if (reg == GGL_REG_SGL) {
+        int rc = upload_par(c, 1, nullptr, l1, 1.0);
+        if (rc) return rc;
+        launch_theta_sgl(c->stream, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, c->par + c->K,
+                         c->has_mask ? c->mask : nullptr, inv_rho, latent, c->partials, c->K, c->p);
+        HIPCHK(hipGetLastError());
+        if (!latent) {
+            launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), GGL_NNORM, c->norms);
+            rows = c->K;
+        }
+    } else {
+        ARGCHK(lambda1 > 0 && lambda2 > 0, "lambda1, lambda2 must be positive");
+        HIPCHK(launch_theta_pair(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, l1, l2,
+                                 groupsq_ready ? c->groupsq : nullptr, latent ? 0 : 1, c->partials, c->K, c->p));
+        if (!latent) {
+            launch_reduce_partials(c->stream, c->partials, 1, pair_blocks(c->p, reg, c->K), GGL_NNORM, c->norms);
+            rows = 1;
+        }
+    }
+    if (latent) {
+        int rc = upload_par(c, 2, mu1, 0.0, rho);   // mu1_k / rho   (admm_solver.py:202)
+        if (rc) return rc;
+        rc = eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)c->K);
+        if (rc) return rc;
+        launch_dual_update(c->stream, c->X, Om, OmPrev, c->Theta, c->L, c->partials, c->K, c->p);
+        launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), GGL_NNORM, c->norms);
+        rows = c->K;
+    }
+    HIPCHK(hipGetLastError());
+    return finish_norms(c, rows, out_norms);
+}
+
+extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lambda2, int reg, int latent,
+                             const double* mu1, const double* nk, double out_norms[5])
+{
+    int rc = ggl_step_omega(c, rho, latent, nk);
+    if (rc) return rc;
+    return ggl_step_finish(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
+}
+
+extern "C" int ggl_scale_X(ggl_ctx* c, double factor)
+{
+    ARGCHK(c, "ctx");
+    HIPCHK(hipSetDevice(c->device));
+    launch_scale(c->stream, c->X, factor, c->n);
+    HIPCHK(hipGetLastError());
+    return GGL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exit checks / objective / kkt
+// ---------------------------------------------------------------------------------------------
+static int host_reduce(ggl_ctx* c, int rows, int nv, double* out /*nv*/, bool take_max)
+{
+    HIPCHK(hipMemcpyAsync(c->norms_h, c->norms, (size_t)rows * nv * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int v = 0; v < nv; ++v) {
+        double s = take_max ? -INFINITY : 0.0;
+        for (int r = 0; r < rows; ++r) {
+            const double x = c->norms_h[(size_t)r * nv + v];
+            s = take_max ? std::max(s, x) : s + x;
+        }
+        out[v] = s;
+    }
+    return GGL_OK;
+}
+
+static int min_eig(ggl_ctx* c, double* A, double* out)
+{
+    int rc = eigvals_only(c, A, c->DvL);
+    if (rc) return rc;
+    std::vector<double> d((size_t)c->K * c->p);
+    HIPCHK(hipMemcpyAsync(d.data(), c->DvL, d.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->info_h, c->info, c->K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = check_info(c, "exit check");
+    if (rc) return rc;
+    *out = *std::min_element(d.begin(), d.end());
+    return GGL_OK;
+}
+
+extern "C" int ggl_exit_checks(ggl_ctx* c, int latent, double out[5])
+{
+    ARGCHK(c && out, "ctx, out");
+    HIPCHK(hipSetDevice(c->device));
+    const double* stacks[3] = {c->Om[c->cur], c->Theta, c->L};
+    for (int i = 0; i < 3; ++i) {
+        launch_asym_max(c->stream, stacks[i], c->K, c->p, c->norms);
+        HIPCHK(hipGetLastError());
+        int rc = host_reduce(c, c->K, 1, &out[i], true);
+        if (rc) return rc;
+    }
+    launch_sub(c->stream, c->W, c->Theta, c->L, c->n);   // admm_solver.py:294
+    int rc = min_eig(c, c->W, &out[3]);
+    if (rc) return rc;
+    out[4] = 0.0;
+    if (latent) {
+        HIPCHK(hipMemcpyAsync(c->W, c->L, c->n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        rc = min_eig(c, c->W, &out[4]);                  // admm_solver.py:299
+        if (rc) return rc;
+    }
+    return GGL_OK;
+}
+
+extern "C" int ggl_objective(ggl_ctx* c, double lambda1, double lambda2, int reg, double out[3])
+{
+    ARGCHK(c && out, "ctx, out");
+    ARGCHK(reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
+    HIPCHK(hipSetDevice(c->device));
+    // -log det Omega_k = -sum_m log phip(d_m): eigenvalues of the last Omega-step (ggl_helper.py:266-270)
+    const size_t kp = (size_t)c->K * c->p;
+    std::vector<double> d(kp);
+    HIPCHK(hipMemcpyAsync(d.data(), c->DvO, kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    launch_dot(c->stream, c->Om[c->cur], c->S, c->K, c->p, c->partials);
+    launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), 1, c->norms);
+    HIPCHK(hipGetLastError());
+    int rc = host_reduce(c, c->K, 1, &out[1], false);
+    if (rc) return rc;
+    double ld = 0.0;
+    for (int k = 0; k < c->K; ++k) {
+        const double beta = c->par_h[k];
+        for (int m = 0; m < c->p; ++m) {
+            const double dv = d[(size_t)k * c->p + m];
+            ld -= std::log(0.5 * (std::sqrt(dv * dv + 4.0 * beta) + dv));
+        }
+    }
+    out[0] = ld;
+    const int nb = pair_blocks(c->p, GGL_REG_GGL, c->K);
+    launch_pval(c->stream, reg, c->Theta, lambda1, lambda2, c->K, c->p, c->partials);
+    launch_reduce_partials(c->stream, c->partials, 1, nb, 1, c->norms);
+    HIPCHK(hipGetLastError());
+    return host_reduce(c, 1, 1, &out[2], false);
+}
+
+static int stack_sq(ggl_ctx* c, const double* A, const double* B, double* out)
+{
+    launch_sqdiff(c->stream, A, B, c->K, c->p, c->partials);
+    launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), 1, c->norms);
+    HIPCHK(hipGetLastError());
+    return host_reduce(c, c->K, 1, out, false);
+}
+
+extern "C" int ggl_kkt_residual(ggl_ctx* c, double rho, double lambda1, double lambda2, int reg, int latent,
+                                const double* mu1, const double* nk, double* out)
+{
+    ARGCHK(c && out, "ctx, out");
+    ARGCHK(!latent || mu1, "latent needs mu1");
+    HIPCHK(hipSetDevice(c->device));
+    double* Om = c->Om[c->cur];
+    double* T1 = c->W;             // scratch
+    double* T2 = c->Om[c->cur ^ 1]; // Omega_{t-1} is dead once the step's norms are out
+    double nTheta, nOmega, v;
+    int rc;
+    if ((rc = stack_sq(c, c->Theta, nullptr, &nTheta))) return rc;
+    if ((rc = stack_sq(c, Om, nullptr, &nOmega))) return rc;
+    nTheta = std::sqrt(nTheta);
+    nOmega = std::sqrt(nOmega);
+    // term1: |Theta - prox(Theta + rho X)| / (1 + |Theta|)
+    launch_axpy(c->stream, T1, c->Theta, rho, c->X, c->n);
+    if (reg == GGL_REG_SGL) {
+        // prox_od_1norm with l = lambda1 (scalar or the (p,p) mask array), per instance
+        for (int k = 0; k < c->K; ++k)
+            launch_prox_od(c->stream, T2 + (size_t)k * c->p * c->p, T1 + (size_t)k * c->p * c->p, lambda1,
+                           c->has_mask ? c->mask : nullptr, c->p);
+    } else {
+        HIPCHK(launch_prox_p(c->stream, reg, T2, T1, lambda1, lambda2, c->K, c->p));
+    }
+    if ((rc = stack_sq(c, c->Theta, T2, &v))) return rc;
+    double res = std::sqrt(v) / (1.0 + nTheta);
+    // term2: |Theta - Omega - L| / (1 + |Theta|)
+    launch_sub(c->stream, T1, c->Theta, Om, c->n);
+    if ((rc = stack_sq(c, T1, latent ? c->L : nullptr, &v))) return rc;
+    res = std::max(res, std::sqrt(v) / (1.0 + nTheta));
+    // term3: |Omega - phiplus(eigh(Omega - nk S - rho X), nk)| / (1 + |Omega|)
+    if ((rc = upload_par(c, 3, nk, 1.0, 1.0))) return rc;
+    const double* nkd = c->par + 3 * (size_t)c->K;
+    launch_kkt_w(c->stream, T1, Om, c->S, c->X, nkd, rho, c->K, c->p);
+    if ((rc = eig_recon(c, T1, T2, c->DvL, MAP_PHIPLUS, nkd))) return rc;
+    if ((rc = stack_sq(c, Om, T2, &v))) return rc;
+    res = std::max(res, std::sqrt(v) / (1.0 + nOmega));
+    if (latent) {
+        double nL;
+        if ((rc = stack_sq(c, c->L, nullptr, &nL))) return rc;
+        if ((rc = upload_par(c, 2, mu1, 0.0, 1.0))) return rc;
+        launch_axpy(c->stream, T1, c->L, -rho, c->X, c->n);
+        if ((rc = eig_recon(c, T1, T2, c->DvL, MAP_RANK, c->par + 2 * (size_t)c->K))) return rc;
+        if ((rc = stack_sq(c, c->L, T2, &v))) return rc;
+        res = std::max(res, std::sqrt(v) / (1.0 + std::sqrt(nL)));
+    }
+    HIPCHK(hipMemcpyAsync(c->info_h, c->info, c->K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((rc = check_info(c, "kkt residual"))) return rc;
+    *out = res;
+    return GGL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stateless operators (host buffers in, host buffers out)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    double* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(double)); }
+};
+}  // namespace
+
+#define UP(dst, src, n) HIPCHK(hipMemcpy(dst, src, (size_t)(n) * sizeof(double), hipMemcpyHostToDevice))
+#define DOWN(dst, src, n) HIPCHK(hipMemcpy(dst, src, (size_t)(n) * sizeof(double), hipMemcpyDeviceToHost))
+
+static int eig_common(int K, int p, const double* A, const double* beta, double* D, double* Q, double* out, int map,
+                      int eig_method)
+{
+    ARGCHK(K >= 1 && p >= 1 && A, "K, p, A");
+    ARGCHK(eig_method != GGL_EIG_JACOBI || jacobi_fits(p), "GGL_EIG_JACOBI needs p <= GGL_JACOBI_MAX_P");
+    const bool jac = (eig_method == GGL_EIG_JACOBI) || (eig_method == GGL_EIG_AUTO && jacobi_fits(p));
+    const size_t n = (size_t)K * p * p, kp = (size_t)K * p;
+    DevBuf dA, dD, dR, dO, dB, dE, dS;
+    int* dinfo = nullptr;
+    HIPCHK(dA.alloc(n));
+    HIPCHK(dD.alloc(kp));
+    HIPCHK(dB.alloc(K));
+    HIPCHK(hipMalloc(&dinfo, K * sizeof(int)));
+    struct InfoFree { int* p; ~InfoFree() { (void)hipFree(p); } } infofree{dinfo};
+    UP(dA.p, A, n);
+    if (beta) UP(dB.p, beta, K);
+    if (out) HIPCHK(dO.alloc(n));
+    std::vector<int> info(K);
+    if (jac) {
+        if (Q) HIPCHK(dR.alloc(n));
+        HIPCHK(launch_jacobi(nullptr, dA.p, dD.p, dR.p, dO.p, map, beta ? dB.p : nullptr, dinfo, K, p));
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(info.data(), dinfo, K * sizeof(int), hipMemcpyDeviceToHost));
+        for (int k = 0; k < K; ++k)
+            if (info[k] < 0) return fail(GGL_E_SOLVER, "Jacobi eigensolver did not converge (instance %d)", k);
+    } else {
+        rocblas_handle h;
+        if (rocblas_create_handle(&h) != rocblas_status_success) return fail(GGL_E_SOLVER, "rocblas_create_handle");
+        HIPCHK(dE.alloc(kp));
+        rocblas_status st = rocsolver_dsyevd_strided_batched(h, (Q || out) ? rocblas_evect_original : rocblas_evect_none,
+                                                             rocblas_fill_upper, p, dA.p, p, (rocblas_stride)p * p,
+                                                             dD.p, p, dE.p, p, dinfo, K);
+        if (st == rocblas_status_success && out) {
+            hipError_t e = dS.alloc(2 * kp);
+            if (e == hipSuccess) launch_recon(nullptr, dO.p, dA.p, dD.p, beta ? dB.p : nullptr, map, K, p, dS.p);
+        }
+        (void)hipDeviceSynchronize();
+        rocblas_destroy_handle(h);
+        if (st != rocblas_status_success) return fail(GGL_E_SOLVER, "rocsolver_dsyevd_strided_batched: status %d", (int)st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(info.data(), dinfo, K * sizeof(int), hipMemcpyDeviceToHost));
+        for (int k = 0; k < K; ++k)
+            if (info[k] != 0) return fail(GGL_E_SOLVER, "rocSOLVER syevd did not converge (instance %d)", k);
+    }
+    if (out) DOWN(out, dO.p, n);
+    if (D || Q) {
+        // NumPy convention across the ABI: ascending eigenvalues, eigenvectors in columns.
+        std::vector<double> hd(kp), hr;
+        DOWN(hd.data(), dD.p, kp);
+        if (Q) { hr.resize(n); DOWN(hr.data(), jac ? dR.p : dA.p, n); }
+        std::vector<int> idx(p);
+        for (int k = 0; k < K; ++k) {
+            std::iota(idx.begin(), idx.end(), 0);
+            const double* dk = hd.data() + (size_t)k * p;
+            std::stable_sort(idx.begin(), idx.end(), [dk](int a, int b) { return dk[a] < dk[b]; });
+            for (int m = 0; m < p; ++m) {
+                if (D) D[(size_t)k * p + m] = dk[idx[m]];
+                if (Q) {
+                    const double* row = hr.data() + (size_t)k * p * p + (size_t)idx[m] * p;
+                    for (int i = 0; i < p; ++i) Q[(size_t)k * p * p + (size_t)i * p + m] = row[i];
+                }
+            }
+        }
+    }
+    return GGL_OK;
+}
+
+extern "C" int ggl_eigh_batched(int K, int p, const double* A, double* D, double* Q, int eig_method)
+{
+    ARGCHK(D, "D");
+    return eig_common(K, p, A, nullptr, D, Q, nullptr, MAP_IDENT, eig_method);
+}
+
+extern "C" int ggl_phiplus_matrix(int K, int p, const double* beta, const double* W, double* out, int eig_method)
+{
+    ARGCHK(beta && out, "beta, out");
+    return eig_common(K, p, W, beta, nullptr, nullptr, out, MAP_PHIPLUS, eig_method);
+}
+
+extern "C" int ggl_rank_matrix(int K, int p, const double* beta, const double* C, double* out, int eig_method)
+{
+    ARGCHK(beta && out, "beta, out");
+    return eig_common(K, p, C, beta, nullptr, nullptr, out, MAP_RANK, eig_method);
+}
+
+static int recon_common(int K, int p, const double* beta, const double* D, const double* Q, double* out, int map)
+{
+    ARGCHK(K >= 1 && p >= 1 && beta && D && Q && out, "arguments");
+    const size_t n = (size_t)K * p * p, kp = (size_t)K * p;
+    // Q has eigenvectors in columns; the kernel wants them in rows
+    std::vector<double> R(n);
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < p; ++i)
+            for (int m = 0; m < p; ++m) R[(size_t)k * p * p + (size_t)m * p + i] = Q[(size_t)k * p * p + (size_t)i * p + m];
+    DevBuf dR, dD, dB, dO, dS;
+    HIPCHK(dR.alloc(n));
+    HIPCHK(dD.alloc(kp));
+    HIPCHK(dB.alloc(K));
+    HIPCHK(dO.alloc(n));
+    HIPCHK(dS.alloc(2 * kp));
+    UP(dR.p, R.data(), n);
+    UP(dD.p, D, kp);
+    UP(dB.p, beta, K);
+    launch_recon(nullptr, dO.p, dR.p, dD.p, dB.p, map, K, p, dS.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(out, dO.p, n);
+    return GGL_OK;
+}
+
+extern "C" int ggl_phiplus(int K, int p, const double* beta, const double* D, const double* Q, double* out)
+{
+    return recon_common(K, p, beta, D, Q, out, MAP_PHIPLUS);
+}
+
+extern "C" int ggl_prox_rank_norm(int K, int p, const double* beta, const double* D, const double* Q, double* out)
+{
+    return recon_common(K, p, beta, D, Q, out, MAP_RANK);
+}
+
+extern "C" int ggl_prox_od_1norm(int p, const double* A, double lam, const double* lam_pp, double* out)
+{
+    ARGCHK(p >= 1 && A && out, "arguments");
+    const size_t n = (size_t)p * p;
+    DevBuf dA, dM, dO;
+    HIPCHK(dA.alloc(n));
+    HIPCHK(dO.alloc(n));
+    UP(dA.p, A, n);
+    if (lam_pp) { HIPCHK(dM.alloc(n)); UP(dM.p, lam_pp, n); }
+    launch_prox_od(nullptr, dO.p, dA.p, lam, lam_pp ? dM.p : nullptr, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(out, dO.p, n);
+    return GGL_OK;
+}
+
+extern "C" int ggl_prox_p(int K, int p, const double* X, double l1, double l2, int reg, double* out)
+{
+    ARGCHK(K >= 1 && p >= 1 && X && out, "arguments");
+    ARGCHK(reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
+    ARGCHK(l1 > 0 && l2 > 0, "lambda 1 and lambda2 have to be positive");
+    const size_t n = (size_t)K * p * p;
+    DevBuf dX, dO;
+    HIPCHK(dX.alloc(n));
+    HIPCHK(dO.alloc(n));
+    UP(dX.p, X, n);
+    HIPCHK(launch_prox_p(nullptr, reg, dO.p, dX.p, l1, l2, K, p));
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(out, dO.p, n);
+    return GGL_OK;
+}
+
+static int vec_common(int mode, int n, int K, const double* Y, double l1, double l2, double* out)
+{
+    ARGCHK(n >= 1 && K >= 1 && Y && out, "arguments");
+    const size_t tot = (size_t)n * K;
+    DevBuf dY, dO;
+    HIPCHK(dY.alloc(tot));
+    HIPCHK(dO.alloc(tot));
+    UP(dY.p, Y, tot);
+    HIPCHK(launch_vec_prox(nullptr, mode, dY.p, dO.p, n, K, l1, l2));
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(out, dO.p, tot);
+    return GGL_OK;
+}
+
+extern "C" int ggl_prox_tv(int n, int K, const double* Y, double lam, double* out)
+{
+    return vec_common(0, n, K, Y, lam, 0.0, out);
+}
+
+extern "C" int ggl_prox_2norm(int n, int K, const double* Y, double lam, double* out)
+{
+    return vec_common(1, n, K, Y, lam, 0.0, out);
+}
+
+extern "C" int ggl_prox_phi(int n, int K, const double* Y, double l1, double l2, int reg, double* out)
+{
+    ARGCHK(reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
+    return vec_common(reg == GGL_REG_GGL ? 2 : 3, n, K, Y, l1, l2, out);
+}

@@ -1,0 +1,91 @@
+// Host-side launchers of the gfx950 kernels behind libggl_hip's C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#define GGL_NNORM 5   // |Omega|^2, |Theta-L|^2, |X|^2, |Omega-Theta+L|^2, |Omega-Omega_prev|^2
+
+namespace ggl {
+
+// eigenvalue maps applied inside reconstruction kernels
+enum EigMap {
+    MAP_PHIPLUS = 0,  // 0.5*(d + sqrt(d^2 + 4 beta))   solver/ggl_helper.py:272-274
+    MAP_RANK = 1,     // max(d - beta, 0)                solver/ggl_helper.py:35
+    MAP_IDENT = 2     // d (plain Q diag(d) Q^T, tests)
+};
+
+// ---- elementwise.hip --------------------------------------------------------------------
+// number of partial-sum slots per instance the elementwise kernels produce for (p)
+int elementwise_blocks(int p);
+// W = ((Theta - L) - X) - beta_k * S        (admm_solver.py:180); L may be null (== 0)
+void launch_form_W(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
+                   const double* S, const double* betaK, int K, int p);
+// SGL Theta-step (prox_od_1norm, ggl_helper.py:16-27) on every instance k with threshold
+// l1K[k] (scalar) or inv_rho*mask[i,j].  latent == 0: also X += Omega - Theta and the norms
+// partials [K][nblk][5].  latent != 0: writes Theta and C = (Theta - X) - Omega.
+void launch_theta_sgl(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
+                      const double* OmegaPrev, const double* L, const double* l1K,
+                      const double* mask, double inv_rho, int latent, double* partials, int K, int p);
+// X += (Omega - Theta) + L and the norms partials (latent path, admm_solver.py:208)
+void launch_dual_update(hipStream_t st, double* X, const double* Omega, const double* OmegaPrev,
+                        const double* Theta, const double* L, double* partials, int K, int p);
+// out[k][v] = sum_b partials[k][b][v]   (fixed order => deterministic)
+void launch_reduce_partials(hipStream_t st, const double* partials, int K, int nblk, int nv, double* out);
+void launch_scale(hipStream_t st, double* X, double f, size_t n);
+// out[k] = max_{i,j} |A[k,i,j] - A[k,j,i]|
+void launch_asym_max(hipStream_t st, const double* A, int K, int p, double* out);
+// D = A - B (B may be null)
+void launch_sub(hipStream_t st, double* D, const double* A, const double* B, size_t n);
+// out[k][0] = sum A*B
+void launch_dot(hipStream_t st, const double* A, const double* B, int K, int p, double* partials);
+// out = A + c * B
+void launch_axpy(hipStream_t st, double* out, const double* A, double c, const double* B, size_t n);
+// out = (Omega - nk_k * S) - rho * X      (argument of the log-det prox in the KKT residual)
+void launch_kkt_w(hipStream_t st, double* out, const double* Omega, const double* S, const double* X,
+                  const double* nkK, double rho, int K, int p);
+// partials[k][b][0] = sum_chunk (A - B)^2   (B may be null)
+void launch_sqdiff(hipStream_t st, const double* A, const double* B, int K, int p, double* partials);
+// plain elementwise prox_od_1norm for the operator entry point
+void launch_prox_od(hipStream_t st, double* out, const double* A, double lam, const double* lam_pp, int p);
+
+// ---- theta_pair.hip ---------------------------------------------------------------------
+int pair_blocks(int p, int reg, int K);
+// GGL/FGL Theta-step on upper-triangle K-vectors (prox_p, ggl_helper.py:190-207), mirrored.
+//   fuse_dual != 0 (non-latent): also X += Omega - Theta and norms partials [K][nblk][5].
+//   fuse_dual == 0 (latent): writes Theta and C = (Theta - X) - Omega  (admm_solver.py:198).
+// groupsq != null (GGL only): use this (p,p) array as sum_k u^2 instead of computing it (K-sharded).
+// Returns hipErrorInvalidValue if K is beyond what the FGL kernel's LDS scan buffer holds.
+hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C,
+                             const double* Omega, const double* OmegaPrev, const double* L,
+                             double l1, double l2, const double* groupsq, int fuse_dual,
+                             double* partials, int K, int p);
+// GGL pass 1 only: groupsq(p,p)[i<j] = sum_k soft(Omega+L+X, l1)^2
+void launch_group_partial(hipStream_t st, double* groupsq, const double* Omega, const double* L,
+                          const double* X, double l1, int K, int p);
+// stateless prox_p: out = prox_p(V)   (V symmetric stack; upper triangle decides)
+hipError_t launch_prox_p(hipStream_t st, int reg, double* out, const double* V, double l1, double l2,
+                         int K, int p);
+// P_val partials (ggl_helper.py:162-176): partials[b] per block, nblk = pair_blocks(p, GGL, K)
+void launch_pval(hipStream_t st, int reg, const double* Theta, double l1, double l2, int K, int p,
+                 double* partials);
+// n independent K-vectors (n,K) row-major: mode 0 prox_tv, 1 prox_2norm, 2 prox_phi_ggl, 3 prox_phi_fgl
+hipError_t launch_vec_prox(hipStream_t st, int mode, const double* Y, double* out, int n, int K,
+                           double l1, double l2);
+
+// ---- eig_jacobi.hip ---------------------------------------------------------------------
+bool jacobi_fits(int p);
+// One workgroup per matrix, matrix resident in LDS (one-sided Jacobi on rows, wave-shuffle
+// reductions).  Reads the LOWER triangle of A (numpy.linalg.eigh default).
+//   D (K,p) eigenvalues (unsorted), R (K,p,p) eigenvectors in ROWS; either may be null.
+//   out != null: out[k] = R^T diag(map(D, betaK[k])) R fused in the same kernel.
+//   info (K ints): sweeps used, negative if not converged.
+hipError_t launch_jacobi(hipStream_t st, const double* A, double* D, double* R, double* out, int map,
+                         const double* betaK, int* info, int K, int p);
+
+// ---- recon_gemm.hip ---------------------------------------------------------------------
+// out[k] = R[k]^T diag(map(D[k], betaK[k])) R[k]; R holds eigenvectors in ROWS. FP64 MFMA.
+// scale_work: 2*K*p doubles of scratch.
+void launch_recon(hipStream_t st, double* out, const double* R, const double* D, const double* betaK,
+                  int map, int K, int p, double* scale_work);
+
+}  // namespace ggl

@@ -1,0 +1,518 @@
+// Theta-step of ADMM_MGL: prox_p (solver/ggl_helper.py:190-207) over the (K,p,p) stack.
+//
+// The penalty acts on the K-vector X[:,i,j] of every upper-triangle pair i<j and the result is
+// mirrored.  One workgroup owns a tile pair (I,J), I<=J: the "upper role" of a thread computes
+// theta for element (i,j) from coalesced row reads of the upper tile, hands it through an LDS
+// tile to the thread that owns the transposed element (j,i) ("lower role"), and both roles then
+// finish their own element in its native, coalesced orientation: Theta write, dual update
+// X += Omega - Theta (admm_solver.py:208) and the five stopping-test sums (admm_solver.py:316-331).
+// Nothing is read or written with a stride: the only transposition happens in LDS.
+//
+// GGL (ggl_helper.py:68-71): two sweeps over k (sum of squares, then scale).
+// FGL (ggl_helper.py:131-134): the K-vector of each pair sits in an LDS column ([k][thread], bank
+// = thread, conflict free however the threads' scan positions diverge) and Condat's scan
+// (fgl_helper.py:11-68) runs on it in place, one pair per thread.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace ggl {
+
+static constexpr int PT = 32;        // GGL tile edge
+static constexpr int PTY = 8;        // thread rows of the 32x8 block
+static constexpr int PQ = PT / PTY;  // elements per thread
+
+__device__ __forceinline__ void decode_pair(int b, int T, int& I, int& J)
+{
+    int i = 0;
+    while (b >= T - i) { b -= T - i; ++i; }
+    I = i;
+    J = i + b;
+}
+
+static inline int ntiles(int p, int t) { return (p + t - 1) / t; }
+static inline int fgl_tile(int K) { return (K <= 32) ? 16 : 8; }
+static constexpr int FGL_MAX_K_TD8 = (160 * 1024 - 1024) / (8 * 8 * 8);   // LDS scan buffer bound
+
+int pair_blocks(int p, int reg, int K)
+{
+    int T = (reg == 2) ? ntiles(p, fgl_tile(K)) : ntiles(p, PT);
+    return T * (T + 1) / 2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GGL
+// ---------------------------------------------------------------------------------------------
+template <bool FUSE_DUAL>
+__global__ __launch_bounds__(256) void k_theta_ggl(double* __restrict__ Theta, double* __restrict__ X,
+                                                   double* __restrict__ C, const double* __restrict__ Omega,
+                                                   const double* __restrict__ OmegaPrev,
+                                                   const double* __restrict__ L, double l1, double l2,
+                                                   const double* __restrict__ groupsq,
+                                                   double* __restrict__ partials, int K, int p)
+{
+    __shared__ double tile[2][PT][PT + 1];
+    __shared__ double scratch[GGL_NNORM * 4];
+    const int T = (p + PT - 1) / PT;
+    int I, J;
+    decode_pair(blockIdx.x, T, I, J);
+    const bool diag = (I == J);
+    const int I0 = I * PT, J0 = J * PT;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const size_t pp = (size_t)p * p;
+
+    bool up_ok[PQ], pr_ok[PQ], lo_ok[PQ];
+    size_t up_off[PQ], lo_off[PQ];
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        const int r = ty + PTY * q;
+        up_ok[q] = (I0 + r < p) && (J0 + tx < p) && (!diag || r <= tx);
+        pr_ok[q] = up_ok[q] && !(diag && r == tx);
+        up_off[q] = (size_t)(I0 + r) * p + (J0 + tx);
+        lo_ok[q] = (J0 + r < p) && (I0 + tx < p) && (!diag || r > tx);   // element (J0+r, I0+tx)
+        lo_off[q] = (size_t)(J0 + r) * p + (I0 + tx);
+    }
+
+    // sweep 1: sum_k soft(v,l1)^2 per pair
+    double ss[PQ];
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) ss[q] = 0.0;
+    if (groupsq) {
+#pragma unroll
+        for (int q = 0; q < PQ; ++q)
+            if (pr_ok[q]) ss[q] = groupsq[up_off[q]];
+    } else {
+        for (int k = 0; k < K; ++k) {
+            const size_t base = (size_t)k * pp;
+#pragma unroll
+            for (int q = 0; q < PQ; ++q) {
+                if (pr_ok[q]) {
+                    double v = Omega[base + up_off[q]];
+                    if (L) v += L[base + up_off[q]];
+                    if (X) v += X[base + up_off[q]];
+                    const double u = soft(v, l1);
+                    ss[q] += u * u;
+                }
+            }
+        }
+    }
+    double amul[PQ], adiv[PQ];   // theta = u * (a - l2) / a     (ggl_helper.py:38-43)
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        const double a = fmax(sqrt(ss[q]), l2);
+        amul[q] = a - l2;
+        adiv[q] = a;
+    }
+
+    // sweep 2
+    double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < K; ++k) {
+        const size_t base = (size_t)k * pp;
+        const int buf = k & 1;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            if (up_ok[q]) {
+                const size_t o = base + up_off[q];
+                const double om = Omega[o];
+                const double l = L ? L[o] : 0.0;
+                const double x = X ? X[o] : 0.0;
+                const double v = (om + l) + x;
+                const double th = pr_ok[q] ? soft(v, l1) * amul[q] / adiv[q] : v;
+                Theta[o] = th;
+                tile[buf][ty + PTY * q][tx] = th;
+                if (FUSE_DUAL) {
+                    const double xn = x + (om - th);
+                    X[o] = xn;
+                    const double dp = om - OmegaPrev[o];
+                    acc[0] += om * om;
+                    acc[1] += th * th;
+                    acc[2] += xn * xn;
+                    acc[3] += (om - th) * (om - th);
+                    acc[4] += dp * dp;
+                } else if (C) {
+                    C[o] = (th - x) - om;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            if (lo_ok[q]) {
+                const size_t o = base + lo_off[q];
+                const double th = tile[buf][tx][ty + PTY * q];
+                Theta[o] = th;
+                if (FUSE_DUAL) {
+                    const double om = Omega[o], x = X[o];
+                    const double xn = x + (om - th);
+                    X[o] = xn;
+                    const double dp = om - OmegaPrev[o];
+                    acc[0] += om * om;
+                    acc[1] += th * th;
+                    acc[2] += xn * xn;
+                    acc[3] += (om - th) * (om - th);
+                    acc[4] += dp * dp;
+                } else if (C) {
+                    C[o] = (th - X[o]) - Omega[o];
+                }
+            }
+        }
+    }
+    if (FUSE_DUAL) {
+        // block_sum indexes waves by threadIdx.x; flatten the 32x8 block first
+        const int lane = (ty * PT + tx) & 63, wid = (ty * PT + tx) >> 6;
+#pragma unroll
+        for (int v = 0; v < GGL_NNORM; ++v) acc[v] = wave_sum(acc[v]);
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) scratch[wid * GGL_NNORM + v] = acc[v];
+        }
+        __syncthreads();
+        if (tx == 0 && ty == 0) {
+            double* o = partials + (size_t)blockIdx.x * GGL_NNORM;
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v)
+                o[v] = (scratch[v] + scratch[GGL_NNORM + v]) + (scratch[2 * GGL_NNORM + v] + scratch[3 * GGL_NNORM + v]);
+        }
+    }
+}
+
+// sweep 1 alone, for K-sharded runs: groupsq[i,j] (i<j) = sum over the local slab
+__global__ __launch_bounds__(256) void k_group_partial(double* __restrict__ groupsq, const double* __restrict__ Omega,
+                                                       const double* __restrict__ L, const double* __restrict__ X,
+                                                       double l1, int K, int p)
+{
+    const int T = (p + PT - 1) / PT;
+    int I, J;
+    decode_pair(blockIdx.x, T, I, J);
+    const bool diag = (I == J);
+    const int I0 = I * PT, J0 = J * PT;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const size_t pp = (size_t)p * p;
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        const int r = ty + PTY * q;
+        const bool ok = (I0 + r < p) && (J0 + tx < p) && (!diag || r < tx);
+        if (!ok) continue;
+        const size_t off = (size_t)(I0 + r) * p + (J0 + tx);
+        double ss = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double v = Omega[(size_t)k * pp + off];
+            if (L) v += L[(size_t)k * pp + off];
+            v += X[(size_t)k * pp + off];
+            const double u = soft(v, l1);
+            ss += u * u;
+        }
+        groupsq[off] = ss;
+    }
+}
+
+void launch_group_partial(hipStream_t st, double* groupsq, const double* Omega, const double* L,
+                          const double* X, double l1, int K, int p)
+{
+    const int T = ntiles(p, PT);
+    hipLaunchKernelGGL(k_group_partial, dim3(T * (T + 1) / 2), dim3(PT, PTY), 0, st, groupsq, Omega, L, X, l1, K, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FGL
+// ---------------------------------------------------------------------------------------------
+// Condat's direct 1-D TV prox (fgl_helper.py:11-68) on y[0], y[s], ..., y[(N-1)s], in place:
+// a segment is only written once the scan has moved past it, so x may overwrite y.
+__device__ __forceinline__ void condat_inplace(double* y, const int s, const int N, const double lam)
+{
+    int k = 0, k0 = 0, kplus = 0, kminus = 0;
+    double vmin = y[0] - lam, vmax = y[0] + lam, umin = lam, umax = -lam;
+    for (;;) {
+        while (k == N - 1) {
+            if (umin < 0.0) {
+                for (int i = k0; i <= kminus; ++i) y[i * s] = vmin;
+                kminus += 1;
+                k = k0 = kminus;
+                umin = lam;
+                vmin = y[k * s];
+                umax = y[k * s] + lam - vmax;
+            } else if (umax > 0.0) {
+                for (int i = k0; i <= kplus; ++i) y[i * s] = vmax;
+                kplus += 1;
+                k = k0 = kplus;
+                umax = -lam;
+                vmax = y[k * s];
+                umin = y[k * s] - lam - vmin;
+            } else {
+                const double v = vmin + umin / (double)(k - k0 + 1);
+                for (int i = k0; i < N; ++i) y[i * s] = v;
+                return;
+            }
+            if (k == N - 1) {
+                y[k * s] = vmin + umin;
+                return;
+            }
+        }
+        const double yn = y[(k + 1) * s];
+        if (yn + umin - vmin < -lam) {
+            for (int i = k0; i <= kminus; ++i) y[i * s] = vmin;
+            kminus += 1;
+            k = kplus = k0 = kminus;
+            vmin = y[k * s];
+            vmax = y[k * s] + 2 * lam;
+            umin = lam;
+            umax = -lam;
+        } else if (yn + umax - vmax > lam) {
+            for (int i = k0; i <= kplus; ++i) y[i * s] = vmax;
+            kplus += 1;
+            k = kminus = k0 = kplus;
+            vmin = y[k * s] - 2 * lam;
+            vmax = y[k * s];
+            umin = lam;
+            umax = -lam;
+        } else {
+            k += 1;
+            umin = umin + yn - vmin;
+            umax = umax + yn - vmax;
+            if (umin >= lam) {
+                vmin += (umin - lam) / (double)(k - k0 + 1);
+                umin = lam;
+                kminus = k;
+            }
+            if (umax <= -lam) {
+                vmax += (umax + lam) / (double)(k - k0 + 1);
+                umax = -lam;
+                kplus = k;
+            }
+        }
+    }
+}
+
+template <int TD, bool FUSE_DUAL>
+__global__ __launch_bounds__(TD * TD) void k_theta_fgl(double* __restrict__ Theta, double* __restrict__ X,
+                                                       double* __restrict__ C, const double* __restrict__ Omega,
+                                                       const double* __restrict__ OmegaPrev,
+                                                       const double* __restrict__ L, double l1, double l2,
+                                                       double* __restrict__ partials, int K, int p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // [K][TD*TD] then scratch
+    constexpr int NT = TD * TD;
+    const int T = (p + TD - 1) / TD;
+    int I, J;
+    decode_pair(blockIdx.x, T, I, J);
+    const bool diag = (I == J);
+    const int I0 = I * TD, J0 = J * TD;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * TD + tx;
+    const size_t pp = (size_t)p * p;
+    double* ycol = lds + tid;
+    double* scratch = lds + (size_t)K * NT;
+
+    const bool up_ok = (I0 + ty < p) && (J0 + tx < p) && (!diag || ty <= tx);
+    const bool pr_ok = up_ok && !(diag && ty == tx);
+    const size_t up_off = (size_t)(I0 + ty) * p + (J0 + tx);
+    const bool lo_ok = (J0 + ty < p) && (I0 + tx < p) && (!diag || ty > tx);
+    const size_t lo_off = (size_t)(J0 + ty) * p + (I0 + tx);
+
+    if (up_ok) {
+        for (int k = 0; k < K; ++k) {
+            const size_t o = (size_t)k * pp + up_off;
+            double v = Omega[o];
+            if (L) v += L[o];
+            if (X) v += X[o];
+            ycol[k * NT] = v;
+        }
+    }
+    if (pr_ok) {
+        condat_inplace(ycol, NT, K, l2);
+        for (int k = 0; k < K; ++k) ycol[k * NT] = soft(ycol[k * NT], l1);
+    }
+    __syncthreads();
+
+    double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < K; ++k) {
+        const size_t base = (size_t)k * pp;
+        if (up_ok) {
+            const size_t o = base + up_off;
+            const double th = ycol[k * NT];
+            Theta[o] = th;
+            if (FUSE_DUAL) {
+                const double om = Omega[o], x = X[o];
+                const double xn = x + (om - th);
+                X[o] = xn;
+                const double dp = om - OmegaPrev[o];
+                acc[0] += om * om;
+                acc[1] += th * th;
+                acc[2] += xn * xn;
+                acc[3] += (om - th) * (om - th);
+                acc[4] += dp * dp;
+            } else if (C) {
+                C[o] = (th - X[o]) - Omega[o];
+            }
+        }
+        if (lo_ok) {
+            const size_t o = base + lo_off;
+            const double th = lds[(size_t)k * NT + tx * TD + ty];
+            Theta[o] = th;
+            if (FUSE_DUAL) {
+                const double om = Omega[o], x = X[o];
+                const double xn = x + (om - th);
+                X[o] = xn;
+                const double dp = om - OmegaPrev[o];
+                acc[0] += om * om;
+                acc[1] += th * th;
+                acc[2] += xn * xn;
+                acc[3] += (om - th) * (om - th);
+                acc[4] += dp * dp;
+            } else if (C) {
+                C[o] = (th - X[o]) - Omega[o];
+            }
+        }
+    }
+    if (FUSE_DUAL) {
+        constexpr int NW = (NT + 63) / 64;
+#pragma unroll
+        for (int v = 0; v < GGL_NNORM; ++v) acc[v] = wave_sum(acc[v]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) scratch[(tid >> 6) * GGL_NNORM + v] = acc[v];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double* o = partials + (size_t)blockIdx.x * GGL_NNORM;
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) {
+                double s = 0.0;
+                for (int w = 0; w < NW; ++w) s += scratch[w * GGL_NNORM + v];
+                o[v] = s;
+            }
+        }
+    }
+}
+
+template <int TD>
+static hipError_t launch_fgl_td(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
+                                const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual,
+                                double* partials, int K, int p)
+{
+    const int T = ntiles(p, TD);
+    const size_t lds = ((size_t)K * TD * TD + GGL_NNORM * 4) * sizeof(double);
+    dim3 grid(T * (T + 1) / 2), blk(TD, TD);
+    hipError_t e;
+    if (fuse_dual) {
+        e = hipFuncSetAttribute((const void*)k_theta_fgl<TD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_theta_fgl<TD, true>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p);
+    } else {
+        e = hipFuncSetAttribute((const void*)k_theta_fgl<TD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_theta_fgl<TD, false>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C, const double* Omega,
+                             const double* OmegaPrev, const double* L, double l1, double l2,
+                             const double* groupsq, int fuse_dual, double* partials, int K, int p)
+{
+    if (reg == 1) {
+        const int T = ntiles(p, PT);
+        dim3 grid(T * (T + 1) / 2), blk(PT, PTY);
+        if (fuse_dual)
+            hipLaunchKernelGGL(k_theta_ggl<true>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, groupsq, partials, K, p);
+        else
+            hipLaunchKernelGGL(k_theta_ggl<false>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, groupsq, partials, K, p);
+        return hipGetLastError();
+    }
+    if (K > FGL_MAX_K_TD8) return hipErrorInvalidValue;
+    if (fgl_tile(K) == 16)
+        return launch_fgl_td<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p);
+    return launch_fgl_td<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p);
+}
+
+hipError_t launch_prox_p(hipStream_t st, int reg, double* out, const double* V, double l1, double l2, int K, int p)
+{
+    return launch_theta_pair(st, reg, out, nullptr, nullptr, V, nullptr, nullptr, l1, l2, nullptr, 0, nullptr, K, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// P_val (ggl_helper.py:162-176): 2 * sum_{i<j} [ l1 |v|_1 + l2 |v|_2 ]  (GGL)
+//                                2 * sum_{i<j} [ l1 |v|_1 + l2 sum_k |v_{k+1}-v_k| ]  (FGL)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pval(int reg, const double* __restrict__ Theta, double l1, double l2, int K,
+                                              int p, double* __restrict__ partials)
+{
+    __shared__ double scratch[4];
+    const int T = (p + PT - 1) / PT;
+    int I, J;
+    decode_pair(blockIdx.x, T, I, J);
+    const bool diag = (I == J);
+    const int I0 = I * PT, J0 = J * PT;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const size_t pp = (size_t)p * p;
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        const int r = ty + PTY * q;
+        const bool ok = (I0 + r < p) && (J0 + tx < p) && (!diag || r < tx);
+        if (!ok) continue;
+        const size_t off = (size_t)(I0 + r) * p + (J0 + tx);
+        double s1 = 0.0, s2 = 0.0, prev = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double v = Theta[(size_t)k * pp + off];
+            s1 += fabs(v);
+            if (reg == 1) s2 += v * v;
+            else if (k > 0) s2 += fabs(v - prev);
+            prev = v;
+        }
+        tot += l1 * s1 + l2 * (reg == 1 ? sqrt(s2) : s2);
+    }
+    tot = wave_sum(tot);
+    const int tid = ty * PT + tx;
+    if ((tid & 63) == 0) scratch[tid >> 6] = tot;
+    __syncthreads();
+    if (tid == 0) partials[blockIdx.x] = 2.0 * ((scratch[0] + scratch[1]) + (scratch[2] + scratch[3]));
+}
+
+void launch_pval(hipStream_t st, int reg, const double* Theta, double l1, double l2, int K, int p, double* partials)
+{
+    const int T = ntiles(p, PT);
+    hipLaunchKernelGGL(k_pval, dim3(T * (T + 1) / 2), dim3(PT, PTY), 0, st, reg, Theta, l1, l2, K, p, partials);
+}
+
+// ---------------------------------------------------------------------------------------------
+// n independent K-vectors (operator-level parity entry points)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_vec_prox(int mode, const double* __restrict__ Y, double* __restrict__ out, int n,
+                                                 int K, double l1, double l2)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // [K][64]
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= n) return;
+    double* y = lds + threadIdx.x;
+    for (int k = 0; k < K; ++k) y[k * 64] = Y[(size_t)v * K + k];
+    if (mode == 0) {                      // prox_tv
+        condat_inplace(y, 64, K, l1);
+    } else if (mode == 1 || mode == 2) {  // prox_2norm / prox_phi_ggl
+        double ss = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double u = y[k * 64];
+            if (mode == 2) u = soft(u, l1);
+            y[k * 64] = u;
+            ss += u * u;
+        }
+        const double l = (mode == 1) ? l1 : l2;
+        const double a = fmax(sqrt(ss), l);
+        for (int k = 0; k < K; ++k) y[k * 64] = y[k * 64] * (a - l) / a;
+    } else {                              // prox_phi_fgl
+        condat_inplace(y, 64, K, l2);
+        for (int k = 0; k < K; ++k) y[k * 64] = soft(y[k * 64], l1);
+    }
+    for (int k = 0; k < K; ++k) out[(size_t)v * K + k] = y[k * 64];
+}
+
+hipError_t launch_vec_prox(hipStream_t st, int mode, const double* Y, double* out, int n, int K, double l1, double l2)
+{
+    const size_t lds = (size_t)K * 64 * sizeof(double);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void*)k_vec_prox, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_vec_prox, dim3((n + 63) / 64), dim3(64), lds, st, mode, Y, out, n, K, l1, l2);
+    return hipGetLastError();
+}
+
+}  // namespace ggl

@@ -1,0 +1,314 @@
+"""Drop-in ADMM solvers: ``ADMM_MGL`` and ``ADMM_SGL`` with the reference's keyword signatures and
+return contracts (solver/admm_solver.py:13-313, solver/single_admm_solver.py:15-275 of
+fabian-sp/GGLasso), usable as the ``solver`` callable of ``grid_search`` (helper/model_selection.py:55,222).
+
+What stays on the host (as in the reference): iteration count, the rho rule, the stopping decision,
+status strings, verbose printing, exit warnings.  What moves to the MI355X: every array operation of
+the loop body.  S, Omega, Theta, L, X live in HBM for the whole solve; per iteration two scalars go
+down (rho, lambda/rho) and five squared norms come back.
+
+There is no CPU fallback: constructing the engine raises if libggl_hip.so or a GPU is missing.
+"""
+import time
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_c, check, ptr
+
+_REG = {"SGL": _lib.REG_SGL, "GGL": _lib.REG_GGL, "FGL": _lib.REG_FGL}
+
+
+class HipEngine:
+    """Device-resident ADMM state behind the C ABI (one ggl_ctx)."""
+
+    def __init__(self, S, Omega_0, Theta_0, X_0, L_0=None, eig=_lib.EIG_AUTO, device=0, stream=None):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        S = as_c(S)
+        self.K, self.p, _ = S.shape
+        h = _lib._vp()
+        check(self.lib.ggl_ctx_create(int(device), self.K, self.p, int(eig), stream, h))
+        self.h = h
+        check(self.lib.ggl_set_S(self.h, ptr(S)))
+        L_0 = None if L_0 is None else as_c(L_0)
+        check(self.lib.ggl_set_state(self.h, ptr(as_c(Omega_0)), ptr(as_c(Theta_0)), ptr(L_0), ptr(as_c(X_0))))
+        self._norms = np.zeros(5)
+
+    # -- iteration pieces ------------------------------------------------------------------
+    def set_lambda1_mask(self, lam_pp):
+        check(self.lib.ggl_set_lambda1_mask(self.h, ptr(None if lam_pp is None else as_c(lam_pp))))
+
+    def step(self, rho, lambda1, lambda2, reg, latent, mu1, nk):
+        check(self.lib.ggl_admm_step(self.h, rho, lambda1, lambda2, _REG[reg], int(latent), ptr(mu1), ptr(nk),
+                                     ptr(self._norms)))
+        return self._norms.copy()
+
+    def step_omega(self, rho, latent, nk):
+        check(self.lib.ggl_step_omega(self.h, rho, int(latent), ptr(nk)))
+
+    def step_group_partial(self, rho, lambda1):
+        check(self.lib.ggl_step_group_partial(self.h, rho, lambda1))
+
+    def step_finish(self, rho, lambda1, lambda2, reg, latent, mu1, groupsq_ready):
+        check(self.lib.ggl_step_finish(self.h, rho, lambda1, lambda2, _REG[reg], int(latent), ptr(mu1),
+                                       int(groupsq_ready), ptr(self._norms)))
+        return self._norms.copy()
+
+    def scale_X(self, f):
+        check(self.lib.ggl_scale_X(self.h, f))
+
+    def objective(self, lambda1, lambda2, reg):
+        out = np.zeros(3)
+        check(self.lib.ggl_objective(self.h, lambda1, lambda2, _REG[reg], ptr(out)))
+        return out
+
+    def kkt_residual(self, rho, lambda1, lambda2, reg, latent, mu1, nk):
+        out = np.zeros(1)
+        check(self.lib.ggl_kkt_residual(self.h, rho, lambda1, lambda2, _REG[reg], int(latent), ptr(mu1), ptr(nk),
+                                        ptr(out)))
+        return float(out[0])
+
+    def exit_checks(self, latent):
+        out = np.zeros(5)
+        check(self.lib.ggl_exit_checks(self.h, int(latent), ptr(out)))
+        return out
+
+    def state(self):
+        shape = (self.K, self.p, self.p)
+        Om, Th, L, X = (np.empty(shape) for _ in range(4))
+        check(self.lib.ggl_get_state(self.h, ptr(Om), ptr(Th), ptr(L), ptr(X)))
+        return {'Omega': Om, 'Theta': Th, 'L': L, 'X': X}
+
+    def device_ptr(self, which):
+        return self.lib.ggl_device_ptr(self.h, which)
+
+    def sync(self):
+        check(self.lib.ggl_ctx_sync(self.h))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.ggl_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# The engine class the solvers instantiate.  Tests of the host logic may substitute a class with
+# the same methods; the shipped value is the HIP engine and nothing else.
+ENGINE = HipEngine
+
+
+def residuals_from_norms(sq, rho, tol, rtol, dim):
+    """ADMM_stopping_criterion (solver/admm_solver.py:316-331) from the five squared norms."""
+    n_om, n_thl, n_x, n_r, n_s = (float(np.sqrt(v)) for v in sq)
+    e_pri = dim * tol + rtol * max(n_om, n_thl)
+    e_dual = dim * tol + rtol * rho * n_x
+    return n_r, rho * n_s, e_pri, e_dual
+
+
+def next_rho(rho, r_t, s_t):
+    """Residual balancing (solver/admm_solver.py:227-233)."""
+    if r_t >= 10 * s_t:
+        return 2 * rho
+    if s_t >= 10 * r_t:
+        return 0.5 * rho
+    return 1. * rho
+
+
+def _run_admm(eng, reg, K_total, p, lambda1, lambda2, latent, mu1, nk, rho, tol, rtol, stopping_criterion,
+              update_rho, max_iter, verbose, measure, title, comm=None, want_objective=False):
+    """Host control flow shared by ADMM_MGL / ADMM_SGL / the K-sharded driver.
+    comm: None or an object with ``allreduce_groupsq(engine)`` and ``allreduce_norms(np.ndarray)``."""
+    runtime = np.zeros(max_iter)
+    residual = np.zeros(max_iter)
+    objective = np.zeros(max_iter)
+    status = ''
+    dim = K_total * ((p ** 2 + p) / 2)
+    sharded_ggl = comm is not None and reg == 'GGL'
+
+    if verbose:
+        print(f"------------ADMM Algorithm for {title} Graphical Lasso----------------")
+        if stopping_criterion == 'boyd':
+            print("%4s\t%10s\t%10s\t%10s\t%10s" % ("iter", "r_t", "s_t", "eps_pri", "eps_dual"))
+        else:
+            print("%4s\t%10s" % ("iter", "kkt residual"))
+
+    r_t = s_t = e_pri = e_dual = 0.0
+    iter_t = -1
+    for iter_t in range(max_iter):
+        if measure:
+            start = time.time()
+        if sharded_ggl:
+            eng.step_omega(rho, latent, nk)
+            eng.step_group_partial(rho, lambda1)
+            comm.allreduce_groupsq(eng)
+            sq = eng.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 1)
+        else:
+            sq = eng.step(rho, lambda1, lambda2, reg, latent, mu1, nk)
+        if comm is not None:
+            sq = comm.allreduce_norms(sq)
+        if measure:
+            runtime[iter_t] = time.time() - start
+            if want_objective:
+                o = eng.objective(lambda1, lambda2, reg)
+                if comm is not None:
+                    o[:2] = comm.allreduce_norms(o[:2])
+                objective[iter_t] = o.sum()
+
+        if stopping_criterion == 'boyd':
+            r_t, s_t, e_pri, e_dual = residuals_from_norms(sq, rho, tol, rtol, dim)
+            if update_rho:
+                rho_new = next_rho(rho, r_t, s_t)
+                if rho_new != rho:
+                    eng.scale_X(rho / rho_new)       # solver/admm_solver.py:236
+                rho = rho_new
+            residual[iter_t] = max(r_t, s_t)
+            if verbose:
+                print("%4d\t%10.4g\t%10.4g\t%10.4g\t%10.4g" % (iter_t, r_t, s_t, e_pri, e_dual))
+            if (r_t <= e_pri) and (s_t <= e_dual):
+                status = 'optimal'
+                break
+        else:
+            eta_A = eng.kkt_residual(rho, lambda1, lambda2, reg, latent, mu1, nk)
+            residual[iter_t] = eta_A
+            if verbose:
+                print("%4d\t%10.4g" % (iter_t, eta_A))
+            if eta_A <= tol:
+                status = 'optimal'
+                break
+
+    if status != 'optimal':
+        if stopping_criterion == 'boyd':
+            if r_t <= e_pri:
+                status = 'primal optimal'
+            elif s_t <= e_dual:
+                status = 'dual optimal'
+            else:
+                status = 'max iterations reached'
+        else:
+            status = 'max iterations reached'
+
+    print(f"ADMM terminated after {iter_t+1} iterations with status: {status}.")
+    info = {'status': status}
+    if measure:
+        info['runtime'] = runtime[:iter_t + 1]
+        info['residual'] = residual[:iter_t + 1]
+        if want_objective:
+            info['objective'] = objective[:iter_t + 1]
+    return info, rho
+
+
+def _exit_report(eng, latent, psd_tol, verbose_min_ev):
+    """Symmetry / definiteness checks after the loop (solver/admm_solver.py:284-301,
+    solver/single_admm_solver.py:244-263)."""
+    a_om, a_th, a_l, min_tl, min_l = eng.exit_checks(latent)
+    for name, dev in (("Omega", a_om), ("Theta", a_th), ("L", a_l)):
+        if dev > 1e-5:
+            warnings.warn(f"{name} variable is not symmetric, largest deviation is {dev}.")
+    if min_tl <= 0:
+        extra = f" (min EV is {min_tl})" if verbose_min_ev else ""
+        print("WARNING: Theta (Theta - L resp.) is not positive definite. Solve to higher accuracy!" + extra)
+    if latent and min_l < -psd_tol:
+        extra = f" (min EV is {min_l})" if verbose_min_ev else ""
+        print("WARNING: L is not positive semidefinite. Solve to higher accuracy!" + extra)
+
+
+def ADMM_MGL(S, lambda1, lambda2, reg, Omega_0, Theta_0=np.array([]), X_0=np.array([]), n_samples=None,
+             tol=1e-5, rtol=1e-4, stopping_criterion='boyd', update_rho=True, rho=1., max_iter=1000,
+             verbose=False, measure=False, latent=False, mu1=None):
+    """Multiple Graphical Lasso by ADMM on the MI355X -- same arguments, defaults, asserts, status
+    strings and return dicts as the reference's ``ADMM_MGL`` (solver/admm_solver.py:13-313).
+
+    Returns ``(sol, info)`` with ``sol = {'Omega','Theta','L','X'}`` (each (K,p,p), X the scaled dual)
+    and ``info = {'status'}`` (+ ``runtime``, ``residual``, ``objective`` when ``measure``)."""
+    assert Omega_0.shape == S.shape
+    assert S.shape[1] == S.shape[2]
+    assert reg in ['GGL', 'FGL']
+    assert min(lambda1, lambda2) > 0
+    (K, p, p) = S.shape
+    assert rho > 0, "ADMM penalization parameter must be positive."
+    assert stopping_criterion in ('boyd', 'kkt')
+
+    if latent:
+        if isinstance(mu1, float):
+            mu1 = mu1 * np.ones(K)
+        assert mu1 is not None
+        assert np.all(mu1 > 0)
+        mu1 = as_c(mu1)
+    else:
+        mu1 = None
+
+    # admm_solver.py:129-139: None -> ones, int -> same weight for every instance, else (K,) array
+    if n_samples is None:
+        nk = np.ones(K)
+    elif isinstance(n_samples, (int, np.integer)):
+        nk = float(n_samples) * np.ones(K)
+    else:
+        nk = as_c(n_samples).reshape(-1)
+        assert len(nk) == K
+
+    if len(Theta_0) == 0:
+        Theta_0 = Omega_0
+    if len(X_0) == 0:
+        X_0 = np.zeros((K, p, p))
+
+    eng = ENGINE(S, Omega_0, Theta_0, X_0)
+    try:
+        info, _ = _run_admm(eng, reg, K, p, float(lambda1), float(lambda2), bool(latent), mu1, nk, float(rho),
+                            tol, rtol, stopping_criterion, update_rho, max_iter, verbose, measure, "Multiple",
+                            want_objective=True)
+        _exit_report(eng, latent, 1e-5, False)
+        sol = eng.state()
+    finally:
+        eng.close()
+    return sol, info
+
+
+def ADMM_SGL(S, lambda1, Omega_0, Theta_0=np.array([]), X_0=np.array([]), rho=1., max_iter=1000, tol=1e-7,
+             rtol=1e-4, stopping_criterion='boyd', update_rho=True, verbose=False, measure=False, latent=False,
+             mu1=None, lambda1_mask=None):
+    """Single Graphical Lasso by ADMM on the MI355X -- the reference's ``ADMM_SGL``
+    (solver/single_admm_solver.py:15-275): same arguments, asserts and return contract (``sol`` has
+    no 'L' unless ``latent``)."""
+    assert Omega_0.shape == S.shape
+    assert S.shape[0] == S.shape[1]
+    (p, p) = S.shape
+    assert lambda1 > 0, ("lambda1 should be positive, otherwise using Graphical Lasso is redundant. "
+                         "Specify entries with zero regularization using lambda1_mask.")
+    lam_pp = None
+    if lambda1_mask is not None:
+        assert lambda1_mask.shape == (p, p), f"lambda1_mask needs to be of shape (p,p), but is {lambda1_mask.shape}."
+        assert np.all(lambda1_mask >= 0), "lambda1_mask needs to be non-negative."
+        assert np.all(np.abs(lambda1_mask.T - lambda1_mask) <= 1e-5), "lambda1_mask needs to be symmetric."
+        lam_pp = lambda1 * lambda1_mask           # single_admm_solver.py:114
+    assert stopping_criterion in ["boyd", "kkt"]
+    if latent:
+        assert mu1 is not None
+        assert mu1 > 0
+    assert rho > 0, "ADMM penalization parameter must be positive."
+
+    if len(Theta_0) == 0:
+        Theta_0 = Omega_0
+    if len(X_0) == 0:
+        X_0 = np.zeros((p, p))
+
+    eng = ENGINE(S[None], np.asarray(Omega_0)[None], np.asarray(Theta_0)[None], np.asarray(X_0)[None])
+    try:
+        eng.set_lambda1_mask(lam_pp)
+        mu = as_c(np.array([mu1])) if latent else None
+        info, _ = _run_admm(eng, 'SGL', 1, p, float(lambda1), 0.0, bool(latent), mu, np.ones(1), float(rho), tol,
+                            rtol, stopping_criterion, update_rho, max_iter, verbose, measure, "Single")
+        _exit_report(eng, latent, 1e-8, True)
+        st = eng.state()
+    finally:
+        eng.close()
+    sol = {'Omega': st['Omega'][0], 'Theta': st['Theta'][0], 'X': st['X'][0]}
+    if latent:
+        sol['L'] = st['L'][0]
+    return sol, info

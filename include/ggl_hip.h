@@ -1,0 +1,143 @@
+/*
+ * ggl_hip.h -- C ABI of libggl_hip.so: the MI355X (gfx950) ADMM inner loop for General Graphical
+ * Lasso.  This is the drop-in boundary for the hot path of fabian-sp/GGLasso; every entry point
+ * names the reference interface it replaces (paths relative to /root/reference/src/gglasso/).
+ *
+ * Conventions
+ *   - All matrices are float64, C-contiguous, row-major; stacks are (K,p,p) with k slowest.
+ *   - "host" pointers are ordinary CPU memory owned by the caller (NumPy arrays); the library
+ *     owns every device buffer inside the opaque ggl_ctx and never keeps a host pointer.
+ *   - Every function returns 0 on success, <0 on error (GGL_E_*); ggl_last_error() returns a
+ *     thread-local message.  No C++ exception crosses the ABI.
+ *   - A ctx is bound to one device and one HIP stream and is not thread-safe.  Multi-GPU = one
+ *     process (rank) per GPU, each with its own ctx (see gglasso_amd/dist.py).
+ *   - Eigenvector matrices cross the ABI in NumPy's convention: Q (K,p,p) with eigenvectors in
+ *     COLUMNS, eigenvalues ascending (numpy.linalg.eigh, called at solver/admm_solver.py:181,199).
+ */
+#ifndef GGL_HIP_H
+#define GGL_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGL_VERSION 100
+
+/* error codes */
+#define GGL_OK 0
+#define GGL_E_ARG (-1)      /* bad argument (the reference would raise AssertionError) */
+#define GGL_E_HIP (-2)      /* HIP runtime error */
+#define GGL_E_SOLVER (-3)   /* rocSOLVER / eigensolver did not converge */
+#define GGL_E_ALLOC (-4)
+
+/* penalty selector: reg argument of ADMM_MGL (solver/admm_solver.py:13-31) / ADMM_SGL */
+#define GGL_REG_SGL 0       /* K independent single problems: prox_od_1norm (ggl_helper.py:16-27) */
+#define GGL_REG_GGL 1       /* prox_phi_ggl (ggl_helper.py:68-71) */
+#define GGL_REG_FGL 2       /* prox_phi_fgl (ggl_helper.py:131-134) */
+
+/* eigensolver selector (ctx flags, low byte) */
+#define GGL_EIG_AUTO 0      /* LDS Jacobi when the matrix fits one workgroup's LDS, else rocSOLVER */
+#define GGL_EIG_JACOBI 1    /* hand-written one-workgroup-per-matrix Jacobi (p <= GGL_JACOBI_MAX_P) */
+#define GGL_EIG_ROCSOLVER 2 /* rocsolver_dsyevd_strided_batched */
+#define GGL_JACOBI_MAX_P 128
+
+/* which-buffer selector of ggl_device_ptr */
+#define GGL_BUF_S 0
+#define GGL_BUF_OMEGA 1
+#define GGL_BUF_THETA 2
+#define GGL_BUF_L 3
+#define GGL_BUF_X 4
+#define GGL_BUF_GROUPSQ 5   /* (p,p) partial sum_k u^2 of the GGL Theta-step (K-sharded runs) */
+#define GGL_BUF_NORMS 6     /* (K,5) per-instance squared norms of the stopping test */
+#define GGL_BUF_OMEGA_PREV 7
+
+typedef struct ggl_ctx ggl_ctx;
+
+int ggl_version(void);
+const char *ggl_last_error(void);
+/* number of visible HIP devices, or <0 (used by the loader to fail loudly on a GPU-less box) */
+int ggl_device_count(void);
+
+/* ---- context ---------------------------------------------------------------------------------
+ * Replaces the NumPy temporaries ADMM_MGL allocates per call (admm_solver.py:142-154).
+ * stream: an existing hipStream_t (e.g. torch's current stream) or NULL to create one. */
+int ggl_ctx_create(int device, int K, int p, int flags, void *stream, ggl_ctx **out);
+int ggl_ctx_destroy(ggl_ctx *ctx);
+int ggl_ctx_sync(ggl_ctx *ctx);
+void *ggl_device_ptr(ggl_ctx *ctx, int which);
+
+/* ---- state upload / download ----------------------------------------------------------------
+ * S: admm_solver.py:13 (argument S).  set_state: Omega_0/Theta_0/X_0 copies, admm_solver.py:142-150
+ * (NULL leaves the buffer as is; L NULL zeroes it like admm_solver.py:149).  get_state: the `sol`
+ * dict of admm_solver.py:303 (NULL = skip). */
+int ggl_set_S(ggl_ctx *ctx, const double *S_host);
+int ggl_set_state(ggl_ctx *ctx, const double *Omega, const double *Theta, const double *L,
+                  const double *X);
+int ggl_get_state(ggl_ctx *ctx, double *Omega, double *Theta, double *L, double *X);
+/* lambda1 * lambda1_mask as a (p,p) array (single_admm_solver.py:114); NULL clears it. */
+int ggl_set_lambda1_mask(ggl_ctx *ctx, const double *lam_pp_host);
+
+/* ---- one ADMM iteration ---------------------------------------------------------------------
+ * Body of the hot loop, admm_solver.py:179-224 / single_admm_solver.py:163-193:
+ *   W = Theta - L - X - (nk/rho) S ; (D,Q) = eigh(W) ; Omega = phiplus(nk/rho, D, Q)
+ *   Theta = prox_p(Omega + L + X, lambda1/rho, lambda2/rho, reg)      (prox_od_1norm for SGL)
+ *   latent: L = prox_rank_norm(Theta - X - Omega, mu1/rho)
+ *   X += Omega - Theta + L
+ * out_norms[5] = squared Frobenius norms over the whole stack that ADMM_stopping_criterion
+ * (admm_solver.py:316-331) needs: |Omega|^2, |Theta-L|^2, |X|^2, |Omega-Theta+L|^2,
+ * |Omega-Omega_prev|^2.  rho update and the stopping decision stay on the host (admm_solver.py:227-246).
+ * mu1: host (K,) or NULL; nk: host (K,) or NULL (= ones).  rho, lambda1 are per-iteration scalars. */
+int ggl_admm_step(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int reg, int latent,
+                  const double *mu1, const double *nk, double out_norms[5]);
+
+/* The same iteration split at the one point where a K-sharded GGL run has to exchange data
+ * (sum_k u^2 couples the shards, ggl_helper.py:38-43):
+ *   ggl_step_omega          Omega-step on the local K-slab
+ *   ggl_step_group_partial  u = soft(Omega+L+X, l1/rho); GROUPSQ(p,p) = sum_{local k} u^2  (GGL only)
+ *   -- caller all-reduces GGL_BUF_GROUPSQ over ranks (RCCL) --
+ *   ggl_step_finish         Theta from the reduced GROUPSQ, L-step, X update, local norms       */
+int ggl_step_omega(ggl_ctx *ctx, double rho, int latent, const double *nk);
+int ggl_step_group_partial(ggl_ctx *ctx, double rho, double lambda1);
+int ggl_step_finish(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int reg, int latent,
+                    const double *mu1, int groupsq_ready, double out_norms[5]);
+
+/* X <- factor * X : dual rescale after a rho update (admm_solver.py:236). */
+int ggl_scale_X(ggl_ctx *ctx, double factor);
+
+/* Exit checks of admm_solver.py:284-301: out = {max|Omega-Omega^T|, max|Theta-Theta^T|,
+ * max|L-L^T|, min eig(Theta-L), min eig(L)}. */
+int ggl_exit_checks(ggl_ctx *ctx, int latent, double out[5]);
+
+/* Objective pieces for measure=True (admm_solver.py:213): out = {sum_k -logdet Omega_k,
+ * <Omega,S>, P_val(Theta)} (ggl_helper.py:266-270,162-176). */
+int ggl_objective(ggl_ctx *ctx, double lambda1, double lambda2, int reg, double out[3]);
+
+/* KKT residual of admm_solver.py:333-371 / single_admm_solver.py:293-320 on the ctx state
+ * (opt-in stopping_criterion='kkt').  The dual passed by the reference is rho*X. */
+int ggl_kkt_residual(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int reg, int latent,
+                     const double *mu1, const double *nk, double *out);
+
+/* ---- stateless operator entry points (host buffers; used for operator-level parity) ---------- */
+/* numpy.linalg.eigh on a stack (lower triangle read); D (K,p) ascending, Q (K,p,p) columns. */
+int ggl_eigh_batched(int K, int p, const double *A, double *D, double *Q, int eig_method);
+/* phiplus(beta,D,Q), ggl_helper.py:280-303, for K matrices; beta (K,). */
+int ggl_phiplus(int K, int p, const double *beta, const double *D, const double *Q, double *out);
+/* prox_rank_norm(A,beta,D,Q), ggl_helper.py:29-36. */
+int ggl_prox_rank_norm(int K, int p, const double *beta, const double *D, const double *Q, double *out);
+/* eigh + phiplus / rank shrink fused, straight from the matrix (what the ADMM step runs). */
+int ggl_phiplus_matrix(int K, int p, const double *beta, const double *W, double *out, int eig_method);
+int ggl_rank_matrix(int K, int p, const double *beta, const double *C, double *out, int eig_method);
+/* prox_od_1norm(A,l), ggl_helper.py:16-27; lam_pp NULL => scalar lam. */
+int ggl_prox_od_1norm(int p, const double *A, double lam, const double *lam_pp, double *out);
+/* prox_p(X,l1,l2,reg), ggl_helper.py:190-207 (reg = GGL_REG_GGL | GGL_REG_FGL). */
+int ggl_prox_p(int K, int p, const double *X, double l1, double l2, int reg, double *out);
+/* n independent K-vectors, Y (n,K) row-major: prox_tv = condat_method (fgl_helper.py:11-68),
+ * prox_2norm (ggl_helper.py:38-43), prox_phi_ggl / prox_phi_fgl. */
+int ggl_prox_tv(int n, int K, const double *Y, double lam, double *out);
+int ggl_prox_2norm(int n, int K, const double *Y, double lam, double *out);
+int ggl_prox_phi(int n, int K, const double *Y, double l1, double l2, int reg, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

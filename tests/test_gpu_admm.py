@@ -1,0 +1,153 @@
+"""ADMM-level parity on the MI355X: fixed-length trajectories, converged solutions, warm starts,
+status strings and the reference's known-answer test, all through the C ABI."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import ggl_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sol():
+    from gglasso_amd import solver
+    return solver
+
+
+def quiet(fn, *a, **k):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = fn(*a, **k)
+    return out, buf.getvalue()
+
+
+@pytest.mark.parametrize("reg", ["GGL", "FGL"])
+@pytest.mark.parametrize("latent", [False, True])
+def test_g8_fixed_length_trajectories(sol, reg, latent):
+    g = load_golden("g8_g9_admm_mgl")
+    S, Om0 = g[f"S_{reg}"], g["Omega_0"]
+    l1, l2, mu1 = g["params"]
+    tag = f"{reg}_{'lat' if latent else 'nol'}"
+    for mi in (1, 2, 10):
+        (s, info), out = quiet(sol.ADMM_MGL, S, l1, l2, reg, Om0, max_iter=mi, tol=1e-20, rtol=1e-20,
+                               latent=latent, mu1=float(mu1), measure=True)
+        for nm in ('Omega', 'Theta', 'L', 'X'):
+            assert np.abs(s[nm] - g[f"{tag}_it{mi}_{nm}"]).max() <= 1e-10, (mi, nm)
+        assert np.allclose(info['residual'], g[f"{tag}_it{mi}_residual"], rtol=1e-8)
+        assert np.allclose(info['objective'], g[f"{tag}_it{mi}_objective"], rtol=1e-10)
+        assert info['status'] == 'max iterations reached'
+        assert f"ADMM terminated after {mi} iterations with status: max iterations reached." in out
+        assert len(info['runtime']) == mi
+
+
+@pytest.mark.parametrize("reg", ["GGL", "FGL"])
+@pytest.mark.parametrize("latent", [False, True])
+def test_g9_converged_and_warm_start(sol, reg, latent):
+    g = load_golden("g8_g9_admm_mgl")
+    S, Om0 = g[f"S_{reg}"], g["Omega_0"]
+    l1, l2, mu1 = g["params"]
+    tag = f"{reg}_{'lat' if latent else 'nol'}"
+    (s, info), _ = quiet(sol.ADMM_MGL, S, l1, l2, reg, Om0, tol=1e-10, rtol=1e-10, latent=latent,
+                         mu1=float(mu1), measure=True)
+    assert np.linalg.norm(s['Theta'] - g[f"{tag}_conv_Theta"]) <= 1e-8      # the north-star tolerance
+    assert info['status'] == str(g[f"{tag}_conv_status"])
+    assert abs(len(info['residual']) - int(g[f"{tag}_conv_iters"])) <= 1
+    (s2, _), _ = quiet(sol.ADMM_MGL, S, l1, l2, reg, g[f"{tag}_warmstart_Omega"],
+                       Theta_0=g[f"{tag}_warmstart_Theta"], X_0=g[f"{tag}_warmstart_X"], n_samples=3,
+                       max_iter=4, tol=1e-20, rtol=1e-20, update_rho=False, rho=0.7, latent=latent,
+                       mu1=float(mu1))
+    for nm in ('Omega', 'Theta', 'L', 'X'):
+        assert np.abs(s2[nm] - g[f"{tag}_warm_{nm}"]).max() <= 1e-10
+
+
+def test_kkt_stopping(sol):
+    g = load_golden("g8_g9_admm_mgl")
+    S = g["S_GGL"]
+    l1, l2, _ = g["params"]
+    (s, info), _ = quiet(sol.ADMM_MGL, S, l1, l2, 'GGL', g["Omega_0"], tol=1e-6, stopping_criterion='kkt',
+                         measure=True)
+    assert len(info['residual']) == int(g["kkt_run_iters"])
+    assert np.abs(s['Theta'] - g["kkt_run_Theta"]).max() <= 1e-10
+
+
+@pytest.mark.parametrize("tag", ["plain", "mask", "latent", "zeromask"])
+def test_g10_admm_sgl(sol, tag):
+    g = load_golden("g10_admm_sgl")
+    S, mask = g["S"], g["mask"]
+    p = S.shape[0]
+    kw = {"plain": {}, "mask": {"lambda1_mask": mask}, "latent": {"latent": True, "mu1": 0.2},
+          "zeromask": {"lambda1_mask": np.zeros((p, p))}}[tag]
+    (s, info), _ = quiet(sol.ADMM_SGL, S, 0.05, np.eye(p), max_iter=10, tol=1e-20, rtol=1e-20, measure=True, **kw)
+    assert ('L' in s) == (tag == "latent")
+    for nm in s:
+        assert np.abs(s[nm] - g[f"{tag}_it10_{nm}"]).max() <= 1e-10, nm
+    assert np.allclose(info['residual'], g[f"{tag}_it10_residual"], rtol=1e-8)
+    assert 'objective' not in info
+    (s, info), _ = quiet(sol.ADMM_SGL, S, 0.05, np.eye(p), tol=1e-10, rtol=1e-10, **kw)
+    assert np.linalg.norm(s['Theta'] - g[f"{tag}_conv_Theta"]) <= 1e-8
+    assert info['status'] == str(g[f"{tag}_conv_status"])
+    if tag == "zeromask":
+        assert np.abs(s['Theta'] - g["inv_S"]).max() <= 1e-4     # reference tests/test_solvers.py:191-216
+
+
+def test_sgl_kkt(sol):
+    g = load_golden("g10_admm_sgl")
+    S = g["S"]
+    p = S.shape[0]
+    (s, info), _ = quiet(sol.ADMM_SGL, S, 0.05, np.eye(p), tol=1e-7, stopping_criterion='kkt', measure=True)
+    ref, rinfo = orc.ADMM_SGL(S, 0.05, np.eye(p), tol=1e-7, stopping_criterion='kkt', measure=True)
+    assert len(info['residual']) == rinfo['iterations']
+    assert np.abs(s['Theta'] - ref['Theta']).max() <= 1e-10
+
+
+def test_status_strings_like_reference_tests(sol):
+    """reference tests/test_solvers.py:25-65: p=50, K=3 -> 'optimal' at tol=rtol=1e-5, two iterations ->
+    'max iterations reached'."""
+    from gglasso_amd import synth
+    for reg in ("GGL", "FGL"):
+        S, _ = synth.make_problem(reg, K=3, p=50, N=1000, seed=3)
+        Om0 = np.stack([np.eye(50)] * 3)
+        for latent in (False, True):
+            (s, info), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, reg, Om0, tol=1e-5, rtol=1e-5, latent=latent, mu1=0.01)
+            assert info['status'] == 'optimal'
+            (s, info), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, reg, Om0, max_iter=2, latent=latent, mu1=0.01)
+            assert info['status'] == 'max iterations reached'
+
+
+@pytest.mark.parametrize("reg,K,p,latent", [("GGL", 4, 96, False), ("FGL", 5, 90, True), ("GGL", 3, 160, False),
+                                            ("FGL", 40, 40, False), ("GGL", 6, 150, True)])
+def test_oracle_trajectory_mid_sizes(sol, reg, K, p, latent):
+    """Seeded problems larger than the fixtures, HIP path vs CPU oracle (covers the LDS-Jacobi /
+    rocSOLVER+MFMA switch at p = 128 and the FGL tile switch at K = 32)."""
+    from gglasso_amd import synth
+    S, _ = synth.make_problem(reg, K=K, p=p, N=2 * p, seed=17)
+    Om0 = np.stack([np.eye(p)] * K)
+    ref, rinfo = orc.ADMM_MGL(S, 0.05, 0.01, reg, Om0, max_iter=12, tol=1e-20, rtol=1e-20, latent=latent, mu1=0.1)
+    (s, info), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, reg, Om0, max_iter=12, tol=1e-20, rtol=1e-20, latent=latent,
+                         mu1=0.1)
+    for nm in ('Omega', 'Theta', 'L', 'X'):
+        assert np.abs(s[nm] - ref[nm]).max() <= 1e-9, nm
+    ref, rinfo = orc.ADMM_MGL(S, 0.05, 0.01, reg, Om0, tol=1e-9, rtol=1e-9, latent=latent, mu1=0.1)
+    (s, info), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, reg, Om0, tol=1e-9, rtol=1e-9, latent=latent, mu1=0.1)
+    assert info['status'] == rinfo['status']
+    assert np.linalg.norm(s['Theta'] - ref['Theta']) <= 1e-8
+
+
+def test_inputs_not_mutated_and_asserts(sol):
+    g = load_golden("g8_g9_admm_mgl")
+    S, Om0 = g["S_GGL"].copy(), g["Omega_0"].copy()
+    S0, O0 = S.copy(), Om0.copy()
+    quiet(sol.ADMM_MGL, S, 0.05, 0.01, 'GGL', Om0, max_iter=3)
+    assert np.array_equal(S, S0) and np.array_equal(Om0, O0)
+    with pytest.raises(AssertionError):
+        sol.ADMM_MGL(S, 0.05, 0.01, 'XYZ', Om0)
+    with pytest.raises(AssertionError):
+        sol.ADMM_MGL(S, 0.05, -1.0, 'GGL', Om0)
+    with pytest.raises(AssertionError):
+        sol.ADMM_MGL(S, 0.05, 0.01, 'GGL', Om0, rho=0.0)
+    with pytest.raises(AssertionError):
+        sol.ADMM_MGL(S, 0.05, 0.01, 'GGL', Om0, latent=True)          # mu1 missing

@@ -1,0 +1,178 @@
+"""Operator-level parity of the gfx950 kernels (through the C ABI) against the golden vectors captured
+from the reference and against the CPU oracle on seeded inputs.  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import ggl_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+EIG_METHODS = [1, 2]   # GGL_EIG_JACOBI, GGL_EIG_ROCSOLVER
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gglasso_amd import ops as o
+    return o
+
+
+def _sym(rng, K, p, scale=1.0):
+    A = rng.standard_normal((K, p, p)) * scale
+    return 0.5 * (A + A.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("method", EIG_METHODS)
+def test_eigh_golden_matrices(ops, method):
+    g = load_golden("g1_g2_eigen_prox")
+    for n in range(0, int(g["count"]), 3):
+        W = g[f"W_{n}"]
+        p = W.shape[0]
+        D, Q = ops.eigh(W, method=method)
+        Dn = np.linalg.eigvalsh(W)
+        scale = max(1.0, np.abs(W).max())
+        assert np.all(np.diff(D) >= 0)
+        assert np.abs(D - Dn).max() <= 1e-12 * scale * p
+        assert np.abs(Q.T @ Q - np.eye(p)).max() <= 1e-12
+        # lower triangle is what counts (numpy.linalg.eigh default)
+        Wl = np.tril(W) + np.tril(W, -1).T
+        assert np.abs((Q * D) @ Q.T - Wl).max() <= 1e-12 * scale * p
+
+
+@pytest.mark.parametrize("method", EIG_METHODS)
+def test_eigh_reads_lower_triangle(ops, method):
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((3, 24, 24))          # NOT symmetric
+    D, Q = ops.eigh(A, method=method)
+    Dn, _ = np.linalg.eigh(A)
+    assert np.abs(D - Dn).max() <= 1e-12 * 24
+
+
+@pytest.mark.parametrize("method", EIG_METHODS)
+def test_g1_g2_phiplus_rank_from_matrix(ops, method):
+    g = load_golden("g1_g2_eigen_prox")
+    for n in range(int(g["count"])):
+        W, beta = g[f"W_{n}"], float(g[f"beta_{n}"])
+        scale = max(1.0, np.abs(W).max())
+        om = ops.phiplus_matrix(W, beta, method=method)
+        assert np.abs(om - g[f"phiplus_{n}"]).max() <= 1e-12 * scale * W.shape[0]
+        assert np.array_equal(om, om.T)
+        lr = ops.rank_matrix(W, beta, method=method)
+        assert np.abs(lr - g[f"rank_{n}"]).max() <= 1e-12 * scale * W.shape[0]
+
+
+def test_g1_g2_phiplus_rank_from_decomposition(ops):
+    g = load_golden("g1_g2_eigen_prox")
+    for n in range(int(g["count"])):
+        W, beta = g[f"W_{n}"], float(g[f"beta_{n}"])
+        D, Q = np.linalg.eigh(W)
+        scale = max(1.0, np.abs(W).max())
+        assert np.abs(ops.phiplus(beta, D, Q) - g[f"phiplus_{n}"]).max() <= 1e-12 * scale
+        assert np.abs(ops.prox_rank_norm(W, beta, D, Q) - g[f"rank_{n}"]).max() <= 1e-12 * scale
+    # no decomposition given: computed on the device (reference ggl_helper.py:31-33)
+    W, beta = g["W_5"], float(g["beta_5"])
+    assert np.abs(ops.prox_rank_norm(W, beta) - g["rank_5"]).max() <= 1e-11
+
+
+@pytest.mark.parametrize("K,p", [(1, 1), (2, 2), (3, 7), (5, 50), (4, 64), (3, 65), (2, 127), (2, 128)])
+def test_phiplus_stack_jacobi_sizes(ops, K, p):
+    rng = np.random.default_rng(100 + p)
+    W = _sym(rng, K, p, 2.0)
+    beta = rng.uniform(0.3, 2.0, K)
+    ref, _ = orc.phiplus_stack(W, beta)
+    out = ops.phiplus_matrix(W, beta, method=1)
+    assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("K,p", [(3, 7), (2, 64), (3, 100), (2, 129), (2, 200), (1, 333)])
+def test_phiplus_stack_rocsolver_mfma_sizes(ops, K, p):
+    rng = np.random.default_rng(200 + p)
+    W = _sym(rng, K, p, 2.0)
+    beta = rng.uniform(0.3, 2.0, K)
+    ref, _ = orc.phiplus_stack(W, beta)
+    out = ops.phiplus_matrix(W, beta, method=2)
+    assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    ref = orc.rank_stack(W, beta)
+    out = ops.rank_matrix(W, beta, method=2)
+    assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_recon_asymmetric_map(ops):
+    """Transpose-detecting check of the MFMA reconstruction: random (non-orthogonal) Q, so
+    Q diag(f) Q^T with swapped operands or a wrong C/D layout cannot pass."""
+    rng = np.random.default_rng(7)
+    for p in (16, 70, 130):
+        Q = rng.standard_normal((2, p, p))
+        D = rng.standard_normal((2, p))
+        beta = np.array([0.7, 1.3])
+        ref = np.stack([orc.phiplus(beta[k], D[k], Q[k]) for k in range(2)])
+        out = ops.phiplus(beta, D, Q)
+        assert np.abs(out - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_g3_prox_od_1norm(ops):
+    g = load_golden("g3_prox_od_1norm")
+    for n in range(int(g["count"])):
+        A, lam, mask = g[f"A_{n}"], float(g[f"lam_{n}"]), g[f"mask_{n}"]
+        assert np.array_equal(ops.prox_od_1norm(A, lam), g[f"scalar_{n}"])
+        assert np.array_equal(ops.prox_od_1norm(A, lam * mask), g[f"masked_{n}"])
+
+
+def test_g4_group_prox(ops):
+    g = load_golden("g4_group_prox")
+    for n in range(int(g["count"])):
+        v, (l1, l2) = g[f"v_{n}"], g[f"l_{n}"]
+        assert np.abs(ops.prox_2norm(v, l2) - g[f"p2_{n}"]).max() <= 1e-15
+        assert np.abs(ops.prox_phi_ggl(v, l1, l2) - g[f"ggl_{n}"]).max() <= 1e-15
+
+
+def test_g5_condat_bit_exact(ops):
+    g = load_golden("g5_condat_tv")
+    for n in range(int(g["count"])):
+        y, lam = g[f"y_{n}"], float(g[f"lam_{n}"])
+        assert np.array_equal(ops.prox_tv(y, lam), g[f"x_{n}"]), n
+        assert np.array_equal(ops.prox_phi_fgl(y, 0.05, lam), g[f"fgl_{n}"]), n
+
+
+def test_condat_batch_vs_oracle(ops):
+    rng = np.random.default_rng(11)
+    for K in (2, 3, 17, 64, 200):
+        Y = np.cumsum(rng.standard_normal((300, K)), axis=1) * 0.2
+        Y[::7] = np.round(Y[::7], 1)
+        for lam in (0.01, 0.3, 3.0):
+            ref = np.stack([orc.condat_method(y, lam) for y in Y])
+            assert np.array_equal(ops.prox_tv(Y, lam), ref)
+
+
+def test_g6_prox_p(ops):
+    g = load_golden("g6_prox_p")
+    for n in range(int(g["count"])):
+        X, (l1, l2) = g[f"X_{n}"], g[f"l_{n}"]
+        for reg, key in (("GGL", "ggl"), ("FGL", "fgl")):
+            out = ops.prox_p(X, l1, l2, reg)
+            assert np.abs(out - g[f"{key}_{n}"]).max() <= 1e-14, (n, reg)
+            assert np.array_equal(out, out.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("K,p", [(1, 5), (2, 31), (3, 32), (4, 33), (20, 70), (33, 40), (50, 45), (7, 130)])
+@pytest.mark.parametrize("reg", ["GGL", "FGL"])
+def test_prox_p_ragged_sizes(ops, K, p, reg):
+    rng = np.random.default_rng(K * 1000 + p)
+    X = _sym(rng, K, p, 0.3)
+    if reg == "FGL":
+        X = np.cumsum(X, axis=0) * 0.5
+    ref = orc.prox_p(X, 0.05, 0.08, reg)
+    out = ops.prox_p(X, 0.05, 0.08, reg)
+    assert np.abs(out - ref).max() <= 1e-14
+    assert np.array_equal(out, out.transpose(0, 2, 1))
+    d = np.arange(p)
+    assert np.array_equal(out[:, d, d], X[:, d, d])
+
+
+def test_prox_p_asserts_like_reference(ops):
+    X = np.zeros((2, 4, 4))
+    X[0, 0, 1] = 1.0
+    with pytest.raises(AssertionError):
+        ops.prox_p(X, 0.1, 0.1, 'GGL')          # not symmetric
+    with pytest.raises(AssertionError):
+        ops.prox_p(np.zeros((2, 4, 4)), 0.0, 0.1, 'GGL')
