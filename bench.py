@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X ADMM hot path: ADMM iterations/second on the Group Graphical Lasso
+workload BASELINE.json quotes the metric on, (K=32, p=500), fp64.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one full ADMM iteration (Omega-step: W formation + batched eigen/phiplus; Theta-step:
+group prox over the (K,p,p) stack; dual update; the five stopping-test norms; rho rule on the host)
+driven by the same host loop ``ADMM_MGL`` uses (gglasso_amd/solver.py::_run_admm) with tol=rtol=1e-20
+so that it cannot exit early.  S, Omega, Theta, X are resident in HBM before the timed region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the K=32 stack is sharded into K/N slabs
+(strong scaling); per iteration one (p,p) fp64 all-reduce of the group sums of squares and one
+5-scalar all-reduce of the residual norms go over RCCL.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the phase that dominates the iteration, timed live with HIP events on the ctx stream
+  cpu_baseline -- the CPU oracle (NumPy/LAPACK + C prox) on this box's host cores, bounded sample
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_MFMA_PEAK_TF = 78.6     # AMD MI355X datasheet, FP64 matrix (= FP64 vector); the guide lists no fp64 row
+
+WORKLOADS = {
+    # name: (reg, K, p, latent, lambda1, lambda2, seed)
+    "ggl_K32_p500": ("GGL", 32, 500, False, 0.05, 0.01, 1239),
+    "ggl_K20_p200": ("GGL", 20, 200, False, 0.05, 0.01, 1236),
+    "fgl_K50_p500_latent": ("FGL", 50, 500, True, 0.05, 0.01, 1237),
+    "ggl_K256_p1000": ("GGL", 256, 1000, False, 0.05, 0.01, 1238),
+}
+
+
+def phase_model(phase, reg, K, p, latent, eig_jacobi):
+    """(bound, algorithmic amount per launch, unit) of one phase.  B = one fp64 stack = 8*K*p^2 bytes.
+    Bytes follow SURVEY.md section 8(d) (compulsory stack passes); flops are LAPACK-equivalent
+    9 p^3 per eigendecomposition and 2 p^3 per reconstruction."""
+    B = 8.0 * K * p * p
+    if phase == "form_W":
+        return "hbm", (5 if latent else 4) * B, "GB/s"
+    if phase in ("eig_omega", "eig_L"):
+        fl = (11.0 if eig_jacobi else 9.0) * K * p ** 3
+        return "mfma", fl, "TFLOP/s"
+    if phase in ("recon_omega", "recon_L"):
+        return "mfma", 2.0 * K * p ** 3, "TFLOP/s"
+    if phase == "theta":
+        return "hbm", (4 if latent else 5) * B, "GB/s"    # latent: Omega,L,X -> Theta ; else Omega,X,Omega_prev -> Theta,X
+    if phase == "dual":
+        return "hbm", 6 * B, "GB/s"
+    return "hbm", 0.0, "GB/s"
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def cpu_baseline(S, reg, lambda1, lambda2, latent, mu1, iters):
+    """CPU oracle (a port: NumPy eigh + C prox), bounded sample of the same workload."""
+    from oracle import ggl_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    except Exception:  # noqa: BLE001
+        threads = os.cpu_count() or 1
+    K, p, _ = S.shape
+    Om0 = np.repeat(np.eye(p)[None], K, axis=0)
+    orc.ADMM_MGL(S, lambda1, lambda2, reg, Om0, max_iter=1, tol=1e-20, rtol=1e-20, latent=latent, mu1=mu1)
+    t0 = time.perf_counter()
+    orc.ADMM_MGL(S, lambda1, lambda2, reg, Om0, max_iter=iters, tol=1e-20, rtol=1e-20, latent=latent, mu1=mu1)
+    dt = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "ADMM iters/s", "cores": int(threads), "kind": "port",
+            "sample": f"{iters} ADMM iterations of the same ({reg}, K={K}, p={p}) problem from the identity start "
+                      f"(oracle/ggl_oracle.py: numpy.linalg.eigh + C prox_p), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="ggl_K32_p500", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eig", type=int, default=0, help="GGL_EIG_* selector (0 auto)")
+    args = ap.parse_args()
+
+    import torch
+    from gglasso_amd import synth, solver, _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GGL_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (1-GPU dev boxes)
+    distributed = world > 1 or bool(os.environ.get("GGL_BENCH_FORCE_DIST"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if distributed:
+        import torch.distributed as dist
+        from gglasso_amd.dist import TorchComm, shard_bounds
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        comm = TorchComm(device=f"cuda:{local_rank}")
+
+    reg, K, p, latent, l1, l2, seed = WORKLOADS[args.workload]
+    S, _ = synth.make_problem(reg, K, p, N=2 * p, seed=seed)
+    mu1 = 0.5 * np.ones(K) if latent else None
+    if distributed:
+        assert reg == "GGL" and not latent, "only GGL shards across K; other workloads run as replicas"
+        k0, k1 = shard_bounds(K, world, rank)
+        S_loc = np.ascontiguousarray(S[k0:k1])
+    else:
+        k0, k1, S_loc = 0, K, S
+    Kl = k1 - k0
+    Om0 = np.repeat(np.eye(p)[None], Kl, axis=0)
+    stream = torch.cuda.current_stream().cuda_stream if distributed else None
+    eng = solver.HipEngine(S_loc, Om0, Om0, np.zeros_like(S_loc), eig=args.eig, device=local_rank, stream=stream)
+    nk = np.ones(Kl)
+    mu_loc = None if mu1 is None else mu1[k0:k1]
+
+    def run(iters, rho):
+        info, rho = quiet(solver._run_admm, eng, reg, K, p, l1, l2, latent, mu_loc, nk, rho, 1e-20, 1e-20, 'boyd',
+                          True, iters, False, False, "Multiple", comm=comm)
+        return rho
+
+    def fence():
+        if distributed:
+            torch.distributed.barrier()
+        eng.sync()
+        torch.cuda.synchronize()
+
+    rho = 1.0
+    if args.warmup > 0:
+        rho = run(args.warmup, rho)
+    eng.profile(True)
+    eng.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    rho = run(args.steps, rho)
+    fence()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = eng.profile_read(reset=True)
+    eng.close()
+
+    if rank == 0:
+        eig_jacobi = (args.eig == _lib.EIG_JACOBI) or (args.eig == _lib.EIG_AUTO and p <= _lib.JACOBI_MAX_P)
+        phases = {ph: {"ms_per_launch": ms / cnt, "launches": cnt} for ph, (ms, cnt) in prof.items() if cnt}
+        dom = max(phases, key=lambda ph: phases[ph]["ms_per_launch"] * phases[ph]["launches"])
+        bound, amount, unit = phase_model(dom, reg, Kl, p, latent, eig_jacobi)
+        sec = phases[dom]["ms_per_launch"] * 1e-3
+        if bound == "hbm":
+            achieved, peak = amount / sec / 1e9, HBM_PEAK_GBS
+        else:
+            achieved, peak = amount / sec / 1e12, FP64_MFMA_PEAK_TF
+        its = args.steps / dt
+        iter_bytes = (120.0 if latent else 72.0) * Kl * p * p          # SURVEY.md 8(d), per GPU
+        out = {
+            "metric": "ADMM iters/sec on (K=32,p=500) GGL at 1/2/4/8 GPUs; eigh HBM GB/s vs peak", "value": its, "unit": "ADMM iters/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{reg} K={K} p={p} lambda1={l1} lambda2={l2} latent={latent}, identity start, "
+                                   f"rho0=1 update_rho, fixed iteration count",
+                       "sharding": f"K-slabs of {Kl} per GPU" if distributed else "single GPU",
+                       "eigensolver": "lds_jacobi" if eig_jacobi else "rocsolver_dsyevd+mfma_recon"},
+            "roofline": {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": None,
+                         "ms_per_launch": phases[dom]["ms_per_launch"]},
+            "iteration_hbm_roofline": {"algorithmic_bytes": iter_bytes, "achieved_GBs": its * iter_bytes / 1e9,
+                                       "frac": its * iter_bytes / 1e9 / HBM_PEAK_GBS},
+            "phases_ms": {ph: round(v["ms_per_launch"], 4) for ph, v in phases.items()},
+        }
+        if not distributed and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S, reg, l1, l2, latent, mu1, args.cpu_iters)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,7 @@ EIG_AUTO, EIG_JACOBI, EIG_ROCSOLVER = 0, 1, 2
 JACOBI_MAX_P = 128
 BUF_S, BUF_OMEGA, BUF_THETA, BUF_L, BUF_X, BUF_GROUPSQ, BUF_NORMS, BUF_OMEGA_PREV = range(8)
 E_ARG, E_HIP, E_SOLVER, E_ALLOC = -1, -2, -3, -4
+PHASES = ("form_W", "eig_omega", "recon_omega", "theta", "eig_L", "recon_L", "dual", "reduce")
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _vp = ctypes.c_void_p
@@ -40,6 +41,8 @@ _SIGNATURES = {
     "ggl_exit_checks": ([_vp, _i, _dp], _i),
     "ggl_objective": ([_vp, _d, _d, _i, _dp], _i),
     "ggl_kkt_residual": ([_vp, _d, _d, _d, _i, _i, _dp, _dp, _dp], _i),
+    "ggl_profile_enable": ([_vp, _i], _i),
+    "ggl_profile_read": ([_vp, _dp, ctypes.POINTER(ctypes.c_longlong), _i], _i),
     "ggl_eigh_batched": ([_i, _i, _dp, _dp, _dp, _i], _i),
     "ggl_phiplus": ([_i, _i, _dp, _dp, _dp, _dp], _i),
     "ggl_prox_rank_norm": ([_i, _i, _dp, _dp, _dp, _dp], _i),

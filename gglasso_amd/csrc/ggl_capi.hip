@@ -60,7 +60,30 @@ struct ggl_ctx {
     double *norms = nullptr, *norms_h = nullptr;  // (K,8) device / pinned
     int* info_h = nullptr;                        // pinned (K)
     bool nk_valid = false;
+    // per-phase HIP-event timing
+    bool prof_on = false;
+    hipEvent_t ev[GGL_NPHASE][2] = {};
+    bool ev_used[GGL_NPHASE] = {};
+    double ph_ms[GGL_NPHASE] = {};
+    long long ph_cnt[GGL_NPHASE] = {};
 };
+
+#define PB(c, ph) do { if ((c)->prof_on) (void)hipEventRecord((c)->ev[ph][0], (c)->stream); } while (0)
+#define PE(c, ph) do { if ((c)->prof_on) { (void)hipEventRecord((c)->ev[ph][1], (c)->stream); (c)->ev_used[ph] = true; } } while (0)
+
+static void prof_collect(ggl_ctx* c)   // call after a stream sync
+{
+    if (!c->prof_on) return;
+    for (int ph = 0; ph < GGL_NPHASE; ++ph) {
+        if (!c->ev_used[ph]) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[ph][0], c->ev[ph][1]) == hipSuccess) {
+            c->ph_ms[ph] += ms;
+            c->ph_cnt[ph] += 1;
+        }
+        c->ev_used[ph] = false;
+    }
+}
 
 static bool use_jacobi(const ggl_ctx* c)
 {
@@ -167,6 +190,9 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->par_h) (void)hipHostFree(c->par_h);
     if (c->norms_h) (void)hipHostFree(c->norms_h);
     if (c->info_h) (void)hipHostFree(c->info_h);
+    for (int ph = 0; ph < GGL_NPHASE; ++ph)
+        for (int e = 0; e < 2; ++e)
+            if (c->ev[ph][e]) (void)hipEventDestroy(c->ev[ph][e]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GGL_OK;
@@ -250,12 +276,16 @@ extern "C" int ggl_set_lambda1_mask(ggl_ctx* c, const double* lam)
 // eigen-decomposition + eigenvalue map + reconstruction of a device stack (in: A, destroyed when
 // the rocSOLVER path is taken; out may alias nothing).  Dv receives the eigenvalues.
 // ---------------------------------------------------------------------------------------------
-static int eig_recon(ggl_ctx* c, double* A, double* out, double* Dv, int map, const double* betaK)
+static int eig_recon(ggl_ctx* c, double* A, double* out, double* Dv, int map, const double* betaK, int ph_eig = -1,
+                     int ph_recon = -1)
 {
     if (use_jacobi(c)) {
+        if (ph_eig >= 0) PB(c, ph_eig);
         HIPCHK(launch_jacobi(c->stream, A, Dv, nullptr, out, map, betaK, c->info, c->K, c->p));
+        if (ph_eig >= 0) PE(c, ph_eig);
         return GGL_OK;
     }
+    if (ph_eig >= 0) PB(c, ph_eig);
     // row-major symmetric == column-major symmetric; the row-major LOWER triangle (what numpy's
     // eigh reads) is the column-major UPPER one.  Eigenvectors come back in column-major columns
     // == row-major ROWS, the layout launch_recon wants.
@@ -263,7 +293,10 @@ static int eig_recon(ggl_ctx* c, double* A, double* out, double* Dv, int map, co
                                                          c->p, (rocblas_stride)c->p * c->p, Dv, c->p, c->E, c->p,
                                                          c->info, c->K);
     if (st != rocblas_status_success) return fail(GGL_E_SOLVER, "rocsolver_dsyevd_strided_batched: status %d", (int)st);
+    if (ph_eig >= 0) PE(c, ph_eig);
+    if (ph_recon >= 0) PB(c, ph_recon);
     launch_recon(c->stream, out, A, Dv, betaK, map, c->K, c->p, c->scale);
+    if (ph_recon >= 0) PE(c, ph_recon);
     HIPCHK(hipGetLastError());
     return GGL_OK;
 }
@@ -313,10 +346,12 @@ extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* 
     int rc = upload_par(c, 0, nk, 1.0, rho);   // beta_k = nk/rho    (admm_solver.py:180,184)
     if (rc) return rc;
     const double* beta = c->par;
+    PB(c, GGL_PH_FORM_W);
     launch_form_W(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->K, c->p);
+    PE(c, GGL_PH_FORM_W);
     HIPCHK(hipGetLastError());
     const int nxt = c->cur ^ 1;
-    rc = eig_recon(c, c->W, c->Om[nxt], c->DvO, MAP_PHIPLUS, beta);
+    rc = eig_recon(c, c->W, c->Om[nxt], c->DvO, MAP_PHIPLUS, beta, GGL_PH_EIG_OMEGA, GGL_PH_RECON_OMEGA);
     if (rc) return rc;
     c->cur = nxt;
     return GGL_OK;
@@ -338,6 +373,7 @@ static int finish_norms(ggl_ctx* c, int rows, double out_norms[5])
                           c->stream));
     HIPCHK(hipMemcpyAsync(c->info_h, c->info, c->K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
     int rc = check_info(c, "ADMM step");
     if (rc) return rc;
     for (int v = 0; v < GGL_NNORM; ++v) {
@@ -365,29 +401,41 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
     if (reg == GGL_REG_SGL) {
         int rc = upload_par(c, 1, nullptr, l1, 1.0);
         if (rc) return rc;
+        PB(c, GGL_PH_THETA);
         launch_theta_sgl(c->stream, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, c->par + c->K,
                          c->has_mask ? c->mask : nullptr, inv_rho, latent, c->partials, c->K, c->p);
+        PE(c, GGL_PH_THETA);
         HIPCHK(hipGetLastError());
         if (!latent) {
+            PB(c, GGL_PH_REDUCE);
             launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), GGL_NNORM, c->norms);
+            PE(c, GGL_PH_REDUCE);
             rows = c->K;
         }
     } else {
         ARGCHK(lambda1 > 0 && lambda2 > 0, "lambda1, lambda2 must be positive");
+        PB(c, GGL_PH_THETA);
         HIPCHK(launch_theta_pair(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, l1, l2,
                                  groupsq_ready ? c->groupsq : nullptr, latent ? 0 : 1, c->partials, c->K, c->p));
+        PE(c, GGL_PH_THETA);
         if (!latent) {
+            PB(c, GGL_PH_REDUCE);
             launch_reduce_partials(c->stream, c->partials, 1, pair_blocks(c->p, reg, c->K), GGL_NNORM, c->norms);
+            PE(c, GGL_PH_REDUCE);
             rows = 1;
         }
     }
     if (latent) {
         int rc = upload_par(c, 2, mu1, 0.0, rho);   // mu1_k / rho   (admm_solver.py:202)
         if (rc) return rc;
-        rc = eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)c->K);
+        rc = eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)c->K, GGL_PH_EIG_L, GGL_PH_RECON_L);
         if (rc) return rc;
+        PB(c, GGL_PH_DUAL);
         launch_dual_update(c->stream, c->X, Om, OmPrev, c->Theta, c->L, c->partials, c->K, c->p);
+        PE(c, GGL_PH_DUAL);
+        PB(c, GGL_PH_REDUCE);
         launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), GGL_NNORM, c->norms);
+        PE(c, GGL_PH_REDUCE);
         rows = c->K;
     }
     HIPCHK(hipGetLastError());
@@ -408,6 +456,29 @@ extern "C" int ggl_scale_X(ggl_ctx* c, double factor)
     HIPCHK(hipSetDevice(c->device));
     launch_scale(c->stream, c->X, factor, c->n);
     HIPCHK(hipGetLastError());
+    return GGL_OK;
+}
+
+extern "C" int ggl_profile_enable(ggl_ctx* c, int on)
+{
+    ARGCHK(c, "ctx");
+    HIPCHK(hipSetDevice(c->device));
+    if (on && !c->ev[0][0]) {
+        for (int ph = 0; ph < GGL_NPHASE; ++ph)
+            for (int e = 0; e < 2; ++e) HIPCHK(hipEventCreate(&c->ev[ph][e]));
+    }
+    c->prof_on = (on != 0);
+    return GGL_OK;
+}
+
+extern "C" int ggl_profile_read(ggl_ctx* c, double ms[GGL_NPHASE], long long count[GGL_NPHASE], int reset)
+{
+    ARGCHK(c && ms && count, "ctx, ms, count");
+    for (int ph = 0; ph < GGL_NPHASE; ++ph) {
+        ms[ph] = c->ph_ms[ph];
+        count[ph] = c->ph_cnt[ph];
+        if (reset) { c->ph_ms[ph] = 0.0; c->ph_cnt[ph] = 0; }
+    }
     return GGL_OK;
 }
 

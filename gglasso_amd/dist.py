@@ -1,0 +1,123 @@
+"""Multi-GPU execution: one process per GPU (torch.distributed; backend "nccl" == RCCL over xGMI).
+
+What shards and what does not:
+  * Omega-step / L-step (eigendecompositions): independent per instance k -> contiguous K-slabs.
+  * GGL Theta-step: the group norm |u[:,i,j]|_2 runs over ALL K (solver/ggl_helper.py:38-43), so a
+    K-sharded run needs one exchange per iteration: every rank soft-thresholds its slab, accumulates
+    sum_k u^2 into a (p,p) buffer, the buffers are all-reduced (8*p*p bytes; 2 MB at p=500), and every
+    rank scales its own slab.  This is the only data-path collective.
+  * stopping test: the five squared norms are all-reduced (40 bytes) before the host takes the sqrt.
+  * FGL Theta-step: Condat's scan is sequential along K (solver/fgl_helper.py:24-66) -> no K-sharding;
+    FGL scales through independent replicas (model-selection grid points), see ``shard_grid``.
+
+The reference has no distributed code at all; there is nothing to translate.
+"""
+import numpy as np
+
+from . import _lib
+from .solver import _run_admm, _exit_report, as_c
+from . import solver as _solver
+
+
+def shard_bounds(K, world, rank):
+    """Contiguous, balanced K-slab [k0, k1) of ``rank``."""
+    base, rem = divmod(K, world)
+    k0 = rank * base + min(rank, rem)
+    return k0, k0 + base + (1 if rank < rem else 0)
+
+
+def shard_grid(n_points, world, rank):
+    """Indices of the model-selection grid points (independent solves) owned by ``rank``:
+    round-robin, so every rank gets a mix of cheap (large lambda) and expensive (small lambda) points."""
+    return list(range(rank, n_points, world))
+
+
+class _DeviceView:
+    """Exposes a raw device pointer to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class TorchComm:
+    """All-reduces over a torch.distributed process group.  With the nccl backend the tensors stay in
+    HBM and the collective is RCCL; with gloo (CPU tests) they are host tensors."""
+
+    def __init__(self, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.backend = dist.get_backend(group)
+        self.device = device
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._gs = None
+        self._nrm = None
+
+    def allreduce_groupsq(self, eng):
+        if self._gs is None:
+            self._gs = eng.groupsq_tensor(self.torch, self.device)
+        self.dist.all_reduce(self._gs, op=self.dist.ReduceOp.SUM, group=self.group)
+        eng.groupsq_written(self._gs)
+
+    def allreduce_norms(self, arr):
+        t = self.torch.as_tensor(np.asarray(arr, dtype=np.float64))
+        if self.backend == "nccl":
+            t = t.to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+
+def _hip_groupsq_tensor(self, torch, device):
+    ptr = self.device_ptr(_lib.BUF_GROUPSQ)
+    return torch.as_tensor(_DeviceView(ptr, (self.p, self.p)), device=device)
+
+
+def _hip_groupsq_written(self, t):
+    pass    # the tensor aliases the ctx buffer; same stream => already ordered
+
+
+_solver.HipEngine.groupsq_tensor = _hip_groupsq_tensor
+_solver.HipEngine.groupsq_written = _hip_groupsq_written
+
+
+def ADMM_MGL_sharded(S_local, lambda1, lambda2, reg, Omega_0, K_total, comm, Theta_0=np.array([]),
+                     X_0=np.array([]), n_samples=None, tol=1e-5, rtol=1e-4, update_rho=True, rho=1.,
+                     max_iter=1000, verbose=False, measure=False, device=0, engine_kwargs=None):
+    """K-sharded Group Graphical Lasso: this rank owns the slab ``S_local`` (K_local,p,p) of a problem
+    with ``K_total`` instances; arguments otherwise as ADMM_MGL (solver/admm_solver.py:13-31).  Every
+    rank executes the same host loop and sees the same residuals, so the rho updates and the stopping
+    decision agree without any further communication.  Returns this rank's slab of the solution."""
+    assert reg == 'GGL', "only the GGL penalty shards across K (FGL scans along K; use grid sharding)"
+    assert Omega_0.shape == S_local.shape
+    assert min(lambda1, lambda2) > 0
+    assert rho > 0
+    Kl, p, _ = S_local.shape
+    if n_samples is None:
+        nk = np.ones(Kl)
+    elif isinstance(n_samples, (int, np.integer)):
+        nk = float(n_samples) * np.ones(Kl)
+    else:
+        nk = as_c(n_samples).reshape(-1)
+        assert len(nk) == Kl
+    if len(Theta_0) == 0:
+        Theta_0 = Omega_0
+    if len(X_0) == 0:
+        X_0 = np.zeros((Kl, p, p))
+    kw = dict(engine_kwargs or {})
+    if comm.backend == "nccl":
+        # run the ctx on torch's current stream: RCCL orders itself against that stream, so the
+        # all-reduce needs no host synchronisation on either side
+        kw.setdefault("stream", comm.torch.cuda.current_stream().cuda_stream)
+        kw.setdefault("device", device)
+    eng = _solver.ENGINE(S_local, Omega_0, Theta_0, X_0, **kw)
+    try:
+        info, _ = _run_admm(eng, reg, K_total, p, float(lambda1), float(lambda2), False, None, nk, float(rho),
+                            tol, rtol, 'boyd', update_rho, max_iter, verbose and comm.rank == 0, measure,
+                            "Multiple", comm=comm, want_objective=False)
+        _exit_report(eng, False, 1e-5, False)
+        sol = eng.state()
+    finally:
+        eng.close()
+    return sol, info

@@ -81,6 +81,17 @@ class HipEngine:
         check(self.lib.ggl_get_state(self.h, ptr(Om), ptr(Th), ptr(L), ptr(X)))
         return {'Omega': Om, 'Theta': Th, 'L': L, 'X': X}
 
+    def profile(self, on=True):
+        check(self.lib.ggl_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset=True):
+        """{phase: (total_ms, launches)} measured with HIP events on the ctx stream."""
+        import ctypes
+        ms = np.zeros(len(_lib.PHASES))
+        cnt = (ctypes.c_longlong * len(_lib.PHASES))()
+        check(self.lib.ggl_profile_read(self.h, ptr(ms), cnt, int(reset)))
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.PHASES)}
+
     def device_ptr(self, which):
         return self.lib.ggl_device_ptr(self.h, which)
 

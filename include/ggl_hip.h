@@ -117,6 +117,20 @@ int ggl_objective(ggl_ctx *ctx, double lambda1, double lambda2, int reg, double 
 int ggl_kkt_residual(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int reg, int latent,
                      const double *mu1, const double *nk, double *out);
 
+/* ---- per-phase device timing (HIP events on the ctx stream; what bench.py's roofline uses) ------
+ * Phases of one iteration; ms[] accumulates elapsed milliseconds, count[] the number of launches. */
+#define GGL_PH_FORM_W 0       /* W = Theta - L - X - (nk/rho) S                                  */
+#define GGL_PH_EIG_OMEGA 1    /* eigensolver of the Omega-step (LDS Jacobi: includes phiplus)     */
+#define GGL_PH_RECON_OMEGA 2  /* Q phip(D) Q^T reconstruction (FP64 MFMA)                          */
+#define GGL_PH_THETA 3        /* Theta-step (+ fused dual update and norms when not latent)       */
+#define GGL_PH_EIG_L 4        /* eigensolver of the L-step                                        */
+#define GGL_PH_RECON_L 5      /* Q max(D-mu,0) Q^T                                                 */
+#define GGL_PH_DUAL 6         /* X += Omega - Theta + L and norms (latent path)                   */
+#define GGL_PH_REDUCE 7       /* partial-sum reduction of the norms                                */
+#define GGL_NPHASE 8
+int ggl_profile_enable(ggl_ctx *ctx, int on);
+int ggl_profile_read(ggl_ctx *ctx, double ms[GGL_NPHASE], long long count[GGL_NPHASE], int reset);
+
 /* ---- stateless operator entry points (host buffers; used for operator-level parity) ---------- */
 /* numpy.linalg.eigh on a stack (lower triangle read); D (K,p) ascending, Q (K,p,p) columns. */
 int ggl_eigh_batched(int K, int p, const double *A, double *D, double *Q, int eig_method);

@@ -1,0 +1,97 @@
+"""TEST-ONLY stand-in for gglasso_amd.solver.HipEngine built on the CPU oracle, so that the host
+logic (control flow of the ADMM loop, K-sharding, collectives) can be exercised without a GPU.
+It lives under tests/ and is never importable from the product package."""
+import numpy as np
+
+from oracle import ggl_oracle as orc
+
+
+class OracleEngine:
+    def __init__(self, S, Omega_0, Theta_0, X_0, L_0=None, **_ignored):
+        self.S = np.array(S, dtype=np.float64)
+        self.K, self.p, _ = self.S.shape
+        self.Om = np.array(Omega_0, dtype=np.float64)
+        self.Om_prev = np.zeros_like(self.Om)
+        self.Th = np.array(Theta_0, dtype=np.float64)
+        self.X = np.array(X_0, dtype=np.float64)
+        self.L = np.zeros_like(self.S) if L_0 is None else np.array(L_0, dtype=np.float64)
+        self.groupsq = np.zeros((self.p, self.p))
+        self.mask = None
+        self.D = None
+        self.beta = None
+
+    def set_lambda1_mask(self, lam_pp):
+        self.mask = lam_pp
+
+    def step_omega(self, rho, latent, nk):
+        nk = np.ones(self.K) if nk is None else np.asarray(nk, dtype=np.float64)
+        W = self.Th - self.L - self.X - (nk[:, None, None] / rho) * self.S
+        self.Om_prev = self.Om
+        self.beta = nk / rho
+        self.Om, self.D = orc.phiplus_stack(W, self.beta)
+
+    def step_group_partial(self, rho, lambda1):
+        U = orc.prox_1norm(self.Om + self.L + self.X, (1 / rho) * lambda1)
+        self.groupsq[...] = np.triu((U * U).sum(axis=0), 1)
+
+    def step_finish(self, rho, lambda1, lambda2, reg, latent, mu1, groupsq_ready):
+        V = self.Om + self.L + self.X
+        l1, l2 = (1 / rho) * lambda1, (1 / rho) * lambda2
+        if reg == 'SGL':
+            lam = l1 if self.mask is None else (1 / rho) * self.mask
+            self.Th = np.stack([orc.prox_od_1norm(V[k], lam) for k in range(self.K)])
+        elif reg == 'GGL' and groupsq_ready:
+            U = orc.prox_1norm(V, l1)
+            a = np.maximum(np.sqrt(self.groupsq + self.groupsq.T), l2)
+            Th = U * ((a - l2) / a)
+            Th = np.triu(Th, 1)
+            Th = Th + Th.transpose(0, 2, 1)
+            d = np.arange(self.p)
+            Th[:, d, d] = V[:, d, d]
+            self.Th = Th
+        else:
+            self.Th = orc.prox_p(V, l1, l2, reg)
+        if latent:
+            self.L = orc.rank_stack(self.Th - self.X - self.Om, np.asarray(mu1) / rho)
+        self.X = self.X + self.Om - self.Th + self.L
+        return np.array([np.sum(self.Om ** 2), np.sum((self.Th - self.L) ** 2), np.sum(self.X ** 2),
+                         np.sum((self.Om - self.Th + self.L) ** 2), np.sum((self.Om - self.Om_prev) ** 2)])
+
+    def step(self, rho, lambda1, lambda2, reg, latent, mu1, nk):
+        self.step_omega(rho, latent, nk)
+        return self.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 0)
+
+    def scale_X(self, f):
+        self.X = f * self.X
+
+    def objective(self, lambda1, lambda2, reg):
+        ld = -np.log(orc.phip(self.D, self.beta[:, None])).sum()
+        return np.array([ld, np.sum(self.Om * self.S), orc.P_val(self.Th, lambda1, lambda2, reg)])
+
+    def kkt_residual(self, rho, lambda1, lambda2, reg, latent, mu1, nk):
+        if reg == 'SGL':
+            lam = lambda1 if self.mask is None else self.mask
+            return orc.kkt_stopping_criterion_sgl(self.Om[0], self.Th[0], self.L[0], rho * self.X[0], self.S[0], lam,
+                                                  latent, None if mu1 is None else mu1[0])
+        return orc.kkt_stopping_criterion_mgl(self.Om, self.Th, self.L, rho * self.X, self.S, lambda1, lambda2,
+                                              np.asarray(nk).reshape(-1, 1, 1), reg, latent, mu1)
+
+    def exit_checks(self, latent):
+        t = lambda A: np.abs(A - A.transpose(0, 2, 1)).max()
+        return np.array([t(self.Om), t(self.Th), t(self.L), np.linalg.eigvalsh(self.Th - self.L).min(),
+                         np.linalg.eigvalsh(self.L).min() if latent else 0.0])
+
+    def state(self):
+        return {'Omega': self.Om.copy(), 'Theta': self.Th.copy(), 'L': self.L.copy(), 'X': self.X.copy()}
+
+    def groupsq_tensor(self, torch, device):
+        return torch.from_numpy(self.groupsq)      # shares memory with self.groupsq
+
+    def groupsq_written(self, t):
+        pass
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass

@@ -1,0 +1,161 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/ggl_hip.h declares, the ctypes table matches the header, the product path refuses to run
+without a GPU (no silent fallback), and the host loop reproduces the reference control flow when
+driven by a test-only oracle engine."""
+import contextlib
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, ROOT
+from oracle import ggl_oracle as orc
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ggl_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ggl_[A-Za-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from gglasso_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    import ctypes
+    names = _declared_symbols()
+    assert len(names) >= 25
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(so, n), f"{n} declared in include/ggl_hip.h but not exported"
+    assert sorted(lib.EXPORTS) == names, "ctypes signature table out of sync with the header"
+    assert lib.load().ggl_version() == 100
+
+
+def test_header_constants_match_python(lib):
+    txt = open(os.path.join(ROOT, "include", "ggl_hip.h")).read()
+    consts = dict(re.findall(r"#define\s+(GGL_[A-Z0-9_]+)\s+\(?(-?\d+)\)?", txt))
+    assert int(consts["GGL_REG_GGL"]) == lib.REG_GGL and int(consts["GGL_REG_FGL"]) == lib.REG_FGL
+    assert int(consts["GGL_EIG_JACOBI"]) == lib.EIG_JACOBI and int(consts["GGL_EIG_ROCSOLVER"]) == lib.EIG_ROCSOLVER
+    assert int(consts["GGL_JACOBI_MAX_P"]) == lib.JACOBI_MAX_P
+    assert int(consts["GGL_BUF_GROUPSQ"]) == lib.BUF_GROUPSQ
+    assert int(consts["GGL_NPHASE"]) == len(lib.PHASES)
+    assert int(consts["GGL_E_ARG"]) == lib.E_ARG
+
+
+def _has_gpu(lib):
+    return lib.load().ggl_device_count() > 0
+
+
+def test_product_path_fails_loudly_without_gpu(lib):
+    if _has_gpu(lib):
+        pytest.skip("GPU present")
+    from gglasso_amd import solver, ops
+    S = np.stack([np.eye(4)] * 2)
+    with pytest.raises(RuntimeError, match="needs an AMD GPU"):
+        solver.ADMM_MGL(S, 0.1, 0.1, 'GGL', S.copy())
+    with pytest.raises(RuntimeError, match="needs an AMD GPU"):
+        ops.prox_p(S, 0.1, 0.1, 'GGL')
+    with pytest.raises(RuntimeError, match="needs an AMD GPU"):
+        ops.eigh(np.eye(3))
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "gglasso_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "from oracle" not in src and "import oracle" not in src and "ggl_oracle" not in src, f
+
+
+def test_argument_asserts_happen_before_any_device_work(lib):
+    from gglasso_amd import solver
+    S = np.stack([np.eye(4)] * 2)
+    with pytest.raises(AssertionError):
+        solver.ADMM_MGL(S, 0.1, 0.1, 'XXX', S.copy())
+    with pytest.raises(AssertionError):
+        solver.ADMM_MGL(S, 0.1, 0.0, 'GGL', S.copy())
+    with pytest.raises(AssertionError):
+        solver.ADMM_MGL(S, 0.1, 0.1, 'GGL', S[:1].copy())
+    with pytest.raises(AssertionError):
+        solver.ADMM_SGL(np.eye(4), -1.0, np.eye(4))
+    with pytest.raises(AssertionError):
+        solver.ADMM_SGL(np.eye(4), 0.1, np.eye(4), lambda1_mask=np.ones((3, 3)))
+    with pytest.raises(AssertionError):
+        solver.ADMM_SGL(np.eye(4), 0.1, np.eye(4), latent=True)
+
+
+@pytest.fixture()
+def oracle_engine(monkeypatch):
+    from gglasso_amd import solver
+    from oracle_engine import OracleEngine
+    monkeypatch.setattr(solver, "ENGINE", OracleEngine)
+    return solver
+
+
+def _quiet(fn, *a, **k):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = fn(*a, **k)
+    return out, buf.getvalue()
+
+
+@pytest.mark.parametrize("reg", ["GGL", "FGL"])
+@pytest.mark.parametrize("latent", [False, True])
+def test_host_loop_control_flow_matches_reference(oracle_engine, reg, latent):
+    """Host loop (rho rule, dim*eps stopping rule, status strings, info arrays, final print) pinned by
+    the reference trajectories G8/G9 -- the array work is done by the test-only oracle engine."""
+    g = load_golden("g8_g9_admm_mgl")
+    S, Om0 = g[f"S_{reg}"], g["Omega_0"]
+    l1, l2, mu1 = g["params"]
+    tag = f"{reg}_{'lat' if latent else 'nol'}"
+    (sol, info), out = _quiet(oracle_engine.ADMM_MGL, S, l1, l2, reg, Om0, max_iter=10, tol=1e-20, rtol=1e-20,
+                              latent=latent, mu1=float(mu1), measure=True)
+    for nm in ('Omega', 'Theta', 'L', 'X'):
+        assert np.abs(sol[nm] - g[f"{tag}_it10_{nm}"]).max() <= 1e-10
+    assert np.allclose(info['residual'], g[f"{tag}_it10_residual"], rtol=1e-8)
+    assert np.allclose(info['objective'], g[f"{tag}_it10_objective"], rtol=1e-10)
+    assert sorted(info) == ['objective', 'residual', 'runtime', 'status']
+    assert "ADMM terminated after 10 iterations with status: max iterations reached." in out
+    (sol, info), out = _quiet(oracle_engine.ADMM_MGL, S, l1, l2, reg, Om0, tol=1e-10, rtol=1e-10, latent=latent,
+                              mu1=float(mu1), verbose=True)
+    assert info == {'status': str(g[f"{tag}_conv_status"])}
+    assert np.linalg.norm(sol['Theta'] - g[f"{tag}_conv_Theta"]) <= 1e-8
+    assert out.count("\n") >= int(g[f"{tag}_conv_iters"]) + 2     # header + one line per iteration + final
+
+
+def test_host_loop_sgl_and_kkt(oracle_engine):
+    g = load_golden("g10_admm_sgl")
+    S, mask = g["S"], g["mask"]
+    p = S.shape[0]
+    (sol, info), _ = _quiet(oracle_engine.ADMM_SGL, S, 0.05, np.eye(p), max_iter=10, tol=1e-20, rtol=1e-20,
+                            lambda1_mask=mask, measure=True)
+    assert sorted(sol) == ['Omega', 'Theta', 'X']
+    for nm in sol:
+        assert np.abs(sol[nm] - g[f"mask_it10_{nm}"]).max() <= 1e-10
+    assert sorted(info) == ['residual', 'runtime', 'status']
+    g2 = load_golden("g8_g9_admm_mgl")
+    l1, l2, _ = g2["params"]
+    (sol, info), _ = _quiet(oracle_engine.ADMM_MGL, g2["S_GGL"], l1, l2, 'GGL', g2["Omega_0"], tol=1e-6,
+                            stopping_criterion='kkt', measure=True)
+    assert len(info['residual']) == int(g2["kkt_run_iters"])
+
+
+def test_synth_generator_properties():
+    from gglasso_amd import synth
+    for reg in ("GGL", "FGL"):
+        S, Th = synth.make_problem(reg, 4, 40, seed=5)
+        S2, _ = synth.make_problem(reg, 4, 40, seed=5)
+        assert np.array_equal(S, S2)
+        assert np.array_equal(S, S.transpose(0, 2, 1))
+        assert np.linalg.eigvalsh(S).min() > 0
+        assert np.linalg.eigvalsh(Th).min() > 0
+        assert (np.abs(Th) > 0).mean() < 0.2

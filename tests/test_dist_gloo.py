@@ -1,0 +1,80 @@
+"""world_size-2 gloo test of the K-sharded GGL driver (gglasso_amd/dist.py): two CPU processes, each
+owning a K-slab, exchange the (p,p) group sums of squares and the 5 residual norms; the result must
+equal the single-process solve.  Array work: test-only oracle engine (no GPU here)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, K, p, out_dir):
+    import contextlib
+    import io
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gglasso_amd import solver, synth
+    from gglasso_amd.dist import ADMM_MGL_sharded, TorchComm, shard_bounds
+    from oracle_engine import OracleEngine
+    solver.ENGINE = OracleEngine
+    S, _ = synth.make_problem("GGL", K, p, seed=21)
+    k0, k1 = shard_bounds(K, world, rank)
+    Om0 = np.repeat(np.eye(p)[None], k1 - k0, axis=0)
+    comm = TorchComm()
+    with contextlib.redirect_stdout(io.StringIO()):
+        sol, info = ADMM_MGL_sharded(S[k0:k1], 0.05, 0.02, "GGL", Om0, K, comm, tol=1e-9, rtol=1e-9, measure=True)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), k0=k0, k1=k1, status=info["status"],
+             iters=len(info["residual"]), **sol)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K,world", [(5, 2), (4, 2)])
+def test_k_sharded_ggl_equals_single_process(tmp_path, K, world):
+    import torch.multiprocessing as mp
+    from oracle import ggl_oracle as orc
+    from gglasso_amd import synth
+    p = 24
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, K, p, str(tmp_path)), nprocs=world, join=True)
+    S, _ = synth.make_problem("GGL", K, p, seed=21)
+    Om0 = np.repeat(np.eye(p)[None], K, axis=0)
+    ref, rinfo = orc.ADMM_MGL(S, 0.05, 0.02, "GGL", Om0, tol=1e-9, rtol=1e-9)
+    covered = 0
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        k0, k1 = int(z["k0"]), int(z["k1"])
+        covered += k1 - k0
+        assert str(z["status"]) == rinfo["status"]
+        assert int(z["iters"]) == rinfo["iterations"]
+        for nm in ("Omega", "Theta", "X"):
+            assert np.abs(z[nm] - ref[nm][k0:k1]).max() <= 1e-10, (r, nm)
+    assert covered == K
+
+
+def test_shard_helpers():
+    from gglasso_amd.dist import shard_bounds, shard_grid
+    for K in (1, 7, 32, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(K, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == K
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    pts = sorted(sum((shard_grid(20, 8, r) for r in range(8)), []))
+    assert pts == list(range(20))
