@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libggl_hip.so")
 
 # mirrors include/ggl_hip.h
 REG_SGL, REG_GGL, REG_FGL = 0, 1, 2
-EIG_AUTO, EIG_JACOBI, EIG_ROCSOLVER = 0, 1, 2
+EIG_AUTO, EIG_JACOBI, EIG_ROCSOLVER, EIG_NEWTON_SCHULZ = 0, 1, 2, 3
 JACOBI_MAX_P = 128
 BUF_S, BUF_OMEGA, BUF_THETA, BUF_L, BUF_X, BUF_GROUPSQ, BUF_NORMS, BUF_OMEGA_PREV = range(8)
 E_ARG, E_HIP, E_SOLVER, E_ALLOC = -1, -2, -3, -4
@@ -43,6 +43,8 @@ _SIGNATURES = {
     "ggl_kkt_residual": ([_vp, _d, _d, _d, _i, _i, _dp, _dp, _dp], _i),
     "ggl_profile_enable": ([_vp, _i], _i),
     "ggl_profile_read": ([_vp, _dp, ctypes.POINTER(ctypes.c_longlong), _i], _i),
+    "ggl_dev_symm": ([_i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _i], _i),
+    "ggl_dev_symm_bench": ([_i, _i, _i, _i, _dp], _i),
     "ggl_eigh_batched": ([_i, _i, _dp, _dp, _dp, _i], _i),
     "ggl_phiplus": ([_i, _i, _dp, _dp, _dp, _dp], _i),
     "ggl_prox_rank_norm": ([_i, _i, _dp, _dp, _dp, _dp], _i),

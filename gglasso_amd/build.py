@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libggl_hip.so")
-SOURCES = ["elementwise.hip", "theta_pair.hip", "eig_jacobi.hip", "recon_gemm.hip", "ggl_capi.hip"]
+SOURCES = ["elementwise.hip", "theta_pair.hip", "eig_jacobi.hip", "recon_gemm.hip", "gemm_sym.hip", "newton_schulz.hip", "ggl_capi.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "ggl_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -40,7 +40,7 @@ def build(force=False, verbose=True):
         for f in os.listdir(LIBDIR):
             if f.endswith(".o") or f.endswith(".so"):
                 os.remove(os.path.join(LIBDIR, f))
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=7) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + \

@@ -1,0 +1,181 @@
+// Batched FP64 matrix-core product of COMMUTING SYMMETRIC matrices, the workhorse of the
+// eigendecomposition-free Omega-step (newton_schulz.hip):
+//
+//     C[k] = cI[k]*I + cAcc[k]*(A[k] * B[k]) + cE[k]*E[k]        (+ optional C2[k] = dI[k]*I + dC[k]*C[k])
+//
+// A, B symmetric and commuting  =>  A*B = A^T*B is symmetric.  Written as a "TN" product both
+// operands are read along contiguous rows (row m of A, columns I0.. and row m of B, columns J0..),
+// only tile pairs I<=J are computed (v_mfma_f64_16x16x4_f64), and the I<J tiles are mirrored through
+// an LDS transpose, so every global access is row-contiguous and the output is bitwise symmetric.
+//
+// Tiling: BM x BM block tile, NW waves as a (BM/WM) x (BM/WN) grid, each wave WM x WN = (WM/16) x
+// (WN/16) MFMA tiles; k-slab BK.  The next slab is fetched from HBM/L2 into registers while the
+// current one is consumed from LDS (software prefetch), one barrier pair per slab.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace ggl {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int BM, int BK, int WM, int WN, bool LM>
+struct SymCfg {
+    static constexpr int NWR = BM / WM, NWC = BM / WN, NW = NWR * NWC, NT = NW * 64;
+    static constexpr int TI = WM / 16, TJ = WN / 16;
+    static constexpr int LDS_LD = BM + 16;           // consecutive rows start on opposite bank halves
+    static constexpr int SLAB = BK * LDS_LD;          // doubles per operand slab
+    static constexpr int CLD = BM + 1;
+    static constexpr int LDS_DOUBLES = (!LM || 2 * SLAB > BM * CLD) ? 2 * SLAB : BM * CLD;   // LM: mirror via LDS
+    static constexpr int LPT = (BK * BM) / NT;       // elements per thread per operand slab
+    static_assert((BK * BM) % NT == 0, "slab must divide evenly over the threads");
+    static_assert(NT % BM == 0, "a row of the slab must be covered by whole thread rows");
+};
+
+constexpr int sym_nt(int BM, int WM, int WN) { return (BM / WM) * (BM / WN) * 64; }
+
+template <int BM, int BK, int WM, int WN, bool LM>
+__global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
+    const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, double* __restrict__ C2,
+    const double* __restrict__ E, const double* __restrict__ coef, int p)
+{
+    using Cfg = SymCfg<BM, BK, WM, WN, LM>;
+    __shared__ __attribute__((aligned(16))) double smem[Cfg::LDS_DOUBLES];
+    double* As = smem;
+    double* Bs = smem + Cfg::SLAB;
+    const int k = blockIdx.y;
+    const int T = (p + BM - 1) / BM;
+    int I = 0, b = blockIdx.x;
+    while (b >= T - I) { b -= T - I; ++I; }
+    const int J = I + b;
+    const int I0 = I * BM, J0 = J * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave / Cfg::NWC) * WM, wc = (wave % Cfg::NWC) * WN;
+    const size_t pp = (size_t)p * p;
+    const double* Ak = A + (size_t)k * pp;
+    const double* Bk = B + (size_t)k * pp;
+
+    v4d acc[Cfg::TI][Cfg::TJ];
+#pragma unroll
+    for (int i = 0; i < Cfg::TI; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TJ; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    // slab element e = tid + q*NT -> row e / BM, col e % BM
+    constexpr int RSTEP = Cfg::NT / BM;
+    const int lcol = tid % BM, lrow = tid / BM;
+    const bool aok = (I0 + lcol) < p, bok = (J0 + lcol) < p;
+    double ra[Cfg::LPT], rb[Cfg::LPT];
+
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int q = 0; q < Cfg::LPT; ++q) {
+            const int m = m0 + lrow + q * RSTEP;
+            ra[q] = (m < p && aok) ? Ak[(size_t)m * p + I0 + lcol] : 0.0;
+            rb[q] = (m < p && bok) ? Bk[(size_t)m * p + J0 + lcol] : 0.0;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < Cfg::LPT; ++q) {
+            const int row = lrow + q * RSTEP;
+            As[row * Cfg::LDS_LD + lcol] = ra[q];
+            Bs[row * Cfg::LDS_LD + lcol] = rb[q];
+        }
+    };
+
+    fetch(0);
+    for (int m0 = 0; m0 < p; m0 += BK) {
+        stage();
+        __syncthreads();
+        if (m0 + BK < p) fetch(m0 + BK);     // in flight while the MFMAs below run
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int row = kk * 4 + (lane >> 4);
+            double af[Cfg::TI], bf[Cfg::TJ];
+#pragma unroll
+            for (int i = 0; i < Cfg::TI; ++i) af[i] = As[row * Cfg::LDS_LD + wr + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < Cfg::TJ; ++j) bf[j] = Bs[row * Cfg::LDS_LD + wc + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < Cfg::TI; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    const double cI = coef[k * 5 + 0], cAcc = coef[k * 5 + 1], cE = coef[k * 5 + 2];
+    const double dI = coef[k * 5 + 3], dC = coef[k * 5 + 4];
+    double* Ck = C + (size_t)k * pp;
+    double* C2k = C2 ? C2 + (size_t)k * pp : nullptr;
+    const double* Ek = E ? E + (size_t)k * pp : nullptr;
+#pragma unroll
+    for (int ti = 0; ti < Cfg::TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < Cfg::TJ; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr + ti * 16 + (lane >> 4) + 4 * r;
+                const int col = wc + tj * 16 + (lane & 15);
+                const int gi = I0 + row, gj = J0 + col;
+                double v = cAcc * acc[ti][tj][r];
+                if (gi < p && gj < p) {
+                    if (gi == gj) v += cI;
+                    if (Ek) v += cE * Ek[(size_t)gi * p + gj];
+                    Ck[(size_t)gi * p + gj] = v;
+                    if (C2k) C2k[(size_t)gi * p + gj] = dC * v + (gi == gj ? dI : 0.0);
+                }
+                if (LM) {
+                    if (I != J) smem[row * Cfg::CLD + col] = v;
+                } else if (I != J && gi < p && gj < p) {
+                    // direct mirrored store: the four r-values of a lane quad complete a 128-B line
+                    Ck[(size_t)gj * p + gi] = v;
+                    if (C2k) C2k[(size_t)gj * p + gi] = dC * v;
+                }
+            }
+    if (LM && I != J) {
+        __syncthreads();
+        for (int e = tid; e < BM * BM; e += Cfg::NT) {
+            const int a = e / BM, c = e % BM;   // out[J0+a][I0+c] = tile[c][a]
+            if (J0 + a < p && I0 + c < p) {
+                const double v = smem[c * Cfg::CLD + a];
+                Ck[(size_t)(J0 + a) * p + I0 + c] = v;
+                if (C2k) C2k[(size_t)(J0 + a) * p + I0 + c] = dC * v;
+            }
+        }
+    }
+}
+
+template <int BM, int BK, int WM, int WN, bool LM>
+static void launch_cfg(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
+                       const double* coef, int K, int p)
+{
+    using Cfg = SymCfg<BM, BK, WM, WN, LM>;
+    const int T = (p + BM - 1) / BM;
+    hipLaunchKernelGGL((k_symm_tn<BM, BK, WM, WN, LM>), dim3(T * (T + 1) / 2, K), dim3(Cfg::NT), 0, st, A, B, C, C2, E,
+                       coef, p);
+}
+
+int symm_variants() { return 6; }
+
+void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
+                 const double* coef, int K, int p, int variant)
+{
+    if (variant < 0) {
+        // enough workgroups to fill 256 CUs a few times over, else the smaller tile
+        const int T128 = (p + 127) / 128;
+        variant = ((long)T128 * (T128 + 1) / 2 * K >= 1024) ? 2 : 0;
+    }
+    switch (variant) {
+        case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, C2, E, coef, K, p); break;
+        case 2: launch_cfg<128, 16, 64, 64, false>(st, A, B, C, C2, E, coef, K, p); break;
+        case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, C2, E, coef, K, p); break;
+        case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, C2, E, coef, K, p); break;
+        case 5: launch_cfg<128, 32, 64, 64, false>(st, A, B, C, C2, E, coef, K, p); break;
+        default: launch_cfg<64, 16, 32, 32, true>(st, A, B, C, C2, E, coef, K, p); break;
+    }
+}
+
+}  // namespace ggl

@@ -60,6 +60,14 @@ struct ggl_ctx {
     double *norms = nullptr, *norms_h = nullptr;  // (K,8) device / pinned
     int* info_h = nullptr;                        // pinned (K)
     bool nk_valid = false;
+    // Newton-Schulz Omega-step (newton_schulz.hip)
+    bool omega_ns = false;
+    bool dvo_valid = false;                    // DvO holds the eigenvalues of the last Omega-step
+    int symm_variant = -1;
+    double *nsY[2] = {nullptr, nullptr}, *nsZ[2] = {nullptr, nullptr}, *nsT = nullptr;
+    double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
+    double *bounds = nullptr, *bounds_h = nullptr;   // [K][2]
+    long long ns_steps_total = 0, ns_calls = 0;
     // per-phase HIP-event timing
     bool prof_on = false;
     hipEvent_t ev[GGL_NPHASE][2] = {};
@@ -89,7 +97,13 @@ static bool use_jacobi(const ggl_ctx* c)
 {
     if (c->eig == GGL_EIG_JACOBI) return true;
     if (c->eig == GGL_EIG_ROCSOLVER) return false;
-    return jacobi_fits(c->p);
+    return jacobi_fits(c->p);   // AUTO and NEWTON_SCHULZ: eigenvalue consumers use Jacobi when it fits
+}
+
+static bool use_ns(int eig, int p)
+{
+    if (eig == GGL_EIG_NEWTON_SCHULZ) return true;
+    return eig == GGL_EIG_AUTO && !jacobi_fits(p);
 }
 
 extern "C" int ggl_version(void) { return GGL_VERSION; }
@@ -138,6 +152,18 @@ static int ctx_alloc(ggl_ctx* c)
     HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
     HIPCHK(hipMemsetAsync(c->X, 0, nb, c->stream));
     HIPCHK(hipMemsetAsync(c->Om[1], 0, nb, c->stream));
+    if (c->omega_ns) {
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipMalloc(&c->nsY[i], nb));
+            HIPCHK(hipMalloc(&c->nsZ[i], nb));
+        }
+        HIPCHK(hipMalloc(&c->nsT, nb));
+        const size_t cl = (size_t)3 * NS_MAX_STEPS * c->K * 5 * sizeof(double);
+        HIPCHK(hipMalloc(&c->coef, cl));
+        HIPCHK(hipHostMalloc(&c->coef_h, cl));
+        HIPCHK(hipMalloc(&c->bounds, 2 * (size_t)c->K * sizeof(double)));
+        HIPCHK(hipHostMalloc(&c->bounds_h, 2 * (size_t)c->K * sizeof(double)));
+    }
     return GGL_OK;
 }
 
@@ -146,7 +172,8 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
     ARGCHK(out != nullptr, "out");
     ARGCHK(K >= 1 && p >= 1, "K, p must be positive");
     const int eig = flags & 0xff;
-    ARGCHK(eig == GGL_EIG_AUTO || eig == GGL_EIG_JACOBI || eig == GGL_EIG_ROCSOLVER, "eigensolver selector");
+    ARGCHK(eig == GGL_EIG_AUTO || eig == GGL_EIG_JACOBI || eig == GGL_EIG_ROCSOLVER || eig == GGL_EIG_NEWTON_SCHULZ,
+           "eigensolver selector");
     ARGCHK(eig != GGL_EIG_JACOBI || jacobi_fits(p), "GGL_EIG_JACOBI needs p <= GGL_JACOBI_MAX_P");
     HIPCHK(hipSetDevice(device));
     ggl_ctx* c = new ggl_ctx();
@@ -155,6 +182,8 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
     c->p = p;
     c->flags = flags;
     c->eig = eig;
+    c->omega_ns = use_ns(eig, p);
+    if (const char* v = getenv("GGL_SYMM_VARIANT")) c->symm_variant = atoi(v);
     c->n = (size_t)K * p * p;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -183,7 +212,10 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
-                      c->E, c->par, c->mask, c->groupsq, c->partials, c->norms};
+                      c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsY[0], c->nsY[1],
+                      c->nsZ[0], c->nsZ[1], c->nsT, c->coef, c->bounds};
+    if (c->coef_h) (void)hipHostFree(c->coef_h);
+    if (c->bounds_h) (void)hipHostFree(c->bounds_h);
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (c->info) (void)hipFree(c->info);
@@ -346,13 +378,41 @@ extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* 
     int rc = upload_par(c, 0, nk, 1.0, rho);   // beta_k = nk/rho    (admm_solver.py:180,184)
     if (rc) return rc;
     const double* beta = c->par;
+    const int nxt = c->cur ^ 1;
+    if (c->omega_ns) {
+        PB(c, GGL_PH_FORM_W);
+        launch_form_W_sym(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->K, c->p);
+        launch_norm_bounds(c->stream, c->W, c->K, c->p, c->bounds);
+        PE(c, GGL_PH_FORM_W);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->bounds_h, c->bounds, 2 * (size_t)c->K * sizeof(double), hipMemcpyDeviceToHost,
+                              c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        NsPlan plan;
+        if (ns_plan(c->bounds_h, c->par_h, c->K, c->coef_h, &plan) != 0)
+            return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");
+        HIPCHK(hipMemcpyAsync(c->coef, c->coef_h, (size_t)plan.products * c->K * 5 * sizeof(double),
+                              hipMemcpyHostToDevice, c->stream));
+        PB(c, GGL_PH_EIG_OMEGA);
+        ns_run(c->stream, plan, c->coef, c->W, c->nsY[0], c->nsY[1], c->nsZ[0], c->nsZ[1], c->nsT, c->Om[nxt], c->K,
+               c->p, c->symm_variant);
+        PE(c, GGL_PH_EIG_OMEGA);
+        HIPCHK(hipGetLastError());
+        if (c->prof_on) c->ph_cnt[GGL_PH_EIG_OMEGA] += plan.products - 1;   // count kernel launches, not phases
+        c->ns_steps_total += plan.steps;
+        c->ns_calls += 1;
+        c->dvo_valid = false;
+        HIPCHK(hipMemsetAsync(c->info, 0, c->K * sizeof(int), c->stream));
+        c->cur = nxt;
+        return GGL_OK;
+    }
     PB(c, GGL_PH_FORM_W);
     launch_form_W(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->K, c->p);
     PE(c, GGL_PH_FORM_W);
     HIPCHK(hipGetLastError());
-    const int nxt = c->cur ^ 1;
     rc = eig_recon(c, c->W, c->Om[nxt], c->DvO, MAP_PHIPLUS, beta, GGL_PH_EIG_OMEGA, GGL_PH_RECON_OMEGA);
     if (rc) return rc;
+    c->dvo_valid = true;
     c->cur = nxt;
     return GGL_OK;
 }
@@ -542,9 +602,16 @@ extern "C" int ggl_objective(ggl_ctx* c, double lambda1, double lambda2, int reg
     ARGCHK(c && out, "ctx, out");
     ARGCHK(reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
     HIPCHK(hipSetDevice(c->device));
-    // -log det Omega_k = -sum_m log phip(d_m): eigenvalues of the last Omega-step (ggl_helper.py:266-270)
+    // -log det Omega_k = -sum_m log phip(d_m): eigenvalues of the last Omega-step (ggl_helper.py:266-270);
+    // the Newton-Schulz Omega-step has none, so there the eigenvalues of Omega itself are computed.
     const size_t kp = (size_t)c->K * c->p;
     std::vector<double> d(kp);
+    const bool from_w = c->dvo_valid;
+    if (!from_w) {
+        HIPCHK(hipMemcpyAsync(c->W, c->Om[c->cur], c->n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        int rc0 = eigvals_only(c, c->W, c->DvO);
+        if (rc0) return rc0;
+    }
     HIPCHK(hipMemcpyAsync(d.data(), c->DvO, kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     launch_dot(c->stream, c->Om[c->cur], c->S, c->K, c->p, c->partials);
     launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), 1, c->norms);
@@ -556,7 +623,7 @@ extern "C" int ggl_objective(ggl_ctx* c, double lambda1, double lambda2, int reg
         const double beta = c->par_h[k];
         for (int m = 0; m < c->p; ++m) {
             const double dv = d[(size_t)k * c->p + m];
-            ld -= std::log(0.5 * (std::sqrt(dv * dv + 4.0 * beta) + dv));
+            ld -= from_w ? std::log(0.5 * (std::sqrt(dv * dv + 4.0 * beta) + dv)) : std::log(dv);
         }
     }
     out[0] = ld;
@@ -710,6 +777,67 @@ static int eig_common(int K, int p, const double* A, const double* beta, double*
     return GGL_OK;
 }
 
+extern "C" int ggl_dev_symm(int K, int p, const double* A, const double* B, const double* E, const double* coef5K,
+                            double* C, double* C2, int variant)
+{
+    ARGCHK(K >= 1 && p >= 1 && A && B && coef5K && C, "arguments");
+    ARGCHK(variant < symm_variants(), "variant");
+    const size_t n = (size_t)K * p * p;
+    DevBuf dA, dB, dE, dC, dC2, dcoef;
+    HIPCHK(dA.alloc(n));
+    HIPCHK(dB.alloc(n));
+    HIPCHK(dC.alloc(n));
+    HIPCHK(dcoef.alloc((size_t)K * 5));
+    UP(dA.p, A, n);
+    UP(dB.p, B, n);
+    UP(dcoef.p, coef5K, (size_t)K * 5);
+    if (E) { HIPCHK(dE.alloc(n)); UP(dE.p, E, n); }
+    if (C2) HIPCHK(dC2.alloc(n));
+    launch_symm(nullptr, dA.p, dB.p, dC.p, C2 ? dC2.p : nullptr, E ? dE.p : nullptr, dcoef.p, K, p, variant);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(C, dC.p, n);
+    if (C2) DOWN(C2, dC2.p, n);
+    return GGL_OK;
+}
+
+extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* ms_out)
+{
+    ARGCHK(K >= 1 && p >= 1 && iters >= 1 && ms_out, "arguments");
+    ARGCHK(variant < symm_variants(), "variant");
+    const size_t n = (size_t)K * p * p;
+    std::vector<double> h(n), coef((size_t)K * 5, 0.0);
+    unsigned long long s = 88172645463325252ull;
+    for (size_t i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        h[i] = (double)(s >> 11) / 9007199254740992.0 - 0.5;
+    }
+    for (int k = 0; k < K; ++k) coef[(size_t)k * 5 + 1] = 1.0 / p;
+    DevBuf dA, dB, dC, dcoef;
+    HIPCHK(dA.alloc(n));
+    HIPCHK(dB.alloc(n));
+    HIPCHK(dC.alloc(n));
+    HIPCHK(dcoef.alloc((size_t)K * 5));
+    UP(dA.p, h.data(), n);
+    UP(dB.p, h.data(), n);
+    UP(dcoef.p, coef.data(), (size_t)K * 5);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_symm(nullptr, dA.p, dB.p, dC.p, nullptr, nullptr, dcoef.p, K, p, variant);
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) launch_symm(nullptr, dA.p, dB.p, dC.p, nullptr, nullptr, dcoef.p, K, p, variant);
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    *ms_out = ms / iters;
+    return GGL_OK;
+}
+
 extern "C" int ggl_eigh_batched(int K, int p, const double* A, double* D, double* Q, int eig_method)
 {
     ARGCHK(D, "D");
@@ -718,7 +846,21 @@ extern "C" int ggl_eigh_batched(int K, int p, const double* A, double* D, double
 
 extern "C" int ggl_phiplus_matrix(int K, int p, const double* beta, const double* W, double* out, int eig_method)
 {
-    ARGCHK(beta && out, "beta, out");
+    ARGCHK(beta && out && W, "beta, W, out");
+    ARGCHK(K >= 1 && p >= 1, "K, p");
+    if (use_ns(eig_method, p)) {
+        // run the Omega-step of a scratch ctx with Theta = W, X = S = 0, nk = beta, rho = 1
+        ggl_ctx* c = nullptr;
+        int rc = ggl_ctx_create(0, K, p, GGL_EIG_NEWTON_SCHULZ, nullptr, &c);
+        if (rc) return rc;
+        std::vector<double> zero((size_t)K * p * p, 0.0);
+        rc = ggl_set_S(c, zero.data());
+        if (!rc) rc = ggl_set_state(c, zero.data(), W, nullptr, zero.data());
+        if (!rc) rc = ggl_step_omega(c, 1.0, 0, beta);
+        if (!rc) rc = ggl_get_state(c, out, nullptr, nullptr, nullptr);
+        ggl_ctx_destroy(c);
+        return rc;
+    }
     return eig_common(K, p, W, beta, nullptr, nullptr, out, MAP_PHIPLUS, eig_method);
 }
 

@@ -88,4 +88,26 @@ hipError_t launch_jacobi(hipStream_t st, const double* A, double* D, double* R, 
 void launch_recon(hipStream_t st, double* out, const double* R, const double* D, const double* betaK,
                   int map, int K, int p, double* scale_work);
 
+// ---- gemm_sym.hip -----------------------------------------------------------------------
+// C[k] = cI*I + cAcc*(A[k]*B[k]) + cE*E[k]  and optionally  C2[k] = dI*I + dC*C[k]  for commuting
+// symmetric A, B (so that A*B = A^T*B is symmetric).  coef: device [K][5] = {cI,cAcc,cE,dI,dC}.
+// variant < 0: pick by problem size.  FP64 MFMA.
+int symm_variants();
+void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
+                 const double* coef, int K, int p, int variant);
+
+// ---- newton_schulz.hip ------------------------------------------------------------------
+static constexpr int NS_MAX_STEPS = 24;
+struct NsPlan { int steps = 0; int products = 0; };
+// W = ((Theta - L) - X) - beta_k S from the lower triangle, mirrored (exactly symmetric)
+void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
+                       const double* S, const double* betaK, int K, int p);
+// bounds[k] = {|W_k|_inf, |W_k|_F^2}
+void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* bounds);
+// host: scaling schedule from the norm bounds; fills coef_h[(3*NS_MAX_STEPS)*K*5]; returns 0 or -1
+int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h, NsPlan* plan);
+// device: Omega = (W + (W^2 + 4 beta)^(1/2))/2 by 3*steps-2 symmetric products
+void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* W, double* Ya, double* Yb,
+            double* Za, double* Zb, double* Tb, double* out, int K, int p, int variant);
+
 }  // namespace ggl

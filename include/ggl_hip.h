@@ -36,9 +36,13 @@ extern "C" {
 #define GGL_REG_FGL 2       /* prox_phi_fgl (ggl_helper.py:131-134) */
 
 /* eigensolver selector (ctx flags, low byte) */
-#define GGL_EIG_AUTO 0      /* LDS Jacobi when the matrix fits one workgroup's LDS, else rocSOLVER */
+#define GGL_EIG_AUTO 0      /* p <= GGL_JACOBI_MAX_P: LDS Jacobi.  Larger p: Newton-Schulz for the Omega-step,
+                             * rocSOLVER where eigenvalues are needed (L-step, exit checks). */
 #define GGL_EIG_JACOBI 1    /* hand-written one-workgroup-per-matrix Jacobi (p <= GGL_JACOBI_MAX_P) */
 #define GGL_EIG_ROCSOLVER 2 /* rocsolver_dsyevd_strided_batched */
+#define GGL_EIG_NEWTON_SCHULZ 3 /* Omega-step without an eigendecomposition: Omega = (W + sqrt(W^2+4 beta I))/2
+                                 * by scaled Newton-Schulz products on the FP64 matrix cores (any p).
+                                 * Steps that need eigenvalues themselves (L-step, exit checks) use AUTO. */
 #define GGL_JACOBI_MAX_P 128
 
 /* which-buffer selector of ggl_device_ptr */
@@ -130,6 +134,13 @@ int ggl_kkt_residual(ggl_ctx *ctx, double rho, double lambda1, double lambda2, i
 #define GGL_NPHASE 8
 int ggl_profile_enable(ggl_ctx *ctx, int on);
 int ggl_profile_read(ggl_ctx *ctx, double ms[GGL_NPHASE], long long count[GGL_NPHASE], int reset);
+
+/* ---- development / tuning entry points (not used by the solvers) ------------------------------
+ * ggl_dev_symm: one launch of the symmetric-product kernel on host data (kernel unit test).
+ * ggl_dev_symm_bench: average milliseconds of `iters` launches on random device data. */
+int ggl_dev_symm(int K, int p, const double *A, const double *B, const double *E, const double *coef5K,
+                 double *C, double *C2, int variant);
+int ggl_dev_symm_bench(int K, int p, int variant, int iters, double *ms_out);
 
 /* ---- stateless operator entry points (host buffers; used for operator-level parity) ---------- */
 /* numpy.linalg.eigh on a stack (lower triangle read); D (K,p) ascending, Q (K,p,p) columns. */

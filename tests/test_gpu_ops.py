@@ -176,3 +176,75 @@ def test_prox_p_asserts_like_reference(ops):
         ops.prox_p(X, 0.1, 0.1, 'GGL')          # not symmetric
     with pytest.raises(AssertionError):
         ops.prox_p(np.zeros((2, 4, 4)), 0.0, 0.1, 'GGL')
+
+
+# ---- eigendecomposition-free Omega-step (Newton-Schulz on the FP64 matrix cores) -------------------
+
+def _commuting_pair(rng, K, p):
+    Q = np.linalg.qr(rng.standard_normal((K, p, p)))[0]
+    da, db = rng.standard_normal((K, p)), rng.standard_normal((K, p))
+    A = (Q * da[:, None, :]) @ Q.transpose(0, 2, 1)
+    B = (Q * db[:, None, :]) @ Q.transpose(0, 2, 1)
+    return 0.5 * (A + A.transpose(0, 2, 1)), 0.5 * (B + B.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("K,p", [(2, 40), (3, 129), (2, 200), (1, 333)])
+def test_symm_product_kernel(variant, K, p):
+    """C = cI*I + cAcc*A*B + cE*E and C2 = dI*I + dC*C for commuting symmetric A, B (every tile shape)."""
+    from gglasso_amd import _lib
+    from gglasso_amd._lib import ptr
+    lib = _lib.load()
+    rng = np.random.default_rng(variant * 100 + p)
+    A, B = _commuting_pair(rng, K, p)
+    E = rng.standard_normal((K, p, p))
+    E = 0.5 * (E + E.transpose(0, 2, 1))
+    coef = rng.uniform(0.5, 1.5, (K, 5))
+    C, C2 = np.empty_like(A), np.empty_like(A)
+    _lib.check(lib.ggl_dev_symm(K, p, ptr(A), ptr(B), ptr(E), ptr(np.ascontiguousarray(coef)), ptr(C), ptr(C2), variant))
+    eye = np.eye(p)[None]
+    ref = coef[:, 0, None, None] * eye + coef[:, 1, None, None] * (A @ B) + coef[:, 2, None, None] * E
+    ref2 = coef[:, 3, None, None] * eye + coef[:, 4, None, None] * ref
+    scale = np.abs(ref).max()
+    assert np.abs(C - ref).max() <= 1e-12 * scale * p
+    assert np.abs(C2 - ref2).max() <= 1e-12 * scale * p
+    assert np.array_equal(C, C.transpose(0, 2, 1))
+    # transpose-detecting: a NON-commuting pair gives A^T B = A B only for symmetric A, and the mirrored
+    # lower triangle then equals (A B)^T's upper one -- check the upper triangle against A @ B
+    A2 = rng.standard_normal((K, p, p)); A2 = 0.5 * (A2 + A2.transpose(0, 2, 1))
+    B2 = rng.standard_normal((K, p, p)); B2 = 0.5 * (B2 + B2.transpose(0, 2, 1))
+    one = np.tile(np.array([0.0, 1.0, 0.0, 0.0, 0.0]), (K, 1))
+    _lib.check(lib.ggl_dev_symm(K, p, ptr(A2), ptr(B2), None, ptr(np.ascontiguousarray(one)), ptr(C), None, variant))
+    iu = np.triu_indices(p)
+    assert np.abs(C[:, iu[0], iu[1]] - (A2 @ B2)[:, iu[0], iu[1]]).max() <= 1e-11 * p
+
+
+def test_g1_g2_phiplus_newton_schulz(ops):
+    g = load_golden("g1_g2_eigen_prox")
+    for n in range(int(g["count"])):
+        W, beta = g[f"W_{n}"], float(g[f"beta_{n}"])
+        scale = max(1.0, np.abs(W).max())
+        om = ops.phiplus_matrix(W, beta, method=3)
+        assert np.abs(om - g[f"phiplus_{n}"]).max() <= 1e-12 * scale * W.shape[0], n
+        assert np.array_equal(om, om.T)
+
+
+@pytest.mark.parametrize("K,p", [(3, 7), (2, 64), (3, 100), (2, 129), (4, 200), (1, 333), (2, 500)])
+def test_phiplus_newton_schulz_sizes(ops, K, p):
+    rng = np.random.default_rng(300 + p)
+    for scale, betas in ((2.0, (0.3, 2.0)), (30.0, (0.05, 0.1)), (0.01, (1.0, 8.0))):   # condition numbers 10 .. 1e5
+        W = _sym(rng, K, p, scale)
+        beta = rng.uniform(*betas, K)
+        ref, _ = orc.phiplus_stack(W, beta)
+        out = ops.phiplus_matrix(W, beta, method=3)
+        assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+        assert np.array_equal(out, out.transpose(0, 2, 1))
+
+
+def test_phiplus_newton_schulz_reads_lower_triangle(ops):
+    rng = np.random.default_rng(9)
+    A = rng.standard_normal((2, 150, 150))                 # NOT symmetric
+    Al = np.tril(A) + np.tril(A, -1).transpose(0, 2, 1)
+    ref, _ = orc.phiplus_stack(Al, 0.7)
+    out = ops.phiplus_matrix(A, 0.7, method=3)
+    assert np.abs(out - ref).max() <= 1e-11 * np.abs(ref).max()
