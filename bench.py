@@ -42,13 +42,17 @@ WORKLOADS = {
 }
 
 
-def phase_model(phase, reg, K, p, latent, eig_jacobi):
+def phase_model(phase, reg, K, p, latent, eig_jacobi, omega_ns=False):
     """(bound, algorithmic amount per launch, unit) of one phase.  B = one fp64 stack = 8*K*p^2 bytes.
     Bytes follow SURVEY.md section 8(d) (compulsory stack passes); flops are LAPACK-equivalent
     9 p^3 per eigendecomposition and 2 p^3 per reconstruction."""
     B = 8.0 * K * p * p
     if phase == "form_W":
         return "hbm", (5 if latent else 4) * B, "GB/s"
+    if phase == "eig_omega" and omega_ns:
+        # one launch = one product of two commuting symmetric matrices per instance: only the upper
+        # triangle is needed, p^3 flop (of the 2 p^3 of a general product)
+        return "mfma", 1.0 * K * p ** 3, "TFLOP/s"
     if phase in ("eig_omega", "eig_L"):
         fl = (11.0 if eig_jacobi else 9.0) * K * p ** 3
         return "mfma", fl, "TFLOP/s"
@@ -162,7 +166,13 @@ def main():
         eig_jacobi = (args.eig == _lib.EIG_JACOBI) or (args.eig == _lib.EIG_AUTO and p <= _lib.JACOBI_MAX_P)
         phases = {ph: {"ms_per_launch": ms / cnt, "launches": cnt} for ph, (ms, cnt) in prof.items() if cnt}
         dom = max(phases, key=lambda ph: phases[ph]["ms_per_launch"] * phases[ph]["launches"])
-        bound, amount, unit = phase_model(dom, reg, Kl, p, latent, eig_jacobi)
+        omega_ns = (args.eig == _lib.EIG_NEWTON_SCHULZ) or (args.eig == _lib.EIG_AUTO and not eig_jacobi)
+        bound, amount, unit = phase_model(dom, reg, Kl, p, latent, eig_jacobi, omega_ns)
+        kernel_name = {"eig_omega": "k_symm_tn (Newton-Schulz product)" if omega_ns else
+                       ("k_jacobi" if eig_jacobi else "rocsolver_dsyevd (library, many kernels)"),
+                       "theta": "k_theta_ggl" if reg == "GGL" else ("k_theta_fgl" if reg == "FGL" else "k_theta_sgl"),
+                       "recon_omega": "k_recon", "recon_L": "k_recon", "form_W": "k_form_W",
+                       "dual": "k_dual_update", "eig_L": "k_jacobi" if eig_jacobi else "rocsolver_dsyevd"}.get(dom, dom)
         sec = phases[dom]["ms_per_launch"] * 1e-3
         if bound == "hbm":
             achieved, peak = amount / sec / 1e9, HBM_PEAK_GBS
@@ -178,8 +188,10 @@ def main():
             "config": {"workload": f"{reg} K={K} p={p} lambda1={l1} lambda2={l2} latent={latent}, identity start, "
                                    f"rho0=1 update_rho, fixed iteration count",
                        "sharding": f"K-slabs of {Kl} per GPU" if distributed else "single GPU",
-                       "eigensolver": "lds_jacobi" if eig_jacobi else "rocsolver_dsyevd+mfma_recon"},
-            "roofline": {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                       "omega_step": "lds_jacobi" if eig_jacobi else ("newton_schulz_fp64_mfma" if omega_ns
+                                                                         else "rocsolver_dsyevd+mfma_recon")},
+            "roofline": {"kernel": kernel_name, "phase": dom, "launches_per_step": phases[dom]["launches"] / args.steps,
+                         "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": None,
                          "ms_per_launch": phases[dom]["ms_per_launch"]},
             "iteration_hbm_roofline": {"algorithmic_bytes": iter_bytes, "achieved_GBs": its * iter_bytes / 1e9,

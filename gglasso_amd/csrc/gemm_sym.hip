@@ -121,19 +121,21 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
                 const int col = wc + tj * 16 + (lane & 15);
                 const int gi = I0 + row, gj = J0 + col;
                 double v = cAcc * acc[ti][tj][r];
-                if (gi < p && gj < p) {
+                const bool in = gi < p && gj < p;
+                if (in && (I != J || gi <= gj)) {
                     if (gi == gj) v += cI;
                     if (Ek) v += cE * Ek[(size_t)gi * p + gj];
                     Ck[(size_t)gi * p + gj] = v;
                     if (C2k) C2k[(size_t)gi * p + gj] = dC * v + (gi == gj ? dI : 0.0);
+                    // mirrored store.  Diagonal tiles: only the upper triangle is kept, so the result is
+                    // bitwise symmetric even though A != B.  Off-diagonal tiles without the LDS transpose:
+                    // the four r-values of a lane quad complete a 128-B line.
+                    if ((I == J && gi != gj) || (!LM && I != J)) {
+                        Ck[(size_t)gj * p + gi] = v;
+                        if (C2k) C2k[(size_t)gj * p + gi] = dC * v;
+                    }
                 }
-                if (LM) {
-                    if (I != J) smem[row * Cfg::CLD + col] = v;
-                } else if (I != J && gi < p && gj < p) {
-                    // direct mirrored store: the four r-values of a lane quad complete a 128-B line
-                    Ck[(size_t)gj * p + gi] = v;
-                    if (C2k) C2k[(size_t)gj * p + gi] = dC * v;
-                }
+                if (LM && I != J) smem[row * Cfg::CLD + col] = v;
             }
     if (LM && I != J) {
         __syncthreads();
@@ -156,6 +158,109 @@ static void launch_cfg(hipStream_t st, const double* A, const double* B, double*
     const int T = (p + BM - 1) / BM;
     hipLaunchKernelGGL((k_symm_tn<BM, BK, WM, WN, LM>), dim3(T * (T + 1) / 2, K), dim3(Cfg::NT), 0, st, A, B, C, C2, E,
                        coef, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// General (non-symmetric result) product with a symmetric right factor:
+//     C[b] = s[b] * A[b] * T[b % K],     b = 0 .. nbatch-1,
+// used by the numerically stable Newton-Schulz path where Y and P = Z^T are both multiplied by
+// the same T from the right (newton_schulz.hip); nbatch = 2K covers both in one launch.  A is
+// read as row panels A[I0+i][m0+k] (k contiguous), T as row panels T[m0+k][J0+j] (T symmetric, so
+// its rows are its columns); full output, no mirroring.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BK, int WM, int WN>
+__global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_gemm_nt_right(const double* __restrict__ A,
+                                                                      const double* __restrict__ T,
+                                                                      double* __restrict__ C,
+                                                                      const double* __restrict__ scal, int K, int p)
+{
+    constexpr int NWC = BM / WN, NT = sym_nt(BM, WM, WN), TI = WM / 16, TJ = WN / 16;
+    constexpr int LDA = BK + 2;      // A tile [BM][BK]: (2 i + k) mod 32 distinct over a half wave
+    constexpr int LDB = BM + 16;     // T tile [BK][BM]
+    __shared__ __attribute__((aligned(16))) double smem[BM * LDA + BK * LDB];
+    double* As = smem;
+    double* Bs = smem + BM * LDA;
+    const int b = blockIdx.y, kt = b % K;
+    const int Tn = (p + BM - 1) / BM;
+    const int I0 = (blockIdx.x / Tn) * BM, J0 = (blockIdx.x % Tn) * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave / NWC) * WM, wc = (wave % NWC) * WN;
+    const size_t pp = (size_t)p * p;
+    const double* Ab = A + (size_t)b * pp;
+    const double* Tb = T + (size_t)kt * pp;
+
+    v4d acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    constexpr int LPT = (BM * BK) / NT;
+    static_assert((BM * BK) % NT == 0 && NT % BK == 0 && NT % BM == 0, "tile/thread mismatch");
+    const int acol = tid % BK, arow = tid / BK;      // A tile element (arow + q*NT/BK, acol)
+    const int bcol = tid % BM, brow = tid / BM;      // T tile element (brow + q*NT/BM, bcol)
+    double ra[LPT], rb[LPT];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int q = 0; q < LPT; ++q) {
+            const int i = I0 + arow + q * (NT / BK), m = m0 + acol;
+            ra[q] = (i < p && m < p) ? Ab[(size_t)i * p + m] : 0.0;
+            const int mb = m0 + brow + q * (NT / BM), j = J0 + bcol;
+            rb[q] = (mb < p && j < p) ? Tb[(size_t)mb * p + j] : 0.0;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < LPT; ++q) {
+            As[(arow + q * (NT / BK)) * LDA + acol] = ra[q];
+            Bs[(brow + q * (NT / BM)) * LDB + bcol] = rb[q];
+        }
+    };
+    fetch(0);
+    for (int m0 = 0; m0 < p; m0 += BK) {
+        stage();
+        __syncthreads();
+        if (m0 + BK < p) fetch(m0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int kq = kk * 4 + (lane >> 4);
+            double af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = As[(wr + i * 16 + (lane & 15)) * LDA + kq];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = Bs[kq * LDB + wc + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const double sc = scal[b];
+    double* Cb = C + (size_t)b * pp;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = I0 + wr + ti * 16 + (lane >> 4) + 4 * r;
+                const int gj = J0 + wc + tj * 16 + (lane & 15);
+                if (gi < p && gj < p) Cb[(size_t)gi * p + gj] = sc * acc[ti][tj][r];
+            }
+}
+
+void launch_gemm_right(hipStream_t st, const double* A, const double* T, double* C, const double* scal, int nbatch,
+                       int K, int p, int variant)
+{
+    if (variant == 1) {
+        const int Tn = (p + 127) / 128;
+        hipLaunchKernelGGL((k_gemm_nt_right<128, 16, 32, 64>), dim3(Tn * Tn, nbatch), dim3(512), 0, st, A, T, C, scal, K, p);
+    } else {
+        const int Tn = (p + 63) / 64;
+        hipLaunchKernelGGL((k_gemm_nt_right<64, 32, 32, 32>), dim3(Tn * Tn, nbatch), dim3(256), 0, st, A, T, C, scal, K, p);
+    }
 }
 
 int symm_variants() { return 6; }

@@ -64,7 +64,9 @@ struct ggl_ctx {
     bool omega_ns = false;
     bool dvo_valid = false;                    // DvO holds the eigenvalues of the last Omega-step
     int symm_variant = -1;
-    double *nsY[2] = {nullptr, nullptr}, *nsZ[2] = {nullptr, nullptr}, *nsT = nullptr;
+    double *nsYP[2] = {nullptr, nullptr}, *nsT = nullptr;   // [Y|Z] scratch pairs (2 stacks each), T
+    int ns_force = 0;                          // 0 auto, 1 symmetric products, 2 stable products
+    long long ns_stable_calls = 0;
     double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
     double *bounds = nullptr, *bounds_h = nullptr;   // [K][2]
     long long ns_steps_total = 0, ns_calls = 0;
@@ -153,10 +155,7 @@ static int ctx_alloc(ggl_ctx* c)
     HIPCHK(hipMemsetAsync(c->X, 0, nb, c->stream));
     HIPCHK(hipMemsetAsync(c->Om[1], 0, nb, c->stream));
     if (c->omega_ns) {
-        for (int i = 0; i < 2; ++i) {
-            HIPCHK(hipMalloc(&c->nsY[i], nb));
-            HIPCHK(hipMalloc(&c->nsZ[i], nb));
-        }
+        for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->nsYP[i], 2 * nb));
         HIPCHK(hipMalloc(&c->nsT, nb));
         const size_t cl = (size_t)3 * NS_MAX_STEPS * c->K * 5 * sizeof(double);
         HIPCHK(hipMalloc(&c->coef, cl));
@@ -184,6 +183,7 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
     c->eig = eig;
     c->omega_ns = use_ns(eig, p);
     if (const char* v = getenv("GGL_SYMM_VARIANT")) c->symm_variant = atoi(v);
+    if (const char* v = getenv("GGL_NS_MODE")) c->ns_force = atoi(v);   // 1 symmetric, 2 stable (testing)
     c->n = (size_t)K * p * p;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -212,8 +212,8 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
-                      c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsY[0], c->nsY[1],
-                      c->nsZ[0], c->nsZ[1], c->nsT, c->coef, c->bounds};
+                      c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
+                      c->nsT, c->coef, c->bounds};
     if (c->coef_h) (void)hipHostFree(c->coef_h);
     if (c->bounds_h) (void)hipHostFree(c->bounds_h);
     for (double* b : bufs)
@@ -389,13 +389,14 @@ extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* 
                               c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         NsPlan plan;
-        if (ns_plan(c->bounds_h, c->par_h, c->K, c->coef_h, &plan) != 0)
+        if (ns_plan(c->bounds_h, c->par_h, c->K, c->coef_h, &plan, c->ns_force) != 0)
             return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");
         HIPCHK(hipMemcpyAsync(c->coef, c->coef_h, (size_t)plan.products * c->K * 5 * sizeof(double),
                               hipMemcpyHostToDevice, c->stream));
         PB(c, GGL_PH_EIG_OMEGA);
-        ns_run(c->stream, plan, c->coef, c->W, c->nsY[0], c->nsY[1], c->nsZ[0], c->nsZ[1], c->nsT, c->Om[nxt], c->K,
-               c->p, c->symm_variant);
+        ns_run(c->stream, plan, c->coef, c->W, c->nsYP[0], c->nsYP[1], c->nsT, c->Om[nxt], c->K, c->p,
+               c->symm_variant);
+        c->ns_stable_calls += plan.stable ? 1 : 0;
         PE(c, GGL_PH_EIG_OMEGA);
         HIPCHK(hipGetLastError());
         if (c->prof_on) c->ph_cnt[GGL_PH_EIG_OMEGA] += plan.products - 1;   // count kernel launches, not phases

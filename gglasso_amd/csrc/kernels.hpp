@@ -96,18 +96,26 @@ int symm_variants();
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                  const double* coef, int K, int p, int variant);
 
+// C[b] = scal[b % K] * A[b] * T[b % K] (T symmetric, A general), b < nbatch; full output.  FP64 MFMA.
+void launch_gemm_right(hipStream_t st, const double* A, const double* T, double* C, const double* scal,
+                       int nbatch, int K, int p, int variant);
+
 // ---- newton_schulz.hip ------------------------------------------------------------------
 static constexpr int NS_MAX_STEPS = 24;
-struct NsPlan { int steps = 0; int products = 0; };
+// all-symmetric products are only accurate while the condition number of W^2 + 4 beta I is small
+static constexpr double NS_SYM_KAPPA_MAX = 300.0;
+struct NsPlan { int steps = 0; int products = 0; bool stable = false; double kappa = 0.0; };
 // W = ((Theta - L) - X) - beta_k S from the lower triangle, mirrored (exactly symmetric)
 void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
                        const double* S, const double* betaK, int K, int p);
 // bounds[k] = {|W_k|_inf, |W_k|_F^2}
 void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* bounds);
 // host: scaling schedule from the norm bounds; fills coef_h[(3*NS_MAX_STEPS)*K*5]; returns 0 or -1
-int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h, NsPlan* plan);
+// force_mode: 0 choose by condition number, 1 all-symmetric products, 2 stable (unsymmetrised) products
+int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h, NsPlan* plan, int force_mode);
 // device: Omega = (W + (W^2 + 4 beta)^(1/2))/2 by 3*steps-2 symmetric products
-void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* W, double* Ya, double* Yb,
-            double* Za, double* Zb, double* Tb, double* out, int K, int p, int variant);
+// YP[0], YP[1]: two scratch buffers of 2 stacks each (Y stack followed by Z/P stack); Tb: one stack.
+void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* W, double* YP0, double* YP1,
+            double* Tb, double* out, int K, int p, int variant);
 
 }  // namespace ggl

@@ -126,21 +126,27 @@ static std::vector<double> ns_schedule(double l)
     return al;
 }
 
-int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h, NsPlan* plan)
+int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h, NsPlan* plan, int force_mode)
 {
     std::vector<std::vector<double>> al(K);
     std::vector<double> c(K);
     int n = 1;
+    double kappa = 1.0;
     for (int k = 0; k < K; ++k) {
         const double w2 = std::fmin(bounds_h[2 * k], std::sqrt(bounds_h[2 * k + 1])) * (1.0 + 1e-10);
         if (!(w2 >= 0.0) || !std::isfinite(w2) || !(beta_h[k] > 0.0)) return -1;
         c[k] = w2 * w2 + 4.0 * beta_h[k];
+        kappa = std::fmax(kappa, c[k] / (4.0 * beta_h[k]));
         al[k] = ns_schedule(std::sqrt(4.0 * beta_h[k] / c[k]));
         n = std::max(n, (int)al[k].size());
     }
+    const bool stable = (force_mode == 2) || (force_mode == 0 && kappa > NS_SYM_KAPPA_MAX);
     plan->steps = n;
-    plan->products = 3 * n - 2;
-    // product g of the sequence (see ns_run) reads coef_h[(g*K + k)*5 ..]
+    plan->stable = stable;
+    plan->kappa = kappa;
+    plan->products = (n == 1) ? 2 : (stable ? 2 + 2 * (n - 2) + 2 : 3 * n - 2);   // kernel launches
+    // launch g of the sequence (see ns_run) reads coef_h[(g*K + k)*5 ..]; a right-multiply launch reads
+    // its 2K scalars from the start of its slot instead.
     for (int k = 0; k < K; ++k) {
         auto a_of = [&](int it) { return it < (int)al[k].size() ? al[k][it] : 1.0; };
         auto put = [&](int g, double cI, double cAcc, double cE, double dI, double dC) {
@@ -152,15 +158,21 @@ int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h,
         double a = a_of(0);
         // g0: Y0 = W^2/c + (4 beta/c) I ; second output T0 = 1.5 I - 0.5 a0^2 Y0
         put(g++, 4.0 * beta_h[k] / c[k], 1.0 / c[k], 0.0, 1.5, -0.5 * a * a);
-        // step 0: Y1 = a0 Y0 T0 (final if n == 1)
-        if (n == 1) put(g++, 0.0, 0.5 * sc * a, 0.5, 0.0, 0.0);
-        else put(g++, 0.0, a, 0.0, 0.0, 0.0);
-        double zs = a;   // Z1 = zs * T0
+        // step 0: Y1 = a0 Y0 T0 (final if n == 1); Z1 = P1 = zs * T0 with zs = a0 kept as a pending scalar
+        if (n == 1) { put(g++, 0.0, 0.5 * sc * a, 0.5, 0.0, 0.0); continue; }
+        put(g++, 0.0, a, 0.0, 0.0, 0.0);
+        double zs = a;
         for (int it = 1; it < n; ++it) {
             a = a_of(it);
             put(g++, 1.5, -0.5 * a * a * zs, 0.0, 0.0, 0.0);                 // T = 1.5 I - 0.5 a^2 (Z Y)
             if (it == n - 1) put(g++, 0.0, 0.5 * sc * a, 0.5, 0.0, 0.0);    // Omega = W/2 + sqrt(c) a (Y T)/2
-            else {
+            else if (stable) {
+                double* o = coef_h + (size_t)g * K * 5;                     // [Y <- a Y T ; P <- a zs P T]
+                o[k] = a;
+                o[K + k] = a * zs;
+                ++g;
+                zs = 1.0;
+            } else {
                 put(g++, 0.0, a, 0.0, 0.0, 0.0);                            // Y <- a Y T
                 put(g++, 0.0, a * zs, 0.0, 0.0, 0.0);                       // Z <- a T Z
                 zs = 1.0;
@@ -170,31 +182,42 @@ int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h,
     return 0;
 }
 
-// buffers: W (input, preserved), Ya, Yb, Za, Zb, Tb: scratch stacks; out: Omega.
-void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* W, double* Ya, double* Yb,
-            double* Za, double* Zb, double* Tb, double* out, int K, int p, int variant)
+// YP0 / YP1: [Y stack | Z stack] scratch pairs (2*K*p*p doubles each); Tb: one stack; W preserved; out: Omega.
+//
+// fast path (plan.stable == false, small condition numbers): every product is a product of
+// commuting symmetric matrices, computed as upper triangle + mirror (3 per step).
+// stable path: Z is replaced by P = Z^T, M = P^T Y is still a congruence (exactly symmetric), but
+// Y <- a Y T and P <- a P T are full, unsymmetrised products in one 2K-batch launch: this keeps
+// Y = Y0 P exactly, which is what makes the coupled iteration insensitive to rounding (the
+// symmetrised form amplifies commutator errors by ~sqrt(kappa)/4 per step).
+void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* W, double* YP0, double* YP1,
+            double* Tb, double* out, int K, int p, int variant)
 {
-    const size_t cs = (size_t)K * 5;
+    const size_t cs = (size_t)K * 5, n1 = (size_t)K * p * p;
     int g = 0;
     const int n = plan.steps;
-    double *Y = Ya, *Yn = Yb, *Z = Za, *Zn = Zb;
-    // g0: Y = Y0, Z = T0 (Z1 up to the scalar folded into later coefficients)
-    launch_symm(st, W, W, Y, Z, nullptr, coef_d + cs * g++, K, p, variant);
+    double *cur = YP0, *nxt = YP1;      // cur = [Y | Z]
+    // g0: Y0 -> cur.Y, T0 -> nxt.Z  (Z1 = P1 = a0 T0: the scalar is folded into later coefficients)
+    launch_symm(st, W, W, cur, nxt + n1, nullptr, coef_d + cs * g++, K, p, variant);
     if (n == 1) {
-        launch_symm(st, Y, Z, out, nullptr, W, coef_d + cs * g++, K, p, variant);
+        launch_symm(st, cur, nxt + n1, out, nullptr, W, coef_d + cs * g++, K, p, variant);
         return;
     }
-    launch_symm(st, Y, Z, Yn, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
-    std::swap(Y, Yn);
+    // step 0: Y1 = a0 Y0 T0 -> nxt.Y, right next to T0, so that nxt = [Y1 | Z1]
+    launch_symm(st, cur, nxt + n1, nxt, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
+    std::swap(cur, nxt);
     for (int it = 1; it < n; ++it) {
-        launch_symm(st, Z, Y, Tb, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
+        // T = 1.5 I - 0.5 a^2 zs (Z Y)   [fast: Z Y = Z^T Y, Z symmetric; stable: P^T Y]
+        launch_symm(st, cur + n1, cur, Tb, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
         if (it == n - 1) {
-            launch_symm(st, Y, Tb, out, nullptr, W, coef_d + cs * g++, K, p, variant);
+            launch_symm(st, cur, Tb, out, nullptr, W, coef_d + cs * g++, K, p, variant);
+        } else if (plan.stable) {
+            launch_gemm_right(st, cur, Tb, nxt, coef_d + cs * g++, 2 * K, K, p, 0);
+            std::swap(cur, nxt);
         } else {
-            launch_symm(st, Y, Tb, Yn, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
-            launch_symm(st, Tb, Z, Zn, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
-            std::swap(Y, Yn);
-            std::swap(Z, Zn);
+            launch_symm(st, cur, Tb, nxt, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
+            launch_symm(st, Tb, cur + n1, nxt + n1, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
+            std::swap(cur, nxt);
         }
     }
 }

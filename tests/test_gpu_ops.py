@@ -241,6 +241,24 @@ def test_phiplus_newton_schulz_sizes(ops, K, p):
         assert np.array_equal(out, out.transpose(0, 2, 1))
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_phiplus_newton_schulz_both_product_modes(ops, mode, monkeypatch):
+    """GGL_NS_MODE=1: all-symmetric products (accurate for small condition numbers only);
+    GGL_NS_MODE=2: stable unsymmetrised products (any condition number)."""
+    monkeypatch.setenv("GGL_NS_MODE", mode)
+    rng = np.random.default_rng(41)
+    W = _sym(rng, 3, 150, 0.3)                    # kappa ~ 10
+    beta = np.array([0.5, 1.0, 2.0])
+    ref, _ = orc.phiplus_stack(W, beta)
+    assert np.abs(ops.phiplus_matrix(W, beta, method=3) - ref).max() <= 1e-12 * np.abs(ref).max()
+    if mode == "2":
+        for scale in (30.0, 1000.0):               # kappa 1e6 .. 1e9
+            W = _sym(rng, 2, 150, scale)
+            ref, _ = orc.phiplus_stack(W, 0.08)
+            out = ops.phiplus_matrix(W, 0.08, method=3)
+            assert np.abs(out - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
 def test_phiplus_newton_schulz_reads_lower_triangle(ops):
     rng = np.random.default_rng(9)
     A = rng.standard_normal((2, 150, 150))                 # NOT symmetric
