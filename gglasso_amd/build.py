@@ -15,7 +15,10 @@ LIB = os.path.join(LIBDIR, "libggl_hip.so")
 SOURCES = ["elementwise.hip", "theta_pair.hip", "eig_jacobi.hip", "recon_gemm.hip", "gemm_sym.hip", "newton_schulz.hip", "ggl_capi.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "ggl_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs; without it hipcc 7.2 shuttles the f64
+# accumulators VGPR<->AGPR around every k-slab (64 extra moves + a full matrix-pipe drain per slab)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _stale(target, deps):

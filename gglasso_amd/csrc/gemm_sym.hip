@@ -33,18 +33,44 @@ struct SymCfg {
 
 constexpr int sym_nt(int BM, int WM, int WN) { return (BM / WM) * (BM / WN) * 64; }
 
-template <int BM, int BK, int WM, int WN, bool LM>
+// XCD-aware work decode.  The 8 XCDs have private 4 MiB L2s and the dispatcher deals consecutive
+// workgroup ids round-robin over them (id % 8, observed; only speed depends on it).  A 1-D grid of
+// 8 * ceil(K/8) * ntiles ids is decoded so that all tiles of instance k run on XCD k % 8 and
+// follow each other in dispatch order: the two operand matrices of an instance (2 x 8 p^2 bytes)
+// are then fetched into ONE L2 once and reused by all of its tiles, instead of being streamed
+// into all eight.  Batches smaller than 8 keep the plain (tile, k) order so that every XCD has work.
+static constexpr int NXCD = 8;
+__host__ __device__ inline int xcd_grid(int ntiles, int K)
+{
+    return (K >= NXCD) ? NXCD * ((K + NXCD - 1) / NXCD) * ntiles : ntiles * K;
+}
+__device__ __forceinline__ bool decode_block_xcd(int ntiles, int K, int& k, int& tile)
+{
+    const int L = blockIdx.x;
+    if (K >= NXCD) {
+        const int xcd = L % NXCD, slot = L / NXCD;
+        k = (slot / ntiles) * NXCD + xcd;
+        tile = slot % ntiles;
+        return k < K;
+    }
+    k = L / ntiles;
+    tile = L % ntiles;
+    return true;
+}
+
+template <int BM, int BK, int WM, int WN, bool LM, int ABL = 0>
 __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, double* __restrict__ C2,
-    const double* __restrict__ E, const double* __restrict__ coef, int p)
+    const double* __restrict__ E, const double* __restrict__ coef, int K, int p)
 {
     using Cfg = SymCfg<BM, BK, WM, WN, LM>;
     __shared__ __attribute__((aligned(16))) double smem[Cfg::LDS_DOUBLES];
     double* As = smem;
     double* Bs = smem + Cfg::SLAB;
-    const int k = blockIdx.y;
     const int T = (p + BM - 1) / BM;
-    int I = 0, b = blockIdx.x;
+    int k, b;
+    if (!decode_block_xcd(T * (T + 1) / 2, K, k, b)) return;
+    int I = 0;
     while (b >= T - I) { b -= T - I; ++I; }
     const int J = I + b;
     const int I0 = I * BM, J0 = J * BM;
@@ -62,32 +88,36 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
 
     // slab element e = tid + q*NT -> row e / BM, col e % BM
     constexpr int RSTEP = Cfg::NT / BM;
+    constexpr int NST = 1;                      // slabs in flight (register stages); 1 measured best, 3 was -8%
     const int lcol = tid % BM, lrow = tid / BM;
     const bool aok = (I0 + lcol) < p, bok = (J0 + lcol) < p;
-    double ra[Cfg::LPT], rb[Cfg::LPT];
+    double ra[NST][Cfg::LPT], rb[NST][Cfg::LPT];
 
-    auto fetch = [&](int m0) {
+    // Unconditional fetch from clamped (always valid) addresses with 32-bit element offsets (p*p < 2^31);
+    // out-of-range elements are zeroed only when the slab is staged into LDS, so nothing consumes a load
+    // early and NST slabs (NST * 2 * BK * BM * 8 bytes per workgroup) stay in flight: the product is
+    // latency-bound on the L2/MALL path otherwise.
+    const unsigned pu = (unsigned)p, pm1 = (unsigned)(p - 1);
+    const unsigned ca = min((unsigned)(I0 + lcol), pm1), cb = min((unsigned)(J0 + lcol), pm1);
+    auto fetch = [&](int m0, double (&xa)[Cfg::LPT], double (&xb)[Cfg::LPT]) {
 #pragma unroll
         for (int q = 0; q < Cfg::LPT; ++q) {
-            const int m = m0 + lrow + q * RSTEP;
-            ra[q] = (m < p && aok) ? Ak[(size_t)m * p + I0 + lcol] : 0.0;
-            rb[q] = (m < p && bok) ? Bk[(size_t)m * p + J0 + lcol] : 0.0;
+            if (ABL == 1) { xa[q] = 1.0 + q; xb[q] = 2.0 + q; continue; }   // ablation: no global loads
+            const unsigned ro = min((unsigned)(m0 + lrow + q * RSTEP), pm1) * pu;
+            xa[q] = Ak[ro + ca];
+            xb[q] = Bk[ro + cb];
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](int m0, const double (&xa)[Cfg::LPT], const double (&xb)[Cfg::LPT]) {
 #pragma unroll
         for (int q = 0; q < Cfg::LPT; ++q) {
             const int row = lrow + q * RSTEP;
-            As[row * Cfg::LDS_LD + lcol] = ra[q];
-            Bs[row * Cfg::LDS_LD + lcol] = rb[q];
+            const bool in = (m0 + row) < p;
+            As[row * Cfg::LDS_LD + lcol] = (in && aok) ? xa[q] : 0.0;
+            Bs[row * Cfg::LDS_LD + lcol] = (in && bok) ? xb[q] : 0.0;
         }
     };
-
-    fetch(0);
-    for (int m0 = 0; m0 < p; m0 += BK) {
-        stage();
-        __syncthreads();
-        if (m0 + BK < p) fetch(m0 + BK);     // in flight while the MFMAs below run
+    auto compute = [&]() {
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             const int row = kk * 4 + (lane >> 4);
@@ -99,10 +129,27 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
 #pragma unroll
             for (int i = 0; i < Cfg::TI; ++i)
 #pragma unroll
-                for (int j = 0; j < Cfg::TJ; ++j)
+                for (int j = 0; j < Cfg::TJ; ++j) {
+                    if (ABL == 2) { acc[i][j][0] += af[i] * bf[j]; continue; }   // ablation: no MFMA
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
         }
-        __syncthreads();
+    };
+
+#pragma unroll
+    for (int s = 0; s < NST; ++s) fetch(s * BK, ra[s], rb[s]);
+    for (int m0 = 0; m0 < p; m0 += NST * BK) {
+#pragma unroll
+        for (int s = 0; s < NST; ++s) {
+            const int ms = m0 + s * BK;
+            if (ms < p) {                                   // uniform over the workgroup
+                stage(ms, ra[s], rb[s]);
+                __syncthreads();
+                fetch(ms + NST * BK, ra[s], rb[s]);          // past the end: clamped, never staged
+                compute();
+                __syncthreads();
+            }
+        }
     }
 
     // epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -156,8 +203,8 @@ static void launch_cfg(hipStream_t st, const double* A, const double* B, double*
 {
     using Cfg = SymCfg<BM, BK, WM, WN, LM>;
     const int T = (p + BM - 1) / BM;
-    hipLaunchKernelGGL((k_symm_tn<BM, BK, WM, WN, LM>), dim3(T * (T + 1) / 2, K), dim3(Cfg::NT), 0, st, A, B, C, C2, E,
-                       coef, p);
+    hipLaunchKernelGGL((k_symm_tn<BM, BK, WM, WN, LM>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(Cfg::NT), 0, st, A, B, C,
+                       C2, E, coef, K, p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -172,7 +219,7 @@ template <int BM, int BK, int WM, int WN>
 __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_gemm_nt_right(const double* __restrict__ A,
                                                                       const double* __restrict__ T,
                                                                       double* __restrict__ C,
-                                                                      const double* __restrict__ scal, int K, int p)
+                                                                      const double* __restrict__ scal, int nbatch, int K, int p)
 {
     constexpr int NWC = BM / WN, NT = sym_nt(BM, WM, WN), TI = WM / 16, TJ = WN / 16;
     constexpr int LDA = BK + 2;      // A tile [BM][BK]: (2 i + k) mod 32 distinct over a half wave
@@ -180,9 +227,11 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_gemm_nt_right(const doub
     __shared__ __attribute__((aligned(16))) double smem[BM * LDA + BK * LDB];
     double* As = smem;
     double* Bs = smem + BM * LDA;
-    const int b = blockIdx.y, kt = b % K;
     const int Tn = (p + BM - 1) / BM;
-    const int I0 = (blockIdx.x / Tn) * BM, J0 = (blockIdx.x % Tn) * BM;
+    int b, tile;
+    if (!decode_block_xcd(Tn * Tn, nbatch, b, tile)) return;
+    const int kt = b % K;
+    const int I0 = (tile / Tn) * BM, J0 = (tile % Tn) * BM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = (wave / NWC) * WM, wc = (wave % NWC) * WN;
     const size_t pp = (size_t)p * p;
@@ -203,24 +252,26 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_gemm_nt_right(const doub
     auto fetch = [&](int m0) {
 #pragma unroll
         for (int q = 0; q < LPT; ++q) {
-            const int i = I0 + arow + q * (NT / BK), m = m0 + acol;
-            ra[q] = (i < p && m < p) ? Ab[(size_t)i * p + m] : 0.0;
-            const int mb = m0 + brow + q * (NT / BM), j = J0 + bcol;
-            rb[q] = (mb < p && j < p) ? Tb[(size_t)mb * p + j] : 0.0;
+            const int i = min(I0 + arow + q * (NT / BK), p - 1), m = min(m0 + acol, p - 1);
+            ra[q] = Ab[(size_t)i * p + m];
+            const int mb = min(m0 + brow + q * (NT / BM), p - 1), j = min(J0 + bcol, p - 1);
+            rb[q] = Tb[(size_t)mb * p + j];
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](int m0) {
 #pragma unroll
         for (int q = 0; q < LPT; ++q) {
-            As[(arow + q * (NT / BK)) * LDA + acol] = ra[q];
-            Bs[(brow + q * (NT / BM)) * LDB + bcol] = rb[q];
+            const bool ina = (I0 + arow + q * (NT / BK)) < p && (m0 + acol) < p;
+            const bool inb = (m0 + brow + q * (NT / BM)) < p && (J0 + bcol) < p;
+            As[(arow + q * (NT / BK)) * LDA + acol] = ina ? ra[q] : 0.0;
+            Bs[(brow + q * (NT / BM)) * LDB + bcol] = inb ? rb[q] : 0.0;
         }
     };
     fetch(0);
     for (int m0 = 0; m0 < p; m0 += BK) {
-        stage();
+        stage(m0);
         __syncthreads();
-        if (m0 + BK < p) fetch(m0 + BK);
+        fetch(m0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             const int kq = kk * 4 + (lane >> 4);
@@ -256,14 +307,62 @@ void launch_gemm_right(hipStream_t st, const double* A, const double* T, double*
 {
     if (variant == 1) {
         const int Tn = (p + 127) / 128;
-        hipLaunchKernelGGL((k_gemm_nt_right<128, 16, 32, 64>), dim3(Tn * Tn, nbatch), dim3(512), 0, st, A, T, C, scal, K, p);
+        hipLaunchKernelGGL((k_gemm_nt_right<128, 16, 32, 64>), dim3(xcd_grid(Tn * Tn, nbatch)), dim3(512), 0, st, A, T, C, scal, nbatch, K, p);
     } else {
         const int Tn = (p + 63) / 64;
-        hipLaunchKernelGGL((k_gemm_nt_right<64, 32, 32, 32>), dim3(Tn * Tn, nbatch), dim3(256), 0, st, A, T, C, scal, K, p);
+        hipLaunchKernelGGL((k_gemm_nt_right<64, 32, 32, 32>), dim3(xcd_grid(Tn * Tn, nbatch)), dim3(256), 0, st, A, T, C, scal, nbatch, K, p);
     }
 }
 
-int symm_variants() { return 6; }
+// FP64 matrix-core ceiling probe: every wave issues `iters` x NACC MFMAs on NACC independent accumulators.
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_f64_peak(double* __restrict__ out, int iters)
+{
+    v4d acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NACC>
+static double mfma_probe(hipStream_t st, double* scratch, int blocks, int iters)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_mfma_f64_peak<NACC>, dim3(blocks), dim3(256), 0, st, scratch, 16);
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(k_mfma_f64_peak<NACC>, dim3(blocks), dim3(256), 0, st, scratch, iters);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double flops = (double)blocks * 4.0 * iters * NACC * 2.0 * 16 * 16 * 4;
+    return flops / (ms * 1e-3) / 1e12;
+}
+
+// nacc in {1,2,4,8}; blocks = workgroups of 4 waves (256 per "one wave per SIMD" layer)
+double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nacc)
+{
+    switch (nacc) {
+        case 1: return mfma_probe<1>(st, scratch, blocks, iters);
+        case 2: return mfma_probe<2>(st, scratch, blocks, iters);
+        case 4: return mfma_probe<4>(st, scratch, blocks, iters);
+        default: return mfma_probe<8>(st, scratch, blocks, iters);
+    }
+}
+
+int symm_variants() { return 8; }
 
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                  const double* coef, int K, int p, int variant)
@@ -279,6 +378,16 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, C2, E, coef, K, p); break;
         case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, C2, E, coef, K, p); break;
         case 5: launch_cfg<128, 32, 64, 64, false>(st, A, B, C, C2, E, coef, K, p); break;
+        case 6: {   // ablation of variant 0: no global loads
+            const int T = (p + 63) / 64;
+            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 1>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p);
+            break;
+        }
+        case 7: {   // ablation of variant 0: no MFMA
+            const int T = (p + 63) / 64;
+            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 2>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p);
+            break;
+        }
         default: launch_cfg<64, 16, 32, 32, true>(st, A, B, C, C2, E, coef, K, p); break;
     }
 }

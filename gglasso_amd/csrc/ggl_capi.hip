@@ -160,8 +160,9 @@ static int ctx_alloc(ggl_ctx* c)
         const size_t cl = (size_t)3 * NS_MAX_STEPS * c->K * 5 * sizeof(double);
         HIPCHK(hipMalloc(&c->coef, cl));
         HIPCHK(hipHostMalloc(&c->coef_h, cl));
-        HIPCHK(hipMalloc(&c->bounds, 2 * (size_t)c->K * sizeof(double)));
-        HIPCHK(hipHostMalloc(&c->bounds_h, 2 * (size_t)c->K * sizeof(double)));
+        const size_t bl = 2 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);
+        HIPCHK(hipMalloc(&c->bounds, bl));
+        HIPCHK(hipHostMalloc(&c->bounds_h, bl));
     }
     return GGL_OK;
 }
@@ -385,9 +386,19 @@ extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* 
         launch_norm_bounds(c->stream, c->W, c->K, c->p, c->bounds);
         PE(c, GGL_PH_FORM_W);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->bounds_h, c->bounds, 2 * (size_t)c->K * sizeof(double), hipMemcpyDeviceToHost,
-                              c->stream));
+        const int nbb = norm_bounds_blocks(c->p);
+        HIPCHK(hipMemcpyAsync(c->bounds_h, c->bounds, 2 * (size_t)c->K * nbb * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < c->K; ++k) {   // finish the reduction over row blocks into slot [k][0]
+            double mx = 0.0, sq = 0.0;
+            for (int b = 0; b < nbb; ++b) {
+                mx = std::max(mx, c->bounds_h[2 * ((size_t)k * nbb + b)]);
+                sq += c->bounds_h[2 * ((size_t)k * nbb + b) + 1];
+            }
+            c->bounds_h[2 * k] = mx;         // k <= k*nbb: never overwrites an unread entry
+            c->bounds_h[2 * k + 1] = sq;
+        }
         NsPlan plan;
         if (ns_plan(c->bounds_h, c->par_h, c->K, c->coef_h, &plan, c->ns_force) != 0)
             return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");
@@ -836,6 +847,25 @@ extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* 
     (void)hipEventDestroy(e1);
     HIPCHK(hipGetLastError());
     *ms_out = ms / iters;
+    return GGL_OK;
+}
+
+extern "C" int ggl_dev_mfma_f64_peak(double* tflops_out)
+{
+    ARGCHK(tflops_out, "tflops_out");
+    const int blocks = 256 * 8;
+    DevBuf d;
+    HIPCHK(d.alloc((size_t)blocks * 256));
+    double best = 0.0;
+    for (int r = 0; r < 3; ++r) best = std::max(best, mfma_f64_peak_tflops(nullptr, d.p, blocks, 2000, 8));
+    HIPCHK(hipGetLastError());
+    if (getenv("GGL_MFMA_PROBE_VERBOSE")) {
+        for (int layers : {1, 2, 4, 8})
+            for (int nacc : {1, 2, 4, 8})
+                fprintf(stderr, "mfma f64 probe: %d wave(s)/SIMD, %d accumulators: %.1f TF/s\n", layers, nacc,
+                        mfma_f64_peak_tflops(nullptr, d.p, 256 * layers, 4000, nacc));
+    }
+    *tflops_out = best;
     return GGL_OK;
 }
 

@@ -96,6 +96,8 @@ int symm_variants();
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                  const double* coef, int K, int p, int variant);
 
+// measured FP64 matrix-core ceiling (MFMA-only probe kernel)
+double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nacc);
 // C[b] = scal[b % K] * A[b] * T[b % K] (T symmetric, A general), b < nbatch; full output.  FP64 MFMA.
 void launch_gemm_right(hipStream_t st, const double* A, const double* T, double* C, const double* scal,
                        int nbatch, int K, int p, int variant);
@@ -108,8 +110,9 @@ struct NsPlan { int steps = 0; int products = 0; bool stable = false; double kap
 // W = ((Theta - L) - X) - beta_k S from the lower triangle, mirrored (exactly symmetric)
 void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
                        const double* S, const double* betaK, int K, int p);
-// bounds[k] = {|W_k|_inf, |W_k|_F^2}
-void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* bounds);
+// part[k][blk] = {max row abs-sum, sum of squares} of row block blk; nblk = norm_bounds_blocks(p)
+int norm_bounds_blocks(int p);
+void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* part);
 // host: scaling schedule from the norm bounds; fills coef_h[(3*NS_MAX_STEPS)*K*5]; returns 0 or -1
 // force_mode: 0 choose by condition number, 1 all-symmetric products, 2 stable (unsymmetrised) products
 int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h, NsPlan* plan, int force_mode);

@@ -77,36 +77,42 @@ void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const dou
         hipLaunchKernelGGL(k_form_W_sym<false>, grid, blk, 0, st, W, Theta, L, X, S, betaK, p);
 }
 
-// bounds[k] = { max_i sum_j |W_ij| , sum_ij W_ij^2 }: both bound |W|_2 (infinity norm, Frobenius norm^2)
-__global__ __launch_bounds__(256) void k_norm_bounds(const double* __restrict__ W, int p, double* __restrict__ bounds)
+// Norm bounds of W: part[k][blk] = { max_i sum_j |W_ij| , sum_ij W_ij^2 } over the 64 rows of row-block
+// blk (one wave per 16 rows).  The host finishes the reduction (max / sum over the blocks, fixed order).
+static constexpr int NB_ROWS = 64;
+
+int norm_bounds_blocks(int p) { return (p + NB_ROWS - 1) / NB_ROWS; }
+
+__global__ __launch_bounds__(256) void k_norm_bounds(const double* __restrict__ W, int p, double* __restrict__ part)
 {
     __shared__ double sh_abs[4], sh_sq[4];
-    const int k = blockIdx.x;
+    const int k = blockIdx.y;
     const double* w = W + (size_t)k * p * p;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * NB_ROWS + wave * 16;
     double mx = 0.0, sq = 0.0;
-    for (int i = wave; i < p; i += 4) {
+    for (int i = r0; i < min(r0 + 16, p); ++i) {
         double a = 0.0;
         for (int j = lane; j < p; j += 64) {
             const double v = w[(size_t)i * p + j];
             a += fabs(v);
             sq += v * v;
         }
-        a = wave_sum(a);
-        mx = fmax(mx, a);
+        mx = fmax(mx, wave_sum(a));
     }
     sq = wave_sum(sq);
     if (lane == 0) { sh_abs[wave] = mx; sh_sq[wave] = sq; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        bounds[2 * k + 0] = fmax(fmax(sh_abs[0], sh_abs[1]), fmax(sh_abs[2], sh_abs[3]));
-        bounds[2 * k + 1] = (sh_sq[0] + sh_sq[1]) + (sh_sq[2] + sh_sq[3]);
+        double* o = part + 2 * ((size_t)k * gridDim.x + blockIdx.x);
+        o[0] = fmax(fmax(sh_abs[0], sh_abs[1]), fmax(sh_abs[2], sh_abs[3]));
+        o[1] = (sh_sq[0] + sh_sq[1]) + (sh_sq[2] + sh_sq[3]);
     }
 }
 
-void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* bounds)
+void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* part)
 {
-    hipLaunchKernelGGL(k_norm_bounds, dim3(K), dim3(256), 0, st, W, p, bounds);
+    hipLaunchKernelGGL(k_norm_bounds, dim3(norm_bounds_blocks(p), K), dim3(256), 0, st, W, p, part);
 }
 
 // ---------------------------------------------------------------------------------------------

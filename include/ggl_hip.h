@@ -141,6 +141,8 @@ int ggl_profile_read(ggl_ctx *ctx, double ms[GGL_NPHASE], long long count[GGL_NP
 int ggl_dev_symm(int K, int p, const double *A, const double *B, const double *E, const double *coef5K,
                  double *C, double *C2, int variant);
 int ggl_dev_symm_bench(int K, int p, int variant, int iters, double *ms_out);
+/* measured FP64 matrix-core ceiling of this GPU in TFLOP/s (MFMA-only probe kernel) */
+int ggl_dev_mfma_f64_peak(double *tflops_out);
 
 /* ---- stateless operator entry points (host buffers; used for operator-level parity) ---------- */
 /* numpy.linalg.eigh on a stack (lower triangle read); D (K,p) ascending, Q (K,p,p) columns. */
