@@ -54,6 +54,7 @@ struct ggl_ctx {
     double* par = nullptr;    // device: beta[K] | l1[K] | mu[K] | nk[K]
     double* par_h = nullptr;  // pinned mirror
     double *mask = nullptr, *groupsq = nullptr;   // (p,p)
+    double* sqwork = nullptr;                     // (ggl_chunks, p, p) per-chunk sums of squares
     bool has_mask = false;
     double* partials = nullptr;
     size_t partials_len = 0;
@@ -143,6 +144,7 @@ static int ctx_alloc(ggl_ctx* c)
     HIPCHK(hipMalloc(&c->mask, (size_t)c->p * c->p * sizeof(double)));
     HIPCHK(hipMalloc(&c->groupsq, (size_t)c->p * c->p * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->groupsq, 0, (size_t)c->p * c->p * sizeof(double), c->stream));
+    HIPCHK(hipMalloc(&c->sqwork, (size_t)ggl_chunks(c->K, c->p) * c->p * c->p * sizeof(double)));
     size_t pl = (size_t)c->K * elementwise_blocks(c->p) * GGL_NNORM;
     pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_GGL, c->K) * GGL_NNORM);
     pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_FGL, c->K) * GGL_NNORM);
@@ -214,7 +216,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
-                      c->nsT, c->coef, c->bounds};
+                      c->nsT, c->coef, c->bounds, c->sqwork};
     if (c->coef_h) (void)hipHostFree(c->coef_h);
     if (c->bounds_h) (void)hipHostFree(c->bounds_h);
     for (double* b : bufs)
@@ -434,7 +436,8 @@ extern "C" int ggl_step_group_partial(ggl_ctx* c, double rho, double lambda1)
     ARGCHK(c, "ctx");
     ARGCHK(rho > 0, "rho must be positive");
     HIPCHK(hipSetDevice(c->device));
-    launch_group_partial(c->stream, c->groupsq, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
+    launch_group_partial(c->stream, c->sqwork, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
+    launch_sum_chunks(c->stream, c->groupsq, c->sqwork, ggl_chunks(c->K, c->p), c->p);
     HIPCHK(hipGetLastError());
     return GGL_OK;
 }
@@ -488,7 +491,8 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
         ARGCHK(lambda1 > 0 && lambda2 > 0, "lambda1, lambda2 must be positive");
         PB(c, GGL_PH_THETA);
         HIPCHK(launch_theta_pair(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, l1, l2,
-                                 groupsq_ready ? c->groupsq : nullptr, latent ? 0 : 1, c->partials, c->K, c->p));
+                                 groupsq_ready ? c->groupsq : nullptr, c->sqwork, latent ? 0 : 1, c->partials, c->K,
+                                 c->p));
         PE(c, GGL_PH_THETA);
         if (!latent) {
             PB(c, GGL_PH_REDUCE);
@@ -677,7 +681,7 @@ extern "C" int ggl_kkt_residual(ggl_ctx* c, double rho, double lambda1, double l
             launch_prox_od(c->stream, T2 + (size_t)k * c->p * c->p, T1 + (size_t)k * c->p * c->p, lambda1,
                            c->has_mask ? c->mask : nullptr, c->p);
     } else {
-        HIPCHK(launch_prox_p(c->stream, reg, T2, T1, lambda1, lambda2, c->K, c->p));
+        HIPCHK(launch_prox_p(c->stream, reg, T2, T1, lambda1, lambda2, c->K, c->p, c->sqwork));
     }
     if ((rc = stack_sq(c, c->Theta, T2, &v))) return rc;
     double res = std::sqrt(v) / (1.0 + nTheta);
@@ -958,11 +962,12 @@ extern "C" int ggl_prox_p(int K, int p, const double* X, double l1, double l2, i
     ARGCHK(reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
     ARGCHK(l1 > 0 && l2 > 0, "lambda 1 and lambda2 have to be positive");
     const size_t n = (size_t)K * p * p;
-    DevBuf dX, dO;
+    DevBuf dX, dO, dW;
     HIPCHK(dX.alloc(n));
     HIPCHK(dO.alloc(n));
+    HIPCHK(dW.alloc((size_t)ggl_chunks(K, p) * p * p));
     UP(dX.p, X, n);
-    HIPCHK(launch_prox_p(nullptr, reg, dO.p, dX.p, l1, l2, K, p));
+    HIPCHK(launch_prox_p(nullptr, reg, dO.p, dX.p, l1, l2, K, p, dW.p));
     HIPCHK(hipDeviceSynchronize());
     DOWN(out, dO.p, n);
     return GGL_OK;

@@ -55,16 +55,21 @@ int pair_blocks(int p, int reg, int K);
 //   fuse_dual == 0 (latent): writes Theta and C = (Theta - X) - Omega  (admm_solver.py:198).
 // groupsq != null (GGL only): use this (p,p) array as sum_k u^2 instead of computing it (K-sharded).
 // Returns hipErrorInvalidValue if K is beyond what the FGL kernel's LDS scan buffer holds.
+// sqwork: ggl_chunks(K,p)*p*p doubles of scratch for the GGL sums of squares (unused when groupsq is given).
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C,
                              const double* Omega, const double* OmegaPrev, const double* L,
-                             double l1, double l2, const double* groupsq, int fuse_dual,
+                             double l1, double l2, const double* groupsq, double* sqwork, int fuse_dual,
                              double* partials, int K, int p);
-// GGL pass 1 only: groupsq(p,p)[i<j] = sum_k soft(Omega+L+X, l1)^2
-void launch_group_partial(hipStream_t st, double* groupsq, const double* Omega, const double* L,
+// number of K-chunks the GGL kernels split the stack into (grid.y)
+int ggl_chunks(int K, int p);
+// GGL pass 1 only: sq[c](p,p)[i<j] = sum_{k in chunk c} soft(Omega+L+X, l1)^2,  c < ggl_chunks(K,p)
+void launch_group_partial(hipStream_t st, double* sq, const double* Omega, const double* L,
                           const double* X, double l1, int K, int p);
+// out(p,p) = sum_c sq[c]
+void launch_sum_chunks(hipStream_t st, double* out, const double* sq, int nsq, int p);
 // stateless prox_p: out = prox_p(V)   (V symmetric stack; upper triangle decides)
 hipError_t launch_prox_p(hipStream_t st, int reg, double* out, const double* V, double l1, double l2,
-                         int K, int p);
+                         int K, int p, double* sqwork);
 // P_val partials (ggl_helper.py:162-176): partials[b] per block, nblk = pair_blocks(p, GGL, K)
 void launch_pval(hipStream_t st, int reg, const double* Theta, double l1, double l2, int K, int p,
                  double* partials);

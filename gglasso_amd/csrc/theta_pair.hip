@@ -33,22 +33,99 @@ static inline int ntiles(int p, int t) { return (p + t - 1) / t; }
 static inline int fgl_tile(int K) { return (K <= 32) ? 16 : 8; }
 static constexpr int FGL_MAX_K_TD8 = (160 * 1024 - 1024) / (8 * 8 * 8);   // LDS scan buffer bound
 
+int ggl_chunks(int K, int p);
+
 int pair_blocks(int p, int reg, int K)
 {
-    int T = (reg == 2) ? ntiles(p, fgl_tile(K)) : ntiles(p, PT);
-    return T * (T + 1) / 2;
+    if (reg == 2) {
+        const int T = ntiles(p, fgl_tile(K));
+        return T * (T + 1) / 2;
+    }
+    const int T = ntiles(p, PT);
+    return T * (T + 1) / 2 * ggl_chunks(K, p);
 }
 
 // ---------------------------------------------------------------------------------------------
-// GGL
+// GGL.  Two kernels so that the work spreads over (tile pair) x (K-chunk) workgroups:
+//   k_group_partial: sq[c][i][j] = sum over the k of chunk c of soft(Omega+L+X, l1)^2      (i<j)
+//   k_theta_ggl:     ss = sum_c sq[c][i][j]; theta for the k of its chunk; mirror; dual update; norms
+// A K-sharded run all-reduces the (p,p) sum between the two (gglasso_amd/dist.py).
 // ---------------------------------------------------------------------------------------------
+int ggl_chunks(int K, int p)
+{
+    const int T = ntiles(p, PT);
+    const int pairs = T * (T + 1) / 2;
+    int kc = (1024 + pairs - 1) / pairs;      // aim at >= ~1024 workgroups
+    if (kc < 1) kc = 1;
+    if (kc > K) kc = K;
+    const int len = (K + kc - 1) / kc;        // k per chunk
+    return (K + len - 1) / len;
+}
+static inline int ggl_chunk_len(int K, int p)
+{
+    const int kc = ggl_chunks(K, p);
+    return (K + kc - 1) / kc;
+}
+
+__global__ __launch_bounds__(256) void k_group_partial(double* __restrict__ sq, const double* __restrict__ Omega,
+                                                       const double* __restrict__ L, const double* __restrict__ X,
+                                                       double l1, int K, int p, int klen)
+{
+    const int T = (p + PT - 1) / PT;
+    int I, J;
+    decode_pair(blockIdx.x, T, I, J);
+    const bool diag = (I == J);
+    const int I0 = I * PT, J0 = J * PT;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const size_t pp = (size_t)p * p;
+    const int k0 = blockIdx.y * klen, k1 = min(K, k0 + klen);
+    double ss[PQ];
+    size_t off[PQ];
+    bool ok[PQ];
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        const int r = ty + PTY * q;
+        ok[q] = (I0 + r < p) && (J0 + tx < p) && (!diag || r < tx);
+        off[q] = (size_t)(I0 + r) * p + (J0 + tx);
+        ss[q] = 0.0;
+    }
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+        const size_t base = (size_t)k * pp;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            if (ok[q]) {
+                double v = Omega[base + off[q]];
+                if (L) v += L[base + off[q]];
+                if (X) v += X[base + off[q]];
+                const double u = soft(v, l1);
+                ss[q] += u * u;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PQ; ++q)
+        if (ok[q]) sq[(size_t)blockIdx.y * pp + off[q]] = ss[q];
+}
+
+// out[i][j] = sum_c sq[c][i][j]   (upper triangle entries only matter)
+__global__ __launch_bounds__(256) void k_sum_chunks(double* __restrict__ out, const double* __restrict__ sq, int nsq,
+                                                    size_t pp)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pp; i += (size_t)gridDim.x * 256) {
+        double s = 0.0;
+        for (int c = 0; c < nsq; ++c) s += sq[(size_t)c * pp + i];
+        out[i] = s;
+    }
+}
+
 template <bool FUSE_DUAL>
 __global__ __launch_bounds__(256) void k_theta_ggl(double* __restrict__ Theta, double* __restrict__ X,
                                                    double* __restrict__ C, const double* __restrict__ Omega,
                                                    const double* __restrict__ OmegaPrev,
                                                    const double* __restrict__ L, double l1, double l2,
-                                                   const double* __restrict__ groupsq,
-                                                   double* __restrict__ partials, int K, int p)
+                                                   const double* __restrict__ sq, int nsq,
+                                                   double* __restrict__ partials, int K, int p, int klen)
 {
     __shared__ double tile[2][PT][PT + 1];
     __shared__ double scratch[GGL_NNORM * 4];
@@ -59,9 +136,11 @@ __global__ __launch_bounds__(256) void k_theta_ggl(double* __restrict__ Theta, d
     const int I0 = I * PT, J0 = J * PT;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const size_t pp = (size_t)p * p;
+    const int k0 = blockIdx.y * klen, k1 = min(K, k0 + klen);
 
     bool up_ok[PQ], pr_ok[PQ], lo_ok[PQ];
     size_t up_off[PQ], lo_off[PQ];
+    double amul[PQ], adiv[PQ];   // theta = u * (a - l2) / a     (ggl_helper.py:38-43)
 #pragma unroll
     for (int q = 0; q < PQ; ++q) {
         const int r = ty + PTY * q;
@@ -70,44 +149,29 @@ __global__ __launch_bounds__(256) void k_theta_ggl(double* __restrict__ Theta, d
         up_off[q] = (size_t)(I0 + r) * p + (J0 + tx);
         lo_ok[q] = (J0 + r < p) && (I0 + tx < p) && (!diag || r > tx);   // element (J0+r, I0+tx)
         lo_off[q] = (size_t)(J0 + r) * p + (I0 + tx);
-    }
-
-    // sweep 1: sum_k soft(v,l1)^2 per pair
-    double ss[PQ];
-#pragma unroll
-    for (int q = 0; q < PQ; ++q) ss[q] = 0.0;
-    if (groupsq) {
-#pragma unroll
-        for (int q = 0; q < PQ; ++q)
-            if (pr_ok[q]) ss[q] = groupsq[up_off[q]];
-    } else {
-        for (int k = 0; k < K; ++k) {
-            const size_t base = (size_t)k * pp;
-#pragma unroll
-            for (int q = 0; q < PQ; ++q) {
-                if (pr_ok[q]) {
-                    double v = Omega[base + up_off[q]];
-                    if (L) v += L[base + up_off[q]];
-                    if (X) v += X[base + up_off[q]];
-                    const double u = soft(v, l1);
-                    ss[q] += u * u;
-                }
-            }
-        }
-    }
-    double amul[PQ], adiv[PQ];   // theta = u * (a - l2) / a     (ggl_helper.py:38-43)
-#pragma unroll
-    for (int q = 0; q < PQ; ++q) {
-        const double a = fmax(sqrt(ss[q]), l2);
+        double ss = 0.0;
+        if (pr_ok[q])
+            for (int c = 0; c < nsq; ++c) ss += sq[(size_t)c * pp + up_off[q]];
+        const double a = fmax(sqrt(ss), l2);
         amul[q] = a - l2;
         adiv[q] = a;
     }
 
-    // sweep 2
     double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
-    for (int k = 0; k < K; ++k) {
+    for (int k = k0; k < k1; ++k) {
         const size_t base = (size_t)k * pp;
-        const int buf = k & 1;
+        const int buf = (k - k0) & 1;
+        // issue the lower-role loads early: they do not depend on the LDS hand-off
+        double lom[PQ], lx[PQ], lop[PQ];
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            lom[q] = lx[q] = lop[q] = 0.0;
+            if (lo_ok[q]) {
+                const size_t o = base + lo_off[q];
+                if (FUSE_DUAL) { lom[q] = Omega[o]; lx[q] = X[o]; lop[q] = OmegaPrev[o]; }
+                else if (C) { lom[q] = Omega[o]; lx[q] = X[o]; }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
             if (up_ok[q]) {
@@ -141,23 +205,22 @@ __global__ __launch_bounds__(256) void k_theta_ggl(double* __restrict__ Theta, d
                 const double th = tile[buf][tx][ty + PTY * q];
                 Theta[o] = th;
                 if (FUSE_DUAL) {
-                    const double om = Omega[o], x = X[o];
-                    const double xn = x + (om - th);
+                    const double om = lom[q];
+                    const double xn = lx[q] + (om - th);
                     X[o] = xn;
-                    const double dp = om - OmegaPrev[o];
+                    const double dp = om - lop[q];
                     acc[0] += om * om;
                     acc[1] += th * th;
                     acc[2] += xn * xn;
                     acc[3] += (om - th) * (om - th);
                     acc[4] += dp * dp;
                 } else if (C) {
-                    C[o] = (th - X[o]) - Omega[o];
+                    C[o] = (th - lx[q]) - lom[q];
                 }
             }
         }
     }
     if (FUSE_DUAL) {
-        // block_sum indexes waves by threadIdx.x; flatten the 32x8 block first
         const int lane = (ty * PT + tx) & 63, wid = (ty * PT + tx) >> 6;
 #pragma unroll
         for (int v = 0; v < GGL_NNORM; ++v) acc[v] = wave_sum(acc[v]);
@@ -167,7 +230,7 @@ __global__ __launch_bounds__(256) void k_theta_ggl(double* __restrict__ Theta, d
         }
         __syncthreads();
         if (tx == 0 && ty == 0) {
-            double* o = partials + (size_t)blockIdx.x * GGL_NNORM;
+            double* o = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GGL_NNORM;
 #pragma unroll
             for (int v = 0; v < GGL_NNORM; ++v)
                 o[v] = (scratch[v] + scratch[GGL_NNORM + v]) + (scratch[2 * GGL_NNORM + v] + scratch[3 * GGL_NNORM + v]);
@@ -175,41 +238,21 @@ __global__ __launch_bounds__(256) void k_theta_ggl(double* __restrict__ Theta, d
     }
 }
 
-// sweep 1 alone, for K-sharded runs: groupsq[i,j] (i<j) = sum over the local slab
-__global__ __launch_bounds__(256) void k_group_partial(double* __restrict__ groupsq, const double* __restrict__ Omega,
-                                                       const double* __restrict__ L, const double* __restrict__ X,
-                                                       double l1, int K, int p)
-{
-    const int T = (p + PT - 1) / PT;
-    int I, J;
-    decode_pair(blockIdx.x, T, I, J);
-    const bool diag = (I == J);
-    const int I0 = I * PT, J0 = J * PT;
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const size_t pp = (size_t)p * p;
-#pragma unroll
-    for (int q = 0; q < PQ; ++q) {
-        const int r = ty + PTY * q;
-        const bool ok = (I0 + r < p) && (J0 + tx < p) && (!diag || r < tx);
-        if (!ok) continue;
-        const size_t off = (size_t)(I0 + r) * p + (J0 + tx);
-        double ss = 0.0;
-        for (int k = 0; k < K; ++k) {
-            double v = Omega[(size_t)k * pp + off];
-            if (L) v += L[(size_t)k * pp + off];
-            v += X[(size_t)k * pp + off];
-            const double u = soft(v, l1);
-            ss += u * u;
-        }
-        groupsq[off] = ss;
-    }
-}
-
-void launch_group_partial(hipStream_t st, double* groupsq, const double* Omega, const double* L,
-                          const double* X, double l1, int K, int p)
+// sq: ggl_chunks(K,p) * p * p doubles.  Writes the per-chunk partial sums of squares.
+void launch_group_partial(hipStream_t st, double* sq, const double* Omega, const double* L, const double* X,
+                          double l1, int K, int p)
 {
     const int T = ntiles(p, PT);
-    hipLaunchKernelGGL(k_group_partial, dim3(T * (T + 1) / 2), dim3(PT, PTY), 0, st, groupsq, Omega, L, X, l1, K, p);
+    hipLaunchKernelGGL(k_group_partial, dim3(T * (T + 1) / 2, ggl_chunks(K, p)), dim3(PT, PTY), 0, st, sq, Omega, L, X,
+                       l1, K, p, ggl_chunk_len(K, p));
+}
+
+void launch_sum_chunks(hipStream_t st, double* out, const double* sq, int nsq, int p)
+{
+    const size_t pp = (size_t)p * p;
+    int blocks = (int)((pp + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_sum_chunks, dim3(blocks), dim3(256), 0, st, out, sq, nsq, pp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -407,15 +450,24 @@ static hipError_t launch_fgl_td(hipStream_t st, double* Theta, double* X, double
 
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C, const double* Omega,
                              const double* OmegaPrev, const double* L, double l1, double l2,
-                             const double* groupsq, int fuse_dual, double* partials, int K, int p)
+                             const double* groupsq, double* sqwork, int fuse_dual, double* partials, int K, int p)
 {
     if (reg == 1) {
         const int T = ntiles(p, PT);
-        dim3 grid(T * (T + 1) / 2), blk(PT, PTY);
+        const int kc = ggl_chunks(K, p), klen = ggl_chunk_len(K, p);
+        dim3 grid(T * (T + 1) / 2, kc), blk(PT, PTY);
+        const double* sq = groupsq;
+        int nsq = 1;
+        if (!sq) {   // single rank: per-chunk sums of squares, summed on the fly by the second kernel
+            if (!sqwork) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(k_group_partial, grid, blk, 0, st, sqwork, Omega, L, X, l1, K, p, klen);
+            sq = sqwork;
+            nsq = kc;
+        }
         if (fuse_dual)
-            hipLaunchKernelGGL(k_theta_ggl<true>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, groupsq, partials, K, p);
+            hipLaunchKernelGGL(k_theta_ggl<true>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, sq, nsq, partials, K, p, klen);
         else
-            hipLaunchKernelGGL(k_theta_ggl<false>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, groupsq, partials, K, p);
+            hipLaunchKernelGGL(k_theta_ggl<false>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, sq, nsq, partials, K, p, klen);
         return hipGetLastError();
     }
     if (K > FGL_MAX_K_TD8) return hipErrorInvalidValue;
@@ -424,9 +476,11 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
     return launch_fgl_td<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p);
 }
 
-hipError_t launch_prox_p(hipStream_t st, int reg, double* out, const double* V, double l1, double l2, int K, int p)
+hipError_t launch_prox_p(hipStream_t st, int reg, double* out, const double* V, double l1, double l2, int K, int p,
+                         double* sqwork)
 {
-    return launch_theta_pair(st, reg, out, nullptr, nullptr, V, nullptr, nullptr, l1, l2, nullptr, 0, nullptr, K, p);
+    return launch_theta_pair(st, reg, out, nullptr, nullptr, V, nullptr, nullptr, l1, l2, nullptr, sqwork, 0, nullptr, K,
+                             p);
 }
 
 // ---------------------------------------------------------------------------------------------
