@@ -643,7 +643,7 @@ extern "C" int ggl_objective(ggl_ctx* c, double lambda1, double lambda2, int reg
         }
     }
     out[0] = ld;
-    const int nb = pair_blocks(c->p, GGL_REG_GGL, c->K);
+    const int nb = pval_blocks(c->p);
     launch_pval(c->stream, reg, c->Theta, lambda1, lambda2, c->K, c->p, c->partials);
     launch_reduce_partials(c->stream, c->partials, 1, nb, 1, c->norms);
     HIPCHK(hipGetLastError());

@@ -70,7 +70,8 @@ void launch_sum_chunks(hipStream_t st, double* out, const double* sq, int nsq, i
 // stateless prox_p: out = prox_p(V)   (V symmetric stack; upper triangle decides)
 hipError_t launch_prox_p(hipStream_t st, int reg, double* out, const double* V, double l1, double l2,
                          int K, int p, double* sqwork);
-// P_val partials (ggl_helper.py:162-176): partials[b] per block, nblk = pair_blocks(p, GGL, K)
+// P_val partials (ggl_helper.py:162-176): partials[b] per block, nblk = pval_blocks(p)
+int pval_blocks(int p);
 void launch_pval(hipStream_t st, int reg, const double* Theta, double l1, double l2, int K, int p,
                  double* partials);
 // n independent K-vectors (n,K) row-major: mode 0 prox_tv, 1 prox_2norm, 2 prox_phi_ggl, 3 prox_phi_fgl

@@ -35,6 +35,12 @@ static constexpr int FGL_MAX_K_TD8 = (160 * 1024 - 1024) / (8 * 8 * 8);   // LDS
 
 int ggl_chunks(int K, int p);
 
+int pval_blocks(int p)
+{
+    const int T = ntiles(p, PT);
+    return T * (T + 1) / 2;
+}
+
 int pair_blocks(int p, int reg, int K)
 {
     if (reg == 2) {
