@@ -65,6 +65,22 @@ def phase_model(phase, reg, K, p, latent, eig_jacobi, omega_ns=False):
     return "hbm", 0.0, "GB/s"
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of this same command
+    (tools/profile_round.sh -> tools/summarize_pmc.py -> profiles/*_pmc_summary.json; FETCH_SIZE and
+    WRITE_SIZE are collected in separate rocprofv3 runs).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None
+    data = json.load(open(files[-1]))
+    key = kernel_name.split(" ")[0]
+    for name, c in data.items():
+        if name.startswith(key) and "hbm_bytes_per_launch" in c:
+            return c["hbm_bytes_per_launch"]
+    return None
+
+
 def quiet(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)
@@ -192,7 +208,7 @@ def main():
                                                                          else "rocsolver_dsyevd+mfma_recon")},
             "roofline": {"kernel": kernel_name, "phase": dom, "launches_per_step": phases[dom]["launches"] / args.steps,
                          "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": pmc_traffic(kernel_name),
                          "ms_per_launch": phases[dom]["ms_per_launch"]},
             "iteration_hbm_roofline": {"algorithmic_bytes": iter_bytes, "achieved_GBs": its * iter_bytes / 1e9,
                                        "frac": its * iter_bytes / 1e9 / HBM_PEAK_GBS},

@@ -117,23 +117,27 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
             Bs[row * Cfg::LDS_LD + lcol] = (in && bok) ? xb[q] : 0.0;
         }
     };
+    // all fragment reads of the slab first, then the MFMAs back to back: one LDS round trip per slab
+    // instead of one per k-quad
     auto compute = [&]() {
+        double af[BK / 4][Cfg::TI], bf[BK / 4][Cfg::TJ];
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             const int row = kk * 4 + (lane >> 4);
-            double af[Cfg::TI], bf[Cfg::TJ];
 #pragma unroll
-            for (int i = 0; i < Cfg::TI; ++i) af[i] = As[row * Cfg::LDS_LD + wr + i * 16 + (lane & 15)];
+            for (int i = 0; i < Cfg::TI; ++i) af[kk][i] = As[row * Cfg::LDS_LD + wr + i * 16 + (lane & 15)];
 #pragma unroll
-            for (int j = 0; j < Cfg::TJ; ++j) bf[j] = Bs[row * Cfg::LDS_LD + wc + j * 16 + (lane & 15)];
+            for (int j = 0; j < Cfg::TJ; ++j) bf[kk][j] = Bs[row * Cfg::LDS_LD + wc + j * 16 + (lane & 15)];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk)
 #pragma unroll
             for (int i = 0; i < Cfg::TI; ++i)
 #pragma unroll
                 for (int j = 0; j < Cfg::TJ; ++j) {
-                    if (ABL == 2) { acc[i][j][0] += af[i] * bf[j]; continue; }   // ablation: no MFMA
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    if (ABL == 2) { acc[i][j][0] += af[kk][i] * bf[kk][j]; continue; }   // ablation: no MFMA
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
                 }
-        }
     };
 
 #pragma unroll

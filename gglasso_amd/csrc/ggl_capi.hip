@@ -70,6 +70,7 @@ struct ggl_ctx {
     long long ns_stable_calls = 0;
     double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
     double *bounds = nullptr, *bounds_h = nullptr;   // [K][2]
+    double *rowpart = nullptr, *sqpart = nullptr;    // scratch of the norm bounds (newton_schulz.hip)
     long long ns_steps_total = 0, ns_calls = 0;
     // per-phase HIP-event timing
     bool prof_on = false;
@@ -162,9 +163,12 @@ static int ctx_alloc(ggl_ctx* c)
         const size_t cl = (size_t)3 * NS_MAX_STEPS * c->K * 5 * sizeof(double);
         HIPCHK(hipMalloc(&c->coef, cl));
         HIPCHK(hipHostMalloc(&c->coef_h, cl));
-        const size_t bl = 2 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);
+        const size_t bl = 2 * (size_t)c->K * sizeof(double);
         HIPCHK(hipMalloc(&c->bounds, bl));
         HIPCHK(hipHostMalloc(&c->bounds_h, bl));
+        const int Tf = form_W_tiles(c->p);
+        HIPCHK(hipMalloc(&c->rowpart, (size_t)c->K * Tf * c->p * sizeof(double)));
+        HIPCHK(hipMalloc(&c->sqpart, (size_t)c->K * (Tf * (Tf + 1) / 2) * sizeof(double)));
     }
     return GGL_OK;
 }
@@ -216,7 +220,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
-                      c->nsT, c->coef, c->bounds, c->sqwork};
+                      c->nsT, c->coef, c->bounds, c->sqwork, c->rowpart, c->sqpart};
     if (c->coef_h) (void)hipHostFree(c->coef_h);
     if (c->bounds_h) (void)hipHostFree(c->bounds_h);
     for (double* b : bufs)
@@ -384,23 +388,13 @@ extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* 
     const int nxt = c->cur ^ 1;
     if (c->omega_ns) {
         PB(c, GGL_PH_FORM_W);
-        launch_form_W_sym(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->K, c->p);
-        launch_norm_bounds(c->stream, c->W, c->K, c->p, c->bounds);
+        launch_form_W_sym(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->rowpart, c->sqpart,
+                          c->bounds, c->K, c->p);
         PE(c, GGL_PH_FORM_W);
         HIPCHK(hipGetLastError());
-        const int nbb = norm_bounds_blocks(c->p);
-        HIPCHK(hipMemcpyAsync(c->bounds_h, c->bounds, 2 * (size_t)c->K * nbb * sizeof(double),
-                              hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->bounds_h, c->bounds, 2 * (size_t)c->K * sizeof(double), hipMemcpyDeviceToHost,
+                              c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        for (int k = 0; k < c->K; ++k) {   // finish the reduction over row blocks into slot [k][0]
-            double mx = 0.0, sq = 0.0;
-            for (int b = 0; b < nbb; ++b) {
-                mx = std::max(mx, c->bounds_h[2 * ((size_t)k * nbb + b)]);
-                sq += c->bounds_h[2 * ((size_t)k * nbb + b) + 1];
-            }
-            c->bounds_h[2 * k] = mx;         // k <= k*nbb: never overwrites an unread entry
-            c->bounds_h[2 * k + 1] = sq;
-        }
         NsPlan plan;
         if (ns_plan(c->bounds_h, c->par_h, c->K, c->coef_h, &plan, c->ns_force) != 0)
             return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");

@@ -114,11 +114,12 @@ static constexpr int NS_MAX_STEPS = 24;
 static constexpr double NS_SYM_KAPPA_MAX = 300.0;
 struct NsPlan { int steps = 0; int products = 0; bool stable = false; double kappa = 0.0; };
 // W = ((Theta - L) - X) - beta_k S from the lower triangle, mirrored (exactly symmetric)
+// also: bounds[k] = {|W_k|_inf, |W_k|_F^2} (device, K*2 doubles) through the scratch arrays
+// rowpart (K * form_W_tiles(p) * p doubles) and sqpart (K * T(T+1)/2 doubles, T = form_W_tiles(p))
+int form_W_tiles(int p);
 void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
-                       const double* S, const double* betaK, int K, int p);
-// part[k][blk] = {max row abs-sum, sum of squares} of row block blk; nblk = norm_bounds_blocks(p)
-int norm_bounds_blocks(int p);
-void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* part);
+                       const double* S, const double* betaK, double* rowpart, double* sqpart, double* bounds,
+                       int K, int p);
 // host: scaling schedule from the norm bounds; fills coef_h[(3*NS_MAX_STEPS)*K*5]; returns 0 or -1
 // force_mode: 0 choose by condition number, 1 all-symmetric products, 2 stable (unsymmetrised) products
 int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h, NsPlan* plan, int force_mode);

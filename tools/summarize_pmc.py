@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile_round.sh output directory into profiles/<tag>_*.{csv,json}.
+
+    python tools/summarize_pmc.py gpurun_out/prof_r1 r1
+"""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    name = name.replace("void ", "").replace("ggl::", "")
+    return name.strip()
+
+
+stats = os.path.join(src, "stats", "bench_kernel_stats.csv")
+if os.path.exists(stats):
+    shutil.copy(stats, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+
+out = {}
+for sub in ("fetch", "write", "sq", "tcc"):
+    path = os.path.join(src, sub, "bench_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for kname, ctrs in agg.items():
+        for c, vals in ctrs.items():
+            out.setdefault(kname, {})[c] = {"mean_per_launch": sum(vals) / len(vals), "launches": len(vals)}
+# HBM traffic per launch in bytes.  FETCH_SIZE / WRITE_SIZE are in KiB.  Calibration for THIS access pattern
+# (8-byte-per-lane row reads): the dev bench of k_symm_tn with A == B (64.0 MB of unique operand bytes at
+# K=32,p=500) reads FETCH_SIZE = 72.2e3 and WRITE_SIZE = 64.7e3 for a 64.0 MB output, i.e. both counters
+# report true bytes here (the 1/2 factor of the guide applies to 16-byte-per-lane streams, which these
+# kernels do not issue), so no correction is applied.
+for kname, c in out.items():
+    f = c.get("FETCH_SIZE", {}).get("mean_per_launch")
+    w = c.get("WRITE_SIZE", {}).get("mean_per_launch")
+    if f is not None and w is not None:
+        c["hbm_bytes_per_launch"] = (f + w) * 1024.0
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps({k: v.get("hbm_bytes_per_launch") for k, v in out.items()}, indent=1))
