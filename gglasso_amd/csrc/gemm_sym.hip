@@ -336,6 +336,62 @@ __global__ __launch_bounds__(256) void k_mfma_f64_peak(double* __restrict__ out,
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// same probe with NV dependent 64-bit integer VALU ops (address arithmetic stand-ins) per MFMA
+template <int NV>
+__global__ __launch_bounds__(256) void k_mfma_valu_mix(double* __restrict__ out, int iters, unsigned long long seed)
+{
+    v4d acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    unsigned long long x = seed + threadIdx.x;
+    double d = a;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (v & 1) x = (x << 3) + seed;           // v_lshl_add_u64
+                else d = (x & 1) ? d : b;                 // v_cndmask pair
+            }
+        }
+    }
+    double s = d + (double)x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NV>
+static double mix_probe(hipStream_t st, double* scratch, int blocks, int iters)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_mfma_valu_mix<NV>, dim3(blocks), dim3(256), 0, st, scratch, 16, 12345ull);
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(k_mfma_valu_mix<NV>, dim3(blocks), dim3(256), 0, st, scratch, iters, 12345ull);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return (double)blocks * 4.0 * iters * 4 * 2.0 * 16 * 16 * 4 / (ms * 1e-3) / 1e12;
+}
+
+double mfma_valu_mix_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nv)
+{
+    switch (nv) {
+        case 0: return mix_probe<0>(st, scratch, blocks, iters);
+        case 2: return mix_probe<2>(st, scratch, blocks, iters);
+        case 4: return mix_probe<4>(st, scratch, blocks, iters);
+        case 8: return mix_probe<8>(st, scratch, blocks, iters);
+        default: return mix_probe<16>(st, scratch, blocks, iters);
+    }
+}
+
 template <int NACC>
 static double mfma_probe(hipStream_t st, double* scratch, int blocks, int iters)
 {
@@ -366,15 +422,16 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
     }
 }
 
-int symm_variants() { return 8; }
+int symm_variants() { return 10; }
 
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                  const double* coef, int K, int p, int variant)
 {
     if (variant < 0) {
-        // enough workgroups to fill 256 CUs a few times over, else the smaller tile
-        const int T128 = (p + 127) / 128;
-        variant = ((long)T128 * (T128 + 1) / 2 * K >= 1024) ? 2 : 0;
+        // Measured on MI355X (tools/tail_test.py): with fewer than ~800 64x64 tile pairs in the batch the
+        // chip is under-filled and 32x32 tiles (4x the workgroups) are 20-30 % faster; above, 64x64.
+        const long T64 = (p + 63) / 64;
+        variant = (T64 * (T64 + 1) / 2 * K <= 800) ? 9 : 0;
     }
     switch (variant) {
         case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, C2, E, coef, K, p); break;
@@ -382,6 +439,8 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, C2, E, coef, K, p); break;
         case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, C2, E, coef, K, p); break;
         case 5: launch_cfg<128, 32, 64, 64, false>(st, A, B, C, C2, E, coef, K, p); break;
+        case 8: launch_cfg<32, 16, 16, 16, true>(st, A, B, C, C2, E, coef, K, p); break;
+        case 9: launch_cfg<32, 32, 16, 16, true>(st, A, B, C, C2, E, coef, K, p); break;
         case 6: {   // ablation of variant 0: no global loads
             const int T = (p + 63) / 64;
             hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 1>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p);

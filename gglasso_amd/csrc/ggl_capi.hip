@@ -863,6 +863,12 @@ extern "C" int ggl_dev_mfma_f64_peak(double* tflops_out)
                 fprintf(stderr, "mfma f64 probe: %d wave(s)/SIMD, %d accumulators: %.1f TF/s\n", layers, nacc,
                         mfma_f64_peak_tflops(nullptr, d.p, 256 * layers, 4000, nacc));
     }
+    if (getenv("GGL_MFMA_MIX_VERBOSE")) {
+        for (int layers : {1, 4})
+            for (int nv : {0, 2, 4, 8, 16})
+                fprintf(stderr, "mfma+valu mix: %d wave(s)/SIMD, %2d VALU per MFMA: %.1f TF/s\n", layers, nv,
+                        mfma_valu_mix_tflops(nullptr, d.p, 256 * layers, 4000, nv));
+    }
     *tflops_out = best;
     return GGL_OK;
 }

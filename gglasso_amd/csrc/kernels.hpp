@@ -104,6 +104,7 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
 
 // measured FP64 matrix-core ceiling (MFMA-only probe kernel)
 double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nacc);
+double mfma_valu_mix_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nv);
 // C[b] = scal[b % K] * A[b] * T[b % K] (T symmetric, A general), b < nbatch; full output.  FP64 MFMA.
 void launch_gemm_right(hipStream_t st, const double* A, const double* T, double* C, const double* scal,
                        int nbatch, int K, int p, int variant);
