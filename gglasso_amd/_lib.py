@@ -38,6 +38,9 @@ _SIGNATURES = {
     "ggl_step_group_partial": ([_vp, _d, _d], _i),
     "ggl_step_finish": ([_vp, _d, _d, _d, _i, _i, _dp, _i, _dp], _i),
     "ggl_scale_X": ([_vp, _d], _i),
+    "ggl_sgl_batch_step": ([_vp, _dp, _dp, _i, _dp, _dp], _i),
+    "ggl_scale_X_batch": ([_vp, _dp], _i),
+    "ggl_get_state_k": ([_vp, _i, _dp, _dp, _dp, _dp], _i),
     "ggl_exit_checks": ([_vp, _i, _dp], _i),
     "ggl_objective": ([_vp, _d, _d, _i, _dp], _i),
     "ggl_kkt_residual": ([_vp, _d, _d, _d, _i, _i, _dp, _dp, _dp], _i),

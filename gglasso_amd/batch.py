@@ -1,0 +1,99 @@
+"""Batched lambda path for the Single Graphical Lasso: K independent ``ADMM_SGL`` problems on the same
+S advance together on one GPU -- one batched Omega-step (K matrices per launch instead of one) and one
+elementwise Theta-step per iteration.
+
+This is the regime of the reference's ``single_grid_search`` (helper/model_selection.py:505-692), which
+solves the lambda1 grid sequentially (each solve is the loop of solver/single_admm_solver.py:157-214).
+Every instance keeps its OWN rho, residuals, rho updates and stopping decision, exactly as if
+``ADMM_SGL(S, lambda1[k], Omega_0, ...)`` had been called on its own, so each returned (sol, info) equals
+the independent solve (the reference's sequential warm start, model_selection.py:632-633, only changes
+iteration counts, not the optimum).  An instance's solution is snapshotted at the iteration it converges;
+it keeps iterating harmlessly until the whole batch is done.
+"""
+import numpy as np
+
+from . import solver as _solver
+from .solver import as_c, residuals_from_norms, next_rho
+
+
+def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max_iter=1000, tol=1e-7,
+                   rtol=1e-4, update_rho=True, verbose=False, latent=False, mu1=None, lambda1_mask=None):
+    """Solve ``ADMM_SGL(S, lambda1[k], ...)`` for every k of the 1-D array ``lambda1`` at once.
+
+    S: (p,p).  Omega_0 / Theta_0 / X_0: (p,p) shared start or (K,p,p) per instance (default identity /
+    Omega_0 / zeros, as in single_admm_solver.py:129-137).  mu1: scalar or (K,) when ``latent``.
+    Returns a list of K ``(sol, info)`` pairs with the reference's keys; ``info`` additionally carries
+    ``'iterations'`` and the final ``'rho'``."""
+    S = as_c(S)
+    assert S.ndim == 2 and S.shape[0] == S.shape[1]
+    p = S.shape[0]
+    lam = as_c(np.atleast_1d(lambda1)).reshape(-1)
+    K = len(lam)
+    assert np.all(lam > 0), "lambda1 should be positive"
+    assert rho > 0
+    lam_pp = None
+    if lambda1_mask is not None:
+        assert lambda1_mask.shape == (p, p)
+        assert np.all(lambda1_mask >= 0)
+        assert np.all(np.abs(lambda1_mask.T - lambda1_mask) <= 1e-5)
+        lam_pp = as_c(lambda1_mask)          # the per-instance factor lambda1[k] multiplies it on the device
+    if latent:
+        assert mu1 is not None
+        mu = as_c(np.broadcast_to(np.asarray(mu1, dtype=np.float64), (K,)))
+        assert np.all(mu > 0)
+    else:
+        mu = None
+
+    def stack(A, default):
+        if A is None or len(A) == 0:
+            A = default
+        A = np.asarray(A, dtype=np.float64)
+        return as_c(np.broadcast_to(A, (K, p, p)))
+
+    Om0 = stack(Omega_0, np.eye(p))
+    Th0 = stack(Theta_0, Om0)
+    X0 = stack(X_0, np.zeros((p, p)))
+    eng = _solver.ENGINE(np.broadcast_to(S, (K, p, p)), Om0, Th0, X0)
+    try:
+        if lam_pp is not None:
+            # threshold (1/rho_k) * lambda1_k * mask: the kernel multiplies 1/rho_k by the (p,p) array, so
+            # the per-instance lambda1 factor has to be the same for all k, or folded per instance
+            assert np.all(lam == lam[0]), "lambda1_mask with different lambda1 per instance is not supported"
+            eng.set_lambda1_mask(lam[0] * lam_pp)
+        rhos = np.full(K, float(rho))
+        done = np.zeros(K, dtype=bool)
+        results = [None] * K
+        last = [None] * K
+        dim = (p ** 2 + p) / 2
+        for it in range(max_iter):
+            sq = eng.sgl_batch_step(rhos, lam, latent, mu)
+            fac = np.ones(K)
+            for k in range(K):
+                if done[k]:
+                    continue
+                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[k], rhos[k], tol, rtol, dim)
+                if update_rho:
+                    rn = next_rho(rhos[k], r_t, s_t)
+                    fac[k] = rhos[k] / rn
+                    rhos[k] = rn
+                last[k] = (r_t, s_t, e_pri, e_dual)
+                if verbose:
+                    print("%4d\t%3d\t%10.4g\t%10.4g\t%10.4g\t%10.4g" % (it, k, r_t, s_t, e_pri, e_dual))
+                if (r_t <= e_pri) and (s_t <= e_dual):
+                    done[k] = True
+            if np.any(fac != 1.0):
+                eng.scale_X_batch(fac)
+            for k in range(K):
+                if done[k] and results[k] is None:
+                    results[k] = (eng.state_k(k, latent), {'status': 'optimal', 'iterations': it + 1, 'rho': rhos[k]})
+            if done.all():
+                break
+        for k in range(K):
+            if results[k] is None:
+                r_t, s_t, e_pri, e_dual = last[k]
+                status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
+                                                                else 'max iterations reached')
+                results[k] = (eng.state_k(k, latent), {'status': status, 'iterations': max_iter, 'rho': rhos[k]})
+    finally:
+        eng.close()
+    return results

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(EW_THREADS) void k_theta_sgl(double* __restrict__ T
                                                           double* __restrict__ C, const double* __restrict__ Omega,
                                                           const double* __restrict__ OmegaPrev,
                                                           const double* __restrict__ L, const double* __restrict__ l1K,
-                                                          const double* __restrict__ mask, double inv_rho,
+                                                          const double* __restrict__ mask,
+                                                          const double* __restrict__ invrhoK,
                                                           double* __restrict__ partials, int p)
 {
     __shared__ double scratch[GGL_NNORM * (EW_THREADS / 64)];
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_theta_sgl(double* __restrict__ T
     const size_t pp = (size_t)p * p;
     const size_t base = (size_t)k * pp;
     const double lk = MASK ? 0.0 : l1K[k];
+    const double inv_rho = MASK ? invrhoK[k] : 0.0;
     double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
     size_t i = (size_t)blockIdx.x * EW_CHUNK + threadIdx.x;
 #pragma unroll
@@ -102,12 +104,12 @@ __global__ __launch_bounds__(EW_THREADS) void k_theta_sgl(double* __restrict__ T
 
 void launch_theta_sgl(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                       const double* OmegaPrev, const double* L, const double* l1K, const double* mask,
-                      double inv_rho, int latent, double* partials, int K, int p)
+                      const double* invrhoK, int latent, double* partials, int K, int p)
 {
     dim3 grid(elementwise_blocks(p), K), blk(EW_THREADS);
 #define GGL_TS(LAT, MSK)                                                                              \
     hipLaunchKernelGGL((k_theta_sgl<LAT, MSK>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1K, \
-                       mask, inv_rho, partials, p)
+                       mask, invrhoK, partials, p)
     if (latent) {
         if (mask) GGL_TS(true, true); else GGL_TS(true, false);
     } else {
@@ -195,6 +197,25 @@ void launch_reduce_partials(hipStream_t st, const double* partials, int K, int n
 __global__ __launch_bounds__(256) void k_scale(double* __restrict__ X, double f, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) X[i] *= f;
+}
+
+__global__ __launch_bounds__(EW_THREADS) void k_scale_batch(double* __restrict__ X, const double* __restrict__ fK,
+                                                            size_t pp)
+{
+    const int k = blockIdx.y;
+    const double f = fK[k];
+    if (f == 1.0) return;
+    const size_t base = (size_t)k * pp;
+    size_t i = (size_t)blockIdx.x * EW_CHUNK + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < EW_EPT; ++e, i += EW_THREADS)
+        if (i < pp) X[base + i] *= f;
+}
+
+void launch_scale_batch(hipStream_t st, double* X, const double* fK, int K, int p)
+{
+    size_t pp = (size_t)p * p;
+    hipLaunchKernelGGL(k_scale_batch, dim3(elementwise_blocks(p), K), dim3(EW_THREADS), 0, st, X, fK, pp);
 }
 
 void launch_scale(hipStream_t st, double* X, double f, size_t n)

@@ -51,7 +51,7 @@ struct ggl_ctx {
     int cur = 0;              // Om[cur] is Omega_t, Om[cur^1] is Omega_{t-1}
     double *DvO = nullptr, *DvL = nullptr, *scale = nullptr, *E = nullptr;   // (K,p), (K,p), (2,K,p), (K,p)
     int* info = nullptr;      // (K)
-    double* par = nullptr;    // device: beta[K] | l1[K] | mu[K] | nk[K]
+    double* par = nullptr;    // device: beta[K] | l1[K] | mu[K] | nk[K] | 1/rho[K] | X scale[K]
     double* par_h = nullptr;  // pinned mirror
     double *mask = nullptr, *groupsq = nullptr;   // (p,p)
     double* sqwork = nullptr;                     // (ggl_chunks, p, p) per-chunk sums of squares
@@ -140,8 +140,8 @@ static int ctx_alloc(ggl_ctx* c)
     HIPCHK(hipMalloc(&c->scale, 2 * kp * sizeof(double)));
     HIPCHK(hipMalloc(&c->E, kp * sizeof(double)));
     HIPCHK(hipMalloc(&c->info, c->K * sizeof(int)));
-    HIPCHK(hipMalloc(&c->par, 4 * (size_t)c->K * sizeof(double)));
-    HIPCHK(hipHostMalloc(&c->par_h, 4 * (size_t)c->K * sizeof(double)));
+    HIPCHK(hipMalloc(&c->par, 6 * (size_t)c->K * sizeof(double)));
+    HIPCHK(hipHostMalloc(&c->par_h, 6 * (size_t)c->K * sizeof(double)));
     HIPCHK(hipMalloc(&c->mask, (size_t)c->p * c->p * sizeof(double)));
     HIPCHK(hipMalloc(&c->groupsq, (size_t)c->p * c->p * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->groupsq, 0, (size_t)c->p * c->p * sizeof(double), c->stream));
@@ -376,6 +376,8 @@ static int upload_par(ggl_ctx* c, int slot, const double* vals, double scalar, d
 // ---------------------------------------------------------------------------------------------
 // the iteration
 // ---------------------------------------------------------------------------------------------
+static int omega_step(ggl_ctx* c, int latent);
+
 extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* nk)
 {
     ARGCHK(c, "ctx");
@@ -384,6 +386,13 @@ extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* 
     // the previous step's pinned parameters are consumed: every step ends with a stream sync
     int rc = upload_par(c, 0, nk, 1.0, rho);   // beta_k = nk/rho    (admm_solver.py:180,184)
     if (rc) return rc;
+    return omega_step(c, latent);
+}
+
+// Omega-step with beta_k already in parameter slot 0
+static int omega_step(ggl_ctx* c, int latent)
+{
+    int rc;
     const double* beta = c->par;
     const int nxt = c->cur ^ 1;
     if (c->omega_ns) {
@@ -470,9 +479,11 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
     if (reg == GGL_REG_SGL) {
         int rc = upload_par(c, 1, nullptr, l1, 1.0);
         if (rc) return rc;
+        rc = upload_par(c, 4, nullptr, inv_rho, 1.0);
+        if (rc) return rc;
         PB(c, GGL_PH_THETA);
         launch_theta_sgl(c->stream, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, c->par + c->K,
-                         c->has_mask ? c->mask : nullptr, inv_rho, latent, c->partials, c->K, c->p);
+                         c->has_mask ? c->mask : nullptr, c->par + 4 * (size_t)c->K, latent, c->partials, c->K, c->p);
         PE(c, GGL_PH_THETA);
         HIPCHK(hipGetLastError());
         if (!latent) {
@@ -518,6 +529,80 @@ extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lamb
     int rc = ggl_step_omega(c, rho, latent, nk);
     if (rc) return rc;
     return ggl_step_finish(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
+}
+
+// ---- K independent single problems with their own rho / lambda1 (batched lambda path) ----------
+extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* lambda1, int latent, const double* mu1,
+                                  double* out_norms)
+{
+    ARGCHK(c && rho && lambda1 && out_norms, "ctx, rho, lambda1, out_norms");
+    ARGCHK(!latent || mu1, "latent needs mu1");
+    HIPCHK(hipSetDevice(c->device));
+    const int K = c->K;
+    for (int k = 0; k < K; ++k) ARGCHK(rho[k] > 0, "rho must be positive");
+    double* h = c->par_h;
+    for (int k = 0; k < K; ++k) {
+        const double ir = 1.0 / rho[k];
+        h[k] = ir;                         // beta_k = 1/rho_k           (single_admm_solver.py:163,166)
+        h[K + k] = ir * lambda1[k];        // (1/rho) * lambda1          (:169)
+        h[2 * K + k] = latent ? mu1[k] / rho[k] : 0.0;   // mu1/rho      (:175)
+        h[4 * K + k] = ir;
+    }
+    HIPCHK(hipMemcpyAsync(c->par, h, 5 * (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = omega_step(c, latent);
+    if (rc) return rc;
+    double* Om = c->Om[c->cur];
+    double* OmPrev = c->Om[c->cur ^ 1];
+    PB(c, GGL_PH_THETA);
+    launch_theta_sgl(c->stream, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, c->par + K,
+                     c->has_mask ? c->mask : nullptr, c->par + 4 * (size_t)K, latent, c->partials, K, c->p);
+    PE(c, GGL_PH_THETA);
+    HIPCHK(hipGetLastError());
+    if (latent) {
+        rc = eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)K, GGL_PH_EIG_L, GGL_PH_RECON_L);
+        if (rc) return rc;
+        PB(c, GGL_PH_DUAL);
+        launch_dual_update(c->stream, c->X, Om, OmPrev, c->Theta, c->L, c->partials, K, c->p);
+        PE(c, GGL_PH_DUAL);
+    }
+    PB(c, GGL_PH_REDUCE);
+    launch_reduce_partials(c->stream, c->partials, K, elementwise_blocks(c->p), GGL_NNORM, c->norms);
+    PE(c, GGL_PH_REDUCE);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->norms_h, c->norms, (size_t)K * GGL_NNORM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->info_h, c->info, K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    rc = check_info(c, "batched SGL step");
+    if (rc) return rc;
+    memcpy(out_norms, c->norms_h, (size_t)K * GGL_NNORM * sizeof(double));
+    return GGL_OK;
+}
+
+extern "C" int ggl_scale_X_batch(ggl_ctx* c, const double* factor)
+{
+    ARGCHK(c && factor, "ctx, factor");
+    HIPCHK(hipSetDevice(c->device));
+    double* h = c->par_h + 5 * (size_t)c->K;
+    memcpy(h, factor, c->K * sizeof(double));
+    HIPCHK(hipMemcpyAsync(c->par + 5 * (size_t)c->K, h, c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_scale_batch(c->stream, c->X, c->par + 5 * (size_t)c->K, c->K, c->p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));   // the pinned slot is reused by the next call
+    return GGL_OK;
+}
+
+extern "C" int ggl_get_state_k(ggl_ctx* c, int k, double* Omega, double* Theta, double* L, double* X)
+{
+    ARGCHK(c && k >= 0 && k < c->K, "ctx, k");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t pp = (size_t)c->p * c->p, nb = pp * sizeof(double), off = (size_t)k * pp;
+    if (Omega) HIPCHK(hipMemcpyAsync(Omega, c->Om[c->cur] + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (Theta) HIPCHK(hipMemcpyAsync(Theta, c->Theta + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (L) HIPCHK(hipMemcpyAsync(L, c->L + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (X) HIPCHK(hipMemcpyAsync(X, c->X + off, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GGL_OK;
 }
 
 extern "C" int ggl_scale_X(ggl_ctx* c, double factor)

@@ -21,17 +21,19 @@ int elementwise_blocks(int p);
 void launch_form_W(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
                    const double* S, const double* betaK, int K, int p);
 // SGL Theta-step (prox_od_1norm, ggl_helper.py:16-27) on every instance k with threshold
-// l1K[k] (scalar) or inv_rho*mask[i,j].  latent == 0: also X += Omega - Theta and the norms
+// l1K[k] (scalar) or invrhoK[k]*mask[i,j].  latent == 0: also X += Omega - Theta and the norms
 // partials [K][nblk][5].  latent != 0: writes Theta and C = (Theta - X) - Omega.
 void launch_theta_sgl(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                       const double* OmegaPrev, const double* L, const double* l1K,
-                      const double* mask, double inv_rho, int latent, double* partials, int K, int p);
+                      const double* mask, const double* invrhoK, int latent, double* partials, int K, int p);
 // X += (Omega - Theta) + L and the norms partials (latent path, admm_solver.py:208)
 void launch_dual_update(hipStream_t st, double* X, const double* Omega, const double* OmegaPrev,
                         const double* Theta, const double* L, double* partials, int K, int p);
 // out[k][v] = sum_b partials[k][b][v]   (fixed order => deterministic)
 void launch_reduce_partials(hipStream_t st, const double* partials, int K, int nblk, int nv, double* out);
 void launch_scale(hipStream_t st, double* X, double f, size_t n);
+// X[k] *= fK[k]
+void launch_scale_batch(hipStream_t st, double* X, const double* fK, int K, int p);
 // out[k] = max_{i,j} |A[k,i,j] - A[k,j,i]|
 void launch_asym_max(hipStream_t st, const double* A, int K, int p, double* out);
 // D = A - B (B may be null)

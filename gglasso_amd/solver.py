@@ -59,6 +59,26 @@ class HipEngine:
     def scale_X(self, f):
         check(self.lib.ggl_scale_X(self.h, f))
 
+    # -- K independent single problems (batched lambda path) ----------------------------------
+    def sgl_batch_step(self, rho, lambda1, latent, mu1):
+        out = np.zeros((self.K, 5))
+        check(self.lib.ggl_sgl_batch_step(self.h, ptr(as_c(rho)), ptr(as_c(lambda1)), int(latent),
+                                          ptr(None if mu1 is None else as_c(mu1)), ptr(out)))
+        return out
+
+    def scale_X_batch(self, factors):
+        check(self.lib.ggl_scale_X_batch(self.h, ptr(as_c(factors))))
+
+    def state_k(self, k, latent=False):
+        shape = (self.p, self.p)
+        Om, Th, X = np.empty(shape), np.empty(shape), np.empty(shape)
+        L = np.empty(shape) if latent else None
+        check(self.lib.ggl_get_state_k(self.h, int(k), ptr(Om), ptr(Th), ptr(L), ptr(X)))
+        sol = {'Omega': Om, 'Theta': Th, 'X': X}
+        if latent:
+            sol['L'] = L
+        return sol
+
     def objective(self, lambda1, lambda2, reg):
         out = np.zeros(3)
         check(self.lib.ggl_objective(self.h, lambda1, lambda2, _REG[reg], ptr(out)))

@@ -105,6 +105,17 @@ int ggl_step_group_partial(ggl_ctx *ctx, double rho, double lambda1);
 int ggl_step_finish(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int reg, int latent,
                     const double *mu1, int groupsq_ready, double out_norms[5]);
 
+/* ---- K independent single problems (batched lambda path) ---------------------------------------
+ * The ctx stack is used as K separate ADMM_SGL problems (single_admm_solver.py:157-214), each with its
+ * own rho_k and lambda1_k -- what the outer loop of single_grid_search (helper/model_selection.py:619-630)
+ * solves one after the other.  out_norms is (K,5): the five squared norms per instance.
+ * ggl_scale_X_batch: X_k <- factor_k X_k.  ggl_get_state_k: one instance of the state (snapshot at the
+ * iteration it converged). */
+int ggl_sgl_batch_step(ggl_ctx *ctx, const double *rho, const double *lambda1, int latent,
+                       const double *mu1, double *out_norms);
+int ggl_scale_X_batch(ggl_ctx *ctx, const double *factor);
+int ggl_get_state_k(ggl_ctx *ctx, int k, double *Omega, double *Theta, double *L, double *X);
+
 /* X <- factor * X : dual rescale after a rho update (admm_solver.py:236). */
 int ggl_scale_X(ggl_ctx *ctx, double factor);
 

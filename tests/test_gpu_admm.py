@@ -151,3 +151,45 @@ def test_inputs_not_mutated_and_asserts(sol):
         sol.ADMM_MGL(S, 0.05, 0.01, 'GGL', Om0, rho=0.0)
     with pytest.raises(AssertionError):
         sol.ADMM_MGL(S, 0.05, 0.01, 'GGL', Om0, latent=True)          # mu1 missing
+
+
+# ---- batched lambda path (K independent ADMM_SGL problems in one ctx) ----------------------------------
+
+@pytest.mark.parametrize("p,latent", [(30, False), (30, True), (150, False), (140, True)])
+def test_sgl_batch_equals_independent_solves(p, latent):
+    """Every instance of the batch must follow the trajectory of its own ADMM_SGL call (own rho, own
+    stopping iteration) -- checked against the CPU oracle at p below and above the LDS-Jacobi limit."""
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_SGL_batch
+    S, _ = synth.make_problem("GGL", 1, p, N=3 * p, seed=5)
+    S = S[0]
+    lams = np.logspace(0, -2, 6)
+    mu1 = 0.3 if latent else None
+    res = ADMM_SGL_batch(S, lams, tol=1e-9, rtol=1e-9, latent=latent, mu1=mu1)
+    assert len(res) == len(lams)
+    for k, lam in enumerate(lams):
+        ref, rinfo = orc.ADMM_SGL(S, lam, np.eye(p), tol=1e-9, rtol=1e-9, latent=latent, mu1=mu1)
+        sol, info = res[k]
+        assert info['status'] == rinfo['status'] == 'optimal'
+        assert info['iterations'] == rinfo['iterations'], (k, lam)
+        assert abs(info['rho'] - rinfo['rho']) == 0
+        for nm in ref:
+            assert np.abs(sol[nm] - ref[nm]).max() <= 1e-9, (k, nm)
+        assert ('L' in sol) == latent
+
+
+def test_sgl_batch_max_iter_status_and_mask():
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_SGL_batch
+    p = 24
+    S, _ = synth.make_problem("GGL", 1, p, N=60, seed=8)
+    S = S[0]
+    mask = np.ones((p, p))
+    mask[:4, :] = mask[:, :4] = 0.3
+    lams = np.array([0.07, 0.07, 0.07])
+    res = ADMM_SGL_batch(S, lams, max_iter=6, tol=1e-20, rtol=1e-20, lambda1_mask=mask)
+    ref, rinfo = orc.ADMM_SGL(S, 0.07, np.eye(p), max_iter=6, tol=1e-20, rtol=1e-20, lambda1_mask=mask)
+    for sol, info in res:
+        assert info['status'] == 'max iterations reached' and info['iterations'] == 6
+        for nm in ref:
+            assert np.abs(sol[nm] - ref[nm]).max() <= 1e-10
