@@ -164,6 +164,7 @@ def main():
     rho = 1.0
     if args.warmup > 0:
         rho = run(args.warmup, rho)
+    ns0 = eng.ns_stats()
     eng.profile(True)
     eng.profile_read(reset=True)
     fence()
@@ -176,6 +177,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     prof = eng.profile_read(reset=True)
+    ns1 = eng.ns_stats()
     eng.close()
 
     if rank == 0:
@@ -190,6 +192,12 @@ def main():
                        "recon_omega": "k_recon", "recon_L": "k_recon", "form_W": "k_form_W",
                        "dual": "k_dual_update", "eig_L": "k_jacobi" if eig_jacobi else "rocsolver_dsyevd"}.get(dom, dom)
         sec = phases[dom]["ms_per_launch"] * 1e-3
+        if dom == "eig_omega" and omega_ns:
+            # the Omega-step's launches differ in size (a pair launch carries two products): average over
+            # the step = algorithmic flop of all its launches / their total duration (HIP events)
+            units = ns1["units"] - ns0["units"]
+            launches = ns1["launches"] - ns0["launches"]
+            amount = units * 1.0 * Kl * p ** 3 / launches
         if bound == "hbm":
             achieved, peak = amount / sec / 1e9, HBM_PEAK_GBS
         else:
@@ -213,6 +221,8 @@ def main():
             "iteration_hbm_roofline": {"algorithmic_bytes": iter_bytes, "achieved_GBs": its * iter_bytes / 1e9,
                                        "frac": its * iter_bytes / 1e9 / HBM_PEAK_GBS},
             "phases_ms": {ph: round(v["ms_per_launch"], 4) for ph, v in phases.items()},
+            "newton_schulz": {"steps_per_omega_step": (ns1["steps"] - ns0["steps"]) / max(1, ns1["calls"] - ns0["calls"]),
+                              "stable_schedule_calls": ns1["stable_calls"] - ns0["stable_calls"]} if omega_ns else None,
         }
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, reg, l1, l2, latent, mu1, args.cpu_iters)

@@ -61,15 +61,21 @@ __device__ __forceinline__ bool decode_block_xcd(int ntiles, int K, int& k, int&
 template <int BM, int BK, int WM, int WN, bool LM, int ABL = 0>
 __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, double* __restrict__ C2,
-    const double* __restrict__ E, const double* __restrict__ coef, int K, int p)
+    const double* __restrict__ E, const double* __restrict__ coef, int K, int p, const double* __restrict__ A1,
+    const double* __restrict__ B1, double* __restrict__ C1, int K1)
 {
+    // Instances k < K use (A, B, C, C2, E); instances K <= k < K + K1 use the second set (A1, B1, C1):
+    // two independent products of one Newton-Schulz step share a launch, so that the chip sees 2K
+    // instances' worth of tiles at once.  coef is indexed by the combined k.
     using Cfg = SymCfg<BM, BK, WM, WN, LM>;
     __shared__ __attribute__((aligned(16))) double smem[Cfg::LDS_DOUBLES];
     double* As = smem;
     double* Bs = smem + Cfg::SLAB;
     const int T = (p + BM - 1) / BM;
     int k, b;
-    if (!decode_block_xcd(T * (T + 1) / 2, K, k, b)) return;
+    if (!decode_block_xcd(T * (T + 1) / 2, K + K1, k, b)) return;
+    const bool second = k >= K;
+    const int kk = second ? k - K : k;
     int I = 0;
     while (b >= T - I) { b -= T - I; ++I; }
     const int J = I + b;
@@ -77,8 +83,8 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = (wave / Cfg::NWC) * WM, wc = (wave % Cfg::NWC) * WN;
     const size_t pp = (size_t)p * p;
-    const double* Ak = A + (size_t)k * pp;
-    const double* Bk = B + (size_t)k * pp;
+    const double* Ak = (second ? A1 : A) + (size_t)kk * pp;
+    const double* Bk = (second ? B1 : B) + (size_t)kk * pp;
 
     v4d acc[Cfg::TI][Cfg::TJ];
 #pragma unroll
@@ -159,9 +165,9 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     // epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
     const double cI = coef[k * 5 + 0], cAcc = coef[k * 5 + 1], cE = coef[k * 5 + 2];
     const double dI = coef[k * 5 + 3], dC = coef[k * 5 + 4];
-    double* Ck = C + (size_t)k * pp;
-    double* C2k = C2 ? C2 + (size_t)k * pp : nullptr;
-    const double* Ek = E ? E + (size_t)k * pp : nullptr;
+    double* Ck = (second ? C1 : C) + (size_t)kk * pp;
+    double* C2k = (C2 && !second) ? C2 + (size_t)kk * pp : nullptr;
+    const double* Ek = (E && !second) ? E + (size_t)kk * pp : nullptr;
 #pragma unroll
     for (int ti = 0; ti < Cfg::TI; ++ti)
 #pragma unroll
@@ -203,12 +209,13 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
 
 template <int BM, int BK, int WM, int WN, bool LM>
 static void launch_cfg(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
-                       const double* coef, int K, int p)
+                       const double* coef, int K, int p, const double* A1 = nullptr, const double* B1 = nullptr,
+                       double* C1 = nullptr, int K1 = 0)
 {
     using Cfg = SymCfg<BM, BK, WM, WN, LM>;
     const int T = (p + BM - 1) / BM;
-    hipLaunchKernelGGL((k_symm_tn<BM, BK, WM, WN, LM>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(Cfg::NT), 0, st, A, B, C,
-                       C2, E, coef, K, p);
+    hipLaunchKernelGGL((k_symm_tn<BM, BK, WM, WN, LM>), dim3(xcd_grid(T * (T + 1) / 2, K + K1)), dim3(Cfg::NT), 0, st, A,
+                       B, C, C2, E, coef, K, p, A1, B1, C1, K1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -424,6 +431,24 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
 
 int symm_variants() { return 10; }
 
+// Two independent products in one launch: C = coef[k]-affine(A*B) for k < K and C1 = coef[K+k]-scaled(A1*B1).
+void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
+                      double* C1, const double* coef2K, int K, int p, int variant)
+{
+    if (variant < 0 || variant == 6 || variant == 7) {
+        const long T64 = (p + 63) / 64;
+        variant = (T64 * (T64 + 1) / 2 * 2 * K <= 800) ? 9 : 0;
+    }
+    switch (variant) {
+        case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
+        case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
+        case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
+        case 8: launch_cfg<32, 16, 16, 16, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
+        case 9: launch_cfg<32, 32, 16, 16, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
+        default: launch_cfg<64, 16, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
+    }
+}
+
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                  const double* coef, int K, int p, int variant)
 {
@@ -443,12 +468,12 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         case 9: launch_cfg<32, 32, 16, 16, true>(st, A, B, C, C2, E, coef, K, p); break;
         case 6: {   // ablation of variant 0: no global loads
             const int T = (p + 63) / 64;
-            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 1>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p);
+            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 1>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0);
             break;
         }
         case 7: {   // ablation of variant 0: no MFMA
             const int T = (p + 63) / 64;
-            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 2>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p);
+            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 2>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0);
             break;
         }
         default: launch_cfg<64, 16, 32, 32, true>(st, A, B, C, C2, E, coef, K, p); break;

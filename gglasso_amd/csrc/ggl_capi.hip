@@ -71,7 +71,7 @@ struct ggl_ctx {
     double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
     double *bounds = nullptr, *bounds_h = nullptr;   // [K][2]
     double *rowpart = nullptr, *sqpart = nullptr;    // scratch of the norm bounds (newton_schulz.hip)
-    long long ns_steps_total = 0, ns_calls = 0;
+    long long ns_steps_total = 0, ns_calls = 0, ns_units_total = 0, ns_launches_total = 0;
     // per-phase HIP-event timing
     bool prof_on = false;
     hipEvent_t ev[GGL_NPHASE][2] = {};
@@ -160,7 +160,7 @@ static int ctx_alloc(ggl_ctx* c)
     if (c->omega_ns) {
         for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->nsYP[i], 2 * nb));
         HIPCHK(hipMalloc(&c->nsT, nb));
-        const size_t cl = (size_t)3 * NS_MAX_STEPS * c->K * 5 * sizeof(double);
+        const size_t cl = (size_t)2 * NS_MAX_STEPS * NS_SLOT(c->K) * sizeof(double);
         HIPCHK(hipMalloc(&c->coef, cl));
         HIPCHK(hipHostMalloc(&c->coef_h, cl));
         const size_t bl = 2 * (size_t)c->K * sizeof(double);
@@ -407,7 +407,7 @@ static int omega_step(ggl_ctx* c, int latent)
         NsPlan plan;
         if (ns_plan(c->bounds_h, c->par_h, c->K, c->coef_h, &plan, c->ns_force) != 0)
             return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");
-        HIPCHK(hipMemcpyAsync(c->coef, c->coef_h, (size_t)plan.products * c->K * 5 * sizeof(double),
+        HIPCHK(hipMemcpyAsync(c->coef, c->coef_h, (size_t)plan.products * NS_SLOT(c->K) * sizeof(double),
                               hipMemcpyHostToDevice, c->stream));
         PB(c, GGL_PH_EIG_OMEGA);
         ns_run(c->stream, plan, c->coef, c->W, c->nsYP[0], c->nsYP[1], c->nsT, c->Om[nxt], c->K, c->p,
@@ -417,6 +417,9 @@ static int omega_step(ggl_ctx* c, int latent)
         HIPCHK(hipGetLastError());
         if (c->prof_on) c->ph_cnt[GGL_PH_EIG_OMEGA] += plan.products - 1;   // count kernel launches, not phases
         c->ns_steps_total += plan.steps;
+        c->ns_launches_total += plan.products;
+        // algorithmic work in units of K p^3 flop (one symmetric product of the whole stack)
+        c->ns_units_total += (plan.steps == 1) ? 2 : (plan.stable ? 5 * plan.steps - 6 : 3 * plan.steps - 2);
         c->ns_calls += 1;
         c->dvo_valid = false;
         HIPCHK(hipMemsetAsync(c->info, 0, c->K * sizeof(int), c->stream));
@@ -623,6 +626,17 @@ extern "C" int ggl_profile_enable(ggl_ctx* c, int on)
             for (int e = 0; e < 2; ++e) HIPCHK(hipEventCreate(&c->ev[ph][e]));
     }
     c->prof_on = (on != 0);
+    return GGL_OK;
+}
+
+extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[5])
+{
+    ARGCHK(c && out, "ctx, out");
+    out[0] = c->ns_calls;
+    out[1] = c->ns_steps_total;
+    out[2] = c->ns_stable_calls;
+    out[3] = c->ns_units_total;
+    out[4] = c->ns_launches_total;
     return GGL_OK;
 }
 

@@ -111,8 +111,14 @@ double mfma_valu_mix_tflops(hipStream_t st, double* scratch, int blocks, int ite
 void launch_gemm_right(hipStream_t st, const double* A, const double* T, double* C, const double* scal,
                        int nbatch, int K, int p, int variant);
 
+// two independent symmetric products in one launch; coef2K: [2K][5] (second half for the second product)
+void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
+                      double* C1, const double* coef2K, int K, int p, int variant);
+
 // ---- newton_schulz.hip ------------------------------------------------------------------
 static constexpr int NS_MAX_STEPS = 24;
+// doubles per launch slot of the coefficient table (a pair launch carries 2K rows of 5)
+static inline size_t NS_SLOT(int K) { return (size_t)K * 10; }
 // all-symmetric products are only accurate while the condition number of W^2 + 4 beta I is small
 static constexpr double NS_SYM_KAPPA_MAX = 300.0;
 struct NsPlan { int steps = 0; int products = 0; bool stable = false; double kappa = 0.0; };
@@ -123,7 +129,7 @@ int form_W_tiles(int p);
 void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
                        const double* S, const double* betaK, double* rowpart, double* sqpart, double* bounds,
                        int K, int p);
-// host: scaling schedule from the norm bounds; fills coef_h[(3*NS_MAX_STEPS)*K*5]; returns 0 or -1
+// host: scaling schedule from the norm bounds; fills coef_h[(2*NS_MAX_STEPS)*NS_SLOT(K)]; returns 0 or -1
 // force_mode: 0 choose by condition number, 1 all-symmetric products, 2 stable (unsymmetrised) products
 int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h, NsPlan* plan, int force_mode);
 // device: Omega = (W + (W^2 + 4 beta)^(1/2))/2 by 3*steps-2 symmetric products

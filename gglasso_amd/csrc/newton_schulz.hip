@@ -189,13 +189,13 @@ int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h,
     plan->steps = n;
     plan->stable = stable;
     plan->kappa = kappa;
-    plan->products = (n == 1) ? 2 : (stable ? 2 + 2 * (n - 2) + 2 : 3 * n - 2);   // kernel launches
+    plan->products = (n == 1) ? 2 : 2 + 2 * (n - 2) + 2;   // kernel launches (both schedules: 2 per step)
     // launch g of the sequence (see ns_run) reads coef_h[(g*K + k)*5 ..]; a right-multiply launch reads
     // its 2K scalars from the start of its slot instead.
     for (int k = 0; k < K; ++k) {
         auto a_of = [&](int it) { return it < (int)al[k].size() ? al[k][it] : 1.0; };
         auto put = [&](int g, double cI, double cAcc, double cE, double dI, double dC) {
-            double* o = coef_h + ((size_t)g * K + k) * 5;
+            double* o = coef_h + (size_t)g * NS_SLOT(K) + (size_t)k * 5;
             o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = dI; o[4] = dC;
         };
         const double sc = std::sqrt(c[k]);
@@ -212,14 +212,19 @@ int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h,
             put(g++, 1.5, -0.5 * a * a * zs, 0.0, 0.0, 0.0);                 // T = 1.5 I - 0.5 a^2 (Z Y)
             if (it == n - 1) put(g++, 0.0, 0.5 * sc * a, 0.5, 0.0, 0.0);    // Omega = W/2 + sqrt(c) a (Y T)/2
             else if (stable) {
-                double* o = coef_h + (size_t)g * K * 5;                     // [Y <- a Y T ; P <- a zs P T]
+                double* o = coef_h + (size_t)g * NS_SLOT(K);                // [Y <- a Y T ; P <- a zs P T]
                 o[k] = a;
                 o[K + k] = a * zs;
                 ++g;
                 zs = 1.0;
             } else {
-                put(g++, 0.0, a, 0.0, 0.0, 0.0);                            // Y <- a Y T
-                put(g++, 0.0, a * zs, 0.0, 0.0, 0.0);                       // Z <- a T Z
+                // one launch, 2K instances: [Y <- a Y T ; Z <- a zs T Z]; its slot holds 2K coefficient rows
+                double* o = coef_h + (size_t)g * NS_SLOT(K);
+                double* y = o + (size_t)k * 5;
+                double* z = o + ((size_t)K + k) * 5;
+                y[0] = 0.0; y[1] = a; y[2] = 0.0; y[3] = 0.0; y[4] = 0.0;
+                z[0] = 0.0; z[1] = a * zs; z[2] = 0.0; z[3] = 0.0; z[4] = 0.0;
+                ++g;
                 zs = 1.0;
             }
         }
@@ -238,7 +243,7 @@ int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h,
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* W, double* YP0, double* YP1,
             double* Tb, double* out, int K, int p, int variant)
 {
-    const size_t cs = (size_t)K * 5, n1 = (size_t)K * p * p;
+    const size_t cs = NS_SLOT(K), n1 = (size_t)K * p * p;
     int g = 0;
     const int n = plan.steps;
     double *cur = YP0, *nxt = YP1;      // cur = [Y | Z]
@@ -260,8 +265,7 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
             launch_gemm_right(st, cur, Tb, nxt, coef_d + cs * g++, 2 * K, K, p, 0);
             std::swap(cur, nxt);
         } else {
-            launch_symm(st, cur, Tb, nxt, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
-            launch_symm(st, Tb, cur + n1, nxt + n1, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
+            launch_symm_pair(st, cur, Tb, nxt, Tb, cur + n1, nxt + n1, coef_d + cs * g++, K, p, variant);
             std::swap(cur, nxt);
         }
     }

@@ -112,6 +112,12 @@ class HipEngine:
         check(self.lib.ggl_profile_read(self.h, ptr(ms), cnt, int(reset)))
         return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.PHASES)}
 
+    def ns_stats(self):
+        import ctypes
+        out = (ctypes.c_longlong * 5)()
+        check(self.lib.ggl_ns_stats(self.h, out))
+        return dict(zip(("calls", "steps", "stable_calls", "units", "launches"), (int(v) for v in out)))
+
     def device_ptr(self, which):
         return self.lib.ggl_device_ptr(self.h, which)
 
