@@ -62,8 +62,10 @@ template <int BM, int BK, int WM, int WN, bool LM, int ABL = 0>
 __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, double* __restrict__ C2,
     const double* __restrict__ E, const double* __restrict__ coef, int K, int p, const double* __restrict__ A1,
-    const double* __restrict__ B1, double* __restrict__ C1, int K1)
+    const double* __restrict__ B1, double* __restrict__ C1, int K1, double* __restrict__ maxdev)
 {
+    // maxdev != null: maxdev[k] = max over the instance of |C - I| (atomic max on the bit pattern of a
+    // non-negative double: order independent, hence deterministic).
     // Instances k < K use (A, B, C, C2, E); instances K <= k < K + K1 use the second set (A1, B1, C1):
     // two independent products of one Newton-Schulz step share a launch, so that the chip sees 2K
     // instances' worth of tiles at once.  coef is indexed by the combined k.
@@ -194,6 +196,25 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
                 }
                 if (LM && I != J) smem[row * Cfg::CLD + col] = v;
             }
+    if (maxdev) {
+        double dev = 0.0;
+#pragma unroll
+        for (int ti = 0; ti < Cfg::TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < Cfg::TJ; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = I0 + wr + ti * 16 + (lane >> 4) + 4 * r;
+                    const int gj = J0 + wc + tj * 16 + (lane & 15);
+                    if (gi < p && gj < p && (I != J || gi <= gj)) {
+                        const double v = cAcc * acc[ti][tj][r] + (gi == gj ? cI - 1.0 : 0.0);
+                        dev = fmax(dev, fabs(v));
+                    }
+                }
+        dev = wave_max(dev);
+        if (lane == 0 && dev > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long*>(maxdev + k), (unsigned long long)__double_as_longlong(dev));
+    }
     if (LM && I != J) {
         __syncthreads();
         for (int e = tid; e < BM * BM; e += Cfg::NT) {
@@ -210,12 +231,12 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
 template <int BM, int BK, int WM, int WN, bool LM>
 static void launch_cfg(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                        const double* coef, int K, int p, const double* A1 = nullptr, const double* B1 = nullptr,
-                       double* C1 = nullptr, int K1 = 0)
+                       double* C1 = nullptr, int K1 = 0, double* maxdev = nullptr)
 {
     using Cfg = SymCfg<BM, BK, WM, WN, LM>;
     const int T = (p + BM - 1) / BM;
     hipLaunchKernelGGL((k_symm_tn<BM, BK, WM, WN, LM>), dim3(xcd_grid(T * (T + 1) / 2, K + K1)), dim3(Cfg::NT), 0, st, A,
-                       B, C, C2, E, coef, K, p, A1, B1, C1, K1);
+                       B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -450,7 +471,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 }
 
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
-                 const double* coef, int K, int p, int variant)
+                 const double* coef, int K, int p, int variant, double* maxdev)
 {
     if (variant < 0) {
         // Measured on MI355X (tools/tail_test.py): with fewer than ~800 64x64 tile pairs in the batch the
@@ -459,24 +480,24 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         variant = (T64 * (T64 + 1) / 2 * K <= 800) ? 9 : 0;
     }
     switch (variant) {
-        case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, C2, E, coef, K, p); break;
-        case 2: launch_cfg<128, 16, 64, 64, false>(st, A, B, C, C2, E, coef, K, p); break;
-        case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, C2, E, coef, K, p); break;
-        case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, C2, E, coef, K, p); break;
-        case 5: launch_cfg<128, 32, 64, 64, false>(st, A, B, C, C2, E, coef, K, p); break;
-        case 8: launch_cfg<32, 16, 16, 16, true>(st, A, B, C, C2, E, coef, K, p); break;
-        case 9: launch_cfg<32, 32, 16, 16, true>(st, A, B, C, C2, E, coef, K, p); break;
+        case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
+        case 2: launch_cfg<128, 16, 64, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
+        case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
+        case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
+        case 5: launch_cfg<128, 32, 64, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
+        case 8: launch_cfg<32, 16, 16, 16, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
+        case 9: launch_cfg<32, 32, 16, 16, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 6: {   // ablation of variant 0: no global loads
             const int T = (p + 63) / 64;
-            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 1>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0);
+            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 1>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, nullptr);
             break;
         }
         case 7: {   // ablation of variant 0: no MFMA
             const int T = (p + 63) / 64;
-            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 2>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0);
+            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 2>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, nullptr);
             break;
         }
-        default: launch_cfg<64, 16, 32, 32, true>(st, A, B, C, C2, E, coef, K, p); break;
+        default: launch_cfg<64, 16, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
     }
 }
 

@@ -67,10 +67,18 @@ struct ggl_ctx {
     int symm_variant = -1;
     double *nsYP[2] = {nullptr, nullptr}, *nsT = nullptr;   // [Y|Z] scratch pairs (2 stacks each), T
     int ns_force = 0;                          // 0 auto, 1 symmetric products, 2 stable products
+    bool use_syevj = false;
+    int* sweeps = nullptr;
     long long ns_stable_calls = 0;
     double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
     double *bounds = nullptr, *bounds_h = nullptr;   // [K][2]
     double *rowpart = nullptr, *sqpart = nullptr;    // scratch of the norm bounds (newton_schulz.hip)
+    double *nbpart = nullptr, *nbpart_h = nullptr;   // [K][blocks][2] norm bounds of C (L-step)
+    double *maxdev = nullptr, *maxdev_h = nullptr;   // [K] residual of the sign iteration
+    bool rank_ns = false;                            // L-step by sign Newton-Schulz (else eigendecomposition)
+    double rank_l0 = 1e-6;                           // resolution of the scaling schedule
+    int rank_hold = 0;                               // iterations to stay at the fine resolution
+    long long rank_calls = 0, rank_retries = 0, rank_fallbacks = 0;
     long long ns_steps_total = 0, ns_calls = 0, ns_units_total = 0, ns_launches_total = 0;
     // per-phase HIP-event timing
     bool prof_on = false;
@@ -140,6 +148,7 @@ static int ctx_alloc(ggl_ctx* c)
     HIPCHK(hipMalloc(&c->scale, 2 * kp * sizeof(double)));
     HIPCHK(hipMalloc(&c->E, kp * sizeof(double)));
     HIPCHK(hipMalloc(&c->info, c->K * sizeof(int)));
+    HIPCHK(hipMalloc(&c->sweeps, c->K * sizeof(int)));
     HIPCHK(hipMalloc(&c->par, 6 * (size_t)c->K * sizeof(double)));
     HIPCHK(hipHostMalloc(&c->par_h, 6 * (size_t)c->K * sizeof(double)));
     HIPCHK(hipMalloc(&c->mask, (size_t)c->p * c->p * sizeof(double)));
@@ -169,6 +178,13 @@ static int ctx_alloc(ggl_ctx* c)
         const int Tf = form_W_tiles(c->p);
         HIPCHK(hipMalloc(&c->rowpart, (size_t)c->K * Tf * c->p * sizeof(double)));
         HIPCHK(hipMalloc(&c->sqpart, (size_t)c->K * (Tf * (Tf + 1) / 2) * sizeof(double)));
+        const size_t nbl = 2 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);
+        HIPCHK(hipMalloc(&c->nbpart, nbl));
+        HIPCHK(hipHostMalloc(&c->nbpart_h, nbl));
+        HIPCHK(hipMalloc(&c->maxdev, c->K * sizeof(double)));
+        HIPCHK(hipHostMalloc(&c->maxdev_h, c->K * sizeof(double)));
+        c->rank_ns = true;
+        if (const char* v = getenv("GGL_RANK_EIG")) c->rank_ns = atoi(v) == 0;   // 1: force the eigh route
     }
     return GGL_OK;
 }
@@ -191,6 +207,7 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
     c->omega_ns = use_ns(eig, p);
     if (const char* v = getenv("GGL_SYMM_VARIANT")) c->symm_variant = atoi(v);
     if (const char* v = getenv("GGL_NS_MODE")) c->ns_force = atoi(v);   // 1 symmetric, 2 stable (testing)
+    if (const char* v = getenv("GGL_ROCSOLVER_SYEVJ")) c->use_syevj = atoi(v) != 0;
     c->n = (size_t)K * p * p;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -220,12 +237,15 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
-                      c->nsT, c->coef, c->bounds, c->sqwork, c->rowpart, c->sqpart};
+                      c->nsT, c->coef, c->bounds, c->sqwork, c->rowpart, c->sqpart, c->nbpart, c->maxdev};
+    if (c->nbpart_h) (void)hipHostFree(c->nbpart_h);
+    if (c->maxdev_h) (void)hipHostFree(c->maxdev_h);
     if (c->coef_h) (void)hipHostFree(c->coef_h);
     if (c->bounds_h) (void)hipHostFree(c->bounds_h);
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (c->info) (void)hipFree(c->info);
+    if (c->sweeps) (void)hipFree(c->sweeps);
     if (c->par_h) (void)hipHostFree(c->par_h);
     if (c->norms_h) (void)hipHostFree(c->norms_h);
     if (c->info_h) (void)hipHostFree(c->info_h);
@@ -325,6 +345,20 @@ static int eig_recon(ggl_ctx* c, double* A, double* out, double* Dv, int map, co
         return GGL_OK;
     }
     if (ph_eig >= 0) PB(c, ph_eig);
+    if (c->use_syevj) {
+        // experiment: rocSOLVER's Jacobi driver instead of syevd (GGL_ROCSOLVER_SYEVJ=1)
+        rocblas_status sj = rocsolver_dsyevj_strided_batched(c->blas, rocblas_esort_none, rocblas_evect_original,
+                                                             rocblas_fill_upper, c->p, A, c->p,
+                                                             (rocblas_stride)c->p * c->p, 0.0, c->E, 100,
+                                                             (rocblas_int*)c->sweeps, Dv, c->p, c->info, c->K);
+        if (sj != rocblas_status_success) return fail(GGL_E_SOLVER, "rocsolver_dsyevj_strided_batched: status %d", (int)sj);
+        if (ph_eig >= 0) PE(c, ph_eig);
+        if (ph_recon >= 0) PB(c, ph_recon);
+        launch_recon(c->stream, out, A, Dv, betaK, map, c->K, c->p, c->scale);
+        if (ph_recon >= 0) PE(c, ph_recon);
+        HIPCHK(hipGetLastError());
+        return GGL_OK;
+    }
     // row-major symmetric == column-major symmetric; the row-major LOWER triangle (what numpy's
     // eigh reads) is the column-major UPPER one.  Eigenvectors come back in column-major columns
     // == row-major ROWS, the layout launch_recon wants.
@@ -465,6 +499,60 @@ static int finish_norms(ggl_ctx* c, int rows, double out_norms[5])
     return GGL_OK;
 }
 
+// L = (C - mu I)_+ with C in c->W and mu_k/rho in parameter slot 2 (pinned mirror par_h + 2K).
+// Sign Newton-Schulz with a-posteriori verification; retries at a finer resolution, then falls back to the
+// eigendecomposition, so the result always meets the eigh route's accuracy.
+static int rank_step(ggl_ctx* c)
+{
+    const int K = c->K;
+    const double* mu_h = c->par_h + 2 * (size_t)K;
+    if (!c->rank_ns) return eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)K, GGL_PH_EIG_L, GGL_PH_RECON_L);
+    PB(c, GGL_PH_EIG_L);
+    const int nbb = norm_bounds_blocks(c->p);
+    launch_norm_bounds(c->stream, c->W, K, c->p, c->nbpart);
+    HIPCHK(hipMemcpyAsync(c->nbpart_h, c->nbpart, 2 * (size_t)K * nbb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<double> cn(K);
+    for (int k = 0; k < K; ++k) {
+        double mx = 0.0, sq = 0.0;
+        for (int b = 0; b < nbb; ++b) {
+            mx = std::max(mx, c->nbpart_h[2 * ((size_t)k * nbb + b)]);
+            sq += c->nbpart_h[2 * ((size_t)k * nbb + b) + 1];
+        }
+        cn[k] = std::min(mx, std::sqrt(sq));
+    }
+    c->rank_calls += 1;
+    double l0 = (c->rank_hold > 0) ? 1e-10 : c->rank_l0;
+    if (c->rank_hold > 0) c->rank_hold -= 1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        NsPlan plan;
+        if (rank_ns_plan(cn.data(), mu_h, K, l0, c->coef_h, &plan) != 0)
+            return fail(GGL_E_SOLVER, "L-step: non-finite C (diverged iterate?)");
+        HIPCHK(hipMemcpyAsync(c->coef, c->coef_h, (size_t)plan.products * NS_SLOT(K) * sizeof(double),
+                              hipMemcpyHostToDevice, c->stream));
+        // scratch: Xa = nsYP[0], Xb = nsYP[0] + n, P2 = nsYP[1], T = nsT
+        rank_ns_run(c->stream, plan, c->coef, c->W, c->nsYP[0], c->nsYP[0] + c->n, c->nsT, c->nsYP[1], c->L, c->maxdev, K,
+                    c->p, c->symm_variant);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->maxdev_h, c->maxdev, K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        double dev = 0.0;
+        for (int k = 0; k < K; ++k) dev = std::max(dev, c->maxdev_h[k]);
+        // |T_last - I| = |I - X^2|/2 of the iterate BEFORE the last step; the last step squares it
+        if (std::isfinite(dev) && 2.0 * dev <= 1e-4) {
+            PE(c, GGL_PH_EIG_L);
+            return GGL_OK;
+        }
+        c->rank_retries += 1;
+        c->rank_hold = 8;       // an eigenvalue sits within l0*|B| of the threshold: stay fine for a while
+        if (l0 <= 1e-10) break;
+        l0 = 1e-10;
+    }
+    PE(c, GGL_PH_EIG_L);
+    c->rank_fallbacks += 1;
+    return eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)K, -1, GGL_PH_RECON_L);
+}
+
 extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double lambda2, int reg, int latent,
                                const double* mu1, int groupsq_ready, double out_norms[5])
 {
@@ -512,7 +600,7 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
     if (latent) {
         int rc = upload_par(c, 2, mu1, 0.0, rho);   // mu1_k / rho   (admm_solver.py:202)
         if (rc) return rc;
-        rc = eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)c->K, GGL_PH_EIG_L, GGL_PH_RECON_L);
+        rc = rank_step(c);
         if (rc) return rc;
         PB(c, GGL_PH_DUAL);
         launch_dual_update(c->stream, c->X, Om, OmPrev, c->Theta, c->L, c->partials, c->K, c->p);
@@ -562,7 +650,7 @@ extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* l
     PE(c, GGL_PH_THETA);
     HIPCHK(hipGetLastError());
     if (latent) {
-        rc = eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)K, GGL_PH_EIG_L, GGL_PH_RECON_L);
+        rc = rank_step(c);
         if (rc) return rc;
         PB(c, GGL_PH_DUAL);
         launch_dual_update(c->stream, c->X, Om, OmPrev, c->Theta, c->L, c->partials, K, c->p);
@@ -629,7 +717,7 @@ extern "C" int ggl_profile_enable(ggl_ctx* c, int on)
     return GGL_OK;
 }
 
-extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[5])
+extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[8])
 {
     ARGCHK(c && out, "ctx, out");
     out[0] = c->ns_calls;
@@ -637,6 +725,9 @@ extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[5])
     out[2] = c->ns_stable_calls;
     out[3] = c->ns_units_total;
     out[4] = c->ns_launches_total;
+    out[5] = c->rank_calls;
+    out[6] = c->rank_retries;
+    out[7] = c->rank_fallbacks;
     return GGL_OK;
 }
 
@@ -1000,7 +1091,27 @@ extern "C" int ggl_phiplus_matrix(int K, int p, const double* beta, const double
 
 extern "C" int ggl_rank_matrix(int K, int p, const double* beta, const double* C, double* out, int eig_method)
 {
-    ARGCHK(beta && out, "beta, out");
+    ARGCHK(beta && out && C, "beta, C, out");
+    ARGCHK(K >= 1 && p >= 1, "K, p");
+    if (use_ns(eig_method, p)) {
+        // the L-step of a scratch ctx: C into the work stack, beta into the mu/rho parameter slot
+        ggl_ctx* c = nullptr;
+        int rc = ggl_ctx_create(0, K, p, GGL_EIG_NEWTON_SCHULZ, nullptr, &c);
+        if (rc) return rc;
+        hipError_t e = hipMemcpyAsync(c->W, C, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            rc = upload_par(c, 2, beta, 0.0, 1.0);
+            if (!rc) rc = rank_step(c);
+            if (!rc) e = hipMemcpyAsync(out, c->L, c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        if (getenv("GGL_RANK_VERBOSE"))
+            fprintf(stderr, "rank_ns: calls %lld retries %lld fallbacks %lld\n", c->rank_calls, c->rank_retries,
+                    c->rank_fallbacks);
+        ggl_ctx_destroy(c);
+        if (e != hipSuccess) return fail(GGL_E_HIP, "ggl_rank_matrix: %s", hipGetErrorString(e));
+        return rc;
+    }
     return eig_common(K, p, C, beta, nullptr, nullptr, out, MAP_RANK, eig_method);
 }
 

@@ -101,8 +101,9 @@ void launch_recon(hipStream_t st, double* out, const double* R, const double* D,
 // symmetric A, B (so that A*B = A^T*B is symmetric).  coef: device [K][5] = {cI,cAcc,cE,dI,dC}.
 // variant < 0: pick by problem size.  FP64 MFMA.
 int symm_variants();
+// maxdev (optional, device [K], zeroed by the caller): max |C - I| per instance.
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
-                 const double* coef, int K, int p, int variant);
+                 const double* coef, int K, int p, int variant, double* maxdev = nullptr);
 
 // measured FP64 matrix-core ceiling (MFMA-only probe kernel)
 double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nacc);
@@ -136,5 +137,12 @@ int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h,
 // YP[0], YP[1]: two scratch buffers of 2 stacks each (Y stack followed by Z/P stack); Tb: one stack.
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* W, double* YP0, double* YP1,
             double* Tb, double* out, int K, int p, int variant);
+
+// L-step (C - mu I)_+ by a sign-function Newton-Schulz iteration (newton_schulz.hip)
+int norm_bounds_blocks(int p);
+void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* part);
+int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan);
+void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
+                 double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant);
 
 }  // namespace ggl

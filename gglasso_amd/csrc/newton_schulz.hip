@@ -271,4 +271,104 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// L-step without an eigendecomposition:  L = (C - mu I)_+ = (C - mu I)(I + sign(C - mu I))/2
+// (prox_rank_norm, solver/ggl_helper.py:29-36 with D,Q from eigh, admm_solver.py:197-205).
+// sign(B) by the scaled Newton-Schulz iteration X <- a X (3I - a^2 X^2)/2, X0 = B/|B|: a single sequence of
+// polynomials in B, so every product is a product of commuting symmetric matrices and the symmetrised
+// form is stable (unlike the coupled square-root iteration).  Eigenvalues of B closer to zero than
+// l0*|B| are not resolved by a schedule built for l0; that is DETECTED from max|T_last - I| (the last
+// step's residual) and the caller then retries with a smaller l0 or falls back to rocSOLVER, so the
+// result is never silently inexact.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_norm_bounds(const double* __restrict__ W, int p, double* __restrict__ part)
+{
+    __shared__ double sh_abs[4], sh_sq[4];
+    const int k = blockIdx.y;
+    const double* w = W + (size_t)k * p * p;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 64 + wave * 16;
+    double mx = 0.0, sq = 0.0;
+    for (int i = r0; i < min(r0 + 16, p); ++i) {
+        double a = 0.0;
+        for (int j = lane; j < p; j += 64) {
+            const double v = w[(size_t)i * p + j];
+            a += fabs(v);
+            sq += v * v;
+        }
+        mx = fmax(mx, wave_sum(a));
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) { sh_abs[wave] = mx; sh_sq[wave] = sq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = part + 2 * ((size_t)k * gridDim.x + blockIdx.x);
+        o[0] = fmax(fmax(sh_abs[0], sh_abs[1]), fmax(sh_abs[2], sh_abs[3]));
+        o[1] = (sh_sq[0] + sh_sq[1]) + (sh_sq[2] + sh_sq[3]);
+    }
+}
+
+int norm_bounds_blocks(int p) { return (p + 63) / 64; }
+
+// part[k][blk] = {max row abs-sum, sum of squares} over row block blk (host finishes the reduction)
+void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* part)
+{
+    hipLaunchKernelGGL(k_norm_bounds, dim3(norm_bounds_blocks(p), K), dim3(256), 0, st, W, p, part);
+}
+
+// cnorm_h[k] >= |C_k|_2, mu_h[k] = mu1_k / rho.  Fills the coefficient table; returns steps.
+int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan)
+{
+    std::vector<double> al = ns_schedule(l0 < 0.5 ? l0 : 0.5);
+    const int n = (int)al.size();
+    if (n < 2) return -1;
+    plan->steps = n;
+    plan->products = 2 * n + 1;
+    plan->stable = false;
+    for (int k = 0; k < K; ++k) {
+        const double mu = mu_h[k];
+        const double nb = (cnorm_h[k] + mu) * (1.0 + 1e-10);      // |C - mu I| <= |C| + mu
+        if (!(nb > 0.0) || !std::isfinite(nb)) return -1;
+        auto put = [&](int g, double cI, double cAcc, double cE, double dI, double dC) {
+            double* o = coef_h + (size_t)g * NS_SLOT(K) + (size_t)k * 5;
+            o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = dI; o[4] = dC;
+        };
+        int g = 0;
+        const double a0 = al[0], s2 = a0 * a0 / (nb * nb);
+        // T0 = 1.5 I - 0.5 a0^2 X0^2, X0 = (C - mu I)/nb   [product C*C, E = C]
+        put(g++, 1.5 - 0.5 * s2 * mu * mu, -0.5 * s2, s2 * mu, 0.0, 0.0);
+        // X1 = a0 X0 T0 = (a0/nb) C T0 - (a0 mu/nb) T0      [product C*T0, E = T0]
+        put(g++, 0.0, a0 / nb, -a0 * mu / nb, 0.0, 0.0);
+        for (int it = 1; it < n; ++it) {
+            const double a = al[it];
+            put(g++, 1.5, -0.5 * a * a, 0.0, 0.0, 0.0);          // T = 1.5 I - 0.5 a^2 X^2
+            put(g++, 0.0, a, 0.0, 1.0, 1.0);                     // X <- a X T ; second output P2 = I + X
+        }
+        // L = (C - mu I) P2 / 2 = 0.5 C P2 - 0.5 mu P2        [product C*P2, E = P2]
+        put(g++, 0.0, 0.5, -0.5 * mu, 0.0, 0.0);
+    }
+    return 0;
+}
+
+// C preserved.  Xa, Xb, Tb, P2: scratch stacks.  maxdev: device [K], receives max|T_last - I|.
+void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
+                 double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant)
+{
+    const size_t cs = NS_SLOT(K);
+    int g = 0;
+    const int n = plan.steps;
+    double *X = Xa, *Xn = Xb;
+    (void)hipMemsetAsync(maxdev, 0, K * sizeof(double), st);
+    launch_symm(st, C, C, Tb, nullptr, C, coef_d + cs * g++, K, p, variant);
+    launch_symm(st, C, Tb, X, nullptr, Tb, coef_d + cs * g++, K, p, variant);
+    for (int it = 1; it < n; ++it) {
+        const bool last = (it == n - 1);
+        launch_symm(st, X, X, Tb, nullptr, nullptr, coef_d + cs * g++, K, p, variant, last ? maxdev : nullptr);
+        launch_symm(st, X, Tb, Xn, last ? P2 : nullptr, nullptr, coef_d + cs * g++, K, p, variant);
+        std::swap(X, Xn);
+    }
+    launch_symm(st, C, P2, out, nullptr, P2, coef_d + cs * g++, K, p, variant);
+}
+
 }  // namespace ggl

@@ -266,3 +266,45 @@ def test_phiplus_newton_schulz_reads_lower_triangle(ops):
     ref, _ = orc.phiplus_stack(Al, 0.7)
     out = ops.phiplus_matrix(A, 0.7, method=3)
     assert np.abs(out - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+# ---- eigendecomposition-free L-step (sign-function Newton-Schulz with verification) ----------------------
+
+def test_g1_g2_rank_newton_schulz(ops):
+    g = load_golden("g1_g2_eigen_prox")
+    for n in range(int(g["count"])):
+        W, beta = g[f"W_{n}"], float(g[f"beta_{n}"])
+        scale = max(1.0, np.abs(W).max())
+        lr = ops.rank_matrix(W, beta, method=3)
+        assert np.abs(lr - g[f"rank_{n}"]).max() <= 1e-12 * scale * W.shape[0], n
+        assert np.array_equal(lr, lr.T)
+
+
+@pytest.mark.parametrize("K,p", [(3, 40), (2, 150), (3, 200), (1, 333)])
+def test_rank_newton_schulz_sizes_and_thresholds(ops, K, p):
+    rng = np.random.default_rng(500 + p)
+    W = _sym(rng, K, p, 1.0)
+    for beta in (0.05, 1.0, 5.0, 100.0):        # many / few / no eigenvalues above the threshold
+        b = np.full(K, beta)
+        ref = orc.rank_stack(W, b)
+        out = ops.rank_matrix(W, b, method=3)
+        assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(W).max()) * p, beta
+        if beta == 100.0:
+            assert np.abs(out).max() <= 1e-12
+
+
+def test_rank_newton_schulz_eigenvalue_at_the_threshold(ops):
+    """An eigenvalue within 1e-13 of the threshold cannot be resolved by any schedule: the residual check
+    must catch it (retry, then eigendecomposition fallback) and the result must still be exact."""
+    rng = np.random.default_rng(77)
+    p = 160
+    Q, _ = np.linalg.qr(rng.standard_normal((p, p)))
+    d = rng.standard_normal(p)
+    d[3] = 0.7 + 1e-13
+    d[4] = 0.7 - 3e-8
+    d[5] = 0.7 + 2e-5
+    C = (Q * d) @ Q.T
+    C = 0.5 * (C + C.T)
+    ref = orc.rank_stack(C[None], 0.7)[0]
+    out = ops.rank_matrix(C, 0.7, method=3)
+    assert np.abs(out - ref).max() <= 1e-11
