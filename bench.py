@@ -192,6 +192,14 @@ def main():
                        "recon_omega": "k_recon", "recon_L": "k_recon", "form_W": "k_form_W",
                        "dual": "k_dual_update", "eig_L": "k_jacobi" if eig_jacobi else "rocsolver_dsyevd"}.get(dom, dom)
         sec = phases[dom]["ms_per_launch"] * 1e-3
+        if dom == "eig_L" and omega_ns and ns1["rank_launches"] > ns0["rank_launches"]:
+            # L-step by sign Newton-Schulz: the phase is (2n+1) symmetric products of K p^3 flop each
+            launches = ns1["rank_launches"] - ns0["rank_launches"]
+            kernel_name = "k_symm_tn (sign Newton-Schulz product, L-step)"
+            bound, unit = "mfma", "TFLOP/s"
+            amount = 1.0 * Kl * p ** 3
+            sec = phases[dom]["ms_per_launch"] * phases[dom]["launches"] * 1e-3 / launches
+            phases[dom]["launches"] = launches
         if dom == "eig_omega" and omega_ns:
             # the Omega-step's launches differ in size (a pair launch carries two products): average over
             # the step = algorithmic flop of all its launches / their total duration (HIP events)
@@ -222,7 +230,10 @@ def main():
                                        "frac": its * iter_bytes / 1e9 / HBM_PEAK_GBS},
             "phases_ms": {ph: round(v["ms_per_launch"], 4) for ph, v in phases.items()},
             "newton_schulz": {"steps_per_omega_step": (ns1["steps"] - ns0["steps"]) / max(1, ns1["calls"] - ns0["calls"]),
-                              "stable_schedule_calls": ns1["stable_calls"] - ns0["stable_calls"]} if omega_ns else None,
+                              "stable_schedule_calls": ns1["stable_calls"] - ns0["stable_calls"],
+                              "lstep_calls": ns1["rank_calls"] - ns0["rank_calls"],
+                              "lstep_retries": ns1["rank_retries"] - ns0["rank_retries"],
+                              "lstep_eigh_fallbacks": ns1["rank_fallbacks"] - ns0["rank_fallbacks"]} if omega_ns else None,
         }
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, reg, l1, l2, latent, mu1, args.cpu_iters)

@@ -78,7 +78,7 @@ struct ggl_ctx {
     bool rank_ns = false;                            // L-step by sign Newton-Schulz (else eigendecomposition)
     double rank_l0 = 1e-6;                           // resolution of the scaling schedule
     int rank_hold = 0;                               // iterations to stay at the fine resolution
-    long long rank_calls = 0, rank_retries = 0, rank_fallbacks = 0;
+    long long rank_calls = 0, rank_retries = 0, rank_fallbacks = 0, rank_launches = 0;
     long long ns_steps_total = 0, ns_calls = 0, ns_units_total = 0, ns_launches_total = 0;
     // per-phase HIP-event timing
     bool prof_on = false;
@@ -169,7 +169,7 @@ static int ctx_alloc(ggl_ctx* c)
     if (c->omega_ns) {
         for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->nsYP[i], 2 * nb));
         HIPCHK(hipMalloc(&c->nsT, nb));
-        const size_t cl = (size_t)2 * NS_MAX_STEPS * NS_SLOT(c->K) * sizeof(double);
+        const size_t cl = (size_t)NS_MAX_LAUNCHES * NS_SLOT(c->K) * sizeof(double);
         HIPCHK(hipMalloc(&c->coef, cl));
         HIPCHK(hipHostMalloc(&c->coef_h, cl));
         const size_t bl = 2 * (size_t)c->K * sizeof(double);
@@ -534,6 +534,7 @@ static int rank_step(ggl_ctx* c)
         rank_ns_run(c->stream, plan, c->coef, c->W, c->nsYP[0], c->nsYP[0] + c->n, c->nsT, c->nsYP[1], c->L, c->maxdev, K,
                     c->p, c->symm_variant);
         HIPCHK(hipGetLastError());
+        c->rank_launches += plan.products;
         HIPCHK(hipMemcpyAsync(c->maxdev_h, c->maxdev, K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         double dev = 0.0;
@@ -717,7 +718,7 @@ extern "C" int ggl_profile_enable(ggl_ctx* c, int on)
     return GGL_OK;
 }
 
-extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[8])
+extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[9])
 {
     ARGCHK(c && out, "ctx, out");
     out[0] = c->ns_calls;
@@ -728,6 +729,7 @@ extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[8])
     out[5] = c->rank_calls;
     out[6] = c->rank_retries;
     out[7] = c->rank_fallbacks;
+    out[8] = c->rank_launches;
     return GGL_OK;
 }
 

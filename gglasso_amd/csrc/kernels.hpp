@@ -117,7 +117,9 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
                       double* C1, const double* coef2K, int K, int p, int variant);
 
 // ---- newton_schulz.hip ------------------------------------------------------------------
-static constexpr int NS_MAX_STEPS = 24;
+static constexpr int NS_MAX_STEPS = 24;        // square-root schedule (condition number up to ~1e18)
+static constexpr int NS_RANK_MAX_STEPS = 40;   // sign schedule (resolution down to ~1e-13)
+static constexpr int NS_MAX_LAUNCHES = 2 * NS_RANK_MAX_STEPS + 1;
 // doubles per launch slot of the coefficient table (a pair launch carries 2K rows of 5)
 static inline size_t NS_SLOT(int K) { return (size_t)K * 10; }
 // all-symmetric products are only accurate while the condition number of W^2 + 4 beta I is small

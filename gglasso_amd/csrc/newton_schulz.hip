@@ -157,10 +157,10 @@ void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const dou
 // ---------------------------------------------------------------------------------------------
 // host side: scaling schedule and the product sequence
 // ---------------------------------------------------------------------------------------------
-static std::vector<double> ns_schedule(double l)
+static std::vector<double> ns_schedule(double l, int max_steps = NS_MAX_STEPS)
 {
     std::vector<double> al;
-    for (int it = 0; it < NS_MAX_STEPS; ++it) {
+    for (int it = 0; it < max_steps; ++it) {
         const double a = (l < 0.99) ? std::sqrt(3.0 / (1.0 + l + l * l)) : 1.0;
         al.push_back(a);
         const double gl = 0.5 * a * l * (3.0 - a * a * l * l);
@@ -320,7 +320,7 @@ void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* p
 // cnorm_h[k] >= |C_k|_2, mu_h[k] = mu1_k / rho.  Fills the coefficient table; returns steps.
 int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan)
 {
-    std::vector<double> al = ns_schedule(l0 < 0.5 ? l0 : 0.5);
+    std::vector<double> al = ns_schedule(l0 < 0.5 ? l0 : 0.5, NS_RANK_MAX_STEPS);
     const int n = (int)al.size();
     if (n < 2) return -1;
     plan->steps = n;
