@@ -20,15 +20,19 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                    rtol=1e-4, update_rho=True, verbose=False, latent=False, mu1=None, lambda1_mask=None):
     """Solve ``ADMM_SGL(S, lambda1[k], ...)`` for every k of the 1-D array ``lambda1`` at once.
 
-    S: (p,p).  Omega_0 / Theta_0 / X_0: (p,p) shared start or (K,p,p) per instance (default identity /
+    S: (p,p) shared by all instances, or (K,p,p) with one covariance matrix per instance (what
+    ``block_SGL`` needs for equally sized blocks).  Omega_0 / Theta_0 / X_0: (p,p) shared start or (K,p,p) per instance (default identity /
     Omega_0 / zeros, as in single_admm_solver.py:129-137).  mu1: scalar or (K,) when ``latent``.
     Returns a list of K ``(sol, info)`` pairs with the reference's keys; ``info`` additionally carries
     ``'iterations'`` and the final ``'rho'``."""
     S = as_c(S)
-    assert S.ndim == 2 and S.shape[0] == S.shape[1]
-    p = S.shape[0]
+    assert S.ndim in (2, 3) and S.shape[-1] == S.shape[-2]
+    p = S.shape[-1]
     lam = as_c(np.atleast_1d(lambda1)).reshape(-1)
+    if S.ndim == 3 and len(lam) == 1:
+        lam = np.repeat(lam, S.shape[0])      # K different covariance matrices, one lambda1
     K = len(lam)
+    assert S.ndim == 2 or S.shape[0] == K
     assert np.all(lam > 0), "lambda1 should be positive"
     assert rho > 0
     lam_pp = None

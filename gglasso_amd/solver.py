@@ -350,3 +350,81 @@ def ADMM_SGL(S, lambda1, Omega_0, Theta_0=np.array([]), X_0=np.array([]), rho=1.
     if latent:
         sol['L'] = st['L'][0]
     return sol, info
+
+
+def get_connected_components(S, lambda1):
+    """Connected components of the graph |S_ij| > lambda1_ij with the diagonal kept
+    (solver/single_admm_solver.py:478-490)."""
+    from scipy.sparse.csgraph import connected_components
+    A = (np.abs(S) > lambda1).astype(int)
+    np.fill_diagonal(A, 1)
+    numC, labels = connected_components(A, directed=False, return_labels=True)
+    return numC, [np.flatnonzero(labels == i) for i in range(numC)]
+
+
+def block_SGL(S, lambda1, Omega_0, Theta_0=None, X_0=None, rho=1., max_iter=1000, tol=1e-7, rtol=1e-3,
+              stopping_criterion="boyd", update_rho=True, verbose=False, measure=False, lambda1_mask=None):
+    """The reference's ``block_SGL`` (solver/single_admm_solver.py:326-475; what ``glasso_problem.solve()``
+    calls for non-latent SGL, problem.py:443-450): split S into the connected components of |S| > lambda1,
+    solve singletons in closed form 1/S_ii and every larger block with ADMM, reassemble.  Returns ``sol`` only,
+    like the reference.
+
+    The graph split stays on the host (SciPy).  Blocks of equal size are solved TOGETHER as one batch on the
+    GPU (gglasso_amd.batch.ADMM_SGL_batch: each block keeps its own rho and stopping iteration, so the
+    result equals the reference's block-by-block loop); with a ``lambda1_mask``, the KKT criterion or
+    ``measure`` the blocks go through ``ADMM_SGL`` one by one exactly as in the reference."""
+    from scipy.linalg import block_diag
+    from .batch import ADMM_SGL_batch
+    assert Omega_0.shape == S.shape
+    assert S.shape[0] == S.shape[1]
+    (p, p) = S.shape
+    assert lambda1 > 0, ("lambda1 should be positive, otherwise using Graphical Lasso is redundant. "
+                         "Specify entries with zero regularization using lambda1_mask.")
+    has_mask = lambda1_mask is not None
+    if has_mask:
+        assert lambda1_mask.shape == (p, p), f"lambda1_mask needs to be of shape (p,p), but is {lambda1_mask.shape}."
+        assert np.all(lambda1_mask >= 0), "lambda1_mask needs to be non-negative."
+        assert np.all(np.abs(lambda1_mask.T - lambda1_mask) <= 1e-5), "lambda1_mask needs to be symmetric."
+    else:
+        lambda1_mask = np.ones((p, p))
+    if Theta_0 is None:
+        Theta_0 = Omega_0.copy()
+    if X_0 is None:
+        X_0 = np.zeros((p, p))
+
+    numC, allC = get_connected_components(S, lambda1 * lambda1_mask)
+    sols = [None] * numC
+    by_size = {}
+    for i, C in enumerate(allC):
+        if len(C) == 1:
+            v = 1 / S[C, C]                     # off-diagonal penalty: 1/S_ii, not 1/(S_ii + lambda1)
+            sols[i] = (v, v, np.array([0]))
+        else:
+            by_size.setdefault(len(C), []).append(i)
+
+    batched = (not has_mask) and stopping_criterion == "boyd" and not measure
+    for size, idx in by_size.items():
+        if batched:
+            ixs = [np.ix_(allC[i], allC[i]) for i in idx]
+            res = ADMM_SGL_batch(np.stack([S[ix] for ix in ixs]), lambda1,
+                                 Omega_0=np.stack([Omega_0[ix] for ix in ixs]),
+                                 Theta_0=np.stack([Theta_0[ix] for ix in ixs]),
+                                 X_0=np.stack([X_0[ix] for ix in ixs]), rho=rho, max_iter=max_iter, tol=tol,
+                                 rtol=rtol, update_rho=update_rho, verbose=verbose)
+            for i, (bs, binfo) in zip(idx, res):
+                print(f"ADMM terminated after {binfo['iterations']} iterations with status: {binfo['status']}.")
+                sols[i] = (bs['Omega'], bs['Theta'], bs['X'])
+        else:
+            for i in idx:
+                ix = np.ix_(allC[i], allC[i])
+                bs, _ = ADMM_SGL(S[ix], lambda1, Omega_0[ix], Theta_0=Theta_0[ix], X_0=X_0[ix], tol=tol, rtol=rtol,
+                                 stopping_criterion=stopping_criterion, update_rho=update_rho, rho=rho,
+                                 max_iter=max_iter, verbose=verbose, measure=measure, lambda1_mask=lambda1_mask[ix])
+                sols[i] = (bs['Omega'], bs['Theta'], bs['X'])
+
+    per = np.hstack(allC)
+    inv = np.empty_like(per)
+    inv[per] = np.arange(per.size)
+    ixp = np.ix_(inv, inv)
+    return {'Omega': block_diag(*[s[0] for s in sols])[ixp], 'Theta': block_diag(*[s[1] for s in sols])[ixp],
+            'X': block_diag(*[s[2] for s in sols])[ixp]}

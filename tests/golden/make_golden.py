@@ -13,7 +13,7 @@ small inputs and stores INPUTS AND OUTPUTS in tests/golden/*.npz.  Nothing of th
 Sets:
   G1 phiplus, G2 prox_rank_norm, G3 prox_od_1norm, G4 prox_2norm/prox_phi_ggl, G5 condat_method,
   G6 prox_p GGL/FGL, G7 ADMM_stopping_criterion, G8 fixed-length ADMM_MGL trajectories,
-  G9 converged ADMM_MGL, G10 ADMM_SGL (+mask, +latent, mask=0 known answer), G11 kkt residuals.
+  G9 converged ADMM_MGL, G10 ADMM_SGL (+mask, +latent, mask=0 known answer, kkt residuals), G11 block_SGL.
 """
 import contextlib
 import io
@@ -248,6 +248,22 @@ def main():
     out["kkt_value"] = np.array(sadmm.kkt_stopping_criterion(sol['Omega'], sol['Theta'], np.zeros((p, p)),
                                                              0.8 * sol['X'], S, 0.05))
     save("g10_admm_sgl", **out)
+
+    # ------------------------------------------------------------------ G11 block_SGL
+    # block-diagonal truth + large lambda1 => several connected components incl. singletons
+    p, N = 30, 200
+    Sig, _ = dg.generate_precision_matrix(p=p, M=5, style='erdos', prob=0.3, seed=1237)
+    S, _ = dg.sample_covariance_matrix(Sig, N, seed=1237)
+    lam = 0.25
+    numC, allC = sadmm.get_connected_components(S, lam)
+    sol = quiet(sadmm.block_SGL, S, lam, np.eye(p), tol=1e-10, rtol=1e-10)
+    full, _ = quiet(sadmm.ADMM_SGL, S, lam, np.eye(p), tol=1e-10, rtol=1e-10)
+    mask = np.ones((p, p))
+    mask[:6, :] = mask[:, :6] = 0.5
+    solm = quiet(sadmm.block_SGL, S, lam, np.eye(p), tol=1e-10, rtol=1e-10, lambda1_mask=mask)
+    save("g11_block_sgl", S=S, lam=np.array(lam), numC=np.array(numC),
+         sizes=np.array(sorted(len(c) for c in allC)), Omega=sol['Omega'], Theta=sol['Theta'], X=sol['X'],
+         full_Theta=full['Theta'], mask=mask, mask_Theta=solm['Theta'], mask_Omega=solm['Omega'])
 
 
 if __name__ == "__main__":

@@ -193,3 +193,37 @@ def test_sgl_batch_max_iter_status_and_mask():
         assert info['status'] == 'max iterations reached' and info['iterations'] == 6
         for nm in ref:
             assert np.abs(sol[nm] - ref[nm]).max() <= 1e-10
+
+
+# ---- block_SGL (connected-component split on the host, equal-size blocks batched on the GPU) ------------
+
+def test_g11_block_sgl(sol):
+    g = load_golden("g11_block_sgl")
+    S, lam = g["S"], float(g["lam"])
+    p = S.shape[0]
+    (out, text) = quiet(sol.block_SGL, S, lam, np.eye(p), tol=1e-10, rtol=1e-10)
+    for nm in ("Omega", "Theta", "X"):
+        assert np.abs(out[nm] - g[nm]).max() <= 1e-9, nm
+    assert text.count("ADMM terminated after") == int(np.sum(g["sizes"] > 1))
+    assert np.abs(out["Theta"] - g["full_Theta"]).max() <= 1e-3          # reference tests/test_solvers.py:123-148
+    (outm, _) = quiet(sol.block_SGL, S, lam, np.eye(p), tol=1e-10, rtol=1e-10, lambda1_mask=g["mask"])
+    assert np.abs(outm["Theta"] - g["mask_Theta"]).max() <= 1e-9
+    assert np.abs(outm["Omega"] - g["mask_Omega"]).max() <= 1e-9
+
+
+def test_block_sgl_like_reference_test(sol):
+    """reference tests/test_solvers.py:123-148: p=100 dense random S, lambda1=0.12, more than one component;
+    block solution vs the un-split ADMM_SGL solution to 3 decimals -- here additionally vs the oracle."""
+    rng = np.random.default_rng(0)
+    p = 100
+    A = rng.uniform(-1, 1, (p, p))
+    S = A @ A.T / p
+    S = 0.5 * (S + S.T) / np.sqrt(np.outer(np.diag(S), np.diag(S)))
+    lam = 0.12 * 3
+    numC, _ = sol.get_connected_components(S, lam)
+    assert numC > 1
+    (out, _) = quiet(sol.block_SGL, S, lam, np.eye(p), tol=1e-8, rtol=1e-8)
+    ref = orc.block_SGL(S, lam, np.eye(p), tol=1e-8, rtol=1e-8)
+    assert np.abs(out["Theta"] - ref["Theta"]).max() <= 1e-8
+    ((full, _), _) = quiet(sol.ADMM_SGL, S, lam, np.eye(p), tol=1e-8, rtol=1e-8)
+    assert np.abs(out["Theta"] - full["Theta"]).max() <= 1e-3

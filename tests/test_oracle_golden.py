@@ -146,3 +146,19 @@ def test_g10_kkt_sgl():
     v = orc.kkt_stopping_criterion_sgl(g["kkt_state_Omega"], g["kkt_state_Theta"], np.zeros((p, p)),
                                        0.8 * g["kkt_state_X"], g["S"], 0.05)
     assert abs(v - float(g["kkt_value"])) <= 1e-12
+
+
+def test_g11_block_sgl():
+    g = load_golden("g11_block_sgl")
+    S, lam = g["S"], float(g["lam"])
+    p = S.shape[0]
+    numC, allC = orc.get_connected_components(S, lam)
+    assert numC == int(g["numC"]) and numC > 1
+    assert sorted(len(c) for c in allC) == list(g["sizes"])
+    sol = orc.block_SGL(S, lam, np.eye(p), tol=1e-10, rtol=1e-10)
+    for nm in ("Omega", "Theta", "X"):
+        assert np.abs(sol[nm] - g[nm]).max() <= 1e-9, nm
+    # reference test tests/test_solvers.py:123-148: block solution == full solution (3 decimals)
+    assert np.abs(sol["Theta"] - g["full_Theta"]).max() <= 1e-3
+    solm = orc.block_SGL(S, lam, np.eye(p), tol=1e-10, rtol=1e-10, lambda1_mask=g["mask"])
+    assert np.abs(solm["Theta"] - g["mask_Theta"]).max() <= 1e-9
