@@ -64,6 +64,37 @@ class OracleEngine:
     def scale_X(self, f):
         self.X = f * self.X
 
+    # K independent single problems (batched lambda path)
+    def sgl_batch_step(self, rho, lambda1, latent, mu1):
+        rho = np.asarray(rho, dtype=np.float64)
+        out = np.zeros((self.K, 5))
+        Om_new = np.empty_like(self.Om)
+        for k in range(self.K):
+            W = self.Th[k] - self.L[k] - self.X[k] - (1 / rho[k]) * self.S[k]
+            D, Q = np.linalg.eigh(W)
+            om = orc.phiplus(1 / rho[k], D, Q)
+            lam = (1 / rho[k]) * lambda1[k] if self.mask is None else (1 / rho[k]) * self.mask
+            th = orc.prox_od_1norm(om + self.L[k] + self.X[k], lam)
+            if latent:
+                C = th - self.X[k] - om
+                D1, Q1 = np.linalg.eigh(C)
+                self.L[k] = orc.prox_rank_norm(C, mu1[k] / rho[k], D1, Q1)
+            x = self.X[k] + om - th + self.L[k]
+            out[k] = [np.sum(om ** 2), np.sum((th - self.L[k]) ** 2), np.sum(x ** 2),
+                      np.sum((om - th + self.L[k]) ** 2), np.sum((om - self.Om[k]) ** 2)]
+            Om_new[k], self.Th[k], self.X[k] = om, th, x
+        self.Om_prev, self.Om = self.Om, Om_new
+        return out
+
+    def scale_X_batch(self, factors):
+        self.X = np.asarray(factors)[:, None, None] * self.X
+
+    def state_k(self, k, latent=False):
+        sol = {'Omega': self.Om[k].copy(), 'Theta': self.Th[k].copy(), 'X': self.X[k].copy()}
+        if latent:
+            sol['L'] = self.L[k].copy()
+        return sol
+
     def objective(self, lambda1, lambda2, reg):
         ld = -np.log(orc.phip(self.D, self.beta[:, None])).sum()
         return np.array([ld, np.sum(self.Om * self.S), orc.P_val(self.Th, lambda1, lambda2, reg)])

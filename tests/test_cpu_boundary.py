@@ -159,3 +159,27 @@ def test_synth_generator_properties():
         assert np.linalg.eigvalsh(S).min() > 0
         assert np.linalg.eigvalsh(Th).min() > 0
         assert (np.abs(Th) > 0).mean() < 0.2
+
+
+def test_host_logic_sgl_batch_and_block_sgl(oracle_engine):
+    """Per-instance rho / stopping bookkeeping of ADMM_SGL_batch and the component split + reassembly of
+    block_SGL, pinned by the reference vectors G10/G11 (array work: test-only oracle engine)."""
+    from gglasso_amd.batch import ADMM_SGL_batch
+    g = load_golden("g10_admm_sgl")
+    S = g["S"]
+    p = S.shape[0]
+    lams = np.array([0.05, 0.2, 0.01])
+    res = ADMM_SGL_batch(S, lams, tol=1e-10, rtol=1e-10)
+    for k, lam in enumerate(lams):
+        ref, rinfo = orc.ADMM_SGL(S, lam, np.eye(p), tol=1e-10, rtol=1e-10)
+        assert res[k][1]['iterations'] == rinfo['iterations'] and res[k][1]['status'] == 'optimal'
+        assert np.abs(res[k][0]['Theta'] - ref['Theta']).max() <= 1e-10
+    assert np.linalg.norm(res[0][0]['Theta'] - g["plain_conv_Theta"]) <= 1e-8
+    g11 = load_golden("g11_block_sgl")
+    S, lam = g11["S"], float(g11["lam"])
+    (sol, out) = _quiet(oracle_engine.block_SGL, S, lam, np.eye(S.shape[0]), tol=1e-10, rtol=1e-10)
+    for nm in ("Omega", "Theta", "X"):
+        assert np.abs(sol[nm] - g11[nm]).max() <= 1e-9
+    (solm, _) = _quiet(oracle_engine.block_SGL, S, lam, np.eye(S.shape[0]), tol=1e-10, rtol=1e-10,
+                       lambda1_mask=g11["mask"])
+    assert np.abs(solm["Theta"] - g11["mask_Theta"]).max() <= 1e-9
