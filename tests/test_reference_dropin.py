@@ -1,0 +1,133 @@
+"""Drop-in check against the REAL reference package (build container only; skipped where /root/reference is
+absent, e.g. on the GPU box).  The reference's own model-selection driver and problem class are run with
+gglasso_amd's solvers plugged in at the two seams SURVEY.md section 8(b) names, and must produce what they produce
+with their own solvers.  No GPU here, so the array work behind gglasso_amd's host loops is done by the test-only
+oracle engine: what is verified is the boundary (signatures, kwargs, return dicts, status strings, warm starts),
+which is exactly what a maintainer's one-line import swap relies on."""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+REF_SRC = "/root/reference/src"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="reference checkout not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    shim = tempfile.mkdtemp(prefix="numba_shim_")
+    os.makedirs(os.path.join(shim, "numba"))
+    with open(os.path.join(shim, "numba", "__init__.py"), "w") as fh:
+        fh.write("def _ident(*a, **k):\n    if len(a) == 1 and callable(a[0]) and not k:\n        return a[0]\n"
+                 "    return lambda f: f\nnjit = jit = _ident\n")
+    with open(os.path.join(shim, "numba", "typed.py"), "w") as fh:
+        fh.write("List = list\n")
+    sys.path.insert(0, REF_SRC)
+    sys.path.insert(0, shim)
+    import gglasso.problem as problem
+    import gglasso.helper.model_selection as ms
+    import gglasso.helper.data_generation as dg
+    import gglasso.solver.admm_solver as admm
+    import gglasso.solver.single_admm_solver as sadmm
+    yield {"problem": problem, "ms": ms, "dg": dg, "admm": admm, "sadmm": sadmm}
+    sys.path.remove(REF_SRC)
+    sys.path.remove(shim)
+
+
+@pytest.fixture()
+def ours(monkeypatch):
+    from gglasso_amd import solver
+    from oracle_engine import OracleEngine
+    monkeypatch.setattr(solver, "ENGINE", OracleEngine)
+    return solver
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def test_seam1_grid_search_takes_our_solver(ref, ours):
+    """helper/model_selection.py:55,222 -- grid_search(solver, ...) calls solver(**kwargs)."""
+    dg, ms = ref["dg"], ref["ms"]
+    K, p, N = 3, 20, 200
+    Sig, _ = dg.group_power_network(p, K=K, M=2, seed=7)
+    S, _ = dg.sample_covariance_matrix(Sig, N, seed=7)
+    l1 = np.logspace(-1, -2, 3)
+    l2 = np.logspace(-1, -2, 2)
+    Nk = np.array([N] * K)
+    a = quiet(ms.grid_search, ref["admm"].ADMM_MGL, S, Nk, p, 'GGL', l1, l2, method='eBIC', gamma=0.3,
+              tol=1e-8, rtol=1e-8)
+    b = quiet(ms.grid_search, ours.ADMM_MGL, S, Nk, p, 'GGL', l1, l2, method='eBIC', gamma=0.3, tol=1e-8, rtol=1e-8)
+    stats_a, ix_a, sol_a = a
+    stats_b, ix_b, sol_b = b
+    assert ix_a == ix_b
+    assert np.allclose(stats_a['BIC'][0.3], stats_b['BIC'][0.3], rtol=1e-8)
+    assert np.allclose(stats_a['SP'], stats_b['SP'])
+    assert np.abs(sol_a['Theta'] - sol_b['Theta']).max() <= 1e-7
+
+
+def test_seam2_glasso_problem_with_patched_solvers(ref, ours, monkeypatch):
+    """problem.py:10-11 imports ADMM_MGL / ADMM_SGL / block_SGL by name; swapping them is the whole integration."""
+    dg, problem, ms = ref["dg"], ref["problem"], ref["ms"]
+    K, p, N = 3, 20, 300
+    Sig, _ = dg.time_varying_power_network(p, K=K, M=4, seed=9)
+    S, _ = dg.sample_covariance_matrix(Sig, N, seed=9)
+
+    def solve(reg, latent):
+        P = problem.glasso_problem(S, N, reg=reg, reg_params={'lambda1': 0.05, 'lambda2': 0.02, 'mu1': 0.3},
+                                   latent=latent, do_scaling=False)
+        quiet(P.solve, tol=1e-9, rtol=1e-9)
+        return P
+
+    base = {(r, l): solve(r, l) for r in ('GGL', 'FGL') for l in (False, True)}
+    monkeypatch.setattr(problem, "ADMM_MGL", ours.ADMM_MGL)
+    monkeypatch.setattr(problem, "ADMM_SGL", ours.ADMM_SGL)
+    monkeypatch.setattr(problem, "block_SGL", ours.block_SGL)
+    monkeypatch.setattr(ms, "ADMM_SGL", ours.ADMM_SGL)
+    monkeypatch.setattr(ms, "block_SGL", ours.block_SGL)
+    for key, P0 in base.items():
+        P1 = solve(*key)
+        assert P1.solver_info['status'] == P0.solver_info['status'] == 'optimal'
+        assert np.abs(P1.solution.precision_ - P0.solution.precision_).max() <= 1e-8
+        if key[1]:
+            assert np.abs(P1.solution.lowrank_ - P0.solution.lowrank_).max() <= 1e-8
+
+    # single problem: non-latent goes through block_SGL (problem.py:443-450), latent through ADMM_SGL (:430-440)
+    for latent in (False, True):
+        monkeypatch.undo()
+        P0 = problem.glasso_problem(S[0], N, reg=None, reg_params={'lambda1': 0.1, 'mu1': 0.4}, latent=latent,
+                                    do_scaling=False)
+        quiet(P0.solve, tol=1e-9, rtol=1e-9)
+        from gglasso_amd import solver
+        from oracle_engine import OracleEngine
+        monkeypatch.setattr(solver, "ENGINE", OracleEngine)
+        monkeypatch.setattr(problem, "ADMM_SGL", solver.ADMM_SGL)
+        monkeypatch.setattr(problem, "block_SGL", solver.block_SGL)
+        P1 = problem.glasso_problem(S[0], N, reg=None, reg_params={'lambda1': 0.1, 'mu1': 0.4}, latent=latent,
+                                    do_scaling=False)
+        quiet(P1.solve, tol=1e-9, rtol=1e-9)
+        assert np.abs(P1.solution.precision_ - P0.solution.precision_).max() <= 1e-8
+
+
+def test_seam2_model_selection_single(ref, ours, monkeypatch):
+    """single_grid_search (model_selection.py:505) drives block_SGL / ADMM_SGL imported at :13."""
+    dg, problem, ms = ref["dg"], ref["problem"], ref["ms"]
+    p, N = 20, 200
+    Sig, _ = dg.generate_precision_matrix(p=p, M=2, style='erdos', prob=0.2, seed=11)
+    S, _ = dg.sample_covariance_matrix(Sig, N, seed=11)
+    lam = np.logspace(0, -2, 5)
+    a = quiet(ms.single_grid_search, S, lam, N, method='eBIC', gamma=0.3, latent=False, use_block=True,
+              tol=1e-8, rtol=1e-8)
+    monkeypatch.setattr(ms, "ADMM_SGL", ours.ADMM_SGL)
+    monkeypatch.setattr(ms, "block_SGL", ours.block_SGL)
+    b = quiet(ms.single_grid_search, S, lam, N, method='eBIC', gamma=0.3, latent=False, use_block=True,
+              tol=1e-8, rtol=1e-8)
+    assert np.abs(a[0]['Theta'] - b[0]['Theta']).max() <= 1e-7
+    assert np.abs(a[1] - b[1]).max() <= 1e-7                       # estimates along the whole lambda path
+    assert np.allclose(a[3]['BIC'][0.3], b[3]['BIC'][0.3], rtol=1e-7)
+    assert a[3]['BEST'] == b[3]['BEST']
