@@ -39,6 +39,8 @@ WORKLOADS = {
     "ggl_K20_p200": ("GGL", 20, 200, False, 0.05, 0.01, 1236),
     "fgl_K50_p500_latent": ("FGL", 50, 500, True, 0.05, 0.01, 1237),
     "ggl_K256_p1000": ("GGL", 256, 1000, False, 0.05, 0.01, 1238),
+    "ggl_K4_p500": ("GGL", 4, 500, False, 0.05, 0.01, 1239),       # per-GPU slab of the headline at 8 GPUs
+    "ggl_K32_p1000": ("GGL", 32, 1000, False, 0.05, 0.01, 1238),   # per-GPU slab of C5 at 8 GPUs
 }
 
 

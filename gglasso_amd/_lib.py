@@ -49,6 +49,7 @@ _SIGNATURES = {
     "ggl_dev_symm": ([_i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _i], _i),
     "ggl_dev_symm_bench": ([_i, _i, _i, _i, _dp], _i),
     "ggl_dev_mfma_f64_peak": ([_dp], _i),
+    "ggl_dev_symm_timeline": ([_i, _i, ctypes.POINTER(ctypes.c_longlong), _i, ctypes.POINTER(_i)], _i),
     "ggl_ns_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_eigh_batched": ([_i, _i, _dp, _dp, _dp, _i], _i),
     "ggl_phiplus": ([_i, _i, _dp, _dp, _dp, _dp], _i),

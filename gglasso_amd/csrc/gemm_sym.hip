@@ -88,6 +88,9 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     const double* Ak = (second ? A1 : A) + (size_t)kk * pp;
     const double* Bk = (second ? B1 : B) + (size_t)kk * pp;
 
+    long long t_start = 0, t_loop = 0, t_loop_end = 0;
+    if (ABL == 3) t_start = clock64();
+
     v4d acc[Cfg::TI][Cfg::TJ];
 #pragma unroll
     for (int i = 0; i < Cfg::TI; ++i)
@@ -148,8 +151,12 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
                 }
     };
 
+    // On a diagonal tile a wave whose sub-tile lies entirely below the diagonal produces nothing that is
+    // kept (only gi <= gj survives there): it still stages and synchronises, but issues no MFMA.
+    const bool dead_wave = (I == J) && (wr >= wc + WN);
 #pragma unroll
     for (int s = 0; s < NST; ++s) fetch(s * BK, ra[s], rb[s]);
+    if (ABL == 3) t_loop = clock64();
     for (int m0 = 0; m0 < p; m0 += NST * BK) {
 #pragma unroll
         for (int s = 0; s < NST; ++s) {
@@ -158,12 +165,13 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
                 stage(ms, ra[s], rb[s]);
                 __syncthreads();
                 fetch(ms + NST * BK, ra[s], rb[s]);          // past the end: clamped, never staged
-                compute();
+                if (!dead_wave) compute();
                 __syncthreads();
             }
         }
     }
 
+    if (ABL == 3) t_loop_end = clock64();
     // epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
     const double cI = coef[k * 5 + 0], cAcc = coef[k * 5 + 1], cE = coef[k * 5 + 2];
     const double dI = coef[k * 5 + 3], dC = coef[k * 5 + 4];
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
                 }
                 if (LM && I != J) smem[row * Cfg::CLD + col] = v;
             }
-    if (maxdev) {
+    if (maxdev && ABL != 3) {
         double dev = 0.0;
 #pragma unroll
         for (int ti = 0; ti < Cfg::TI; ++ti)
@@ -225,6 +233,14 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
                 if (C2k) C2k[(size_t)(J0 + a) * p + I0 + c] = dC * v;
             }
         }
+    }
+    if (ABL == 3 && tid == 0) {
+        // timeline probe: maxdev is (ab)used as a [gridDim.x][5] long long buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* tl = reinterpret_cast<long long*>(maxdev) + (size_t)blockIdx.x * 5;
+        unsigned xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tl[0] = t_start; tl[1] = t_loop; tl[2] = t_loop_end; tl[3] = clock64(); tl[4] = (long long)xcc;
     }
 }
 
@@ -450,7 +466,7 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
     }
 }
 
-int symm_variants() { return 10; }
+int symm_variants() { return 11; }
 
 // Two independent products in one launch: C = coef[k]-affine(A*B) for k < K and C1 = coef[K+k]-scaled(A1*B1).
 void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
@@ -490,6 +506,11 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         case 6: {   // ablation of variant 0: no global loads
             const int T = (p + 63) / 64;
             hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 1>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, nullptr);
+            break;
+        }
+        case 10: {  // timeline probe of variant 0 (maxdev = [grid][5] long long buffer)
+            const int T = (p + 63) / 64;
+            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 3>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev);
             break;
         }
         case 7: {   // ablation of variant 0: no MFMA

@@ -1040,6 +1040,35 @@ extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* 
     return GGL_OK;
 }
 
+// timeline probe: one launch of variant 10; out = [nblocks][5] long long {start, loop, loop_end, end, xcc}
+extern "C" int ggl_dev_symm_timeline(int K, int p, long long* out, int max_blocks, int* nblocks_out)
+{
+    ARGCHK(K >= 1 && p >= 1 && out && nblocks_out, "arguments");
+    const size_t n = (size_t)K * p * p;
+    std::vector<double> h(n, 0.25), coef((size_t)K * 5, 0.0);
+    for (int k = 0; k < K; ++k) coef[(size_t)k * 5 + 1] = 1.0 / p;
+    const int T = (p + 63) / 64;
+    const int nb = (K >= 8 ? 8 * ((K + 7) / 8) : K) * (T * (T + 1) / 2);
+    ARGCHK(nb <= max_blocks, "max_blocks too small");
+    DevBuf dA, dB, dC, dcoef, dT;
+    HIPCHK(dA.alloc(n));
+    HIPCHK(dB.alloc(n));
+    HIPCHK(dC.alloc(n));
+    HIPCHK(dcoef.alloc((size_t)K * 5));
+    HIPCHK(dT.alloc((size_t)nb * 5));
+    UP(dA.p, h.data(), n);
+    UP(dB.p, h.data(), n);
+    UP(dcoef.p, coef.data(), (size_t)K * 5);
+    HIPCHK(hipMemset(dT.p, 0, (size_t)nb * 5 * sizeof(double)));
+    for (int i = 0; i < 3; ++i) launch_symm(nullptr, dA.p, dB.p, dC.p, nullptr, nullptr, dcoef.p, K, p, 0);
+    launch_symm(nullptr, dA.p, dB.p, dC.p, nullptr, nullptr, dcoef.p, K, p, 10, dT.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dT.p, (size_t)nb * 5 * sizeof(long long), hipMemcpyDeviceToHost));
+    *nblocks_out = nb;
+    return GGL_OK;
+}
+
 extern "C" int ggl_dev_mfma_f64_peak(double* tflops_out)
 {
     ARGCHK(tflops_out, "tflops_out");

@@ -158,6 +158,8 @@ int ggl_dev_symm(int K, int p, const double *A, const double *B, const double *E
 int ggl_dev_symm_bench(int K, int p, int variant, int iters, double *ms_out);
 /* measured FP64 matrix-core ceiling of this GPU in TFLOP/s (MFMA-only probe kernel) */
 int ggl_dev_mfma_f64_peak(double *tflops_out);
+/* per-workgroup timestamps {start, loop begin, loop end, end, XCC id} of one launch of the 64x64 kernel */
+int ggl_dev_symm_timeline(int K, int p, long long *out, int max_blocks, int *nblocks_out);
 
 /* ---- stateless operator entry points (host buffers; used for operator-level parity) ---------- */
 /* numpy.linalg.eigh on a stack (lower triangle read); D (K,p) ascending, Q (K,p,p) columns. */
