@@ -227,3 +227,36 @@ def test_block_sgl_like_reference_test(sol):
     assert np.abs(out["Theta"] - ref["Theta"]).max() <= 1e-8
     ((full, _), _) = quiet(sol.ADMM_SGL, S, lam, np.eye(p), tol=1e-8, rtol=1e-8)
     assert np.abs(out["Theta"] - full["Theta"]).max() <= 1e-3
+
+
+# ---- K-sharded driver on the real RCCL backend (single rank: exercises the device all-reduce path) -----------
+
+def test_sharded_driver_on_rccl_single_rank(sol):
+    """ADMM_MGL_sharded with backend nccl (= RCCL) and world size 1: the group sums of squares go through
+    k_group_partial -> k_sum_chunks -> all_reduce on the ctx's device buffer (wrapped through
+    __cuda_array_interface__) -> k_theta_ggl, on torch's current stream.  Must equal the unsharded solve."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from gglasso_amd import synth
+    from gglasso_amd.dist import ADMM_MGL_sharded, TorchComm
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        for (K, p) in ((5, 40), (3, 150)):
+            S, _ = synth.make_problem("GGL", K, p, seed=31)
+            Om0 = np.stack([np.eye(p)] * K)
+            comm = TorchComm(device="cuda:0")
+            (a, ia), _ = quiet(ADMM_MGL_sharded, S, 0.05, 0.02, "GGL", Om0, K, comm, tol=1e-9, rtol=1e-9, measure=True)
+            (b, ib), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.02, "GGL", Om0, tol=1e-9, rtol=1e-9, measure=True)
+            assert ia["status"] == ib["status"] == "optimal"
+            assert len(ia["residual"]) == len(ib["residual"])
+            for nm in ("Omega", "Theta", "X"):
+                assert np.abs(a[nm] - b[nm]).max() <= 1e-10, nm
+    finally:
+        dist.destroy_process_group()
