@@ -79,7 +79,7 @@ struct ggl_ctx {
     double rank_l0 = 1e-6;                           // resolution of the scaling schedule
     int rank_hold = 0;                               // iterations to stay at the fine resolution
     long long rank_calls = 0, rank_retries = 0, rank_fallbacks = 0, rank_launches = 0;
-    long long ns_steps_total = 0, ns_calls = 0, ns_units_total = 0, ns_launches_total = 0;
+    long long ns_steps_total = 0, ns_calls = 0, ns_units_total = 0, ns_launches_total = 0, ns_eigh_fallbacks = 0;
     // per-phase HIP-event timing
     bool prof_on = false;
     hipEvent_t ev[GGL_NPHASE][2] = {};
@@ -439,8 +439,17 @@ static int omega_step(ggl_ctx* c, int latent)
                               c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         NsPlan plan;
-        if (ns_plan(c->bounds_h, c->par_h, c->K, c->coef_h, &plan, c->ns_force) != 0)
-            return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");
+        const int prc = ns_plan(c->bounds_h, c->par_h, c->K, c->coef_h, &plan, c->ns_force);
+        if (prc == -1) return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");
+        if (prc == -2) {
+            // pathological scaling (|W|^2 rho / nk > 1e12): eigendecomposition of the (already formed) W
+            c->ns_eigh_fallbacks += 1;
+            rc = eig_recon(c, c->W, c->Om[nxt], c->DvO, MAP_PHIPLUS, beta, GGL_PH_EIG_OMEGA, GGL_PH_RECON_OMEGA);
+            if (rc) return rc;
+            c->dvo_valid = true;
+            c->cur = nxt;
+            return GGL_OK;
+        }
         HIPCHK(hipMemcpyAsync(c->coef, c->coef_h, (size_t)plan.products * NS_SLOT(c->K) * sizeof(double),
                               hipMemcpyHostToDevice, c->stream));
         PB(c, GGL_PH_EIG_OMEGA);

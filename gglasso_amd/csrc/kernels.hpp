@@ -124,6 +124,8 @@ static constexpr int NS_MAX_LAUNCHES = 2 * NS_RANK_MAX_STEPS + 1;
 static inline size_t NS_SLOT(int K) { return (size_t)K * 10; }
 // all-symmetric products are only accurate while the condition number of W^2 + 4 beta I is small
 static constexpr double NS_SYM_KAPPA_MAX = 300.0;
+// above this condition number of W^2 + 4 beta I the Omega-step uses the eigendecomposition instead
+static constexpr double NS_KAPPA_LIMIT = 1e12;
 struct NsPlan { int steps = 0; int products = 0; bool stable = false; double kappa = 0.0; };
 // W = ((Theta - L) - X) - beta_k S from the lower triangle, mirrored (exactly symmetric)
 // also: bounds[k] = {|W_k|_inf, |W_k|_F^2} (device, K*2 doubles) through the scratch arrays
@@ -132,7 +134,8 @@ int form_W_tiles(int p);
 void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
                        const double* S, const double* betaK, double* rowpart, double* sqpart, double* bounds,
                        int K, int p);
-// host: scaling schedule from the norm bounds; fills coef_h[(2*NS_MAX_STEPS)*NS_SLOT(K)]; returns 0 or -1
+// host: scaling schedule from the norm bounds; fills coef_h[NS_MAX_LAUNCHES*NS_SLOT(K)]; returns 0, -1 (non-finite
+// input) or -2 (condition number above NS_KAPPA_LIMIT: use the eigendecomposition)
 // force_mode: 0 choose by condition number, 1 all-symmetric products, 2 stable (unsymmetrised) products
 int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h, NsPlan* plan, int force_mode);
 // device: Omega = (W + (W^2 + 4 beta)^(1/2))/2 by 3*steps-2 symmetric products

@@ -186,6 +186,9 @@ int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h,
         n = std::max(n, (int)al[k].size());
     }
     const bool stable = (force_mode == 2) || (force_mode == 0 && kappa > NS_SYM_KAPPA_MAX);
+    // Beyond this the schedule would be cut off at NS_MAX_STEPS and fp64 (error ~ eps*sqrt(kappa)) could not
+    // deliver the accuracy anyway: the caller takes the eigendecomposition route for this call.
+    if (kappa > NS_KAPPA_LIMIT) return -2;
     plan->steps = n;
     plan->stable = stable;
     plan->kappa = kappa;

@@ -308,3 +308,13 @@ def test_rank_newton_schulz_eigenvalue_at_the_threshold(ops):
     ref = orc.rank_stack(C[None], 0.7)[0]
     out = ops.rank_matrix(C, 0.7, method=3)
     assert np.abs(out - ref).max() <= 1e-11
+
+
+def test_phiplus_newton_schulz_extreme_scaling_falls_back(ops):
+    """|W|^2 / beta > 1e12: the square-root iteration is not attempted; the eigendecomposition route answers."""
+    rng = np.random.default_rng(91)
+    W = _sym(rng, 2, 140, 1e5)
+    beta = np.array([1e-4, 2e-4])
+    ref, _ = orc.phiplus_stack(W, beta)
+    out = ops.phiplus_matrix(W, beta, method=3)
+    assert np.abs(out - ref).max() <= 1e-10 * np.abs(ref).max()
