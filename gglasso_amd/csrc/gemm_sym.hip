@@ -113,7 +113,7 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     auto fetch = [&](int m0, double (&xa)[Cfg::LPT], double (&xb)[Cfg::LPT]) {
 #pragma unroll
         for (int q = 0; q < Cfg::LPT; ++q) {
-            if (ABL == 1) { xa[q] = 1.0 + q; xb[q] = 2.0 + q; continue; }   // ablation: no global loads
+            if (ABL == 1 || ABL == 4 || ABL == 5) { xa[q] = 1.0 + q; xb[q] = 2.0 + q; continue; }   // ablation: no global loads
             const unsigned ro = min((unsigned)(m0 + lrow + q * RSTEP), pm1) * pu;
             xa[q] = Ak[ro + ca];
             xb[q] = Bk[ro + cb];
@@ -162,11 +162,11 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
         for (int s = 0; s < NST; ++s) {
             const int ms = m0 + s * BK;
             if (ms < p) {                                   // uniform over the workgroup
-                stage(ms, ra[s], rb[s]);
-                __syncthreads();
+                if (ABL != 4) stage(ms, ra[s], rb[s]);       // ABL 4: ds_read + MFMA only; ABL 5: + ds_write
+                if (ABL != 4 && ABL != 5) __syncthreads();
                 fetch(ms + NST * BK, ra[s], rb[s]);          // past the end: clamped, never staged
                 if (!dead_wave) compute();
-                __syncthreads();
+                if (ABL != 4 && ABL != 5) __syncthreads();
             }
         }
     }
@@ -466,7 +466,7 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
     }
 }
 
-int symm_variants() { return 11; }
+int symm_variants() { return 16; }
 
 // Two independent products in one launch: C = coef[k]-affine(A*B) for k < K and C1 = coef[K+k]-scaled(A1*B1).
 void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
@@ -501,6 +501,9 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 5: launch_cfg<128, 32, 64, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
+        case 11: launch_cfg<64, 16, 16, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
+        case 12: launch_cfg<64, 32, 16, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
+        case 13: launch_cfg<64, 16, 32, 16, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 8: launch_cfg<32, 16, 16, 16, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 9: launch_cfg<32, 32, 16, 16, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 6: {   // ablation of variant 0: no global loads
@@ -511,6 +514,16 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         case 10: {  // timeline probe of variant 0 (maxdev = [grid][5] long long buffer)
             const int T = (p + 63) / 64;
             hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 3>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev);
+            break;
+        }
+        case 14: {  // ablation: ds_read + MFMA only (no loads, no ds_write, no barriers)
+            const int T = (p + 63) / 64;
+            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 4>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, nullptr);
+            break;
+        }
+        case 15: {  // ablation: ds_write + ds_read + MFMA, no loads, no barriers
+            const int T = (p + 63) / 64;
+            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 5>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, nullptr);
             break;
         }
         case 7: {   // ablation of variant 0: no MFMA

@@ -260,3 +260,25 @@ def test_sharded_driver_on_rccl_single_rank(sol):
                 assert np.abs(a[nm] - b[nm]).max() <= 1e-10, nm
     finally:
         dist.destroy_process_group()
+
+
+# ---- stress: extreme penalty parameters and scalings (condition numbers from 1 to 1e9 inside the Omega-step) ------
+
+@pytest.mark.parametrize("rho0,scale,lam", [(1e-3, 1.0, 0.05), (1e3, 1.0, 0.05), (1.0, 1e3, 5.0), (1.0, 1e-3, 1e-4),
+                                            (50.0, 30.0, 0.5)])
+@pytest.mark.parametrize("reg,latent", [("GGL", False), ("FGL", True)])
+def test_extreme_rho_and_scaling_vs_oracle(sol, rho0, scale, lam, reg, latent):
+    """S scaled by 1e-3 .. 1e3 and rho0 from 1e-3 to 1e3: kappa(W^2 + 4/rho I) sweeps 1 .. 1e9, so both
+    Newton-Schulz schedules, the L-step retry logic and the rho rule are all exercised; 15 iterations with
+    rho updates must track the CPU oracle."""
+    from gglasso_amd import synth
+    K, p = 3, 140
+    S, _ = synth.make_problem(reg, K, p, seed=23)
+    S = S * scale
+    Om0 = np.stack([np.eye(p)] * K)
+    kw = dict(max_iter=15, tol=1e-20, rtol=1e-20, rho=rho0, latent=latent, mu1=0.2 * scale)
+    ref, _ = orc.ADMM_MGL(S, lam, lam / 3, reg, Om0, **kw)
+    (out, _), _ = quiet(sol.ADMM_MGL, S, lam, lam / 3, reg, Om0, **kw)
+    for nm in ("Omega", "Theta", "L", "X"):
+        tol = 1e-9 * max(1.0, np.abs(ref[nm]).max())
+        assert np.abs(out[nm] - ref[nm]).max() <= tol, (nm, np.abs(out[nm] - ref[nm]).max())
