@@ -76,6 +76,17 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m gglasso_amd.build` "
             "(gglasso_amd has no CPU fallback)")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 / rocBLAS / rocSOLVER under the
+    # same SONAMEs as /opt/rocm.  Whichever copy is loaded first serves the whole process; if the system
+    # copies come first and torch is imported later, torch's second HSA runtime sees no GPU ("No HIP GPUs are
+    # available").  The multi-GPU path (gglasso_amd.dist) needs torch in the same process, so torch -- when it
+    # is installed -- is imported before the library, once (set GGL_TORCH_FIRST=0 to skip).
+    import sys
+    if "torch" not in sys.modules and os.environ.get("GGL_TORCH_FIRST", "1") != "0":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # noqa: BLE001  (torch absent or broken: the single-GPU path does not need it)
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (argtypes, restype) in _SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol

@@ -256,6 +256,165 @@ static void launch_cfg(hipStream_t st, const double* A, const double* B, double*
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_symm_dl: the same symmetric product with the operand slabs DMA'd straight into LDS
+// (global_load_lds, 16 bytes per lane, no VGPR round trip and no ds_write pass) and a double-buffered
+// LDS image, one barrier per k-slab.  64x64 tile, 4 waves (32x32 each), k-slab 16.
+//   * one wave instruction moves 1 KiB = two 64-double rows; its LDS destination is wave-linear
+//     (base + lane*16), so the slab is stored unpadded [16][64]; rows r and r+1 would put the two 16-lane
+//     groups of a half wave on the same banks, so odd rows are stored with their 16-double halves
+//     swapped -- done on the SOURCE address (the DMA cannot scatter), and undone in the fragment read.
+//   * needs 16-byte aligned rows: p even (odd p takes k_symm_tn).  Out-of-range columns read a
+//     clamped address (their products only reach outputs that are never stored); out-of-range k-rows of
+//     the last slab are zeroed in LDS after the DMA has landed.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, const double* __restrict__ B,
+                                                 double* __restrict__ C, double* __restrict__ C2,
+                                                 const double* __restrict__ E, const double* __restrict__ coef, int K,
+                                                 int p, const double* __restrict__ A1, const double* __restrict__ B1,
+                                                 double* __restrict__ C1, int K1, double* __restrict__ maxdev)
+{
+    constexpr int BM = 64, BK = 16, WM = 32, WN = 32, TI = 2, TJ = 2;
+    constexpr int SLAB = BK * BM;                        // doubles per operand slab (8 KiB)
+    __shared__ __attribute__((aligned(16))) double smem[4 * SLAB];   // [buf][A|B][16][64] = 32 KiB; later the mirror tile
+    const int T = (p + BM - 1) / BM;
+    int k, b;
+    if (!decode_block_xcd(T * (T + 1) / 2, K + K1, k, b)) return;
+    const bool second = k >= K;
+    const int kk = second ? k - K : k;
+    int I = 0;
+    while (b >= T - I) { b -= T - I; ++I; }
+    const int J = I + b;
+    const int I0 = I * BM, J0 = J * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * WM, wc = (wave & 1) * WN;
+    const size_t pp = (size_t)p * p;
+    const double* Ak = (second ? A1 : A) + (size_t)kk * pp;
+    const double* Bk = (second ? B1 : B) + (size_t)kk * pp;
+
+    v4d acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    // DMA geometry: wave w issues instructions i = 2w, 2w+1 per operand; instruction i covers slab rows
+    // 2i, 2i+1; lane l -> row 2i + (l >> 5), LDS position (l & 31) * 2, source column position ^ 16*(row & 1).
+    const unsigned pu = (unsigned)p, pm1 = (unsigned)(p - 1), pm2 = (unsigned)(p - 2);
+    const int lrow = lane >> 5;
+    const unsigned cpos = (unsigned)((lane & 31) * 2) ^ (unsigned)(16 * lrow);
+    const unsigned ca = min((unsigned)I0 + cpos, pm2), cb = min((unsigned)J0 + cpos, pm2);
+    auto issue = [&](int m0, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = wave * 2 + j;
+            const unsigned ro = min((unsigned)(m0 + 2 * i + lrow), pm1) * pu;
+            double* la = smem + (size_t)buf * 2 * SLAB + i * 128;            // wave-uniform LDS base
+            double* lb = la + SLAB;
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ak + ro + ca), (lptr_t)la, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Bk + ro + cb), (lptr_t)lb, 16, 0, 0);
+        }
+    };
+    const bool dead_wave = (I == J) && (wr >= wc + WN);
+    const int S = (p + BK - 1) / BK;
+    issue(0, 0);
+    for (int s = 0; s < S; ++s) {
+        const int buf = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA of slab s has landed
+        const int valid = p - s * BK;                          // k-rows of this slab inside the matrix
+        if (valid < BK) {
+            // zero the rows beyond the matrix (each wave cleans the rows its own DMA wrote)
+            for (int e = lane; e < 4 * 64; e += 64) {
+                const int row = wave * 4 + (e >> 6);
+                if (row >= valid) {
+                    smem[(size_t)buf * 2 * SLAB + row * 64 + (e & 63)] = 0.0;
+                    smem[(size_t)buf * 2 * SLAB + SLAB + row * 64 + (e & 63)] = 0.0;
+                }
+            }
+        }
+        __syncthreads();                                       // slab s visible to all; slab s-1 fully consumed
+        if (s + 1 < S) issue((s + 1) * BK, buf ^ 1);
+        if (!dead_wave) {
+            const double* As = smem + (size_t)buf * 2 * SLAB;
+            const double* Bs = As + SLAB;
+#pragma unroll
+            for (int kq4 = 0; kq4 < BK / 4; ++kq4) {
+                const int row = kq4 * 4 + (lane >> 4);
+                const int sw = 16 * (row & 1);
+                double af[TI], bf[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) af[i] = As[row * 64 + ((wr + i * 16 + (lane & 15)) ^ sw)];
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bf[j] = Bs[row * 64 + ((wc + j * 16 + (lane & 15)) ^ sw)];
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();     // all fragment reads done before the slabs are reused as the mirror tile
+
+    const double cI = coef[k * 5 + 0], cAcc = coef[k * 5 + 1], cE = coef[k * 5 + 2];
+    const double dI = coef[k * 5 + 3], dC = coef[k * 5 + 4];
+    double* Ck = (second ? C1 : C) + (size_t)kk * pp;
+    double* C2k = (C2 && !second) ? C2 + (size_t)kk * pp : nullptr;
+    const double* Ek = (E && !second) ? E + (size_t)kk * pp : nullptr;
+    double dev = 0.0;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr + ti * 16 + (lane >> 4) + 4 * r;
+                const int col = wc + tj * 16 + (lane & 15);
+                const int gi = I0 + row, gj = J0 + col;
+                double v = cAcc * acc[ti][tj][r];
+                if (gi < p && gj < p && (I != J || gi <= gj)) {
+                    if (gi == gj) v += cI;
+                    dev = fmax(dev, fabs(v - (gi == gj ? 1.0 : 0.0)));
+                    if (Ek) v += cE * Ek[(size_t)gi * p + gj];
+                    Ck[(size_t)gi * p + gj] = v;
+                    if (C2k) C2k[(size_t)gi * p + gj] = dC * v + (gi == gj ? dI : 0.0);
+                    if (I == J && gi != gj) {
+                        Ck[(size_t)gj * p + gi] = v;
+                        if (C2k) C2k[(size_t)gj * p + gi] = dC * v;
+                    }
+                }
+                if (I != J) smem[row * 64 + (col ^ row)] = v;        // XOR-swizzled 64x64 mirror tile
+            }
+    if (maxdev) {
+        dev = wave_max(dev);
+        if (lane == 0 && dev > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long*>(maxdev + k), (unsigned long long)__double_as_longlong(dev));
+    }
+    if (I != J) {
+        __syncthreads();
+        for (int e = tid; e < BM * BM; e += 256) {
+            const int a = e >> 6, c = e & 63;   // out[J0+a][I0+c] = tile[c][a]
+            if (J0 + a < p && I0 + c < p) {
+                const double v = smem[c * 64 + (a ^ c)];
+                Ck[(size_t)(J0 + a) * p + I0 + c] = v;
+                if (C2k) C2k[(size_t)(J0 + a) * p + I0 + c] = dC * v;
+            }
+        }
+    }
+}
+
+static void launch_dl(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
+                      const double* coef, int K, int p, const double* A1, const double* B1, double* C1, int K1,
+                      double* maxdev)
+{
+    const int T = (p + 63) / 64;
+    hipLaunchKernelGGL(k_symm_dl, dim3(xcd_grid(T * (T + 1) / 2, K + K1)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p,
+                       A1, B1, C1, K1, maxdev);
+}
+
+// ---------------------------------------------------------------------------------------------
 // General (non-symmetric result) product with a symmetric right factor:
 //     C[b] = s[b] * A[b] * T[b % K],     b = 0 .. nbatch-1,
 // used by the numerically stable Newton-Schulz path where Y and P = Z^T are both multiplied by
@@ -466,7 +625,7 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
     }
 }
 
-int symm_variants() { return 16; }
+int symm_variants() { return 17; }
 
 // Two independent products in one launch: C = coef[k]-affine(A*B) for k < K and C1 = coef[K+k]-scaled(A1*B1).
 void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
@@ -474,9 +633,13 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 {
     if (variant < 0 || variant == 6 || variant == 7) {
         const long T64 = (p + 63) / 64;
-        variant = (T64 * (T64 + 1) / 2 * 2 * K <= 800) ? 9 : 0;
+        variant = (T64 * (T64 + 1) / 2 * 2 * K <= 800) ? 9 : 16;
     }
     switch (variant) {
+        case 16:
+            if ((p & 1) == 0 && p >= 2) { launch_dl(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K, nullptr); break; }
+            launch_cfg<64, 16, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K);
+            break;
         case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
         case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
         case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
@@ -493,7 +656,7 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         // Measured on MI355X (tools/tail_test.py): with fewer than ~800 64x64 tile pairs in the batch the
         // chip is under-filled and 32x32 tiles (4x the workgroups) are 20-30 % faster; above, 64x64.
         const long T64 = (p + 63) / 64;
-        variant = (T64 * (T64 + 1) / 2 * K <= 800) ? 9 : 0;
+        variant = (T64 * (T64 + 1) / 2 * K <= 800) ? 9 : 16;   // 16 = direct-to-LDS (falls back to 0 for odd p)
     }
     switch (variant) {
         case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
@@ -501,6 +664,10 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 5: launch_cfg<128, 32, 64, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
+        case 16:
+            if ((p & 1) == 0 && p >= 2) { launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break; }
+            launch_cfg<64, 16, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev);
+            break;
         case 11: launch_cfg<64, 16, 16, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 12: launch_cfg<64, 32, 16, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 13: launch_cfg<64, 16, 32, 16, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;

@@ -188,8 +188,8 @@ def _commuting_pair(rng, K, p):
     return 0.5 * (A + A.transpose(0, 2, 1)), 0.5 * (B + B.transpose(0, 2, 1))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
-@pytest.mark.parametrize("K,p", [(2, 40), (3, 129), (2, 200), (1, 333)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 8, 9, 16])
+@pytest.mark.parametrize("K,p", [(2, 40), (3, 129), (2, 200), (1, 333), (9, 70), (2, 500)])
 def test_symm_product_kernel(variant, K, p):
     """C = cI*I + cAcc*A*B + cE*E and C2 = dI*I + dC*C for commuting symmetric A, B (every tile shape)."""
     from gglasso_amd import _lib
