@@ -188,7 +188,9 @@ def main():
         dom = max(phases, key=lambda ph: phases[ph]["ms_per_launch"] * phases[ph]["launches"])
         omega_ns = (args.eig == _lib.EIG_NEWTON_SCHULZ) or (args.eig == _lib.EIG_AUTO and not eig_jacobi)
         bound, amount, unit = phase_model(dom, reg, Kl, p, latent, eig_jacobi, omega_ns)
-        kernel_name = {"eig_omega": "k_symm_tn (Newton-Schulz product)" if omega_ns else
+        t64 = (p + 63) // 64
+        ns_kernel = "k_symm_dl" if (p % 2 == 0 and t64 * (t64 + 1) // 2 * Kl > 800) else "k_symm_tn"
+        kernel_name = {"eig_omega": ns_kernel + " (Newton-Schulz product)" if omega_ns else
                        ("k_jacobi" if eig_jacobi else "rocsolver_dsyevd (library, many kernels)"),
                        "theta": "k_theta_ggl" if reg == "GGL" else ("k_theta_fgl" if reg == "FGL" else "k_theta_sgl"),
                        "recon_omega": "k_recon", "recon_L": "k_recon", "form_W": "k_form_W",
@@ -197,7 +199,7 @@ def main():
         if dom == "eig_L" and omega_ns and ns1["rank_launches"] > ns0["rank_launches"]:
             # L-step by sign Newton-Schulz: the phase is (2n+1) symmetric products of K p^3 flop each
             launches = ns1["rank_launches"] - ns0["rank_launches"]
-            kernel_name = "k_symm_tn (sign Newton-Schulz product, L-step)"
+            kernel_name = ns_kernel + " (sign Newton-Schulz product, L-step)"
             bound, unit = "mfma", "TFLOP/s"
             amount = 1.0 * Kl * p ** 3
             sec = phases[dom]["ms_per_launch"] * phases[dom]["launches"] * 1e-3 / launches
