@@ -185,6 +185,12 @@ def main():
     if rank == 0:
         eig_jacobi = (args.eig == _lib.EIG_JACOBI) or (args.eig == _lib.EIG_AUTO and p <= _lib.JACOBI_MAX_P)
         phases = {ph: {"ms_per_launch": ms / cnt, "launches": cnt} for ph, (ms, cnt) in prof.items() if cnt}
+        if "eig_omega2" in phases:
+            # the Newton-Schulz Omega-step is timed in two event pairs (before / after the spectral-bound sync)
+            tot = sum(phases[q]["ms_per_launch"] * phases[q]["launches"] for q in ("eig_omega", "eig_omega2"))
+            nl = max(1, ns1["launches"] - ns0["launches"])
+            phases["eig_omega"] = {"ms_per_launch": tot / nl, "launches": nl}
+            del phases["eig_omega2"]
         dom = max(phases, key=lambda ph: phases[ph]["ms_per_launch"] * phases[ph]["launches"])
         omega_ns = (args.eig == _lib.EIG_NEWTON_SCHULZ) or (args.eig == _lib.EIG_AUTO and not eig_jacobi)
         bound, amount, unit = phase_model(dom, reg, Kl, p, latent, eig_jacobi, omega_ns)

@@ -14,7 +14,7 @@ EIG_AUTO, EIG_JACOBI, EIG_ROCSOLVER, EIG_NEWTON_SCHULZ = 0, 1, 2, 3
 JACOBI_MAX_P = 128
 BUF_S, BUF_OMEGA, BUF_THETA, BUF_L, BUF_X, BUF_GROUPSQ, BUF_NORMS, BUF_OMEGA_PREV = range(8)
 E_ARG, E_HIP, E_SOLVER, E_ALLOC = -1, -2, -3, -4
-PHASES = ("form_W", "eig_omega", "recon_omega", "theta", "eig_L", "recon_L", "dual", "reduce")
+PHASES = ("form_W", "eig_omega", "recon_omega", "theta", "eig_L", "recon_L", "dual", "reduce", "eig_omega2", "bound")
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _vp = ctypes.c_void_p

@@ -169,7 +169,7 @@ static int ctx_alloc(ggl_ctx* c)
     if (c->omega_ns) {
         for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->nsYP[i], 2 * nb));
         HIPCHK(hipMalloc(&c->nsT, nb));
-        const size_t cl = (size_t)NS_MAX_LAUNCHES * NS_SLOT(c->K) * sizeof(double);
+        const size_t cl = (size_t)NS_MAX_LAUNCHES * NS_SLOT(c->K) * sizeof(double);   // last 3 slots: start / pre tables
         HIPCHK(hipMalloc(&c->coef, cl));
         HIPCHK(hipHostMalloc(&c->coef_h, cl));
         const size_t bl = 2 * (size_t)c->K * sizeof(double);
@@ -430,42 +430,73 @@ static int omega_step(ggl_ctx* c, int latent)
     const double* beta = c->par;
     const int nxt = c->cur ^ 1;
     if (c->omega_ns) {
+        const int K = c->K;
         PB(c, GGL_PH_FORM_W);
         launch_form_W_sym(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->rowpart, c->sqpart,
-                          c->bounds, c->K, c->p);
+                          nullptr, K, c->p);
         PE(c, GGL_PH_FORM_W);
+        // phase A: A' = W^2 + 4 beta I, B' = A'^2 (both needed anyway), then the bound from B'
+        double* pre = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 2) * NS_SLOT(K);
+        for (int k = 0; k < K; ++k) {
+            double* o0 = pre + (size_t)k * 5;
+            double* o1 = pre + NS_SLOT(K) + (size_t)k * 5;
+            o0[0] = 4.0 * c->par_h[k]; o0[1] = 1.0; o0[2] = o0[3] = o0[4] = 0.0;
+            o1[0] = 0.0; o1[1] = 1.0; o1[2] = o1[3] = o1[4] = 0.0;
+        }
+        double* pre_d = c->coef + (size_t)(NS_MAX_LAUNCHES - 2) * NS_SLOT(K);
+        HIPCHK(hipMemcpyAsync(pre_d, pre, 2 * NS_SLOT(K) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PB(c, GGL_PH_EIG_OMEGA);
+        ns_prepare(c->stream, pre_d, c->W, c->nsYP[0], K, c->p, c->symm_variant);
+        PE(c, GGL_PH_EIG_OMEGA);
+        PB(c, GGL_PH_BOUND);
+        const int nbb = norm_bounds_blocks(c->p);
+        launch_norm_bounds(c->stream, c->nsYP[0] + c->n, K, c->p, c->nbpart);
+        PE(c, GGL_PH_BOUND);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->bounds_h, c->bounds, 2 * (size_t)c->K * sizeof(double), hipMemcpyDeviceToHost,
+        HIPCHK(hipMemcpyAsync(c->nbpart_h, c->nbpart, 2 * (size_t)K * nbb * sizeof(double), hipMemcpyDeviceToHost,
                               c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < K; ++k) {
+            double mx = 0.0, sq = 0.0;
+            for (int b2 = 0; b2 < nbb; ++b2) {
+                mx = std::max(mx, c->nbpart_h[2 * ((size_t)k * nbb + b2)]);
+                sq += c->nbpart_h[2 * ((size_t)k * nbb + b2) + 1];
+            }
+            // lambda_max(A')^2 = lambda_max(B') <= min(|B'|_inf, |B'|_F)
+            c->bounds_h[k] = std::sqrt(std::min(mx, std::sqrt(sq)));
+        }
         NsPlan plan;
-        const int prc = ns_plan(c->bounds_h, c->par_h, c->K, c->coef_h, &plan, c->ns_force);
+        double* start_h = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
+        const int prc = ns_plan(c->bounds_h, c->par_h, K, c->coef_h, start_h, &plan, c->ns_force);
         if (prc == -1) return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");
         if (prc == -2) {
-            // pathological scaling (|W|^2 rho / nk > 1e12): eigendecomposition of the (already formed) W
+            // pathological scaling (|W|^2 rho / nk > 1e12): eigendecomposition of the (still intact) W
             c->ns_eigh_fallbacks += 1;
-            rc = eig_recon(c, c->W, c->Om[nxt], c->DvO, MAP_PHIPLUS, beta, GGL_PH_EIG_OMEGA, GGL_PH_RECON_OMEGA);
+            rc = eig_recon(c, c->W, c->Om[nxt], c->DvO, MAP_PHIPLUS, beta, -1, GGL_PH_RECON_OMEGA);
             if (rc) return rc;
             c->dvo_valid = true;
             c->cur = nxt;
             return GGL_OK;
         }
-        HIPCHK(hipMemcpyAsync(c->coef, c->coef_h, (size_t)plan.products * NS_SLOT(c->K) * sizeof(double),
-                              hipMemcpyHostToDevice, c->stream));
-        PB(c, GGL_PH_EIG_OMEGA);
-        ns_run(c->stream, plan, c->coef, c->W, c->nsYP[0], c->nsYP[1], c->nsT, c->Om[nxt], c->K, c->p,
+        const int nb_launch = plan.products - 2;     // launches of phase B
+        if (nb_launch > 0)
+            HIPCHK(hipMemcpyAsync(c->coef, c->coef_h, (size_t)nb_launch * NS_SLOT(K) * sizeof(double),
+                                  hipMemcpyHostToDevice, c->stream));
+        double* start_d = c->coef + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
+        HIPCHK(hipMemcpyAsync(start_d, start_h, (size_t)K * 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PB(c, GGL_PH_EIG_OMEGA2);
+        ns_run(c->stream, plan, c->coef, start_d, c->W, c->nsYP[0], c->nsYP[1], c->nsT, c->Om[nxt], K, c->p,
                c->symm_variant);
-        c->ns_stable_calls += plan.stable ? 1 : 0;
-        PE(c, GGL_PH_EIG_OMEGA);
+        PE(c, GGL_PH_EIG_OMEGA2);
         HIPCHK(hipGetLastError());
-        if (c->prof_on) c->ph_cnt[GGL_PH_EIG_OMEGA] += plan.products - 1;   // count kernel launches, not phases
+        c->ns_stable_calls += plan.stable ? 1 : 0;
         c->ns_steps_total += plan.steps;
         c->ns_launches_total += plan.products;
         // algorithmic work in units of K p^3 flop (one symmetric product of the whole stack)
         c->ns_units_total += (plan.steps == 1) ? 2 : (plan.stable ? 5 * plan.steps - 6 : 3 * plan.steps - 2);
         c->ns_calls += 1;
         c->dvo_valid = false;
-        HIPCHK(hipMemsetAsync(c->info, 0, c->K * sizeof(int), c->stream));
+        HIPCHK(hipMemsetAsync(c->info, 0, K * sizeof(int), c->stream));
         c->cur = nxt;
         return GGL_OK;
     }

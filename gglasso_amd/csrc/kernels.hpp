@@ -119,7 +119,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 // ---- newton_schulz.hip ------------------------------------------------------------------
 static constexpr int NS_MAX_STEPS = 24;        // square-root schedule (condition number up to ~1e18)
 static constexpr int NS_RANK_MAX_STEPS = 40;   // sign schedule (resolution down to ~1e-13)
-static constexpr int NS_MAX_LAUNCHES = 2 * NS_RANK_MAX_STEPS + 1;
+static constexpr int NS_MAX_LAUNCHES = 2 * NS_RANK_MAX_STEPS + 1 + 3;   // + start table + two pre-bound slots
 // doubles per launch slot of the coefficient table (a pair launch carries 2K rows of 5)
 static inline size_t NS_SLOT(int K) { return (size_t)K * 10; }
 // all-symmetric products are only accurate while the condition number of W^2 + 4 beta I is small
@@ -134,14 +134,17 @@ int form_W_tiles(int p);
 void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
                        const double* S, const double* betaK, double* rowpart, double* sqpart, double* bounds,
                        int K, int p);
-// host: scaling schedule from the norm bounds; fills coef_h[NS_MAX_LAUNCHES*NS_SLOT(K)]; returns 0, -1 (non-finite
-// input) or -2 (condition number above NS_KAPPA_LIMIT: use the eigendecomposition)
-// force_mode: 0 choose by condition number, 1 all-symmetric products, 2 stable (unsymmetrised) products
-int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h, NsPlan* plan, int force_mode);
-// device: Omega = (W + (W^2 + 4 beta)^(1/2))/2 by 3*steps-2 symmetric products
-// YP[0], YP[1]: two scratch buffers of 2 stacks each (Y stack followed by Z/P stack); Tb: one stack.
-void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* W, double* YP0, double* YP1,
-            double* Tb, double* out, int K, int p, int variant);
+// Omega-step in two phases around the one host sync that fetches the spectral bound:
+//   ns_prepare: A' = W^2 + 4 beta I and B' = A'^2 into AB = [A' | B'] (pre_d: 2 coefficient slots)
+//   -- host: c_k = sqrt(min(|B'_k|_inf, |B'_k|_F)) >= lambda_max(A'_k); ns_plan --
+//   ns_run: start kernel (Y1, Z1 as polynomials of A', B') + the remaining products
+// ns_plan returns 0, -1 (non-finite input) or -2 (condition number above NS_KAPPA_LIMIT: use the
+// eigendecomposition); fills coef_h[launch slots] and start_h[K][5].
+int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h, double* start_h, NsPlan* plan,
+            int force_mode);
+void ns_prepare(hipStream_t st, const double* pre_d, const double* W, double* AB, int K, int p, int variant);
+void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
+            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant);
 
 // L-step (C - mu I)_+ by a sign-function Newton-Schulz iteration (newton_schulz.hip)
 int norm_bounds_blocks(int p);

@@ -151,7 +151,7 @@ void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const dou
         hipLaunchKernelGGL(k_form_W_sym<true>, grid, blk, 0, st, W, Theta, L, X, S, betaK, rowpart, sqpart, p);
     else
         hipLaunchKernelGGL(k_form_W_sym<false>, grid, blk, 0, st, W, Theta, L, X, S, betaK, rowpart, sqpart, p);
-    hipLaunchKernelGGL(k_bounds_final, dim3(K), dim3(256), 0, st, rowpart, sqpart, T, nblk, p, bounds);
+    if (bounds) hipLaunchKernelGGL(k_bounds_final, dim3(K), dim3(256), 0, st, rowpart, sqpart, T, nblk, p, bounds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -171,16 +171,49 @@ static std::vector<double> ns_schedule(double l, int max_steps = NS_MAX_STEPS)
     return al;
 }
 
-int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h, NsPlan* plan, int force_mode)
+// Start of the iteration from the unscaled A' = W^2 + 4 beta I and B' = A'^2 (both already formed as products):
+//   Y1 = a0 Y0 T0 = (1.5 a0/c) A' - (0.5 a0^3/c^2) B',   Z1 = a0 T0 = 1.5 a0 I - (0.5 a0^3/c) A'   (Y0 = A'/c)
+// so the spectral bound c may come from B' itself: lambda_max(A')^2 <= |A'^2|_inf, a fourth-root-of-W^4 bound
+// that is 2-3x tighter than |W|_inf and saves one to two Newton-Schulz steps.  st[k] = {y1a, y1b, z1i, z1a, h}
+// with h = 0.5 sqrt(c) when the start is already the end (one step: Omega = W/2 + h Y1).
+__global__ __launch_bounds__(256) void k_ns_start(double* __restrict__ Y1, double* __restrict__ Z1,
+                                                  const double* __restrict__ Ap, const double* __restrict__ Bp,
+                                                  const double* __restrict__ W, const double* __restrict__ st, int p,
+                                                  int final_step)
+{
+    const int k = blockIdx.y;
+    const size_t pp = (size_t)p * p, base = (size_t)k * pp;
+    const double y1a = st[k * 5 + 0], y1b = st[k * 5 + 1], z1i = st[k * 5 + 2], z1a = st[k * 5 + 3], h = st[k * 5 + 4];
+    size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e, i += 256) {
+        if (i < pp) {
+            const double a = Ap[base + i], b2 = Bp[base + i];
+            const double y = y1a * a + y1b * b2;
+            if (final_step) {
+                Y1[base + i] = 0.5 * W[base + i] + h * y;          // Y1 is Omega here
+            } else {
+                const int r = (int)(i / p), c = (int)(i - (size_t)r * p);
+                Y1[base + i] = y;
+                Z1[base + i] = z1a * a + (r == c ? z1i : 0.0);
+            }
+        }
+    }
+}
+
+// cbound_h[k] >= lambda_max(A'_k).  Returns 0, -1 (non-finite) or -2 (condition number above NS_KAPPA_LIMIT).
+// Coefficient slots are numbered from the first launch AFTER the start kernel; start_h: [K][5].
+int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h, double* start_h, NsPlan* plan,
+            int force_mode)
 {
     std::vector<std::vector<double>> al(K);
     std::vector<double> c(K);
     int n = 1;
     double kappa = 1.0;
     for (int k = 0; k < K; ++k) {
-        const double w2 = std::fmin(bounds_h[2 * k], std::sqrt(bounds_h[2 * k + 1])) * (1.0 + 1e-10);
-        if (!(w2 >= 0.0) || !std::isfinite(w2) || !(beta_h[k] > 0.0)) return -1;
-        c[k] = w2 * w2 + 4.0 * beta_h[k];
+        c[k] = cbound_h[k] * (1.0 + 1e-10);
+        if (!(c[k] > 0.0) || !std::isfinite(c[k]) || !(beta_h[k] > 0.0)) return -1;
+        if (c[k] < 4.0 * beta_h[k]) c[k] = 4.0 * beta_h[k];          // lambda_min(A') = 4 beta is exact
         kappa = std::fmax(kappa, c[k] / (4.0 * beta_h[k]));
         al[k] = ns_schedule(std::sqrt(4.0 * beta_h[k] / c[k]));
         n = std::max(n, (int)al[k].size());
@@ -192,9 +225,7 @@ int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h,
     plan->steps = n;
     plan->stable = stable;
     plan->kappa = kappa;
-    plan->products = (n == 1) ? 2 : 2 + 2 * (n - 2) + 2;   // kernel launches (both schedules: 2 per step)
-    // launch g of the sequence (see ns_run) reads coef_h[(g*K + k)*5 ..]; a right-multiply launch reads
-    // its 2K scalars from the start of its slot instead.
+    plan->products = 2 + 2 * (n - 1);      // kernel launches of symmetric / right-multiply products (incl. A', B')
     for (int k = 0; k < K; ++k) {
         auto a_of = [&](int it) { return it < (int)al[k].size() ? al[k][it] : 1.0; };
         auto put = [&](int g, double cI, double cAcc, double cE, double dI, double dC) {
@@ -202,65 +233,70 @@ int ns_plan(const double* bounds_h, const double* beta_h, int K, double* coef_h,
             o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = dI; o[4] = dC;
         };
         const double sc = std::sqrt(c[k]);
-        int g = 0;
         double a = a_of(0);
-        // g0: Y0 = W^2/c + (4 beta/c) I ; second output T0 = 1.5 I - 0.5 a0^2 Y0
-        put(g++, 4.0 * beta_h[k] / c[k], 1.0 / c[k], 0.0, 1.5, -0.5 * a * a);
-        // step 0: Y1 = a0 Y0 T0 (final if n == 1); Z1 = P1 = zs * T0 with zs = a0 kept as a pending scalar
-        if (n == 1) { put(g++, 0.0, 0.5 * sc * a, 0.5, 0.0, 0.0); continue; }
-        put(g++, 0.0, a, 0.0, 0.0, 0.0);
-        double zs = a;
+        double* s = start_h + (size_t)k * 5;
+        s[0] = 1.5 * a / c[k];
+        s[1] = -0.5 * a * a * a / (c[k] * c[k]);
+        s[2] = 1.5 * a;
+        s[3] = -0.5 * a * a * a / c[k];
+        s[4] = 0.5 * sc;
+        int g = 0;
         for (int it = 1; it < n; ++it) {
             a = a_of(it);
-            put(g++, 1.5, -0.5 * a * a * zs, 0.0, 0.0, 0.0);                 // T = 1.5 I - 0.5 a^2 (Z Y)
+            put(g++, 1.5, -0.5 * a * a, 0.0, 0.0, 0.0);                      // T = 1.5 I - 0.5 a^2 (Z Y)
             if (it == n - 1) put(g++, 0.0, 0.5 * sc * a, 0.5, 0.0, 0.0);    // Omega = W/2 + sqrt(c) a (Y T)/2
             else if (stable) {
-                double* o = coef_h + (size_t)g * NS_SLOT(K);                // [Y <- a Y T ; P <- a zs P T]
+                double* o = coef_h + (size_t)g * NS_SLOT(K);                // [Y <- a Y T ; P <- a P T]
                 o[k] = a;
-                o[K + k] = a * zs;
+                o[K + k] = a;
                 ++g;
-                zs = 1.0;
             } else {
-                // one launch, 2K instances: [Y <- a Y T ; Z <- a zs T Z]; its slot holds 2K coefficient rows
+                // one launch, 2K instances: [Y <- a Y T ; Z <- a T Z]; its slot holds 2K coefficient rows
                 double* o = coef_h + (size_t)g * NS_SLOT(K);
                 double* y = o + (size_t)k * 5;
                 double* z = o + ((size_t)K + k) * 5;
                 y[0] = 0.0; y[1] = a; y[2] = 0.0; y[3] = 0.0; y[4] = 0.0;
-                z[0] = 0.0; z[1] = a * zs; z[2] = 0.0; z[3] = 0.0; z[4] = 0.0;
+                z[0] = 0.0; z[1] = a; z[2] = 0.0; z[3] = 0.0; z[4] = 0.0;
                 ++g;
-                zs = 1.0;
             }
         }
     }
     return 0;
 }
 
-// YP0 / YP1: [Y stack | Z stack] scratch pairs (2*K*p*p doubles each); Tb: one stack; W preserved; out: Omega.
-//
-// fast path (plan.stable == false, small condition numbers): every product is a product of
-// commuting symmetric matrices, computed as upper triangle + mirror (3 per step).
-// stable path: Z is replaced by P = Z^T, M = P^T Y is still a congruence (exactly symmetric), but
-// Y <- a Y T and P <- a P T are full, unsymmetrised products in one 2K-batch launch: this keeps
-// Y = Y0 P exactly, which is what makes the coupled iteration insensitive to rounding (the
-// symmetrised form amplifies commutator errors by ~sqrt(kappa)/4 per step).
-void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* W, double* YP0, double* YP1,
-            double* Tb, double* out, int K, int p, int variant)
+// Phase A (before the bound is known): A' = W^2 + 4 beta I -> AB.Y, B' = A'^2 -> AB.Z.
+// pre_d: two coefficient slots {4 beta, 1, 0, 0, 0} and {0, 1, 0, 0, 0} per instance.
+void ns_prepare(hipStream_t st, const double* pre_d, const double* W, double* AB, int K, int p, int variant)
 {
     const size_t cs = NS_SLOT(K), n1 = (size_t)K * p * p;
-    int g = 0;
+    launch_symm(st, W, W, AB, nullptr, nullptr, pre_d, K, p, variant);
+    launch_symm(st, AB, AB, AB + n1, nullptr, nullptr, pre_d + cs, K, p, variant);
+}
+
+// Phase B.  AB = [A' | B'] from ns_prepare (free afterwards), YP = the other [Y | Z] scratch pair, Tb one stack,
+// W preserved, out = Omega.
+//
+// fast schedule (plan.stable == false, small condition numbers): every product is a product of commuting
+// symmetric matrices, computed as upper triangle + mirror.
+// stable schedule: Z is replaced by P = Z^T, M = P^T Y is still a congruence (exactly symmetric), but
+// Y <- a Y T and P <- a P T are full, unsymmetrised products in one 2K-batch launch: this keeps Y = Y0 P
+// exactly, which is what makes the coupled iteration insensitive to rounding (the symmetrised form
+// amplifies commutator errors by ~sqrt(kappa)/4 per step).
+void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
+            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant)
+{
+    const size_t cs = NS_SLOT(K), n1 = (size_t)K * p * p;
     const int n = plan.steps;
-    double *cur = YP0, *nxt = YP1;      // cur = [Y | Z]
-    // g0: Y0 -> cur.Y, T0 -> nxt.Z  (Z1 = P1 = a0 T0: the scalar is folded into later coefficients)
-    launch_symm(st, W, W, cur, nxt + n1, nullptr, coef_d + cs * g++, K, p, variant);
+    dim3 grid((unsigned)(((size_t)p * p + 1023) / 1024), K);
     if (n == 1) {
-        launch_symm(st, cur, nxt + n1, out, nullptr, W, coef_d + cs * g++, K, p, variant);
+        hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, out, nullptr, AB, AB + n1, W, start_d, p, 1);
         return;
     }
-    // step 0: Y1 = a0 Y0 T0 -> nxt.Y, right next to T0, so that nxt = [Y1 | Z1]
-    launch_symm(st, cur, nxt + n1, nxt, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
-    std::swap(cur, nxt);
+    hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, YP, YP + n1, AB, AB + n1, W, start_d, p, 0);
+    double *cur = YP, *nxt = AB;      // cur = [Y | Z]
+    int g = 0;
     for (int it = 1; it < n; ++it) {
-        // T = 1.5 I - 0.5 a^2 zs (Z Y)   [fast: Z Y = Z^T Y, Z symmetric; stable: P^T Y]
+        // T = 1.5 I - 0.5 a^2 (Z Y)   [fast: Z Y = Z^T Y, Z symmetric; stable: P^T Y]
         launch_symm(st, cur + n1, cur, Tb, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
         if (it == n - 1) {
             launch_symm(st, cur, Tb, out, nullptr, W, coef_d + cs * g++, K, p, variant);
@@ -274,7 +310,6 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
     }
 }
 
-
 // ---------------------------------------------------------------------------------------------
 // L-step without an eigendecomposition:  L = (C - mu I)_+ = (C - mu I)(I + sign(C - mu I))/2
 // (prox_rank_norm, solver/ggl_helper.py:29-36 with D,Q from eigh, admm_solver.py:197-205).
@@ -287,21 +322,31 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_norm_bounds(const double* __restrict__ W, int p, double* __restrict__ part)
 {
+    // 16 rows per workgroup, 4 per wave, all four streamed together (independent loads in flight)
     __shared__ double sh_abs[4], sh_sq[4];
     const int k = blockIdx.y;
     const double* w = W + (size_t)k * p * p;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = blockIdx.x * 64 + wave * 16;
-    double mx = 0.0, sq = 0.0;
-    for (int i = r0; i < min(r0 + 16, p); ++i) {
-        double a = 0.0;
-        for (int j = lane; j < p; j += 64) {
-            const double v = w[(size_t)i * p + j];
-            a += fabs(v);
+    const int r0 = blockIdx.x * 16 + wave * 4;
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, sq = 0.0;
+    size_t ro[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ok[q] = (r0 + q) < p;
+        ro[q] = (size_t)min(r0 + q, p - 1) * p;
+    }
+    for (int j = lane; j < p; j += 64) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double v = ok[q] ? w[ro[q] + j] : 0.0;
+            a[q] += fabs(v);
             sq += v * v;
         }
-        mx = fmax(mx, wave_sum(a));
     }
+    double mx = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mx = fmax(mx, wave_sum(a[q]));
     sq = wave_sum(sq);
     if (lane == 0) { sh_abs[wave] = mx; sh_sq[wave] = sq; }
     __syncthreads();
@@ -312,7 +357,7 @@ __global__ __launch_bounds__(256) void k_norm_bounds(const double* __restrict__ 
     }
 }
 
-int norm_bounds_blocks(int p) { return (p + 63) / 64; }
+int norm_bounds_blocks(int p) { return (p + 15) / 16; }
 
 // part[k][blk] = {max row abs-sum, sum of squares} over row block blk (host finishes the reduction)
 void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* part)

@@ -142,7 +142,9 @@ int ggl_kkt_residual(ggl_ctx *ctx, double rho, double lambda1, double lambda2, i
 #define GGL_PH_RECON_L 5      /* Q max(D-mu,0) Q^T                                                 */
 #define GGL_PH_DUAL 6         /* X += Omega - Theta + L and norms (latent path)                   */
 #define GGL_PH_REDUCE 7       /* partial-sum reduction of the norms                                */
-#define GGL_NPHASE 8
+#define GGL_PH_EIG_OMEGA2 8   /* second part of the Newton-Schulz Omega-step (after the spectral-bound sync) */
+#define GGL_PH_BOUND 9        /* norm pass that gives the spectral bound                           */
+#define GGL_NPHASE 10
 int ggl_profile_enable(ggl_ctx *ctx, int on);
 int ggl_profile_read(ggl_ctx *ctx, double ms[GGL_NPHASE], long long count[GGL_NPHASE], int reset);
 /* Newton-Schulz statistics since ctx creation: Omega-step {calls, steps, calls that took the stable
