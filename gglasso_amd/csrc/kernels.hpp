@@ -144,7 +144,7 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
             int force_mode);
 void ns_prepare(hipStream_t st, const double* pre_d, const double* W, double* AB, int K, int p, int variant);
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
-            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant);
+            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride = 0);
 
 // L-step (C - mu I)_+ by a sign-function Newton-Schulz iteration (newton_schulz.hip)
 int norm_bounds_blocks(int p);

@@ -283,9 +283,11 @@ void ns_prepare(hipStream_t st, const double* pre_d, const double* W, double* AB
 // exactly, which is what makes the coupled iteration insensitive to rounding (the symmetrised form
 // amplifies commutator errors by ~sqrt(kappa)/4 per step).
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
-            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant)
+            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride)
 {
-    const size_t cs = NS_SLOT(K), n1 = (size_t)K * p * p;
+    // pstride: distance (doubles) between the two stacks of a [Y|Z] pair; 0 = contiguous (K*p*p).  A sub-batch
+    // of a larger ctx (two-stream execution) passes the full-stack stride.
+    const size_t cs = NS_SLOT(K), n1 = pstride ? pstride : (size_t)K * p * p;
     const int n = plan.steps;
     dim3 grid((unsigned)(((size_t)p * p + 1023) / 1024), K);
     if (n == 1) {
@@ -301,7 +303,7 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
         if (it == n - 1) {
             launch_symm(st, cur, Tb, out, nullptr, W, coef_d + cs * g++, K, p, variant);
         } else if (plan.stable) {
-            launch_gemm_right(st, cur, Tb, nxt, coef_d + cs * g++, 2 * K, K, p, 0);
+            launch_gemm_right(st, cur, Tb, nxt, coef_d + cs * g++, 2 * K, K, p, 0);   // needs a contiguous pair
             std::swap(cur, nxt);
         } else {
             launch_symm_pair(st, cur, Tb, nxt, Tb, cur + n1, nxt + n1, coef_d + cs * g++, K, p, variant);
