@@ -121,3 +121,25 @@ def ADMM_MGL_sharded(S_local, lambda1, lambda2, reg, Omega_0, K_total, comm, The
     finally:
         eng.close()
     return sol, info
+
+
+def lambda_path_sharded(S, lambda1, group=None, **kwargs):
+    """The lambda1 path of a Single Graphical Lasso problem (the outer loop of the reference's
+    ``single_grid_search``, helper/model_selection.py:619-630) spread over the ranks of a process group:
+    rank r solves the grid points ``shard_grid(len(lambda1), world, r)`` as ONE batch on its GPU
+    (gglasso_amd.batch.ADMM_SGL_batch) and the (sol, info) pairs are gathered on every rank, in grid order.
+    Grid points are independent problems, so there is no data-path collective -- replicas only.
+    ``kwargs`` go to ``ADMM_SGL_batch`` (tol, rtol, latent, mu1, ...)."""
+    import torch.distributed as dist
+    from .batch import ADMM_SGL_batch
+    lam = np.atleast_1d(np.asarray(lambda1, dtype=np.float64))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = shard_grid(len(lam), world, rank)
+    local = ADMM_SGL_batch(S, lam[mine], **kwargs) if mine else []
+    gathered = [None] * world
+    dist.all_gather_object(gathered, list(zip(mine, local)), group=group)
+    out = [None] * len(lam)
+    for part in gathered:
+        for idx, res in part:
+            out[idx] = res
+    return out

@@ -78,3 +78,43 @@ def test_shard_helpers():
             assert max(sizes) - min(sizes) <= 1
     pts = sorted(sum((shard_grid(20, 8, r) for r in range(8)), []))
     assert pts == list(range(20))
+
+
+def _path_worker(rank, world, port, out_dir):
+    import contextlib
+    import io
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gglasso_amd import solver, synth
+    from gglasso_amd.dist import lambda_path_sharded
+    from oracle_engine import OracleEngine
+    solver.ENGINE = OracleEngine
+    S, _ = synth.make_problem("GGL", 1, 18, N=60, seed=3)
+    lams = np.logspace(-0.3, -1.5, 5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = lambda_path_sharded(S[0], lams, tol=1e-9, rtol=1e-9)
+    np.savez(os.path.join(out_dir, f"path{rank}.npz"), thetas=np.stack([r[0]["Theta"] for r in res]),
+             iters=np.array([r[1]["iterations"] for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lambda_path_sharded_over_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import ggl_oracle as orc
+    from gglasso_amd import synth
+    port = _free_port()
+    mp.spawn(_path_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    S, _ = synth.make_problem("GGL", 1, 18, N=60, seed=3)
+    lams = np.logspace(-0.3, -1.5, 5)
+    a = np.load(os.path.join(str(tmp_path), "path0.npz"))
+    b = np.load(os.path.join(str(tmp_path), "path1.npz"))
+    assert np.array_equal(a["thetas"], b["thetas"])          # every rank holds the whole path
+    for i, lam in enumerate(lams):
+        ref, rinfo = orc.ADMM_SGL(S[0], lam, np.eye(18), tol=1e-9, rtol=1e-9)
+        assert int(a["iters"][i]) == rinfo["iterations"]
+        assert np.abs(a["thetas"][i] - ref["Theta"]).max() <= 1e-10
