@@ -167,7 +167,9 @@ def main():
     if args.warmup > 0:
         rho = run(args.warmup, rho)
     ns0 = eng.ns_stats()
-    eng.profile(True)
+    # live HIP-event timing of the dominant (eigen / matrix-function) phases only during the timed region:
+    # every extra event pair costs a few microseconds of host time per iteration
+    eng.profile(2)
     eng.profile_read(reset=True)
     fence()
     t0 = time.perf_counter()
@@ -180,6 +182,14 @@ def main():
         dt = float(t.item())
     prof = eng.profile_read(reset=True)
     ns1 = eng.ns_stats()
+    # untimed extra pass with every phase instrumented, for the per-phase breakdown
+    eng.profile(1)
+    extra_iters = min(10, args.steps)
+    run(extra_iters, rho)
+    prof_all = eng.profile_read(reset=True)
+    for ph, v in prof_all.items():
+        if ph not in ("eig_omega", "eig_omega2", "eig_L"):
+            prof[ph] = v
     eng.close()
 
     if rank == 0:
@@ -191,7 +201,12 @@ def main():
             nl = max(1, ns1["launches"] - ns0["launches"])
             phases["eig_omega"] = {"ms_per_launch": tot / nl, "launches": nl}
             del phases["eig_omega2"]
-        dom = max(phases, key=lambda ph: phases[ph]["ms_per_launch"] * phases[ph]["launches"])
+        hot = ("eig_omega", "eig_L")
+
+        def per_iter(ph):   # hot phases were timed over the timed region, the others over the extra pass
+            return phases[ph]["ms_per_launch"] * phases[ph]["launches"] / (args.steps if ph in hot else extra_iters)
+
+        dom = max(phases, key=per_iter)
         omega_ns = (args.eig == _lib.EIG_NEWTON_SCHULZ) or (args.eig == _lib.EIG_AUTO and not eig_jacobi)
         bound, amount, unit = phase_model(dom, reg, Kl, p, latent, eig_jacobi, omega_ns)
         t64 = (p + 63) // 64
@@ -209,7 +224,7 @@ def main():
             bound, unit = "mfma", "TFLOP/s"
             amount = 1.0 * Kl * p ** 3
             sec = phases[dom]["ms_per_launch"] * phases[dom]["launches"] * 1e-3 / launches
-            phases[dom]["launches"] = launches
+            phases[dom] = {"ms_per_launch": sec * 1e3, "launches": launches}
         if dom == "eig_omega" and omega_ns:
             # the Omega-step's launches differ in size (a pair launch carries two products): average over
             # the step = algorithmic flop of all its launches / their total duration (HIP events)
@@ -235,10 +250,16 @@ def main():
             "roofline": {"kernel": kernel_name, "phase": dom, "launches_per_step": phases[dom]["launches"] / args.steps,
                          "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": pmc_traffic(kernel_name),
-                         "ms_per_launch": phases[dom]["ms_per_launch"]},
+                         "ms_per_launch": phases[dom]["ms_per_launch"],
+                         "note": ("elapsed time of the phase / its kernel launches; at this size the two halves of the "
+                                  "batch run their launch sequences concurrently on two streams, so a single kernel's "
+                                  "own duration (rocprofv3) is up to 2x this figure") if (omega_ns and dom == "eig_omega"
+                                                                                        and Kl >= 16 and t64 * (t64 + 1) // 2 * Kl <= 2048)
+                         else "elapsed time of the phase / its kernel launches"},
             "iteration_hbm_roofline": {"algorithmic_bytes": iter_bytes, "achieved_GBs": its * iter_bytes / 1e9,
                                        "frac": its * iter_bytes / 1e9 / HBM_PEAK_GBS},
             "phases_ms": {ph: round(v["ms_per_launch"], 4) for ph, v in phases.items()},
+            "phases_ms_per_step": {ph: round(per_iter(ph), 4) for ph in phases},
             "newton_schulz": {"steps_per_omega_step": (ns1["steps"] - ns0["steps"]) / max(1, ns1["calls"] - ns0["calls"]),
                               "stable_schedule_calls": ns1["stable_calls"] - ns0["stable_calls"],
                               "lstep_calls": ns1["rank_calls"] - ns0["rank_calls"],

@@ -85,15 +85,17 @@ struct ggl_ctx {
     long long ns_steps_total = 0, ns_calls = 0, ns_units_total = 0, ns_launches_total = 0, ns_eigh_fallbacks = 0;
     double ns_units_frac = 0.0, ns_steps_frac = 0.0;
     // per-phase HIP-event timing
-    bool prof_on = false;
+    int prof_on = 0;          // 0 off, 1 every phase, 2 only the eigen/matrix-function phases (fewer event records)
     hipEvent_t ev[GGL_NPHASE][2] = {};
     bool ev_used[GGL_NPHASE] = {};
     double ph_ms[GGL_NPHASE] = {};
     long long ph_cnt[GGL_NPHASE] = {};
 };
 
-#define PB(c, ph) do { if ((c)->prof_on) (void)hipEventRecord((c)->ev[ph][0], (c)->stream); } while (0)
-#define PE(c, ph) do { if ((c)->prof_on) { (void)hipEventRecord((c)->ev[ph][1], (c)->stream); (c)->ev_used[ph] = true; } } while (0)
+#define PROF_HOT(ph) ((ph) == GGL_PH_EIG_OMEGA || (ph) == GGL_PH_EIG_OMEGA2 || (ph) == GGL_PH_EIG_L)
+#define PROF_ACTIVE(c, ph) ((c)->prof_on == 1 || ((c)->prof_on == 2 && PROF_HOT(ph)))
+#define PB(c, ph) do { if (PROF_ACTIVE(c, ph)) (void)hipEventRecord((c)->ev[ph][0], (c)->stream); } while (0)
+#define PE(c, ph) do { if (PROF_ACTIVE(c, ph)) { (void)hipEventRecord((c)->ev[ph][1], (c)->stream); (c)->ev_used[ph] = true; } } while (0)
 
 static void prof_collect(ggl_ctx* c)   // call after a stream sync
 {
@@ -804,7 +806,7 @@ extern "C" int ggl_profile_enable(ggl_ctx* c, int on)
         for (int ph = 0; ph < GGL_NPHASE; ++ph)
             for (int e = 0; e < 2; ++e) HIPCHK(hipEventCreate(&c->ev[ph][e]));
     }
-    c->prof_on = (on != 0);
+    c->prof_on = (on == 2) ? 2 : (on != 0 ? 1 : 0);
     return GGL_OK;
 }
 

@@ -101,7 +101,8 @@ class HipEngine:
         check(self.lib.ggl_get_state(self.h, ptr(Om), ptr(Th), ptr(L), ptr(X)))
         return {'Omega': Om, 'Theta': Th, 'L': L, 'X': X}
 
-    def profile(self, on=True):
+    def profile(self, on=1):
+        """0 off, 1 every phase, 2 only the eigen / matrix-function phases (cheapest live timing)."""
         check(self.lib.ggl_profile_enable(self.h, int(on)))
 
     def profile_read(self, reset=True):
