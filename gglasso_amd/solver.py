@@ -9,6 +9,7 @@ down (rho, lambda/rho) and five squared norms come back.
 
 There is no CPU fallback: constructing the engine raises if libggl_hip.so or a GPU is missing.
 """
+import math
 import time
 import warnings
 
@@ -35,15 +36,29 @@ class HipEngine:
         L_0 = None if L_0 is None else as_c(L_0)
         check(self.lib.ggl_set_state(self.h, ptr(as_c(Omega_0)), ptr(as_c(Theta_0)), ptr(L_0), ptr(as_c(X_0))))
         self._norms = np.zeros(5)
+        self._norms_p = ptr(self._norms)
+        self._ptr_cache = {}
 
     # -- iteration pieces ------------------------------------------------------------------
     def set_lambda1_mask(self, lam_pp):
         check(self.lib.ggl_set_lambda1_mask(self.h, ptr(None if lam_pp is None else as_c(lam_pp))))
 
+    def _cptr(self, a):
+        """ctypes pointer of a parameter vector, cached per array object (this sits on the per-iteration path)."""
+        if a is None:
+            return None
+        hit = self._ptr_cache.get(id(a))
+        if hit is None or hit[0] is not a:
+            hit = (a, ptr(a))
+            self._ptr_cache[id(a)] = hit
+        return hit[1]
+
     def step(self, rho, lambda1, lambda2, reg, latent, mu1, nk):
-        check(self.lib.ggl_admm_step(self.h, rho, lambda1, lambda2, _REG[reg], int(latent), ptr(mu1), ptr(nk),
-                                     ptr(self._norms)))
-        return self._norms.copy()
+        rc = self.lib.ggl_admm_step(self.h, rho, lambda1, lambda2, _REG[reg], int(latent), self._cptr(mu1),
+                                    self._cptr(nk), self._norms_p)
+        if rc < 0:
+            check(rc)
+        return self._norms
 
     def step_omega(self, rho, latent, nk):
         check(self.lib.ggl_step_omega(self.h, rho, int(latent), ptr(nk)))
@@ -145,7 +160,7 @@ ENGINE = HipEngine
 
 def residuals_from_norms(sq, rho, tol, rtol, dim):
     """ADMM_stopping_criterion (solver/admm_solver.py:316-331) from the five squared norms."""
-    n_om, n_thl, n_x, n_r, n_s = (float(np.sqrt(v)) for v in sq)
+    n_om, n_thl, n_x, n_r, n_s = (math.sqrt(v) for v in sq)
     e_pri = dim * tol + rtol * max(n_om, n_thl)
     e_dual = dim * tol + rtol * rho * n_x
     return n_r, rho * n_s, e_pri, e_dual
