@@ -254,7 +254,7 @@ def main():
                          "note": ("elapsed time of the phase / its kernel launches; at this size the two halves of the "
                                   "batch run their launch sequences concurrently on two streams, so a single kernel's "
                                   "own duration (rocprofv3) is up to 2x this figure") if (omega_ns and dom == "eig_omega"
-                                                                                        and Kl >= 16 and t64 * (t64 + 1) // 2 * Kl <= 2048)
+                                                                                        and Kl >= 16 and 600 <= t64 * (t64 + 1) // 2 * Kl <= 2048)
                          else "elapsed time of the phase / its kernel launches"},
             "iteration_hbm_roofline": {"algorithmic_bytes": iter_bytes, "achieved_GBs": its * iter_bytes / 1e9,
                                        "frac": its * iter_bytes / 1e9 / HBM_PEAK_GBS},

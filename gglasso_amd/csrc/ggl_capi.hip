@@ -484,7 +484,9 @@ static int omega_step(ggl_ctx* c, int latent)
         // for ~20 % of every product at p = 500).  Each half gets its own schedule.
         // (measured: +2.6 % at K=32,p=500; -2 % at p=1000 where several rounds of tiles already overlap)
         const long t64 = (c->p + 63) / 64;
-        const int nh = (c->two_stream && K >= 16 && t64 * (t64 + 1) / 2 * K <= 2048) ? 2 : 1;
+        // and -12 % at K=20,p=200 where the launches are too small to split)
+        const long ntile = t64 * (t64 + 1) / 2 * K;
+        const int nh = (c->two_stream && K >= 16 && ntile >= 600 && ntile <= 2048) ? 2 : 1;
         const int Kh[2] = {nh == 2 ? K / 2 : K, K - K / 2};
         const size_t region = (size_t)(NS_MAX_LAUNCHES - 4) / 2 * NS_SLOT(K);       // coefficient slots per half
         NsPlan plans[2];
