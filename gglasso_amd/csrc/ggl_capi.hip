@@ -68,9 +68,10 @@ struct ggl_ctx {
     double *nsYP[2] = {nullptr, nullptr}, *nsT = nullptr;   // [Y|Z] scratch pairs (2 stacks each), T
     int ns_force = 0;                          // 0 auto, 1 symmetric products, 2 stable products
     bool use_syevj = false;
-    hipStream_t stream2 = nullptr;             // second stream: the two halves of the batch run their
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // Newton-Schulz launch sequences concurrently
-    bool two_stream = false;
+    static constexpr int MAX_PARTS = 4;
+    hipStream_t streamx[MAX_PARTS - 1] = {};   // extra streams: the parts of the batch run their
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS - 1] = {};   // Newton-Schulz launch sequences concurrently
+    int ns_parts = 1;                          // concurrent launch sequences (parts of the batch) wanted
     int* sweeps = nullptr;
     long long ns_stable_calls = 0;
     double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
@@ -189,9 +190,11 @@ static int ctx_alloc(ggl_ctx* c)
         HIPCHK(hipHostMalloc(&c->nbpart_h, nbl));
         HIPCHK(hipMalloc(&c->maxdev, c->K * sizeof(double)));
         HIPCHK(hipHostMalloc(&c->maxdev_h, c->K * sizeof(double)));
-        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        for (int i = 0; i < ggl_ctx::MAX_PARTS - 1; ++i) {
+            HIPCHK(hipStreamCreateWithFlags(&c->streamx[i], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+        }
         c->rank_ns = true;
         if (const char* v = getenv("GGL_RANK_EIG")) c->rank_ns = atoi(v) == 0;   // 1: force the eigh route
     }
@@ -217,8 +220,8 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
     if (const char* v = getenv("GGL_SYMM_VARIANT")) c->symm_variant = atoi(v);
     if (const char* v = getenv("GGL_NS_MODE")) c->ns_force = atoi(v);   // 1 symmetric, 2 stable (testing)
     if (const char* v = getenv("GGL_ROCSOLVER_SYEVJ")) c->use_syevj = atoi(v) != 0;
-    c->two_stream = true;
-    if (const char* v = getenv("GGL_TWO_STREAM")) c->two_stream = atoi(v) != 0;
+    c->ns_parts = 2;
+    if (const char* v = getenv("GGL_TWO_STREAM")) c->ns_parts = std::min(std::max(atoi(v), 1), (int)ggl_ctx::MAX_PARTS);
     c->n = (size_t)K * p * p;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -263,9 +266,11 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     for (int ph = 0; ph < GGL_NPHASE; ++ph)
         for (int e = 0; e < 2; ++e)
             if (c->ev[ph][e]) (void)hipEventDestroy(c->ev[ph][e]);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (int i = 0; i < ggl_ctx::MAX_PARTS - 1; ++i) {
+        if (c->streamx[i]) (void)hipStreamDestroy(c->streamx[i]);
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GGL_OK;
@@ -486,14 +491,21 @@ static int omega_step(ggl_ctx* c, int latent)
         const long t64 = (c->p + 63) / 64;
         // and -12 % at K=20,p=200 where the launches are too small to split)
         const long ntile = t64 * (t64 + 1) / 2 * K;
-        const int nh = (c->two_stream && K >= 16 && ntile >= 600 && ntile <= 2048) ? 2 : 1;
-        const int Kh[2] = {nh == 2 ? K / 2 : K, K - K / 2};
-        const size_t region = (size_t)(NS_MAX_LAUNCHES - 4) / 2 * NS_SLOT(K);       // coefficient slots per half
-        NsPlan plans[2];
+        int nh = (K >= 16 && ntile >= 600 && ntile <= 2048) ? std::min(c->ns_parts, K / 8) : 1;
+        nh = std::max(nh, 1);
+        int Kh[ggl_ctx::MAX_PARTS], k0h[ggl_ctx::MAX_PARTS];
+        for (int h = 0, k0 = 0; h < nh; ++h) {
+            Kh[h] = K / nh + (h < K % nh ? 1 : 0);
+            k0h[h] = k0;
+            k0 += Kh[h];
+        }
+        const size_t region = (size_t)(NS_MAX_LAUNCHES - 4) / nh * NS_SLOT(K);      // coefficient slots per part
+        NsPlan plans[ggl_ctx::MAX_PARTS];
         double* start_base_h = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
         double* start_base_d = c->coef + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
         bool any_stable = false;
-        for (int h = 0, k0 = 0; h < nh; k0 += Kh[h], ++h) {
+        for (int h = 0; h < nh; ++h) {
+            const int k0 = k0h[h];
             const int prc = ns_plan(c->bounds_h + k0, c->par_h + k0, Kh[h], c->coef_h + h * region, start_base_h + 5 * k0,
                                     &plans[h], c->ns_force);
             if (prc == -1) return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");
@@ -508,32 +520,33 @@ static int omega_step(ggl_ctx* c, int latent)
             }
             any_stable = any_stable || plans[h].stable;
         }
-        if (nh == 2 && any_stable) {
+        if (nh > 1 && any_stable) {
             // the stable schedule multiplies a contiguous [Y|P] pair: run the whole batch as one sequence
             const int prc = ns_plan(c->bounds_h, c->par_h, K, c->coef_h, start_base_h, &plans[0], c->ns_force);
             if (prc != 0) return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: plan failed (%d)", prc);
         }
-        const int nrun = (nh == 2 && !any_stable) ? 2 : 1;
+        const int nrun = (nh > 1 && !any_stable) ? nh : 1;
+        if (nrun == 1) { Kh[0] = K; k0h[0] = 0; }
         const size_t pp = (size_t)c->p * c->p;
         HIPCHK(hipMemcpyAsync(start_base_d, start_base_h, (size_t)K * 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
         for (int h = 0; h < nrun; ++h) {
-            const int Kr = (nrun == 2) ? Kh[h] : K;
             const int nb_launch = plans[h].products - 2;     // launches of phase B
             if (nb_launch > 0)
                 HIPCHK(hipMemcpyAsync(c->coef + h * region, c->coef_h + h * region,
-                                      (size_t)nb_launch * NS_SLOT(Kr) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                                      (size_t)nb_launch * NS_SLOT(Kh[h]) * sizeof(double), hipMemcpyHostToDevice, c->stream));
         }
         PB(c, GGL_PH_EIG_OMEGA2);
-        if (nrun == 2) {
+        if (nrun > 1) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-            HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            for (int h = 1; h < nrun; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
         }
-        for (int h = 0, k0 = 0; h < nrun; k0 += Kh[h], ++h) {
-            const int Kr = (nrun == 2) ? Kh[h] : K;
-            ns_run(h == 0 ? c->stream : c->stream2, plans[h], c->coef + h * region, start_base_d + 5 * k0, c->W + k0 * pp,
-                   c->nsYP[0] + k0 * pp, c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kr, c->p,
-                   // tile choice by the work of the WHOLE batch: the other half shares the chip (measured +6.7 %)
-                   (c->symm_variant < 0 && nrun == 2) ? 16 : c->symm_variant, nrun == 2 ? c->n : 0);
+        for (int h = 0; h < nrun; ++h) {
+            const int Kr = Kh[h], k0 = k0h[h];
+            ns_run(h == 0 ? c->stream : c->streamx[h - 1], plans[h], c->coef + h * region, start_base_d + 5 * k0,
+                   c->W + k0 * pp, c->nsYP[0] + k0 * pp, c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kr,
+                   c->p,
+                   // tile choice by the work of the WHOLE batch: the other parts share the chip (measured +6.7 %)
+                   (c->symm_variant < 0 && nrun > 1) ? 16 : c->symm_variant, nrun > 1 ? c->n : 0);
             c->ns_stable_calls += plans[h].stable ? 1 : 0;
             c->ns_launches_total += plans[h].products - (h > 0 ? 2 : 0);   // phase A was one sequence
             // algorithmic work in units of (whole-stack) K p^3 flop
@@ -541,9 +554,9 @@ static int omega_step(ggl_ctx* c, int latent)
             c->ns_units_frac += frac * ((plans[h].steps == 1) ? 2 : (plans[h].stable ? 5 * plans[h].steps - 6 : 3 * plans[h].steps - 2));
             c->ns_steps_frac += frac * plans[h].steps;
         }
-        if (nrun == 2) {
-            HIPCHK(hipEventRecord(c->ev_join, c->stream2));
-            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        for (int h = 1; h < nrun; ++h) {
+            HIPCHK(hipEventRecord(c->ev_join[h - 1], c->streamx[h - 1]));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
         }
         PE(c, GGL_PH_EIG_OMEGA2);
         HIPCHK(hipGetLastError());
