@@ -71,12 +71,14 @@ struct ggl_ctx {
     static constexpr int MAX_PARTS = 4;
     hipStream_t streamx[MAX_PARTS - 1] = {};   // extra streams: the parts of the batch run their
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS - 1] = {};   // Newton-Schulz launch sequences concurrently
+    int ns_degrees = 5;                        // 3: cubic Newton-Schulz steps only; 5: cubic/quintic mix
     int ns_parts = 1;                          // concurrent launch sequences (parts of the batch) wanted
     int* sweeps = nullptr;
     long long ns_stable_calls = 0;
     double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
     double *bounds = nullptr, *bounds_h = nullptr;   // [K][2]
     double *rowpart = nullptr, *sqpart = nullptr;    // scratch of the norm bounds (newton_schulz.hip)
+    double* nbrow = nullptr;                   // [K][p] row abs-sums of B' (Collatz-Wielandt weight vector)
     double *nbpart = nullptr, *nbpart_h = nullptr;   // [K][blocks][2] norm bounds of C (L-step)
     double *maxdev = nullptr, *maxdev_h = nullptr;   // [K] residual of the sign iteration
     bool rank_ns = false;                            // L-step by sign Newton-Schulz (else eigendecomposition)
@@ -185,7 +187,8 @@ static int ctx_alloc(ggl_ctx* c)
         const int Tf = form_W_tiles(c->p);
         HIPCHK(hipMalloc(&c->rowpart, (size_t)c->K * Tf * c->p * sizeof(double)));
         HIPCHK(hipMalloc(&c->sqpart, (size_t)c->K * (Tf * (Tf + 1) / 2) * sizeof(double)));
-        const size_t nbl = 2 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);
+        const size_t nbl = 3 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);   // + Collatz-Wielandt maxima
+        HIPCHK(hipMalloc(&c->nbrow, (size_t)c->K * c->p * sizeof(double)));
         HIPCHK(hipMalloc(&c->nbpart, nbl));
         HIPCHK(hipHostMalloc(&c->nbpart_h, nbl));
         HIPCHK(hipMalloc(&c->maxdev, c->K * sizeof(double)));
@@ -221,6 +224,7 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
     if (const char* v = getenv("GGL_NS_MODE")) c->ns_force = atoi(v);   // 1 symmetric, 2 stable (testing)
     if (const char* v = getenv("GGL_ROCSOLVER_SYEVJ")) c->use_syevj = atoi(v) != 0;
     c->ns_parts = 2;
+    if (const char* v = getenv("GGL_NS_DEGREES")) c->ns_degrees = atoi(v) >= 5 ? 5 : 3;
     if (const char* v = getenv("GGL_TWO_STREAM")) c->ns_parts = std::min(std::max(atoi(v), 1), (int)ggl_ctx::MAX_PARTS);
     c->n = (size_t)K * p * p;
     if (stream) {
@@ -251,7 +255,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
-                      c->nsT, c->coef, c->bounds, c->sqwork, c->rowpart, c->sqpart, c->nbpart, c->maxdev};
+                      c->nsT, c->coef, c->bounds, c->sqwork, c->rowpart, c->sqpart, c->nbpart, c->maxdev, c->nbrow};
     if (c->nbpart_h) (void)hipHostFree(c->nbpart_h);
     if (c->maxdev_h) (void)hipHostFree(c->maxdev_h);
     if (c->coef_h) (void)hipHostFree(c->coef_h);
@@ -469,19 +473,23 @@ static int omega_step(ggl_ctx* c, int latent)
         PE(c, GGL_PH_EIG_OMEGA);
         PB(c, GGL_PH_BOUND);
         const int nbb = norm_bounds_blocks(c->p);
-        launch_norm_bounds(c->stream, c->nsYP[0] + c->n, K, c->p, c->nbpart);
+        launch_norm_bounds(c->stream, c->nsYP[0] + c->n, K, c->p, c->nbpart, c->nbrow);
+        launch_cw_bounds(c->stream, c->nsYP[0] + c->n, c->nbrow, K, c->p, c->nbpart + 2 * (size_t)K * nbb);
         PE(c, GGL_PH_BOUND);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->nbpart_h, c->nbpart, 2 * (size_t)K * nbb * sizeof(double), hipMemcpyDeviceToHost,
+        HIPCHK(hipMemcpyAsync(c->nbpart_h, c->nbpart, 3 * (size_t)K * nbb * sizeof(double), hipMemcpyDeviceToHost,
                               c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         for (int k = 0; k < K; ++k) {
-            double mx = 0.0, sq = 0.0;
+            double mx = 0.0, sq = 0.0, cw = 0.0;
             for (int b2 = 0; b2 < nbb; ++b2) {
                 mx = std::max(mx, c->nbpart_h[2 * ((size_t)k * nbb + b2)]);
                 sq += c->nbpart_h[2 * ((size_t)k * nbb + b2) + 1];
+                cw = std::max(cw, c->nbpart_h[2 * (size_t)K * nbb + (size_t)k * nbb + b2]);
             }
-            // lambda_max(A')^2 = lambda_max(B') <= min(|B'|_inf, |B'|_F)
+            // lambda_max(A')^2 = lambda_max(B') <= min(|B'|_inf, |B'|_F, Collatz-Wielandt ratio); the ratio is
+            // computed in floating point from ~p terms, hence the small inflation
+            if (std::isfinite(cw) && cw > 0.0) mx = std::min(mx, cw * (1.0 + 1e-12));
             c->bounds_h[k] = std::sqrt(std::min(mx, std::sqrt(sq)));
         }
         // Two halves of the batch on two streams: while one half's product drains its output and the next
@@ -507,7 +515,7 @@ static int omega_step(ggl_ctx* c, int latent)
         for (int h = 0; h < nh; ++h) {
             const int k0 = k0h[h];
             const int prc = ns_plan(c->bounds_h + k0, c->par_h + k0, Kh[h], c->coef_h + h * region, start_base_h + 5 * k0,
-                                    &plans[h], c->ns_force);
+                                    &plans[h], c->ns_force, c->ns_degrees);
             if (prc == -1) return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");
             if (prc == -2) {
                 // pathological scaling (|W|^2 rho / nk > 1e12): eigendecomposition of the (still intact) W
@@ -522,7 +530,7 @@ static int omega_step(ggl_ctx* c, int latent)
         }
         if (nh > 1 && any_stable) {
             // the stable schedule multiplies a contiguous [Y|P] pair: run the whole batch as one sequence
-            const int prc = ns_plan(c->bounds_h, c->par_h, K, c->coef_h, start_base_h, &plans[0], c->ns_force);
+            const int prc = ns_plan(c->bounds_h, c->par_h, K, c->coef_h, start_base_h, &plans[0], c->ns_force, c->ns_degrees);
             if (prc != 0) return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: plan failed (%d)", prc);
         }
         const int nrun = (nh > 1 && !any_stable) ? nh : 1;
@@ -551,7 +559,7 @@ static int omega_step(ggl_ctx* c, int latent)
             c->ns_launches_total += plans[h].products - (h > 0 ? 2 : 0);   // phase A was one sequence
             // algorithmic work in units of (whole-stack) K p^3 flop
             const double frac = (double)Kr / K;
-            c->ns_units_frac += frac * ((plans[h].steps == 1) ? 2 : (plans[h].stable ? 5 * plans[h].steps - 6 : 3 * plans[h].steps - 2));
+            c->ns_units_frac += frac * plans[h].units;
             c->ns_steps_frac += frac * plans[h].steps;
         }
         for (int h = 1; h < nrun; ++h) {
@@ -1175,6 +1183,15 @@ extern "C" int ggl_dev_symm_timeline(int K, int p, long long* out, int max_block
     HIPCHK(hipMemcpy(out, dT.p, (size_t)nb * 5 * sizeof(long long), hipMemcpyDeviceToHost));
     *nblocks_out = nb;
     return GGL_OK;
+}
+
+extern "C" int ggl_dev_ns_schedule(double l, int degrees, int max_steps, int* deg_out, double* coef_out, int* units_out)
+{
+    ARGCHK(deg_out && coef_out && units_out, "output pointers");
+    ARGCHK(l > 0.0 && l <= 1.0, "l must be in (0,1]");
+    const int n = ns_schedule_query(l, degrees, max_steps, deg_out, coef_out, units_out);
+    if (n < 0) return fail(GGL_E_ARG, "no schedule within %d steps", max_steps);
+    return n;
 }
 
 extern "C" int ggl_dev_mfma_f64_peak(double* tflops_out)

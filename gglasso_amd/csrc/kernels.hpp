@@ -126,7 +126,12 @@ static inline size_t NS_SLOT(int K) { return (size_t)K * 10; }
 static constexpr double NS_SYM_KAPPA_MAX = 300.0;
 // above this condition number of W^2 + 4 beta I the Omega-step uses the eigendecomposition instead
 static constexpr double NS_KAPPA_LIMIT = 1e12;
-struct NsPlan { int steps = 0; int products = 0; bool stable = false; double kappa = 0.0; };
+// steps: polynomial steps; products: kernel launches of products (incl. A', B'); units: symmetric products
+// of the whole stack (K p^3 flop each); deg[it]: degree (3 or 5) of step it in x = sqrt(eig(Z Y))
+struct NsPlan {
+    int steps = 0; int products = 0; bool stable = false; double kappa = 0.0; int units = 0;
+    unsigned char deg[NS_MAX_STEPS] = {};
+};
 // W = ((Theta - L) - X) - beta_k S from the lower triangle, mirrored (exactly symmetric)
 // also: bounds[k] = {|W_k|_inf, |W_k|_F^2} (device, K*2 doubles) through the scratch arrays
 // rowpart (K * form_W_tiles(p) * p doubles) and sqpart (K * T(T+1)/2 doubles, T = form_W_tiles(p))
@@ -140,15 +145,21 @@ void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const dou
 //   ns_run: start kernel (Y1, Z1 as polynomials of A', B') + the remaining products
 // ns_plan returns 0, -1 (non-finite input) or -2 (condition number above NS_KAPPA_LIMIT: use the
 // eigendecomposition); fills coef_h[launch slots] and start_h[K][5].
+// degrees: 3 = cubic steps only, 5 = cheapest mix of cubic and quintic steps (fast schedule only).
 int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h, double* start_h, NsPlan* plan,
-            int force_mode);
+            int force_mode, int degrees = 5);
+// the schedule alone (host): returns steps, fills deg[max_steps], coef[max_steps*4] = {t0,t1,t2,l_after}
+int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units);
 void ns_prepare(hipStream_t st, const double* pre_d, const double* W, double* AB, int K, int p, int variant);
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
             double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride = 0);
 
 // L-step (C - mu I)_+ by a sign-function Newton-Schulz iteration (newton_schulz.hip)
 int norm_bounds_blocks(int p);
-void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* part);
+// part[k][blk] = {max row abs-sum, sum of squares}; rowsum (optional, K*p): every row's abs-sum
+void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* part, double* rowsum = nullptr);
+// Collatz-Wielandt refinement of the row-sum bound: part[k][blk] = max_i (|W| d)_i / d_i, d = rowsum
+void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int K, int p, double* part);
 int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan);
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
                  double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant);
