@@ -71,7 +71,7 @@ struct ggl_ctx {
     static constexpr int MAX_PARTS = 4;
     hipStream_t streamx[MAX_PARTS - 1] = {};   // extra streams: the parts of the batch run their
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS - 1] = {};   // Newton-Schulz launch sequences concurrently
-    int ns_degrees = 5;                        // 3: cubic Newton-Schulz steps only; 5: cubic/quintic mix
+    int ns_degrees = 9;                        // highest Newton-Schulz step degree: 3, 5 or 9
     int ns_parts = 1;                          // concurrent launch sequences (parts of the batch) wanted
     int* sweeps = nullptr;
     long long ns_stable_calls = 0;
@@ -224,7 +224,7 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
     if (const char* v = getenv("GGL_NS_MODE")) c->ns_force = atoi(v);   // 1 symmetric, 2 stable (testing)
     if (const char* v = getenv("GGL_ROCSOLVER_SYEVJ")) c->use_syevj = atoi(v) != 0;
     c->ns_parts = 2;
-    if (const char* v = getenv("GGL_NS_DEGREES")) c->ns_degrees = atoi(v) >= 5 ? 5 : 3;
+    if (const char* v = getenv("GGL_NS_DEGREES")) c->ns_degrees = atoi(v) >= 9 ? 9 : (atoi(v) >= 5 ? 5 : 3);
     if (const char* v = getenv("GGL_TWO_STREAM")) c->ns_parts = std::min(std::max(atoi(v), 1), (int)ggl_ctx::MAX_PARTS);
     c->n = (size_t)K * p * p;
     if (stream) {

@@ -127,7 +127,7 @@ static constexpr double NS_SYM_KAPPA_MAX = 300.0;
 // above this condition number of W^2 + 4 beta I the Omega-step uses the eigendecomposition instead
 static constexpr double NS_KAPPA_LIMIT = 1e12;
 // steps: polynomial steps; products: kernel launches of products (incl. A', B'); units: symmetric products
-// of the whole stack (K p^3 flop each); deg[it]: degree (3 or 5) of step it in x = sqrt(eig(Z Y))
+// of the whole stack (K p^3 flop each); deg[it]: degree (3, 5 or 9) of step it in x = sqrt(eig(Z Y))
 struct NsPlan {
     int steps = 0; int products = 0; bool stable = false; double kappa = 0.0; int units = 0;
     unsigned char deg[NS_MAX_STEPS] = {};
@@ -145,10 +145,10 @@ void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const dou
 //   ns_run: start kernel (Y1, Z1 as polynomials of A', B') + the remaining products
 // ns_plan returns 0, -1 (non-finite input) or -2 (condition number above NS_KAPPA_LIMIT: use the
 // eigendecomposition); fills coef_h[launch slots] and start_h[K][5].
-// degrees: 3 = cubic steps only, 5 = cheapest mix of cubic and quintic steps (fast schedule only).
+// degrees: highest step degree of the fast schedule: 3 = cubic only, 5 = cubic/quintic mix, 9 = + degree nine.
 int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h, double* start_h, NsPlan* plan,
-            int force_mode, int degrees = 5);
-// the schedule alone (host): returns steps, fills deg[max_steps], coef[max_steps*4] = {t0,t1,t2,l_after}
+            int force_mode, int degrees = 9);
+// the schedule alone (host): returns steps, fills deg[max_steps], coef[max_steps*6] = {t0..t4,l_after}
 int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units);
 void ns_prepare(hipStream_t st, const double* pre_d, const double* W, double* AB, int K, int p, int variant);
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,

@@ -173,19 +173,52 @@ static std::vector<double> ns_schedule(double l, int max_steps = NS_MAX_STEPS)
 }
 
 // ---- mixed-degree schedule (fast, all-symmetric mode) --------------------------------------------------
-// One step maps x = sqrt(eig(Z Y)) in [l,1] by x -> x t(x^2) with t of degree 1 (cubic step, Chen-Chow scaling)
-// or degree 2 (quintic step, the minimax polynomial for the constant 1 on [l,1]; cf. the "Polar Express"
-// construction, Amsel et al. 2025).  A quintic step costs one more symmetric product (M^2) but contracts the
+// One step maps x = sqrt(eig(Z Y)) in [l,1] by x -> x t(x^2), t of degree 1 (cubic step, Chen-Chow scaling),
+// 2 (quintic) or 4 (degree 9): the minimax polynomial for the constant 1 on [l,1] (cf. the "Polar Express"
+// construction, Amsel et al. 2025).  Higher degrees cost more symmetric products per step but contract the
 // interval much faster; which mix is cheapest depends on l.  Cost in symmetric products of the stack, on top of
-// A' and B':  cubic first 0 / middle 3 / last 2,  quintic first 1 / middle 4 / last 3.
-struct NsStep { double t0, t1, t2, lnew; };
+// A' and B':   cubic first 0 / middle 3 / last 2,  quintic 1 / 4 / 3,  degree nine 2 / 5 / 4
+// (t of degree 4 takes two products: Q = M^2 + a M, t(M) = t4 Q (Q + d I) + e M + f I).
+struct NsStep { double t[5]; double lnew; };
 
 static NsStep ns_cubic_step(double l)
 {
     const double a = (l < 0.99) ? std::sqrt(3.0 / (1.0 + l + l * l)) : 1.0;
     const double gl = 0.5 * a * l * (3.0 - a * a * l * l);
     const double g1 = 0.5 * a * (3.0 - a * a);
-    return {1.5 * a, -0.5 * a * a * a, 0.0, std::fmin(gl, g1)};
+    return {{1.5 * a, -0.5 * a * a * a, 0.0, 0.0, 0.0}, std::fmin(gl, g1)};
+}
+
+// Narrow intervals (s = 1 - x^2 in [0, smax], smax <= 0.05), where the minimax deviation drops below what an
+// exchange algorithm can resolve in fp64: t(s) = the Taylor polynomial of (1-s)^(-1/2) of degree m with its
+// leading term s^m replaced by the degree-(m-1) Chebyshev economisation on [0, smax].  Deviation
+// <= a_m smax^m / 2^(2m-1) + sum_{j>m} a_j smax^j, a_j = binom(2j,j)/4^j: within a few per cent of the minimax.
+static NsStep ns_econ_step(double l, int m)
+{
+    static const double cheb3[4] = {-1.0, 18.0, -48.0, 32.0};                       // T3*(u) = T3(2u-1)
+    static const double cheb5[6] = {-1.0, 50.0, -400.0, 1120.0, -1280.0, 512.0};    // T5*(u)
+    const double* ch = (m == 3) ? cheb3 : cheb5;
+    const double smax = 1.0 - l * l;
+    double a[48];
+    a[0] = 1.0;
+    for (int j = 1; j < 48; ++j) a[j] = a[j - 1] * (2.0 * j - 1.0) / (2.0 * j);
+    double cs[5] = {0, 0, 0, 0, 0};                       // t in powers of s
+    double smj = 1.0;                                     // smax^(m-i)
+    for (int i = m - 1; i >= 0; --i) {
+        smj *= smax;
+        cs[i] = a[i] - a[m] * smj * ch[i] / ch[m];
+    }
+    double E = a[m] * std::pow(smax, m) / ch[m], sp = std::pow(smax, m + 1);
+    for (int j = m + 1; j < 48; ++j, sp *= smax) E += a[j] * sp;
+    E *= 1.0 + 1e-6;
+    NsStep r = {{0, 0, 0, 0, 0}, 0.0};
+    static const double binom[5][5] = {{1, 0, 0, 0, 0}, {1, 1, 0, 0, 0}, {1, 2, 1, 0, 0}, {1, 3, 3, 1, 0}, {1, 4, 6, 4, 1}};
+    for (int j = 0; j < m; ++j)                           // s^j = (1 - x^2)^j
+        for (int i = 0; i <= j; ++i) r.t[i] += cs[j] * binom[j][i] * ((i & 1) ? -1.0 : 1.0);
+    const double sc = 1.0 / (1.0 + E);
+    for (int i = 0; i < m; ++i) r.t[i] *= sc;
+    r.lnew = (1.0 - E) * sc;
+    return r;
 }
 
 // minimax p(x) = a x + b x^3 + c x^5 ~ 1 on [l,1] by Remez exchange: the reference is {l, q1, q2, 1} and the
@@ -193,11 +226,7 @@ static NsStep ns_cubic_step(double l)
 static NsStep ns_quintic_step(double l)
 {
     const double e = 1.0 - l;
-    if (e < 2e-3) {
-        // near the fixed point the exchange is ill-conditioned; the Pade step x(15 - 10x^2 + 3x^4)/8 maps
-        // 1-e to 1 - (5/2)e^3 + O(e^4) and stays <= 1
-        return {15.0 / 8.0, -10.0 / 8.0, 3.0 / 8.0, 1.0 - 2.6 * e * e * e};
-    }
+    if (1.0 - l * l <= 0.05) return ns_econ_step(l, 3);
     double q1 = l + e / 3.0, q2 = l + 2.0 * e / 3.0, co[4] = {0, 0, 0, 0};
     for (int iter = 0; iter < 60; ++iter) {
         const double pts[4] = {l, q1, q2, 1.0};
@@ -233,63 +262,198 @@ static NsStep ns_quintic_step(double l)
                          std::fmax(std::fabs(pv(q2) - 1.0), std::fabs(pv(1.0) - 1.0)));
     E *= 1.0 + 1e-9;
     const double s = 1.0 / (1.0 + E);                     // rescale: the image is [ (1-E)/(1+E), 1 ]
-    return {co[0] * s, co[1] * s, co[2] * s, (1.0 - E) * s};
+    return {{co[0] * s, co[1] * s, co[2] * s, 0.0, 0.0}, (1.0 - E) * s};
+}
+
+// degree 9: Remez exchange on a Chebyshev-spaced grid of [l,1], in the basis x ((1-x^2)/smax)^j (well conditioned
+// whatever l); the grid maximum is inflated by 1e-3 for what lies between grid points (the error curve has six
+// alternations; between neighbours of a 384-point grid it cannot rise by more than ~2e-4 of its amplitude).
+static NsStep ns_nonic_step(double l)
+{
+    constexpr int m = 5, G = 384;
+    const double smax = 1.0 - l * l;
+    if (smax <= 0.05) return ns_econ_step(l, m);
+    static thread_local double gx[G + 1], gb[G + 1][m], err[G + 1];
+    for (int i = 0; i <= G; ++i) {
+        const double x = l + (1.0 - l) * 0.5 * (1.0 - std::cos(M_PI * i / G));
+        gx[i] = x;
+        const double u = (1.0 - x * x) / smax;
+        double b = x;
+        for (int j = 0; j < m; ++j, b *= u) gb[i][j] = b;
+    }
+    int ref[m + 1];
+    for (int k = 0; k <= m; ++k) ref[k] = (int)std::lround((double)G * k / m);
+    double co[m + 1] = {};
+    for (int iter = 0; iter < 30; ++iter) {
+        double A[m + 1][m + 2];
+        for (int r = 0; r <= m; ++r) {
+            for (int j = 0; j < m; ++j) A[r][j] = gb[ref[r]][j];
+            A[r][m] = (r & 1) ? -1.0 : 1.0;               // p(ref_0) = 1 - E, p(ref_1) = 1 + E, ...
+            A[r][m + 1] = 1.0;
+        }
+        for (int i = 0; i <= m; ++i) {
+            int pv = i;
+            for (int r = i + 1; r <= m; ++r) if (std::fabs(A[r][i]) > std::fabs(A[pv][i])) pv = r;
+            for (int cc = 0; cc <= m + 1; ++cc) std::swap(A[i][cc], A[pv][cc]);
+            for (int r = 0; r <= m; ++r) {
+                if (r == i) continue;
+                const double f = A[r][i] / A[i][i];
+                for (int cc = i; cc <= m + 1; ++cc) A[r][cc] -= f * A[i][cc];
+            }
+        }
+        for (int i = 0; i <= m; ++i) co[i] = A[i][m + 1] / A[i][i];
+        for (int i = 0; i <= G; ++i) {
+            double v = 0.0;
+            for (int j = 0; j < m; ++j) v += co[j] * gb[i][j];
+            err[i] = v - 1.0;
+        }
+        // local extrema of the error (end points included), reduced to an alternating set of m+1
+        int alt[G + 2], na = 0;
+        for (int i = 0; i <= G; ++i) {
+            const bool ext = (i == 0 || i == G) || ((err[i] - err[i - 1]) * (err[i + 1] - err[i]) <= 0.0);
+            if (!ext) continue;
+            if (na > 0 && (err[i] > 0.0) == (err[alt[na - 1]] > 0.0)) {
+                if (std::fabs(err[i]) > std::fabs(err[alt[na - 1]])) alt[na - 1] = i;
+            } else {
+                alt[na++] = i;
+            }
+        }
+        int lo = 0;
+        while (na - lo > m + 1) {
+            if (std::fabs(err[alt[lo]]) < std::fabs(err[alt[na - 1]])) ++lo; else --na;
+        }
+        if (na - lo < m + 1) break;
+        bool same = true;
+        for (int k = 0; k <= m; ++k) { same = same && (ref[k] == alt[lo + k]); ref[k] = alt[lo + k]; }
+        if (same) break;
+    }
+    NsStep r = {{0, 0, 0, 0, 0}, 0.0};
+    static const double binom[5][5] = {{1, 0, 0, 0, 0}, {1, 1, 0, 0, 0}, {1, 2, 1, 0, 0}, {1, 3, 3, 1, 0}, {1, 4, 6, 4, 1}};
+    double sj = 1.0;
+    for (int j = 0; j < m; ++j, sj *= smax)
+        for (int i = 0; i <= j; ++i) r.t[i] += co[j] / sj * binom[j][i] * ((i & 1) ? -1.0 : 1.0);
+    double E = 0.0;
+    for (int i = 0; i <= G; ++i) {
+        const double x2 = gx[i] * gx[i];
+        const double pv = gx[i] * (r.t[0] + x2 * (r.t[1] + x2 * (r.t[2] + x2 * (r.t[3] + x2 * r.t[4]))));
+        E = std::fmax(E, std::fabs(pv - 1.0));
+    }
+    E *= 1.0 + 1e-3;
+    const double sc = 1.0 / (1.0 + E);
+    for (int i = 0; i < m; ++i) r.t[i] *= sc;
+    r.lnew = (1.0 - E) * sc;
+    return r;
 }
 
 static int ns_step_cost(int d, bool first, bool last)
 {
-    if (first && last) return d == 3 ? 0 : 1;
-    if (d == 3) return first ? 0 : (last ? 2 : 3);
-    return first ? 1 : (last ? 3 : 4);
+    const int base = (d == 3) ? 0 : (d == 5 ? 1 : 2);     // products inside t(M) beyond M itself
+    if (first) return base;                               // Z1 = T1 from A', B'; Y1 (or Omega) one product unless cubic
+    return base + (last ? 2 : 3);                         // M, [t(M)], Y T, [T Z]
 }
 
 struct NsSeq { int n = 0; int cost = 1 << 30; unsigned char deg[NS_MAX_STEPS]; NsStep st[NS_MAX_STEPS]; };
 
-static void ns_search(double l, int depth, int cost_so_far, NsSeq& cur, NsSeq& best, int degrees)
+// The schedule is a deterministic function of a QUANTISED interval: l is rounded down on a geometric grid
+// (ratio 1.01) below 0.5 and 1-l is rounded up on a geometric grid (ratio 1.02) above, at the start and after
+// every step.  Rounding only widens the interval, so the polynomials stay valid; it makes every step and the
+// cost-to-go a function of an integer key, which is what the dynamic programme below memoises.
+struct NsKey { int key; double l; };
+static NsKey ns_quantise(double l)
 {
-    // cost_so_far prices every step so far as a non-last step
-    if (depth >= NS_MAX_STEPS || cost_so_far >= best.cost) return;
-    // far from convergence (long schedules, only reachable when the fast mode is forced) the quintic step always
-    // pays; branching is confined to the last few steps
-    for (int d = (degrees == 5 && l < 0.05) ? 5 : 3; d <= degrees; d += 2) {
-        const NsStep s = (d == 3) ? ns_cubic_step(l) : ns_quintic_step(l);
-        cur.deg[depth] = (unsigned char)d;
-        cur.st[depth] = s;
-        if (1.0 - s.lnew < 4e-16) {
-            const int cost = cost_so_far + ns_step_cost(d, depth == 0, true);
-            if (cost < best.cost) { best = cur; best.n = depth + 1; best.cost = cost; }
-        } else {
-            ns_search(s.lnew, depth + 1, cost_so_far + ns_step_cost(d, depth == 0, false), cur, best, degrees);
-        }
+    if (l < 0.5) {
+        const double lg = std::log(1.01);
+        const int idx = (int)std::floor(std::log(l) / lg);
+        return {idx, std::exp(idx * lg)};
     }
+    const double lg = std::log(1.02), e = std::fmax(1.0 - l, 1e-300);
+    const int j = (int)std::ceil(std::log(e) / lg);
+    const double eq = std::exp(j * lg);
+    if (eq > 0.5) return {-70, std::exp(-70 * std::log(1.01))};        // just below 0.5 on the lower grid
+    return {1000000 + j, 1.0 - eq};
 }
 
-// schedules are cached on a geometric grid of l (ratio 1.01): the plan for the grid point below l is valid for l
-// (its interval contains [l,1]) and a deterministic function of the grid index, whatever the cache holds
+struct NsPlanner {
+    int degrees;
+    struct Node { int cost; int d; };
+    std::unordered_map<long long, NsStep> steps;          // (key, degree) -> step
+    std::unordered_map<int, Node> togo;                   // key -> cheapest completion as a non-first step
+    std::unordered_map<int, NsSeq> plans;                 // key -> whole schedule from a first step
+    const NsStep& step(const NsKey& q, int d)
+    {
+        const long long id = (long long)q.key * 16 + d;
+        auto it = steps.find(id);
+        if (it != steps.end()) return it->second;
+        const NsStep s = (d == 3) ? ns_cubic_step(q.l) : (d == 5 ? ns_quintic_step(q.l) : ns_nonic_step(q.l));
+        return steps.emplace(id, s).first->second;
+    }
+    static bool converged(const NsStep& s) { return 1.0 - s.lnew < 4e-16; }
+    Node best_from(const NsKey& q, int depth)
+    {
+        auto it = togo.find(q.key);
+        if (it != togo.end()) return it->second;
+        Node b = {1 << 29, 3};
+        if (depth < NS_MAX_STEPS - 1) {
+            for (int d = 3; d <= degrees; d += (d == 5 ? 4 : 2)) {
+                const NsStep& s = step(q, d);
+                int cost;
+                if (converged(s)) cost = ns_step_cost(d, false, true);
+                else {
+                    const NsKey nq = ns_quantise(s.lnew);
+                    if (nq.l <= q.l) continue;            // no progress (cannot happen for l in (0,1))
+                    cost = ns_step_cost(d, false, false) + best_from(nq, depth + 1).cost;
+                }
+                if (cost < b.cost) b = {cost, d};
+            }
+        }
+        togo.emplace(q.key, b);
+        return b;
+    }
+    const NsSeq& plan(double l)
+    {
+        const NsKey q0 = ns_quantise(l);
+        auto it = plans.find(q0.key);
+        if (it != plans.end()) return it->second;
+        if (plans.size() > 4096) { plans.clear(); }
+        NsSeq best;
+        int bd = 3, bc = 1 << 30;
+        for (int d = 3; d <= degrees; d += (d == 5 ? 4 : 2)) {
+            const NsStep& s = step(q0, d);
+            int cost = ns_step_cost(d, true, converged(s));
+            if (!converged(s)) cost += best_from(ns_quantise(s.lnew), 1).cost;
+            if (cost < bc) { bc = cost; bd = d; }
+        }
+        best.cost = bc;
+        NsKey q = q0;
+        int d = bd;
+        for (int i = 0; i < NS_MAX_STEPS; ++i) {
+            const NsStep& s = step(q, d);
+            best.deg[i] = (unsigned char)d;
+            best.st[i] = s;
+            best.n = i + 1;
+            if (converged(s)) break;
+            q = ns_quantise(s.lnew);
+            d = best_from(q, i + 1).d;
+        }
+        return plans.emplace(q0.key, best).first->second;
+    }
+};
+
 static const NsSeq& ns_mixed_schedule(double l, int degrees)
 {
-    static thread_local std::unordered_map<int, NsSeq> cache[2];
-    const double lg = std::log(1.01);
-    int idx = (int)std::floor(std::log(l) / lg);
-    if (idx > -1) idx = -1;                                // l = 1 (W = 0): plan for 0.99
-    auto& cm = cache[degrees == 3 ? 0 : 1];
-    auto it = cm.find(idx);
-    if (it != cm.end()) return it->second;
-    NsSeq cur, best;
-    ns_search(std::exp(idx * lg), 0, 0, cur, best, degrees);
-    if (cm.size() > 4096) cm.clear();
-    return cm.emplace(idx, best).first->second;
+    static thread_local NsPlanner planners[3] = {{3}, {5}, {9}};
+    return planners[degrees >= 9 ? 2 : (degrees >= 5 ? 1 : 0)].plan(l);
 }
 
 int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units)
 {
     if (!(l > 0.0) || !(l <= 1.0)) return -1;
-    const NsSeq& sq = ns_mixed_schedule(l, degrees >= 5 ? 5 : 3);
-    if (sq.n < 1 || sq.n > max_steps) return -1;
+    const NsSeq& sq = ns_mixed_schedule(l, degrees);
+    if (sq.n < 1 || sq.n > max_steps || sq.cost >= (1 << 29)) return -1;
     for (int i = 0; i < sq.n; ++i) {
         deg[i] = sq.deg[i];
-        coef[4 * i] = sq.st[i].t0; coef[4 * i + 1] = sq.st[i].t1; coef[4 * i + 2] = sq.st[i].t2;
-        coef[4 * i + 3] = sq.st[i].lnew;
+        for (int j = 0; j < 5; ++j) coef[6 * i + j] = sq.st[i].t[j];
+        coef[6 * i + 5] = sq.st[i].lnew;
     }
     *units = 2 + sq.cost;
     return sq.n;
@@ -303,6 +467,8 @@ int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* co
 // that is 2-3x tighter than |W|_inf and saves one to two Newton-Schulz steps.  st[k] = {y1a, y1b, z1i, z1a, h}
 // with h = 0.5 sqrt(c) when the start is already the end (one step: Omega = W/2 + h Y1); mode 2 reads
 // {-, z1b, z1i, z1a, -}.
+// degree-nine first step (mode 3):  Y1 <- Q = (1/c^2) B' + (a/c) A',  Z1 <- Q + d I   {qa, qb, d, -, -};
+// T1 = f I + t4 Q (Q + d I) + (e/c) A' and Y1 = A' T1 / c are products.
 __global__ __launch_bounds__(256) void k_ns_start(double* __restrict__ Y1, double* __restrict__ Z1,
                                                   const double* __restrict__ Ap, const double* __restrict__ Bp,
                                                   const double* __restrict__ W, const double* __restrict__ st, int p,
@@ -319,6 +485,12 @@ __global__ __launch_bounds__(256) void k_ns_start(double* __restrict__ Y1, doubl
             const int r = (int)(i / p), c = (int)(i - (size_t)r * p);
             if (mode == 2) {
                 Z1[base + i] = (z1a * a + y1b * b2) + (r == c ? z1i : 0.0);
+                continue;
+            }
+            if (mode == 3) {
+                const double q = y1a * a + y1b * b2;
+                Y1[base + i] = q;
+                Z1[base + i] = q + (r == c ? z1i : 0.0);
                 continue;
             }
             const double y = y1a * a + y1b * b2;
@@ -354,12 +526,13 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
     const double lmin = 1.0 / std::sqrt(kappa);
     plan->stable = stable;
     plan->kappa = kappa;
-    auto put = [&](int g, int k, double cI, double cAcc, double cE) {
+    auto put = [&](int g, int k, double cI, double cAcc, double cE, double dI = 0.0, double dC = 0.0) {
         double* o = coef_h + (size_t)g * NS_SLOT(K) + (size_t)k * 5;
-        o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = 0.0; o[4] = 0.0;
+        o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = dI; o[4] = dC;
     };
     if (!stable) {
-        const NsSeq& sq = ns_mixed_schedule(lmin, degrees >= 5 ? 5 : 3);
+        const NsSeq& sq = ns_mixed_schedule(lmin, degrees);
+        if (sq.n < 1 || sq.cost >= (1 << 29)) return -2;
         const int n = sq.n;
         plan->steps = n;
         plan->units = 2 + sq.cost;
@@ -368,22 +541,34 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
         for (int k = 0; k < K; ++k) {
             const double ck = c[k], sc = std::sqrt(ck);
             double* s = start_h + (size_t)k * 5;
-            const NsStep& s0 = sq.st[0];
+            const double* t = sq.st[0].t;
             g = 0;
             if (sq.deg[0] == 3) {
-                s[0] = s0.t0 / ck; s[1] = s0.t1 / (ck * ck); s[2] = s0.t0; s[3] = s0.t1 / ck; s[4] = 0.5 * sc;
+                s[0] = t[0] / ck; s[1] = t[1] / (ck * ck); s[2] = t[0]; s[3] = t[1] / ck; s[4] = 0.5 * sc;
             } else {
-                s[0] = 0.0; s[1] = s0.t2 / (ck * ck); s[2] = s0.t0; s[3] = s0.t1 / ck; s[4] = 0.0;
+                if (sq.deg[0] == 5) {
+                    s[0] = 0.0; s[1] = t[2] / (ck * ck); s[2] = t[0]; s[3] = t[1] / ck; s[4] = 0.0;
+                } else {
+                    // t(m) = t4 Q (Q + d) + e m + f,  Q = m^2 + a m,  m = A'/c
+                    const double a = t[3] / (2.0 * t[4]), d = t[2] / t[4] - a * a, e = t[1] - t[4] * d * a;
+                    s[0] = a / ck; s[1] = 1.0 / (ck * ck); s[2] = d; s[3] = 0.0; s[4] = 0.0;
+                    put(g++, k, t[0], t[4], e / ck);                  // Z1 = f I + t4 Q (Q + d I) + (e/c) A'
+                }
                 if (n == 1) put(g++, k, 0.0, 0.5 * sc / ck, 0.5);     // Omega = W/2 + sqrt(c)/2 (A'/c) Z1
                 else put(g++, k, 0.0, 1.0 / ck, 0.0);                 // Y1 = (A'/c) Z1
             }
             for (int it = 1; it < n; ++it) {
-                const NsStep& si = sq.st[it];
+                t = sq.st[it].t;
                 if (sq.deg[it] == 3) {
-                    put(g++, k, si.t0, si.t1, 0.0);                  // T = t0 I + t1 (Z Y)
-                } else {
+                    put(g++, k, t[0], t[1], 0.0);                    // T = t0 I + t1 (Z Y)
+                } else if (sq.deg[it] == 5) {
                     put(g++, k, 0.0, 1.0, 0.0);                      // M = Z Y
-                    put(g++, k, si.t0, si.t2, si.t1);                // T = t0 I + t2 (M M) + t1 M
+                    put(g++, k, t[0], t[2], t[1]);                   // T = t0 I + t2 (M M) + t1 M
+                } else {
+                    const double a = t[3] / (2.0 * t[4]), d = t[2] / t[4] - a * a, e = t[1] - t[4] * d * a;
+                    put(g++, k, 0.0, 1.0, 0.0);                      // M = Z Y
+                    put(g++, k, 0.0, 1.0, a, d, 1.0);                // Q = M M + a M;  Q2 = Q + d I
+                    put(g++, k, t[0], t[4], e);                      // T = f I + t4 (Q Q2) + e M
                 }
                 if (it == n - 1) put(g++, k, 0.0, 0.5 * sc, 0.5);    // Omega = W/2 + sqrt(c) (Y T)/2
                 else {
@@ -462,9 +647,16 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
     dim3 grid((unsigned)(((size_t)p * p + 1023) / 1024), K);
     int g = 0;
     double *cur = YP, *nxt = AB;      // cur = [Y | Z]
-    if (plan.deg[0] == 5 && !plan.stable) {
-        // quintic first step: Z1 = T1 elementwise, Y1 = (A'/c) Z1 (or Omega directly when it is the only step)
-        hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, nullptr, YP + n1, AB, AB + n1, W, start_d, p, 2);
+    if (plan.deg[0] >= 5 && !plan.stable) {
+        if (plan.deg[0] == 5) {
+            // quintic first step: Z1 = T1 elementwise
+            hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, nullptr, YP + n1, AB, AB + n1, W, start_d, p, 2);
+        } else {
+            // degree nine: Q -> Tb and Q + d I -> Y slot elementwise, Z1 = T1 = f I + t4 Q (Q + d I) + (e/c) A'
+            hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, Tb, YP, AB, AB + n1, W, start_d, p, 3);
+            launch_symm(st, Tb, YP, YP + n1, nullptr, AB, coef_d + cs * g++, K, p, variant);
+        }
+        // Y1 = (A'/c) Z1 (or Omega directly when it is the only step)
         if (n == 1) {
             launch_symm(st, AB, YP + n1, out, nullptr, W, coef_d + cs * g++, K, p, variant);
             return;
@@ -482,6 +674,12 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
             // M = Z Y into the (free) Y slot of the other pair, then T = t0 I + t1 M + t2 M^2
             launch_symm(st, cur + n1, cur, nxt, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
             launch_symm(st, nxt, nxt, Tb, nullptr, nxt, coef_d + cs * g++, K, p, variant);
+        } else if (plan.deg[it] == 9 && !plan.stable) {
+            // M = Z Y into the output stack (scratch until the last launch), Q and Q + d I into the other pair,
+            // T = f I + t4 Q (Q + d I) + e M
+            launch_symm(st, cur + n1, cur, out, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
+            launch_symm(st, out, out, nxt, nxt + n1, out, coef_d + cs * g++, K, p, variant);
+            launch_symm(st, nxt, nxt + n1, Tb, nullptr, out, coef_d + cs * g++, K, p, variant);
         } else {
             // T = t0 I + t1 (Z Y)   [fast: Z Y = Z^T Y, Z symmetric; stable: P^T Y]
             launch_symm(st, cur + n1, cur, Tb, nullptr, nullptr, coef_d + cs * g++, K, p, variant);

@@ -162,8 +162,9 @@ int ggl_dev_symm_bench(int K, int p, int variant, int iters, double *ms_out);
 /* measured FP64 matrix-core ceiling of this GPU in TFLOP/s (MFMA-only probe kernel) */
 int ggl_dev_mfma_f64_peak(double *tflops_out);
 /* host only (no GPU needed): the Newton-Schulz step schedule the Omega-step would run for a spectrum in [l,1]
- * (x = sqrt(eig(Z Y))).  degrees 3 = cubic steps, 5 = cubic/quintic mix.  deg_out[max_steps] receives 3 or 5
- * per step, coef_out[max_steps*4] = {t0,t1,t2,l_after} of x -> x (t0 + t1 x^2 + t2 x^4), *units_out the number of
+ * (x = sqrt(eig(Z Y))).  degrees 3 = cubic steps, 5 = cubic/quintic mix, 9 = cubic/quintic/degree-nine mix.
+ * deg_out[max_steps] receives 3, 5 or 9 per step, coef_out[max_steps*6] = {t0..t4,l_after} of
+ * x -> x (t0 + t1 x^2 + ... + t4 x^8), *units_out the number of
  * symmetric products of the stack (incl. A' and B').  Returns the number of steps or GGL_E_ARG. */
 int ggl_dev_ns_schedule(double l, int degrees, int max_steps, int *deg_out, double *coef_out, int *units_out);
 /* per-workgroup timestamps {start, loop begin, loop end, end, XCC id} of one launch of the 64x64 kernel */
