@@ -1,6 +1,7 @@
 // HBM-streaming kernels of the ADMM iteration: W formation, SGL Theta-step, dual update,
 // stopping-test norms, small utilities.  grid = (chunks of p*p, K); every block writes its
 // five partial sums to a fixed slot so the reduction order (and the result) is deterministic.
+#include <algorithm>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -216,6 +217,24 @@ void launch_scale_batch(hipStream_t st, double* X, const double* fK, int K, int 
 {
     size_t pp = (size_t)p * p;
     hipLaunchKernelGGL(k_scale_batch, dim3(elementwise_blocks(p), K), dim3(EW_THREADS), 0, st, X, fK, pp);
+}
+
+__global__ __launch_bounds__(256) void k_copy_small(CopySegs sg)
+{
+    const int s = blockIdx.y;
+    if (s >= sg.n) return;
+    unsigned* d = (unsigned*)sg.dst[s];
+    const unsigned* src = (const unsigned*)sg.src[s];
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < sg.words[s]; i += gridDim.x * 256) d[i] = src ? src[i] : 0u;
+}
+
+void launch_copy_small(hipStream_t st, const CopySegs& segs)
+{
+    if (segs.n == 0) return;
+    unsigned mx = 1;
+    for (int i = 0; i < segs.n; ++i) mx = std::max(mx, segs.words[i]);
+    const unsigned bx = std::min((mx + 1023u) / 1024u, 64u);
+    hipLaunchKernelGGL(k_copy_small, dim3(bx, segs.n), dim3(256), 0, st, segs);
 }
 
 void launch_scale(hipStream_t st, double* X, double f, size_t n)

@@ -71,6 +71,8 @@ struct ggl_ctx {
     static constexpr int MAX_PARTS = 4;
     hipStream_t streamx[MAX_PARTS - 1] = {};   // extra streams: the parts of the batch run their
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS - 1] = {};   // Newton-Schulz launch sequences concurrently
+    bool theta_flat = true;                    // GGL Theta-step: per-element kernel when the state is symmetric
+    bool state_symmetric = true;               // X and L exactly symmetric (checked when the state is set)
     int ns_degrees = 9;                        // highest Newton-Schulz step degree: 3, 5 or 9
     int ns_parts = 1;                          // concurrent launch sequences (parts of the batch) wanted
     int* sweeps = nullptr;
@@ -167,6 +169,7 @@ static int ctx_alloc(ggl_ctx* c)
     size_t pl = (size_t)c->K * elementwise_blocks(c->p) * GGL_NNORM;
     pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_GGL, c->K) * GGL_NNORM);
     pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_FGL, c->K) * GGL_NNORM);
+    pl = std::max(pl, (size_t)theta_partial_blocks(c->p, GGL_REG_GGL, c->K, 1) * GGL_NNORM);
     c->partials_len = pl;
     HIPCHK(hipMalloc(&c->partials, pl * sizeof(double)));
     HIPCHK(hipMalloc(&c->norms, (size_t)c->K * 8 * sizeof(double)));
@@ -224,6 +227,7 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
     if (const char* v = getenv("GGL_NS_MODE")) c->ns_force = atoi(v);   // 1 symmetric, 2 stable (testing)
     if (const char* v = getenv("GGL_ROCSOLVER_SYEVJ")) c->use_syevj = atoi(v) != 0;
     c->ns_parts = 2;
+    if (const char* v = getenv("GGL_THETA_FLAT")) c->theta_flat = atoi(v) != 0;
     if (const char* v = getenv("GGL_NS_DEGREES")) c->ns_degrees = atoi(v) >= 9 ? 9 : (atoi(v) >= 5 ? 5 : 3);
     if (const char* v = getenv("GGL_TWO_STREAM")) c->ns_parts = std::min(std::max(atoi(v), 1), (int)ggl_ctx::MAX_PARTS);
     c->n = (size_t)K * p * p;
@@ -315,6 +319,8 @@ extern "C" int ggl_set_S(ggl_ctx* c, const double* S)
     return GGL_OK;
 }
 
+static int host_reduce(ggl_ctx* c, int rows, int nv, double* out /*nv*/, bool take_max);
+
 extern "C" int ggl_set_state(ggl_ctx* c, const double* Omega, const double* Theta, const double* L, const double* X)
 {
     ARGCHK(c, "ctx");
@@ -326,6 +332,18 @@ extern "C" int ggl_set_state(ggl_ctx* c, const double* Omega, const double* Thet
     else HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
     if (X) HIPCHK(hipMemcpyAsync(c->X, X, nb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    // exact symmetry of the dual and latent stacks decides whether the per-element Theta-step may be used
+    c->state_symmetric = true;
+    const double* chk[2] = {X ? c->X : nullptr, L ? c->L : nullptr};
+    for (int i = 0; i < 2; ++i) {
+        if (!chk[i]) continue;
+        launch_asym_max(c->stream, chk[i], c->K, c->p, c->norms);
+        HIPCHK(hipGetLastError());
+        double asym = 0.0;
+        int rc = host_reduce(c, c->K, 1, &asym, true);
+        if (rc) return rc;
+        if (!(asym == 0.0)) c->state_symmetric = false;
+    }
     return GGL_OK;
 }
 
@@ -421,19 +439,28 @@ static int check_info(ggl_ctx* c, const char* what)
     return GGL_OK;
 }
 
-static int upload_par(ggl_ctx* c, int slot, const double* vals, double scalar, double div)
+// Small host<->device transfers of the iteration go through launch_copy_small (pinned host memory is
+// device-visible): an ordinary kernel in the stream instead of a blit with its queue barriers.
+static int upload_par(ggl_ctx* c, int slot, const double* vals, double scalar, double div, CopySegs* pending = nullptr)
 {
-    // par[slot][k] = (vals ? vals[k] : scalar) / div
+    // par[slot][k] = (vals ? vals[k] : scalar) / div;  pending: append to a transfer the caller launches
     double* h = c->par_h + (size_t)slot * c->K;
     for (int k = 0; k < c->K; ++k) h[k] = (vals ? vals[k] : scalar) / div;
-    HIPCHK(hipMemcpyAsync(c->par + (size_t)slot * c->K, h, c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (pending) {
+        pending->add(c->par + (size_t)slot * c->K, h, c->K * sizeof(double));
+        return GGL_OK;
+    }
+    CopySegs sg;
+    sg.add(c->par + (size_t)slot * c->K, h, c->K * sizeof(double));
+    launch_copy_small(c->stream, sg);
+    HIPCHK(hipGetLastError());
     return GGL_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // the iteration
 // ---------------------------------------------------------------------------------------------
-static int omega_step(ggl_ctx* c, int latent);
+static int omega_step(ggl_ctx* c, int latent, CopySegs* pending = nullptr);
 
 extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* nk)
 {
@@ -441,23 +468,22 @@ extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* 
     ARGCHK(rho > 0, "rho must be positive");
     HIPCHK(hipSetDevice(c->device));
     // the previous step's pinned parameters are consumed: every step ends with a stream sync
-    int rc = upload_par(c, 0, nk, 1.0, rho);   // beta_k = nk/rho    (admm_solver.py:180,184)
+    CopySegs sg;
+    int rc = upload_par(c, 0, nk, 1.0, rho, &sg);   // beta_k = nk/rho    (admm_solver.py:180,184)
     if (rc) return rc;
-    return omega_step(c, latent);
+    return omega_step(c, latent, &sg);
 }
 
-// Omega-step with beta_k already in parameter slot 0
-static int omega_step(ggl_ctx* c, int latent)
+// Omega-step with beta_k in parameter slot 0 (already on the device, or part of the pending transfer)
+static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
 {
     int rc;
     const double* beta = c->par;
     const int nxt = c->cur ^ 1;
+    CopySegs first;
+    if (pending) first = *pending;
     if (c->omega_ns) {
         const int K = c->K;
-        PB(c, GGL_PH_FORM_W);
-        launch_form_W_sym(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->rowpart, c->sqpart,
-                          nullptr, K, c->p);
-        PE(c, GGL_PH_FORM_W);
         // phase A: A' = W^2 + 4 beta I, B' = A'^2 (both needed anyway), then the bound from B'
         double* pre = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 2) * NS_SLOT(K);
         for (int k = 0; k < K; ++k) {
@@ -467,18 +493,22 @@ static int omega_step(ggl_ctx* c, int latent)
             o1[0] = 0.0; o1[1] = 1.0; o1[2] = o1[3] = o1[4] = 0.0;
         }
         double* pre_d = c->coef + (size_t)(NS_MAX_LAUNCHES - 2) * NS_SLOT(K);
-        HIPCHK(hipMemcpyAsync(pre_d, pre, 2 * NS_SLOT(K) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        first.add(pre_d, pre, 2 * NS_SLOT(K) * sizeof(double));
+        launch_copy_small(c->stream, first);
+        PB(c, GGL_PH_FORM_W);
+        launch_form_W_sym(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->rowpart, c->sqpart,
+                          nullptr, K, c->p);
+        PE(c, GGL_PH_FORM_W);
         PB(c, GGL_PH_EIG_OMEGA);
         ns_prepare(c->stream, pre_d, c->W, c->nsYP[0], K, c->p, c->symm_variant);
         PE(c, GGL_PH_EIG_OMEGA);
         PB(c, GGL_PH_BOUND);
         const int nbb = norm_bounds_blocks(c->p);
-        launch_norm_bounds(c->stream, c->nsYP[0] + c->n, K, c->p, c->nbpart, c->nbrow);
-        launch_cw_bounds(c->stream, c->nsYP[0] + c->n, c->nbrow, K, c->p, c->nbpart + 2 * (size_t)K * nbb);
+        // the per-block results go straight into the pinned host array (a few KB of posted writes)
+        launch_norm_bounds(c->stream, c->nsYP[0] + c->n, K, c->p, c->nbpart_h, c->nbrow);
+        launch_cw_bounds(c->stream, c->nsYP[0] + c->n, c->nbrow, K, c->p, c->nbpart_h + 2 * (size_t)K * nbb);
         PE(c, GGL_PH_BOUND);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->nbpart_h, c->nbpart, 3 * (size_t)K * nbb * sizeof(double), hipMemcpyDeviceToHost,
-                              c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         for (int k = 0; k < K; ++k) {
             double mx = 0.0, sq = 0.0, cw = 0.0;
@@ -536,13 +566,15 @@ static int omega_step(ggl_ctx* c, int latent)
         const int nrun = (nh > 1 && !any_stable) ? nh : 1;
         if (nrun == 1) { Kh[0] = K; k0h[0] = 0; }
         const size_t pp = (size_t)c->p * c->p;
-        HIPCHK(hipMemcpyAsync(start_base_d, start_base_h, (size_t)K * 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        CopySegs up;
+        up.add(start_base_d, start_base_h, (size_t)K * 5 * sizeof(double));
         for (int h = 0; h < nrun; ++h) {
             const int nb_launch = plans[h].products - 2;     // launches of phase B
             if (nb_launch > 0)
-                HIPCHK(hipMemcpyAsync(c->coef + h * region, c->coef_h + h * region,
-                                      (size_t)nb_launch * NS_SLOT(Kh[h]) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                up.add(c->coef + h * region, c->coef_h + h * region, (size_t)nb_launch * NS_SLOT(Kh[h]) * sizeof(double));
         }
+        up.add(c->info, nullptr, K * sizeof(int));           // no eigensolver ran: info = 0
+        launch_copy_small(c->stream, up);
         PB(c, GGL_PH_EIG_OMEGA2);
         if (nrun > 1) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
@@ -572,10 +604,10 @@ static int omega_step(ggl_ctx* c, int latent)
         c->ns_steps_total = (long long)(c->ns_steps_frac + 0.5);
         c->ns_calls += 1;
         c->dvo_valid = false;
-        HIPCHK(hipMemsetAsync(c->info, 0, K * sizeof(int), c->stream));
         c->cur = nxt;
         return GGL_OK;
     }
+    launch_copy_small(c->stream, first);
     PB(c, GGL_PH_FORM_W);
     launch_form_W(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->K, c->p);
     PE(c, GGL_PH_FORM_W);
@@ -600,9 +632,11 @@ extern "C" int ggl_step_group_partial(ggl_ctx* c, double rho, double lambda1)
 
 static int finish_norms(ggl_ctx* c, int rows, double out_norms[5])
 {
-    HIPCHK(hipMemcpyAsync(c->norms_h, c->norms, (size_t)rows * GGL_NNORM * sizeof(double), hipMemcpyDeviceToHost,
-                          c->stream));
-    HIPCHK(hipMemcpyAsync(c->info_h, c->info, c->K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    CopySegs dn;
+    dn.add(c->norms_h, c->norms, (size_t)rows * GGL_NNORM * sizeof(double));
+    dn.add(c->info_h, c->info, c->K * sizeof(int));
+    launch_copy_small(c->stream, dn);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
     int rc = check_info(c, "ADMM step");
@@ -625,8 +659,8 @@ static int rank_step(ggl_ctx* c)
     if (!c->rank_ns) return eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)K, GGL_PH_EIG_L, GGL_PH_RECON_L);
     PB(c, GGL_PH_EIG_L);
     const int nbb = norm_bounds_blocks(c->p);
-    launch_norm_bounds(c->stream, c->W, K, c->p, c->nbpart);
-    HIPCHK(hipMemcpyAsync(c->nbpart_h, c->nbpart, 2 * (size_t)K * nbb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    launch_norm_bounds(c->stream, c->W, K, c->p, c->nbpart_h);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<double> cn(K);
     for (int k = 0; k < K; ++k) {
@@ -644,14 +678,18 @@ static int rank_step(ggl_ctx* c)
         NsPlan plan;
         if (rank_ns_plan(cn.data(), mu_h, K, l0, c->coef_h, &plan) != 0)
             return fail(GGL_E_SOLVER, "L-step: non-finite C (diverged iterate?)");
-        HIPCHK(hipMemcpyAsync(c->coef, c->coef_h, (size_t)plan.products * NS_SLOT(K) * sizeof(double),
-                              hipMemcpyHostToDevice, c->stream));
+        CopySegs up;
+        up.add(c->coef, c->coef_h, (size_t)plan.products * NS_SLOT(K) * sizeof(double));
+        launch_copy_small(c->stream, up);
         // scratch: Xa = nsYP[0], Xb = nsYP[0] + n, P2 = nsYP[1], T = nsT
         rank_ns_run(c->stream, plan, c->coef, c->W, c->nsYP[0], c->nsYP[0] + c->n, c->nsT, c->nsYP[1], c->L, c->maxdev, K,
                     c->p, c->symm_variant);
         HIPCHK(hipGetLastError());
         c->rank_launches += plan.products;
-        HIPCHK(hipMemcpyAsync(c->maxdev_h, c->maxdev, K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        CopySegs dn;
+        dn.add(c->maxdev_h, c->maxdev, K * sizeof(double));
+        launch_copy_small(c->stream, dn);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
         double dev = 0.0;
         for (int k = 0; k < K; ++k) dev = std::max(dev, c->maxdev_h[k]);
@@ -703,13 +741,16 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
     } else {
         ARGCHK(lambda1 > 0 && lambda2 > 0, "lambda1, lambda2 must be positive");
         PB(c, GGL_PH_THETA);
+        // the flat GGL kernel computes every (i,j) from its own inputs: only for an exactly symmetric state
+        const int flat = (c->theta_flat && c->state_symmetric && !groupsq_ready) ? 1 : 0;
         HIPCHK(launch_theta_pair(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, l1, l2,
                                  groupsq_ready ? c->groupsq : nullptr, c->sqwork, latent ? 0 : 1, c->partials, c->K,
-                                 c->p));
+                                 c->p, flat));
         PE(c, GGL_PH_THETA);
         if (!latent) {
             PB(c, GGL_PH_REDUCE);
-            launch_reduce_partials(c->stream, c->partials, 1, pair_blocks(c->p, reg, c->K), GGL_NNORM, c->norms);
+            launch_reduce_partials(c->stream, c->partials, 1, theta_partial_blocks(c->p, reg, c->K, flat), GGL_NNORM,
+                                   c->norms);
             PE(c, GGL_PH_REDUCE);
             rows = 1;
         }
@@ -756,8 +797,9 @@ extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* l
         h[2 * K + k] = latent ? mu1[k] / rho[k] : 0.0;   // mu1/rho      (:175)
         h[4 * K + k] = ir;
     }
-    HIPCHK(hipMemcpyAsync(c->par, h, 5 * (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    int rc = omega_step(c, latent);
+    CopySegs sg;
+    sg.add(c->par, h, 5 * (size_t)K * sizeof(double));
+    int rc = omega_step(c, latent, &sg);
     if (rc) return rc;
     double* Om = c->Om[c->cur];
     double* OmPrev = c->Om[c->cur ^ 1];
@@ -777,8 +819,11 @@ extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* l
     launch_reduce_partials(c->stream, c->partials, K, elementwise_blocks(c->p), GGL_NNORM, c->norms);
     PE(c, GGL_PH_REDUCE);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->norms_h, c->norms, (size_t)K * GGL_NNORM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->info_h, c->info, K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    CopySegs dn;
+    dn.add(c->norms_h, c->norms, (size_t)K * GGL_NNORM * sizeof(double));
+    dn.add(c->info_h, c->info, K * sizeof(int));
+    launch_copy_small(c->stream, dn);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
     rc = check_info(c, "batched SGL step");
@@ -793,7 +838,9 @@ extern "C" int ggl_scale_X_batch(ggl_ctx* c, const double* factor)
     HIPCHK(hipSetDevice(c->device));
     double* h = c->par_h + 5 * (size_t)c->K;
     memcpy(h, factor, c->K * sizeof(double));
-    HIPCHK(hipMemcpyAsync(c->par + 5 * (size_t)c->K, h, c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CopySegs sg;
+    sg.add(c->par + 5 * (size_t)c->K, h, c->K * sizeof(double));
+    launch_copy_small(c->stream, sg);
     launch_scale_batch(c->stream, c->X, c->par + 5 * (size_t)c->K, c->K, c->p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));   // the pinned slot is reused by the next call

@@ -32,6 +32,18 @@ void launch_dual_update(hipStream_t st, double* X, const double* Omega, const do
 // out[k][v] = sum_b partials[k][b][v]   (fixed order => deterministic)
 void launch_reduce_partials(hipStream_t st, const double* partials, int K, int nblk, int nv, double* out);
 void launch_scale(hipStream_t st, double* X, double f, size_t n);
+// Small transfers between pinned host memory (device-visible) and HBM as an ordinary kernel in the stream:
+// a hipMemcpyAsync of a few KB costs ~15 us of queue idle time around its blit (measured, rocprofv3), this
+// costs a launch.  Up to 6 segments of 32-bit words per launch; src == nullptr zero-fills.
+struct CopySegs {
+    static constexpr int MAX = 6;
+    int n = 0;
+    void* dst[MAX];
+    const void* src[MAX];
+    unsigned words[MAX];
+    void add(void* d, const void* s, size_t bytes) { dst[n] = d; src[n] = s; words[n] = (unsigned)(bytes / 4); ++n; }
+};
+void launch_copy_small(hipStream_t st, const CopySegs& segs);
 // X[k] *= fK[k]
 void launch_scale_batch(hipStream_t st, double* X, const double* fK, int K, int p);
 // out[k] = max_{i,j} |A[k,i,j] - A[k,j,i]|
@@ -52,6 +64,10 @@ void launch_prox_od(hipStream_t st, double* out, const double* A, double lam, co
 
 // ---- theta_pair.hip ---------------------------------------------------------------------
 int pair_blocks(int p, int reg, int K);
+// flat != 0 and K <= GGL_FLAT_MAX_K (GGL only): one thread per element with its K-column in registers; valid for an
+// exactly symmetric state only.  theta_partial_blocks: norms partial rows written by launch_theta_pair.
+static constexpr int GGL_FLAT_MAX_K = 32;
+int theta_partial_blocks(int p, int reg, int K, int flat);
 // GGL/FGL Theta-step on upper-triangle K-vectors (prox_p, ggl_helper.py:190-207), mirrored.
 //   fuse_dual != 0 (non-latent): also X += Omega - Theta and norms partials [K][nblk][5].
 //   fuse_dual == 0 (latent): writes Theta and C = (Theta - X) - Omega  (admm_solver.py:198).
@@ -61,7 +77,7 @@ int pair_blocks(int p, int reg, int K);
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C,
                              const double* Omega, const double* OmegaPrev, const double* L,
                              double l1, double l2, const double* groupsq, double* sqwork, int fuse_dual,
-                             double* partials, int K, int p);
+                             double* partials, int K, int p, int flat = 0);
 // number of K-chunks the GGL kernels split the stack into (grid.y)
 int ggl_chunks(int K, int p);
 // GGL pass 1 only: sq[c](p,p)[i<j] = sum_{k in chunk c} soft(Omega+L+X, l1)^2,  c < ggl_chunks(K,p)

@@ -41,6 +41,14 @@ int pval_blocks(int p)
     return T * (T + 1) / 2;
 }
 
+static inline int flat_blocks(int p) { return (int)(((size_t)p * p + 255) / 256); }
+
+int theta_partial_blocks(int p, int reg, int K, int flat)
+{
+    if (reg == 1 && flat && K <= GGL_FLAT_MAX_K) return flat_blocks(p);
+    return pair_blocks(p, reg, K);
+}
+
 int pair_blocks(int p, int reg, int K)
 {
     if (reg == 2) {
@@ -454,10 +462,108 @@ static hipError_t launch_fgl_td(hipStream_t st, double* Theta, double* X, double
     return hipGetLastError();
 }
 
+// GGL with the whole K-column of an element in registers (K <= GGL_FLAT_MAX_K): one thread per (i,j), all k.
+// Plain streaming -- no tile pairs, no LDS, no second pass over Omega and X for the group norm: the element's
+// soft-thresholded values are summed, scaled and written in one go.  Every (i,j) is computed from its OWN
+// inputs, which equals the reference's "upper triangle, then mirror" (ggl_helper.py:191-208) only for an
+// exactly symmetric state; the caller enables this path only then (the ADMM state is, by construction).
+template <int KMAX, bool FUSE_DUAL>
+__global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ Theta, double* __restrict__ X,
+                                                        double* __restrict__ C, const double* __restrict__ Omega,
+                                                        const double* __restrict__ OmegaPrev,
+                                                        const double* __restrict__ L, double l1, double l2,
+                                                        double* __restrict__ partials, int K, int p)
+{
+    __shared__ double scratch[GGL_NNORM * 4];
+    const size_t pp = (size_t)p * p;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
+    if (e < pp) {
+        const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
+        const bool offd = (i != j);
+        double om[KMAX], x[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) {
+                om[k] = Omega[(size_t)k * pp + e];
+                x[k] = X ? X[(size_t)k * pp + e] : 0.0;
+            }
+        }
+        double ss = 0.0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) {
+                const double l = L ? L[(size_t)k * pp + e] : 0.0;
+                const double u = soft((om[k] + l) + x[k], l1);
+                ss += u * u;
+            }
+        }
+        const double a = fmax(sqrt(ss), l2);
+        const double amul = a - l2;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) {
+                const size_t o = (size_t)k * pp + e;
+                const double l = L ? L[o] : 0.0;
+                const double v = (om[k] + l) + x[k];
+                const double th = offd ? soft(v, l1) * amul / a : v;
+                Theta[o] = th;
+                if (FUSE_DUAL) {
+                    const double xn = x[k] + (om[k] - th);
+                    X[o] = xn;
+                    const double dp = om[k] - OmegaPrev[o];
+                    acc[0] += om[k] * om[k];
+                    acc[1] += th * th;
+                    acc[2] += xn * xn;
+                    acc[3] += (om[k] - th) * (om[k] - th);
+                    acc[4] += dp * dp;
+                } else if (C) {
+                    C[o] = (th - x[k]) - om[k];
+                }
+            }
+        }
+    }
+    if (FUSE_DUAL) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+        for (int v = 0; v < GGL_NNORM; ++v) acc[v] = wave_sum(acc[v]);
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) scratch[wid * GGL_NNORM + v] = acc[v];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double* o = partials + (size_t)blockIdx.x * GGL_NNORM;
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v)
+                o[v] = (scratch[v] + scratch[GGL_NNORM + v]) + (scratch[2 * GGL_NNORM + v] + scratch[3 * GGL_NNORM + v]);
+        }
+    }
+}
+
+template <int KMAX>
+static void launch_flat(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
+                        const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual, double* partials,
+                        int K, int p)
+{
+    dim3 grid(flat_blocks(p)), blk(256);
+    if (fuse_dual)
+        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p);
+    else
+        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p);
+}
+
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C, const double* Omega,
                              const double* OmegaPrev, const double* L, double l1, double l2,
-                             const double* groupsq, double* sqwork, int fuse_dual, double* partials, int K, int p)
+                             const double* groupsq, double* sqwork, int fuse_dual, double* partials, int K, int p,
+                             int flat)
 {
+    if (reg == 1 && flat && !groupsq && K <= GGL_FLAT_MAX_K) {
+        if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p);
+        else if (K <= 16) launch_flat<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p);
+        else launch_flat<32>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p);
+        return hipGetLastError();
+    }
     if (reg == 1) {
         const int T = ntiles(p, PT);
         const int kc = ggl_chunks(K, p), klen = ggl_chunk_len(K, p);
