@@ -499,29 +499,6 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
         launch_form_W_sym(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->rowpart, c->sqpart,
                           nullptr, K, c->p);
         PE(c, GGL_PH_FORM_W);
-        PB(c, GGL_PH_EIG_OMEGA);
-        ns_prepare(c->stream, pre_d, c->W, c->nsYP[0], K, c->p, c->symm_variant);
-        PE(c, GGL_PH_EIG_OMEGA);
-        PB(c, GGL_PH_BOUND);
-        const int nbb = norm_bounds_blocks(c->p);
-        // the per-block results go straight into the pinned host array (a few KB of posted writes)
-        launch_norm_bounds(c->stream, c->nsYP[0] + c->n, K, c->p, c->nbpart_h, c->nbrow);
-        launch_cw_bounds(c->stream, c->nsYP[0] + c->n, c->nbrow, K, c->p, c->nbpart_h + 2 * (size_t)K * nbb);
-        PE(c, GGL_PH_BOUND);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
-        for (int k = 0; k < K; ++k) {
-            double mx = 0.0, sq = 0.0, cw = 0.0;
-            for (int b2 = 0; b2 < nbb; ++b2) {
-                mx = std::max(mx, c->nbpart_h[2 * ((size_t)k * nbb + b2)]);
-                sq += c->nbpart_h[2 * ((size_t)k * nbb + b2) + 1];
-                cw = std::max(cw, c->nbpart_h[2 * (size_t)K * nbb + (size_t)k * nbb + b2]);
-            }
-            // lambda_max(A')^2 = lambda_max(B') <= min(|B'|_inf, |B'|_F, Collatz-Wielandt ratio); the ratio is
-            // computed in floating point from ~p terms, hence the small inflation
-            if (std::isfinite(cw) && cw > 0.0) mx = std::min(mx, cw * (1.0 + 1e-12));
-            c->bounds_h[k] = std::sqrt(std::min(mx, std::sqrt(sq)));
-        }
         // Two halves of the batch on two streams: while one half's product drains its output and the next
         // launch ramps up, the other half keeps the matrix cores busy (a single launch sequence leaves them idle
         // for ~20 % of every product at p = 500).  Each half gets its own schedule.
@@ -536,6 +513,45 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
             Kh[h] = K / nh + (h < K % nh ? 1 : 0);
             k0h[h] = k0;
             k0 += Kh[h];
+        }
+        const size_t pp = (size_t)c->p * c->p;
+        const int nbb = norm_bounds_blocks(c->p);
+        const int var_parts = (c->symm_variant < 0 && nh > 1) ? 16 : c->symm_variant;
+        PB(c, GGL_PH_EIG_OMEGA);
+        if (nh > 1) {
+            HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+            for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
+        }
+        for (int h = 0; h < nh; ++h) {
+            hipStream_t sh = h == 0 ? c->stream : c->streamx[h - 1];
+            const int k0 = k0h[h];
+            double* Ap = c->nsYP[0] + k0 * pp;
+            double* Bp = c->nsYP[0] + c->n + k0 * pp;
+            ns_prepare(sh, pre_d + 5 * (size_t)k0, pre_d + NS_SLOT(K) + 5 * (size_t)k0, c->W + k0 * pp, Ap, Bp, Kh[h], c->p,
+                       var_parts);
+            // bounds of B' (the per-block results go straight into the pinned host array: a few KB of posted writes)
+            launch_norm_bounds(sh, Bp, Kh[h], c->p, c->nbpart_h + 2 * (size_t)k0 * nbb, c->nbrow + (size_t)k0 * c->p);
+            launch_cw_bounds(sh, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p,
+                             c->nbpart_h + 2 * (size_t)K * nbb + (size_t)k0 * nbb);
+        }
+        for (int h = 1; h < nh; ++h) {
+            HIPCHK(hipEventRecord(c->ev_join[h - 1], c->streamx[h - 1]));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
+        }
+        PE(c, GGL_PH_EIG_OMEGA);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < K; ++k) {
+            double mx = 0.0, sq = 0.0, cw = 0.0;
+            for (int b2 = 0; b2 < nbb; ++b2) {
+                mx = std::max(mx, c->nbpart_h[2 * ((size_t)k * nbb + b2)]);
+                sq += c->nbpart_h[2 * ((size_t)k * nbb + b2) + 1];
+                cw = std::max(cw, c->nbpart_h[2 * (size_t)K * nbb + (size_t)k * nbb + b2]);
+            }
+            // lambda_max(A')^2 = lambda_max(B') <= min(|B'|_inf, |B'|_F, Collatz-Wielandt ratio); the ratio is
+            // computed in floating point from ~p terms, hence the small inflation
+            if (std::isfinite(cw) && cw > 0.0) mx = std::min(mx, cw * (1.0 + 1e-12));
+            c->bounds_h[k] = std::sqrt(std::min(mx, std::sqrt(sq)));
         }
         const size_t region = (size_t)(NS_MAX_LAUNCHES - 4) / nh * NS_SLOT(K);      // coefficient slots per part
         NsPlan plans[ggl_ctx::MAX_PARTS];
@@ -565,7 +581,6 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
         }
         const int nrun = (nh > 1 && !any_stable) ? nh : 1;
         if (nrun == 1) { Kh[0] = K; k0h[0] = 0; }
-        const size_t pp = (size_t)c->p * c->p;
         CopySegs up;
         up.add(start_base_d, start_base_h, (size_t)K * 5 * sizeof(double));
         for (int h = 0; h < nrun; ++h) {
@@ -680,10 +695,31 @@ static int rank_step(ggl_ctx* c)
             return fail(GGL_E_SOLVER, "L-step: non-finite C (diverged iterate?)");
         CopySegs up;
         up.add(c->coef, c->coef_h, (size_t)plan.products * NS_SLOT(K) * sizeof(double));
+        up.add(c->maxdev, nullptr, K * sizeof(double));
         launch_copy_small(c->stream, up);
-        // scratch: Xa = nsYP[0], Xb = nsYP[0] + n, P2 = nsYP[1], T = nsT
-        rank_ns_run(c->stream, plan, c->coef, c->W, c->nsYP[0], c->nsYP[0] + c->n, c->nsT, c->nsYP[1], c->L, c->maxdev, K,
-                    c->p, c->symm_variant);
+        // the parts of the batch run their launch sequences concurrently, as in the Omega-step
+        const long t64 = (c->p + 63) / 64;
+        const long ntile = t64 * (t64 + 1) / 2 * K;
+        int nh = (K >= 16 && ntile >= 600 && ntile <= 2048) ? std::min(c->ns_parts, K / 8) : 1;
+        nh = std::max(nh, 1);
+        const size_t pp = (size_t)c->p * c->p;
+        if (nh > 1) {
+            HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+            for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
+        }
+        for (int h = 0, k0 = 0; h < nh; ++h) {
+            const int Kr = K / nh + (h < K % nh ? 1 : 0);
+            // scratch: Xa = nsYP[0], Xb = nsYP[0] + n, P2 = nsYP[1], T = nsT
+            rank_ns_run(h == 0 ? c->stream : c->streamx[h - 1], plan, c->coef + 5 * (size_t)k0, c->W + k0 * pp,
+                        c->nsYP[0] + k0 * pp, c->nsYP[0] + c->n + k0 * pp, c->nsT + k0 * pp, c->nsYP[1] + k0 * pp,
+                        c->L + k0 * pp, c->maxdev + k0, Kr, c->p, (c->symm_variant < 0 && nh > 1) ? 16 : c->symm_variant,
+                        NS_SLOT(K));
+            k0 += Kr;
+        }
+        for (int h = 1; h < nh; ++h) {
+            HIPCHK(hipEventRecord(c->ev_join[h - 1], c->streamx[h - 1]));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
+        }
         HIPCHK(hipGetLastError());
         c->rank_launches += plan.products;
         CopySegs dn;

@@ -166,7 +166,8 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
             int force_mode, int degrees = 9);
 // the schedule alone (host): returns steps, fills deg[max_steps], coef[max_steps*6] = {t0..t4,l_after}
 int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units);
-void ns_prepare(hipStream_t st, const double* pre_d, const double* W, double* AB, int K, int p, int variant);
+void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, const double* W, double* Ap, double* Bp,
+                int K, int p, int variant);
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
             double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride = 0);
 
@@ -178,6 +179,6 @@ void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* p
 void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int K, int p, double* part);
 int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan);
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
-                 double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant);
+                 double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot = 0);
 
 }  // namespace ggl

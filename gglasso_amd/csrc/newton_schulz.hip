@@ -619,13 +619,13 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
     return 0;
 }
 
-// Phase A (before the bound is known): A' = W^2 + 4 beta I -> AB.Y, B' = A'^2 -> AB.Z.
-// pre_d: two coefficient slots {4 beta, 1, 0, 0, 0} and {0, 1, 0, 0, 0} per instance.
-void ns_prepare(hipStream_t st, const double* pre_d, const double* W, double* AB, int K, int p, int variant)
+// Phase A (before the bound is known): A' = W^2 + 4 beta I -> Ap, B' = A'^2 -> Bp.
+// pre0_d / pre1_d: the coefficient rows {4 beta, 1, 0, 0, 0} and {0, 1, 0, 0, 0} of the K instances.
+void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, const double* W, double* Ap, double* Bp, int K,
+                int p, int variant)
 {
-    const size_t cs = NS_SLOT(K), n1 = (size_t)K * p * p;
-    launch_symm(st, W, W, AB, nullptr, nullptr, pre_d, K, p, variant);
-    launch_symm(st, AB, AB, AB + n1, nullptr, nullptr, pre_d + cs, K, p, variant);
+    launch_symm(st, W, W, Ap, nullptr, nullptr, pre0_d, K, p, variant);
+    launch_symm(st, Ap, Ap, Bp, nullptr, nullptr, pre1_d, K, p, variant);
 }
 
 // Phase B.  AB = [A' | B'] from ns_prepare (free afterwards), YP = the other [Y | Z] scratch pair, Tb one stack,
@@ -834,13 +834,14 @@ int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, do
 
 // C preserved.  Xa, Xb, Tb, P2: scratch stacks.  maxdev: device [K], receives max|T_last - I|.
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
-                 double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant)
+                 double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot)
 {
-    const size_t cs = NS_SLOT(K);
+    // maxdev must be zero on entry; cslot: doubles between the coefficient slots of successive launches
+    // (0 = NS_SLOT(K); a sub-batch of a larger table passes the table's slot size)
+    const size_t cs = cslot ? cslot : NS_SLOT(K);
     int g = 0;
     const int n = plan.steps;
     double *X = Xa, *Xn = Xb;
-    (void)hipMemsetAsync(maxdev, 0, K * sizeof(double), st);
     launch_symm(st, C, C, Tb, nullptr, C, coef_d + cs * g++, K, p, variant);
     launch_symm(st, C, Tb, X, nullptr, Tb, coef_d + cs * g++, K, p, variant);
     for (int it = 1; it < n; ++it) {

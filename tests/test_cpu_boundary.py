@@ -183,3 +183,44 @@ def test_host_logic_sgl_batch_and_block_sgl(oracle_engine):
     (solm, _) = _quiet(oracle_engine.block_SGL, S, lam, np.eye(S.shape[0]), tol=1e-10, rtol=1e-10,
                        lambda1_mask=g11["mask"])
     assert np.abs(solm["Theta"] - g11["mask_Theta"]).max() <= 1e-9
+
+
+def _ns_schedule(lib, l, degrees):
+    import ctypes
+    deg = (ctypes.c_int * 24)()
+    co = (ctypes.c_double * (24 * 6))()
+    units = ctypes.c_int()
+    n = lib.load().ggl_dev_ns_schedule(float(l), int(degrees), 24, deg, co, ctypes.byref(units))
+    assert n > 0, (l, degrees, n)
+    return list(deg)[:n], np.array(co[:6 * n]).reshape(n, 6), units.value
+
+
+@pytest.mark.parametrize("degrees", [3, 5, 9])
+def test_newton_schulz_schedule_converges_on_its_interval(lib, degrees):
+    """Host logic of the eigendecomposition-free Omega-step (no GPU): composing the planned step polynomials
+    x -> x t(x^2) maps every x in [l,1] to 1 within a few ulps, every step stays inside the interval it
+    promises to the next one, and the product count is what the step costs add up to."""
+    cost = {3: (0, 3, 2), 5: (1, 4, 3), 9: (2, 5, 4)}         # first / middle / last, on top of A', B'
+    for l in np.concatenate([np.geomspace(1e-6, 0.999, 60), 1 - np.geomspace(1e-12, 1e-3, 10), [1.0]]):
+        deg, co, units = _ns_schedule(lib, l, degrees)
+        assert set(deg) <= {3, 5, 9} and max(deg) <= degrees
+        n = len(deg)
+        expect = 2 + sum(cost[d][0] if i == 0 else (cost[d][2] if i == n - 1 else cost[d][1]) for i, d in enumerate(deg))
+        assert units == expect, (l, deg, units, expect)
+        x = np.unique(np.concatenate([np.linspace(l, 1, 20001), np.geomspace(l, 1, 20001)])).astype(np.longdouble)
+        for i in range(n):
+            x2 = x * x
+            x = x * (co[i, 0] + x2 * (co[i, 1] + x2 * (co[i, 2] + x2 * (co[i, 3] + x2 * co[i, 4]))))
+            assert x.min() >= co[i, 5] - 1e-13 and x.max() <= 1 + 1e-13, (l, i, deg)
+        assert float(np.abs(1 - x).max()) < 2e-15, (l, deg)
+
+
+def test_newton_schulz_schedule_higher_degrees_never_cost_more(lib):
+    for l in np.geomspace(1e-4, 0.99, 40):
+        u3 = _ns_schedule(lib, l, 3)[2]
+        u5 = _ns_schedule(lib, l, 5)[2]
+        u9 = _ns_schedule(lib, l, 9)[2]
+        assert u9 <= u5 <= u3, (l, u3, u5, u9)
+    # the headline workload's interval: two degree-nine steps, eight products
+    deg, _, units = _ns_schedule(lib, 0.67, 9)
+    assert deg == [9, 9] and units == 8
