@@ -79,7 +79,7 @@ struct ggl_ctx {
     long long ns_stable_calls = 0;
     double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
     double *bounds = nullptr, *bounds_h = nullptr;   // [K][2]
-    double *rowpart = nullptr, *sqpart = nullptr;    // scratch of the norm bounds (newton_schulz.hip)
+
     double* nbrow = nullptr;                   // [K][p] row abs-sums of B' (Collatz-Wielandt weight vector)
     double *nbpart = nullptr, *nbpart_h = nullptr;   // [K][blocks][2] norm bounds of C (L-step)
     double *maxdev = nullptr, *maxdev_h = nullptr;   // [K] residual of the sign iteration
@@ -187,9 +187,6 @@ static int ctx_alloc(ggl_ctx* c)
         const size_t bl = 2 * (size_t)c->K * sizeof(double);
         HIPCHK(hipMalloc(&c->bounds, bl));
         HIPCHK(hipHostMalloc(&c->bounds_h, bl));
-        const int Tf = form_W_tiles(c->p);
-        HIPCHK(hipMalloc(&c->rowpart, (size_t)c->K * Tf * c->p * sizeof(double)));
-        HIPCHK(hipMalloc(&c->sqpart, (size_t)c->K * (Tf * (Tf + 1) / 2) * sizeof(double)));
         const size_t nbl = 3 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);   // + Collatz-Wielandt maxima
         HIPCHK(hipMalloc(&c->nbrow, (size_t)c->K * c->p * sizeof(double)));
         HIPCHK(hipMalloc(&c->nbpart, nbl));
@@ -259,7 +256,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
-                      c->nsT, c->coef, c->bounds, c->sqwork, c->rowpart, c->sqpart, c->nbpart, c->maxdev, c->nbrow};
+                      c->nsT, c->coef, c->bounds, c->sqwork, c->nbpart, c->maxdev, c->nbrow};
     if (c->nbpart_h) (void)hipHostFree(c->nbpart_h);
     if (c->maxdev_h) (void)hipHostFree(c->maxdev_h);
     if (c->coef_h) (void)hipHostFree(c->coef_h);
@@ -493,18 +490,15 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
             o1[0] = 0.0; o1[1] = 1.0; o1[2] = o1[3] = o1[4] = 0.0;
         }
         double* pre_d = c->coef + (size_t)(NS_MAX_LAUNCHES - 2) * NS_SLOT(K);
-        first.add(pre_d, pre, 2 * NS_SLOT(K) * sizeof(double));
-        launch_copy_small(c->stream, first);
-        PB(c, GGL_PH_FORM_W);
-        launch_form_W_sym(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->rowpart, c->sqpart,
-                          nullptr, K, c->p);
-        PE(c, GGL_PH_FORM_W);
-        // Two halves of the batch on two streams: while one half's product drains its output and the next
-        // launch ramps up, the other half keeps the matrix cores busy (a single launch sequence leaves them idle
-        // for ~20 % of every product at p = 500).  Each half gets its own schedule.
-        // (measured: +2.6 % at K=32,p=500; -2 % at p=1000 where several rounds of tiles already overlap)
+        // Parts of the batch on concurrent streams: while one part's product drains its output and the next
+        // launch ramps up, the other part keeps the matrix cores busy (a single launch sequence leaves them idle
+        // for ~20 % of every product at p = 500).  Each part gets its own schedule.
+        // (measured: +9 % at K=32,p=500; -2 % at p=1000 where several rounds of tiles already overlap;
+        //  -12 % at K=20,p=200 where the launches are too small to split)
+        // Every part runs its WHOLE chain (parameters, W, A', B', bound | schedule, products) on its own stream:
+        // cross-stream event waits cost ~15 us of queue idle time each (rocprofv3 kernel trace), so there is one
+        // fork at the very start, when the streams are idle anyway, and one join at the end.
         const long t64 = (c->p + 63) / 64;
-        // and -12 % at K=20,p=200 where the launches are too small to split)
         const long ntile = t64 * (t64 + 1) / 2 * K;
         int nh = (K >= 16 && ntile >= 600 && ntile <= 2048) ? std::min(c->ns_parts, K / 8) : 1;
         nh = std::max(nh, 1);
@@ -517,7 +511,6 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
         const size_t pp = (size_t)c->p * c->p;
         const int nbb = norm_bounds_blocks(c->p);
         const int var_parts = (c->symm_variant < 0 && nh > 1) ? 16 : c->symm_variant;
-        PB(c, GGL_PH_EIG_OMEGA);
         if (nh > 1) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
             for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
@@ -525,34 +518,30 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
         for (int h = 0; h < nh; ++h) {
             hipStream_t sh = h == 0 ? c->stream : c->streamx[h - 1];
             const int k0 = k0h[h];
+            // the pending parameter transfers are repeated on every part's stream (identical values, a few KB)
+            CopySegs sg = first;
+            sg.add(pre_d + 5 * (size_t)k0, pre + 5 * (size_t)k0, (size_t)Kh[h] * 5 * sizeof(double));
+            sg.add(pre_d + NS_SLOT(K) + 5 * (size_t)k0, pre + NS_SLOT(K) + 5 * (size_t)k0, (size_t)Kh[h] * 5 * sizeof(double));
+            launch_copy_small(sh, sg);
+            if (h == 0) PB(c, GGL_PH_FORM_W);
+            launch_form_W_sym(sh, c->W + k0 * pp, c->Theta + k0 * pp, latent ? c->L + k0 * pp : nullptr, c->X + k0 * pp,
+                              c->S + k0 * pp, beta + k0, nullptr, nullptr, nullptr, Kh[h], c->p);
+            if (h == 0) { PE(c, GGL_PH_FORM_W); PB(c, GGL_PH_EIG_OMEGA); }
             double* Ap = c->nsYP[0] + k0 * pp;
             double* Bp = c->nsYP[0] + c->n + k0 * pp;
             ns_prepare(sh, pre_d + 5 * (size_t)k0, pre_d + NS_SLOT(K) + 5 * (size_t)k0, c->W + k0 * pp, Ap, Bp, Kh[h], c->p,
                        var_parts);
-            // bounds of B' (the per-block results go straight into the pinned host array: a few KB of posted writes)
-            launch_norm_bounds(sh, Bp, Kh[h], c->p, c->nbpart_h + 2 * (size_t)k0 * nbb, c->nbrow + (size_t)k0 * c->p);
-            launch_cw_bounds(sh, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p,
-                             c->nbpart_h + 2 * (size_t)K * nbb + (size_t)k0 * nbb);
+            // lambda_max(A')^2 = lambda_max(B') <= min(|B'|_inf, |B'|_F, Collatz-Wielandt ratio), reduced on the
+            // device; only the K_part bounds travel to the (pinned, device-visible) host array
+            double* nb2 = c->nbpart + 2 * (size_t)k0 * nbb;
+            double* nbc = c->nbpart + 2 * (size_t)K * nbb + (size_t)k0 * nbb;
+            launch_norm_bounds(sh, Bp, Kh[h], c->p, nb2, c->nbrow + (size_t)k0 * c->p);
+            launch_cw_bounds(sh, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p, nbc);
+            launch_bound_final(sh, nb2, nbc, nbb, Kh[h], c->bounds_h + k0, 0);
+            if (h == 0) PE(c, GGL_PH_EIG_OMEGA);
         }
-        for (int h = 1; h < nh; ++h) {
-            HIPCHK(hipEventRecord(c->ev_join[h - 1], c->streamx[h - 1]));
-            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
-        }
-        PE(c, GGL_PH_EIG_OMEGA);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
-        for (int k = 0; k < K; ++k) {
-            double mx = 0.0, sq = 0.0, cw = 0.0;
-            for (int b2 = 0; b2 < nbb; ++b2) {
-                mx = std::max(mx, c->nbpart_h[2 * ((size_t)k * nbb + b2)]);
-                sq += c->nbpart_h[2 * ((size_t)k * nbb + b2) + 1];
-                cw = std::max(cw, c->nbpart_h[2 * (size_t)K * nbb + (size_t)k * nbb + b2]);
-            }
-            // lambda_max(A')^2 = lambda_max(B') <= min(|B'|_inf, |B'|_F, Collatz-Wielandt ratio); the ratio is
-            // computed in floating point from ~p terms, hence the small inflation
-            if (std::isfinite(cw) && cw > 0.0) mx = std::min(mx, cw * (1.0 + 1e-12));
-            c->bounds_h[k] = std::sqrt(std::min(mx, std::sqrt(sq)));
-        }
+        for (int h = 0; h < nh; ++h) HIPCHK(hipStreamSynchronize(h == 0 ? c->stream : c->streamx[h - 1]));
         const size_t region = (size_t)(NS_MAX_LAUNCHES - 4) / nh * NS_SLOT(K);      // coefficient slots per part
         NsPlan plans[ggl_ctx::MAX_PARTS];
         double* start_base_h = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
@@ -581,29 +570,24 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
         }
         const int nrun = (nh > 1 && !any_stable) ? nh : 1;
         if (nrun == 1) { Kh[0] = K; k0h[0] = 0; }
-        CopySegs up;
-        up.add(start_base_d, start_base_h, (size_t)K * 5 * sizeof(double));
-        for (int h = 0; h < nrun; ++h) {
-            const int nb_launch = plans[h].products - 2;     // launches of phase B
-            if (nb_launch > 0)
-                up.add(c->coef + h * region, c->coef_h + h * region, (size_t)nb_launch * NS_SLOT(Kh[h]) * sizeof(double));
-        }
-        up.add(c->info, nullptr, K * sizeof(int));           // no eigensolver ran: info = 0
-        launch_copy_small(c->stream, up);
         PB(c, GGL_PH_EIG_OMEGA2);
-        if (nrun > 1) {
-            HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-            for (int h = 1; h < nrun; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
-        }
         for (int h = 0; h < nrun; ++h) {
             const int Kr = Kh[h], k0 = k0h[h];
-            ns_run(h == 0 ? c->stream : c->streamx[h - 1], plans[h], c->coef + h * region, start_base_d + 5 * k0,
+            hipStream_t sh = h == 0 ? c->stream : c->streamx[h - 1];
+            CopySegs up;
+            up.add(start_base_d + 5 * (size_t)k0, start_base_h + 5 * (size_t)k0, (size_t)Kr * 5 * sizeof(double));
+            const int nb_launch = plans[h].products - 2;     // launches of phase B
+            if (nb_launch > 0)
+                up.add(c->coef + h * region, c->coef_h + h * region, (size_t)nb_launch * NS_SLOT(Kr) * sizeof(double));
+            if (h == 0) up.add(c->info, nullptr, K * sizeof(int));           // no eigensolver ran: info = 0
+            launch_copy_small(sh, up);
+            ns_run(sh, plans[h], c->coef + h * region, start_base_d + 5 * k0,
                    c->W + k0 * pp, c->nsYP[0] + k0 * pp, c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kr,
                    c->p,
                    // tile choice by the work of the WHOLE batch: the other parts share the chip (measured +6.7 %)
                    (c->symm_variant < 0 && nrun > 1) ? 16 : c->symm_variant, nrun > 1 ? c->n : 0);
             c->ns_stable_calls += plans[h].stable ? 1 : 0;
-            c->ns_launches_total += plans[h].products - (h > 0 ? 2 : 0);   // phase A was one sequence
+            c->ns_launches_total += plans[h].products;
             // algorithmic work in units of (whole-stack) K p^3 flop
             const double frac = (double)Kr / K;
             c->ns_units_frac += frac * plans[h].units;
@@ -674,18 +658,11 @@ static int rank_step(ggl_ctx* c)
     if (!c->rank_ns) return eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)K, GGL_PH_EIG_L, GGL_PH_RECON_L);
     PB(c, GGL_PH_EIG_L);
     const int nbb = norm_bounds_blocks(c->p);
-    launch_norm_bounds(c->stream, c->W, K, c->p, c->nbpart_h);
+    launch_norm_bounds(c->stream, c->W, K, c->p, c->nbpart);
+    launch_bound_final(c->stream, c->nbpart, nullptr, nbb, K, c->bounds_h, 1);     // min(|C|_inf, |C|_F)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
-    std::vector<double> cn(K);
-    for (int k = 0; k < K; ++k) {
-        double mx = 0.0, sq = 0.0;
-        for (int b = 0; b < nbb; ++b) {
-            mx = std::max(mx, c->nbpart_h[2 * ((size_t)k * nbb + b)]);
-            sq += c->nbpart_h[2 * ((size_t)k * nbb + b) + 1];
-        }
-        cn[k] = std::min(mx, std::sqrt(sq));
-    }
+    std::vector<double> cn(c->bounds_h, c->bounds_h + K);
     c->rank_calls += 1;
     double l0 = (c->rank_hold > 0) ? 1e-10 : c->rank_l0;
     if (c->rank_hold > 0) c->rank_hold -= 1;

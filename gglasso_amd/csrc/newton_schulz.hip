@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_form_W_sym(double* __restrict__ W, cons
             rs_nat += __shfl_xor(rs_nat, off, 64);
             rs_mir += __shfl_xor(rs_mir, off, 64);
         }
-        if (tx == 0) {
+        if (tx == 0 && rowpart) {
             double* rp = rowpart + (size_t)k * T * p;
             if (diag) {
                 if (I0 + r < p) rp[(size_t)I * p + I0 + r] = rs_nat + rs_mir;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_form_W_sym(double* __restrict__ W, cons
     const int tid = ty * FT + tx;
     if ((tid & 63) == 0) shsq[tid >> 6] = sq;
     __syncthreads();
-    if (tid == 0) sqpart[(size_t)k * gridDim.x + blockIdx.x] = (shsq[0] + shsq[1]) + (shsq[2] + shsq[3]);
+    if (tid == 0 && sqpart) sqpart[(size_t)k * gridDim.x + blockIdx.x] = (shsq[0] + shsq[1]) + (shsq[2] + shsq[3]);
 }
 
 // bounds[k] = { max_i sum_j |W_ij| , sum_ij W_ij^2 } from the partials above (fixed order)
@@ -791,6 +791,36 @@ __global__ __launch_bounds__(256) void k_cw_bounds(const double* __restrict__ W,
     if (lane == 0) sh[wave] = mx;
     __syncthreads();
     if (threadIdx.x == 0) part[(size_t)k * gridDim.x + blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+// out[k] = sqrt(min(max_b part2[k][b][0], cw bound, sqrt(sum_b part2[k][b][1])))   (mode 0: spectral bound of A' from B')
+//        = min(max_b part2[k][b][0], sqrt(sum_b part2[k][b][1]))                   (mode 1: norm bound of C)
+// `out` may be pinned host memory: K doubles.
+__global__ __launch_bounds__(256) void k_bound_final(const double* __restrict__ part2, const double* __restrict__ cwpart,
+                                                     int nbb, int K, double* __restrict__ out, int mode)
+{
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
+        double mx = 0.0, sq = 0.0, cw = 0.0;
+        for (int b = 0; b < nbb; ++b) {
+            const double m = part2[2 * ((size_t)k * nbb + b)];
+            mx = (mx < m) ? m : mx;
+            sq += part2[2 * ((size_t)k * nbb + b) + 1];
+            if (cwpart) { const double w = cwpart[(size_t)k * nbb + b]; cw = (cw < w) ? w : cw; }
+        }
+        const double fr = sqrt(sq);
+        if (mode == 0) {
+            // the ratio is computed in floating point from ~p terms, hence the small inflation
+            if (cwpart && isfinite(cw) && cw > 0.0) { const double w = cw * (1.0 + 1e-12); mx = (w < mx) ? w : mx; }
+            out[k] = sqrt((fr < mx) ? fr : mx);
+        } else {
+            out[k] = (fr < mx) ? fr : mx;
+        }
+    }
+}
+
+void launch_bound_final(hipStream_t st, const double* part2, const double* cwpart, int nbb, int K, double* out, int mode)
+{
+    hipLaunchKernelGGL(k_bound_final, dim3((K + 255) / 256), dim3(256), 0, st, part2, cwpart, nbb, K, out, mode);
 }
 
 void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int K, int p, double* part)
