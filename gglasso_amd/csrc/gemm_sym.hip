@@ -270,15 +270,32 @@ static void launch_cfg(hipStream_t st, const double* A, const double* B, double*
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt range");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else static_assert(N == 0, "add the immediate");
+}
+
+// BK: k-slab depth (16 or 32); NSTG: slabs resident in LDS (2 = double buffer; more = deeper DMA prefetch)
+template <int BK, int NSTG>
 __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, const double* __restrict__ B,
                                                  double* __restrict__ C, double* __restrict__ C2,
                                                  const double* __restrict__ E, const double* __restrict__ coef, int K,
                                                  int p, const double* __restrict__ A1, const double* __restrict__ B1,
                                                  double* __restrict__ C1, int K1, double* __restrict__ maxdev)
 {
-    constexpr int BM = 64, BK = 16, WM = 32, WN = 32, TI = 2, TJ = 2;
-    constexpr int SLAB = BK * BM;                        // doubles per operand slab (8 KiB)
-    __shared__ __attribute__((aligned(16))) double smem[4 * SLAB];   // [buf][A|B][16][64] = 32 KiB; later the mirror tile
+    constexpr int BM = 64, WM = 32, WN = 32, TI = 2, TJ = 2;
+    constexpr int SLAB = BK * BM;                        // doubles per operand slab (8 KiB at BK = 16)
+    constexpr int IPW = BK / 8;                          // DMA instructions per wave, operand and slab
+    static_assert(NSTG * 2 * SLAB >= BM * BM, "the mirror tile reuses the slab storage");
+    __shared__ __attribute__((aligned(16))) double smem[NSTG * 2 * SLAB];   // [buf][A|B][BK][64]; later the mirror tile
     const int T = (p + BM - 1) / BM;
     int k, b;
     if (!decode_block_xcd(T * (T + 1) / 2, K + K1, k, b)) return;
@@ -308,8 +325,8 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
     const unsigned ca = min((unsigned)I0 + cpos, pm2), cb = min((unsigned)J0 + cpos, pm2);
     auto issue = [&](int m0, int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = wave * 2 + j;
+        for (int j = 0; j < IPW; ++j) {
+            const int i = wave * IPW + j;
             const unsigned ro = min((unsigned)(m0 + 2 * i + lrow), pm1) * pu;
             double* la = smem + (size_t)buf * 2 * SLAB + i * 128;            // wave-uniform LDS base
             double* lb = la + SLAB;
@@ -319,15 +336,21 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
     };
     const bool dead_wave = (I == J) && (wr >= wc + WN);
     const int S = (p + BK - 1) / BK;
-    issue(0, 0);
+#pragma unroll
+    for (int q = 0; q < NSTG - 1; ++q)
+        if (q < S) issue(q * BK, q);
     for (int s = 0; s < S; ++s) {
-        const int buf = s & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA of slab s has landed
+        const int buf = s % NSTG;
+        // this wave's DMA of slab s has landed: at most the later slabs' instructions may still be in flight
+        const int ahead = min(NSTG - 2, S - 1 - s);
+        if (NSTG >= 4 && ahead >= 2) wait_vmcnt<4 * IPW>();
+        else if (NSTG >= 3 && ahead >= 1) wait_vmcnt<2 * IPW>();
+        else wait_vmcnt<0>();
         const int valid = p - s * BK;                          // k-rows of this slab inside the matrix
         if (valid < BK) {
             // zero the rows beyond the matrix (each wave cleans the rows its own DMA wrote)
-            for (int e = lane; e < 4 * 64; e += 64) {
-                const int row = wave * 4 + (e >> 6);
+            for (int e = lane; e < (BK / 4) * 64; e += 64) {
+                const int row = wave * (BK / 4) + (e >> 6);
                 if (row >= valid) {
                     smem[(size_t)buf * 2 * SLAB + row * 64 + (e & 63)] = 0.0;
                     smem[(size_t)buf * 2 * SLAB + SLAB + row * 64 + (e & 63)] = 0.0;
@@ -335,7 +358,7 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
             }
         }
         __syncthreads();                                       // slab s visible to all; slab s-1 fully consumed
-        if (s + 1 < S) issue((s + 1) * BK, buf ^ 1);
+        if (s + NSTG - 1 < S) issue((s + NSTG - 1) * BK, (s + NSTG - 1) % NSTG);
         if (!dead_wave) {
             const double* As = smem + (size_t)buf * 2 * SLAB;
             const double* Bs = As + SLAB;
@@ -407,11 +430,18 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
 
 static void launch_dl(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                       const double* coef, int K, int p, const double* A1, const double* B1, double* C1, int K1,
-                      double* maxdev)
+                      double* maxdev, int dl_cfg = 0)
 {
     const int T = (p + 63) / 64;
-    hipLaunchKernelGGL(k_symm_dl, dim3(xcd_grid(T * (T + 1) / 2, K + K1)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p,
-                       A1, B1, C1, K1, maxdev);
+    const dim3 grid(xcd_grid(T * (T + 1) / 2, K + K1));
+    if (dl_cfg == 1)
+        hipLaunchKernelGGL((k_symm_dl<16, 3>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
+    else if (dl_cfg == 2)
+        hipLaunchKernelGGL((k_symm_dl<16, 4>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
+    else if (dl_cfg == 3)
+        hipLaunchKernelGGL((k_symm_dl<32, 2>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
+    else
+        hipLaunchKernelGGL((k_symm_dl<16, 2>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -625,7 +655,7 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
     }
 }
 
-int symm_variants() { return 17; }
+int symm_variants() { return 20; }   // 17..19: direct-to-LDS with 3 stages, 4 stages, k-slab 32
 
 // Two independent products in one launch: C = coef[k]-affine(A*B) for k < K and C1 = coef[K+k]-scaled(A1*B1).
 void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
@@ -636,8 +666,11 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
         variant = (T64 * (T64 + 1) / 2 * 2 * K <= 800) ? 9 : 16;
     }
     switch (variant) {
-        case 16:
-            if ((p & 1) == 0 && p >= 2) { launch_dl(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K, nullptr); break; }
+        case 16: case 17: case 18: case 19:
+            if ((p & 1) == 0 && p >= 2) {
+                launch_dl(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K, nullptr, variant - 16);
+                break;
+            }
             launch_cfg<64, 16, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K);
             break;
         case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
@@ -664,8 +697,11 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 5: launch_cfg<128, 32, 64, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 16:
-            if ((p & 1) == 0 && p >= 2) { launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break; }
+        case 16: case 17: case 18: case 19:
+            if ((p & 1) == 0 && p >= 2) {
+                launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16);
+                break;
+            }
             launch_cfg<64, 16, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev);
             break;
         case 11: launch_cfg<64, 16, 16, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;

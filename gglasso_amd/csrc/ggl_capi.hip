@@ -510,7 +510,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
         }
         const size_t pp = (size_t)c->p * c->p;
         const int nbb = norm_bounds_blocks(c->p);
-        const int var_parts = (c->symm_variant < 0 && nh > 1) ? 16 : c->symm_variant;
+        const int var_parts = (c->symm_variant < 0 && nh > 1) ? 17 : c->symm_variant;
         if (nh > 1) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
             for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
@@ -584,8 +584,9 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
             ns_run(sh, plans[h], c->coef + h * region, start_base_d + 5 * k0,
                    c->W + k0 * pp, c->nsYP[0] + k0 * pp, c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kr,
                    c->p,
-                   // tile choice by the work of the WHOLE batch: the other parts share the chip (measured +6.7 %)
-                   (c->symm_variant < 0 && nrun > 1) ? 16 : c->symm_variant, nrun > 1 ? c->n : 0);
+                   // tile choice by the work of the WHOLE batch: the other parts share the chip (measured +6.7 %);
+                   // with parts, the 3-stage DMA pipeline is 2.8 % ahead of the double buffer (4 % behind without)
+                   (c->symm_variant < 0 && nrun > 1) ? 17 : c->symm_variant, nrun > 1 ? c->n : 0);
             c->ns_stable_calls += plans[h].stable ? 1 : 0;
             c->ns_launches_total += plans[h].products;
             // algorithmic work in units of (whole-stack) K p^3 flop
@@ -689,7 +690,7 @@ static int rank_step(ggl_ctx* c)
             // scratch: Xa = nsYP[0], Xb = nsYP[0] + n, P2 = nsYP[1], T = nsT
             rank_ns_run(h == 0 ? c->stream : c->streamx[h - 1], plan, c->coef + 5 * (size_t)k0, c->W + k0 * pp,
                         c->nsYP[0] + k0 * pp, c->nsYP[0] + c->n + k0 * pp, c->nsT + k0 * pp, c->nsYP[1] + k0 * pp,
-                        c->L + k0 * pp, c->maxdev + k0, Kr, c->p, (c->symm_variant < 0 && nh > 1) ? 16 : c->symm_variant,
+                        c->L + k0 * pp, c->maxdev + k0, Kr, c->p, (c->symm_variant < 0 && nh > 1) ? 17 : c->symm_variant,
                         NS_SLOT(K));
             k0 += Kr;
         }
