@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ggl_K32_p500", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eig", type=int, default=0, help="GGL_EIG_* selector (0 auto)")
     args = ap.parse_args()

@@ -259,6 +259,29 @@ def test_phiplus_newton_schulz_both_product_modes(ops, mode, monkeypatch):
             assert np.abs(out - ref).max() <= 1e-10 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("degrees", ["3", "5", "9"])
+def test_phiplus_newton_schulz_step_degrees(ops, degrees, monkeypatch):
+    """GGL_NS_DEGREES caps the step degree of the fast schedule (cubic only / + quintic / + degree nine): every
+    mix must reach the eigendecomposition's accuracy over the whole range of condition numbers the fast
+    (all-symmetric) schedule serves, kappa(W^2 + 4 beta I) from 1 to 300."""
+    monkeypatch.setenv("GGL_NS_DEGREES", degrees)
+    rng = np.random.default_rng(17)
+    p, beta = 192, 0.7
+    for kappa in (1.0, 1.5, 4.0, 50.0, 280.0):
+        wmax = np.sqrt(4 * beta * (kappa - 1.0))
+        W = np.empty((3, p, p))
+        for k in range(3):
+            Q, _ = np.linalg.qr(rng.standard_normal((p, p)))
+            w = rng.uniform(-wmax, wmax, p)
+            w[0], w[1] = wmax, -wmax
+            W[k] = (Q * w) @ Q.T
+            W[k] = 0.5 * (W[k] + W[k].T)
+        ref, _ = orc.phiplus_stack(W, beta)
+        out = ops.phiplus_matrix(W, beta, method=3)
+        assert np.abs(out - ref).max() <= 2e-13 * max(1.0, np.abs(ref).max()), (degrees, kappa)
+        assert np.array_equal(out, out.transpose(0, 2, 1))
+
+
 def test_phiplus_newton_schulz_reads_lower_triangle(ops):
     rng = np.random.default_rng(9)
     A = rng.standard_normal((2, 150, 150))                 # NOT symmetric

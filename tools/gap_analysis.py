@@ -10,8 +10,14 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:60]))
 rows.sort()
-# an iteration starts at every k_form_W_sym launch
-starts = [i for i, r in enumerate(rows) if "form_W" in r[2]]
+# an iteration starts at the first k_form_W launch after the previous iteration's norm reduction
+starts, armed = [], True
+for i, r in enumerate(rows):
+    if "form_W" in r[2] and armed:
+        starts.append(i)
+        armed = False
+    elif "reduce_partials" in r[2]:
+        armed = True
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 its = list(zip(starts[skip:-1], starts[skip + 1:]))
 tot = busy = 0.0
