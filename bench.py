@@ -83,6 +83,21 @@ def pmc_traffic(kernel_name):
     return None
 
 
+def rocprof_kernel_avg_ms(kernel_name):
+    """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of this
+    same command (profiles/*_bench_kernel_stats.csv), for comparison with the live figure.  None when absent."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_kernel_stats.csv")))
+    if not files:
+        return None
+    key = kernel_name.split(" ")[0]
+    for row in csv.DictReader(open(files[-1])):
+        if key in row["Name"]:
+            return float(row["AverageNs"]) * 1e-6
+    return None
+
+
 def quiet(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)
@@ -251,9 +266,13 @@ def main():
                          "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": pmc_traffic(kernel_name),
                          "ms_per_launch": phases[dom]["ms_per_launch"],
-                         "note": ("elapsed time of the phase / its kernel launches; at this size the two halves of the "
-                                  "batch run their launch sequences concurrently on two streams, so a single kernel's "
-                                  "own duration (rocprofv3) is up to 2x this figure") if (omega_ns and dom == "eig_omega"
+                         "rocprof_kernel_avg_ms": rocprof_kernel_avg_ms(kernel_name),
+                         "concurrent_launch_sequences": 2 if (omega_ns and dom in ("eig_omega", "eig_L") and Kl >= 16
+                                                              and 600 <= t64 * (t64 + 1) // 2 * Kl <= 2048) else 1,
+                         "note": ("ms_per_launch = elapsed time of the phase / its kernel launches; at this size two parts "
+                                  "of the batch run their launch sequences concurrently on two streams, so a single "
+                                  "kernel's own duration (rocprof_kernel_avg_ms, rocprofv3) is about "
+                                  "concurrent_launch_sequences x ms_per_launch") if (omega_ns and dom == "eig_omega"
                                                                                         and Kl >= 16 and 600 <= t64 * (t64 + 1) // 2 * Kl <= 2048)
                          else "elapsed time of the phase / its kernel launches"},
             "iteration_hbm_roofline": {"algorithmic_bytes": iter_bytes, "achieved_GBs": its * iter_bytes / 1e9,

@@ -48,6 +48,8 @@ _SIGNATURES = {
     "ggl_profile_read": ([_vp, _dp, ctypes.POINTER(ctypes.c_longlong), _i], _i),
     "ggl_dev_symm": ([_i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _i], _i),
     "ggl_dev_symm_bench": ([_i, _i, _i, _i, _dp], _i),
+    "ggl_snapshot_k": ([_vp, _i], _i),
+    "ggl_selection_stats": ([_vp, _dp], _i),
     "ggl_dev_ns_schedule": ([_d, _i, _i, ctypes.POINTER(_i), _dp, ctypes.POINTER(_i)], _i),
     "ggl_dev_mfma_f64_peak": ([_dp], _i),
     "ggl_dev_symm_timeline": ([_i, _i, ctypes.POINTER(ctypes.c_longlong), _i, ctypes.POINTER(_i)], _i),

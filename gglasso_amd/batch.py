@@ -17,14 +17,17 @@ from .solver import as_c, residuals_from_norms, next_rho
 
 
 def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max_iter=1000, tol=1e-7,
-                   rtol=1e-4, update_rho=True, verbose=False, latent=False, mu1=None, lambda1_mask=None):
+                   rtol=1e-4, update_rho=True, verbose=False, latent=False, mu1=None, lambda1_mask=None,
+                   selection_stats=False):
     """Solve ``ADMM_SGL(S, lambda1[k], ...)`` for every k of the 1-D array ``lambda1`` at once.
 
     S: (p,p) shared by all instances, or (K,p,p) with one covariance matrix per instance (what
     ``block_SGL`` needs for equally sized blocks).  Omega_0 / Theta_0 / X_0: (p,p) shared start or (K,p,p) per instance (default identity /
     Omega_0 / zeros, as in single_admm_solver.py:129-137).  mu1: scalar or (K,) when ``latent``.
     Returns a list of K ``(sol, info)`` pairs with the reference's keys; ``info`` additionally carries
-    ``'iterations'`` and the final ``'rho'``."""
+    ``'iterations'`` and the final ``'rho'``.  ``selection_stats``: also keep a device snapshot of every instance's
+    solution's Theta and attach ``info['selection'] = {'Sdot','logdet','nnz','lambda_min'}`` computed on the GPU
+    (what the AIC / eBIC tables of model selection are made of)."""
     S = as_c(S)
     assert S.ndim in (2, 3) and S.shape[-1] == S.shape[-2]
     p = S.shape[-1]
@@ -90,6 +93,8 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
             for k in range(K):
                 if done[k] and results[k] is None:
                     results[k] = (eng.state_k(k, latent), {'status': 'optimal', 'iterations': it + 1, 'rho': rhos[k]})
+                    if selection_stats:
+                        eng.snapshot_k(k)
             if done.all():
                 break
         for k in range(K):
@@ -98,6 +103,13 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                 status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
                                                                 else 'max iterations reached')
                 results[k] = (eng.state_k(k, latent), {'status': status, 'iterations': max_iter, 'rho': rhos[k]})
+                if selection_stats:
+                    eng.snapshot_k(k)
+        if selection_stats:
+            st = eng.selection_stats()
+            for k in range(K):
+                results[k][1]['selection'] = {'Sdot': st[k, 0], 'logdet': st[k, 1], 'nnz': st[k, 2],
+                                              'lambda_min': st[k, 3]}
     finally:
         eng.close()
     return results

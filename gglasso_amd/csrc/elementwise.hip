@@ -297,6 +297,28 @@ __global__ __launch_bounds__(EW_THREADS) void k_dot(const double* __restrict__ A
     if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = acc[0];
 }
 
+// partials[k][b][0] = number of non-zero entries of the chunk (exact: counts are far below 2^53)
+__global__ __launch_bounds__(EW_THREADS) void k_count_nonzero(const double* __restrict__ A, size_t pp,
+                                                              double* __restrict__ partials)
+{
+    __shared__ double scratch[EW_THREADS / 64];
+    const int k = blockIdx.y;
+    const size_t base = (size_t)k * pp;
+    double acc[1] = {0.0};
+    size_t i = (size_t)blockIdx.x * EW_CHUNK + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < EW_EPT; ++e, i += EW_THREADS)
+        if (i < pp && A[base + i] != 0.0) acc[0] += 1.0;
+    block_sum<1>(acc, scratch);
+    if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = acc[0];
+}
+
+void launch_count_nonzero(hipStream_t st, const double* A, int K, int p, double* partials)
+{
+    size_t pp = (size_t)p * p;
+    hipLaunchKernelGGL(k_count_nonzero, dim3(elementwise_blocks(p), K), dim3(EW_THREADS), 0, st, A, pp, partials);
+}
+
 void launch_dot(hipStream_t st, const double* A, const double* B, int K, int p, double* partials)
 {
     size_t pp = (size_t)p * p;

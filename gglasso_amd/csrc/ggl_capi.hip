@@ -80,6 +80,7 @@ struct ggl_ctx {
     double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
     double *bounds = nullptr, *bounds_h = nullptr;   // [K][2]
 
+    double* snapT = nullptr;                   // per-instance snapshots of Theta (model selection), lazy
     double* nbrow = nullptr;                   // [K][p] row abs-sums of B' (Collatz-Wielandt weight vector)
     double *nbpart = nullptr, *nbpart_h = nullptr;   // [K][blocks][2] norm bounds of C (L-step)
     double *maxdev = nullptr, *maxdev_h = nullptr;   // [K] residual of the sign iteration
@@ -256,7 +257,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
-                      c->nsT, c->coef, c->bounds, c->sqwork, c->nbpart, c->maxdev, c->nbrow};
+                      c->nsT, c->coef, c->bounds, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT};
     if (c->nbpart_h) (void)hipHostFree(c->nbpart_h);
     if (c->maxdev_h) (void)hipHostFree(c->maxdev_h);
     if (c->coef_h) (void)hipHostFree(c->coef_h);
@@ -972,6 +973,62 @@ extern "C" int ggl_exit_checks(ggl_ctx* c, int latent, double out[5])
         HIPCHK(hipMemcpyAsync(c->W, c->L, c->n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         rc = min_eig(c, c->W, &out[4]);                  // admm_solver.py:299
         if (rc) return rc;
+    }
+    return GGL_OK;
+}
+
+extern "C" int ggl_snapshot_k(ggl_ctx* c, int k)
+{
+    ARGCHK(c, "ctx");
+    ARGCHK(k >= 0 && k < c->K, "instance index");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t pp = (size_t)c->p * c->p, nb = pp * sizeof(double);
+    if (!c->snapT) {
+        HIPCHK(hipMalloc(&c->snapT, c->n * sizeof(double)));
+        HIPCHK(hipMemsetAsync(c->snapT, 0, c->n * sizeof(double), c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(c->snapT + k * pp, c->Theta + k * pp, nb, hipMemcpyDeviceToDevice, c->stream));
+    return GGL_OK;
+}
+
+extern "C" int ggl_selection_stats(ggl_ctx* c, double* out)
+{
+    ARGCHK(c && out, "ctx, out");
+    ARGCHK(c->snapT, "no snapshot taken (ggl_snapshot_k)");
+    HIPCHK(hipSetDevice(c->device));
+    const int K = c->K, p = c->p;
+    const size_t kp = (size_t)K * p;
+    const int nblk = elementwise_blocks(p);
+    std::vector<double> d(kp), dot(K), nnz(K);
+    // <S_k, Theta_k> and the non-zero count, per instance
+    launch_dot(c->stream, c->snapT, c->S, K, p, c->partials);
+    launch_reduce_partials(c->stream, c->partials, K, nblk, 1, c->norms);
+    HIPCHK(hipMemcpyAsync(dot.data(), c->norms, K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    launch_count_nonzero(c->stream, c->snapT, K, p, c->partials);
+    launch_reduce_partials(c->stream, c->partials, K, nblk, 1, c->norms + K);
+    HIPCHK(hipMemcpyAsync(nnz.data(), c->norms + K, K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipGetLastError());
+    // eigenvalues of Theta_k: log det and the smallest one (robust_logdet, model_selection.py:884-894)
+    HIPCHK(hipMemcpyAsync(c->W, c->snapT, c->n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    int rc = eigvals_only(c, c->W, c->DvO);
+    if (rc) return rc;
+    c->dvo_valid = false;
+    HIPCHK(hipMemcpyAsync(d.data(), c->DvO, kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->info_h, c->info, K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = check_info(c, "selection statistics");
+    if (rc) return rc;
+    for (int k = 0; k < K; ++k) {
+        double mn = INFINITY, ld = 0.0;
+        for (int m = 0; m < p; ++m) {
+            const double v = d[(size_t)k * p + m];
+            mn = std::min(mn, v);
+            ld += std::log(v);
+        }
+        out[k * 4 + 0] = dot[k];
+        out[k * 4 + 1] = (mn <= 1e-12 || !(mn == mn)) ? -INFINITY : ld;
+        out[k * 4 + 2] = nnz[k];
+        out[k * 4 + 3] = mn;
     }
     return GGL_OK;
 }

@@ -48,6 +48,8 @@ void launch_copy_small(hipStream_t st, const CopySegs& segs);
 void launch_scale_batch(hipStream_t st, double* X, const double* fK, int K, int p);
 // out[k] = max_{i,j} |A[k,i,j] - A[k,j,i]|
 void launch_asym_max(hipStream_t st, const double* A, int K, int p, double* out);
+// partials[K][elementwise_blocks(p)]: non-zero entries per chunk of every instance
+void launch_count_nonzero(hipStream_t st, const double* A, int K, int p, double* partials);
 // D = A - B (B may be null)
 void launch_sub(hipStream_t st, double* D, const double* A, const double* B, size_t n);
 // out[k][0] = sum A*B

@@ -94,6 +94,16 @@ class HipEngine:
             sol['L'] = L
         return sol
 
+    def snapshot_k(self, k):
+        check(self.lib.ggl_snapshot_k(self.h, int(k)))
+
+    def selection_stats(self):
+        """(K,4): <S,Theta>, log det Theta (-inf if lambda_min <= 1e-12), count_nonzero(Theta), lambda_min(Theta)
+        of every instance's snapshot."""
+        out = np.zeros((self.K, 4))
+        check(self.lib.ggl_selection_stats(self.h, ptr(out)))
+        return out
+
     def objective(self, lambda1, lambda2, reg):
         out = np.zeros(3)
         check(self.lib.ggl_objective(self.h, lambda1, lambda2, _REG[reg], ptr(out)))

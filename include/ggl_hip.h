@@ -123,6 +123,15 @@ int ggl_scale_X(ggl_ctx *ctx, double factor);
  * max|L-L^T|, min eig(Theta-L), min eig(L)}. */
 int ggl_exit_checks(ggl_ctx *ctx, int latent, double out[5]);
 
+/* Model selection over a batch of independent problems (reference: single_grid_search,
+ * helper/model_selection.py:505-692; criteria :812-856; robust_logdet :884-894).
+ * ggl_snapshot_k keeps a device copy of instance k's Theta at the moment the host loop declares it converged;
+ * ggl_selection_stats then returns, for every instance's snapshot,
+ * out[k*4..] = { <S_k,Theta_k>, log det Theta_k (-inf if lambda_min <= 1e-12), count_nonzero(Theta_k),
+ * lambda_min(Theta_k) }.  (The rank of the latent component is left to the host: numpy's matrix_rank tolerance
+ * p*eps*|L| is below the absolute accuracy of the device eigensolvers.) */
+int ggl_snapshot_k(ggl_ctx *ctx, int k);
+int ggl_selection_stats(ggl_ctx *ctx, double *out);
 /* Objective pieces for measure=True (admm_solver.py:213): out = {sum_k -logdet Omega_k,
  * <Omega,S>, P_val(Theta)} (ggl_helper.py:266-270,162-176). */
 int ggl_objective(ggl_ctx *ctx, double lambda1, double lambda2, int reg, double out[3]);

@@ -95,6 +95,21 @@ class OracleEngine:
             sol['L'] = self.L[k].copy()
         return sol
 
+    def snapshot_k(self, k):
+        if not hasattr(self, "_snapT"):
+            self._snapT = np.zeros_like(self.Th)
+        self._snapT[k] = self.Th[k]
+
+    def selection_stats(self):
+        K = self.Th.shape[0]
+        out = np.zeros((K, 4))
+        for k in range(K):
+            T = self._snapT[k]
+            d = np.linalg.eigvalsh(T)
+            out[k] = [np.sum(self.S[k] * T), -np.inf if d.min() <= 1e-12 else np.linalg.slogdet(T)[1],
+                      np.count_nonzero(T), d.min()]
+        return out
+
     def objective(self, lambda1, lambda2, reg):
         ld = -np.log(orc.phip(self.D, self.beta[:, None])).sum()
         return np.array([ld, np.sum(self.Om * self.S), orc.P_val(self.Th, lambda1, lambda2, reg)])

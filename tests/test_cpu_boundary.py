@@ -224,3 +224,34 @@ def test_newton_schulz_schedule_higher_degrees_never_cost_more(lib):
     # the headline workload's interval: two degree-nine steps, eight products
     deg, _, units = _ns_schedule(lib, 0.67, 9)
     assert deg == [9, 9] and units == 8
+
+
+def test_batched_single_grid_search_matches_reference_tables(oracle_engine):
+    """the whole (lambda1[, mu1]) grid as one batch reproduces the AIC / eBIC / sparsity / rank
+    tables, the selected point and the selected Theta of the reference's sequential single_grid_search
+    (fixture G12, generated from the real reference).  Array work: test-only oracle engine."""
+    from grid_checks import check_single_grid_search
+    check_single_grid_search(load_golden)
+
+
+def test_selection_criteria_definitions():
+    from gglasso_amd import model_selection as ms
+    rng = np.random.default_rng(3)
+    p, N = 12, 80
+    A = rng.standard_normal((p, 3 * p))
+    S = A @ A.T / (3 * p)
+    Th = np.linalg.inv(S + 0.5 * np.eye(p))
+    Th[np.abs(Th) < 0.05] = 0.0
+    Th = 0.5 * (Th + Th.T)
+    E = (np.count_nonzero(Th) - p) / 2
+    fit = N * np.sum(S * Th) - N * np.linalg.slogdet(Th)[1]
+    assert np.isclose(ms.aic_single(S, Th, N), fit + E)
+    assert np.isclose(ms.ebic_single(S, Th, N, 0.3), fit + E * (np.log(N) + 4 * np.log(p) * 0.3))
+    mask = np.ones((p, p)); mask[:3] = mask[:, :3] = 0.25
+    Em = (((Th != 0) * mask).sum() - np.trace((Th != 0) * mask)) / 2
+    assert np.isclose(ms.ebic_single(S, Th, N, 0.5, lambda1_mask=mask), fit + Em * (np.log(N) + 4 * np.log(p) * 0.5))
+    assert ms.robust_logdet(np.diag([1.0, 1e-13])) == -np.inf
+    assert np.isclose(ms.sparsity(Th), 2 * E / (p * p - p))
+    S3, T3 = np.stack([S, S]), np.stack([Th, Th])
+    assert np.isclose(ms.aic(S3, T3, N), 2 * ms.aic_single(S, Th, N))
+    assert np.isclose(ms.ebic(S3, T3, np.array([N, N]), 0.1), 2 * ms.ebic_single(S, Th, N, 0.1))

@@ -137,6 +137,34 @@ def test_oracle_trajectory_mid_sizes(sol, reg, K, p, latent):
     assert np.linalg.norm(s['Theta'] - ref['Theta']) <= 1e-8
 
 
+@pytest.mark.parametrize("p", [60, 160])
+def test_asymmetric_dual_start_takes_the_mirroring_kernels(sol, p, monkeypatch):
+    """The per-element GGL Theta-step is only valid for a bitwise symmetric state.  A dual start X_0 that is
+    symmetric only to ~1e-8 (inside the reference's own 1e-5 assert, ggl_helper.py:193) must follow the
+    reference's 'upper triangle, then mirror' semantics: the ctx detects the asymmetry when the state is set and
+    runs the tile-pair kernels.  Both dispatches agree with the oracle; for a symmetric start they agree with
+    each other to rounding."""
+    from gglasso_amd import synth
+    K = 4
+    S, _ = synth.make_problem("GGL", K=K, p=p, N=2 * p, seed=23)
+    Om0 = np.stack([np.eye(p)] * K)
+    rng = np.random.default_rng(5)
+    X0 = 0.01 * rng.standard_normal((K, p, p))
+    X0 = 0.5 * (X0 + X0.transpose(0, 2, 1))
+    Xa = X0 + 1e-8 * np.triu(rng.standard_normal((K, p, p)), 1)           # upper triangle perturbed
+    for X_start in (X0, Xa):
+        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, X_0=X_start, max_iter=10, tol=1e-20, rtol=1e-20)
+        (s, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, X_0=X_start, max_iter=10, tol=1e-20, rtol=1e-20)
+        for nm in ('Omega', 'Theta', 'X'):
+            assert np.abs(s[nm] - ref[nm]).max() <= 1e-9, nm
+        assert np.array_equal(s['Theta'], s['Theta'].transpose(0, 2, 1))
+    monkeypatch.setenv("GGL_THETA_FLAT", "0")
+    (s0, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, X_0=X0, max_iter=10, tol=1e-20, rtol=1e-20)
+    monkeypatch.setenv("GGL_THETA_FLAT", "1")
+    (s1, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, X_0=X0, max_iter=10, tol=1e-20, rtol=1e-20)
+    assert np.abs(s0['Theta'] - s1['Theta']).max() <= 1e-12
+
+
 def test_inputs_not_mutated_and_asserts(sol):
     g = load_golden("g8_g9_admm_mgl")
     S, Om0 = g["S_GGL"].copy(), g["Omega_0"].copy()
@@ -282,3 +310,9 @@ def test_extreme_rho_and_scaling_vs_oracle(sol, rho0, scale, lam, reg, latent):
     for nm in ("Omega", "Theta", "L", "X"):
         tol = 1e-9 * max(1.0, np.abs(ref[nm]).max())
         assert np.abs(out[nm] - ref[nm]).max() <= tol, (nm, np.abs(out[nm] - ref[nm]).max())
+
+
+def test_g12_batched_single_grid_search(sol):
+    """The (lambda1[, mu1]) grid solved as one batch on the GPU against the reference's single_grid_search tables."""
+    from grid_checks import check_single_grid_search
+    check_single_grid_search(load_golden)
