@@ -131,3 +131,37 @@ def test_seam2_model_selection_single(ref, ours, monkeypatch):
     assert np.abs(a[1] - b[1]).max() <= 1e-7                       # estimates along the whole lambda path
     assert np.allclose(a[3]['BIC'][0.3], b[3]['BIC'][0.3], rtol=1e-7)
     assert a[3]['BEST'] == b[3]['BEST']
+
+
+def test_seam3a_glasso_problem_model_selection_with_the_batched_grid(ref, ours, monkeypatch):
+    """problem.py:14 imports single_grid_search by name and model_selection() calls it at :606; swapping in
+    gglasso_amd.model_selection.single_grid_search (the whole grid as one batch) must select the same point and
+    the same estimate as the reference's sequential walk, with and without latent variables."""
+    dg, problem = ref["dg"], ref["problem"]
+    from gglasso_amd import model_selection as ours_ms
+    p, N = 20, 200
+    Sig, _ = dg.generate_precision_matrix(p=p, M=2, style='erdos', prob=0.2, seed=13)
+    S, _ = dg.sample_covariance_matrix(Sig, N, seed=13)
+
+    def select(latent):
+        P = problem.glasso_problem(S, N, reg=None, latent=latent, do_scaling=False)
+        P.set_modelselect_params({'lambda1_range': np.logspace(0, -2, 5), 'mu1_range': np.array([1.0, 0.4])})
+        quiet(P.model_selection, method='eBIC', gamma=0.3, tol=1e-9, rtol=1e-9)
+        return P
+
+    for latent in (False, True):
+        monkeypatch.undo()
+        P0 = select(latent)
+        from gglasso_amd import solver
+        from oracle_engine import OracleEngine
+        monkeypatch.setattr(solver, "ENGINE", OracleEngine)
+        monkeypatch.setattr(problem, "single_grid_search", ours_ms.single_grid_search)
+        P1 = select(latent)
+        assert P1.reg_params['lambda1'] == P0.reg_params['lambda1']
+        if latent:
+            assert P1.reg_params['mu1'] == P0.reg_params['mu1']
+            assert np.abs(P1.solution.lowrank_ - P0.solution.lowrank_).max() <= 1e-6
+        assert np.abs(P1.solution.precision_ - P0.solution.precision_).max() <= 1e-6
+        assert np.allclose(P1.modelselect_stats['BIC'][0.3], P0.modelselect_stats['BIC'][0.3], rtol=1e-7)
+        assert np.array_equal(P1.modelselect_stats['SP'], P0.modelselect_stats['SP'])
+        assert np.array_equal(P1.modelselect_stats['RANK'], P0.modelselect_stats['RANK'])
