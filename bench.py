@@ -145,9 +145,16 @@ def main():
     torch.cuda.set_device(local_rank)
     comm = None
     if distributed:
+        if world == 1:      # GGL_BENCH_FORCE_DIST=1 without a launcher: single-rank rendezvous on the loopback
+            for kk, vv in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"),
+                           ("MASTER_PORT", "29511")):
+                os.environ.setdefault(kk, vv)
         import torch.distributed as dist
         from gglasso_amd.dist import TorchComm, shard_bounds
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:      # GGL_BENCH_FORCE_DIST=1 without a launcher: single-rank rendezvous on the loopback
+            for kk, vv in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29511")):
+                os.environ.setdefault(kk, vv)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         comm = TorchComm(device=f"cuda:{local_rank}")
 

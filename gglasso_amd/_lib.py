@@ -37,6 +37,7 @@ _SIGNATURES = {
     "ggl_step_omega": ([_vp, _d, _i, _dp], _i),
     "ggl_step_group_partial": ([_vp, _d, _d], _i),
     "ggl_step_finish": ([_vp, _d, _d, _d, _i, _i, _dp, _i, _dp], _i),
+    "ggl_norms_read": ([_vp, _dp], _i),
     "ggl_scale_X": ([_vp, _d], _i),
     "ggl_sgl_batch_step": ([_vp, _dp, _dp, _i, _dp, _dp], _i),
     "ggl_scale_X_batch": ([_vp, _dp], _i),

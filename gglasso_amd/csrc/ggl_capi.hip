@@ -732,6 +732,8 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
     ARGCHK(!latent || mu1, "latent needs mu1");
     ARGCHK(!(groupsq_ready && latent), "K-sharded GGL with latent variables is not supported");
     HIPCHK(hipSetDevice(c->device));
+    const bool defer_norms = (groupsq_ready & 2) != 0;
+    groupsq_ready &= 1;
     const double inv_rho = 1.0 / rho;
     const double l1 = inv_rho * lambda1, l2 = inv_rho * lambda2;   // admm_solver.py:191-192
     double* Om = c->Om[c->cur];
@@ -784,7 +786,19 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
         rows = c->K;
     }
     HIPCHK(hipGetLastError());
+    if (defer_norms) {
+        // K-sharded run: the caller all-reduces the five sums in NORMS on the device, then ggl_norms_read
+        if (rows != 1) return fail(GGL_E_ARG, "deferred norms need a single row of sums (non-latent GGL/FGL)");
+        return GGL_OK;
+    }
     return finish_norms(c, rows, out_norms);
+}
+
+extern "C" int ggl_norms_read(ggl_ctx* c, double out_norms[5])
+{
+    ARGCHK(c && out_norms, "ctx, out_norms");
+    HIPCHK(hipSetDevice(c->device));
+    return finish_norms(c, 1, out_norms);
 }
 
 extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lambda2, int reg, int latent,

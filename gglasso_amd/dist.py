@@ -54,12 +54,21 @@ class TorchComm:
         self.rank = dist.get_rank(group)
         self._gs = None
         self._nrm = None
+        self.device_norms = self.backend == "nccl"      # all-reduce the norms where the kernels leave them
 
     def allreduce_groupsq(self, eng):
-        if self._gs is None:
-            self._gs = eng.groupsq_tensor(self.torch, self.device)
-        self.dist.all_reduce(self._gs, op=self.dist.ReduceOp.SUM, group=self.group)
-        eng.groupsq_written(self._gs)
+        # the tensor aliases a buffer of THIS engine's ctx: one comm may serve several solves
+        if self._gs is None or self._gs[0] is not eng:
+            self._gs = (eng, eng.groupsq_tensor(self.torch, self.device))
+        self.dist.all_reduce(self._gs[1], op=self.dist.ReduceOp.SUM, group=self.group)
+        eng.groupsq_written(self._gs[1])
+
+    def allreduce_norms_device(self, eng):
+        if self._nrm is None or self._nrm[0] is not eng:
+            view = _DeviceView(eng.device_ptr(_lib.BUF_NORMS), (5,))
+            self._nrm = (eng, self.torch.as_tensor(view, device=self.device))
+        self.dist.all_reduce(self._nrm[1], op=self.dist.ReduceOp.SUM, group=self.group)
+        return eng.read_norms()
 
     def allreduce_norms(self, arr):
         t = self.torch.as_tensor(np.asarray(arr, dtype=np.float64))

@@ -66,9 +66,15 @@ class HipEngine:
     def step_group_partial(self, rho, lambda1):
         check(self.lib.ggl_step_group_partial(self.h, rho, lambda1))
 
-    def step_finish(self, rho, lambda1, lambda2, reg, latent, mu1, groupsq_ready):
+    def step_finish(self, rho, lambda1, lambda2, reg, latent, mu1, groupsq_ready, defer_norms=False):
+        """defer_norms: leave the five local sums on the device (BUF_NORMS) for an on-device all-reduce; fetch
+        them with ``read_norms`` afterwards."""
         check(self.lib.ggl_step_finish(self.h, rho, lambda1, lambda2, _REG[reg], int(latent), ptr(mu1),
-                                       int(groupsq_ready), ptr(self._norms)))
+                                       int(groupsq_ready) | (2 if defer_norms else 0), ptr(self._norms)))
+        return None if defer_norms else self._norms.copy()
+
+    def read_norms(self):
+        check(self.lib.ggl_norms_read(self.h, ptr(self._norms)))
         return self._norms.copy()
 
     def scale_X(self, f):
@@ -195,6 +201,7 @@ def _run_admm(eng, reg, K_total, p, lambda1, lambda2, latent, mu1, nk, rho, tol,
     status = ''
     dim = K_total * ((p ** 2 + p) / 2)
     sharded_ggl = comm is not None and reg == 'GGL'
+    device_norms = sharded_ggl and getattr(comm, "device_norms", False) and hasattr(eng, "read_norms")
 
     if verbose:
         print(f"------------ADMM Algorithm for {title} Graphical Lasso----------------")
@@ -212,11 +219,16 @@ def _run_admm(eng, reg, K_total, p, lambda1, lambda2, latent, mu1, nk, rho, tol,
             eng.step_omega(rho, latent, nk)
             eng.step_group_partial(rho, lambda1)
             comm.allreduce_groupsq(eng)
-            sq = eng.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 1)
+            if device_norms:
+                # the five sums are all-reduced where they are (HBM) and cross PCIe once, already global
+                eng.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 1, defer_norms=True)
+                sq = comm.allreduce_norms_device(eng)
+            else:
+                sq = comm.allreduce_norms(eng.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 1))
         else:
             sq = eng.step(rho, lambda1, lambda2, reg, latent, mu1, nk)
-        if comm is not None:
-            sq = comm.allreduce_norms(sq)
+            if comm is not None:
+                sq = comm.allreduce_norms(sq)
         if measure:
             runtime[iter_t] = time.time() - start
             if want_objective:

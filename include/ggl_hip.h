@@ -104,6 +104,10 @@ int ggl_step_omega(ggl_ctx *ctx, double rho, int latent, const double *nk);
 int ggl_step_group_partial(ggl_ctx *ctx, double rho, double lambda1);
 int ggl_step_finish(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int reg, int latent,
                     const double *mu1, int groupsq_ready, double out_norms[5]);
+/* groupsq_ready bit 1 (value 2): leave the five local sums in the NORMS buffer instead of returning them, so that
+ * a K-sharded run can all-reduce them on the device (no host round trip); ggl_norms_read then copies them out
+ * (one stream sync), exactly what ggl_step_finish does itself without the bit. */
+int ggl_norms_read(ggl_ctx *ctx, double out_norms[5]);
 
 /* ---- K independent single problems (batched lambda path) ---------------------------------------
  * The ctx stack is used as K separate ADMM_SGL problems (single_admm_solver.py:157-214), each with its
