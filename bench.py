@@ -290,7 +290,9 @@ def main():
                               "stable_schedule_calls": ns1["stable_calls"] - ns0["stable_calls"],
                               "lstep_calls": ns1["rank_calls"] - ns0["rank_calls"],
                               "lstep_retries": ns1["rank_retries"] - ns0["rank_retries"],
-                              "lstep_eigh_fallbacks": ns1["rank_fallbacks"] - ns0["rank_fallbacks"]} if omega_ns else None,
+                              "lstep_eigh_fallbacks": ns1["rank_fallbacks"] - ns0["rank_fallbacks"],
+                              "speculative_omega_steps": ns1["spec_calls"] - ns0["spec_calls"],
+                              "speculation_misses": ns1["spec_misses"] - ns0["spec_misses"]} if omega_ns else None,
         }
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, reg, l1, l2, latent, mu1, args.cpu_iters)

@@ -58,9 +58,11 @@ __global__ __launch_bounds__(EW_THREADS) void k_theta_sgl(double* __restrict__ T
                                                           const double* __restrict__ L, const double* __restrict__ l1K,
                                                           const double* __restrict__ mask,
                                                           const double* __restrict__ invrhoK,
-                                                          double* __restrict__ partials, int p)
+                                                          double* __restrict__ partials, int p,
+                                                          const int* __restrict__ skip)
 {
     __shared__ double scratch[GGL_NNORM * (EW_THREADS / 64)];
+    if (spec_failed(skip)) return;
     const int k = blockIdx.y;
     const size_t pp = (size_t)p * p;
     const size_t base = (size_t)k * pp;
@@ -105,12 +107,12 @@ __global__ __launch_bounds__(EW_THREADS) void k_theta_sgl(double* __restrict__ T
 
 void launch_theta_sgl(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                       const double* OmegaPrev, const double* L, const double* l1K, const double* mask,
-                      const double* invrhoK, int latent, double* partials, int K, int p)
+                      const double* invrhoK, int latent, double* partials, int K, int p, const int* skip)
 {
     dim3 grid(elementwise_blocks(p), K), blk(EW_THREADS);
 #define GGL_TS(LAT, MSK)                                                                              \
     hipLaunchKernelGGL((k_theta_sgl<LAT, MSK>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1K, \
-                       mask, invrhoK, partials, p)
+                       mask, invrhoK, partials, p, skip)
     if (latent) {
         if (mask) GGL_TS(true, true); else GGL_TS(true, false);
     } else {

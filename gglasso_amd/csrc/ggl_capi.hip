@@ -73,6 +73,16 @@ struct ggl_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS - 1] = {};   // Newton-Schulz launch sequences concurrently
     bool theta_flat = true;                    // GGL Theta-step: per-element kernel when the state is symmetric
     bool state_symmetric = true;               // X and L exactly symmetric (checked when the state is set)
+    // speculative Omega-step: the schedule is built from the PREVIOUS iteration's spectral bounds (inflated) and the
+    // products are launched without waiting for this iteration's bounds; a device-side check sets spec_flag when a
+    // bound was exceeded, the state-changing kernels of the step then do nothing and the host repeats the step
+    bool spec_enable = true, spec_have = false, spec_pending = false;
+    double *spec_c = nullptr, *spec_beta = nullptr;   // host: bounds / beta of the last validated step (K each)
+    double *cuse = nullptr, *cuse_h = nullptr;        // bounds the running schedule assumes (device / pinned)
+    int *spec_flag = nullptr, *spec_flag_h = nullptr; // MAX_PARTS validation flags (device / pinned)
+    long long spec_calls = 0, spec_misses = 0;
+    double spec_factor = 1.02;                 // inflation of the previous bounds (GGL_SPEC_FACTOR; < 1 forces misses)
+    int spec_cool = 0;                         // iterations without speculation left after a failed one
     int ns_degrees = 9;                        // highest Newton-Schulz step degree: 3, 5 or 9
     int ns_parts = 1;                          // concurrent launch sequences (parts of the batch) wanted
     int* sweeps = nullptr;
@@ -192,6 +202,16 @@ static int ctx_alloc(ggl_ctx* c)
         HIPCHK(hipMalloc(&c->nbrow, (size_t)c->K * c->p * sizeof(double)));
         HIPCHK(hipMalloc(&c->nbpart, nbl));
         HIPCHK(hipHostMalloc(&c->nbpart_h, nbl));
+        HIPCHK(hipMalloc(&c->cuse, c->K * sizeof(double)));
+        HIPCHK(hipHostMalloc(&c->cuse_h, c->K * sizeof(double)));
+        HIPCHK(hipMalloc(&c->spec_flag, ggl_ctx::MAX_PARTS * sizeof(int)));
+        HIPCHK(hipMemset(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int)));
+        HIPCHK(hipHostMalloc(&c->spec_flag_h, ggl_ctx::MAX_PARTS * sizeof(int)));
+        memset(c->spec_flag_h, 0, ggl_ctx::MAX_PARTS * sizeof(int));
+        c->spec_c = (double*)malloc(c->K * sizeof(double));
+        c->spec_beta = (double*)malloc(c->K * sizeof(double));
+        if (const char* v = getenv("GGL_SPECULATE")) c->spec_enable = atoi(v) != 0;
+        if (const char* v = getenv("GGL_SPEC_FACTOR")) c->spec_factor = atof(v);
         HIPCHK(hipMalloc(&c->maxdev, c->K * sizeof(double)));
         HIPCHK(hipHostMalloc(&c->maxdev_h, c->K * sizeof(double)));
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -257,8 +277,13 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
-                      c->nsT, c->coef, c->bounds, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT};
+                      c->nsT, c->coef, c->bounds, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->cuse};
+    if (c->spec_flag) (void)hipFree(c->spec_flag);
     if (c->nbpart_h) (void)hipHostFree(c->nbpart_h);
+    if (c->cuse_h) (void)hipHostFree(c->cuse_h);
+    if (c->spec_flag_h) (void)hipHostFree(c->spec_flag_h);
+    free(c->spec_c);
+    free(c->spec_beta);
     if (c->maxdev_h) (void)hipHostFree(c->maxdev_h);
     if (c->coef_h) (void)hipHostFree(c->coef_h);
     if (c->bounds_h) (void)hipHostFree(c->bounds_h);
@@ -458,7 +483,8 @@ static int upload_par(ggl_ctx* c, int slot, const double* vals, double scalar, d
 // ---------------------------------------------------------------------------------------------
 // the iteration
 // ---------------------------------------------------------------------------------------------
-static int omega_step(ggl_ctx* c, int latent, CopySegs* pending = nullptr);
+static constexpr int GGL_SPEC_RETRY = 1;     // internal: a speculative step failed validation, repeat it
+static int omega_step(ggl_ctx* c, int latent, CopySegs* pending = nullptr, bool allow_spec = false);
 
 extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* nk)
 {
@@ -473,7 +499,7 @@ extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* 
 }
 
 // Omega-step with beta_k in parameter slot 0 (already on the device, or part of the pending transfer)
-static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
+static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec)
 {
     int rc;
     const double* beta = c->par;
@@ -512,6 +538,25 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
         const size_t pp = (size_t)c->p * c->p;
         const int nbb = norm_bounds_blocks(c->p);
         const int var_parts = (c->symm_variant < 0 && nh > 1) ? 17 : c->symm_variant;
+        const size_t region = (size_t)(NS_MAX_LAUNCHES - 4) / nh * NS_SLOT(K);      // coefficient slots per part
+        NsPlan plans[ggl_ctx::MAX_PARTS];
+        double* start_base_h = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
+        double* start_base_d = c->coef + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
+        // Speculation: same beta as the last validated step => its bounds, inflated by 2 %, are very likely still
+        // bounds (W moves little between ADMM iterations and the spectrum usually shrinks); the schedule is built
+        // from them NOW and the products follow the bound kernels without the host round trip.
+        bool spec = allow_spec && c->spec_enable && c->spec_have && !latent && c->spec_cool == 0;
+        if (allow_spec && c->spec_cool > 0) c->spec_cool -= 1;
+        for (int k = 0; spec && k < K; ++k) spec = (c->par_h[k] == c->spec_beta[k]);
+        if (spec) {
+            for (int k = 0; k < K; ++k) c->cuse_h[k] = c->spec_c[k] * c->spec_factor;
+            for (int h = 0; spec && h < nh; ++h) {
+                const int k0 = k0h[h];
+                const int prc = ns_plan(c->cuse_h + k0, c->par_h + k0, Kh[h], c->coef_h + h * region,
+                                        start_base_h + 5 * k0, &plans[h], c->ns_force, c->ns_degrees);
+                spec = (prc == 0) && !plans[h].stable;
+            }
+        }
         if (nh > 1) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
             for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
@@ -523,6 +568,15 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
             CopySegs sg = first;
             sg.add(pre_d + 5 * (size_t)k0, pre + 5 * (size_t)k0, (size_t)Kh[h] * 5 * sizeof(double));
             sg.add(pre_d + NS_SLOT(K) + 5 * (size_t)k0, pre + NS_SLOT(K) + 5 * (size_t)k0, (size_t)Kh[h] * 5 * sizeof(double));
+            if (spec) {
+                sg.add(start_base_d + 5 * (size_t)k0, start_base_h + 5 * (size_t)k0, (size_t)Kh[h] * 5 * sizeof(double));
+                const int nb_launch = plans[h].products - 2;
+                if (nb_launch > 0)
+                    sg.add(c->coef + h * region, c->coef_h + h * region, (size_t)nb_launch * NS_SLOT(Kh[h]) * sizeof(double));
+                sg.add(c->cuse + k0, c->cuse_h + k0, (size_t)Kh[h] * sizeof(double));
+                sg.add(c->spec_flag + h, nullptr, sizeof(int));
+                if (h == 0) sg.add(c->info, nullptr, K * sizeof(int));
+            }
             launch_copy_small(sh, sg);
             if (h == 0) PB(c, GGL_PH_FORM_W);
             launch_form_W_sym(sh, c->W + k0 * pp, c->Theta + k0 * pp, latent ? c->L + k0 * pp : nullptr, c->X + k0 * pp,
@@ -538,15 +592,39 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending)
             double* nbc = c->nbpart + 2 * (size_t)K * nbb + (size_t)k0 * nbb;
             launch_norm_bounds(sh, Bp, Kh[h], c->p, nb2, c->nbrow + (size_t)k0 * c->p);
             launch_cw_bounds(sh, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p, nbc);
-            launch_bound_final(sh, nb2, nbc, nbb, Kh[h], c->bounds_h + k0, 0);
-            if (h == 0) PE(c, GGL_PH_EIG_OMEGA);
+            launch_bound_final(sh, nb2, nbc, nbb, Kh[h], c->bounds_h + k0, 0, spec ? c->cuse + k0 : nullptr,
+                               spec ? c->spec_flag + h : nullptr);
+            if (spec) {
+                ns_run(sh, plans[h], c->coef + h * region, start_base_d + 5 * k0, c->W + k0 * pp, c->nsYP[0] + k0 * pp,
+                       c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kh[h], c->p,
+                       (c->symm_variant < 0 && nh > 1) ? 17 : c->symm_variant, nh > 1 ? c->n : 0);
+                c->ns_launches_total += plans[h].products;
+                const double frac = (double)Kh[h] / K;
+                c->ns_units_frac += frac * plans[h].units;
+                c->ns_steps_frac += frac * plans[h].steps;
+            }
+            if (h == 0 && !spec) PE(c, GGL_PH_EIG_OMEGA);
         }
         HIPCHK(hipGetLastError());
+        if (spec) {
+            for (int h = 1; h < nh; ++h) {
+                HIPCHK(hipEventRecord(c->ev_join[h - 1], c->streamx[h - 1]));
+                HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
+            }
+            PE(c, GGL_PH_EIG_OMEGA);
+            c->ns_units_total = (long long)(c->ns_units_frac + 0.5);
+            c->ns_steps_total = (long long)(c->ns_steps_frac + 0.5);
+            c->ns_calls += 1;
+            c->spec_calls += 1;
+            c->spec_pending = true;        // validated by the caller after its stream sync (spec_resolve)
+            c->dvo_valid = false;
+            c->cur = nxt;
+            return GGL_OK;
+        }
         for (int h = 0; h < nh; ++h) HIPCHK(hipStreamSynchronize(h == 0 ? c->stream : c->streamx[h - 1]));
-        const size_t region = (size_t)(NS_MAX_LAUNCHES - 4) / nh * NS_SLOT(K);      // coefficient slots per part
-        NsPlan plans[ggl_ctx::MAX_PARTS];
-        double* start_base_h = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
-        double* start_base_d = c->coef + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
+        // validated bounds: the next step may speculate on them
+        for (int k = 0; k < K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
+        c->spec_have = true;
         bool any_stable = false;
         for (int h = 0; h < nh; ++h) {
             const int k0 = k0h[h];
@@ -636,10 +714,26 @@ static int finish_norms(ggl_ctx* c, int rows, double out_norms[5])
     CopySegs dn;
     dn.add(c->norms_h, c->norms, (size_t)rows * GGL_NNORM * sizeof(double));
     dn.add(c->info_h, c->info, c->K * sizeof(int));
+    if (c->spec_pending) dn.add(c->spec_flag_h, c->spec_flag, ggl_ctx::MAX_PARTS * sizeof(int));
     launch_copy_small(c->stream, dn);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
+    if (c->spec_pending) {
+        // speculative Omega-step: were last iteration's (inflated) bounds still bounds?
+        c->spec_pending = false;
+        bool bad = false;
+        for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) bad = bad || (c->spec_flag_h[h] != 0);
+        if (bad) {
+            // no: the Theta-step kernels saw the flag and left the iterate alone; un-flip Omega and tell the caller
+            c->spec_misses += 1;
+            c->spec_have = false;
+            c->spec_cool = 4;
+            c->cur ^= 1;
+            return GGL_SPEC_RETRY;
+        }
+        for (int k = 0; k < c->K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
+    }
     int rc = check_info(c, "ADMM step");
     if (rc) return rc;
     for (int v = 0; v < GGL_NNORM; ++v) {
@@ -746,7 +840,8 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
         if (rc) return rc;
         PB(c, GGL_PH_THETA);
         launch_theta_sgl(c->stream, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, c->par + c->K,
-                         c->has_mask ? c->mask : nullptr, c->par + 4 * (size_t)c->K, latent, c->partials, c->K, c->p);
+                         c->has_mask ? c->mask : nullptr, c->par + 4 * (size_t)c->K, latent, c->partials, c->K, c->p,
+                         c->spec_pending ? c->spec_flag : nullptr);
         PE(c, GGL_PH_THETA);
         HIPCHK(hipGetLastError());
         if (!latent) {
@@ -762,7 +857,7 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
         const int flat = (c->theta_flat && c->state_symmetric && !groupsq_ready) ? 1 : 0;
         HIPCHK(launch_theta_pair(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, l1, l2,
                                  groupsq_ready ? c->groupsq : nullptr, c->sqwork, latent ? 0 : 1, c->partials, c->K,
-                                 c->p, flat));
+                                 c->p, flat, c->spec_pending ? c->spec_flag : nullptr));
         PE(c, GGL_PH_THETA);
         if (!latent) {
             PB(c, GGL_PH_REDUCE);
@@ -804,7 +899,18 @@ extern "C" int ggl_norms_read(ggl_ctx* c, double out_norms[5])
 extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lambda2, int reg, int latent,
                              const double* mu1, const double* nk, double out_norms[5])
 {
-    int rc = ggl_step_omega(c, rho, latent, nk);
+    ARGCHK(c, "ctx");
+    ARGCHK(rho > 0, "rho must be positive");
+    HIPCHK(hipSetDevice(c->device));
+    CopySegs sg;
+    int rc = upload_par(c, 0, nk, 1.0, rho, &sg);   // beta_k = nk/rho    (admm_solver.py:180,184)
+    if (rc) return rc;
+    rc = omega_step(c, latent, &sg, /*allow_spec=*/true);
+    if (rc) return rc;
+    rc = ggl_step_finish(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
+    if (rc != GGL_SPEC_RETRY) return rc;
+    // the speculative schedule did not cover this iteration's spectrum: same step again, bounds first
+    rc = omega_step(c, latent, nullptr, false);
     if (rc) return rc;
     return ggl_step_finish(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
 }
@@ -910,7 +1016,7 @@ extern "C" int ggl_profile_enable(ggl_ctx* c, int on)
     return GGL_OK;
 }
 
-extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[9])
+extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[11])
 {
     ARGCHK(c && out, "ctx, out");
     out[0] = c->ns_calls;
@@ -922,6 +1028,8 @@ extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[9])
     out[6] = c->rank_retries;
     out[7] = c->rank_fallbacks;
     out[8] = c->rank_launches;
+    out[9] = c->spec_calls;
+    out[10] = c->spec_misses;
     return GGL_OK;
 }
 

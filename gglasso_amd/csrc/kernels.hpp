@@ -25,7 +25,7 @@ void launch_form_W(hipStream_t st, double* W, const double* Theta, const double*
 // partials [K][nblk][5].  latent != 0: writes Theta and C = (Theta - X) - Omega.
 void launch_theta_sgl(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                       const double* OmegaPrev, const double* L, const double* l1K,
-                      const double* mask, const double* invrhoK, int latent, double* partials, int K, int p);
+                      const double* mask, const double* invrhoK, int latent, double* partials, int K, int p, const int* skip = nullptr);
 // X += (Omega - Theta) + L and the norms partials (latent path, admm_solver.py:208)
 void launch_dual_update(hipStream_t st, double* X, const double* Omega, const double* OmegaPrev,
                         const double* Theta, const double* L, double* partials, int K, int p);
@@ -34,9 +34,9 @@ void launch_reduce_partials(hipStream_t st, const double* partials, int K, int n
 void launch_scale(hipStream_t st, double* X, double f, size_t n);
 // Small transfers between pinned host memory (device-visible) and HBM as an ordinary kernel in the stream:
 // a hipMemcpyAsync of a few KB costs ~15 us of queue idle time around its blit (measured, rocprofv3), this
-// costs a launch.  Up to 6 segments of 32-bit words per launch; src == nullptr zero-fills.
+// costs a launch.  Up to 10 segments of 32-bit words per launch; src == nullptr zero-fills.
 struct CopySegs {
-    static constexpr int MAX = 6;
+    static constexpr int MAX = 10;
     int n = 0;
     void* dst[MAX];
     const void* src[MAX];
@@ -79,7 +79,7 @@ int theta_partial_blocks(int p, int reg, int K, int flat);
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C,
                              const double* Omega, const double* OmegaPrev, const double* L,
                              double l1, double l2, const double* groupsq, double* sqwork, int fuse_dual,
-                             double* partials, int K, int p, int flat = 0);
+                             double* partials, int K, int p, int flat = 0, const int* skip = nullptr);
 // number of K-chunks the GGL kernels split the stack into (grid.y)
 int ggl_chunks(int K, int p);
 // GGL pass 1 only: sq[c](p,p)[i<j] = sum_{k in chunk c} soft(Omega+L+X, l1)^2,  c < ggl_chunks(K,p)
@@ -181,7 +181,9 @@ void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* p
 void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int K, int p, double* part);
 // per-instance reduction of the block partials on the device; out (K doubles) may be pinned host memory.
 // mode 0: sqrt(min(|.|_inf, cw, |.|_F)) (cwpart may be null); mode 1: min(|.|_inf, |.|_F)
-void launch_bound_final(hipStream_t st, const double* part2, const double* cwpart, int nbb, int K, double* out, int mode);
+// cuse/flag (optional, mode 0): speculative validation -- *flag = 1 if some out[k] exceeds cuse[k] or is not finite
+void launch_bound_final(hipStream_t st, const double* part2, const double* cwpart, int nbb, int K, double* out, int mode,
+                        const double* cuse = nullptr, int* flag = nullptr);
 int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan);
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
                  double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot = 0);

@@ -797,7 +797,8 @@ __global__ __launch_bounds__(256) void k_cw_bounds(const double* __restrict__ W,
 //        = min(max_b part2[k][b][0], sqrt(sum_b part2[k][b][1]))                   (mode 1: norm bound of C)
 // `out` may be pinned host memory: K doubles.
 __global__ __launch_bounds__(256) void k_bound_final(const double* __restrict__ part2, const double* __restrict__ cwpart,
-                                                     int nbb, int K, double* __restrict__ out, int mode)
+                                                     int nbb, int K, double* __restrict__ out, int mode,
+                                                     const double* __restrict__ cuse, int* __restrict__ flag)
 {
     for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
         double mx = 0.0, sq = 0.0, cw = 0.0;
@@ -811,16 +812,21 @@ __global__ __launch_bounds__(256) void k_bound_final(const double* __restrict__ 
         if (mode == 0) {
             // the ratio is computed in floating point from ~p terms, hence the small inflation
             if (cwpart && isfinite(cw) && cw > 0.0) { const double w = cw * (1.0 + 1e-12); mx = (w < mx) ? w : mx; }
-            out[k] = sqrt((fr < mx) ? fr : mx);
+            const double b = sqrt((fr < mx) ? fr : mx);
+            out[k] = b;
+            // the schedule already running was built for a spectrum inside [4 beta, cuse[k]]
+            if (flag && !(b <= cuse[k])) atomicOr(flag, 1);
         } else {
             out[k] = (fr < mx) ? fr : mx;
         }
     }
 }
 
-void launch_bound_final(hipStream_t st, const double* part2, const double* cwpart, int nbb, int K, double* out, int mode)
+void launch_bound_final(hipStream_t st, const double* part2, const double* cwpart, int nbb, int K, double* out, int mode,
+                        const double* cuse, int* flag)
 {
-    hipLaunchKernelGGL(k_bound_final, dim3((K + 255) / 256), dim3(256), 0, st, part2, cwpart, nbb, K, out, mode);
+    hipLaunchKernelGGL(k_bound_final, dim3((K + 255) / 256), dim3(256), 0, st, part2, cwpart, nbb, K, out, mode, cuse,
+                       flag);
 }
 
 void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int K, int p, double* part)

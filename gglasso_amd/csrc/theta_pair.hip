@@ -139,10 +139,12 @@ __global__ __launch_bounds__(256) void k_theta_ggl(double* __restrict__ Theta, d
                                                    const double* __restrict__ OmegaPrev,
                                                    const double* __restrict__ L, double l1, double l2,
                                                    const double* __restrict__ sq, int nsq,
-                                                   double* __restrict__ partials, int K, int p, int klen)
+                                                   double* __restrict__ partials, int K, int p, int klen,
+                                                   const int* __restrict__ skip)
 {
     __shared__ double tile[2][PT][PT + 1];
     __shared__ double scratch[GGL_NNORM * 4];
+    if (spec_failed(skip)) return;
     const int T = (p + PT - 1) / PT;
     int I, J;
     decode_pair(blockIdx.x, T, I, J);
@@ -344,10 +346,12 @@ __global__ __launch_bounds__(TD * TD) void k_theta_fgl(double* __restrict__ Thet
                                                        double* __restrict__ C, const double* __restrict__ Omega,
                                                        const double* __restrict__ OmegaPrev,
                                                        const double* __restrict__ L, double l1, double l2,
-                                                       double* __restrict__ partials, int K, int p)
+                                                       double* __restrict__ partials, int K, int p,
+                                                       const int* __restrict__ skip)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // [K][TD*TD] then scratch
     constexpr int NT = TD * TD;
+    if (spec_failed(skip)) return;
     const int T = (p + TD - 1) / TD;
     int I, J;
     decode_pair(blockIdx.x, T, I, J);
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(TD * TD) void k_theta_fgl(double* __restrict__ Thet
 template <int TD>
 static hipError_t launch_fgl_td(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                                 const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual,
-                                double* partials, int K, int p)
+                                double* partials, int K, int p, const int* skip)
 {
     const int T = ntiles(p, TD);
     const size_t lds = ((size_t)K * TD * TD + GGL_NNORM * 4) * sizeof(double);
@@ -453,11 +457,11 @@ static hipError_t launch_fgl_td(hipStream_t st, double* Theta, double* X, double
     if (fuse_dual) {
         e = hipFuncSetAttribute((const void*)k_theta_fgl<TD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_theta_fgl<TD, true>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p);
+        hipLaunchKernelGGL((k_theta_fgl<TD, true>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip);
     } else {
         e = hipFuncSetAttribute((const void*)k_theta_fgl<TD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_theta_fgl<TD, false>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p);
+        hipLaunchKernelGGL((k_theta_fgl<TD, false>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip);
     }
     return hipGetLastError();
 }
@@ -472,9 +476,11 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
                                                         double* __restrict__ C, const double* __restrict__ Omega,
                                                         const double* __restrict__ OmegaPrev,
                                                         const double* __restrict__ L, double l1, double l2,
-                                                        double* __restrict__ partials, int K, int p)
+                                                        double* __restrict__ partials, int K, int p,
+                                                        const int* __restrict__ skip)
 {
     __shared__ double scratch[GGL_NNORM * 4];
+    if (spec_failed(skip)) return;
     const size_t pp = (size_t)p * p;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
@@ -544,24 +550,24 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
 template <int KMAX>
 static void launch_flat(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                         const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual, double* partials,
-                        int K, int p)
+                        int K, int p, const int* skip)
 {
     dim3 grid(flat_blocks(p)), blk(256);
     if (fuse_dual)
-        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p);
+        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip);
     else
-        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p);
+        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip);
 }
 
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C, const double* Omega,
                              const double* OmegaPrev, const double* L, double l1, double l2,
                              const double* groupsq, double* sqwork, int fuse_dual, double* partials, int K, int p,
-                             int flat)
+                             int flat, const int* skip)
 {
     if (reg == 1 && flat && !groupsq && K <= GGL_FLAT_MAX_K) {
-        if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p);
-        else if (K <= 16) launch_flat<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p);
-        else launch_flat<32>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p);
+        if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
+        else if (K <= 16) launch_flat<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
+        else launch_flat<32>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
         return hipGetLastError();
     }
     if (reg == 1) {
@@ -577,22 +583,22 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
             nsq = kc;
         }
         if (fuse_dual)
-            hipLaunchKernelGGL(k_theta_ggl<true>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, sq, nsq, partials, K, p, klen);
+            hipLaunchKernelGGL(k_theta_ggl<true>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, sq, nsq, partials, K, p, klen, skip);
         else
-            hipLaunchKernelGGL(k_theta_ggl<false>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, sq, nsq, partials, K, p, klen);
+            hipLaunchKernelGGL(k_theta_ggl<false>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, sq, nsq, partials, K, p, klen, skip);
         return hipGetLastError();
     }
     if (K > FGL_MAX_K_TD8) return hipErrorInvalidValue;
     if (fgl_tile(K) == 16)
-        return launch_fgl_td<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p);
-    return launch_fgl_td<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p);
+        return launch_fgl_td<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
+    return launch_fgl_td<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
 }
 
 hipError_t launch_prox_p(hipStream_t st, int reg, double* out, const double* V, double l1, double l2, int K, int p,
                          double* sqwork)
 {
     return launch_theta_pair(st, reg, out, nullptr, nullptr, V, nullptr, nullptr, l1, l2, nullptr, sqwork, 0, nullptr, K,
-                             p);
+                             p, 0, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -146,10 +146,10 @@ class HipEngine:
 
     def ns_stats(self):
         import ctypes
-        out = (ctypes.c_longlong * 9)()
+        out = (ctypes.c_longlong * 11)()
         check(self.lib.ggl_ns_stats(self.h, out))
         return dict(zip(("calls", "steps", "stable_calls", "units", "launches", "rank_calls", "rank_retries",
-                         "rank_fallbacks", "rank_launches"), (int(v) for v in out)))
+                         "rank_fallbacks", "rank_launches", "spec_calls", "spec_misses"), (int(v) for v in out)))
 
     def device_ptr(self, which):
         return self.lib.ggl_device_ptr(self.h, which)

@@ -163,8 +163,9 @@ int ggl_profile_enable(ggl_ctx *ctx, int on);
 int ggl_profile_read(ggl_ctx *ctx, double ms[GGL_NPHASE], long long count[GGL_NPHASE], int reset);
 /* Newton-Schulz statistics since ctx creation: Omega-step {calls, steps, calls that took the stable
  * schedule, algorithmic work in units of K*p^3 flop, kernel launches}; L-step {calls, retries at the
- * finer resolution, fallbacks to the eigendecomposition, kernel launches (each K*p^3 flop)}. */
-int ggl_ns_stats(ggl_ctx *ctx, long long out[9]);
+ * finer resolution, fallbacks to the eigendecomposition, kernel launches (each K*p^3 flop)}; speculative
+ * Omega-steps {taken, failed validation and repeated}. */
+int ggl_ns_stats(ggl_ctx *ctx, long long out[11]);
 
 /* ---- development / tuning entry points (not used by the solvers) ------------------------------
  * ggl_dev_symm: one launch of the symmetric-product kernel on host data (kernel unit test).

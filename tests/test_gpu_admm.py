@@ -316,3 +316,40 @@ def test_g12_batched_single_grid_search(sol):
     """The (lambda1[, mu1]) grid solved as one batch on the GPU against the reference's single_grid_search tables."""
     from grid_checks import check_single_grid_search
     check_single_grid_search(load_golden)
+
+
+@pytest.mark.parametrize("reg,K,p", [("GGL", 4, 160), ("FGL", 3, 150), ("GGL", 16, 200)])
+def test_speculative_omega_step_hit_and_miss(sol, reg, K, p, monkeypatch):
+    """The Omega-step runs its products on a schedule built from the previous iteration's spectral bounds and
+    validates them on the device afterwards.  Hits (default 2 % inflation) and forced misses (bounds deflated by
+    GGL_SPEC_FACTOR=0.9: the Theta-step kernels must leave the iterate alone and the step is repeated) and no
+    speculation at all must produce the same trajectory as the oracle."""
+    from gglasso_amd import synth, solver
+    S, _ = synth.make_problem(reg, K=K, p=p, N=2 * p, seed=31)
+    Om0 = np.stack([np.eye(p)] * K)
+    ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, reg, Om0, max_iter=14, tol=1e-20, rtol=1e-20)
+    stats = {}
+    real_close = solver.HipEngine.close
+
+    def closing(self):
+        stats.update(self.ns_stats())
+        real_close(self)
+
+    monkeypatch.setattr(solver.HipEngine, "close", closing)
+    for env, want_spec, want_miss in (({"GGL_SPECULATE": "0"}, False, False), ({}, True, False),
+                                      ({"GGL_SPEC_FACTOR": "0.9"}, True, True)):
+        for k in ("GGL_SPECULATE", "GGL_SPEC_FACTOR"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        (s, info), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, reg, Om0, max_iter=14, tol=1e-20, rtol=1e-20)
+        for nm in ('Omega', 'Theta', 'X'):
+            assert np.abs(s[nm] - ref[nm]).max() <= 1e-9, (env, nm)
+        assert (stats["spec_calls"] > 0) == want_spec, (env, stats)
+        if not want_spec:
+            assert stats["spec_misses"] == 0
+        elif want_miss:
+            assert stats["spec_misses"] == stats["spec_calls"], (env, stats)       # every attempt is rejected
+        else:
+            # from the identity start the spectrum still grows in the first iterations: a natural miss may occur
+            assert stats["spec_misses"] < stats["spec_calls"], (env, stats)
