@@ -82,6 +82,8 @@ struct ggl_ctx {
     int *spec_flag = nullptr, *spec_flag_h = nullptr; // MAX_PARTS validation flags (device / pinned)
     long long spec_calls = 0, spec_misses = 0;
     double spec_factor = 1.02;                 // inflation of the previous bounds (GGL_SPEC_FACTOR; < 1 forces misses)
+    bool info_dirty = true;                    // an eigensolver wrote `info` since it was last fetched
+    bool norms_host = false;                   // the last norm reduction wrote straight into norms_h
     int spec_cool = 0;                         // iterations without speculation left after a failed one
     int ns_degrees = 9;                        // highest Newton-Schulz step degree: 3, 5 or 9
     int ns_parts = 1;                          // concurrent launch sequences (parts of the batch) wanted
@@ -402,6 +404,7 @@ extern "C" int ggl_set_lambda1_mask(ggl_ctx* c, const double* lam)
 static int eig_recon(ggl_ctx* c, double* A, double* out, double* Dv, int map, const double* betaK, int ph_eig = -1,
                      int ph_recon = -1)
 {
+    c->info_dirty = true;
     if (use_jacobi(c)) {
         if (ph_eig >= 0) PB(c, ph_eig);
         HIPCHK(launch_jacobi(c->stream, A, Dv, nullptr, out, map, betaK, c->info, c->K, c->p));
@@ -440,6 +443,7 @@ static int eig_recon(ggl_ctx* c, double* A, double* out, double* Dv, int map, co
 
 static int eigvals_only(ggl_ctx* c, double* A, double* Dv)
 {
+    c->info_dirty = true;
     if (use_jacobi(c)) {
         HIPCHK(launch_jacobi(c->stream, A, Dv, nullptr, nullptr, MAP_IDENT, nullptr, c->info, c->K, c->p));
         return GGL_OK;
@@ -575,7 +579,8 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                     sg.add(c->coef + h * region, c->coef_h + h * region, (size_t)nb_launch * NS_SLOT(Kh[h]) * sizeof(double));
                 sg.add(c->cuse + k0, c->cuse_h + k0, (size_t)Kh[h] * sizeof(double));
                 sg.add(c->spec_flag + h, nullptr, sizeof(int));
-                if (h == 0) sg.add(c->info, nullptr, K * sizeof(int));
+                c->spec_flag_h[h] = 0;
+                if (h == 0 && c->info_dirty) sg.add(c->info, nullptr, K * sizeof(int));
             }
             launch_copy_small(sh, sg);
             if (h == 0) PB(c, GGL_PH_FORM_W);
@@ -593,7 +598,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             launch_norm_bounds(sh, Bp, Kh[h], c->p, nb2, c->nbrow + (size_t)k0 * c->p);
             launch_cw_bounds(sh, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p, nbc);
             launch_bound_final(sh, nb2, nbc, nbb, Kh[h], c->bounds_h + k0, 0, spec ? c->cuse + k0 : nullptr,
-                               spec ? c->spec_flag + h : nullptr);
+                               spec ? c->spec_flag + h : nullptr, spec ? c->spec_flag_h + h : nullptr);
             if (spec) {
                 ns_run(sh, plans[h], c->coef + h * region, start_base_d + 5 * k0, c->W + k0 * pp, c->nsYP[0] + k0 * pp,
                        c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kh[h], c->p,
@@ -616,7 +621,8 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             c->ns_steps_total = (long long)(c->ns_steps_frac + 0.5);
             c->ns_calls += 1;
             c->spec_calls += 1;
-            c->spec_pending = true;        // validated by the caller after its stream sync (spec_resolve)
+            c->spec_pending = true;        // validated by the caller after its stream sync (finish_norms)
+            if (c->info_dirty) { memset(c->info_h, 0, K * sizeof(int)); c->info_dirty = false; }
             c->dvo_valid = false;
             c->cur = nxt;
             return GGL_OK;
@@ -658,7 +664,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             const int nb_launch = plans[h].products - 2;     // launches of phase B
             if (nb_launch > 0)
                 up.add(c->coef + h * region, c->coef_h + h * region, (size_t)nb_launch * NS_SLOT(Kr) * sizeof(double));
-            if (h == 0) up.add(c->info, nullptr, K * sizeof(int));           // no eigensolver ran: info = 0
+            if (h == 0 && c->info_dirty) up.add(c->info, nullptr, K * sizeof(int));   // no eigensolver ran: info = 0
             launch_copy_small(sh, up);
             ns_run(sh, plans[h], c->coef + h * region, start_base_d + 5 * k0,
                    c->W + k0 * pp, c->nsYP[0] + k0 * pp, c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kr,
@@ -683,6 +689,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         c->ns_steps_total = (long long)(c->ns_steps_frac + 0.5);
         c->ns_calls += 1;
         c->dvo_valid = false;
+        if (c->info_dirty) { memset(c->info_h, 0, K * sizeof(int)); c->info_dirty = false; }
         c->cur = nxt;
         return GGL_OK;
     }
@@ -711,13 +718,15 @@ extern "C" int ggl_step_group_partial(ggl_ctx* c, double rho, double lambda1)
 
 static int finish_norms(ggl_ctx* c, int rows, double out_norms[5])
 {
+    // the reduction usually wrote the sums straight into pinned host memory and no eigensolver touched `info`:
+    // then there is nothing to copy, only the stream to wait for
     CopySegs dn;
-    dn.add(c->norms_h, c->norms, (size_t)rows * GGL_NNORM * sizeof(double));
-    dn.add(c->info_h, c->info, c->K * sizeof(int));
-    if (c->spec_pending) dn.add(c->spec_flag_h, c->spec_flag, ggl_ctx::MAX_PARTS * sizeof(int));
+    if (!c->norms_host) dn.add(c->norms_h, c->norms, (size_t)rows * GGL_NNORM * sizeof(double));
+    if (c->info_dirty) dn.add(c->info_h, c->info, c->K * sizeof(int));
     launch_copy_small(c->stream, dn);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->norms_host = false;
     prof_collect(c);
     if (c->spec_pending) {
         // speculative Omega-step: were last iteration's (inflated) bounds still bounds?
@@ -828,6 +837,9 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
     HIPCHK(hipSetDevice(c->device));
     const bool defer_norms = (groupsq_ready & 2) != 0;
     groupsq_ready &= 1;
+    // the five sums go straight to pinned host memory, unless a K-sharded run wants them on the device first
+    double* norms_dst = defer_norms ? c->norms : c->norms_h;
+    c->norms_host = !defer_norms;
     const double inv_rho = 1.0 / rho;
     const double l1 = inv_rho * lambda1, l2 = inv_rho * lambda2;   // admm_solver.py:191-192
     double* Om = c->Om[c->cur];
@@ -846,7 +858,7 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
         HIPCHK(hipGetLastError());
         if (!latent) {
             PB(c, GGL_PH_REDUCE);
-            launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), GGL_NNORM, c->norms);
+            launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), GGL_NNORM, norms_dst);
             PE(c, GGL_PH_REDUCE);
             rows = c->K;
         }
@@ -862,7 +874,7 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
         if (!latent) {
             PB(c, GGL_PH_REDUCE);
             launch_reduce_partials(c->stream, c->partials, 1, theta_partial_blocks(c->p, reg, c->K, flat), GGL_NNORM,
-                                   c->norms);
+                                   norms_dst);
             PE(c, GGL_PH_REDUCE);
             rows = 1;
         }
@@ -876,7 +888,7 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
         launch_dual_update(c->stream, c->X, Om, OmPrev, c->Theta, c->L, c->partials, c->K, c->p);
         PE(c, GGL_PH_DUAL);
         PB(c, GGL_PH_REDUCE);
-        launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), GGL_NNORM, c->norms);
+        launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), GGL_NNORM, norms_dst);
         PE(c, GGL_PH_REDUCE);
         rows = c->K;
     }
@@ -951,12 +963,11 @@ extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* l
         PE(c, GGL_PH_DUAL);
     }
     PB(c, GGL_PH_REDUCE);
-    launch_reduce_partials(c->stream, c->partials, K, elementwise_blocks(c->p), GGL_NNORM, c->norms);
+    launch_reduce_partials(c->stream, c->partials, K, elementwise_blocks(c->p), GGL_NNORM, c->norms_h);
     PE(c, GGL_PH_REDUCE);
     HIPCHK(hipGetLastError());
     CopySegs dn;
-    dn.add(c->norms_h, c->norms, (size_t)K * GGL_NNORM * sizeof(double));
-    dn.add(c->info_h, c->info, K * sizeof(int));
+    if (c->info_dirty) dn.add(c->info_h, c->info, K * sizeof(int));
     launch_copy_small(c->stream, dn);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -181,9 +181,10 @@ void launch_norm_bounds(hipStream_t st, const double* W, int K, int p, double* p
 void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int K, int p, double* part);
 // per-instance reduction of the block partials on the device; out (K doubles) may be pinned host memory.
 // mode 0: sqrt(min(|.|_inf, cw, |.|_F)) (cwpart may be null); mode 1: min(|.|_inf, |.|_F)
-// cuse/flag (optional, mode 0): speculative validation -- *flag = 1 if some out[k] exceeds cuse[k] or is not finite
+// cuse/flag/flag_host (optional, mode 0): speculative validation -- *flag (device) and *flag_host (pinned) are set
+// to 1 if some out[k] exceeds cuse[k] or is not finite
 void launch_bound_final(hipStream_t st, const double* part2, const double* cwpart, int nbb, int K, double* out, int mode,
-                        const double* cuse = nullptr, int* flag = nullptr);
+                        const double* cuse = nullptr, int* flag = nullptr, int* flag_host = nullptr);
 int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan);
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
                  double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot = 0);

@@ -798,7 +798,8 @@ __global__ __launch_bounds__(256) void k_cw_bounds(const double* __restrict__ W,
 // `out` may be pinned host memory: K doubles.
 __global__ __launch_bounds__(256) void k_bound_final(const double* __restrict__ part2, const double* __restrict__ cwpart,
                                                      int nbb, int K, double* __restrict__ out, int mode,
-                                                     const double* __restrict__ cuse, int* __restrict__ flag)
+                                                     const double* __restrict__ cuse, int* __restrict__ flag,
+                                                     int* __restrict__ flag_host)
 {
     for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
         double mx = 0.0, sq = 0.0, cw = 0.0;
@@ -815,7 +816,10 @@ __global__ __launch_bounds__(256) void k_bound_final(const double* __restrict__ 
             const double b = sqrt((fr < mx) ? fr : mx);
             out[k] = b;
             // the schedule already running was built for a spectrum inside [4 beta, cuse[k]]
-            if (flag && !(b <= cuse[k])) atomicOr(flag, 1);
+            if (flag && !(b <= cuse[k])) {
+                atomicOr(flag, 1);          // for the kernels of this step
+                *flag_host = 1;             // pinned: for the host, after its stream sync
+            }
         } else {
             out[k] = (fr < mx) ? fr : mx;
         }
@@ -823,10 +827,10 @@ __global__ __launch_bounds__(256) void k_bound_final(const double* __restrict__ 
 }
 
 void launch_bound_final(hipStream_t st, const double* part2, const double* cwpart, int nbb, int K, double* out, int mode,
-                        const double* cuse, int* flag)
+                        const double* cuse, int* flag, int* flag_host)
 {
     hipLaunchKernelGGL(k_bound_final, dim3((K + 255) / 256), dim3(256), 0, st, part2, cwpart, nbb, K, out, mode, cuse,
-                       flag);
+                       flag, flag_host);
 }
 
 void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int K, int p, double* part)
