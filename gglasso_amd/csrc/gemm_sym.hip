@@ -215,7 +215,8 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
                     const int gi = I0 + wr + ti * 16 + (lane >> 4) + 4 * r;
                     const int gj = J0 + wc + tj * 16 + (lane & 15);
                     if (gi < p && gj < p && (I != J || gi <= gj)) {
-                        const double v = cAcc * acc[ti][tj][r] + (gi == gj ? cI - 1.0 : 0.0);
+                        double v = cAcc * acc[ti][tj][r] + (gi == gj ? cI - 1.0 : 0.0);
+                        if (Ek) v += cE * Ek[(size_t)gi * p + gj];      // the deviation of the OUTPUT, E term included
                         dev = fmax(dev, fabs(v));
                     }
                 }
@@ -399,8 +400,8 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
                 double v = cAcc * acc[ti][tj][r];
                 if (gi < p && gj < p && (I != J || gi <= gj)) {
                     if (gi == gj) v += cI;
-                    dev = fmax(dev, fabs(v - (gi == gj ? 1.0 : 0.0)));
                     if (Ek) v += cE * Ek[(size_t)gi * p + gj];
+                    dev = fmax(dev, fabs(v - (gi == gj ? 1.0 : 0.0)));
                     Ck[(size_t)gi * p + gj] = v;
                     if (C2k) C2k[(size_t)gi * p + gj] = dC * v + (gi == gj ? dI : 0.0);
                     if (I == J && gi != gj) {

@@ -773,7 +773,7 @@ static int rank_step(ggl_ctx* c)
     if (c->rank_hold > 0) c->rank_hold -= 1;
     for (int attempt = 0; attempt < 2; ++attempt) {
         NsPlan plan;
-        if (rank_ns_plan(cn.data(), mu_h, K, l0, c->coef_h, &plan) != 0)
+        if (rank_ns_plan(cn.data(), mu_h, K, l0, c->coef_h, &plan, c->ns_degrees) != 0)
             return fail(GGL_E_SOLVER, "L-step: non-finite C (diverged iterate?)");
         CopySegs up;
         up.add(c->coef, c->coef_h, (size_t)plan.products * NS_SLOT(K) * sizeof(double));
@@ -812,7 +812,7 @@ static int rank_step(ggl_ctx* c)
         double dev = 0.0;
         for (int k = 0; k < K; ++k) dev = std::max(dev, c->maxdev_h[k]);
         // |T_last - I| = |I - X^2|/2 of the iterate BEFORE the last step; the last step squares it
-        if (std::isfinite(dev) && 2.0 * dev <= 1e-4) {
+        if (std::isfinite(dev) && dev <= plan.check) {
             PE(c, GGL_PH_EIG_L);
             return GGL_OK;
         }

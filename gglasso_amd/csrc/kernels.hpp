@@ -148,7 +148,8 @@ static constexpr double NS_KAPPA_LIMIT = 1e12;
 // of the whole stack (K p^3 flop each); deg[it]: degree (3, 5 or 9) of step it in x = sqrt(eig(Z Y))
 struct NsPlan {
     int steps = 0; int products = 0; bool stable = false; double kappa = 0.0; int units = 0;
-    unsigned char deg[NS_MAX_STEPS] = {};
+    double check = 5e-5;      // L-step: largest max|T_last - I| that still means "every eigenvalue resolved"
+    unsigned char deg[NS_RANK_MAX_STEPS] = {};
 };
 // W = ((Theta - L) - X) - beta_k S from the lower triangle, mirrored (exactly symmetric)
 // also: bounds[k] = {|W_k|_inf, |W_k|_F^2} (device, K*2 doubles) through the scratch arrays
@@ -185,7 +186,8 @@ void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int
 // to 1 if some out[k] exceeds cuse[k] or is not finite
 void launch_bound_final(hipStream_t st, const double* part2, const double* cwpart, int nbb, int K, double* out, int mode,
                         const double* cuse = nullptr, int* flag = nullptr, int* flag_host = nullptr);
-int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan);
+int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan,
+                 int degrees = 9);
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
                  double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot = 0);
 

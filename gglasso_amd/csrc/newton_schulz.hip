@@ -345,14 +345,17 @@ static NsStep ns_nonic_step(double l)
     return r;
 }
 
-static int ns_step_cost(int d, bool first, bool last)
+// kind 0: coupled square-root iteration (Omega-step); kind 1: sign iteration X <- X t(X^2) (L-step), where every
+// step costs X^2, [t], X t: 2 / 3 / 4 products
+static int ns_step_cost(int kind, int d, bool first, bool last)
 {
     const int base = (d == 3) ? 0 : (d == 5 ? 1 : 2);     // products inside t(M) beyond M itself
+    if (kind == 1) return base + 2;
     if (first) return base;                               // Z1 = T1 from A', B'; Y1 (or Omega) one product unless cubic
     return base + (last ? 2 : 3);                         // M, [t(M)], Y T, [T Z]
 }
 
-struct NsSeq { int n = 0; int cost = 1 << 30; unsigned char deg[NS_MAX_STEPS]; NsStep st[NS_MAX_STEPS]; };
+struct NsSeq { int n = 0; int cost = 1 << 30; unsigned char deg[NS_RANK_MAX_STEPS]; NsStep st[NS_RANK_MAX_STEPS]; };
 
 // The schedule is a deterministic function of a QUANTISED interval: l is rounded down on a geometric grid
 // (ratio 1.01) below 0.5 and 1-l is rounded up on a geometric grid (ratio 1.02) above, at the start and after
@@ -375,6 +378,7 @@ static NsKey ns_quantise(double l)
 
 struct NsPlanner {
     int degrees;
+    int kind;
     struct Node { int cost; int d; };
     std::unordered_map<long long, NsStep> steps;          // (key, degree) -> step
     std::unordered_map<int, Node> togo;                   // key -> cheapest completion as a non-first step
@@ -390,18 +394,21 @@ struct NsPlanner {
     static bool converged(const NsStep& s) { return 1.0 - s.lnew < 4e-16; }
     Node best_from(const NsKey& q, int depth)
     {
+        // the cost-to-go of a key must not depend on how deep the query was that first reached it (it is memoised):
+        // no depth cut here -- every step strictly narrows the interval, so the recursion is finite (< 40 levels
+        // down to l = 1e-13); schedules that are too long are refused where they are used
         auto it = togo.find(q.key);
         if (it != togo.end()) return it->second;
         Node b = {1 << 29, 3};
-        if (depth < NS_MAX_STEPS - 1) {
+        {
             for (int d = 3; d <= degrees; d += (d == 5 ? 4 : 2)) {
                 const NsStep& s = step(q, d);
                 int cost;
-                if (converged(s)) cost = ns_step_cost(d, false, true);
+                if (converged(s)) cost = ns_step_cost(kind, d, false, true);
                 else {
                     const NsKey nq = ns_quantise(s.lnew);
                     if (nq.l <= q.l) continue;            // no progress (cannot happen for l in (0,1))
-                    cost = ns_step_cost(d, false, false) + best_from(nq, depth + 1).cost;
+                    cost = ns_step_cost(kind, d, false, false) + best_from(nq, depth + 1).cost;
                 }
                 if (cost < b.cost) b = {cost, d};
             }
@@ -419,43 +426,51 @@ struct NsPlanner {
         int bd = 3, bc = 1 << 30;
         for (int d = 3; d <= degrees; d += (d == 5 ? 4 : 2)) {
             const NsStep& s = step(q0, d);
-            int cost = ns_step_cost(d, true, converged(s));
+            int cost = ns_step_cost(kind, d, true, converged(s));
             if (!converged(s)) cost += best_from(ns_quantise(s.lnew), 1).cost;
             if (cost < bc) { bc = cost; bd = d; }
         }
         best.cost = bc;
         NsKey q = q0;
         int d = bd;
-        for (int i = 0; i < NS_MAX_STEPS; ++i) {
+        bool done = false;
+        for (int i = 0; i < NS_RANK_MAX_STEPS; ++i) {
             const NsStep& s = step(q, d);
             best.deg[i] = (unsigned char)d;
             best.st[i] = s;
             best.n = i + 1;
-            if (converged(s)) break;
+            if (converged(s)) { done = true; break; }
             q = ns_quantise(s.lnew);
             d = best_from(q, i + 1).d;
         }
+        if (!done) best.cost = 1 << 30;            // longer than any table: refused by the callers
         return plans.emplace(q0.key, best).first->second;
     }
 };
 
 static const NsSeq& ns_mixed_schedule(double l, int degrees)
 {
-    static thread_local NsPlanner planners[3] = {{3}, {5}, {9}};
+    static thread_local NsPlanner planners[3] = {{3, 0}, {5, 0}, {9, 0}};
+    return planners[degrees >= 9 ? 2 : (degrees >= 5 ? 1 : 0)].plan(l);
+}
+
+static const NsSeq& ns_sign_schedule(double l, int degrees)
+{
+    static thread_local NsPlanner planners[3] = {{3, 1}, {5, 1}, {9, 1}};
     return planners[degrees >= 9 ? 2 : (degrees >= 5 ? 1 : 0)].plan(l);
 }
 
 int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units)
 {
     if (!(l > 0.0) || !(l <= 1.0)) return -1;
-    const NsSeq& sq = ns_mixed_schedule(l, degrees);
+    const NsSeq& sq = (degrees >= 100) ? ns_sign_schedule(l, degrees - 100) : ns_mixed_schedule(l, degrees);
     if (sq.n < 1 || sq.n > max_steps || sq.cost >= (1 << 29)) return -1;
     for (int i = 0; i < sq.n; ++i) {
         deg[i] = sq.deg[i];
         for (int j = 0; j < 5; ++j) coef[6 * i + j] = sq.st[i].t[j];
         coef[6 * i + 5] = sq.st[i].lnew;
     }
-    *units = 2 + sq.cost;
+    *units = (degrees >= 100) ? sq.cost : 2 + sq.cost;
     return sq.n;
 }
 
@@ -532,7 +547,7 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
     };
     if (!stable) {
         const NsSeq& sq = ns_mixed_schedule(lmin, degrees);
-        if (sq.n < 1 || sq.cost >= (1 << 29)) return -2;
+        if (sq.n < 1 || sq.n > NS_MAX_STEPS || sq.cost >= (1 << 29)) return -2;
         const int n = sq.n;
         plan->steps = n;
         plan->units = 2 + sq.cost;
@@ -839,45 +854,71 @@ void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int
 }
 
 // cnorm_h[k] >= |C_k|_2, mu_h[k] = mu1_k / rho.  Fills the coefficient table; returns steps.
-int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan)
+int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan, int degrees)
 {
-    std::vector<double> al = ns_schedule(l0 < 0.5 ? l0 : 0.5, NS_RANK_MAX_STEPS);
-    const int n = (int)al.size();
-    if (n < 2) return -1;
+    // first step: cubic with the shift by mu folded into its two products; then the cheapest mix of cubic, quintic
+    // and degree-nine steps for what is left of [l,1] (every step X^2, [t], X t: 2 / 3 / 4 products)
+    const double lq = l0 < 0.5 ? l0 : 0.5;
+    const NsStep s0 = ns_cubic_step(lq);
+    const double a0 = (lq < 0.99) ? std::sqrt(3.0 / (1.0 + lq + lq * lq)) : 1.0;
+    const bool more = 1.0 - s0.lnew >= 4e-16;
+    const NsSeq* sq = more ? &ns_sign_schedule(s0.lnew, degrees) : nullptr;
+    const int n = 1 + (sq ? sq->n : 0);
+    if (n < 2 || n > NS_RANK_MAX_STEPS || (sq && sq->cost >= (1 << 29))) return -1;
     plan->steps = n;
-    plan->products = 2 * n + 1;
     plan->stable = false;
+    plan->deg[0] = 3;
+    for (int i = 1; i < n; ++i) plan->deg[i] = sq->deg[i - 1];
+    // Residual check of the result: an eigenvalue x of the iterate before the last step shows up as |t(x^2) - 1| ~
+    // e = 1 - |x| in T_last, and the last step turns it into a sign error of 1.5 e^2 (cubic), 2.5 e^3 (quintic) or
+    // 7.9 e^5 (degree nine).  Accept up to a sign error of 4e-9 on such an eigenvalue -- it sits within l0 |B| of
+    // the threshold, so its contribution |lambda| * error to L is far below 1e-14 |B| -- i.e. e up to:
+    const int dl = plan->deg[n - 1];
+    plan->check = (dl == 3) ? 5e-5 : (dl == 5 ? 1.1e-3 : 8e-3);
+    int g = 0;
     for (int k = 0; k < K; ++k) {
         const double mu = mu_h[k];
         const double nb = (cnorm_h[k] + mu) * (1.0 + 1e-10);      // |C - mu I| <= |C| + mu
         if (!(nb > 0.0) || !std::isfinite(nb)) return -1;
-        auto put = [&](int g, double cI, double cAcc, double cE, double dI, double dC) {
-            double* o = coef_h + (size_t)g * NS_SLOT(K) + (size_t)k * 5;
+        auto put = [&](int gg, double cI, double cAcc, double cE, double dI, double dC) {
+            double* o = coef_h + (size_t)gg * NS_SLOT(K) + (size_t)k * 5;
             o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = dI; o[4] = dC;
         };
-        int g = 0;
-        const double a0 = al[0], s2 = a0 * a0 / (nb * nb);
+        g = 0;
+        const double s2 = a0 * a0 / (nb * nb);
         // T0 = 1.5 I - 0.5 a0^2 X0^2, X0 = (C - mu I)/nb   [product C*C, E = C]
         put(g++, 1.5 - 0.5 * s2 * mu * mu, -0.5 * s2, s2 * mu, 0.0, 0.0);
         // X1 = a0 X0 T0 = (a0/nb) C T0 - (a0 mu/nb) T0      [product C*T0, E = T0]
         put(g++, 0.0, a0 / nb, -a0 * mu / nb, 0.0, 0.0);
         for (int it = 1; it < n; ++it) {
-            const double a = al[it];
-            put(g++, 1.5, -0.5 * a * a, 0.0, 0.0, 0.0);          // T = 1.5 I - 0.5 a^2 X^2
-            put(g++, 0.0, a, 0.0, 1.0, 1.0);                     // X <- a X T ; second output P2 = I + X
+            const double* t = sq->st[it - 1].t;
+            const int d = sq->deg[it - 1];
+            if (d == 3) {
+                put(g++, t[0], t[1], 0.0, 0.0, 0.0);             // T = t0 I + t1 X^2
+            } else if (d == 5) {
+                put(g++, 0.0, 1.0, 0.0, 0.0, 0.0);               // M = X^2
+                put(g++, t[0], t[2], t[1], 0.0, 0.0);            // T = t0 I + t2 M^2 + t1 M
+            } else {
+                const double a = t[3] / (2.0 * t[4]), dl = t[2] / t[4] - a * a, e = t[1] - t[4] * dl * a;
+                put(g++, 0.0, 1.0, 0.0, 0.0, 0.0);               // M = X^2
+                put(g++, 0.0, 1.0, a, dl, 1.0);                  // Q = M^2 + a M; second output Q + d I
+                put(g++, t[0], t[4], e, 0.0, 0.0);               // T = f I + t4 Q (Q + d I) + e M
+            }
+            put(g++, 0.0, 1.0, 0.0, 1.0, 1.0);                   // X <- X T ; second output P2 = I + X (last step)
         }
         // L = (C - mu I) P2 / 2 = 0.5 C P2 - 0.5 mu P2        [product C*P2, E = P2]
         put(g++, 0.0, 0.5, -0.5 * mu, 0.0, 0.0);
     }
+    plan->products = g;
     return 0;
 }
-
-// C preserved.  Xa, Xb, Tb, P2: scratch stacks.  maxdev: device [K], receives max|T_last - I|.
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
                  double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot)
 {
     // maxdev must be zero on entry; cslot: doubles between the coefficient slots of successive launches
-    // (0 = NS_SLOT(K); a sub-batch of a larger table passes the table's slot size)
+    // (0 = NS_SLOT(K); a sub-batch of a larger table passes the table's slot size).
+    // scratch of the higher-degree steps: M = X^2 in `out` (free until the last launch), Q in P2 (free until the last
+    // step's second output), Q + d I in the other X buffer (free until X T is written there)
     const size_t cs = cslot ? cslot : NS_SLOT(K);
     int g = 0;
     const int n = plan.steps;
@@ -886,7 +927,17 @@ void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const
     launch_symm(st, C, Tb, X, nullptr, Tb, coef_d + cs * g++, K, p, variant);
     for (int it = 1; it < n; ++it) {
         const bool last = (it == n - 1);
-        launch_symm(st, X, X, Tb, nullptr, nullptr, coef_d + cs * g++, K, p, variant, last ? maxdev : nullptr);
+        double* md = last ? maxdev : nullptr;        // max |T_last - I| = |t(X^2) - 1|: the residual check
+        if (plan.deg[it] == 5) {
+            launch_symm(st, X, X, out, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
+            launch_symm(st, out, out, Tb, nullptr, out, coef_d + cs * g++, K, p, variant, md);
+        } else if (plan.deg[it] == 9) {
+            launch_symm(st, X, X, out, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
+            launch_symm(st, out, out, P2, Xn, out, coef_d + cs * g++, K, p, variant);
+            launch_symm(st, P2, Xn, Tb, nullptr, out, coef_d + cs * g++, K, p, variant, md);
+        } else {
+            launch_symm(st, X, X, Tb, nullptr, nullptr, coef_d + cs * g++, K, p, variant, md);
+        }
         launch_symm(st, X, Tb, Xn, last ? P2 : nullptr, nullptr, coef_d + cs * g++, K, p, variant);
         std::swap(X, Xn);
     }

@@ -179,7 +179,9 @@ int ggl_dev_mfma_f64_peak(double *tflops_out);
  * (x = sqrt(eig(Z Y))).  degrees 3 = cubic steps, 5 = cubic/quintic mix, 9 = cubic/quintic/degree-nine mix.
  * deg_out[max_steps] receives 3, 5 or 9 per step, coef_out[max_steps*6] = {t0..t4,l_after} of
  * x -> x (t0 + t1 x^2 + ... + t4 x^8), *units_out the number of
- * symmetric products of the stack (incl. A' and B').  Returns the number of steps or GGL_E_ARG. */
+ * symmetric products of the stack (incl. A' and B').  degrees + 100: the schedule of the L-step's sign iteration
+ * instead (every step costs X^2, [t], X t: 2 / 3 / 4 products; *units_out without the first and the last product).
+ * Returns the number of steps or GGL_E_ARG. */
 int ggl_dev_ns_schedule(double l, int degrees, int max_steps, int *deg_out, double *coef_out, int *units_out);
 /* per-workgroup timestamps {start, loop begin, loop end, end, XCC id} of one launch of the 64x64 kernel */
 int ggl_dev_symm_timeline(int K, int p, long long *out, int max_blocks, int *nblocks_out);

@@ -316,6 +316,23 @@ def test_rank_newton_schulz_sizes_and_thresholds(ops, K, p):
             assert np.abs(out).max() <= 1e-12
 
 
+@pytest.mark.parametrize("degrees", ["3", "5", "9"])
+def test_rank_newton_schulz_step_degrees(ops, degrees, monkeypatch):
+    """The sign iteration of the L-step under every cap of the step degree (cubic only / + quintic / + degree nine):
+    same accuracy, and the residual check (which reads max|T_last - I| of a T that has an E term for the higher
+    degrees) must accept the converged result instead of falling back."""
+    monkeypatch.setenv("GGL_NS_DEGREES", degrees)
+    rng = np.random.default_rng(61)
+    K, p = 3, 180
+    W = _sym(rng, K, p, 1.0)
+    for beta in (0.05, 1.0, 5.0):
+        b = np.full(K, beta)
+        ref = orc.rank_stack(W, b)
+        out = ops.rank_matrix(W, b, method=3)
+        assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(W).max()) * p, (degrees, beta)
+        assert np.array_equal(out, out.transpose(0, 2, 1))
+
+
 def test_rank_newton_schulz_eigenvalue_at_the_threshold(ops):
     """An eigenvalue within 1e-13 of the threshold cannot be resolved by any schedule: the residual check
     must catch it (retry, then eigendecomposition fallback) and the result must still be exact."""
