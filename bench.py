@@ -217,12 +217,14 @@ def main():
     if rank == 0:
         eig_jacobi = (args.eig == _lib.EIG_JACOBI) or (args.eig == _lib.EIG_AUTO and p <= _lib.JACOBI_MAX_P)
         phases = {ph: {"ms_per_launch": ms / cnt, "launches": cnt} for ph, (ms, cnt) in prof.items() if cnt}
-        if "eig_omega2" in phases:
-            # the Newton-Schulz Omega-step is timed in two event pairs (before / after the spectral-bound sync)
-            tot = sum(phases[q]["ms_per_launch"] * phases[q]["launches"] for q in ("eig_omega", "eig_omega2"))
+        if "eig_omega" in phases and ns1["launches"] > ns0["launches"]:
+            # the Newton-Schulz Omega-step is timed in one event pair (speculative step: no host sync inside) or two
+            # (before / after the spectral-bound sync); either way: total elapsed time / product launches
+            tot = sum(phases[q]["ms_per_launch"] * phases[q]["launches"] for q in ("eig_omega", "eig_omega2")
+                      if q in phases)
             nl = max(1, ns1["launches"] - ns0["launches"])
             phases["eig_omega"] = {"ms_per_launch": tot / nl, "launches": nl}
-            del phases["eig_omega2"]
+            phases.pop("eig_omega2", None)
         hot = ("eig_omega", "eig_L")
 
         def per_iter(ph):   # hot phases were timed over the timed region, the others over the extra pass
@@ -258,6 +260,8 @@ def main():
         else:
             achieved, peak = amount / sec / 1e12, FP64_MFMA_PEAK_TF
         its = args.steps / dt
+        # the committed rocprofv3 / PMC summaries are of the default command only
+        profiled_cfg = (args.workload == "ggl_K32_p500" and args.eig == 0 and not os.environ.get("GGL_NS_MODE"))
         iter_bytes = (120.0 if latent else 72.0) * Kl * p * p          # SURVEY.md 8(d), per GPU
         out = {
             "metric": "ADMM iters/sec on (K=32,p=500) GGL at 1/2/4/8 GPUs; eigh HBM GB/s vs peak", "value": its, "unit": "ADMM iters/s",
@@ -271,9 +275,9 @@ def main():
                                                                          else "rocsolver_dsyevd+mfma_recon")},
             "roofline": {"kernel": kernel_name, "phase": dom, "launches_per_step": phases[dom]["launches"] / args.steps,
                          "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": pmc_traffic(kernel_name),
+                         "frac": achieved / peak, "traffic": pmc_traffic(kernel_name) if profiled_cfg else None,
                          "ms_per_launch": phases[dom]["ms_per_launch"],
-                         "rocprof_kernel_avg_ms": rocprof_kernel_avg_ms(kernel_name),
+                         "rocprof_kernel_avg_ms": rocprof_kernel_avg_ms(kernel_name) if profiled_cfg else None,
                          "concurrent_launch_sequences": 2 if (omega_ns and dom in ("eig_omega", "eig_L") and Kl >= 16
                                                               and 600 <= t64 * (t64 + 1) // 2 * Kl <= 2048) else 1,
                          "note": ("ms_per_launch = elapsed time of the phase / its kernel launches; at this size two parts "
