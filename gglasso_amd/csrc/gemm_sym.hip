@@ -130,10 +130,12 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     };
     // all fragment reads of the slab first, then the MFMAs back to back: one LDS round trip per slab
     // instead of one per k-quad
-    auto compute = [&]() {
+    // nq: k-quads of the slab that lie inside the matrix (the last slab of p = 200 at BK = 32 has 2 of 8)
+    auto compute = [&](int nq) {
         double af[BK / 4][Cfg::TI], bf[BK / 4][Cfg::TJ];
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
+            if (kk >= nq) break;
             const int row = kk * 4 + (lane >> 4);
 #pragma unroll
             for (int i = 0; i < Cfg::TI; ++i) af[kk][i] = As[row * Cfg::LDS_LD + wr + i * 16 + (lane & 15)];
@@ -141,7 +143,8 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
             for (int j = 0; j < Cfg::TJ; ++j) bf[kk][j] = Bs[row * Cfg::LDS_LD + wc + j * 16 + (lane & 15)];
         }
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk)
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            if (kk >= nq) break;
 #pragma unroll
             for (int i = 0; i < Cfg::TI; ++i)
 #pragma unroll
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
                     if (ABL == 2) { acc[i][j][0] += af[kk][i] * bf[kk][j]; continue; }   // ablation: no MFMA
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
                 }
+        }
     };
 
     // On a diagonal tile a wave whose sub-tile lies entirely below the diagonal produces nothing that is
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
                 if (ABL != 4) stage(ms, ra[s], rb[s]);       // ABL 4: ds_read + MFMA only; ABL 5: + ds_write
                 if (ABL != 4 && ABL != 5) __syncthreads();
                 fetch(ms + NST * BK, ra[s], rb[s]);          // past the end: clamped, never staged
-                if (!dead_wave) compute();
+                if (!dead_wave) compute(min(BK / 4, (p - ms + 3) / 4));
                 if (ABL != 4 && ABL != 5) __syncthreads();
             }
         }
@@ -363,8 +367,10 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
         if (!dead_wave) {
             const double* As = smem + (size_t)buf * 2 * SLAB;
             const double* Bs = As + SLAB;
+            const int nq = min(BK / 4, (valid + 3) / 4);      // k-quads inside the matrix (last slab: 1 of 4 at p = 500)
 #pragma unroll
             for (int kq4 = 0; kq4 < BK / 4; ++kq4) {
+                if (kq4 >= nq) break;
                 const int row = kq4 * 4 + (lane >> 4);
                 const int sw = 16 * (row & 1);
                 double af[TI], bf[TJ];
