@@ -90,11 +90,11 @@ struct ggl_ctx {
     int* sweeps = nullptr;
     long long ns_stable_calls = 0;
     double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
-    double *bounds = nullptr, *bounds_h = nullptr;   // [K][2]
+    double* bounds_h = nullptr;                // pinned: spectral / norm bound per instance, written by k_bound_final
 
     double* snapT = nullptr;                   // per-instance snapshots of Theta (model selection), lazy
     double* nbrow = nullptr;                   // [K][p] row abs-sums of B' (Collatz-Wielandt weight vector)
-    double *nbpart = nullptr, *nbpart_h = nullptr;   // [K][blocks][2] norm bounds of C (L-step)
+    double* nbpart = nullptr;                  // [K][blocks][2] + [K][blocks]: norm / Collatz-Wielandt partials
     double *maxdev = nullptr, *maxdev_h = nullptr;   // [K] residual of the sign iteration
     bool rank_ns = false;                            // L-step by sign Newton-Schulz (else eigendecomposition)
     double rank_l0 = 1e-6;                           // resolution of the scaling schedule
@@ -198,12 +198,10 @@ static int ctx_alloc(ggl_ctx* c)
         HIPCHK(hipMalloc(&c->coef, cl));
         HIPCHK(hipHostMalloc(&c->coef_h, cl));
         const size_t bl = 2 * (size_t)c->K * sizeof(double);
-        HIPCHK(hipMalloc(&c->bounds, bl));
         HIPCHK(hipHostMalloc(&c->bounds_h, bl));
         const size_t nbl = 3 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);   // + Collatz-Wielandt maxima
         HIPCHK(hipMalloc(&c->nbrow, (size_t)c->K * c->p * sizeof(double)));
         HIPCHK(hipMalloc(&c->nbpart, nbl));
-        HIPCHK(hipHostMalloc(&c->nbpart_h, nbl));
         HIPCHK(hipMalloc(&c->cuse, c->K * sizeof(double)));
         HIPCHK(hipHostMalloc(&c->cuse_h, c->K * sizeof(double)));
         HIPCHK(hipMalloc(&c->spec_flag, ggl_ctx::MAX_PARTS * sizeof(int)));
@@ -279,9 +277,8 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
-                      c->nsT, c->coef, c->bounds, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->cuse};
+                      c->nsT, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->cuse};
     if (c->spec_flag) (void)hipFree(c->spec_flag);
-    if (c->nbpart_h) (void)hipHostFree(c->nbpart_h);
     if (c->cuse_h) (void)hipHostFree(c->cuse_h);
     if (c->spec_flag_h) (void)hipHostFree(c->spec_flag_h);
     free(c->spec_c);
@@ -585,7 +582,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             launch_copy_small(sh, sg);
             if (h == 0) PB(c, GGL_PH_FORM_W);
             launch_form_W_sym(sh, c->W + k0 * pp, c->Theta + k0 * pp, latent ? c->L + k0 * pp : nullptr, c->X + k0 * pp,
-                              c->S + k0 * pp, beta + k0, nullptr, nullptr, nullptr, Kh[h], c->p);
+                              c->S + k0 * pp, beta + k0, Kh[h], c->p);
             if (h == 0) { PE(c, GGL_PH_FORM_W); PB(c, GGL_PH_EIG_OMEGA); }
             double* Ap = c->nsYP[0] + k0 * pp;
             double* Bp = c->nsYP[0] + c->n + k0 * pp;

@@ -152,12 +152,9 @@ struct NsPlan {
     unsigned char deg[NS_RANK_MAX_STEPS] = {};
 };
 // W = ((Theta - L) - X) - beta_k S from the lower triangle, mirrored (exactly symmetric)
-// also: bounds[k] = {|W_k|_inf, |W_k|_F^2} (device, K*2 doubles) through the scratch arrays
-// rowpart (K * form_W_tiles(p) * p doubles) and sqpart (K * T(T+1)/2 doubles, T = form_W_tiles(p))
 int form_W_tiles(int p);
 void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
-                       const double* S, const double* betaK, double* rowpart, double* sqpart, double* bounds,
-                       int K, int p);
+                       const double* S, const double* betaK, int K, int p);
 // Omega-step in two phases around the one host sync that fetches the spectral bound:
 //   ns_prepare: A' = W^2 + 4 beta I and B' = A'^2 into AB = [A' | B'] (pre_d: 2 coefficient slots)
 //   -- host: c_k = sqrt(min(|B'_k|_inf, |B'_k|_F)) >= lambda_max(A'_k); ns_plan --

@@ -26,17 +26,13 @@ namespace ggl {
 // ---------------------------------------------------------------------------------------------
 static constexpr int FT = 32, FTY = 8, FQ = FT / FTY;
 
-// Also emits what the spectral bound needs, so that W is not read a second time:
-//   rowpart[k][c][i] = sum over the columns j of column tile c of |W_ij|
-//   sqpart[k][block] = sum of W_ij^2 over the block's elements
 template <bool HAS_L>
 __global__ __launch_bounds__(256) void k_form_W_sym(double* __restrict__ W, const double* __restrict__ Theta,
                                                     const double* __restrict__ L, const double* __restrict__ X,
                                                     const double* __restrict__ S, const double* __restrict__ betaK,
-                                                    double* __restrict__ rowpart, double* __restrict__ sqpart, int p)
+                                                    int p)
 {
     __shared__ double tile[FT][FT + 1];
-    __shared__ double shsq[4];
     const int k = blockIdx.y;
     const int T = (p + FT - 1) / FT;
     int I = 0, b = blockIdx.x;
@@ -47,8 +43,6 @@ __global__ __launch_bounds__(256) void k_form_W_sym(double* __restrict__ W, cons
     const int tx = threadIdx.x, ty = threadIdx.y;
     const double beta = betaK[k];
     const size_t base = (size_t)k * p * p;
-    double sq = 0.0;
-    double nat[FQ];
     // native element of the lower tile: (J0 + r, I0 + tx)
 #pragma unroll
     for (int q = 0; q < FQ; ++q) {
@@ -63,8 +57,6 @@ __global__ __launch_bounds__(256) void k_form_W_sym(double* __restrict__ W, cons
             W[o] = w;
         }
         tile[r][tx] = w;
-        nat[q] = fabs(w);
-        sq += w * w;
     }
     __syncthreads();
     // mirrored element (I0 + r, J0 + tx) = tile[tx][r]
@@ -72,87 +64,21 @@ __global__ __launch_bounds__(256) void k_form_W_sym(double* __restrict__ W, cons
     for (int q = 0; q < FQ; ++q) {
         const int r = ty + FTY * q;
         const int gi = I0 + r, gj = J0 + tx;
-        double m = 0.0;
-        if (gi < p && gj < p && (!diag || tx > r)) {
-            m = tile[tx][r];
-            W[base + (size_t)gi * p + gj] = m;
-            sq += m * m;
-        }
-        // row sums over the 32 lanes that share this row (a half wave: tx is the fast lane index)
-        double rs_nat = nat[q], rs_mir = fabs(m);
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-            rs_nat += __shfl_xor(rs_nat, off, 64);
-            rs_mir += __shfl_xor(rs_mir, off, 64);
-        }
-        if (tx == 0 && rowpart) {
-            double* rp = rowpart + (size_t)k * T * p;
-            if (diag) {
-                if (I0 + r < p) rp[(size_t)I * p + I0 + r] = rs_nat + rs_mir;
-            } else {
-                if (J0 + r < p) rp[(size_t)I * p + J0 + r] = rs_nat;     // row J0+r, column tile I
-                if (I0 + r < p) rp[(size_t)J * p + I0 + r] = rs_mir;     // row I0+r, column tile J
-            }
-        }
-    }
-    sq = wave_sum(sq);
-    const int tid = ty * FT + tx;
-    if ((tid & 63) == 0) shsq[tid >> 6] = sq;
-    __syncthreads();
-    if (tid == 0 && sqpart) sqpart[(size_t)k * gridDim.x + blockIdx.x] = (shsq[0] + shsq[1]) + (shsq[2] + shsq[3]);
-}
-
-// bounds[k] = { max_i sum_j |W_ij| , sum_ij W_ij^2 } from the partials above (fixed order)
-__global__ __launch_bounds__(256) void k_bounds_final(const double* __restrict__ rowpart,
-                                                      const double* __restrict__ sqpart, int T, int nblk, int p,
-                                                      double* __restrict__ bounds)
-{
-    __shared__ double sh[256];
-    const int k = blockIdx.x;
-    const double* rp = rowpart + (size_t)k * T * p;
-    double mx = 0.0;
-    for (int i = threadIdx.x; i < p; i += 256) {
-        double s = 0.0;
-        for (int c = 0; c < T; ++c) s += rp[(size_t)c * p + i];
-        mx = fmax(mx, s);
-    }
-    sh[threadIdx.x] = mx;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + off]);
-        __syncthreads();
-    }
-    const double rowmax = sh[0];
-    __syncthreads();
-    double sq = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += 256) sq += sqpart[(size_t)k * nblk + b];
-    sh[threadIdx.x] = sq;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        bounds[2 * k + 0] = rowmax;
-        bounds[2 * k + 1] = sh[0];
+        if (gi < p && gj < p && (!diag || tx > r)) W[base + (size_t)gi * p + gj] = tile[tx][r];
     }
 }
 
 int form_W_tiles(int p) { return (p + FT - 1) / FT; }
 
-// rowpart: K * form_W_tiles(p) * p doubles; sqpart: K * T(T+1)/2 doubles; bounds: K * 2 doubles
 void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const double* L, const double* X,
-                       const double* S, const double* betaK, double* rowpart, double* sqpart, double* bounds, int K,
-                       int p)
+                       const double* S, const double* betaK, int K, int p)
 {
     const int T = (p + FT - 1) / FT;
-    const int nblk = T * (T + 1) / 2;
-    dim3 grid(nblk, K), blk(FT, FTY);
+    dim3 grid(T * (T + 1) / 2, K), blk(FT, FTY);
     if (L)
-        hipLaunchKernelGGL(k_form_W_sym<true>, grid, blk, 0, st, W, Theta, L, X, S, betaK, rowpart, sqpart, p);
+        hipLaunchKernelGGL(k_form_W_sym<true>, grid, blk, 0, st, W, Theta, L, X, S, betaK, p);
     else
-        hipLaunchKernelGGL(k_form_W_sym<false>, grid, blk, 0, st, W, Theta, L, X, S, betaK, rowpart, sqpart, p);
-    if (bounds) hipLaunchKernelGGL(k_bounds_final, dim3(K), dim3(256), 0, st, rowpart, sqpart, T, nblk, p, bounds);
+        hipLaunchKernelGGL(k_form_W_sym<false>, grid, blk, 0, st, W, Theta, L, X, S, betaK, p);
 }
 
 // ---------------------------------------------------------------------------------------------
