@@ -119,7 +119,9 @@ def test_status_strings_like_reference_tests(sol):
 
 
 @pytest.mark.parametrize("reg,K,p,latent", [("GGL", 4, 96, False), ("FGL", 5, 90, True), ("GGL", 3, 160, False),
-                                            ("FGL", 40, 40, False), ("GGL", 6, 150, True)])
+                                            ("FGL", 40, 40, False), ("GGL", 6, 150, True),
+                                            # odd p: the direct-to-LDS product kernel needs 16-byte rows, k_symm_tn steps in
+                                            ("GGL", 3, 151, False), ("FGL", 7, 133, True)])
 def test_oracle_trajectory_mid_sizes(sol, reg, K, p, latent):
     """Seeded problems larger than the fixtures, HIP path vs CPU oracle (covers the LDS-Jacobi /
     rocSOLVER+MFMA switch at p = 128 and the FGL tile switch at K = 32)."""
