@@ -35,6 +35,7 @@ _SIGNATURES = {
     "ggl_set_lambda1_mask": ([_vp, _dp], _i),
     "ggl_admm_step": ([_vp, _d, _d, _d, _i, _i, _dp, _dp, _dp], _i),
     "ggl_step_omega": ([_vp, _d, _i, _dp], _i),
+    "ggl_step_omega_spec": ([_vp, _d, _i, _dp], _i),
     "ggl_step_group_partial": ([_vp, _d, _d], _i),
     "ggl_step_finish": ([_vp, _d, _d, _d, _i, _i, _dp, _i, _dp], _i),
     "ggl_norms_read": ([_vp, _dp], _i),

@@ -221,6 +221,32 @@ void launch_scale_batch(hipStream_t st, double* X, const double* fK, int K, int 
     hipLaunchKernelGGL(k_scale_batch, dim3(elementwise_blocks(p), K), dim3(EW_THREADS), 0, st, X, fK, pp);
 }
 
+// K-sharded speculation: the validation flags of this rank travel with the (p,p) all-reduce of the GGL Theta-step
+// as one extra double (pack), and come back as the number of ranks that missed (unpack: > 0 => every rank skips
+// its Theta-step and repeats the iteration).
+__global__ void k_spec_pack(const int* __restrict__ flags, double* __restrict__ dst)
+{
+    dst[0] = (flags != nullptr && (flags[0] | flags[1] | flags[2] | flags[3]) != 0) ? 1.0 : 0.0;
+}
+
+__global__ void k_spec_unpack(const double* __restrict__ src, int* __restrict__ flag, int* __restrict__ flag_host)
+{
+    if (src[0] > 0.5) {
+        *flag = 1;
+        *flag_host = 1;
+    }
+}
+
+void launch_spec_pack(hipStream_t st, const int* flags, double* dst)
+{
+    hipLaunchKernelGGL(k_spec_pack, dim3(1), dim3(1), 0, st, flags, dst);
+}
+
+void launch_spec_unpack(hipStream_t st, const double* src, int* flag, int* flag_host)
+{
+    hipLaunchKernelGGL(k_spec_unpack, dim3(1), dim3(1), 0, st, src, flag, flag_host);
+}
+
 __global__ __launch_bounds__(256) void k_copy_small(CopySegs sg)
 {
     const int s = blockIdx.y;

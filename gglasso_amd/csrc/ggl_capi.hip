@@ -176,8 +176,9 @@ static int ctx_alloc(ggl_ctx* c)
     HIPCHK(hipMalloc(&c->par, 6 * (size_t)c->K * sizeof(double)));
     HIPCHK(hipHostMalloc(&c->par_h, 6 * (size_t)c->K * sizeof(double)));
     HIPCHK(hipMalloc(&c->mask, (size_t)c->p * c->p * sizeof(double)));
-    HIPCHK(hipMalloc(&c->groupsq, (size_t)c->p * c->p * sizeof(double)));
-    HIPCHK(hipMemsetAsync(c->groupsq, 0, (size_t)c->p * c->p * sizeof(double), c->stream));
+    // (p,p) + one trailing double: the speculation flag of K-sharded runs rides on the same all-reduce
+    HIPCHK(hipMalloc(&c->groupsq, ((size_t)c->p * c->p + 8) * sizeof(double)));
+    HIPCHK(hipMemsetAsync(c->groupsq, 0, ((size_t)c->p * c->p + 8) * sizeof(double), c->stream));
     HIPCHK(hipMalloc(&c->sqwork, (size_t)ggl_chunks(c->K, c->p) * c->p * c->p * sizeof(double)));
     size_t pl = (size_t)c->K * elementwise_blocks(c->p) * GGL_NNORM;
     pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_GGL, c->K) * GGL_NNORM);
@@ -335,6 +336,7 @@ extern "C" void* ggl_device_ptr(ggl_ctx* c, int which)
 extern "C" int ggl_set_S(ggl_ctx* c, const double* S)
 {
     ARGCHK(c && S, "ctx, S");
+    c->spec_have = false;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->S, S, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -346,6 +348,7 @@ static int host_reduce(ggl_ctx* c, int rows, int nv, double* out /*nv*/, bool ta
 extern "C" int ggl_set_state(ggl_ctx* c, const double* Omega, const double* Theta, const double* L, const double* X)
 {
     ARGCHK(c, "ctx");
+    c->spec_have = false;      // bounds of another iterate say nothing about this one
     HIPCHK(hipSetDevice(c->device));
     const size_t nb = c->n * sizeof(double);
     if (Omega) HIPCHK(hipMemcpyAsync(c->Om[c->cur], Omega, nb, hipMemcpyHostToDevice, c->stream));
@@ -499,6 +502,18 @@ extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* 
     return omega_step(c, latent, &sg);
 }
 
+extern "C" int ggl_step_omega_spec(ggl_ctx* c, double rho, int latent, const double* nk)
+{
+    ARGCHK(c, "ctx");
+    ARGCHK(rho > 0, "rho must be positive");
+    HIPCHK(hipSetDevice(c->device));
+    CopySegs sg;
+    int rc = upload_par(c, 0, nk, 1.0, rho, &sg);
+    if (rc) return rc;
+    // with more than MAX_PARTS - 1 parts there is no slot left for the all-reduced flag
+    return omega_step(c, latent, &sg, c->ns_parts < ggl_ctx::MAX_PARTS);
+}
+
 // Omega-step with beta_k in parameter slot 0 (already on the device, or part of the pending transfer)
 static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec)
 {
@@ -577,6 +592,10 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 sg.add(c->cuse + k0, c->cuse_h + k0, (size_t)Kh[h] * sizeof(double));
                 sg.add(c->spec_flag + h, nullptr, sizeof(int));
                 c->spec_flag_h[h] = 0;
+                if (h == 0 && nh < ggl_ctx::MAX_PARTS) {      // slot of the all-reduced (global) flag of sharded runs
+                    sg.add(c->spec_flag + ggl_ctx::MAX_PARTS - 1, nullptr, sizeof(int));
+                    c->spec_flag_h[ggl_ctx::MAX_PARTS - 1] = 0;
+                }
                 if (h == 0 && c->info_dirty) sg.add(c->info, nullptr, K * sizeof(int));
             }
             launch_copy_small(sh, sg);
@@ -709,6 +728,7 @@ extern "C" int ggl_step_group_partial(ggl_ctx* c, double rho, double lambda1)
     HIPCHK(hipSetDevice(c->device));
     launch_group_partial(c->stream, c->sqwork, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
     launch_sum_chunks(c->stream, c->groupsq, c->sqwork, ggl_chunks(c->K, c->p), c->p);
+    launch_spec_pack(c->stream, c->spec_pending ? c->spec_flag : nullptr, c->groupsq + (size_t)c->p * c->p);
     HIPCHK(hipGetLastError());
     return GGL_OK;
 }
@@ -862,6 +882,9 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
     } else {
         ARGCHK(lambda1 > 0 && lambda2 > 0, "lambda1, lambda2 must be positive");
         PB(c, GGL_PH_THETA);
+        if (groupsq_ready && c->spec_pending)
+            launch_spec_unpack(c->stream, c->groupsq + (size_t)c->p * c->p, c->spec_flag + ggl_ctx::MAX_PARTS - 1,
+                               c->spec_flag_h + ggl_ctx::MAX_PARTS - 1);
         // the flat GGL kernel computes every (i,j) from its own inputs: only for an exactly symmetric state
         const int flat = (c->theta_flat && c->state_symmetric && !groupsq_ready) ? 1 : 0;
         HIPCHK(launch_theta_pair(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, l1, l2,
@@ -902,7 +925,7 @@ extern "C" int ggl_norms_read(ggl_ctx* c, double out_norms[5])
 {
     ARGCHK(c && out_norms, "ctx, out_norms");
     HIPCHK(hipSetDevice(c->device));
-    return finish_norms(c, 1, out_norms);
+    return finish_norms(c, 1, out_norms);      // 1 = a speculative step failed validation on some rank: repeat it
 }
 
 extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lambda2, int reg, int latent,

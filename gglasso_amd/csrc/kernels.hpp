@@ -44,6 +44,9 @@ struct CopySegs {
     void add(void* d, const void* s, size_t bytes) { dst[n] = d; src[n] = s; words[n] = (unsigned)(bytes / 4); ++n; }
 };
 void launch_copy_small(hipStream_t st, const CopySegs& segs);
+// K-sharded speculation: this rank's validation flags -> one double behind the (p,p) all-reduce buffer, and back
+void launch_spec_pack(hipStream_t st, const int* flags /*4, or null*/, double* dst);
+void launch_spec_unpack(hipStream_t st, const double* src, int* flag, int* flag_host);
 // X[k] *= fK[k]
 void launch_scale_batch(hipStream_t st, double* X, const double* fK, int K, int p);
 // out[k] = max_{i,j} |A[k,i,j] - A[k,j,i]|

@@ -79,8 +79,9 @@ class TorchComm:
 
 
 def _hip_groupsq_tensor(self, torch, device):
+    # (p,p) sums + the trailing speculation flag (include/ggl_hip.h, ggl_step_omega_spec): one flat vector
     ptr = self.device_ptr(_lib.BUF_GROUPSQ)
-    return torch.as_tensor(_DeviceView(ptr, (self.p, self.p)), device=device)
+    return torch.as_tensor(_DeviceView(ptr, (self.p * self.p + 1,)), device=device)
 
 
 def _hip_groupsq_written(self, t):

@@ -60,8 +60,9 @@ class HipEngine:
             check(rc)
         return self._norms
 
-    def step_omega(self, rho, latent, nk):
-        check(self.lib.ggl_step_omega(self.h, rho, int(latent), ptr(nk)))
+    def step_omega(self, rho, latent, nk, speculate=False):
+        fn = self.lib.ggl_step_omega_spec if speculate else self.lib.ggl_step_omega
+        check(fn(self.h, rho, int(latent), ptr(nk)))
 
     def step_group_partial(self, rho, lambda1):
         check(self.lib.ggl_step_group_partial(self.h, rho, lambda1))
@@ -74,7 +75,11 @@ class HipEngine:
         return None if defer_norms else self._norms.copy()
 
     def read_norms(self):
-        check(self.lib.ggl_norms_read(self.h, ptr(self._norms)))
+        """The five sums, or None when a speculative Omega-step failed validation on some rank (repeat the step)."""
+        rc = self.lib.ggl_norms_read(self.h, ptr(self._norms))
+        if rc == 1:
+            return None
+        check(rc)
         return self._norms.copy()
 
     def scale_X(self, f):
@@ -216,13 +221,21 @@ def _run_admm(eng, reg, K_total, p, lambda1, lambda2, latent, mu1, nk, rho, tol,
         if measure:
             start = time.time()
         if sharded_ggl:
-            eng.step_omega(rho, latent, nk)
+            # device_norms: HIP engine over RCCL.  The Omega-step may then run speculatively; its validation flag
+            # rides on the (p,p) all-reduce, so either every rank accepts the step or every rank repeats it.
+            eng.step_omega(rho, latent, nk, *((True,) if device_norms else ()))
             eng.step_group_partial(rho, lambda1)
             comm.allreduce_groupsq(eng)
             if device_norms:
                 # the five sums are all-reduced where they are (HBM) and cross PCIe once, already global
                 eng.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 1, defer_norms=True)
                 sq = comm.allreduce_norms_device(eng)
+                if sq is None:
+                    eng.step_omega(rho, latent, nk)
+                    eng.step_group_partial(rho, lambda1)
+                    comm.allreduce_groupsq(eng)
+                    eng.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 1, defer_norms=True)
+                    sq = comm.allreduce_norms_device(eng)
             else:
                 sq = comm.allreduce_norms(eng.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 1))
         else:

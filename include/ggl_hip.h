@@ -51,7 +51,7 @@ extern "C" {
 #define GGL_BUF_THETA 2
 #define GGL_BUF_L 3
 #define GGL_BUF_X 4
-#define GGL_BUF_GROUPSQ 5   /* (p,p) partial sum_k u^2 of the GGL Theta-step (K-sharded runs) */
+#define GGL_BUF_GROUPSQ 5   /* (p,p) partial sum_k u^2 of the GGL Theta-step (K-sharded runs) + 1 flag double */
 #define GGL_BUF_NORMS 6     /* (K,5) per-instance squared norms of the stopping test */
 #define GGL_BUF_OMEGA_PREV 7
 
@@ -102,6 +102,12 @@ int ggl_admm_step(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int 
  *   ggl_step_finish         Theta from the reduced GROUPSQ, L-step, X update, local norms       */
 int ggl_step_omega(ggl_ctx *ctx, double rho, int latent, const double *nk);
 int ggl_step_group_partial(ggl_ctx *ctx, double rho, double lambda1);
+/* ggl_step_omega that may run speculatively (schedule from the previous iteration's bounds, no host sync).  The
+ * validation flag of this rank is appended to GROUPSQ as element p*p by ggl_step_group_partial, so the caller's
+ * all-reduce must cover p*p+1 doubles; ggl_step_finish reads the reduced flag back and, if ANY rank missed, leaves
+ * the iterate alone; ggl_norms_read (or ggl_step_finish without deferred norms) then returns 1 on every rank:
+ * repeat the iteration with ggl_step_omega. */
+int ggl_step_omega_spec(ggl_ctx *ctx, double rho, int latent, const double *nk);
 int ggl_step_finish(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int reg, int latent,
                     const double *mu1, int groupsq_ready, double out_norms[5]);
 /* groupsq_ready bit 1 (value 2): leave the five local sums in the NORMS buffer instead of returning them, so that

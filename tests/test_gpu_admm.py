@@ -277,17 +277,28 @@ def test_sharded_driver_on_rccl_single_rank(sol):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda:0"))
+    import os
     try:
-        for (K, p) in ((5, 40), (3, 150)):
+        # p = 150 takes the Newton-Schulz Omega-step, speculative after the first iteration: its validation flag rides
+        # on the (p,p) all-reduce.  GGL_SPEC_FACTOR=0.9 deflates the assumed bounds so that every speculative step
+        # is rejected (by the all-reduced flag) and repeated; 0 switches speculation off.
+        for (K, p, env) in ((5, 40, {}), (3, 150, {}), (3, 150, {"GGL_SPEC_FACTOR": "0.9"}), (3, 150, {"GGL_SPECULATE": "0"})):
             S, _ = synth.make_problem("GGL", K, p, seed=31)
             Om0 = np.stack([np.eye(p)] * K)
             comm = TorchComm(device="cuda:0")
-            (a, ia), _ = quiet(ADMM_MGL_sharded, S, 0.05, 0.02, "GGL", Om0, K, comm, tol=1e-9, rtol=1e-9, measure=True)
+            saved = {k: os.environ.get(k) for k in ("GGL_SPEC_FACTOR", "GGL_SPECULATE")}
+            os.environ.update(env)
+            try:
+                (a, ia), _ = quiet(ADMM_MGL_sharded, S, 0.05, 0.02, "GGL", Om0, K, comm, tol=1e-9, rtol=1e-9,
+                                   measure=True)
+            finally:
+                for k, v in saved.items():
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
             (b, ib), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.02, "GGL", Om0, tol=1e-9, rtol=1e-9, measure=True)
             assert ia["status"] == ib["status"] == "optimal"
             assert len(ia["residual"]) == len(ib["residual"])
             for nm in ("Omega", "Theta", "X"):
-                assert np.abs(a[nm] - b[nm]).max() <= 1e-10, nm
+                assert np.abs(a[nm] - b[nm]).max() <= 1e-10, (nm, env)
     finally:
         dist.destroy_process_group()
 
