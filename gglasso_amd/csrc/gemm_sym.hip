@@ -289,7 +289,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 }
 
 // BK: k-slab depth (16 or 32); NSTG: slabs resident in LDS (2 = double buffer; more = deeper DMA prefetch)
-template <int BK, int NSTG>
+template <int BK, int NSTG, int ABL = 0>      // ABL 1: no mirror write (timing ablation, wrong lower triangle)
 __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, const double* __restrict__ B,
                                                  double* __restrict__ C, double* __restrict__ C2,
                                                  const double* __restrict__ E, const double* __restrict__ coef, int K,
@@ -415,14 +415,14 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
                         if (C2k) C2k[(size_t)gj * p + gi] = dC * v;
                     }
                 }
-                if (I != J) smem[row * 64 + (col ^ row)] = v;        // XOR-swizzled 64x64 mirror tile
+                if (I != J && ABL != 1) smem[row * 64 + (col ^ row)] = v;        // XOR-swizzled 64x64 mirror tile
             }
     if (maxdev) {
         dev = wave_max(dev);
         if (lane == 0 && dev > 0.0)
             atomicMax(reinterpret_cast<unsigned long long*>(maxdev + k), (unsigned long long)__double_as_longlong(dev));
     }
-    if (I != J) {
+    if (I != J && ABL != 1) {
         __syncthreads();
         for (int e = tid; e < BM * BM; e += 256) {
             const int a = e >> 6, c = e & 63;   // out[J0+a][I0+c] = tile[c][a]
@@ -447,6 +447,8 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
         hipLaunchKernelGGL((k_symm_dl<16, 4>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
     else if (dl_cfg == 3)
         hipLaunchKernelGGL((k_symm_dl<32, 2>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
+    else if (dl_cfg == 4)
+        hipLaunchKernelGGL((k_symm_dl<16, 2, 1>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
     else
         hipLaunchKernelGGL((k_symm_dl<16, 2>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
 }
@@ -662,7 +664,7 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
     }
 }
 
-int symm_variants() { return 20; }   // 17..19: direct-to-LDS with 3 stages, 4 stages, k-slab 32
+int symm_variants() { return 20; }   // 17..19: direct-to-LDS with 3 stages, 4 stages, k-slab 32 (20: ablation, dev bench only)
 
 // Two independent products in one launch: C = coef[k]-affine(A*B) for k < K and C1 = coef[K+k]-scaled(A1*B1).
 void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
@@ -704,7 +706,7 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 5: launch_cfg<128, 32, 64, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 16: case 17: case 18: case 19:
+        case 16: case 17: case 18: case 19: case 20:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16);
                 break;

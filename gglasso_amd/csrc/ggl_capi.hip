@@ -1393,7 +1393,7 @@ extern "C" int ggl_dev_symm(int K, int p, const double* A, const double* B, cons
 extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* ms_out)
 {
     ARGCHK(K >= 1 && p >= 1 && iters >= 1 && ms_out, "arguments");
-    ARGCHK(variant < symm_variants(), "variant");
+    ARGCHK(variant <= symm_variants(), "variant");   // symm_variants() itself: the no-mirror timing ablation
     const size_t n = (size_t)K * p * p;
     std::vector<double> h(n), coef((size_t)K * 5, 0.0);
     unsigned long long s = 88172645463325252ull;

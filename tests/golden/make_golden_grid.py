@@ -8,6 +8,8 @@ importing the REAL reference in the build container:
       walk of the reference and a batched identity-start solve agree far below the criteria's resolution.
       Stored: inputs (S, N, grids) and the reference's tables AIC, BIC[gamma], SP, RANK, the best point and
       the best Theta.
+  G13 K_single_grid (:300-503): three data sets on a 3 x 2 latent grid; tables, ix_uniform / ix_indv / ix_mu and
+      the uniformly and individually selected estimates.
 
     python tests/golden/make_golden_grid.py
 """
@@ -50,6 +52,17 @@ def main():
     out["latent_best_Theta"], out["latent_best_L"] = best['Theta'], best['L']
     out["latent_lowrank"] = low
     mg.save("g12_single_grid_search", **out)
+
+    # ---- G13 K_single_grid (model_selection.py:300-503): K = 3 data sets on a 3 x 2 (lambda1, mu1) grid, latent
+    K = 3
+    Sig, _ = dg.group_power_network(p, K=K, M=2, seed=1241)
+    S3, _ = dg.sample_covariance_matrix(Sig, N, seed=1241)
+    Nk = np.array([N, N + 30, N - 20])
+    est_u, est_i, st = mg.quiet(ms.K_single_grid, S3, lam2, Nk, method='eBIC', gamma=0.3, latent=True, mu_range=mu,
+                                use_block=False, store_all=True, tol=1e-10, rtol=1e-10)
+    mg.save("g13_k_single_grid", S=S3, N=Nk, lambda_range=lam2, mu_range=mu, BIC=st['BIC'], AIC=st['AIC'], SP=st['SP'],
+            RANK=st['RANK'], ix_uniform=np.array(st['ix_uniform']), ix_indv=st['ix_indv'], ix_mu=st['ix_mu'],
+            uniform_Theta=est_u['Theta'], uniform_L=est_u['L'], indv_Theta=est_i['Theta'], indv_L=est_i['L'])
 
 
 if __name__ == "__main__":

@@ -51,3 +51,24 @@ def check_single_grid_search(load_golden):
         pass
     else:
         raise AssertionError("thresholding must be refused, not silently ignored")
+
+
+def check_k_single_grid(load_golden):
+    """K data sets x (lambda1, mu1) grid as one batch against the reference's K_single_grid (fixture G13)."""
+    from gglasso_amd import model_selection as ms
+    g = load_golden("g13_k_single_grid")
+    S, N, lam, mu = g["S"], g["N"], g["lambda_range"], g["mu_range"]
+    est_u, est_i, st = ms.K_single_grid(S, lam, N, method='eBIC', gamma=0.3, latent=True, mu_range=mu, tol=1e-10,
+                                        rtol=1e-10)
+    assert st['BIC'].shape == (3, 3, 2)
+    assert np.allclose(st['BIC'], g["BIC"], rtol=1e-7, atol=1e-5) and np.allclose(st['AIC'], g["AIC"], rtol=1e-7, atol=1e-5)
+    assert np.array_equal(st['SP'], g["SP"]) and np.array_equal(st['RANK'], g["RANK"])
+    assert int(st['ix_uniform']) == int(g["ix_uniform"])
+    assert np.array_equal(st['ix_indv'], g["ix_indv"]) and np.array_equal(st['ix_mu'], g["ix_mu"])
+    for ours, ref in ((est_u['Theta'], g["uniform_Theta"]), (est_u['L'], g["uniform_L"]),
+                      (est_i['Theta'], g["indv_Theta"]), (est_i['L'], g["indv_L"])):
+        assert ours.shape == ref.shape and np.abs(ours - ref).max() <= 2e-7
+    # two small batches instead of one must give the same tables
+    _, _, st2 = ms.K_single_grid(S, lam, N, method='eBIC', gamma=0.3, latent=True, mu_range=mu, tol=1e-10, rtol=1e-10,
+                                 store_all=False, max_batch_bytes=14 * 6 * S.shape[1] ** 2 * 8 * 2)
+    assert np.allclose(st2['BIC'], st['BIC'], rtol=1e-9) and np.array_equal(st2['ix_mu'], st['ix_mu'])

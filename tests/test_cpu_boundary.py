@@ -230,8 +230,9 @@ def test_batched_single_grid_search_matches_reference_tables(oracle_engine):
     """the whole (lambda1[, mu1]) grid as one batch reproduces the AIC / eBIC / sparsity / rank
     tables, the selected point and the selected Theta of the reference's sequential single_grid_search
     (fixture G12, generated from the real reference).  Array work: test-only oracle engine."""
-    from grid_checks import check_single_grid_search
+    from grid_checks import check_single_grid_search, check_k_single_grid
     check_single_grid_search(load_golden)
+    check_k_single_grid(load_golden)
 
 
 def test_selection_criteria_definitions():

@@ -327,8 +327,9 @@ def test_extreme_rho_and_scaling_vs_oracle(sol, rho0, scale, lam, reg, latent):
 
 def test_g12_batched_single_grid_search(sol):
     """The (lambda1[, mu1]) grid solved as one batch on the GPU against the reference's single_grid_search tables."""
-    from grid_checks import check_single_grid_search
+    from grid_checks import check_single_grid_search, check_k_single_grid
     check_single_grid_search(load_golden)
+    check_k_single_grid(load_golden)
 
 
 @pytest.mark.parametrize("reg,K,p", [("GGL", 4, 160), ("FGL", 3, 150), ("GGL", 16, 200)])
