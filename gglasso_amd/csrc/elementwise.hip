@@ -173,7 +173,8 @@ void launch_dual_update(hipStream_t st, double* X, const double* Omega, const do
 // ---------------------------------------------------------------------------------------------
 // out[k][v] = sum_b partials[k][b][v]; one block per k, fixed summation tree.
 __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partials, int nblk, int nv,
-                                                         double* __restrict__ out)
+                                                         double* __restrict__ out, unsigned long long* seq,
+                                                         unsigned long long seq_val)
 {
     __shared__ double sh[256];
     const int k = blockIdx.x;
@@ -189,11 +190,19 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
         if (threadIdx.x == 0) out[(size_t)k * nv + v] = sh[0];
         __syncthreads();
     }
+    // single-row reductions into pinned host memory: publish a sequence number AFTER the sums, so that the host can
+    // wait for this kernel by polling one word instead of a stream synchronisation
+    if (seq != nullptr && threadIdx.x == 0 && blockIdx.x == 0) {
+        __threadfence_system();
+        *(volatile unsigned long long*)seq = seq_val;
+    }
 }
 
-void launch_reduce_partials(hipStream_t st, const double* partials, int K, int nblk, int nv, double* out)
+void launch_reduce_partials(hipStream_t st, const double* partials, int K, int nblk, int nv, double* out,
+                            unsigned long long* seq, unsigned long long seq_val)
 {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(256), 0, st, partials, nblk, nv, out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(256), 0, st, partials, nblk, nv, out, K == 1 ? seq : nullptr,
+                       seq_val);
 }
 
 // ---------------------------------------------------------------------------------------------

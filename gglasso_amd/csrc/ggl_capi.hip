@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <atomic>
 #include <vector>
 
 #include "../../include/ggl_hip.h"
@@ -82,6 +83,9 @@ struct ggl_ctx {
     int *spec_flag = nullptr, *spec_flag_h = nullptr; // MAX_PARTS validation flags (device / pinned)
     long long spec_calls = 0, spec_misses = 0;
     double spec_factor = 1.02;                 // inflation of the previous bounds (GGL_SPEC_FACTOR; < 1 forces misses)
+    unsigned long long* seq_h = nullptr;       // pinned: sequence number published by the last kernel of a step
+    unsigned long long seq_next = 0, seq_wait = 0;   // seq_wait != 0: finish_norms may poll instead of synchronising
+    bool spin_wait = true;
     bool info_dirty = true;                    // an eigensolver wrote `info` since it was last fetched
     bool norms_host = false;                   // the last norm reduction wrote straight into norms_h
     int spec_cool = 0;                         // iterations without speculation left after a failed one
@@ -205,6 +209,9 @@ static int ctx_alloc(ggl_ctx* c)
         HIPCHK(hipMalloc(&c->nbpart, nbl));
         HIPCHK(hipMalloc(&c->cuse, c->K * sizeof(double)));
         HIPCHK(hipHostMalloc(&c->cuse_h, c->K * sizeof(double)));
+        HIPCHK(hipHostMalloc(&c->seq_h, sizeof(unsigned long long)));
+        *c->seq_h = 0;
+        if (const char* v = getenv("GGL_SPIN_WAIT")) c->spin_wait = atoi(v) != 0;
         HIPCHK(hipMalloc(&c->spec_flag, ggl_ctx::MAX_PARTS * sizeof(int)));
         HIPCHK(hipMemset(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int)));
         HIPCHK(hipHostMalloc(&c->spec_flag_h, ggl_ctx::MAX_PARTS * sizeof(int)));
@@ -281,6 +288,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
                       c->nsT, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->cuse};
     if (c->spec_flag) (void)hipFree(c->spec_flag);
     if (c->cuse_h) (void)hipHostFree(c->cuse_h);
+    if (c->seq_h) (void)hipHostFree(c->seq_h);
     if (c->spec_flag_h) (void)hipHostFree(c->spec_flag_h);
     free(c->spec_c);
     free(c->spec_beta);
@@ -742,7 +750,17 @@ static int finish_norms(ggl_ctx* c, int rows, double out_norms[5])
     if (c->info_dirty) dn.add(c->info_h, c->info, c->K * sizeof(int));
     launch_copy_small(c->stream, dn);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
+    bool waited = false;
+    if (c->seq_wait != 0 && dn.n == 0) {
+        // everything this step produced for the host is in pinned memory and the reduction publishes a sequence
+        // number after it: poll that word (the stream is in order, so all earlier work is complete as well)
+        const volatile unsigned long long* sq = c->seq_h;
+        for (long spin = 0; spin < 400000000L; ++spin)
+            if (*sq == c->seq_wait) { waited = true; break; }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    c->seq_wait = 0;
+    if (!waited || c->prof_on) HIPCHK(hipStreamSynchronize(c->stream));
     c->norms_host = false;
     prof_collect(c);
     if (c->spec_pending) {
@@ -893,8 +911,9 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
         PE(c, GGL_PH_THETA);
         if (!latent) {
             PB(c, GGL_PH_REDUCE);
+            if (!defer_norms && c->seq_h && c->spin_wait) c->seq_wait = ++c->seq_next;
             launch_reduce_partials(c->stream, c->partials, 1, theta_partial_blocks(c->p, reg, c->K, flat), GGL_NNORM,
-                                   norms_dst);
+                                   norms_dst, c->seq_wait ? c->seq_h : nullptr, c->seq_wait);
             PE(c, GGL_PH_REDUCE);
             rows = 1;
         }
