@@ -86,6 +86,7 @@ struct ggl_ctx {
     unsigned long long* seq_h = nullptr;       // pinned: sequence number published by the last kernel of a step
     unsigned long long seq_next = 0, seq_wait = 0;   // seq_wait != 0: finish_norms may poll instead of synchronising
     bool spin_wait = true;
+    bool sharded_check = false;                // this step's Theta kernels ran under the all-reduced validation flag
     bool info_dirty = true;                    // an eigensolver wrote `info` since it was last fetched
     bool norms_host = false;                   // the last norm reduction wrote straight into norms_h
     int spec_cool = 0;                         // iterations without speculation left after a failed one
@@ -592,18 +593,21 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             CopySegs sg = first;
             sg.add(pre_d + 5 * (size_t)k0, pre + 5 * (size_t)k0, (size_t)Kh[h] * 5 * sizeof(double));
             sg.add(pre_d + NS_SLOT(K) + 5 * (size_t)k0, pre + NS_SLOT(K) + 5 * (size_t)k0, (size_t)Kh[h] * 5 * sizeof(double));
+            // validation flags of this step: this part's slot, and (part 0) the slot of the all-reduced flag of K-sharded
+            // runs, where a rank must skip and repeat the step when ANY rank's speculation failed -- also a rank that
+            // did not speculate itself
+            sg.add(c->spec_flag + h, nullptr, sizeof(int));
+            c->spec_flag_h[h] = 0;
+            if (h == 0 && nh < ggl_ctx::MAX_PARTS) {
+                sg.add(c->spec_flag + ggl_ctx::MAX_PARTS - 1, nullptr, sizeof(int));
+                c->spec_flag_h[ggl_ctx::MAX_PARTS - 1] = 0;
+            }
             if (spec) {
                 sg.add(start_base_d + 5 * (size_t)k0, start_base_h + 5 * (size_t)k0, (size_t)Kh[h] * 5 * sizeof(double));
                 const int nb_launch = plans[h].products - 2;
                 if (nb_launch > 0)
                     sg.add(c->coef + h * region, c->coef_h + h * region, (size_t)nb_launch * NS_SLOT(Kh[h]) * sizeof(double));
                 sg.add(c->cuse + k0, c->cuse_h + k0, (size_t)Kh[h] * sizeof(double));
-                sg.add(c->spec_flag + h, nullptr, sizeof(int));
-                c->spec_flag_h[h] = 0;
-                if (h == 0 && nh < ggl_ctx::MAX_PARTS) {      // slot of the all-reduced (global) flag of sharded runs
-                    sg.add(c->spec_flag + ggl_ctx::MAX_PARTS - 1, nullptr, sizeof(int));
-                    c->spec_flag_h[ggl_ctx::MAX_PARTS - 1] = 0;
-                }
                 if (h == 0 && c->info_dirty) sg.add(c->info, nullptr, K * sizeof(int));
             }
             launch_copy_small(sh, sg);
@@ -763,20 +767,23 @@ static int finish_norms(ggl_ctx* c, int rows, double out_norms[5])
     if (!waited || c->prof_on) HIPCHK(hipStreamSynchronize(c->stream));
     c->norms_host = false;
     prof_collect(c);
-    if (c->spec_pending) {
-        // speculative Omega-step: were last iteration's (inflated) bounds still bounds?
+    if (c->spec_pending || c->sharded_check) {
+        // speculative Omega-step (here, or on another rank of a K-sharded run): were the assumed bounds still bounds?
+        const bool mine = c->spec_pending;
         c->spec_pending = false;
+        c->sharded_check = false;
         bool bad = false;
         for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) bad = bad || (c->spec_flag_h[h] != 0);
         if (bad) {
             // no: the Theta-step kernels saw the flag and left the iterate alone; un-flip Omega and tell the caller
-            c->spec_misses += 1;
+            if (mine) c->spec_misses += 1;
             c->spec_have = false;
             c->spec_cool = 4;
             c->cur ^= 1;
             return GGL_SPEC_RETRY;
         }
-        for (int k = 0; k < c->K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
+        if (mine)
+            for (int k = 0; k < c->K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
     }
     int rc = check_info(c, "ADMM step");
     if (rc) return rc;
@@ -900,14 +907,17 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
     } else {
         ARGCHK(lambda1 > 0 && lambda2 > 0, "lambda1, lambda2 must be positive");
         PB(c, GGL_PH_THETA);
-        if (groupsq_ready && c->spec_pending)
+        if (groupsq_ready && c->omega_ns) {
+            // K-sharded: the reduced flag decides for every rank, whether it speculated itself or not
             launch_spec_unpack(c->stream, c->groupsq + (size_t)c->p * c->p, c->spec_flag + ggl_ctx::MAX_PARTS - 1,
                                c->spec_flag_h + ggl_ctx::MAX_PARTS - 1);
+            c->sharded_check = true;
+        }
         // the flat GGL kernel computes every (i,j) from its own inputs: only for an exactly symmetric state
         const int flat = (c->theta_flat && c->state_symmetric && !groupsq_ready) ? 1 : 0;
         HIPCHK(launch_theta_pair(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, l1, l2,
                                  groupsq_ready ? c->groupsq : nullptr, c->sqwork, latent ? 0 : 1, c->partials, c->K,
-                                 c->p, flat, c->spec_pending ? c->spec_flag : nullptr));
+                                 c->p, flat, (c->spec_pending || c->sharded_check) ? c->spec_flag : nullptr));
         PE(c, GGL_PH_THETA);
         if (!latent) {
             PB(c, GGL_PH_REDUCE);
