@@ -65,8 +65,7 @@ class TorchComm:
 
     def allreduce_norms_device(self, eng):
         if self._nrm is None or self._nrm[0] is not eng:
-            view = _DeviceView(eng.device_ptr(_lib.BUF_NORMS), (5,))
-            self._nrm = (eng, self.torch.as_tensor(view, device=self.device))
+            self._nrm = (eng, eng.norms_tensor(self.torch, self.device))
         self.dist.all_reduce(self._nrm[1], op=self.dist.ReduceOp.SUM, group=self.group)
         return eng.read_norms()
 
@@ -84,12 +83,17 @@ def _hip_groupsq_tensor(self, torch, device):
     return torch.as_tensor(_DeviceView(ptr, (self.p * self.p + 1,)), device=device)
 
 
+def _hip_norms_tensor(self, torch, device):
+    return torch.as_tensor(_DeviceView(self.device_ptr(_lib.BUF_NORMS), (5,)), device=device)
+
+
 def _hip_groupsq_written(self, t):
     pass    # the tensor aliases the ctx buffer; same stream => already ordered
 
 
 _solver.HipEngine.groupsq_tensor = _hip_groupsq_tensor
 _solver.HipEngine.groupsq_written = _hip_groupsq_written
+_solver.HipEngine.norms_tensor = _hip_norms_tensor
 
 
 def ADMM_MGL_sharded(S_local, lambda1, lambda2, reg, Omega_0, K_total, comm, Theta_0=np.array([]),

@@ -141,3 +141,63 @@ class OracleEngine:
 
     def close(self):
         pass
+
+
+class SpeculatingOracleEngine(OracleEngine):
+    """TEST-ONLY emulation of the HIP engine's K-sharded speculation protocol on the host, for world_size-2 gloo runs
+    of the real driver loop (gglasso_amd.solver._run_admm): a speculative Omega-step may "miss" (scripted through
+    GGL_TEST_MISS = "rank:call,rank:call"), which corrupts this rank's Omega and raises its flag; the flag rides
+    on the group-sum all-reduce as element p*p; when the reduced flag is set every rank leaves its iterate alone,
+    read_norms returns None and the driver repeats the step without speculation -- on all ranks, in lockstep."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        import os
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        self._miss_calls = {int(c) for r, c in (t.split(":") for t in os.environ.get("GGL_TEST_MISS", "").split(",") if t)
+                            if int(r) == rank}
+        self._spec_calls = 0
+        self.retries = 0
+        self._gsflat = np.zeros(self.p * self.p + 1)
+        self._norms_dev = np.zeros(5)
+        self._retry = False
+
+    def step_omega(self, rho, latent, nk, speculate=False):
+        self._saved = (self.Om, self.Om_prev)
+        super().step_omega(rho, latent, nk)
+        self._flag = 0.0
+        if speculate:
+            self._spec_calls += 1
+            if self._spec_calls in self._miss_calls:
+                self.Om = 1.5 * self.Om          # what a schedule built for too small a bound would deliver: garbage
+                self._flag = 1.0
+
+    def step_group_partial(self, rho, lambda1):
+        super().step_group_partial(rho, lambda1)
+        self._gsflat[:-1] = self.groupsq.ravel()
+        self._gsflat[-1] = self._flag
+
+    def groupsq_tensor(self, torch, device):
+        return torch.from_numpy(self._gsflat)
+
+    def norms_tensor(self, torch, device):
+        return torch.from_numpy(self._norms_dev)
+
+    def step_finish(self, rho, lambda1, lambda2, reg, latent, mu1, groupsq_ready, defer_norms=False):
+        self.groupsq[...] = self._gsflat[:-1].reshape(self.p, self.p)
+        if self._gsflat[-1] > 0.5:               # some rank missed: nobody touches Theta / X
+            self._retry = True
+            self._norms_dev[:] = np.nan
+            return None
+        sq = super().step_finish(rho, lambda1, lambda2, reg, latent, mu1, groupsq_ready)
+        self._norms_dev[:] = sq
+        return None if defer_norms else sq
+
+    def read_norms(self):
+        if self._retry:
+            self._retry = False
+            self.retries += 1
+            self.Om, self.Om_prev = self._saved   # un-flip
+            return None
+        return self._norms_dev.copy()

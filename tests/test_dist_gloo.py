@@ -19,7 +19,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, K, p, out_dir):
+def _worker(rank, world, port, K, p, out_dir, miss=""):
     import contextlib
     import io
     sys.path.insert(0, ROOT)
@@ -30,28 +30,42 @@ def _worker(rank, world, port, K, p, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gglasso_amd import solver, synth
     from gglasso_amd.dist import ADMM_MGL_sharded, TorchComm, shard_bounds
-    from oracle_engine import OracleEngine
+    from oracle_engine import OracleEngine, SpeculatingOracleEngine
     solver.ENGINE = OracleEngine
     S, _ = synth.make_problem("GGL", K, p, seed=21)
     k0, k1 = shard_bounds(K, world, rank)
     Om0 = np.repeat(np.eye(p)[None], k1 - k0, axis=0)
     comm = TorchComm()
+    retries = []
+    if miss:
+        # the device protocol of the HIP engine (norms all-reduced where they are, speculative Omega-steps validated
+        # through a flag on the group-sum all-reduce), emulated on the host with scripted misses
+        os.environ["GGL_TEST_MISS"] = miss
+        comm.device_norms = True
+
+        class Eng(SpeculatingOracleEngine):
+            def close(self):
+                retries.append(self.retries)
+        solver.ENGINE = Eng
     with contextlib.redirect_stdout(io.StringIO()):
         sol, info = ADMM_MGL_sharded(S[k0:k1], 0.05, 0.02, "GGL", Om0, K, comm, tol=1e-9, rtol=1e-9, measure=True)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), k0=k0, k1=k1, status=info["status"],
-             iters=len(info["residual"]), **sol)
+             iters=len(info["residual"]), retries=np.array(retries[-1] if retries else 0), **sol)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,world", [(5, 2), (4, 2)])
-def test_k_sharded_ggl_equals_single_process(tmp_path, K, world):
+@pytest.mark.parametrize("K,world,miss", [(5, 2, ""), (4, 2, ""), (5, 2, "1:2,0:5,1:5,0:9")])
+def test_k_sharded_ggl_equals_single_process(tmp_path, K, world, miss):
+    """miss != "": the device protocol of the HIP engine with scripted speculation misses (rank:call) -- rank 1 alone at
+    its 2nd speculative step, both ranks at their 5th, rank 0 alone at its 9th.  Every rank must repeat exactly those
+    steps (three repeats each), stay in lockstep with the collectives, and end with the unsharded solution."""
     import torch.multiprocessing as mp
     from oracle import ggl_oracle as orc
     from gglasso_amd import synth
     p = 24
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, K, p, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, K, p, str(tmp_path), miss), nprocs=world, join=True)
     S, _ = synth.make_problem("GGL", K, p, seed=21)
     Om0 = np.repeat(np.eye(p)[None], K, axis=0)
     ref, rinfo = orc.ADMM_MGL(S, 0.05, 0.02, "GGL", Om0, tol=1e-9, rtol=1e-9)
@@ -64,6 +78,8 @@ def test_k_sharded_ggl_equals_single_process(tmp_path, K, world):
         assert int(z["iters"]) == rinfo["iterations"]
         for nm in ("Omega", "Theta", "X"):
             assert np.abs(z[nm] - ref[nm][k0:k1]).max() <= 1e-10, (r, nm)
+        if miss:
+            assert int(z["retries"]) == 3, (r, int(z["retries"]))
     assert covered == K
 
 
