@@ -91,6 +91,7 @@ struct ggl_ctx {
     bool norms_host = false;                   // the last norm reduction wrote straight into norms_h
     int spec_cool = 0;                         // iterations without speculation left after a failed one
     int ns_degrees = 9;                        // highest Newton-Schulz step degree: 3, 5 or 9
+    long parts_max_tiles = 2048;               // concurrent parts only up to this many 64x64 tile pairs in the batch
     int ns_parts = 1;                          // concurrent launch sequences (parts of the batch) wanted
     int* sweeps = nullptr;
     long long ns_stable_calls = 0;
@@ -254,6 +255,7 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
     if (const char* v = getenv("GGL_NS_MODE")) c->ns_force = atoi(v);   // 1 symmetric, 2 stable (testing)
     if (const char* v = getenv("GGL_ROCSOLVER_SYEVJ")) c->use_syevj = atoi(v) != 0;
     c->ns_parts = 2;
+    if (const char* v = getenv("GGL_PARTS_MAX_TILES")) c->parts_max_tiles = atol(v);
     if (const char* v = getenv("GGL_THETA_FLAT")) c->theta_flat = atoi(v) != 0;
     if (const char* v = getenv("GGL_NS_DEGREES")) c->ns_degrees = atoi(v) >= 9 ? 9 : (atoi(v) >= 5 ? 5 : 3);
     if (const char* v = getenv("GGL_TWO_STREAM")) c->ns_parts = std::min(std::max(atoi(v), 1), (int)ggl_ctx::MAX_PARTS);
@@ -552,7 +554,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         // fork at the very start, when the streams are idle anyway, and one join at the end.
         const long t64 = (c->p + 63) / 64;
         const long ntile = t64 * (t64 + 1) / 2 * K;
-        int nh = (K >= 16 && ntile >= 600 && ntile <= 2048) ? std::min(c->ns_parts, K / 8) : 1;
+        int nh = (K >= 16 && ntile >= 600 && ntile <= c->parts_max_tiles) ? std::min(c->ns_parts, K / 8) : 1;
         nh = std::max(nh, 1);
         int Kh[ggl_ctx::MAX_PARTS], k0h[ggl_ctx::MAX_PARTS];
         for (int h = 0, k0 = 0; h < nh; ++h) {
@@ -824,7 +826,7 @@ static int rank_step(ggl_ctx* c)
         // the parts of the batch run their launch sequences concurrently, as in the Omega-step
         const long t64 = (c->p + 63) / 64;
         const long ntile = t64 * (t64 + 1) / 2 * K;
-        int nh = (K >= 16 && ntile >= 600 && ntile <= 2048) ? std::min(c->ns_parts, K / 8) : 1;
+        int nh = (K >= 16 && ntile >= 600 && ntile <= c->parts_max_tiles) ? std::min(c->ns_parts, K / 8) : 1;
         nh = std::max(nh, 1);
         const size_t pp = (size_t)c->p * c->p;
         if (nh > 1) {
