@@ -39,7 +39,9 @@ WORKLOADS = {
     "ggl_K20_p200": ("GGL", 20, 200, False, 0.05, 0.01, 1236),
     "fgl_K50_p500_latent": ("FGL", 50, 500, True, 0.05, 0.01, 1237),
     "ggl_K256_p1000": ("GGL", 256, 1000, False, 0.05, 0.01, 1238),
-    "ggl_K4_p500": ("GGL", 4, 500, False, 0.05, 0.01, 1239),       # per-GPU slab of the headline at 8 GPUs
+    "ggl_K16_p500": ("GGL", 16, 500, False, 0.05, 0.01, 1239),     # per-GPU slabs of the headline at 2 / 4 / 8 GPUs
+    "ggl_K8_p500": ("GGL", 8, 500, False, 0.05, 0.01, 1239),
+    "ggl_K4_p500": ("GGL", 4, 500, False, 0.05, 0.01, 1239),
     "ggl_K32_p1000": ("GGL", 32, 1000, False, 0.05, 0.01, 1238),   # per-GPU slab of C5 at 8 GPUs
 }
 
@@ -234,7 +236,7 @@ def main():
         omega_ns = (args.eig == _lib.EIG_NEWTON_SCHULZ) or (args.eig == _lib.EIG_AUTO and not eig_jacobi)
         bound, amount, unit = phase_model(dom, reg, Kl, p, latent, eig_jacobi, omega_ns)
         t64 = (p + 63) // 64
-        ns_kernel = "k_symm_dl" if (p % 2 == 0 and t64 * (t64 + 1) // 2 * Kl > 800) else "k_symm_tn"
+        ns_kernel = "k_symm_dl" if (p % 2 == 0 and t64 * (t64 + 1) // 2 * Kl > 400) else "k_symm_tn"
         kernel_name = {"eig_omega": ns_kernel + " (Newton-Schulz product)" if omega_ns else
                        ("k_jacobi" if eig_jacobi else "rocsolver_dsyevd (library, many kernels)"),
                        "theta": "k_theta_ggl" if reg == "GGL" else ("k_theta_fgl" if reg == "FGL" else "k_theta_sgl"),

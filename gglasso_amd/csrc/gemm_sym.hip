@@ -664,6 +664,8 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
     }
 }
 
+static constexpr long SMALL_BATCH_TILES = 400;   // up to here the 32x32-tile kernel, above the 64x64 direct-to-LDS one
+
 int symm_variants() { return 20; }   // 17..19: direct-to-LDS with 3 stages, 4 stages, k-slab 32 (20: ablation, dev bench only)
 
 // Two independent products in one launch: C = coef[k]-affine(A*B) for k < K and C1 = coef[K+k]-scaled(A1*B1).
@@ -672,7 +674,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 {
     if (variant < 0 || variant == 6 || variant == 7) {
         const long T64 = (p + 63) / 64;
-        variant = (T64 * (T64 + 1) / 2 * 2 * K <= 800) ? 9 : 16;
+        variant = (T64 * (T64 + 1) / 2 * 2 * K <= SMALL_BATCH_TILES) ? 9 : 16;
     }
     switch (variant) {
         case 16: case 17: case 18: case 19:
@@ -695,10 +697,11 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
                  const double* coef, int K, int p, int variant, double* maxdev)
 {
     if (variant < 0) {
-        // Measured on MI355X (tools/tail_test.py): with fewer than ~800 64x64 tile pairs in the batch the
-        // chip is under-filled and 32x32 tiles (4x the workgroups) are 20-30 % faster; above, 64x64.
+        // Measured on MI355X (tools/bench_small_batches.py, p = 500): with few 64x64 tile pairs in the batch the chip is
+        // under-filled and 32x32 tiles (4x the workgroups) win -- 288 tiles (K=8): 41.6 vs 44.7 us; at 576 tiles
+        // (K=16) the direct-to-LDS 64x64 kernel is ahead, 63.3 vs 72.7 us.
         const long T64 = (p + 63) / 64;
-        variant = (T64 * (T64 + 1) / 2 * K <= 800) ? 9 : 16;   // 16 = direct-to-LDS (falls back to 0 for odd p)
+        variant = (T64 * (T64 + 1) / 2 * K <= SMALL_BATCH_TILES) ? 9 : 16;   // 16 = direct-to-LDS (falls back to 0 for odd p)
     }
     switch (variant) {
         case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
