@@ -289,16 +289,22 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 }
 
 // BK: k-slab depth (16 or 32); NSTG: slabs resident in LDS (2 = double buffer; more = deeper DMA prefetch)
-template <int BK, int NSTG, int ABL = 0>      // ABL 1: no mirror write (timing ablation, wrong lower triangle)
+// BM: tile edge (64, or 32 for under-filled batches: 4x the workgroups, and with NSTG = 4 enough slabs in flight to
+// cover the load latency that bounds the small-batch regime); ABL 1: no mirror write (timing ablation)
+template <int BK, int NSTG, int ABL = 0, int BM = 64>
 __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, const double* __restrict__ B,
                                                  double* __restrict__ C, double* __restrict__ C2,
                                                  const double* __restrict__ E, const double* __restrict__ coef, int K,
                                                  int p, const double* __restrict__ A1, const double* __restrict__ B1,
                                                  double* __restrict__ C1, int K1, double* __restrict__ maxdev)
 {
-    constexpr int BM = 64, WM = 32, WN = 32, TI = 2, TJ = 2;
+    constexpr int WM = BM / 2, WN = BM / 2, TI = BM / 32, TJ = BM / 32;
+    constexpr int RPI = 128 / BM;                        // slab rows per DMA instruction (1 KiB)
+    constexpr int LPR = 64 / RPI;                        // lanes per row
     constexpr int SLAB = BK * BM;                        // doubles per operand slab (8 KiB at BK = 16)
-    constexpr int IPW = BK / 8;                          // DMA instructions per wave, operand and slab
+    constexpr int IPW = BK / (4 * RPI);                  // DMA instructions per wave, operand and slab
+    static_assert(BM == 64 || BM == 32, "tile edge");
+    static_assert(IPW >= 1, "k-slab too shallow for this tile");
     static_assert(NSTG * 2 * SLAB >= BM * BM, "the mirror tile reuses the slab storage");
     __shared__ __attribute__((aligned(16))) double smem[NSTG * 2 * SLAB];   // [buf][A|B][BK][64]; later the mirror tile
     const int T = (p + BM - 1) / BM;
@@ -325,14 +331,14 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
     // DMA geometry: wave w issues instructions i = 2w, 2w+1 per operand; instruction i covers slab rows
     // 2i, 2i+1; lane l -> row 2i + (l >> 5), LDS position (l & 31) * 2, source column position ^ 16*(row & 1).
     const unsigned pu = (unsigned)p, pm1 = (unsigned)(p - 1), pm2 = (unsigned)(p - 2);
-    const int lrow = lane >> 5;
-    const unsigned cpos = (unsigned)((lane & 31) * 2) ^ (unsigned)(16 * lrow);
+    const int lrow = lane / LPR;
+    const unsigned cpos = (unsigned)((lane % LPR) * 2) ^ (unsigned)(16 * (lrow & 1));
     const unsigned ca = min((unsigned)I0 + cpos, pm2), cb = min((unsigned)J0 + cpos, pm2);
     auto issue = [&](int m0, int buf) {
 #pragma unroll
         for (int j = 0; j < IPW; ++j) {
             const int i = wave * IPW + j;
-            const unsigned ro = min((unsigned)(m0 + 2 * i + lrow), pm1) * pu;
+            const unsigned ro = min((unsigned)(m0 + RPI * i + lrow), pm1) * pu;
             double* la = smem + (size_t)buf * 2 * SLAB + i * 128;            // wave-uniform LDS base
             double* lb = la + SLAB;
             __builtin_amdgcn_global_load_lds((gptr_t)(Ak + ro + ca), (lptr_t)la, 16, 0, 0);
@@ -354,11 +360,11 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
         const int valid = p - s * BK;                          // k-rows of this slab inside the matrix
         if (valid < BK) {
             // zero the rows beyond the matrix (each wave cleans the rows its own DMA wrote)
-            for (int e = lane; e < (BK / 4) * 64; e += 64) {
-                const int row = wave * (BK / 4) + (e >> 6);
+            for (int e = lane; e < (BK / 4) * BM; e += 64) {
+                const int row = wave * (BK / 4) + e / BM;
                 if (row >= valid) {
-                    smem[(size_t)buf * 2 * SLAB + row * 64 + (e & 63)] = 0.0;
-                    smem[(size_t)buf * 2 * SLAB + SLAB + row * 64 + (e & 63)] = 0.0;
+                    smem[(size_t)buf * 2 * SLAB + row * BM + (e % BM)] = 0.0;
+                    smem[(size_t)buf * 2 * SLAB + SLAB + row * BM + (e % BM)] = 0.0;
                 }
             }
         }
@@ -375,9 +381,9 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
                 const int sw = 16 * (row & 1);
                 double af[TI], bf[TJ];
 #pragma unroll
-                for (int i = 0; i < TI; ++i) af[i] = As[row * 64 + ((wr + i * 16 + (lane & 15)) ^ sw)];
+                for (int i = 0; i < TI; ++i) af[i] = As[row * BM + ((wr + i * 16 + (lane & 15)) ^ sw)];
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) bf[j] = Bs[row * 64 + ((wc + j * 16 + (lane & 15)) ^ sw)];
+                for (int j = 0; j < TJ; ++j) bf[j] = Bs[row * BM + ((wc + j * 16 + (lane & 15)) ^ sw)];
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
                         if (C2k) C2k[(size_t)gj * p + gi] = dC * v;
                     }
                 }
-                if (I != J && ABL != 1) smem[row * 64 + (col ^ row)] = v;        // XOR-swizzled 64x64 mirror tile
+                if (I != J && ABL != 1) smem[row * BM + (col ^ row)] = v;        // XOR-swizzled BM x BM mirror tile
             }
     if (maxdev) {
         dev = wave_max(dev);
@@ -425,9 +431,9 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
     if (I != J && ABL != 1) {
         __syncthreads();
         for (int e = tid; e < BM * BM; e += 256) {
-            const int a = e >> 6, c = e & 63;   // out[J0+a][I0+c] = tile[c][a]
+            const int a = e / BM, c = e % BM;   // out[J0+a][I0+c] = tile[c][a]
             if (J0 + a < p && I0 + c < p) {
-                const double v = smem[c * 64 + (a ^ c)];
+                const double v = smem[c * BM + (a ^ c)];
                 Ck[(size_t)(J0 + a) * p + I0 + c] = v;
                 if (C2k) C2k[(size_t)(J0 + a) * p + I0 + c] = dC * v;
             }
@@ -439,6 +445,12 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
                       const double* coef, int K, int p, const double* A1, const double* B1, double* C1, int K1,
                       double* maxdev, int dl_cfg = 0)
 {
+    if (dl_cfg == 4) {
+        const int T32 = (p + 31) / 32;
+        hipLaunchKernelGGL((k_symm_dl<32, 4, 0, 32>), dim3(xcd_grid(T32 * (T32 + 1) / 2, K + K1)), dim3(256), 0, st, A, B, C,
+                           C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
+        return;
+    }
     const int T = (p + 63) / 64;
     const dim3 grid(xcd_grid(T * (T + 1) / 2, K + K1));
     if (dl_cfg == 1)
@@ -447,7 +459,7 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
         hipLaunchKernelGGL((k_symm_dl<16, 4>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
     else if (dl_cfg == 3)
         hipLaunchKernelGGL((k_symm_dl<32, 2>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
-    else if (dl_cfg == 4)
+    else if (dl_cfg == 5)
         hipLaunchKernelGGL((k_symm_dl<16, 2, 1>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
     else
         hipLaunchKernelGGL((k_symm_dl<16, 2>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
@@ -666,7 +678,8 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
 
 static constexpr long SMALL_BATCH_TILES = 400;   // up to here the 32x32-tile kernel, above the 64x64 direct-to-LDS one
 
-int symm_variants() { return 20; }   // 17..19: direct-to-LDS with 3 stages, 4 stages, k-slab 32 (20: ablation, dev bench only)
+int symm_variants() { return 21; }   // 17..19: direct-to-LDS with 3 stages, 4 stages, k-slab 32; 20: 32x32 tiles, 4 stages
+                                     // (21: no-mirror timing ablation, dev bench only)
 
 // Two independent products in one launch: C = coef[k]-affine(A*B) for k < K and C1 = coef[K+k]-scaled(A1*B1).
 void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
@@ -677,7 +690,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
         variant = (T64 * (T64 + 1) / 2 * 2 * K <= SMALL_BATCH_TILES) ? 9 : 16;
     }
     switch (variant) {
-        case 16: case 17: case 18: case 19:
+        case 16: case 17: case 18: case 19: case 20:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K, nullptr, variant - 16);
                 break;
@@ -709,7 +722,7 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 5: launch_cfg<128, 32, 64, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 16: case 17: case 18: case 19: case 20:
+        case 16: case 17: case 18: case 19: case 20: case 21:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16);
                 break;
