@@ -368,7 +368,12 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
                 }
             }
         }
-        __syncthreads();                                       // slab s visible to all; slab s-1 fully consumed
+        // slab s visible to all, slab s-1 fully consumed.  A raw barrier with an LDS-only wait: __syncthreads() would
+        // make hipcc drain vmcnt(0) here, i.e. wait for the slabs prefetched AHEAD as well and collapse the pipeline
+        // to one slab of overlap whatever NSTG is (this wave's own slab-s DMA was waited for by the counted vmcnt above)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         if (s + NSTG - 1 < S) issue((s + NSTG - 1) * BK, (s + NSTG - 1) % NSTG);
         if (!dead_wave) {
             const double* As = smem + (size_t)buf * 2 * SLAB;
@@ -687,7 +692,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 {
     if (variant < 0 || variant == 6 || variant == 7) {
         const long T64 = (p + 63) / 64;
-        variant = (T64 * (T64 + 1) / 2 * 2 * K <= SMALL_BATCH_TILES) ? 9 : 16;
+        variant = (T64 * (T64 + 1) / 2 * 2 * K <= SMALL_BATCH_TILES) ? 20 : 16;
     }
     switch (variant) {
         case 16: case 17: case 18: case 19: case 20:
@@ -695,7 +700,8 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
                 launch_dl(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K, nullptr, variant - 16);
                 break;
             }
-            launch_cfg<64, 16, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K);
+            if (variant == 20) launch_cfg<32, 32, 16, 16, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K);
+            else launch_cfg<64, 16, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K);
             break;
         case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
         case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
@@ -711,10 +717,11 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
 {
     if (variant < 0) {
         // Measured on MI355X (tools/bench_small_batches.py, p = 500): with few 64x64 tile pairs in the batch the chip is
-        // under-filled and 32x32 tiles (4x the workgroups) win -- 288 tiles (K=8): 41.6 vs 44.7 us; at 576 tiles
-        // (K=16) the direct-to-LDS 64x64 kernel is ahead, 63.3 vs 72.7 us.
+        // under-filled and 32x32 tiles (4x the workgroups) win -- 288 tiles (K=8): 39.5 (direct-to-LDS) / 41.5
+        // (register-staged) vs 44.4 us; at 576 tiles (K=16) the 64x64 direct-to-LDS kernel is ahead, 63.3 vs 71.9 us.
         const long T64 = (p + 63) / 64;
-        variant = (T64 * (T64 + 1) / 2 * K <= SMALL_BATCH_TILES) ? 9 : 16;   // 16 = direct-to-LDS (falls back to 0 for odd p)
+        // 20 / 16 = direct-to-LDS with 32x32 / 64x64 tiles (odd p: the register-staged kernels 9 / 0)
+        variant = (T64 * (T64 + 1) / 2 * K <= SMALL_BATCH_TILES) ? 20 : 16;
     }
     switch (variant) {
         case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
@@ -727,7 +734,8 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
                 launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16);
                 break;
             }
-            launch_cfg<64, 16, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev);
+            if (variant == 20) launch_cfg<32, 32, 16, 16, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev);
+            else launch_cfg<64, 16, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev);
             break;
         case 11: launch_cfg<64, 16, 16, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 12: launch_cfg<64, 32, 16, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
