@@ -236,7 +236,7 @@ def main():
         omega_ns = (args.eig == _lib.EIG_NEWTON_SCHULZ) or (args.eig == _lib.EIG_AUTO and not eig_jacobi)
         bound, amount, unit = phase_model(dom, reg, Kl, p, latent, eig_jacobi, omega_ns)
         t64 = (p + 63) // 64
-        ns_kernel = "k_symm_dl" if p % 2 == 0 else "k_symm_tn"
+        ns_kernel = "k_symm_dl" if (p % 2 == 0 and (t64 * (t64 + 1) // 2 * Kl > 400 or p >= 384)) else "k_symm_tn"
         kernel_name = {"eig_omega": ns_kernel + " (Newton-Schulz product)" if omega_ns else
                        ("k_jacobi" if eig_jacobi else "rocsolver_dsyevd (library, many kernels)"),
                        "theta": "k_theta_ggl" if reg == "GGL" else ("k_theta_fgl" if reg == "FGL" else "k_theta_sgl"),

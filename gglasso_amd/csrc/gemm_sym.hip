@@ -681,6 +681,7 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
     }
 }
 
+static constexpr int SMALL_DL_MIN_P = 384;        // below: too few k-slabs for the four-stage 32x32 kernel
 static constexpr long SMALL_BATCH_TILES = 400;   // up to here the 32x32-tile kernel, above the 64x64 direct-to-LDS one
 
 int symm_variants() { return 21; }   // 17..19: direct-to-LDS with 3 stages, 4 stages, k-slab 32; 20: 32x32 tiles, 4 stages
@@ -692,7 +693,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 {
     if (variant < 0 || variant == 6 || variant == 7) {
         const long T64 = (p + 63) / 64;
-        variant = (T64 * (T64 + 1) / 2 * 2 * K <= SMALL_BATCH_TILES) ? 20 : 16;
+        variant = (T64 * (T64 + 1) / 2 * 2 * K <= SMALL_BATCH_TILES) ? (p >= SMALL_DL_MIN_P ? 20 : 9) : 16;
     }
     switch (variant) {
         case 16: case 17: case 18: case 19: case 20:
@@ -721,7 +722,8 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
         // (register-staged) vs 44.4 us; at 576 tiles (K=16) the 64x64 direct-to-LDS kernel is ahead, 63.3 vs 71.9 us.
         const long T64 = (p + 63) / 64;
         // 20 / 16 = direct-to-LDS with 32x32 / 64x64 tiles (odd p: the register-staged kernels 9 / 0)
-        variant = (T64 * (T64 + 1) / 2 * K <= SMALL_BATCH_TILES) ? 20 : 16;
+        // (few k-slabs, p = 200: the four-stage prologue does not pay, 9 is 3 % ahead of 20)
+        variant = (T64 * (T64 + 1) / 2 * K <= SMALL_BATCH_TILES) ? (p >= SMALL_DL_MIN_P ? 20 : 9) : 16;
     }
     switch (variant) {
         case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
