@@ -90,7 +90,11 @@ int ggl_set_lambda1_mask(ggl_ctx *ctx, const double *lam_pp_host);
  * out_norms[5] = squared Frobenius norms over the whole stack that ADMM_stopping_criterion
  * (admm_solver.py:316-331) needs: |Omega|^2, |Theta-L|^2, |X|^2, |Omega-Theta+L|^2,
  * |Omega-Omega_prev|^2.  rho update and the stopping decision stay on the host (admm_solver.py:227-246).
- * mu1: host (K,) or NULL; nk: host (K,) or NULL (= ones).  rho, lambda1 are per-iteration scalars. */
+ * mu1: host (K,) or NULL; nk: host (K,) or NULL (= ones).  rho, lambda1 are per-iteration scalars.
+ * For p > 128 the Omega- and L-steps are matrix-function iterations on the FP64 matrix cores; with
+ * the same rho as in the previous call the Omega-step runs on a schedule built from that call's spectral bounds
+ * and is validated on the device -- a rejected step leaves the iterate untouched and is repeated inside this call
+ * (GGL_SPECULATE=0 switches that off).  One host synchronisation per call in the common case. */
 int ggl_admm_step(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int reg, int latent,
                   const double *mu1, const double *nk, double out_norms[5]);
 
@@ -162,7 +166,7 @@ int ggl_kkt_residual(ggl_ctx *ctx, double rho, double lambda1, double lambda2, i
 #define GGL_PH_DUAL 6         /* X += Omega - Theta + L and norms (latent path)                   */
 #define GGL_PH_REDUCE 7       /* partial-sum reduction of the norms                                */
 #define GGL_PH_EIG_OMEGA2 8   /* second part of the Newton-Schulz Omega-step (after the spectral-bound sync) */
-#define GGL_PH_BOUND 9        /* norm pass that gives the spectral bound                           */
+#define GGL_PH_BOUND 9        /* (not recorded any more: the bound kernels run inside the Omega-step chains) */
 #define GGL_NPHASE 10
 /* on: 0 off, 1 every phase, 2 only GGL_PH_EIG_OMEGA / _OMEGA2 / _EIG_L (4-6 event records per iteration) */
 int ggl_profile_enable(ggl_ctx *ctx, int on);
