@@ -171,7 +171,7 @@ def main():
         k0, k1, S_loc = 0, K, S
     Kl = k1 - k0
     Om0 = np.repeat(np.eye(p)[None], Kl, axis=0)
-    stream = torch.cuda.current_stream().cuda_stream if distributed else None
+    stream = comm.stream_handle if distributed else None      # the communicator's dedicated stream (gglasso_amd/dist.py)
     eng = solver.HipEngine(S_loc, Om0, Om0, np.zeros_like(S_loc), eig=args.eig, device=local_rank, stream=stream)
     nk = np.ones(Kl)
     mu_loc = None if mu1 is None else mu1[k0:k1]

@@ -7,10 +7,21 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libggl_hip.so")
+DEV_LIB_PATH = os.path.join(_HERE, "lib", "libggl_hip_dev.so")     # python -m gglasso_amd.build --dev (tools/ only)
 
 # mirrors include/ggl_hip.h
 REG_SGL, REG_GGL, REG_FGL = 0, 1, 2
 EIG_AUTO, EIG_JACOBI, EIG_ROCSOLVER, EIG_NEWTON_SCHULZ = 0, 1, 2, 3
+CTX_STREAM_GIVEN = 1 << 16
+# ggl_ctx_set_option ids (GGL_OPT_*)
+OPTIONS = {"speculate": 1, "spec_factor": 2, "ns_mode": 3, "ns_degrees": 4, "theta_flat": 5, "rank_eig": 6, "parts": 7,
+           "parts_max_tiles": 8, "symm_variant": 9, "spin_wait": 10}
+
+
+def eig_flags(method=EIG_AUTO, ns_mode=0, ns_degrees=0):
+    """eigensolver selector with the Newton-Schulz controls in the upper bits (GGL_EIG_NS_MODE / GGL_EIG_NS_DEGREES)."""
+    return int(method) | ((int(ns_mode) & 0x3) << 8) | ((int(ns_degrees) & 0xf) << 12)
+
 JACOBI_MAX_P = 128
 BUF_S, BUF_OMEGA, BUF_THETA, BUF_L, BUF_X, BUF_GROUPSQ, BUF_NORMS, BUF_OMEGA_PREV = range(8)
 E_ARG, E_HIP, E_SOLVER, E_ALLOC = -1, -2, -3, -4
@@ -29,6 +40,8 @@ _SIGNATURES = {
     "ggl_ctx_destroy": ([_vp], _i),
     "ggl_ctx_sync": ([_vp], _i),
     "ggl_device_ptr": ([_vp, _i], _vp),
+    "ggl_ctx_set_option": ([_vp, _i, _d], _i),
+    "ggl_ctx_get_option": ([_vp, _i, _dp], _i),
     "ggl_set_S": ([_vp, _dp], _i),
     "ggl_set_state": ([_vp, _dp, _dp, _dp, _dp], _i),
     "ggl_get_state": ([_vp, _dp, _dp, _dp, _dp], _i),
@@ -53,8 +66,6 @@ _SIGNATURES = {
     "ggl_snapshot_k": ([_vp, _i], _i),
     "ggl_selection_stats": ([_vp, _dp], _i),
     "ggl_dev_ns_schedule": ([_d, _i, _i, ctypes.POINTER(_i), _dp, ctypes.POINTER(_i)], _i),
-    "ggl_dev_mfma_f64_peak": ([_dp], _i),
-    "ggl_dev_symm_timeline": ([_i, _i, ctypes.POINTER(ctypes.c_longlong), _i, ctypes.POINTER(_i)], _i),
     "ggl_ns_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_eigh_batched": ([_i, _i, _dp, _dp, _dp, _i], _i),
     "ggl_phiplus": ([_i, _i, _dp, _dp, _dp, _dp], _i),
@@ -66,6 +77,12 @@ _SIGNATURES = {
     "ggl_prox_tv": ([_i, _i, _dp, _d, _dp], _i),
     "ggl_prox_2norm": ([_i, _i, _dp, _d, _dp], _i),
     "ggl_prox_phi": ([_i, _i, _dp, _d, _d, _i, _dp], _i),
+}
+
+# libggl_hip_dev.so only (-DGGL_DEV)
+_DEV_SIGNATURES = {
+    "ggl_dev_mfma_f64_peak": ([_dp], _i),
+    "ggl_dev_symm_timeline": ([_i, _i, ctypes.POINTER(ctypes.c_longlong), _i, ctypes.POINTER(_i)], _i),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -92,13 +109,25 @@ def load():
             import torch  # noqa: F401
         except Exception:  # noqa: BLE001  (torch absent or broken: the single-GPU path does not need it)
             pass
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (argtypes, restype) in _SIGNATURES.items():
+    _lib = _bind(ctypes.CDLL(LIB_PATH), _SIGNATURES)
+    return _lib
+
+
+def _bind(lib, table):
+    for name, (argtypes, restype) in table.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = restype
-    _lib = lib
     return lib
+
+
+def load_dev():
+    """The development build (ablation variants, probes, GGL_* environment knobs) for tools/; never used by the
+    solvers.  Build it with `python -m gglasso_amd.build --dev`."""
+    load()      # import order (torch first), see above
+    if not os.path.exists(DEV_LIB_PATH):
+        raise RuntimeError(f"{DEV_LIB_PATH} is missing: python -m gglasso_amd.build --dev")
+    return _bind(_bind(ctypes.CDLL(DEV_LIB_PATH), _SIGNATURES), _DEV_SIGNATURES)
 
 
 def last_error():

@@ -1,7 +1,10 @@
 """Builds gglasso_amd/lib/libggl_hip.so (gfx950 only) with hipcc.  In-tree, no JIT cache:
 the .so travels to the GPU box with the repo snapshot.
 
-    python -m gglasso_amd.build [--force]
+    python -m gglasso_amd.build [--force] [--dev]
+
+--dev additionally builds libggl_hip_dev.so with -DGGL_DEV: the measured-and-rejected product-kernel variants, timing
+ablations, probe kernels and the GGL_* environment knobs that tools/ uses.  The solvers never load it.
 """
 import os
 import subprocess
@@ -28,16 +31,26 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src):
-    obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+DEV_LIB = os.path.join(LIBDIR, "libggl_hip_dev.so")
+
+
+def _compile(src, dev=False):
+    obj = os.path.join(LIBDIR, src.replace(".hip", ".dev.o" if dev else ".o"))
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
     if _stale(obj, deps):
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + (["-DGGL_DEV"] if dev else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         subprocess.check_call(cmd)
     return obj
 
 
-def build(force=False, verbose=True):
+def _link(lib, objs):
+    if _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + \
+              ["-L/opt/rocm/lib", "-lrocsolver", "-lrocblas", "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
+        subprocess.check_call(cmd)
+
+
+def build(force=False, verbose=True, dev=False):
     os.makedirs(LIBDIR, exist_ok=True)
     if force:
         for f in os.listdir(LIBDIR):
@@ -45,14 +58,14 @@ def build(force=False, verbose=True):
                 os.remove(os.path.join(LIBDIR, f))
     with ThreadPoolExecutor(max_workers=7) as ex:
         objs = list(ex.map(_compile, SOURCES))
-    if _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + \
-              ["-L/opt/rocm/lib", "-lrocsolver", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"]
-        subprocess.check_call(cmd)
+        dev_objs = list(ex.map(lambda s: _compile(s, True), SOURCES)) if dev else []
+    _link(LIB, objs)
+    if dev:
+        _link(DEV_LIB, dev_objs)
     if verbose:
-        print(f"built {LIB}")
+        print(f"built {LIB}" + (f" and {DEV_LIB}" if dev else ""))
     return LIB
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, dev="--dev" in sys.argv)

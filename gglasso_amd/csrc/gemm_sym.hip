@@ -58,6 +58,7 @@ __device__ __forceinline__ bool decode_block_xcd(int ntiles, int K, int& k, int&
     return true;
 }
 
+// ABL != 0: timing ablations and the timeline probe, instantiated by GGL_DEV builds only (tools/bench_tail.py)
 template <int BM, int BK, int WM, int WN, bool LM, int ABL = 0>
 __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, double* __restrict__ C2,
@@ -88,8 +89,10 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     const double* Ak = (second ? A1 : A) + (size_t)kk * pp;
     const double* Bk = (second ? B1 : B) + (size_t)kk * pp;
 
+#ifdef GGL_DEV
     long long t_start = 0, t_loop = 0, t_loop_end = 0;
     if (ABL == 3) t_start = clock64();
+#endif
 
     v4d acc[Cfg::TI][Cfg::TJ];
 #pragma unroll
@@ -160,7 +163,9 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     const bool dead_wave = (I == J) && (wr >= wc + WN);
 #pragma unroll
     for (int s = 0; s < NST; ++s) fetch(s * BK, ra[s], rb[s]);
+#ifdef GGL_DEV
     if (ABL == 3) t_loop = clock64();
+#endif
     for (int m0 = 0; m0 < p; m0 += NST * BK) {
 #pragma unroll
         for (int s = 0; s < NST; ++s) {
@@ -175,7 +180,9 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
         }
     }
 
+#ifdef GGL_DEV
     if (ABL == 3) t_loop_end = clock64();
+#endif
     // epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
     const double cI = coef[k * 5 + 0], cAcc = coef[k * 5 + 1], cE = coef[k * 5 + 2];
     const double dI = coef[k * 5 + 3], dC = coef[k * 5 + 4];
@@ -239,6 +246,7 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
             }
         }
     }
+#ifdef GGL_DEV
     if (ABL == 3 && tid == 0) {
         // timeline probe: maxdev is (ab)used as a [gridDim.x][5] long long buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -247,6 +255,7 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         tl[0] = t_start; tl[1] = t_loop; tl[2] = t_loop_end; tl[3] = clock64(); tl[4] = (long long)xcc;
     }
+#endif
 }
 
 template <int BM, int BK, int WM, int WN, bool LM>
@@ -450,24 +459,23 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
                       const double* coef, int K, int p, const double* A1, const double* B1, double* C1, int K1,
                       double* maxdev, int dl_cfg = 0)
 {
+#define GGL_DL(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev)
     if (dl_cfg == 4) {
         const int T32 = (p + 31) / 32;
-        hipLaunchKernelGGL((k_symm_dl<32, 4, 0, 32>), dim3(xcd_grid(T32 * (T32 + 1) / 2, K + K1)), dim3(256), 0, st, A, B, C,
-                           C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
+        const dim3 grid(xcd_grid(T32 * (T32 + 1) / 2, K + K1));
+        GGL_DL(32, 4, 0, 32);
         return;
     }
     const int T = (p + 63) / 64;
     const dim3 grid(xcd_grid(T * (T + 1) / 2, K + K1));
-    if (dl_cfg == 1)
-        hipLaunchKernelGGL((k_symm_dl<16, 3>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
-    else if (dl_cfg == 2)
-        hipLaunchKernelGGL((k_symm_dl<16, 4>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
-    else if (dl_cfg == 3)
-        hipLaunchKernelGGL((k_symm_dl<32, 2>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
-    else if (dl_cfg == 5)
-        hipLaunchKernelGGL((k_symm_dl<16, 2, 1>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
-    else
-        hipLaunchKernelGGL((k_symm_dl<16, 2>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev);
+    if (dl_cfg == 1) GGL_DL(16, 3);
+#ifdef GGL_DEV
+    else if (dl_cfg == 2) GGL_DL(16, 4);
+    else if (dl_cfg == 3) GGL_DL(32, 2);
+    else if (dl_cfg == 5) GGL_DL(16, 2, 1);      // no mirror write: timing ablation, wrong results
+#endif
+    else GGL_DL(16, 2);
+#undef GGL_DL
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -577,6 +585,7 @@ void launch_gemm_right(hipStream_t st, const double* A, const double* T, double*
     }
 }
 
+#ifdef GGL_DEV
 // FP64 matrix-core ceiling probe: every wave issues `iters` x NACC MFMAs on NACC independent accumulators.
 template <int NACC>
 __global__ __launch_bounds__(256) void k_mfma_f64_peak(double* __restrict__ out, int iters)
@@ -680,21 +689,44 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
         default: return mfma_probe<8>(st, scratch, blocks, iters);
     }
 }
+#endif   // GGL_DEV
 
 static constexpr int SMALL_DL_MIN_P = 384;        // below: too few k-slabs for the four-stage 32x32 kernel
 static constexpr long SMALL_BATCH_TILES = 400;   // up to here the 32x32-tile kernel, above the 64x64 direct-to-LDS one
 
-int symm_variants() { return 21; }   // 17..19: direct-to-LDS with 3 stages, 4 stages, k-slab 32; 20: 32x32 tiles, 4 stages
-                                     // (21: no-mirror timing ablation, dev bench only)
+// Product-kernel variants.  The shipped library holds the instances the solvers dispatch to:
+//    0  k_symm_tn 64x64 tile, k-slab 16 (register-staged; odd p, where the DMA kernel's 16-byte rows do not exist)
+//    9  k_symm_tn 32x32 tile, k-slab 32 (small batches below p = 384)
+//   16  k_symm_dl 64x64, double-buffered DMA      17  k_symm_dl 64x64, three DMA stages (concurrent parts)
+//   20  k_symm_dl 32x32, four DMA stages (small batches from p = 384)
+// A GGL_DEV build (libggl_hip_dev.so) adds the measured alternatives 1-5, 8, 11-13, 18, 19 and the ablations 6, 7, 10,
+// 14, 15, 21 (tools/bench_*.py).
+int symm_variants() { return 21; }
+bool symm_variant_built(int v)
+{
+#ifdef GGL_DEV
+    return v >= 0 && v <= 21;
+#else
+    return v == 0 || v == 9 || v == 16 || v == 17 || v == 20;
+#endif
+}
+
+// Measured on MI355X (tools/bench_small_batches.py, p = 500): with few 64x64 tile pairs in the batch the chip is
+// under-filled and 32x32 tiles (4x the workgroups) win -- 288 tiles (K=8): 39.5 (direct-to-LDS) / 41.5
+// (register-staged) vs 44.4 us; at 576 tiles (K=16) the 64x64 direct-to-LDS kernel is ahead, 63.3 vs 71.9 us.
+// 20 / 16 = direct-to-LDS with 32x32 / 64x64 tiles (odd p: the register-staged kernels 9 / 0); few k-slabs
+// (p = 200): the four-stage prologue does not pay, 9 is 3 % ahead of 20.
+int symm_auto_variant(int nprod, int p)
+{
+    const long T64 = (p + 63) / 64;
+    return (T64 * (T64 + 1) / 2 * nprod <= SMALL_BATCH_TILES) ? (p >= SMALL_DL_MIN_P ? 20 : 9) : 16;
+}
 
 // Two independent products in one launch: C = coef[k]-affine(A*B) for k < K and C1 = coef[K+k]-scaled(A1*B1).
 void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
                       double* C1, const double* coef2K, int K, int p, int variant)
 {
-    if (variant < 0 || variant == 6 || variant == 7) {
-        const long T64 = (p + 63) / 64;
-        variant = (T64 * (T64 + 1) / 2 * 2 * K <= SMALL_BATCH_TILES) ? (p >= SMALL_DL_MIN_P ? 20 : 9) : 16;
-    }
+    if (variant < 0) variant = symm_auto_variant(2 * K, p);
     switch (variant) {
         case 16: case 17: case 18: case 19: case 20:
             if ((p & 1) == 0 && p >= 2) {
@@ -704,11 +736,13 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
             if (variant == 20) launch_cfg<32, 32, 16, 16, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K);
             else launch_cfg<64, 16, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K);
             break;
+        case 9: launch_cfg<32, 32, 16, 16, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
+#ifdef GGL_DEV
         case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
         case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
         case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
         case 8: launch_cfg<32, 16, 16, 16, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
-        case 9: launch_cfg<32, 32, 16, 16, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
+#endif
         default: launch_cfg<64, 16, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
     }
 }
@@ -716,61 +750,45 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                  const double* coef, int K, int p, int variant, double* maxdev)
 {
-    if (variant < 0) {
-        // Measured on MI355X (tools/bench_small_batches.py, p = 500): with few 64x64 tile pairs in the batch the chip is
-        // under-filled and 32x32 tiles (4x the workgroups) win -- 288 tiles (K=8): 39.5 (direct-to-LDS) / 41.5
-        // (register-staged) vs 44.4 us; at 576 tiles (K=16) the 64x64 direct-to-LDS kernel is ahead, 63.3 vs 71.9 us.
-        const long T64 = (p + 63) / 64;
-        // 20 / 16 = direct-to-LDS with 32x32 / 64x64 tiles (odd p: the register-staged kernels 9 / 0)
-        // (few k-slabs, p = 200: the four-stage prologue does not pay, 9 is 3 % ahead of 20)
-        variant = (T64 * (T64 + 1) / 2 * K <= SMALL_BATCH_TILES) ? (p >= SMALL_DL_MIN_P ? 20 : 9) : 16;
-    }
+    if (variant < 0) variant = symm_auto_variant(K, p);
+#define GGL_TN(BM, BK, WM, WN, LM) \
+    launch_cfg<BM, BK, WM, WN, LM>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev)
     switch (variant) {
-        case 1: launch_cfg<64, 32, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 2: launch_cfg<128, 16, 64, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 3: launch_cfg<128, 16, 32, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 4: launch_cfg<64, 16, 32, 32, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 5: launch_cfg<128, 32, 64, 64, false>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
         case 16: case 17: case 18: case 19: case 20: case 21:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16);
                 break;
             }
-            if (variant == 20) launch_cfg<32, 32, 16, 16, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev);
-            else launch_cfg<64, 16, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev);
+            if (variant == 20) GGL_TN(32, 32, 16, 16, true);
+            else GGL_TN(64, 16, 32, 32, true);
             break;
-        case 11: launch_cfg<64, 16, 16, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 12: launch_cfg<64, 32, 16, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 13: launch_cfg<64, 16, 32, 16, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 8: launch_cfg<32, 16, 16, 16, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 9: launch_cfg<32, 32, 16, 16, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
-        case 6: {   // ablation of variant 0: no global loads
+        case 9: GGL_TN(32, 32, 16, 16, true); break;
+#ifdef GGL_DEV
+        case 1: GGL_TN(64, 32, 32, 32, true); break;
+        case 2: GGL_TN(128, 16, 64, 64, false); break;
+        case 3: GGL_TN(128, 16, 32, 64, false); break;
+        case 4: GGL_TN(64, 16, 32, 32, false); break;
+        case 5: GGL_TN(128, 32, 64, 64, false); break;
+        case 8: GGL_TN(32, 16, 16, 16, true); break;
+        case 11: GGL_TN(64, 16, 16, 32, true); break;
+        case 12: GGL_TN(64, 32, 16, 32, true); break;
+        case 13: GGL_TN(64, 16, 32, 16, true); break;
+        case 6: case 7: case 10: case 14: case 15: {
+            // ablations of variant 0: 6 no global loads, 7 no MFMA, 14 ds_read + MFMA only, 15 + ds_write; 10 = timeline
+            // probe (maxdev is a [grid][5] long long buffer)
             const int T = (p + 63) / 64;
-            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 1>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, nullptr);
+            const dim3 grid(xcd_grid(T * (T + 1) / 2, K));
+            double* md = (variant == 10) ? maxdev : nullptr;
+#define GGL_ABL(N) hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, N>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, md)
+            if (variant == 6) GGL_ABL(1); else if (variant == 7) GGL_ABL(2); else if (variant == 10) GGL_ABL(3);
+            else if (variant == 14) GGL_ABL(4); else GGL_ABL(5);
+#undef GGL_ABL
             break;
         }
-        case 10: {  // timeline probe of variant 0 (maxdev = [grid][5] long long buffer)
-            const int T = (p + 63) / 64;
-            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 3>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev);
-            break;
-        }
-        case 14: {  // ablation: ds_read + MFMA only (no loads, no ds_write, no barriers)
-            const int T = (p + 63) / 64;
-            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 4>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, nullptr);
-            break;
-        }
-        case 15: {  // ablation: ds_write + ds_read + MFMA, no loads, no barriers
-            const int T = (p + 63) / 64;
-            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 5>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, nullptr);
-            break;
-        }
-        case 7: {   // ablation of variant 0: no MFMA
-            const int T = (p + 63) / 64;
-            hipLaunchKernelGGL((k_symm_tn<64, 16, 32, 32, true, 2>), dim3(xcd_grid(T * (T + 1) / 2, K)), dim3(256), 0, st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, nullptr);
-            break;
-        }
-        default: launch_cfg<64, 16, 32, 32, true>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev); break;
+#endif
+        default: GGL_TN(64, 16, 32, 32, true); break;
     }
+#undef GGL_TN
 }
 
 }  // namespace ggl

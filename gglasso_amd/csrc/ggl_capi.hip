@@ -12,6 +12,7 @@
 #include <cstring>
 #include <numeric>
 #include <atomic>
+#include <chrono>
 #include <vector>
 
 #include "../../include/ggl_hip.h"
@@ -86,6 +87,7 @@ struct ggl_ctx {
     unsigned long long* seq_h = nullptr;       // pinned: sequence number published by the last kernel of a step
     unsigned long long seq_next = 0, seq_wait = 0;   // seq_wait != 0: finish_norms may poll instead of synchronising
     bool spin_wait = true;
+    long long spin_timeouts = 0;               // polls that hit GGL_SPIN_LIMIT_MS and fell back to a stream sync
     bool sharded_check = false;                // this step's Theta kernels ran under the all-reduced validation flag
     bool info_dirty = true;                    // an eigensolver wrote `info` since it was last fetched
     bool norms_host = false;                   // the last norm reduction wrote straight into norms_h
@@ -95,6 +97,7 @@ struct ggl_ctx {
     int ns_parts = 1;                          // concurrent launch sequences (parts of the batch) wanted
     int* sweeps = nullptr;
     long long ns_stable_calls = 0;
+    int last_parts = 0, last_variant = -1;     // concurrent parts / product-kernel variant of the last matrix-function step
     double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
     double* bounds_h = nullptr;                // pinned: spectral / norm bound per instance, written by k_bound_final
 
@@ -103,6 +106,7 @@ struct ggl_ctx {
     double* nbpart = nullptr;                  // [K][blocks][2] + [K][blocks]: norm / Collatz-Wielandt partials
     double *maxdev = nullptr, *maxdev_h = nullptr;   // [K] residual of the sign iteration
     bool rank_ns = false;                            // L-step by sign Newton-Schulz (else eigendecomposition)
+    bool rank_eig = false;                           // GGL_OPT_RANK_EIG: force the eigendecomposition route
     double rank_l0 = 1e-6;                           // resolution of the scaling schedule
     int rank_hold = 0;                               // iterations to stay at the fine resolution
     long long rank_calls = 0, rank_retries = 0, rank_fallbacks = 0, rank_launches = 0;
@@ -193,7 +197,7 @@ static int ctx_alloc(ggl_ctx* c)
     c->partials_len = pl;
     HIPCHK(hipMalloc(&c->partials, pl * sizeof(double)));
     HIPCHK(hipMalloc(&c->norms, (size_t)c->K * 8 * sizeof(double)));
-    HIPCHK(hipHostMalloc(&c->norms_h, (size_t)c->K * 8 * sizeof(double)));
+    HIPCHK(hipHostMalloc(&c->norms_h, (size_t)c->K * 8 * sizeof(double), hipHostMallocCoherent));
     HIPCHK(hipHostMalloc(&c->info_h, (size_t)c->K * sizeof(int)));
     HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
     HIPCHK(hipMemsetAsync(c->X, 0, nb, c->stream));
@@ -205,23 +209,22 @@ static int ctx_alloc(ggl_ctx* c)
         HIPCHK(hipMalloc(&c->coef, cl));
         HIPCHK(hipHostMalloc(&c->coef_h, cl));
         const size_t bl = 2 * (size_t)c->K * sizeof(double);
-        HIPCHK(hipHostMalloc(&c->bounds_h, bl));
+        HIPCHK(hipHostMalloc(&c->bounds_h, bl, hipHostMallocCoherent));
         const size_t nbl = 3 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);   // + Collatz-Wielandt maxima
         HIPCHK(hipMalloc(&c->nbrow, (size_t)c->K * c->p * sizeof(double)));
         HIPCHK(hipMalloc(&c->nbpart, nbl));
         HIPCHK(hipMalloc(&c->cuse, c->K * sizeof(double)));
         HIPCHK(hipHostMalloc(&c->cuse_h, c->K * sizeof(double)));
-        HIPCHK(hipHostMalloc(&c->seq_h, sizeof(unsigned long long)));
+        // the words the host polls / reads right after the poll: explicitly coherent (fine-grained) pinned memory, so a
+        // device store is visible to the host without a stream synchronisation whatever HIP_HOST_COHERENT says
+        HIPCHK(hipHostMalloc(&c->seq_h, sizeof(unsigned long long), hipHostMallocCoherent));
         *c->seq_h = 0;
-        if (const char* v = getenv("GGL_SPIN_WAIT")) c->spin_wait = atoi(v) != 0;
         HIPCHK(hipMalloc(&c->spec_flag, ggl_ctx::MAX_PARTS * sizeof(int)));
         HIPCHK(hipMemset(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int)));
-        HIPCHK(hipHostMalloc(&c->spec_flag_h, ggl_ctx::MAX_PARTS * sizeof(int)));
+        HIPCHK(hipHostMalloc(&c->spec_flag_h, ggl_ctx::MAX_PARTS * sizeof(int), hipHostMallocCoherent));
         memset(c->spec_flag_h, 0, ggl_ctx::MAX_PARTS * sizeof(int));
         c->spec_c = (double*)malloc(c->K * sizeof(double));
         c->spec_beta = (double*)malloc(c->K * sizeof(double));
-        if (const char* v = getenv("GGL_SPECULATE")) c->spec_enable = atoi(v) != 0;
-        if (const char* v = getenv("GGL_SPEC_FACTOR")) c->spec_factor = atof(v);
         HIPCHK(hipMalloc(&c->maxdev, c->K * sizeof(double)));
         HIPCHK(hipHostMalloc(&c->maxdev_h, c->K * sizeof(double)));
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -229,11 +232,79 @@ static int ctx_alloc(ggl_ctx* c)
             HIPCHK(hipStreamCreateWithFlags(&c->streamx[i], hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
         }
-        c->rank_ns = true;
-        if (const char* v = getenv("GGL_RANK_EIG")) c->rank_ns = atoi(v) == 0;   // 1: force the eigh route
+        c->rank_ns = !c->rank_eig;
     }
     return GGL_OK;
 }
+
+static int set_option(ggl_ctx* c, int opt, double v)
+{
+    switch (opt) {
+        case GGL_OPT_SPECULATE: c->spec_enable = v != 0.0; break;
+        case GGL_OPT_SPEC_FACTOR:
+            if (!(v > 0.0)) return fail(GGL_E_ARG, "bad argument: GGL_OPT_SPEC_FACTOR must be positive");
+            c->spec_factor = v;
+            break;
+        case GGL_OPT_NS_MODE:
+            if (v != 0.0 && v != 1.0 && v != 2.0) return fail(GGL_E_ARG, "bad argument: GGL_OPT_NS_MODE is 0, 1 or 2");
+            c->ns_force = (int)v;
+            break;
+        case GGL_OPT_NS_DEGREES: c->ns_degrees = v >= 9 ? 9 : (v >= 5 ? 5 : 3); break;
+        case GGL_OPT_THETA_FLAT: c->theta_flat = v != 0.0; break;
+        case GGL_OPT_RANK_EIG: c->rank_eig = v != 0.0; c->rank_ns = c->omega_ns && !c->rank_eig; break;
+        case GGL_OPT_PARTS: c->ns_parts = std::min(std::max((int)v, 1), (int)ggl_ctx::MAX_PARTS); break;
+        case GGL_OPT_PARTS_MAX_TILES: c->parts_max_tiles = (long)v; break;
+        case GGL_OPT_SYMM_VARIANT:
+            if (v >= 0 && !symm_variant_built((int)v))
+                return fail(GGL_E_ARG, "bad argument: product-kernel variant not in this build");
+            c->symm_variant = (int)v;
+            break;
+        case GGL_OPT_SPIN_WAIT: c->spin_wait = v != 0.0; break;
+        default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
+    }
+    c->spec_have = false;      // a schedule built under other settings is not reused
+    return GGL_OK;
+}
+
+extern "C" int ggl_ctx_set_option(ggl_ctx* c, int opt, double value)
+{
+    ARGCHK(c, "ctx");
+    return set_option(c, opt, value);
+}
+
+extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
+{
+    ARGCHK(c && value, "ctx, value");
+    switch (opt) {
+        case GGL_OPT_SPECULATE: *value = c->spec_enable; break;
+        case GGL_OPT_SPEC_FACTOR: *value = c->spec_factor; break;
+        case GGL_OPT_NS_MODE: *value = c->ns_force; break;
+        case GGL_OPT_NS_DEGREES: *value = c->ns_degrees; break;
+        case GGL_OPT_THETA_FLAT: *value = c->theta_flat; break;
+        case GGL_OPT_RANK_EIG: *value = c->rank_eig; break;
+        case GGL_OPT_PARTS: *value = c->ns_parts; break;
+        case GGL_OPT_PARTS_MAX_TILES: *value = (double)c->parts_max_tiles; break;
+        case GGL_OPT_SYMM_VARIANT: *value = c->symm_variant; break;
+        case GGL_OPT_SPIN_WAIT: *value = c->spin_wait; break;
+        default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
+    }
+    return GGL_OK;
+}
+
+#ifdef GGL_DEV
+// development builds only (libggl_hip_dev.so): experiment knobs from the environment, applied on top of the defaults
+static void dev_env_options(ggl_ctx* c)
+{
+    static const struct { const char* name; int opt; } tab[] = {
+        {"GGL_SPECULATE", GGL_OPT_SPECULATE}, {"GGL_SPEC_FACTOR", GGL_OPT_SPEC_FACTOR}, {"GGL_NS_MODE", GGL_OPT_NS_MODE},
+        {"GGL_NS_DEGREES", GGL_OPT_NS_DEGREES}, {"GGL_THETA_FLAT", GGL_OPT_THETA_FLAT}, {"GGL_RANK_EIG", GGL_OPT_RANK_EIG},
+        {"GGL_TWO_STREAM", GGL_OPT_PARTS}, {"GGL_PARTS_MAX_TILES", GGL_OPT_PARTS_MAX_TILES},
+        {"GGL_SYMM_VARIANT", GGL_OPT_SYMM_VARIANT}, {"GGL_SPIN_WAIT", GGL_OPT_SPIN_WAIT}};
+    for (const auto& t : tab)
+        if (const char* v = getenv(t.name)) (void)set_option(c, t.opt, atof(v));
+    if (const char* v = getenv("GGL_ROCSOLVER_SYEVJ")) c->use_syevj = atoi(v) != 0;
+}
+#endif
 
 extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream, ggl_ctx** out)
 {
@@ -243,6 +314,9 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
     ARGCHK(eig == GGL_EIG_AUTO || eig == GGL_EIG_JACOBI || eig == GGL_EIG_ROCSOLVER || eig == GGL_EIG_NEWTON_SCHULZ,
            "eigensolver selector");
     ARGCHK(eig != GGL_EIG_JACOBI || jacobi_fits(p), "GGL_EIG_JACOBI needs p <= GGL_JACOBI_MAX_P");
+    const int nsm = (flags >> 8) & 0x3, nsd = (flags >> 12) & 0xf;
+    ARGCHK(nsm <= 2, "GGL_EIG_NS_MODE is 0, 1 or 2");
+    ARGCHK(nsd == 0 || nsd == 3 || nsd == 5 || nsd == 9, "GGL_EIG_NS_DEGREES is 3, 5 or 9");
     HIPCHK(hipSetDevice(device));
     ggl_ctx* c = new ggl_ctx();
     c->device = device;
@@ -251,22 +325,22 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
     c->flags = flags;
     c->eig = eig;
     c->omega_ns = use_ns(eig, p);
-    if (const char* v = getenv("GGL_SYMM_VARIANT")) c->symm_variant = atoi(v);
-    if (const char* v = getenv("GGL_NS_MODE")) c->ns_force = atoi(v);   // 1 symmetric, 2 stable (testing)
-    if (const char* v = getenv("GGL_ROCSOLVER_SYEVJ")) c->use_syevj = atoi(v) != 0;
+    c->ns_force = nsm;
+    if (nsd) c->ns_degrees = nsd;
     c->ns_parts = 2;
-    if (const char* v = getenv("GGL_PARTS_MAX_TILES")) c->parts_max_tiles = atol(v);
-    if (const char* v = getenv("GGL_THETA_FLAT")) c->theta_flat = atoi(v) != 0;
-    if (const char* v = getenv("GGL_NS_DEGREES")) c->ns_degrees = atoi(v) >= 9 ? 9 : (atoi(v) >= 5 ? 5 : 3);
-    if (const char* v = getenv("GGL_TWO_STREAM")) c->ns_parts = std::min(std::max(atoi(v), 1), (int)ggl_ctx::MAX_PARTS);
     c->n = (size_t)K * p * p;
-    if (stream) {
+    if (stream || (flags & GGL_CTX_STREAM_GIVEN)) {
+        // GGL_CTX_STREAM_GIVEN: `stream` is the caller's stream even when the handle is NULL (the legacy default
+        // stream, e.g. torch's default stream); without the bit a NULL handle means "create one"
         c->stream = (hipStream_t)stream;
     } else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return fail(GGL_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
+#ifdef GGL_DEV
+    dev_env_options(c);
+#endif
     int rc = ctx_alloc(c);
     if (rc != GGL_OK) { ggl_ctx_destroy(c); return rc; }
     if (!use_jacobi(c)) {
@@ -284,7 +358,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
 {
     if (!c) return GGL_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);      // also valid for the NULL (legacy default) stream
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
@@ -498,6 +572,7 @@ static int upload_par(ggl_ctx* c, int slot, const double* vals, double scalar, d
 // ---------------------------------------------------------------------------------------------
 // the iteration
 // ---------------------------------------------------------------------------------------------
+static constexpr int GGL_SPIN_LIMIT_MS = 2000;
 static constexpr int GGL_SPEC_RETRY = 1;     // internal: a speculative step failed validation, repeat it
 static int omega_step(ggl_ctx* c, int latent, CopySegs* pending = nullptr, bool allow_spec = false);
 
@@ -565,6 +640,8 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         const size_t pp = (size_t)c->p * c->p;
         const int nbb = norm_bounds_blocks(c->p);
         const int var_parts = (c->symm_variant < 0 && nh > 1) ? 17 : c->symm_variant;
+        c->last_parts = nh;
+        c->last_variant = var_parts >= 0 ? var_parts : symm_auto_variant(Kh[0], c->p);
         const size_t region = (size_t)(NS_MAX_LAUNCHES - 4) / nh * NS_SLOT(K);      // coefficient slots per part
         NsPlan plans[ggl_ctx::MAX_PARTS];
         double* start_base_h = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
@@ -685,6 +762,8 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         }
         const int nrun = (nh > 1 && !any_stable) ? nh : 1;
         if (nrun == 1) { Kh[0] = K; k0h[0] = 0; }
+        c->last_parts = nrun;
+        c->last_variant = (c->symm_variant >= 0) ? c->symm_variant : (nrun > 1 ? 17 : symm_auto_variant(K, c->p));
         PB(c, GGL_PH_EIG_OMEGA2);
         for (int h = 0; h < nrun; ++h) {
             const int Kr = Kh[h], k0 = k0h[h];
@@ -757,16 +836,30 @@ static int finish_norms(ggl_ctx* c, int rows, double out_norms[5])
     launch_copy_small(c->stream, dn);
     HIPCHK(hipGetLastError());
     bool waited = false;
-    if (c->seq_wait != 0 && dn.n == 0) {
-        // everything this step produced for the host is in pinned memory and the reduction publishes a sequence
-        // number after it: poll that word (the stream is in order, so all earlier work is complete as well)
+    const unsigned long long want = c->seq_wait;
+    if (want != 0 && dn.n == 0) {
+        // everything this step produced for the host is in (coherent) pinned memory and the reduction publishes a
+        // sequence number after it: poll that word (the stream is in order, so all earlier work is complete as well).
+        // Bounded: after GGL_SPIN_LIMIT_MS the wait falls back to a stream synchronisation, and a sequence number that
+        // is still missing after THAT is an error, not a silent pass.
         const volatile unsigned long long* sq = c->seq_h;
-        for (long spin = 0; spin < 400000000L; ++spin)
-            if (*sq == c->seq_wait) { waited = true; break; }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 1;; ++spin) {
+            if (*sq == want) { waited = true; break; }
+            __builtin_ia32_pause();
+            if ((spin & 0xfff) == 0 &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(GGL_SPIN_LIMIT_MS)) {
+                c->spin_timeouts += 1;
+                break;
+            }
+        }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
     c->seq_wait = 0;
     if (!waited || c->prof_on) HIPCHK(hipStreamSynchronize(c->stream));
+    if (want != 0 && dn.n == 0 && !waited && *(const volatile unsigned long long*)c->seq_h != want)
+        return fail(GGL_E_HIP, "end of iteration: the norm reduction did not publish sequence number %llu (found %llu) "
+                    "although the stream is idle", want, *(const volatile unsigned long long*)c->seq_h);
     c->norms_host = false;
     prof_collect(c);
     if (c->spec_pending || c->sharded_check) {
@@ -828,6 +921,8 @@ static int rank_step(ggl_ctx* c)
         const long ntile = t64 * (t64 + 1) / 2 * K;
         int nh = (K >= 16 && ntile >= 600 && ntile <= c->parts_max_tiles) ? std::min(c->ns_parts, K / 8) : 1;
         nh = std::max(nh, 1);
+        c->last_parts = nh;
+        c->last_variant = (c->symm_variant >= 0) ? c->symm_variant : (nh > 1 ? 17 : symm_auto_variant(K, c->p));
         const size_t pp = (size_t)c->p * c->p;
         if (nh > 1) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
@@ -908,6 +1003,9 @@ extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double la
         }
     } else {
         ARGCHK(lambda1 > 0 && lambda2 > 0, "lambda1, lambda2 must be positive");
+        if (reg == GGL_REG_FGL && c->K > fgl_max_K())
+            return fail(GGL_E_ARG, "FGL Theta-step: K = %d exceeds the %d instances whose K-vectors fit the LDS scan buffer "
+                        "of one workgroup (solver/fgl_helper.py:11-68 is a serial scan along K)", c->K, fgl_max_K());
         PB(c, GGL_PH_THETA);
         if (groupsq_ready && c->omega_ns) {
             // K-sharded: the reduced flag decides for every rank, whether it speculated itself or not
@@ -1078,7 +1176,7 @@ extern "C" int ggl_profile_enable(ggl_ctx* c, int on)
     return GGL_OK;
 }
 
-extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[11])
+extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[16])
 {
     ARGCHK(c && out, "ctx, out");
     out[0] = c->ns_calls;
@@ -1092,6 +1190,11 @@ extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[11])
     out[8] = c->rank_launches;
     out[9] = c->spec_calls;
     out[10] = c->spec_misses;
+    out[11] = c->spin_timeouts;
+    out[12] = c->last_parts;
+    out[13] = c->last_variant;
+    out[14] = c->ns_eigh_fallbacks;
+    out[15] = 0;
     return GGL_OK;
 }
 
@@ -1401,7 +1504,7 @@ extern "C" int ggl_dev_symm(int K, int p, const double* A, const double* B, cons
                             double* C, double* C2, int variant)
 {
     ARGCHK(K >= 1 && p >= 1 && A && B && coef5K && C, "arguments");
-    ARGCHK(variant < symm_variants(), "variant");
+    ARGCHK(variant < 0 || symm_variant_built(variant), "product-kernel variant not in this build");
     const size_t n = (size_t)K * p * p;
     DevBuf dA, dB, dE, dC, dC2, dcoef;
     HIPCHK(dA.alloc(n));
@@ -1424,7 +1527,7 @@ extern "C" int ggl_dev_symm(int K, int p, const double* A, const double* B, cons
 extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* ms_out)
 {
     ARGCHK(K >= 1 && p >= 1 && iters >= 1 && ms_out, "arguments");
-    ARGCHK(variant <= symm_variants(), "variant");   // symm_variants() itself: the no-mirror timing ablation
+    ARGCHK(variant < 0 || symm_variant_built(variant), "product-kernel variant not in this build");
     const size_t n = (size_t)K * p * p;
     std::vector<double> h(n), coef((size_t)K * 5, 0.0);
     unsigned long long s = 88172645463325252ull;
@@ -1458,6 +1561,7 @@ extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* 
     return GGL_OK;
 }
 
+#ifdef GGL_DEV
 // timeline probe: one launch of variant 10; out = [nblocks][5] long long {start, loop, loop_end, end, xcc}
 extern "C" int ggl_dev_symm_timeline(int K, int p, long long* out, int max_blocks, int* nblocks_out)
 {
@@ -1487,6 +1591,8 @@ extern "C" int ggl_dev_symm_timeline(int K, int p, long long* out, int max_block
     return GGL_OK;
 }
 
+#endif   // GGL_DEV
+
 extern "C" int ggl_dev_ns_schedule(double l, int degrees, int max_steps, int* deg_out, double* coef_out, int* units_out)
 {
     ARGCHK(deg_out && coef_out && units_out, "output pointers");
@@ -1496,6 +1602,7 @@ extern "C" int ggl_dev_ns_schedule(double l, int degrees, int max_steps, int* de
     return n;
 }
 
+#ifdef GGL_DEV
 extern "C" int ggl_dev_mfma_f64_peak(double* tflops_out)
 {
     ARGCHK(tflops_out, "tflops_out");
@@ -1520,21 +1627,22 @@ extern "C" int ggl_dev_mfma_f64_peak(double* tflops_out)
     *tflops_out = best;
     return GGL_OK;
 }
+#endif   // GGL_DEV
 
 extern "C" int ggl_eigh_batched(int K, int p, const double* A, double* D, double* Q, int eig_method)
 {
     ARGCHK(D, "D");
-    return eig_common(K, p, A, nullptr, D, Q, nullptr, MAP_IDENT, eig_method);
+    return eig_common(K, p, A, nullptr, D, Q, nullptr, MAP_IDENT, eig_method & 0xff);
 }
 
 extern "C" int ggl_phiplus_matrix(int K, int p, const double* beta, const double* W, double* out, int eig_method)
 {
     ARGCHK(beta && out && W, "beta, W, out");
     ARGCHK(K >= 1 && p >= 1, "K, p");
-    if (use_ns(eig_method, p)) {
+    if (use_ns(eig_method & 0xff, p)) {
         // run the Omega-step of a scratch ctx with Theta = W, X = S = 0, nk = beta, rho = 1
         ggl_ctx* c = nullptr;
-        int rc = ggl_ctx_create(0, K, p, GGL_EIG_NEWTON_SCHULZ, nullptr, &c);
+        int rc = ggl_ctx_create(0, K, p, (eig_method & ~0xff) | GGL_EIG_NEWTON_SCHULZ, nullptr, &c);
         if (rc) return rc;
         std::vector<double> zero((size_t)K * p * p, 0.0);
         rc = ggl_set_S(c, zero.data());
@@ -1544,17 +1652,17 @@ extern "C" int ggl_phiplus_matrix(int K, int p, const double* beta, const double
         ggl_ctx_destroy(c);
         return rc;
     }
-    return eig_common(K, p, W, beta, nullptr, nullptr, out, MAP_PHIPLUS, eig_method);
+    return eig_common(K, p, W, beta, nullptr, nullptr, out, MAP_PHIPLUS, eig_method & 0xff);
 }
 
 extern "C" int ggl_rank_matrix(int K, int p, const double* beta, const double* C, double* out, int eig_method)
 {
     ARGCHK(beta && out && C, "beta, C, out");
     ARGCHK(K >= 1 && p >= 1, "K, p");
-    if (use_ns(eig_method, p)) {
+    if (use_ns(eig_method & 0xff, p)) {
         // the L-step of a scratch ctx: C into the work stack, beta into the mu/rho parameter slot
         ggl_ctx* c = nullptr;
-        int rc = ggl_ctx_create(0, K, p, GGL_EIG_NEWTON_SCHULZ, nullptr, &c);
+        int rc = ggl_ctx_create(0, K, p, (eig_method & ~0xff) | GGL_EIG_NEWTON_SCHULZ, nullptr, &c);
         if (rc) return rc;
         hipError_t e = hipMemcpyAsync(c->W, C, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
@@ -1563,14 +1671,11 @@ extern "C" int ggl_rank_matrix(int K, int p, const double* beta, const double* C
             if (!rc) e = hipMemcpyAsync(out, c->L, c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
             if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
-        if (getenv("GGL_RANK_VERBOSE"))
-            fprintf(stderr, "rank_ns: calls %lld retries %lld fallbacks %lld\n", c->rank_calls, c->rank_retries,
-                    c->rank_fallbacks);
         ggl_ctx_destroy(c);
         if (e != hipSuccess) return fail(GGL_E_HIP, "ggl_rank_matrix: %s", hipGetErrorString(e));
         return rc;
     }
-    return eig_common(K, p, C, beta, nullptr, nullptr, out, MAP_RANK, eig_method);
+    return eig_common(K, p, C, beta, nullptr, nullptr, out, MAP_RANK, eig_method & 0xff);
 }
 
 static int recon_common(int K, int p, const double* beta, const double* D, const double* Q, double* out, int map)
@@ -1629,6 +1734,8 @@ extern "C" int ggl_prox_p(int K, int p, const double* X, double l1, double l2, i
     ARGCHK(K >= 1 && p >= 1 && X && out, "arguments");
     ARGCHK(reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
     ARGCHK(l1 > 0 && l2 > 0, "lambda 1 and lambda2 have to be positive");
+    if (reg == GGL_REG_FGL && K > fgl_max_K())
+        return fail(GGL_E_ARG, "prox_p (FGL): K = %d exceeds the %d instances the LDS scan buffer holds", K, fgl_max_K());
     const size_t n = (size_t)K * p * p;
     DevBuf dX, dO, dW;
     HIPCHK(dX.alloc(n));

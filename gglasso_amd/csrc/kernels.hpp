@@ -85,6 +85,8 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
                              const double* Omega, const double* OmegaPrev, const double* L,
                              double l1, double l2, const double* groupsq, double* sqwork, int fuse_dual,
                              double* partials, int K, int p, int flat = 0, const int* skip = nullptr);
+// largest K the FGL Theta-step kernel serves (K-vectors of an 8x8 tile pair in one workgroup's LDS)
+int fgl_max_K();
 // number of K-chunks the GGL kernels split the stack into (grid.y)
 int ggl_chunks(int K, int p);
 // GGL pass 1 only: sq[c](p,p)[i<j] = sum_{k in chunk c} soft(Omega+L+X, l1)^2,  c < ggl_chunks(K,p)
@@ -124,11 +126,13 @@ void launch_recon(hipStream_t st, double* out, const double* R, const double* D,
 // symmetric A, B (so that A*B = A^T*B is symmetric).  coef: device [K][5] = {cI,cAcc,cE,dI,dC}.
 // variant < 0: pick by problem size.  FP64 MFMA.
 int symm_variants();
+bool symm_variant_built(int v);          // the shipped library holds the dispatched instances only (gemm_sym.hip)
+int symm_auto_variant(int nprod, int p); // what variant < 0 resolves to for nprod products of p x p matrices in a launch
 // maxdev (optional, device [K], zeroed by the caller): max |C - I| per instance.
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                  const double* coef, int K, int p, int variant, double* maxdev = nullptr);
 
-// measured FP64 matrix-core ceiling (MFMA-only probe kernel)
+// measured FP64 matrix-core ceiling (MFMA-only probe kernel; GGL_DEV builds)
 double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nacc);
 double mfma_valu_mix_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nv);
 // C[b] = scal[b % K] * A[b] * T[b % K] (T symmetric, A general), b < nbatch; full output.  FP64 MFMA.

@@ -34,6 +34,7 @@ static inline int fgl_tile(int K) { return (K <= 32) ? 16 : 8; }
 static constexpr int FGL_MAX_K_TD8 = (160 * 1024 - 1024) / (8 * 8 * 8);   // LDS scan buffer bound
 
 int ggl_chunks(int K, int p);
+int fgl_max_K() { return FGL_MAX_K_TD8; }
 
 int pval_blocks(int p)
 {

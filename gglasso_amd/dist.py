@@ -42,9 +42,15 @@ class _DeviceView:
 
 class TorchComm:
     """All-reduces over a torch.distributed process group.  With the nccl backend the tensors stay in
-    HBM and the collective is RCCL; with gloo (CPU tests) they are host tensors."""
+    HBM and the collective is RCCL; with gloo (CPU tests) they are host tensors.
 
-    def __init__(self, group=None, device=None):
+    Stream discipline (nccl): the engine's kernels and the collectives must be ordered on ONE stream -- RCCL orders
+    a collective against the stream that is current when it is issued, and nothing else orders it against kernels on
+    another stream.  The communicator therefore owns a dedicated ``torch.cuda.Stream`` (``self.stream``), the ctx is
+    created on that stream's (non-NULL) handle, and every collective is issued under ``torch.cuda.stream(self.stream)``
+    after checking that the engine really runs on it."""
+
+    def __init__(self, group=None, device=None, stream=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -55,26 +61,47 @@ class TorchComm:
         self._gs = None
         self._nrm = None
         self.device_norms = self.backend == "nccl"      # all-reduce the norms where the kernels leave them
+        self.stream = None
+        if self.backend == "nccl":
+            self.stream = stream if stream is not None else torch.cuda.Stream(device=device)
+
+    @property
+    def stream_handle(self):
+        """HIP stream handle to create the engine on (None for host backends)."""
+        return None if self.stream is None else int(self.stream.cuda_stream)
+
+    def _on_stream(self, eng=None):
+        import contextlib
+        if self.stream is None:
+            return contextlib.nullcontext()
+        if eng is not None and getattr(eng, "stream_handle", None) != self.stream_handle:
+            raise RuntimeError("TorchComm: the engine does not run on the communicator's stream "
+                               f"(engine {getattr(eng, 'stream_handle', None)}, comm {self.stream_handle}): the collective "
+                               "would not be ordered against its kernels")
+        return self.torch.cuda.stream(self.stream)
 
     def allreduce_groupsq(self, eng):
         # the tensor aliases a buffer of THIS engine's ctx: one comm may serve several solves
         if self._gs is None or self._gs[0] is not eng:
             self._gs = (eng, eng.groupsq_tensor(self.torch, self.device))
-        self.dist.all_reduce(self._gs[1], op=self.dist.ReduceOp.SUM, group=self.group)
+        with self._on_stream(eng):
+            self.dist.all_reduce(self._gs[1], op=self.dist.ReduceOp.SUM, group=self.group)
         eng.groupsq_written(self._gs[1])
 
     def allreduce_norms_device(self, eng):
         if self._nrm is None or self._nrm[0] is not eng:
             self._nrm = (eng, eng.norms_tensor(self.torch, self.device))
-        self.dist.all_reduce(self._nrm[1], op=self.dist.ReduceOp.SUM, group=self.group)
+        with self._on_stream(eng):
+            self.dist.all_reduce(self._nrm[1], op=self.dist.ReduceOp.SUM, group=self.group)
         return eng.read_norms()
 
     def allreduce_norms(self, arr):
         t = self.torch.as_tensor(np.asarray(arr, dtype=np.float64))
-        if self.backend == "nccl":
-            t = t.to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return t.cpu().numpy()
+        with self._on_stream():
+            if self.backend == "nccl":
+                t = t.to(self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            return t.cpu().numpy()
 
 
 def _hip_groupsq_tensor(self, torch, device):
@@ -88,7 +115,7 @@ def _hip_norms_tensor(self, torch, device):
 
 
 def _hip_groupsq_written(self, t):
-    pass    # the tensor aliases the ctx buffer; same stream => already ordered
+    pass    # the tensor aliases the ctx buffer; TorchComm issued the collective on the ctx's own stream => ordered
 
 
 _solver.HipEngine.groupsq_tensor = _hip_groupsq_tensor
@@ -121,9 +148,9 @@ def ADMM_MGL_sharded(S_local, lambda1, lambda2, reg, Omega_0, K_total, comm, The
         X_0 = np.zeros((Kl, p, p))
     kw = dict(engine_kwargs or {})
     if comm.backend == "nccl":
-        # run the ctx on torch's current stream: RCCL orders itself against that stream, so the
-        # all-reduce needs no host synchronisation on either side
-        kw.setdefault("stream", comm.torch.cuda.current_stream().cuda_stream)
+        # the ctx runs on the communicator's dedicated stream: RCCL orders a collective against the stream it is
+        # issued on, so kernels and all-reduces need no host synchronisation on either side (TorchComm checks it)
+        kw.setdefault("stream", comm.stream_handle)
         kw.setdefault("device", device)
     eng = _solver.ENGINE(S_local, Omega_0, Theta_0, X_0, **kw)
     try:

@@ -63,19 +63,20 @@ def prox_rank_norm(A, beta, D=np.array([]), Q=np.array([])):
     return out[0] if single else out
 
 
-def phiplus_matrix(W, beta, method=_lib.EIG_AUTO):
-    """eigh + phiplus fused (what one Omega-step runs, admm_solver.py:180-187)."""
+def phiplus_matrix(W, beta, method=_lib.EIG_AUTO, ns_mode=0, ns_degrees=0):
+    """eigh + phiplus fused (what one Omega-step runs, admm_solver.py:180-187).  ns_mode / ns_degrees: the
+    Newton-Schulz controls of include/ggl_hip.h (GGL_EIG_NS_MODE / GGL_EIG_NS_DEGREES), for the parity tests."""
     W = as_c(W)
     single = W.ndim == 2
     W3 = W[None] if single else W
     K, p, _ = W3.shape
     b = as_c(np.broadcast_to(np.asarray(beta, dtype=np.float64), (K,)))
     out = np.empty((K, p, p))
-    check(_lib_gpu().ggl_phiplus_matrix(K, p, ptr(b), ptr(W3), ptr(out), method))
+    check(_lib_gpu().ggl_phiplus_matrix(K, p, ptr(b), ptr(W3), ptr(out), _lib.eig_flags(method, ns_mode, ns_degrees)))
     return out[0] if single else out
 
 
-def rank_matrix(C, beta, method=_lib.EIG_AUTO):
+def rank_matrix(C, beta, method=_lib.EIG_AUTO, ns_degrees=0):
     """eigh + prox_rank_norm fused (L-step, admm_solver.py:197-205)."""
     C = as_c(C)
     single = C.ndim == 2
@@ -83,7 +84,7 @@ def rank_matrix(C, beta, method=_lib.EIG_AUTO):
     K, p, _ = C3.shape
     b = as_c(np.broadcast_to(np.asarray(beta, dtype=np.float64), (K,)))
     out = np.empty((K, p, p))
-    check(_lib_gpu().ggl_rank_matrix(K, p, ptr(b), ptr(C3), ptr(out), method))
+    check(_lib_gpu().ggl_rank_matrix(K, p, ptr(b), ptr(C3), ptr(out), _lib.eig_flags(method, 0, ns_degrees)))
     return out[0] if single else out
 
 

@@ -21,23 +21,43 @@ from ._lib import as_c, check, ptr
 _REG = {"SGL": _lib.REG_SGL, "GGL": _lib.REG_GGL, "FGL": _lib.REG_FGL}
 
 
+# ctx options (include/ggl_hip.h GGL_OPT_*, names in _lib.OPTIONS) every engine is created with.  Empty in normal
+# use: the library's defaults are the measured best.  The parity tests set entries to drive the iteration through
+# every dispatch (speculation hits and forced misses, both Newton-Schulz product modes, the mirroring Theta kernels).
+ENGINE_OPTIONS = {}
+
+
 class HipEngine:
     """Device-resident ADMM state behind the C ABI (one ggl_ctx)."""
 
-    def __init__(self, S, Omega_0, Theta_0, X_0, L_0=None, eig=_lib.EIG_AUTO, device=0, stream=None):
+    def __init__(self, S, Omega_0, Theta_0, X_0, L_0=None, eig=_lib.EIG_AUTO, device=0, stream=None, options=None):
+        """stream: None (the ctx creates a private stream) or an int HIP stream handle -- 0 is the legacy default
+        stream itself, not "none" (a NULL handle used to be read as "create one")."""
         _lib.require_gpu()
         self.lib = _lib.load()
         S = as_c(S)
         self.K, self.p, _ = S.shape
         h = _lib._vp()
-        check(self.lib.ggl_ctx_create(int(device), self.K, self.p, int(eig), stream, h))
+        flags = int(eig) | (0 if stream is None else _lib.CTX_STREAM_GIVEN)
+        check(self.lib.ggl_ctx_create(int(device), self.K, self.p, flags, stream, h))
         self.h = h
+        self.stream_handle = None if stream is None else int(stream)
+        for name, value in {**ENGINE_OPTIONS, **(options or {})}.items():
+            self.set_option(name, value)
         check(self.lib.ggl_set_S(self.h, ptr(S)))
         L_0 = None if L_0 is None else as_c(L_0)
         check(self.lib.ggl_set_state(self.h, ptr(as_c(Omega_0)), ptr(as_c(Theta_0)), ptr(L_0), ptr(as_c(X_0))))
         self._norms = np.zeros(5)
         self._norms_p = ptr(self._norms)
         self._ptr_cache = {}
+
+    def set_option(self, name, value):
+        check(self.lib.ggl_ctx_set_option(self.h, _lib.OPTIONS[name], float(value)))
+
+    def get_option(self, name):
+        out = np.zeros(1)
+        check(self.lib.ggl_ctx_get_option(self.h, _lib.OPTIONS[name], ptr(out)))
+        return float(out[0])
 
     # -- iteration pieces ------------------------------------------------------------------
     def set_lambda1_mask(self, lam_pp):
@@ -56,7 +76,11 @@ class HipEngine:
     def step(self, rho, lambda1, lambda2, reg, latent, mu1, nk):
         rc = self.lib.ggl_admm_step(self.h, rho, lambda1, lambda2, _REG[reg], int(latent), self._cptr(mu1),
                                     self._cptr(nk), self._norms_p)
-        if rc < 0:
+        if rc != 0:
+            # ggl_admm_step repeats a rejected speculative step itself; a positive code here would mean the
+            # repeat (which does not speculate) was rejected as well
+            if rc > 0:
+                raise RuntimeError(f"ggl_admm_step: unexpected return code {rc} (speculative step rejected twice)")
             check(rc)
         return self._norms
 
@@ -70,9 +94,13 @@ class HipEngine:
     def step_finish(self, rho, lambda1, lambda2, reg, latent, mu1, groupsq_ready, defer_norms=False):
         """defer_norms: leave the five local sums on the device (BUF_NORMS) for an on-device all-reduce; fetch
         them with ``read_norms`` afterwards."""
-        check(self.lib.ggl_step_finish(self.h, rho, lambda1, lambda2, _REG[reg], int(latent), ptr(mu1),
-                                       int(groupsq_ready) | (2 if defer_norms else 0), ptr(self._norms)))
-        return None if defer_norms else self._norms.copy()
+        rc = check(self.lib.ggl_step_finish(self.h, rho, lambda1, lambda2, _REG[reg], int(latent), ptr(mu1),
+                                            int(groupsq_ready) | (2 if defer_norms else 0), ptr(self._norms)))
+        if defer_norms:
+            return None
+        # 1 = the speculative Omega-step of this iteration was rejected (the iterate is untouched, Omega un-flipped):
+        # there are no norms; the caller repeats the iteration with step_omega(speculate=False)
+        return None if rc == 1 else self._norms.copy()
 
     def read_norms(self):
         """The five sums, or None when a speculative Omega-step failed validation on some rank (repeat the step)."""
@@ -151,10 +179,11 @@ class HipEngine:
 
     def ns_stats(self):
         import ctypes
-        out = (ctypes.c_longlong * 11)()
+        out = (ctypes.c_longlong * 16)()
         check(self.lib.ggl_ns_stats(self.h, out))
         return dict(zip(("calls", "steps", "stable_calls", "units", "launches", "rank_calls", "rank_retries",
-                         "rank_fallbacks", "rank_launches", "spec_calls", "spec_misses"), (int(v) for v in out)))
+                         "rank_fallbacks", "rank_launches", "spec_calls", "spec_misses", "spin_timeouts", "last_parts",
+                         "last_variant", "eigh_fallbacks"), (int(v) for v in out)))
 
     def device_ptr(self, which):
         return self.lib.ggl_device_ptr(self.h, which)
@@ -223,21 +252,24 @@ def _run_admm(eng, reg, K_total, p, lambda1, lambda2, latent, mu1, nk, rho, tol,
         if sharded_ggl:
             # device_norms: HIP engine over RCCL.  The Omega-step may then run speculatively; its validation flag
             # rides on the (p,p) all-reduce, so either every rank accepts the step or every rank repeats it.
-            eng.step_omega(rho, latent, nk, *((True,) if device_norms else ()))
-            eng.step_group_partial(rho, lambda1)
-            comm.allreduce_groupsq(eng)
-            if device_norms:
-                # the five sums are all-reduced where they are (HBM) and cross PCIe once, already global
-                eng.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 1, defer_norms=True)
-                sq = comm.allreduce_norms_device(eng)
-                if sq is None:
-                    eng.step_omega(rho, latent, nk)
-                    eng.step_group_partial(rho, lambda1)
-                    comm.allreduce_groupsq(eng)
+            def sharded_pass(speculate):
+                eng.step_omega(rho, latent, nk, *((True,) if speculate else ()))
+                eng.step_group_partial(rho, lambda1)
+                comm.allreduce_groupsq(eng)
+                if device_norms:
+                    # the five sums are all-reduced where they are (HBM) and cross PCIe once, already global
                     eng.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 1, defer_norms=True)
-                    sq = comm.allreduce_norms_device(eng)
-            else:
-                sq = comm.allreduce_norms(eng.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 1))
+                    return comm.allreduce_norms_device(eng)
+                loc = eng.step_finish(rho, lambda1, lambda2, reg, latent, mu1, 1)
+                return None if loc is None else comm.allreduce_norms(loc)
+
+            sq = sharded_pass(device_norms)
+            if sq is None:
+                # the reduced validation flag says some rank's speculative schedule did not cover its spectrum: every
+                # rank left its iterate alone; same iteration again, bounds first
+                sq = sharded_pass(False)
+                if sq is None:
+                    raise RuntimeError("K-sharded ADMM: the non-speculative repeat of an iteration was rejected")
         else:
             sq = eng.step(rho, lambda1, lambda2, reg, latent, mu1, nk)
             if comm is not None:

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GGL_VERSION 100
+#define GGL_VERSION 200
 
 /* error codes */
 #define GGL_OK 0
@@ -44,6 +44,16 @@ extern "C" {
                                  * by scaled Newton-Schulz products on the FP64 matrix cores (any p).
                                  * Steps that need eigenvalues themselves (L-step, exit checks) use AUTO. */
 #define GGL_JACOBI_MAX_P 128
+/* Newton-Schulz controls in the bits above the selector (ctx flags and the eig_method argument of the stateless
+ * ggl_phiplus_matrix / ggl_rank_matrix): product mode 0 auto (by condition number), 1 all-symmetric products,
+ * 2 stable unsymmetrised products; highest step degree 3, 5 or 9 (0 = 9).  Used by the parity tests to reach every
+ * schedule; the solvers pass neither. */
+#define GGL_EIG_NS_MODE(m) (((m) & 0x3) << 8)
+#define GGL_EIG_NS_DEGREES(d) (((d) & 0xf) << 12)
+/* ctx flag: the `stream` argument of ggl_ctx_create is the caller's stream even when the handle is NULL (the legacy
+ * default stream -- what torch.cuda.current_stream().cuda_stream is for torch's default stream).  Without the bit a
+ * NULL handle means "create a private non-blocking stream", which has NO implicit ordering with the NULL stream. */
+#define GGL_CTX_STREAM_GIVEN (1 << 16)
 
 /* which-buffer selector of ggl_device_ptr */
 #define GGL_BUF_S 0
@@ -64,11 +74,29 @@ int ggl_device_count(void);
 
 /* ---- context ---------------------------------------------------------------------------------
  * Replaces the NumPy temporaries ADMM_MGL allocates per call (admm_solver.py:142-154).
- * stream: an existing hipStream_t (e.g. torch's current stream) or NULL to create one. */
+ * stream: an existing hipStream_t or NULL to create one (see GGL_CTX_STREAM_GIVEN for the NULL stream itself). */
 int ggl_ctx_create(int device, int K, int p, int flags, void *stream, ggl_ctx **out);
 int ggl_ctx_destroy(ggl_ctx *ctx);
 int ggl_ctx_sync(ggl_ctx *ctx);
 void *ggl_device_ptr(ggl_ctx *ctx, int which);
+
+/* ctx options.  The shipped library reads NO environment variables: every dispatch decision is a function of the
+ * problem shape and of these options (defaults in brackets).  None of them changes what is computed, only how; the
+ * parity tests run the iteration under each setting.  (A GGL_DEV build of the library -- libggl_hip_dev.so, used by
+ * tools/ -- additionally maps the environment variables GGL_SPECULATE, GGL_SPEC_FACTOR, GGL_NS_MODE, GGL_NS_DEGREES,
+ * GGL_THETA_FLAT, GGL_RANK_EIG, GGL_TWO_STREAM, GGL_PARTS_MAX_TILES, GGL_SYMM_VARIANT, GGL_SPIN_WAIT onto them.) */
+#define GGL_OPT_SPECULATE 1        /* [1] speculative Omega-step (schedule from the previous iteration's bounds)     */
+#define GGL_OPT_SPEC_FACTOR 2      /* [1.02] inflation of the previous bounds; < 1 forces validation misses (tests)  */
+#define GGL_OPT_NS_MODE 3          /* [0] as GGL_EIG_NS_MODE                                                          */
+#define GGL_OPT_NS_DEGREES 4       /* [9] as GGL_EIG_NS_DEGREES                                                       */
+#define GGL_OPT_THETA_FLAT 5       /* [1] per-element GGL Theta-step kernel for exactly symmetric states, K <= 32    */
+#define GGL_OPT_RANK_EIG 6         /* [0] L-step by eigendecomposition instead of the sign iteration                 */
+#define GGL_OPT_PARTS 7            /* [2] parts of the batch that run their launch sequences concurrently (1..4)     */
+#define GGL_OPT_PARTS_MAX_TILES 8  /* [2048] concurrent parts only up to this many 64x64 tile pairs in the batch     */
+#define GGL_OPT_SYMM_VARIANT 9     /* [-1 = by size] product-kernel instance, see csrc/gemm_sym.hip                   */
+#define GGL_OPT_SPIN_WAIT 10       /* [1] wait for the end of an iteration by polling a pinned sequence number       */
+int ggl_ctx_set_option(ggl_ctx *ctx, int option, double value);
+int ggl_ctx_get_option(ggl_ctx *ctx, int option, double *value);
 
 /* ---- state upload / download ----------------------------------------------------------------
  * S: admm_solver.py:13 (argument S).  set_state: Omega_0/Theta_0/X_0 copies, admm_solver.py:142-150
@@ -174,17 +202,18 @@ int ggl_profile_read(ggl_ctx *ctx, double ms[GGL_NPHASE], long long count[GGL_NP
 /* Newton-Schulz statistics since ctx creation: Omega-step {calls, steps, calls that took the stable
  * schedule, algorithmic work in units of K*p^3 flop, kernel launches}; L-step {calls, retries at the
  * finer resolution, fallbacks to the eigendecomposition, kernel launches (each K*p^3 flop)}; speculative
- * Omega-steps {taken, failed validation and repeated}. */
-int ggl_ns_stats(ggl_ctx *ctx, long long out[11]);
+ * Omega-steps {taken, failed validation and repeated}; [11] end-of-iteration polls that timed out and fell back to a
+ * stream synchronisation; what the LAST matrix-function step dispatched: [12] concurrent parts, [13] product-kernel
+ * variant (csrc/gemm_sym.hip); [14] Omega-steps that fell back to the eigendecomposition; [15] reserved. */
+int ggl_ns_stats(ggl_ctx *ctx, long long out[16]);
 
-/* ---- development / tuning entry points (not used by the solvers) ------------------------------
- * ggl_dev_symm: one launch of the symmetric-product kernel on host data (kernel unit test).
- * ggl_dev_symm_bench: average milliseconds of `iters` launches on random device data. */
+/* ---- kernel-level test / measurement entry points (not used by the solvers) --------------------
+ * ggl_dev_symm: one launch of the symmetric-product kernel on host data (kernel unit test; variant < 0 = by size).
+ * ggl_dev_symm_bench: average milliseconds of `iters` launches on random device data (HIP events).
+ * Both return GGL_E_ARG for a variant that is not in this build. */
 int ggl_dev_symm(int K, int p, const double *A, const double *B, const double *E, const double *coef5K,
                  double *C, double *C2, int variant);
 int ggl_dev_symm_bench(int K, int p, int variant, int iters, double *ms_out);
-/* measured FP64 matrix-core ceiling of this GPU in TFLOP/s (MFMA-only probe kernel) */
-int ggl_dev_mfma_f64_peak(double *tflops_out);
 /* host only (no GPU needed): the Newton-Schulz step schedule the Omega-step would run for a spectrum in [l,1]
  * (x = sqrt(eig(Z Y))).  degrees 3 = cubic steps, 5 = cubic/quintic mix, 9 = cubic/quintic/degree-nine mix.
  * deg_out[max_steps] receives 3, 5 or 9 per step, coef_out[max_steps*6] = {t0..t4,l_after} of
@@ -193,8 +222,13 @@ int ggl_dev_mfma_f64_peak(double *tflops_out);
  * instead (every step costs X^2, [t], X t: 2 / 3 / 4 products; *units_out without the first and the last product).
  * Returns the number of steps or GGL_E_ARG. */
 int ggl_dev_ns_schedule(double l, int degrees, int max_steps, int *deg_out, double *coef_out, int *units_out);
-/* per-workgroup timestamps {start, loop begin, loop end, end, XCC id} of one launch of the 64x64 kernel */
+#ifdef GGL_DEV
+/* libggl_hip_dev.so only (python -m gglasso_amd.build --dev): measured FP64 matrix-core ceiling of this GPU in TFLOP/s
+ * (MFMA-only probe kernel); per-workgroup timestamps {start, loop begin, loop end, end, XCC id} of one launch of the
+ * 64x64 kernel */
+int ggl_dev_mfma_f64_peak(double *tflops_out);
 int ggl_dev_symm_timeline(int K, int p, long long *out, int max_blocks, int *nblocks_out);
+#endif
 
 /* ---- stateless operator entry points (host buffers; used for operator-level parity) ---------- */
 /* numpy.linalg.eigh on a stack (lower triangle read); D (K,p) ascending, Q (K,p,p) columns. */

@@ -160,9 +160,9 @@ def test_asymmetric_dual_start_takes_the_mirroring_kernels(sol, p, monkeypatch):
         for nm in ('Omega', 'Theta', 'X'):
             assert np.abs(s[nm] - ref[nm]).max() <= 1e-9, nm
         assert np.array_equal(s['Theta'], s['Theta'].transpose(0, 2, 1))
-    monkeypatch.setenv("GGL_THETA_FLAT", "0")
+    monkeypatch.setitem(sol.ENGINE_OPTIONS, "theta_flat", 0)
     (s0, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, X_0=X0, max_iter=10, tol=1e-20, rtol=1e-20)
-    monkeypatch.setenv("GGL_THETA_FLAT", "1")
+    monkeypatch.setitem(sol.ENGINE_OPTIONS, "theta_flat", 1)
     (s1, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, X_0=X0, max_iter=10, tol=1e-20, rtol=1e-20)
     assert np.abs(s0['Theta'] - s1['Theta']).max() <= 1e-12
 
@@ -280,20 +280,15 @@ def test_sharded_driver_on_rccl_single_rank(sol):
     import os
     try:
         # p = 150 takes the Newton-Schulz Omega-step, speculative after the first iteration: its validation flag rides
-        # on the (p,p) all-reduce.  GGL_SPEC_FACTOR=0.9 deflates the assumed bounds so that every speculative step
-        # is rejected (by the all-reduced flag) and repeated; 0 switches speculation off.
-        for (K, p, env) in ((5, 40, {}), (3, 150, {}), (3, 150, {"GGL_SPEC_FACTOR": "0.9"}), (3, 150, {"GGL_SPECULATE": "0"})):
+        # on the (p,p) all-reduce.  spec_factor 0.9 deflates the assumed bounds so that every speculative step
+        # is rejected (by the all-reduced flag) and repeated; speculate 0 switches speculation off.
+        for (K, p, env) in ((5, 40, {}), (3, 150, {}), (3, 150, {"spec_factor": 0.9}), (3, 150, {"speculate": 0})):
             S, _ = synth.make_problem("GGL", K, p, seed=31)
             Om0 = np.stack([np.eye(p)] * K)
             comm = TorchComm(device="cuda:0")
-            saved = {k: os.environ.get(k) for k in ("GGL_SPEC_FACTOR", "GGL_SPECULATE")}
-            os.environ.update(env)
-            try:
-                (a, ia), _ = quiet(ADMM_MGL_sharded, S, 0.05, 0.02, "GGL", Om0, K, comm, tol=1e-9, rtol=1e-9,
-                                   measure=True)
-            finally:
-                for k, v in saved.items():
-                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            assert comm.stream_handle not in (None, 0)       # a dedicated stream, never the NULL handle
+            (a, ia), _ = quiet(ADMM_MGL_sharded, S, 0.05, 0.02, "GGL", Om0, K, comm, tol=1e-9, rtol=1e-9,
+                               measure=True, engine_kwargs={"options": env})
             (b, ib), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.02, "GGL", Om0, tol=1e-9, rtol=1e-9, measure=True)
             assert ia["status"] == ib["status"] == "optimal"
             assert len(ia["residual"]) == len(ib["residual"])
@@ -336,7 +331,7 @@ def test_g12_batched_single_grid_search(sol):
 def test_speculative_omega_step_hit_and_miss(sol, reg, K, p, monkeypatch):
     """The Omega-step runs its products on a schedule built from the previous iteration's spectral bounds and
     validates them on the device afterwards.  Hits (default 2 % inflation) and forced misses (bounds deflated by
-    GGL_SPEC_FACTOR=0.9: the Theta-step kernels must leave the iterate alone and the step is repeated) and no
+    spec_factor 0.9: the Theta-step kernels must leave the iterate alone and the step is repeated) and no
     speculation at all must produce the same trajectory as the oracle."""
     from gglasso_amd import synth, solver
     S, _ = synth.make_problem(reg, K=K, p=p, N=2 * p, seed=31)
@@ -350,12 +345,9 @@ def test_speculative_omega_step_hit_and_miss(sol, reg, K, p, monkeypatch):
         real_close(self)
 
     monkeypatch.setattr(solver.HipEngine, "close", closing)
-    for env, want_spec, want_miss in (({"GGL_SPECULATE": "0"}, False, False), ({}, True, False),
-                                      ({"GGL_SPEC_FACTOR": "0.9"}, True, True)):
-        for k in ("GGL_SPECULATE", "GGL_SPEC_FACTOR"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for env, want_spec, want_miss in (({"speculate": 0}, False, False), ({}, True, False),
+                                      ({"spec_factor": 0.9}, True, True)):
+        monkeypatch.setattr(solver, "ENGINE_OPTIONS", dict(env))
         (s, info), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, reg, Om0, max_iter=14, tol=1e-20, rtol=1e-20)
         for nm in ('Omega', 'Theta', 'X'):
             assert np.abs(s[nm] - ref[nm]).max() <= 1e-9, (env, nm)

@@ -188,13 +188,18 @@ def _commuting_pair(rng, K, p):
     return 0.5 * (A + A.transpose(0, 2, 1)), 0.5 * (B + B.transpose(0, 2, 1))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 8, 9, 16])
-@pytest.mark.parametrize("K,p", [(2, 40), (3, 129), (2, 200), (1, 333), (9, 70), (2, 500)])
+# the instances the shipped library dispatches to (csrc/gemm_sym.hip): 0 / 9 register-staged 64x64 / 32x32 tiles,
+# 16 / 17 direct-to-LDS 64x64 with 2 / 3 DMA stages (17 = the headline's concurrent parts), 20 direct-to-LDS 32x32;
+# -1 = the size rule itself.  (16, 500) is one concurrent part of the headline batch: 576 tile pairs, > 1 round of tiles.
+@pytest.mark.parametrize("variant", [-1, 0, 9, 16, 17, 20])
+@pytest.mark.parametrize("K,p", [(2, 40), (3, 129), (2, 200), (1, 333), (9, 70), (2, 500), (16, 500), (3, 1000)])
 def test_symm_product_kernel(variant, K, p):
     """C = cI*I + cAcc*A*B + cE*E and C2 = dI*I + dC*C for commuting symmetric A, B (every tile shape)."""
     from gglasso_amd import _lib
     from gglasso_amd._lib import ptr
     lib = _lib.load()
+    if K * p * p > 3_000_000 and variant in (0, 9):
+        pytest.skip("large batches are covered on the kernels that are dispatched there")
     rng = np.random.default_rng(variant * 100 + p)
     A, B = _commuting_pair(rng, K, p)
     E = rng.standard_normal((K, p, p))
@@ -241,30 +246,28 @@ def test_phiplus_newton_schulz_sizes(ops, K, p):
         assert np.array_equal(out, out.transpose(0, 2, 1))
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_phiplus_newton_schulz_both_product_modes(ops, mode, monkeypatch):
-    """GGL_NS_MODE=1: all-symmetric products (accurate for small condition numbers only);
-    GGL_NS_MODE=2: stable unsymmetrised products (any condition number)."""
-    monkeypatch.setenv("GGL_NS_MODE", mode)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_phiplus_newton_schulz_both_product_modes(ops, mode):
+    """GGL_EIG_NS_MODE(1): all-symmetric products (accurate for small condition numbers only);
+    GGL_EIG_NS_MODE(2): stable unsymmetrised products (any condition number)."""
     rng = np.random.default_rng(41)
     W = _sym(rng, 3, 150, 0.3)                    # kappa ~ 10
     beta = np.array([0.5, 1.0, 2.0])
     ref, _ = orc.phiplus_stack(W, beta)
-    assert np.abs(ops.phiplus_matrix(W, beta, method=3) - ref).max() <= 1e-12 * np.abs(ref).max()
-    if mode == "2":
+    assert np.abs(ops.phiplus_matrix(W, beta, method=3, ns_mode=mode) - ref).max() <= 1e-12 * np.abs(ref).max()
+    if mode == 2:
         for scale in (30.0, 1000.0):               # kappa 1e6 .. 1e9
             W = _sym(rng, 2, 150, scale)
             ref, _ = orc.phiplus_stack(W, 0.08)
-            out = ops.phiplus_matrix(W, 0.08, method=3)
+            out = ops.phiplus_matrix(W, 0.08, method=3, ns_mode=mode)
             assert np.abs(out - ref).max() <= 1e-10 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("degrees", ["3", "5", "9"])
-def test_phiplus_newton_schulz_step_degrees(ops, degrees, monkeypatch):
-    """GGL_NS_DEGREES caps the step degree of the fast schedule (cubic only / + quintic / + degree nine): every
+@pytest.mark.parametrize("degrees", [3, 5, 9])
+def test_phiplus_newton_schulz_step_degrees(ops, degrees):
+    """GGL_EIG_NS_DEGREES caps the step degree of the fast schedule (cubic only / + quintic / + degree nine): every
     mix must reach the eigendecomposition's accuracy over the whole range of condition numbers the fast
     (all-symmetric) schedule serves, kappa(W^2 + 4 beta I) from 1 to 300."""
-    monkeypatch.setenv("GGL_NS_DEGREES", degrees)
     rng = np.random.default_rng(17)
     p, beta = 192, 0.7
     for kappa in (1.0, 1.5, 4.0, 50.0, 280.0):
@@ -277,7 +280,7 @@ def test_phiplus_newton_schulz_step_degrees(ops, degrees, monkeypatch):
             W[k] = (Q * w) @ Q.T
             W[k] = 0.5 * (W[k] + W[k].T)
         ref, _ = orc.phiplus_stack(W, beta)
-        out = ops.phiplus_matrix(W, beta, method=3)
+        out = ops.phiplus_matrix(W, beta, method=3, ns_degrees=degrees)
         assert np.abs(out - ref).max() <= 2e-13 * max(1.0, np.abs(ref).max()), (degrees, kappa)
         assert np.array_equal(out, out.transpose(0, 2, 1))
 
@@ -316,19 +319,18 @@ def test_rank_newton_schulz_sizes_and_thresholds(ops, K, p):
             assert np.abs(out).max() <= 1e-12
 
 
-@pytest.mark.parametrize("degrees", ["3", "5", "9"])
-def test_rank_newton_schulz_step_degrees(ops, degrees, monkeypatch):
+@pytest.mark.parametrize("degrees", [3, 5, 9])
+def test_rank_newton_schulz_step_degrees(ops, degrees):
     """The sign iteration of the L-step under every cap of the step degree (cubic only / + quintic / + degree nine):
     same accuracy, and the residual check (which reads max|T_last - I| of a T that has an E term for the higher
     degrees) must accept the converged result instead of falling back."""
-    monkeypatch.setenv("GGL_NS_DEGREES", degrees)
     rng = np.random.default_rng(61)
     K, p = 3, 180
     W = _sym(rng, K, p, 1.0)
     for beta in (0.05, 1.0, 5.0):
         b = np.full(K, beta)
         ref = orc.rank_stack(W, b)
-        out = ops.rank_matrix(W, b, method=3)
+        out = ops.rank_matrix(W, b, method=3, ns_degrees=degrees)
         assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(W).max()) * p, (degrees, beta)
         assert np.array_equal(out, out.transpose(0, 2, 1))
 

@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gglasso_amd import _lib
 from gglasso_amd._lib import ptr
-lib = _lib.load()
+lib = _lib.load_dev()      # libggl_hip_dev.so: python -m gglasso_amd.build --dev
 for (K, p) in ((16, 500), (8, 500), (4, 500), (20, 200), (8, 1000)):
     for v in (9, 20, 16, 17):
         ms = np.zeros(1)

@@ -3,7 +3,7 @@ import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from gglasso_amd import _lib
 from gglasso_amd._lib import ptr
-lib = _lib.load()
+lib = _lib.load_dev()      # libggl_hip_dev.so: python -m gglasso_amd.build --dev
 pk = np.zeros(1); _lib.check(lib.ggl_dev_mfma_f64_peak(ptr(pk))); print('FP64 MFMA probe peak: %.1f TF/s' % pk[0], flush=True)
 for (K, p) in ((32, 500), (64, 500), (32, 1000), (4, 500)):
     for v in (0, 16):

@@ -13,7 +13,7 @@ comm = TorchComm(device="cuda:0")
 K, p = 4, 500
 S, _ = synth.make_problem("GGL", K, p, N=2 * p, seed=3)
 Om0 = np.stack([np.eye(p)] * K)
-eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), stream=torch.cuda.current_stream().cuda_stream, device=0)
+eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), stream=comm.stream_handle, device=0)
 nk = np.ones(K)
 T = {k: 0.0 for k in ("omega", "gp", "ar_gs", "finish", "ar_n", "finish_sync", "ar_n_host")}
 def tick(name, t0):

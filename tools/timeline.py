@@ -4,7 +4,7 @@ import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gglasso_amd import _lib
-lib = _lib.load()
+lib = _lib.load_dev()      # libggl_hip_dev.so: python -m gglasso_amd.build --dev
 K, p = int(sys.argv[1]), int(sys.argv[2])
 mx = 20000
 buf = (ctypes.c_longlong * (mx * 5))()
