@@ -535,3 +535,173 @@ def block_SGL(S, lambda1, Omega_0, Theta_0=None, X_0=None, rho=1., max_iter=1000
     inv[per] = np.arange(per.size)
     ixp = np.ix_(inv, inv)
     return {'Omega': block_diag(*allOmega)[ixp], 'Theta': block_diag(*allTheta)[ixp], 'X': block_diag(*allX)[ixp]}
+
+
+# ---------------------------------------------------------------------------------------------
+# ext_ADMM_MGL: Group Graphical Lasso over instances of DIFFERENT dimension (solver/ext_admm_solver.py)
+# ---------------------------------------------------------------------------------------------
+
+def check_G(G, p):
+    """helper/ext_admm_helper.py:82-102."""
+    K = G.shape[2]
+    assert G.dtype == int, "G needs to be an integer array"
+    assert np.all(G.sum(axis=2) >= -K), "G has rows with only -1 entries"
+    assert np.all(((G == -1).sum(axis=0) == 2) | ((G == -1).sum(axis=0) == 0)), \
+        "Only row or column index specified in some group"
+    assert np.all((G[0] + G[1] == -2) | (G[0] != G[1])), "G has entries on the diagonal!"
+    assert np.all(G >= -1), "No negative indices allowed (only -1 for indicating a missing feature)"
+    assert np.all(G.max(axis=(0, 1)) < p), "indices larger as dimension were found"
+    assert np.all(G[0] <= G[1]), "Only upper diagonal entries should be contained in G"
+
+
+def construct_trivial_G(p, K):
+    """helper/ext_admm_helper.py:31-44: every pair i<j present in every instance, row-major pair order."""
+    iu = np.triu_indices(p, 1)
+    G = np.zeros((2, len(iu[0]), K), dtype=int)
+    G[0] = iu[0][:, None]
+    G[1] = iu[1][:, None]
+    return G
+
+
+def prox_2norm_G(X, G, l2):
+    """solver/ext_admm_solver.py:394-453 (prox_2norm_G + prox_G_inner): for every group l the vector of the entries
+    X[k][G[0,l,k], G[1,l,k]] of the instances that hold the pair (G != -1) is shrunk with threshold
+    l2*sqrt(group size) and written back to (i,j) and (j,i); entries outside every group pass through.
+    X: dict k -> (p_k,p_k) symmetric array.  The groups are processed in order on the same arrays, exactly as the
+    reference's loop does (an entry listed in two groups is shrunk twice)."""
+    assert l2 > 0
+    K = len(X)
+    for k in range(K):
+        assert np.abs(X[k] - X[k].T).max() <= 1e-5, "X[k] has to be symmetric"
+    assert G.shape[0] == 2 and G.shape[2] == K
+    group_size = (G[0] != -1).sum(axis=1)
+    out = {k: X[k].copy() for k in range(K)}
+    for l in range(G.shape[1]):
+        ks = np.flatnonzero(G[0, l] != -1)
+        v = np.array([out[k][G[0, l, k], G[1, l, k]] for k in ks])
+        lam = l2 * np.sqrt(group_size[l])
+        a = max(np.sqrt((v ** 2).sum()), lam)
+        z = v * (a - lam) / a
+        for n, k in enumerate(ks):
+            out[k][G[0, l, k], G[1, l, k]] = z[n]
+            out[k][G[1, l, k], G[0, l, k]] = z[n]
+    return out
+
+
+def ext_stopping_criterion(Omega, Omega_t_1, Theta, L, Lambda, Lambda_t_1, X0, X1, rho, p, eps_abs, eps_rel):
+    """solver/ext_admm_solver.py:325-345."""
+    K = len(Omega)
+    dim = ((p ** 2 + p) / 2).sum()
+    n2 = lambda A: np.linalg.norm(A) ** 2
+    D1 = np.sqrt(sum(n2(Omega[k]) + n2(Lambda[k]) for k in range(K)))
+    D2 = np.sqrt(sum(n2(Theta[k] - L[k]) + n2(Theta[k]) for k in range(K)))
+    D3 = np.sqrt(sum(n2(X0[k]) + n2(X1[k]) for k in range(K)))
+    e_pri = dim * eps_abs + eps_rel * max(D1, D2)
+    e_dual = dim * eps_abs + eps_rel * rho * D3
+    r = np.sqrt(sum(n2(Omega[k] - Theta[k] + L[k]) + n2(Lambda[k] - Theta[k]) for k in range(K)))
+    s = rho * np.sqrt(sum(n2(Omega[k] - Omega_t_1[k]) + n2(Lambda[k] - Lambda_t_1[k]) for k in range(K)))
+    return r, s, e_pri, e_dual
+
+
+def ext_kkt_stopping_criterion(Omega, Theta, L, Lambda, X0, X1, S, G, lambda1, lambda2, latent=False, mu1=None):
+    """solver/ext_admm_solver.py:347-392; X0, X1 are the UNscaled duals (rho * scaled)."""
+    K = len(S)
+    t = np.zeros((6, K))
+    V = {}
+    n = np.linalg.norm
+    for k in range(K):
+        D, Q = np.linalg.eigh(Omega[k] - S[k] - X0[k])
+        t[0, k] = n(Omega[k] - phiplus(1, D, Q)) / (1 + n(Omega[k]))
+        t[1, k] = n(Theta[k] - prox_od_1norm(Theta[k] + X0[k] - X1[k], lambda1[k])) / (1 + n(Theta[k]))
+        if latent:
+            D, Q = np.linalg.eigh(L[k] - X0[k])
+            t[2, k] = n(L[k] - prox_rank_norm(L[k] - X0[k], mu1[k], D, Q)) / (1 + n(L[k]))
+        V[k] = Lambda[k] + X1[k]
+        t[4, k] = n(Omega[k] - Theta[k] + L[k]) / (1 + n(Theta[k]))
+        t[5, k] = n(Lambda[k] - Theta[k]) / (1 + n(Theta[k]))
+    V = prox_2norm_G(V, G, lambda2)
+    for k in range(K):
+        t[3, k] = n(V[k] - Lambda[k]) / (1 + n(Lambda[k]))
+    return max(n(t[i]) for i in range(6))
+
+
+def ext_ADMM_MGL(S, lambda1, lambda2, reg, Omega_0, G, X0=None, X1=None, tol=1e-5, rtol=1e-4,
+                 stopping_criterion='boyd', rho=1., max_iter=1000, verbose=False, measure=False, latent=False,
+                 mu1=None):
+    """solver/ext_admm_solver.py:18-323.  S, Omega_0, X0, X1: dicts with keys 0..K-1 and (p_k,p_k) arrays.
+    No rho update in this solver (the reference has none)."""
+    K = len(S)
+    p = np.array([S[k].shape[0] for k in range(K)], dtype=int)
+    if isinstance(lambda1, float):
+        lambda1 = lambda1 * np.ones(K)
+    if latent:
+        if isinstance(mu1, float):
+            mu1 = mu1 * np.ones(K)
+        assert mu1 is not None
+        assert np.all(mu1 > 0)
+    assert min(lambda1.min(), lambda2) > 0
+    assert reg in ['GGL']
+    check_G(G, p)
+    assert rho > 0
+    Omega_t = {k: Omega_0[k].copy() for k in range(K)}
+    Theta_t = {k: Omega_0[k].copy() for k in range(K)}
+    Lambda_t = {k: Omega_0[k].copy() for k in range(K)}
+    L_t = {k: np.zeros((p[k], p[k])) for k in range(K)}
+    X0_t = {k: (np.zeros((p[k], p[k])) if X0 is None else X0[k].copy()) for k in range(K)}
+    X1_t = {k: (np.zeros((p[k], p[k])) if X1 is None else X1[k].copy()) for k in range(K)}
+    residual = np.zeros(max_iter)
+    status = ''
+    for iter_t in range(max_iter):
+        Omega_t_1 = Omega_t
+        Omega_t = {}
+        for k in range(K):
+            W = Theta_t[k] - L_t[k] - X0_t[k] - (1 / rho) * S[k]
+            D, Q = np.linalg.eigh(W)
+            Omega_t[k] = phiplus(1 / rho, D, Q)
+        for k in range(K):
+            V = (Omega_t[k] + L_t[k] + X0_t[k] + Lambda_t[k] - X1_t[k]) * 0.5
+            Theta_t[k] = prox_od_1norm(V, lambda1[k] / (2 * rho))
+        if latent:
+            for k in range(K):
+                C = Theta_t[k] - X0_t[k] - Omega_t[k]
+                C = (C.T + C) / 2
+                D, Q = np.linalg.eigh(C)
+                L_t[k] = prox_rank_norm(C, mu1[k] / rho, D, Q)
+        Lambda_t_1 = Lambda_t
+        Lambda_t = prox_2norm_G({k: Theta_t[k] + X1_t[k] for k in range(K)}, G, lambda2 / rho)
+        for k in range(K):
+            X0_t[k] = X0_t[k] + Omega_t[k] - Theta_t[k] + L_t[k]
+            X1_t[k] = X1_t[k] + Theta_t[k] - Lambda_t[k]
+        if stopping_criterion == 'boyd':
+            r_t, s_t, e_pri, e_dual = ext_stopping_criterion(Omega_t, Omega_t_1, Theta_t, L_t, Lambda_t, Lambda_t_1,
+                                                             X0_t, X1_t, rho, p, tol, rtol)
+            residual[iter_t] = max(r_t, s_t)
+            if (r_t <= e_pri) and (s_t <= e_dual):
+                status = 'optimal'
+                break
+        else:
+            eta_A = ext_kkt_stopping_criterion(Omega_t, Theta_t, L_t, Lambda_t, {k: rho * v for k, v in X0_t.items()},
+                                               {k: rho * v for k, v in X1_t.items()}, S, G, lambda1, lambda2, latent,
+                                               mu1)
+            residual[iter_t] = eta_A
+            if eta_A <= tol:
+                status = 'optimal'
+                break
+    if status != 'optimal':
+        if stopping_criterion == 'boyd':
+            status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
+                                                            else 'max iterations reached')
+        else:
+            status = 'max iterations reached'
+    sol = {'Omega': Omega_t, 'Theta': Theta_t, 'L': L_t, 'X0': X0_t, 'X1': X1_t, 'Lambda': Lambda_t}
+    info = {'status': status, 'iterations': iter_t + 1}
+    if measure:
+        info['residual'] = residual[:iter_t + 1]
+    return sol, info
+
+
+def ext_ADMM_MGL_printing(*a, **k):
+    """ext_ADMM_MGL plus the reference's final status line (solver/ext_admm_solver.py:288), for the shared checks."""
+    sol, info = ext_ADMM_MGL(*a, **k)
+    print(f"ADMM terminated after {info['iterations']} iterations with status: {info['status']}.")
+    return sol, info

@@ -1,0 +1,179 @@
+"""Parity at the REAL dispatch of every BASELINE.json configuration: the kernels, tile shapes,
+concurrent-part split and speculation that run at the full sizes are the ones checked here, against the CPU oracle
+on the same seeded inputs (a few iterations -- the oracle's eigh dominates the cost) and through size-independent
+properties (exact symmetry, positive definiteness, norm identities) for what the oracle does not re-compute.
+
+  headline  GGL K=32, p=500            two concurrent parts, direct-to-LDS 64x64 kernel with 3 DMA stages (variant 17),
+                                       speculative Omega-step, per-element Theta kernel <32>
+  C3        GGL K=20, p=200            single launch sequence, 32x32 register-staged product kernel (variant 9)
+  C4        FGL K=50, p=500, latent    TD=8 Condat tile, two-part sign iteration of the L-step
+  C2        SGL p=1000, 20-point grid  batched lambda path, 64x64 DMA kernel over several rounds of tiles
+  C5 slab   GGL K=32, p=1000           per-GPU slab of C5 at 8 GPUs: unsplit launch sequence above 2048 tile pairs
+Reference loop bodies: solver/admm_solver.py:172-246, solver/single_admm_solver.py:157-214.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from oracle import ggl_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+@contextlib.contextmanager
+def oracle_threads(n=16):
+    """LAPACK's eigh on p <= 1000 gets slower beyond a few threads (the GPU box has 128 cores)."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # noqa: BLE001
+        yield
+        return
+    with threadpool_limits(limits=n):
+        yield
+
+
+@pytest.fixture()
+def stats(monkeypatch):
+    """ns_stats of every engine a solver call creates, captured when it is closed."""
+    from gglasso_amd import solver
+    seen = []
+    real_close = solver.HipEngine.close
+
+    def closing(self):
+        if getattr(self, "h", None):
+            seen.append(self.ns_stats())
+        real_close(self)
+
+    monkeypatch.setattr(solver.HipEngine, "close", closing)
+    return seen
+
+
+def _problem(reg, K, p, seed):
+    from gglasso_amd import synth
+    S, _ = synth.make_problem(reg, K, p, N=2 * p, seed=seed)
+    return S, np.repeat(np.eye(p)[None], K, axis=0)
+
+
+def _check_state(out, ref, names, tol):
+    for nm in names:
+        err = float(np.abs(out[nm] - ref[nm]).max())
+        assert err <= tol * max(1.0, float(np.abs(ref[nm]).max())), (nm, err)
+
+
+def test_headline_dispatch_ggl_K32_p500(stats):
+    """bench.py's workload: 6 iterations with the rho rule from the identity start, then 3 at fixed rho (every
+    iteration after the first speculative), both against the oracle at 1e-9."""
+    from gglasso_amd import solver
+    S, Om0 = _problem("GGL", 32, 500, 1239)
+    kw = dict(max_iter=6, tol=1e-20, rtol=1e-20)
+    with oracle_threads():
+        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
+    out, info = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
+    _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
+    assert np.array_equal(out["Theta"], out["Theta"].transpose(0, 2, 1))
+    assert np.array_equal(out["Omega"], out["Omega"].transpose(0, 2, 1))
+    st = stats[-1]
+    assert st["last_parts"] == 2 and st["last_variant"] == 17, st          # fork/join two-part chains on variant 17
+    assert st["stable_calls"] == 0 and st["eigh_fallbacks"] == 0, st
+    kw = dict(max_iter=3, tol=1e-20, rtol=1e-20, update_rho=False, rho=2.0)
+    with oracle_threads():
+        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
+    out, info = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
+    _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
+    st = stats[-1]
+    assert st["spec_calls"] >= 1, st            # fixed rho: the iterations after the first run speculatively
+    assert st["last_parts"] == 2 and st["last_variant"] == 17, st
+
+
+def test_c3_dispatch_ggl_K20_p200(stats):
+    from gglasso_amd import solver
+    S, Om0 = _problem("GGL", 20, 200, 1236)
+    kw = dict(max_iter=12, tol=1e-20, rtol=1e-20)
+    with oracle_threads():
+        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
+    out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
+    _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
+    st = stats[-1]
+    assert st["last_parts"] == 1 and st["last_variant"] == 9, st
+    assert st["spec_calls"] >= 1, st
+
+
+def test_c4_dispatch_fgl_K50_p500_latent(stats):
+    """FGL with latent variables at full size: TD=8 Condat tiles (K > 32), the L-step's sign iteration in two
+    concurrent parts with its a-posteriori check (retries and eigh fallbacks are legal, wrong results are not)."""
+    from gglasso_amd import solver
+    S, Om0 = _problem("FGL", 50, 500, 1237)
+    mu1 = 0.5 * np.ones(50)
+    kw = dict(max_iter=2, tol=1e-20, rtol=1e-20, latent=True, mu1=mu1)
+    with oracle_threads():
+        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "FGL", Om0, **kw)
+    out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "FGL", Om0, **kw)
+    _check_state(out, ref, ("Omega", "Theta", "L", "X"), 1e-9)
+    for nm in ("Omega", "Theta", "L"):
+        assert np.array_equal(out[nm], out[nm].transpose(0, 2, 1)), nm
+    st = stats[-1]
+    assert st["rank_calls"] == 2 and st["last_parts"] == 2 and st["last_variant"] == 17, st
+
+
+def test_c2_dispatch_sgl_p1000_grid20():
+    """The 20-point lambda1 grid of a p=1000 SGL problem as one batch, 2 iterations: three grid points against the
+    oracle's ADMM_SGL, all twenty through properties (exact symmetry, finite dual, Omega positive definite)."""
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_SGL_batch
+    p = 1000
+    S, _ = synth.make_problem("GGL", 1, p, N=2 * p, seed=1235)
+    S = S[0]
+    lams = np.logspace(0, -2, 20)
+    res = ADMM_SGL_batch(S, lams, max_iter=2, tol=1e-20, rtol=1e-20)
+    assert len(res) == 20
+    for k in (0, 9, 19):
+        with oracle_threads():
+            ref, _ = orc.ADMM_SGL(S, lams[k], np.eye(p), max_iter=2, tol=1e-20, rtol=1e-20)
+        sol, info = res[k]
+        assert info["status"] == "max iterations reached" and info["iterations"] == 2
+        _check_state(sol, ref, ("Omega", "Theta", "X"), 1e-9)
+    for k, (sol, info) in enumerate(res):
+        assert np.array_equal(sol["Omega"], sol["Omega"].T), k
+        assert np.array_equal(sol["Theta"], sol["Theta"].T), k
+        assert np.isfinite(sol["X"]).all()
+        # Omega = phiplus(...) is positive definite whatever lambda1 (single_admm_solver.py:164-166)
+        with oracle_threads():
+            assert np.linalg.eigvalsh(sol["Omega"]).min() > 0, k
+
+
+def test_c5_slab_dispatch_ggl_K32_p1000(stats):
+    """Per-GPU slab of C5 (K=256, p=1000 over 8 GPUs): 4352 tile pairs, unsplit launch sequence on the double-buffered
+    64x64 DMA kernel; iteration 2 speculates.  Whole state against the oracle."""
+    from gglasso_amd import solver
+    S, Om0 = _problem("GGL", 32, 1000, 1238)
+    kw = dict(max_iter=2, tol=1e-20, rtol=1e-20, update_rho=False)
+    with oracle_threads():
+        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
+    out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
+    _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
+    assert np.array_equal(out["Theta"], out["Theta"].transpose(0, 2, 1))
+    st = stats[-1]
+    assert st["last_parts"] == 1 and st["last_variant"] == 16, st
+    assert st["spec_calls"] == 1, st
+
+
+@pytest.mark.parametrize("K", [4, 8, 16])
+def test_headline_slab_dispatch(stats, K):
+    """Per-GPU slabs of the headline under K-sharding at 8 / 4 / 2 GPUs (what decides strong scaling): K = 4 and 8
+    take the 32x32 four-stage DMA kernel (variant 20), K = 16 (576 tile pairs) the double-buffered 64x64 one."""
+    from gglasso_amd import solver
+    S, Om0 = _problem("GGL", K, 500, 1239)
+    kw = dict(max_iter=5, tol=1e-20, rtol=1e-20)
+    with oracle_threads():
+        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
+    out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
+    _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
+    st = stats[-1]
+    assert (st["last_parts"], st["last_variant"]) == {4: (1, 20), 8: (1, 20), 16: (1, 16)}[K], st

@@ -162,3 +162,31 @@ def test_g11_block_sgl():
     assert np.abs(sol["Theta"] - g["full_Theta"]).max() <= 1e-3
     solm = orc.block_SGL(S, lam, np.eye(p), tol=1e-10, rtol=1e-10, lambda1_mask=g["mask"])
     assert np.abs(solm["Theta"] - g["mask_Theta"]).max() <= 1e-9
+
+
+# ---- ext_ADMM_MGL (instances of different dimension; fixtures G14 / G15 from the real reference) ---------------
+
+def test_g14_prox_2norm_G():
+    g = load_golden("g14_ext_admm_nonconforming")
+    K, G = int(g["K"]), g["G"]
+    orc.check_G(G, g["p"])
+    for n in range(2):
+        res = orc.prox_2norm_G({k: g[f"proxG_in_{k}"].copy() for k in range(K)}, G, float(g[f"proxG{n}_lam"]))
+        for k in range(K):
+            assert np.abs(res[k] - g[f"proxG{n}_out_{k}"]).max() <= 1e-15
+            assert np.array_equal(res[k], res[k].T)
+
+
+@pytest.mark.parametrize("latent", [False, True])
+def test_g14_ext_admm_oracle(latent):
+    import ext_checks
+    ext_checks.check_g14(load_golden, orc.ext_ADMM_MGL_printing, latent)
+    ext_checks.check_g14_kkt(load_golden, orc.ext_ADMM_MGL_printing, latent)
+
+
+@pytest.mark.parametrize("latent", [False, True])
+def test_g15_ext_admm_conforming_oracle(latent):
+    import ext_checks
+    ext_checks.check_g15(load_golden, orc.ext_ADMM_MGL_printing, latent)
+    g = load_golden("g15_ext_admm_conforming")
+    assert np.array_equal(orc.construct_trivial_G(g["S"].shape[1], g["S"].shape[0]), g["G"])
