@@ -57,6 +57,12 @@ _SIGNATURES = {
     "ggl_scale_X_batch": ([_vp, _dp], _i),
     "ggl_get_state_k": ([_vp, _i, _dp, _dp, _dp, _dp], _i),
     "ggl_exit_checks": ([_vp, _i, _dp], _i),
+    "ggl_exit_checks_k": ([_vp, _i, _dp], _i),
+    "ggl_ext_setup": ([_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), _i], _i),
+    "ggl_ext_set_state": ([_vp, _dp, _dp], _i),
+    "ggl_ext_get_state": ([_vp, _dp, _dp], _i),
+    "ggl_ext_admm_step": ([_vp, _d, _dp, _d, _i, _dp, _dp], _i),
+    "ggl_ext_kkt_residual": ([_vp, _d, _dp, _d, _i, _dp, _dp], _i),
     "ggl_objective": ([_vp, _d, _d, _i, _dp], _i),
     "ggl_kkt_residual": ([_vp, _d, _d, _d, _i, _i, _dp, _dp, _dp], _i),
     "ggl_profile_enable": ([_vp, _i], _i),

@@ -105,6 +105,26 @@ void launch_pval(hipStream_t st, int reg, const double* Theta, double l1, double
 hipError_t launch_vec_prox(hipStream_t st, int mode, const double* Y, double* out, int n, int K,
                            double l1, double l2);
 
+// ---- ext_group.hip (ext_ADMM_MGL, solver/ext_admm_solver.py) ------------------------------
+int ext_blocks(int p);
+// Theta-step + Z = Theta + X1 (into Znew) [+ X0 update and its sums when not latent, C = Theta - X0 - Omega when latent]
+void launch_ext_theta(hipStream_t st, double* Theta, double* X0, double* Znew, double* C, const double* Omega,
+                      const double* OmegaPrev, const double* L, const double* Lambda, const double* X1, const double* l1K,
+                      const int* pk, int latent, double* partials, int K, int p, const int* skip);
+// prox_2norm_G in place on Lam (holding Z): Gt [2][K][L] int32 (-1 = pair absent), gsize [L]
+void launch_ext_group(hipStream_t st, double* Lam, const int* Gt, const int* gsize, double l2, int L, int K, int p,
+                      const int* skip);
+// X1 += Theta - Lambda [latent: X0 += Omega - Theta + L] and the remaining stopping-test sums
+void launch_ext_dual(hipStream_t st, double* X0, double* X1, const double* Omega, const double* OmegaPrev,
+                     const double* Theta, const double* L, const double* Lam, const double* LamPrev, const int* pk,
+                     int latent, double* partials, int K, int p, const int* skip);
+void launch_lin3(hipStream_t st, double* out, double a, const double* A, double b, const double* B, double c,
+                 const double* C, size_t n);
+// partials[k][ext_blocks(p)] of |(A - B) + C|^2 over the leading (pk,pk) block of every instance
+void launch_ext_sq(hipStream_t st, const double* A, const double* B, const double* C, const int* pk, int K, int p,
+                   double* partials);
+void launch_ext_prox_od(hipStream_t st, double* out, const double* A, const double* l1K, int K, int p);
+
 // ---- eig_jacobi.hip ---------------------------------------------------------------------
 bool jacobi_fits(int p);
 // One workgroup per matrix, matrix resident in LDS (one-sided Jacobi on rows, wave-shuffle

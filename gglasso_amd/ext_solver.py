@@ -1,0 +1,150 @@
+"""Drop-in ``ext_ADMM_MGL``: Group Graphical Lasso where the instances have DIFFERENT dimensions (some variables are
+present in some instances only), with the reference's signature, asserts, status strings, prints and return dicts
+(solver/ext_admm_solver.py:18-323 of fabian-sp/GGLasso; called by ``glasso_problem.solve()`` at problem.py:468 and as
+the ``solver`` of ``grid_search``, helper/model_selection.py:628).
+
+The reference walks Python dicts of (p_k,p_k) arrays instance by instance.  Here the K instances are ONE padded
+(K,p,p) stack on the MI355X, p = max_k p_k: instance k is the leading (p_k,p_k) block of its slot, the rest of the
+diagonal is an identity block (a decoupled fixed point of every step, include/ggl_hip.h), so the batched Omega-/L-step
+kernels, the elementwise Theta-step and the gather/scatter group shrink over the bookkeeping array G all run once per
+iteration for the whole problem.  Per iteration two scalars go down and five sums come back.
+"""
+import time
+import warnings
+
+import numpy as np
+
+from . import solver as _solver
+from .solver import as_c, residuals_from_norms
+
+
+def check_G(G, p):
+    """helper/ext_admm_helper.py:82-102 (same messages)."""
+    K = G.shape[2]
+    assert G.dtype == int, "G needs to be an integer array"
+    assert np.all(G.sum(axis=2) >= -K), "G has rows with only -1 entries"
+    assert np.all(((G == -1).sum(axis=0) == 2) | ((G == -1).sum(axis=0) == 0)), \
+        "Only row or column index specified in some group"
+    assert np.all((G[0, :, :] + G[1, :, :] == -2) | (G[0, :, :] != G[1, :, :])), "G has entries on the diagonal!"
+    assert np.all(G >= -1), "No negative indices allowed (only -1 for indicating a missing feature)"
+    assert np.all(G.max(axis=(0, 1)) < p), "indices larger as dimension were found"
+    assert np.all(G[0, :, :] <= G[1, :, :]), "Only upper diagonal entries should be contained in G"
+
+
+def _pad(blocks, K, p, P, identity):
+    """dict k -> (p_k,p_k)  =>  (K,P,P) stack with an identity (or zero) block behind every instance."""
+    out = np.zeros((K, P, P))
+    for k in range(K):
+        out[k, :p[k], :p[k]] = blocks[k]
+        if identity and p[k] < P:
+            d = np.arange(p[k], P)
+            out[k, d, d] = 1.0
+    return out
+
+
+def _unpad(stack, K, p):
+    return {k: stack[k, :p[k], :p[k]].copy() for k in range(K)}
+
+
+def ext_ADMM_MGL(S, lambda1, lambda2, reg, Omega_0, G, X0=None, X1=None, tol=1e-5, rtol=1e-4,
+                 stopping_criterion='boyd', rho=1., max_iter=1000, verbose=False, measure=False, latent=False, mu1=None):
+    """Same arguments, defaults and return contract as the reference's ``ext_ADMM_MGL``: ``S``, ``Omega_0``, ``X0``,
+    ``X1`` are dicts with keys 0..K-1 and (p_k,p_k) arrays, ``G`` the (2,L,K) integer bookkeeping array;
+    ``sol = {'Omega','Theta','L','X0','X1'}`` (dicts again), ``info = {'status'}`` (+ ``runtime``, ``residual``).
+
+    One restriction beyond ``check_G``: an entry (k,i,j) may belong to one group only (``create_group_array`` never
+    produces anything else); the reference would shrink such an entry once per group, one group after the other."""
+    K = len(S.keys())
+    p = np.zeros(K, dtype=int)
+    for k in np.arange(K):
+        p[k] = S[k].shape[0]
+    if isinstance(lambda1, float):
+        lambda1 = lambda1 * np.ones(K)
+    if latent:
+        if isinstance(mu1, float):
+            mu1 = mu1 * np.ones(K)
+        assert mu1 is not None
+        assert np.all(mu1 > 0)
+        mu1 = as_c(mu1)
+    else:
+        mu1 = None
+    lambda1 = as_c(lambda1)
+    assert min(lambda1.min(), lambda2) > 0
+    assert reg in ['GGL']
+    check_G(G, p)
+    assert rho > 0, "ADMM penalization parameter must be positive."
+    assert stopping_criterion in ('boyd', 'kkt')
+
+    P = int(p.max())
+    Om0 = _pad(Omega_0, K, p, P, True)
+    eng = _solver.ENGINE(_pad(S, K, p, P, True), Om0, Om0, _pad(X0, K, p, P, False) if X0 is not None
+                         else np.zeros((K, P, P)))
+    try:
+        eng.ext_setup(p, G)
+        eng.ext_set_state(Om0, None if X1 is None else _pad(X1, K, p, P, False))
+        runtime = np.zeros(max_iter)
+        residual = np.zeros(max_iter)
+        status = ''
+        dim = ((p ** 2 + p) / 2).sum()
+        lambda2, rho = float(lambda2), float(rho)
+        if verbose:
+            print("------------ADMM Algorithm for Multiple Graphical Lasso----------------")
+            if stopping_criterion == 'boyd':
+                print("%4s\t%10s\t%10s\t%10s\t%10s" % ("iter", "r_t", "s_t", "eps_pri", "eps_dual"))
+            else:
+                print("%4s\t%10s" % ("iter", "kkt residual"))
+        r_t = s_t = e_pri = e_dual = 0.0
+        iter_t = -1
+        for iter_t in range(max_iter):
+            if measure:
+                start = time.time()
+            sq = eng.ext_step(rho, lambda1, lambda2, bool(latent), mu1)
+            if measure:
+                runtime[iter_t] = time.time() - start
+            if stopping_criterion == 'boyd':
+                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq, rho, tol, rtol, dim)
+                residual[iter_t] = max(r_t, s_t)
+                if verbose:
+                    print("%4d\t%10.4g\t%10.4g\t%10.4g\t%10.4g" % (iter_t, r_t, s_t, e_pri, e_dual))
+                if (r_t <= e_pri) and (s_t <= e_dual):
+                    status = 'optimal'
+                    break
+            else:
+                eta_A = eng.ext_kkt(rho, lambda1, lambda2, bool(latent), mu1)
+                residual[iter_t] = eta_A
+                if verbose:
+                    print("%4d\t%10.4g" % (iter_t, eta_A))
+                if eta_A <= tol:
+                    status = 'optimal'
+                    break
+        if status != 'optimal':
+            if stopping_criterion == 'boyd':
+                if r_t <= e_pri:
+                    status = 'primal optimal'
+                elif s_t <= e_dual:
+                    status = 'dual optimal'
+                else:
+                    status = 'max iterations reached'
+            else:
+                status = 'max iterations reached'
+        print(f"ADMM terminated after {iter_t+1} iterations with status: {status}.")
+
+        # per-instance exit checks (ext_admm_solver.py:290-311)
+        for a_om, a_th, a_l, min_tl, min_l in eng.exit_checks_k(bool(latent)):
+            for name, dev in (("Omega", a_om), ("Theta", a_th), ("L", a_l)):
+                if dev > 1e-5:
+                    warnings.warn(f"{name} variable is not symmetric, largest deviation is {dev}.")
+            if min_tl <= 1e-5:
+                print("WARNING: Theta (Theta-L resp.) may be not positive definite -- increase accuracy!")
+            if latent and min_l <= -1e-5:
+                print("WARNING: L may be not positive semidefinite -- increase accuracy!")
+        st, xs = eng.state(), eng.ext_state()
+    finally:
+        eng.close()
+    sol = {'Omega': _unpad(st['Omega'], K, p), 'Theta': _unpad(st['Theta'], K, p), 'L': _unpad(st['L'], K, p),
+           'X0': _unpad(st['X'], K, p), 'X1': _unpad(xs['X1'], K, p)}
+    if measure:
+        info = {'status': status, 'runtime': runtime[:iter_t + 1], 'residual': residual[:iter_t + 1]}
+    else:
+        info = {'status': status}
+    return sol, info

@@ -159,6 +159,43 @@ class HipEngine:
         check(self.lib.ggl_exit_checks(self.h, int(latent), ptr(out)))
         return out
 
+    def exit_checks_k(self, latent):
+        out = np.zeros((self.K, 5))
+        check(self.lib.ggl_exit_checks_k(self.h, int(latent), ptr(out)))
+        return out
+
+    # -- ext_ADMM_MGL: instances of different dimension in one padded stack (gglasso_amd/ext_solver.py) -----------
+    def ext_setup(self, pk, G):
+        import ctypes
+        pk = np.ascontiguousarray(pk, dtype=np.int32)
+        G = np.ascontiguousarray(G, dtype=np.int32)
+        assert G.ndim == 3 and G.shape[0] == 2 and G.shape[2] == self.K
+        ip = ctypes.POINTER(ctypes.c_int)
+        check(self.lib.ggl_ext_setup(self.h, pk.ctypes.data_as(ip), G.ctypes.data_as(ip), int(G.shape[1])))
+
+    def ext_set_state(self, Lambda, X1):
+        check(self.lib.ggl_ext_set_state(self.h, ptr(as_c(Lambda)), ptr(None if X1 is None else as_c(X1))))
+
+    def ext_state(self):
+        shape = (self.K, self.p, self.p)
+        Lam, X1 = np.empty(shape), np.empty(shape)
+        check(self.lib.ggl_ext_get_state(self.h, ptr(Lam), ptr(X1)))
+        return {'Lambda': Lam, 'X1': X1}
+
+    def ext_step(self, rho, lambda1K, lambda2, latent, mu1):
+        rc = self.lib.ggl_ext_admm_step(self.h, rho, self._cptr(lambda1K), lambda2, int(latent), self._cptr(mu1),
+                                        self._norms_p)
+        if rc != 0:
+            if rc > 0:
+                raise RuntimeError(f"ggl_ext_admm_step: unexpected return code {rc} (speculative step rejected twice)")
+            check(rc)
+        return self._norms
+
+    def ext_kkt(self, rho, lambda1K, lambda2, latent, mu1):
+        out = np.zeros(1)
+        check(self.lib.ggl_ext_kkt_residual(self.h, rho, ptr(lambda1K), lambda2, int(latent), ptr(mu1), ptr(out)))
+        return float(out[0])
+
     def state(self):
         shape = (self.K, self.p, self.p)
         Om, Th, L, X = (np.empty(shape) for _ in range(4))

@@ -165,6 +165,30 @@ int ggl_scale_X(ggl_ctx *ctx, double factor);
  * max|L-L^T|, min eig(Theta-L), min eig(L)}. */
 int ggl_exit_checks(ggl_ctx *ctx, int latent, double out[5]);
 
+/* The same five numbers per instance, out (K,5) (what the per-instance messages of solver/ext_admm_solver.py:290-311 need). */
+int ggl_exit_checks_k(ggl_ctx *ctx, int latent, double *out);
+
+/* ---- ext_ADMM_MGL: Group Graphical Lasso over instances of DIFFERENT dimension -------------------
+ * solver/ext_admm_solver.py:18-323 (loop body :196-231, prox_2norm_G / prox_G_inner :394-453, stopping criterion :325-345,
+ * KKT residual :347-392); bookkeeping array G as built by helper/ext_admm_helper.py:104-144, checked like check_G :82-102.
+ * Layout: the ctx is created with p = max_k p_k; instance k is the leading (p_k,p_k) block of its (p,p) slot and the
+ * caller pads the rest of every stack with an identity block for S, Omega, Theta, Lambda and zeros for the duals (a
+ * decoupled fixed point of the iteration; the stopping-test sums skip it).  Omega/Theta/L/X0 travel through
+ * ggl_set_state / ggl_get_state (X is X0), Lambda and X1 through ggl_ext_set_state / ggl_ext_get_state.
+ *   ggl_ext_setup      pk (K) instance dimensions; G (2,L,K) int32 row-major, -1 = the instance does not hold the pair.
+ *                      Every (instance, i, j) may be listed once (GGL_E_ARG otherwise: the groups run in parallel).
+ *   ggl_ext_admm_step  one iteration; lambda1 (K) per instance (:133-134), out_norms = the five sums of :325-345:
+ *                      |Omega|^2+|Lambda|^2, |Theta-L|^2+|Theta|^2, |X0|^2+|X1|^2, |Omega-Theta+L|^2+|Lambda-Theta|^2,
+ *                      |Omega-Omega_prev|^2+|Lambda-Lambda_prev|^2 over all instances (this solver has no rho update).
+ *   ggl_ext_kkt_residual  the opt-in stopping_criterion='kkt' of the same solver. */
+int ggl_ext_setup(ggl_ctx *ctx, const int *pk, const int *G, int L);
+int ggl_ext_set_state(ggl_ctx *ctx, const double *Lambda, const double *X1);
+int ggl_ext_get_state(ggl_ctx *ctx, double *Lambda, double *X1);
+int ggl_ext_admm_step(ggl_ctx *ctx, double rho, const double *lambda1K, double lambda2, int latent,
+                      const double *mu1, double out_norms[5]);
+int ggl_ext_kkt_residual(ggl_ctx *ctx, double rho, const double *lambda1K, double lambda2, int latent,
+                         const double *mu1, double *out);
+
 /* Model selection over a batch of independent problems (reference: single_grid_search,
  * helper/model_selection.py:505-692; criteria :812-856; robust_logdet :884-894).
  * ggl_snapshot_k keeps a device copy of instance k's Theta at the moment the host loop declares it converged;

@@ -127,6 +127,54 @@ class OracleEngine:
         return np.array([t(self.Om), t(self.Th), t(self.L), np.linalg.eigvalsh(self.Th - self.L).min(),
                          np.linalg.eigvalsh(self.L).min() if latent else 0.0])
 
+    def exit_checks_k(self, latent):
+        t = lambda A: np.abs(A - A.T).max()
+        return np.array([[t(self.Om[k]), t(self.Th[k]), t(self.L[k]), np.linalg.eigvalsh(self.Th[k] - self.L[k]).min(),
+                          np.linalg.eigvalsh(self.L[k]).min() if latent else 0.0] for k in range(self.K)])
+
+    # ext_ADMM_MGL on the PADDED stacks (the layout of include/ggl_hip.h: identity block behind every instance), with
+    # the oracle's per-instance operators: exercises the product's padding / un-padding and its host loop on the CPU
+    def ext_setup(self, pk, G):
+        self.pk = np.asarray(pk, dtype=int)
+        self.G = np.asarray(G, dtype=int)
+        self.Lam = None
+        self.X1 = np.zeros_like(self.S)
+
+    def ext_set_state(self, Lambda, X1):
+        self.Lam = np.array(Lambda, dtype=np.float64)
+        self.X1 = np.zeros_like(self.S) if X1 is None else np.array(X1, dtype=np.float64)
+
+    def ext_state(self):
+        return {'Lambda': self.Lam.copy(), 'X1': self.X1.copy()}
+
+    def _inner(self, A, k):
+        return A[k, :self.pk[k], :self.pk[k]]
+
+    def ext_step(self, rho, lambda1K, lambda2, latent, mu1):
+        K = self.K
+        self.step_omega(rho, latent, None)                   # block-diagonal: acts on data and padding separately
+        V = (self.Om + self.L + self.X + self.Lam - self.X1) * 0.5
+        self.Th = np.stack([orc.prox_od_1norm(V[k], lambda1K[k] / (2 * rho)) for k in range(K)])
+        if latent:
+            self.L = orc.rank_stack(self.Th - self.X - self.Om, np.asarray(mu1) / rho)
+        Lam_prev = self.Lam
+        Z = self.Th + self.X1
+        self.Lam = np.stack([Z[k] for k in range(K)])
+        shrunk = orc.prox_2norm_G({k: self._inner(Z, k) for k in range(K)}, self.G, lambda2 / rho)
+        for k in range(K):
+            self.Lam[k, :self.pk[k], :self.pk[k]] = shrunk[k]
+        self.X = self.X + self.Om - self.Th + self.L
+        self.X1 = self.X1 + self.Th - self.Lam
+        n2 = lambda A: sum(np.sum(self._inner(A, k) ** 2) for k in range(K))
+        return np.array([n2(self.Om) + n2(self.Lam), n2(self.Th - self.L) + n2(self.Th), n2(self.X) + n2(self.X1),
+                         n2(self.Om - self.Th + self.L) + n2(self.Lam - self.Th),
+                         n2(self.Om - self.Om_prev) + n2(self.Lam - Lam_prev)])
+
+    def ext_kkt(self, rho, lambda1K, lambda2, latent, mu1):
+        d = lambda A: {k: self._inner(A, k) for k in range(self.K)}
+        return orc.ext_kkt_stopping_criterion(d(self.Om), d(self.Th), d(self.L), d(self.Lam), d(rho * self.X),
+                                              d(rho * self.X1), d(self.S), self.G, lambda1K, lambda2, latent, mu1)
+
     def state(self):
         return {'Omega': self.Om.copy(), 'Theta': self.Th.copy(), 'L': self.L.copy(), 'X': self.X.copy()}
 
