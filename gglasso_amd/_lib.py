@@ -54,6 +54,7 @@ _SIGNATURES = {
     "ggl_norms_read": ([_vp, _dp], _i),
     "ggl_scale_X": ([_vp, _d], _i),
     "ggl_sgl_batch_step": ([_vp, _dp, _dp, _i, _dp, _dp], _i),
+    "ggl_mgl_batch_step": ([_vp, _i, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp], _i),
     "ggl_scale_X_batch": ([_vp, _dp], _i),
     "ggl_get_state_k": ([_vp, _i, _dp, _dp, _dp, _dp], _i),
     "ggl_exit_checks": ([_vp, _i, _dp], _i),

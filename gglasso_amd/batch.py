@@ -113,3 +113,102 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     finally:
         eng.close()
     return results
+
+
+def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1e-5, rtol=1e-4, update_rho=True,
+                   rho=1., max_iter=1000, verbose=False, latent=False, mu1=None, selection_stats=False):
+    """Solve ``ADMM_MGL(S, lambda1[g], lambda2[g], reg, Omega_0, ...)`` (solver/admm_solver.py:13-313) for every
+    g of the 1-D arrays ``lambda1`` / ``lambda2`` at once: the G problems are the slabs of one (G*K,p,p) stack on
+    the GPU, one batched Omega-step (and L-step) over all G*K matrices and one Theta-step launch per iteration.
+    This is what the MAIN LOOP of the reference's ``grid_search`` (helper/model_selection.py:208-224) does one
+    (lambda1, lambda2) point after the other.
+
+    Every problem keeps its OWN rho, residuals, rho updates and stopping decision, exactly as if it had been solved
+    on its own from ``Omega_0`` (default: identity; Theta_0 = Omega_0, X_0 = 0 as in admm_solver.py:142-150), so each
+    returned (sol, info) equals the independent solve; a problem's solution is snapshotted at the iteration it
+    converges and it keeps iterating harmlessly until the batch is done.
+    mu1: (K,) shared by all problems or (G,K); n_samples as in ADMM_MGL.
+    Returns a list of G ``(sol, info)``; ``info`` carries 'status', 'iterations', 'rho' (+ 'selection': per-instance
+    (K,4) array of <S,Theta>, log det Theta, count_nonzero(Theta), lambda_min(Theta) from the GPU when
+    ``selection_stats``)."""
+    S = as_c(S)
+    assert S.ndim == 3 and S.shape[1] == S.shape[2]
+    assert reg in ['GGL', 'FGL']
+    K, p, _ = S.shape
+    lam1 = as_c(np.atleast_1d(lambda1)).reshape(-1)
+    lam2 = as_c(np.atleast_1d(lambda2)).reshape(-1)
+    assert len(lam1) == len(lam2)
+    G = len(lam1)
+    assert min(lam1.min(), lam2.min()) > 0
+    assert rho > 0, "ADMM penalization parameter must be positive."
+    if latent:
+        assert mu1 is not None
+        mu = np.asarray(mu1, dtype=np.float64)
+        if mu.ndim == 0:
+            mu = mu * np.ones(K)
+        mu = as_c(np.broadcast_to(mu, (G, K))).reshape(-1)
+        assert np.all(mu > 0)
+    else:
+        mu = None
+    if n_samples is None:
+        nk = None
+    elif isinstance(n_samples, (int, np.integer)):
+        nk = float(n_samples) * np.ones(K)
+    else:
+        nk = as_c(n_samples).reshape(-1)
+        assert len(nk) == K
+    Om0 = np.repeat(np.eye(p)[None], K, axis=0) if Omega_0 is None else as_c(Omega_0)
+    assert Om0.shape == S.shape
+    rep = lambda A: as_c(np.broadcast_to(A, (G,) + A.shape)).reshape(G * K, p, p)
+    eng = _solver.ENGINE(rep(S), rep(Om0), rep(Om0), np.zeros((G * K, p, p)))
+    try:
+        rhos = np.full(G, float(rho))
+        done = np.zeros(G, dtype=bool)
+        results = [None] * G
+        last = [None] * G
+        dim = K * ((p ** 2 + p) / 2)
+
+        def collect(g, status, iters):
+            parts = [eng.state_k(g * K + k, True) for k in range(K)]
+            sol = {nm: np.stack([q[nm] for q in parts]) for nm in ('Omega', 'Theta', 'L', 'X')}
+            results[g] = (sol, {'status': status, 'iterations': iters, 'rho': rhos[g]})
+            if selection_stats:
+                for k in range(K):
+                    eng.snapshot_k(g * K + k)
+
+        for it in range(max_iter):
+            sq = eng.mgl_batch_step(G, rhos, lam1, lam2, reg, latent, mu, nk)
+            fac = np.ones(G)
+            for g in range(G):
+                if done[g]:
+                    continue
+                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[g], rhos[g], tol, rtol, dim)
+                if update_rho:
+                    rn = next_rho(rhos[g], r_t, s_t)
+                    fac[g] = rhos[g] / rn
+                    rhos[g] = rn
+                last[g] = (r_t, s_t, e_pri, e_dual)
+                if verbose:
+                    print("%4d\t%3d\t%10.4g\t%10.4g\t%10.4g\t%10.4g" % (it, g, r_t, s_t, e_pri, e_dual))
+                if (r_t <= e_pri) and (s_t <= e_dual):
+                    done[g] = True
+            if np.any(fac != 1.0):
+                eng.scale_X_batch(np.repeat(fac, K))
+            for g in range(G):
+                if done[g] and results[g] is None:
+                    collect(g, 'optimal', it + 1)
+            if done.all():
+                break
+        for g in range(G):
+            if results[g] is None:
+                r_t, s_t, e_pri, e_dual = last[g]
+                status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
+                                                                else 'max iterations reached')
+                collect(g, status, max_iter)
+        if selection_stats:
+            st = eng.selection_stats()
+            for g in range(G):
+                results[g][1]['selection'] = st[g * K:(g + 1) * K].copy()
+    finally:
+        eng.close()
+    return results

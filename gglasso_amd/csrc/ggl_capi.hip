@@ -53,7 +53,7 @@ struct ggl_ctx {
     int cur = 0;              // Om[cur] is Omega_t, Om[cur^1] is Omega_{t-1}
     double *DvO = nullptr, *DvL = nullptr, *scale = nullptr, *E = nullptr;   // (K,p), (K,p), (2,K,p), (K,p)
     int* info = nullptr;      // (K)
-    double* par = nullptr;    // device: beta[K] | l1[K] | mu[K] | nk[K] | 1/rho[K] | X scale[K]
+    double* par = nullptr;    // device: beta[K] | l1[K] | mu[K] | nk[K] | 1/rho[K] | X scale[K] | l2[K] | spare
     double* par_h = nullptr;  // pinned mirror
     double *mask = nullptr, *groupsq = nullptr;   // (p,p)
     double* sqwork = nullptr;                     // (ggl_chunks, p, p) per-chunk sums of squares
@@ -188,8 +188,8 @@ static int ctx_alloc(ggl_ctx* c)
     HIPCHK(hipMalloc(&c->E, kp * sizeof(double)));
     HIPCHK(hipMalloc(&c->info, c->K * sizeof(int)));
     HIPCHK(hipMalloc(&c->sweeps, c->K * sizeof(int)));
-    HIPCHK(hipMalloc(&c->par, 6 * (size_t)c->K * sizeof(double)));
-    HIPCHK(hipHostMalloc(&c->par_h, 6 * (size_t)c->K * sizeof(double)));
+    HIPCHK(hipMalloc(&c->par, 8 * (size_t)c->K * sizeof(double)));
+    HIPCHK(hipHostMalloc(&c->par_h, 8 * (size_t)c->K * sizeof(double)));
     HIPCHK(hipMalloc(&c->mask, (size_t)c->p * c->p * sizeof(double)));
     // (p,p) + one trailing double: the speculation flag of K-sharded runs rides on the same all-reduce
     HIPCHK(hipMalloc(&c->groupsq, ((size_t)c->p * c->p + 8) * sizeof(double)));
@@ -834,8 +834,9 @@ extern "C" int ggl_step_group_partial(ggl_ctx* c, double rho, double lambda1)
     return GGL_OK;
 }
 
-static int finish_norms(ggl_ctx* c, int rows, double out_norms[5])
+static int finish_norms(ggl_ctx* c, int rows, double* out_norms, int group = 0)
 {
+    // out_norms: 5 sums over all rows; group > 0: (rows/group, 5) -- one row of sums per `group` consecutive rows
     // the reduction usually wrote the sums straight into pinned host memory and no eigensolver touched `info`:
     // then there is nothing to copy, only the stream to wait for
     CopySegs dn;
@@ -890,10 +891,13 @@ static int finish_norms(ggl_ctx* c, int rows, double out_norms[5])
     }
     int rc = check_info(c, "ADMM step");
     if (rc) return rc;
-    for (int v = 0; v < GGL_NNORM; ++v) {
-        double s = 0.0;
-        for (int r = 0; r < rows; ++r) s += c->norms_h[(size_t)r * GGL_NNORM + v];
-        out_norms[v] = s;
+    const int gsz = group > 0 ? group : rows;
+    for (int r0 = 0, o = 0; r0 < rows; r0 += gsz, ++o) {
+        for (int v = 0; v < GGL_NNORM; ++v) {
+            double s = 0.0;
+            for (int r = r0; r < r0 + gsz; ++r) s += c->norms_h[(size_t)r * GGL_NNORM + v];
+            out_norms[(size_t)o * GGL_NNORM + v] = s;
+        }
     }
     return GGL_OK;
 }
@@ -1133,6 +1137,95 @@ extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* l
     if (rc) return rc;
     memcpy(out_norms, c->norms_h, (size_t)K * GGL_NNORM * sizeof(double));
     return GGL_OK;
+}
+
+static int ensure_partials(ggl_ctx* c, size_t need)
+{
+    if (need <= c->partials_len) return GGL_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->partials);
+    c->partials = nullptr;
+    c->partials_len = 0;
+    HIPCHK(hipMalloc(&c->partials, need * sizeof(double)));
+    c->partials_len = need;
+    return GGL_OK;
+}
+
+// ---- G independent multiple-graph problems of K instances each (batched model-selection grid) -------------------
+static int mgl_batch_finish(ggl_ctx* c, int G, int Kp, int reg, int latent, double* out_norms)
+{
+    const int K = c->K;
+    double* Om = c->Om[c->cur];
+    double* OmPrev = c->Om[c->cur ^ 1];
+    const int* skip = c->spec_pending ? c->spec_flag : nullptr;
+    PB(c, GGL_PH_THETA);
+    HIPCHK(launch_theta_batch(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, c->par + K,
+                              c->par + 6 * (size_t)K, latent ? 0 : 1, c->partials, G, Kp, c->p, skip));
+    PE(c, GGL_PH_THETA);
+    int rows, group;
+    c->norms_host = true;
+    if (!latent) {
+        PB(c, GGL_PH_REDUCE);
+        launch_reduce_partials(c->stream, c->partials, G, theta_partial_blocks(c->p, reg, Kp, 1), GGL_NNORM, c->norms_h);
+        PE(c, GGL_PH_REDUCE);
+        rows = G;
+        group = 1;
+    } else {
+        int rc = rank_step(c);
+        if (rc) return rc;
+        PB(c, GGL_PH_DUAL);
+        launch_dual_update(c->stream, c->X, Om, OmPrev, c->Theta, c->L, c->partials, K, c->p);
+        PE(c, GGL_PH_DUAL);
+        PB(c, GGL_PH_REDUCE);
+        launch_reduce_partials(c->stream, c->partials, K, elementwise_blocks(c->p), GGL_NNORM, c->norms_h);
+        PE(c, GGL_PH_REDUCE);
+        rows = K;
+        group = Kp;
+    }
+    HIPCHK(hipGetLastError());
+    return finish_norms(c, rows, out_norms, group);
+}
+
+extern "C" int ggl_mgl_batch_step(ggl_ctx* c, int G, const double* rho, const double* lambda1, const double* lambda2,
+                                  int reg, int latent, const double* mu1, const double* nk, double* out_norms)
+{
+    ARGCHK(c && rho && lambda1 && lambda2 && out_norms, "ctx, rho, lambda1, lambda2, out_norms");
+    ARGCHK(reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
+    ARGCHK(G >= 1 && c->K % G == 0, "the ctx holds G problems of K/G instances each");
+    ARGCHK(!latent || mu1, "latent needs mu1");
+    ARGCHK(c->state_symmetric, "the batched Theta-step needs exactly symmetric dual / latent start points");
+    HIPCHK(hipSetDevice(c->device));
+    const int K = c->K, Kp = K / G;
+    if (reg == GGL_REG_GGL && Kp > GGL_FLAT_MAX_K)
+        return fail(GGL_E_ARG, "batched GGL grid: %d instances per problem exceed the %d of the per-element Theta kernel", Kp,
+                    GGL_FLAT_MAX_K);
+    if (reg == GGL_REG_FGL && Kp > fgl_max_K())
+        return fail(GGL_E_ARG, "batched FGL grid: %d instances per problem exceed the %d of the Condat tile kernel", Kp,
+                    fgl_max_K());
+    int rc = ensure_partials(c, (size_t)G * theta_partial_blocks(c->p, reg, Kp, 1) * GGL_NNORM);
+    if (rc) return rc;
+    double* h = c->par_h;
+    for (int g = 0; g < G; ++g) {
+        ARGCHK(rho[g] > 0 && lambda1[g] > 0 && lambda2[g] > 0, "rho, lambda1, lambda2 must be positive");
+        const double ir = 1.0 / rho[g];
+        for (int k = 0; k < Kp; ++k) {
+            const int i = g * Kp + k;
+            h[i] = (nk ? nk[k] : 1.0) / rho[g];           // beta = nk / rho              (admm_solver.py:180,184)
+            h[K + i] = ir * lambda1[g];                   // (1/rho) lambda1              (:191)
+            h[2 * (size_t)K + i] = latent ? mu1[i] / rho[g] : 0.0;   // mu1_k / rho     (:202)
+            h[6 * (size_t)K + i] = ir * lambda2[g];       // (1/rho) lambda2              (:192)
+        }
+    }
+    CopySegs sg;
+    sg.add(c->par, h, 3 * (size_t)K * sizeof(double));
+    sg.add(c->par + 6 * (size_t)K, h + 6 * (size_t)K, (size_t)K * sizeof(double));
+    rc = omega_step(c, latent, &sg, /*allow_spec=*/true);
+    if (rc) return rc;
+    rc = mgl_batch_finish(c, G, Kp, reg, latent, out_norms);
+    if (rc != GGL_SPEC_RETRY) return rc;
+    rc = omega_step(c, latent, nullptr, false);
+    if (rc) return rc;
+    return mgl_batch_finish(c, G, Kp, reg, latent, out_norms);
 }
 
 extern "C" int ggl_scale_X_batch(ggl_ctx* c, const double* factor)
@@ -1494,13 +1587,8 @@ extern "C" int ggl_ext_setup(ggl_ctx* c, const int* pk, const int* G, int L)
         for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->Lam[i], nb));
         HIPCHK(hipMalloc(&c->X1, nb));
         // the ext kernels write GGL_NNORM sums per (instance, chunk) twice per iteration
-        const size_t need = 2 * (size_t)K * ext_blocks(p) * GGL_NNORM;
-        if (need > c->partials_len) {
-            (void)hipFree(c->partials);
-            c->partials = nullptr;
-            HIPCHK(hipMalloc(&c->partials, need * sizeof(double)));
-            c->partials_len = need;
-        }
+        int rcp = ensure_partials(c, 2 * (size_t)K * ext_blocks(p) * GGL_NNORM);
+        if (rcp) return rcp;
     }
     HIPCHK(hipMemsetAsync(c->X1, 0, nb, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));      // Gt / gs are host temporaries

@@ -87,6 +87,11 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
                              double* partials, int K, int p, int flat = 0, const int* skip = nullptr);
 // largest K the FGL Theta-step kernel serves (K-vectors of an 8x8 tile pair in one workgroup's LDS)
 int fgl_max_K();
+// G independent problems of K instances each in one launch: stacks (G*K,p,p), thresholds of problem g at l1G[g*K] /
+// l2G[g*K], partial sums [g][theta_partial_blocks(p,reg,K,1)].  GGL: K <= GGL_FLAT_MAX_K; symmetric states only.
+hipError_t launch_theta_batch(hipStream_t st, int reg, double* Theta, double* X, double* C, const double* Omega,
+                              const double* OmegaPrev, const double* L, const double* l1G, const double* l2G,
+                              int fuse_dual, double* partials, int G, int K, int p, const int* skip);
 // number of K-chunks the GGL kernels split the stack into (grid.y)
 int ggl_chunks(int K, int p);
 // GGL pass 1 only: sq[c](p,p)[i<j] = sum_{k in chunk c} soft(Omega+L+X, l1)^2,  c < ggl_chunks(K,p)

@@ -342,17 +342,31 @@ __device__ __forceinline__ void condat_inplace(double* y, const int s, const int
     }
 }
 
+// A batch of G independent problems of K instances each (model-selection grid, ggl_mgl_batch_step): blockIdx.y = g,
+// the stacks are (G*K,p,p), l1G / l2G hold the thresholds of instance g*K (null: the scalars l1 / l2, G = 1), the
+// partial sums are rows [g][blocks].
 template <int TD, bool FUSE_DUAL>
 __global__ __launch_bounds__(TD * TD) void k_theta_fgl(double* __restrict__ Theta, double* __restrict__ X,
                                                        double* __restrict__ C, const double* __restrict__ Omega,
                                                        const double* __restrict__ OmegaPrev,
                                                        const double* __restrict__ L, double l1, double l2,
                                                        double* __restrict__ partials, int K, int p,
-                                                       const int* __restrict__ skip)
+                                                       const int* __restrict__ skip, const double* __restrict__ l1G,
+                                                       const double* __restrict__ l2G)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // [K][TD*TD] then scratch
     constexpr int NT = TD * TD;
     if (spec_failed(skip)) return;
+    {
+        const size_t goff = (size_t)blockIdx.y * K * p * p;
+        Theta += goff; Omega += goff;
+        if (X) X += goff;
+        if (C) C += goff;
+        if (OmegaPrev) OmegaPrev += goff;
+        if (L) L += goff;
+        if (l1G) { l1 = l1G[(size_t)blockIdx.y * K]; l2 = l2G[(size_t)blockIdx.y * K]; }
+        if (partials) partials += (size_t)blockIdx.y * gridDim.x * GGL_NNORM;
+    }
     const int T = (p + TD - 1) / TD;
     int I, J;
     decode_pair(blockIdx.x, T, I, J);
@@ -449,20 +463,21 @@ __global__ __launch_bounds__(TD * TD) void k_theta_fgl(double* __restrict__ Thet
 template <int TD>
 static hipError_t launch_fgl_td(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                                 const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual,
-                                double* partials, int K, int p, const int* skip)
+                                double* partials, int K, int p, const int* skip, int G = 1, const double* l1G = nullptr,
+                                const double* l2G = nullptr)
 {
     const int T = ntiles(p, TD);
     const size_t lds = ((size_t)K * TD * TD + GGL_NNORM * 4) * sizeof(double);
-    dim3 grid(T * (T + 1) / 2), blk(TD, TD);
+    dim3 grid(T * (T + 1) / 2, G), blk(TD, TD);
     hipError_t e;
     if (fuse_dual) {
         e = hipFuncSetAttribute((const void*)k_theta_fgl<TD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_theta_fgl<TD, true>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip);
+        hipLaunchKernelGGL((k_theta_fgl<TD, true>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
     } else {
         e = hipFuncSetAttribute((const void*)k_theta_fgl<TD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_theta_fgl<TD, false>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip);
+        hipLaunchKernelGGL((k_theta_fgl<TD, false>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
     }
     return hipGetLastError();
 }
@@ -478,11 +493,22 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
                                                         const double* __restrict__ OmegaPrev,
                                                         const double* __restrict__ L, double l1, double l2,
                                                         double* __restrict__ partials, int K, int p,
-                                                        const int* __restrict__ skip)
+                                                        const int* __restrict__ skip, const double* __restrict__ l1G,
+                                                        const double* __restrict__ l2G)
 {
     __shared__ double scratch[GGL_NNORM * 4];
     if (spec_failed(skip)) return;
     const size_t pp = (size_t)p * p;
+    {   // grid-point dimension of a batch of independent problems (see k_theta_fgl)
+        const size_t goff = (size_t)blockIdx.y * K * pp;
+        Theta += goff; Omega += goff;
+        if (X) X += goff;
+        if (C) C += goff;
+        if (OmegaPrev) OmegaPrev += goff;
+        if (L) L += goff;
+        if (l1G) { l1 = l1G[(size_t)blockIdx.y * K]; l2 = l2G[(size_t)blockIdx.y * K]; }
+        if (partials) partials += (size_t)blockIdx.y * gridDim.x * GGL_NNORM;
+    }
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
     if (e < pp) {
@@ -551,13 +577,13 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
 template <int KMAX>
 static void launch_flat(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                         const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual, double* partials,
-                        int K, int p, const int* skip)
+                        int K, int p, const int* skip, int G = 1, const double* l1G = nullptr, const double* l2G = nullptr)
 {
-    dim3 grid(flat_blocks(p)), blk(256);
+    dim3 grid(flat_blocks(p), G), blk(256);
     if (fuse_dual)
-        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip);
+        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
     else
-        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip);
+        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
 }
 
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C, const double* Omega,
@@ -593,6 +619,26 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
     if (fgl_tile(K) == 16)
         return launch_fgl_td<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
     return launch_fgl_td<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
+}
+
+// Theta-step of G independent problems of K instances each in one launch (stacks (G*K,p,p); thresholds of problem g at
+// l1G[g*K], l2G[g*K]; partial sums [g][theta_partial_blocks]).  Exactly symmetric states only (the callers start from
+// symmetric points): GGL runs the per-element kernel (K <= GGL_FLAT_MAX_K), FGL the Condat tile kernel.
+hipError_t launch_theta_batch(hipStream_t st, int reg, double* Theta, double* X, double* C, const double* Omega,
+                              const double* OmegaPrev, const double* L, const double* l1G, const double* l2G,
+                              int fuse_dual, double* partials, int G, int K, int p, const int* skip)
+{
+    if (reg == 1) {
+        if (K > GGL_FLAT_MAX_K) return hipErrorInvalidValue;
+        if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
+        else if (K <= 16) launch_flat<16>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
+        else launch_flat<32>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
+        return hipGetLastError();
+    }
+    if (K > FGL_MAX_K_TD8) return hipErrorInvalidValue;
+    if (fgl_tile(K) == 16)
+        return launch_fgl_td<16>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
+    return launch_fgl_td<8>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
 }
 
 hipError_t launch_prox_p(hipStream_t st, int reg, double* out, const double* V, double l1, double l2, int K, int p,

@@ -9,8 +9,10 @@ a grid point does not depend on its start, so the selection statistics agree wit
 solver tolerance; the bookkeeping below (AIC / eBIC tables, sparsity, rank, best point) follows the
 reference's definitions (:769-894, helper/utils.py:17-23) and its return layout.
 
-``grid_search`` for the multiple-graph solvers needs nothing from this module: the reference's own driver takes
-``gglasso_amd.ADMM_MGL`` as its ``solver`` argument unchanged (tests/test_reference_dropin.py).
+``grid_search`` (lambda1 x lambda2 grid of the multiple-graph problems, :55-298) is at the end of this module: the whole
+grid as one batch on the GPU (``gglasso_amd.batch.ADMM_MGL_batch``), or -- for any other solver callable -- the
+reference's sequential warm-started walk.  The reference's own ``grid_search`` also takes ``gglasso_amd.ADMM_MGL``
+as its ``solver`` argument unchanged (tests/test_reference_dropin.py).
 """
 import numpy as np
 
@@ -87,9 +89,11 @@ def _solve_grid(S, lam, mu, latent, tol, rtol, max_iter):
     return [s for s, _ in res], [info['selection'] for _, info in res]
 
 
-def _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma, gammas, store_all, lambda1_mask):
+def _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma, gammas, store_all, lambda1_mask,
+                 thresholding=False):
     """AIC / eBIC / sparsity / rank tables, best point and stored estimates of one (lambda1, mu1) grid
-    (model_selection.py:583-690); sols[j*M+m] solves (lambda_range[j], mu_range[m])."""
+    (model_selection.py:583-690); sols[j*M+m] solves (lambda_range[j], mu_range[m]).  thresholding: every point's
+    Theta is replaced by its best thresholded version (tune_threshold, :641-650) before the criteria are taken."""
     p = S.shape[0]
     nl, nm = len(lambda_range), len(mu_range)
     MU, LAMB = np.meshgrid(mu_range, lambda_range)
@@ -97,6 +101,7 @@ def _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma,
     AIC = np.full((nl, nm), np.nan)
     SP = np.full((nl, nm), np.nan)
     RANK = np.zeros((nl, nm))
+    TAU = np.zeros((nl, nm)) if thresholding else None
     estimates = np.zeros((nl, nm, p, p)) if store_all else None
     lowrank = np.zeros((nl, nm, p, p)) if store_all else None
     best_sol, curr_min = dict(), np.inf
@@ -109,9 +114,12 @@ def _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma,
                     lowrank[j, m] = sol['L']
                 # on the host: matrix_rank's tolerance p*eps*|L| (:638) is below what the device eigensolvers resolve
                 RANK[j, m] = np.linalg.matrix_rank(sol['L'], hermitian=True)
+            if thresholding:
+                sol['Theta'], TAU[j, m], _ = tune_threshold(Theta, S, N, tau_range=None, method=method, gamma=gamma)
+                Theta = sol['Theta']
             # the criteria share the expensive terms <S,Theta> and log det Theta: from the
-            # device statistics of the batch, or on the host for the point-by-point (mask) walk
-            if dev is not None:
+            # device statistics of the batch, or on the host for the point-by-point (mask) walk and thresholded estimates
+            if dev is not None and not thresholding:
                 d = dev[j * nm + m]
                 fit = N * d['Sdot'] - N * d['logdet']
                 E0 = (d['nnz'] - p) / 2
@@ -135,7 +143,7 @@ def _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma,
         BIC[g][BIC[g] == -np.inf] = np.nan
     table = AIC if method == 'AIC' else BIC[gamma]
     ix = np.unravel_index(np.nanargmin(table), table.shape)
-    stats = {'BIC': BIC, 'AIC': AIC, 'SP': SP, 'RANK': RANK, 'LAMBDA': LAMB, 'MU': MU, 'TAU': None,
+    stats = {'BIC': BIC, 'AIC': AIC, 'SP': SP, 'RANK': RANK, 'LAMBDA': LAMB, 'MU': MU, 'TAU': TAU,
              'BEST': {'lambda1': LAMB[ix], 'mu1': MU[ix]}, 'GAMMA': gammas}
     return best_sol, estimates, lowrank, stats
 
@@ -149,10 +157,9 @@ def single_grid_search(S, lambda_range, N, method='eBIC', gamma=0.3, latent=Fals
     All grid points are solved as ONE batch from the reference's start (Omega_0 = X_0 = identity, :595-596);
     ``use_block`` is accepted and ignored (block splitting changes how a point is solved, not its optimum).
     ``lambda1_mask`` grids run point by point with the reference's warm start (the mask is a per-problem
-    array).  ``thresholding`` (tune_threshold, :698-766) is not built."""
+    array).  ``thresholding``: each point's estimate is thresholded on the host (tune_threshold, :698-737) before the
+    criteria are taken, as in the reference."""
     assert method in ('AIC', 'eBIC')
-    if thresholding:
-        raise NotImplementedError("thresholded estimators are outside the accelerated path")
     S = np.ascontiguousarray(S, dtype=np.float64)
     p = S.shape[0]
     lambda_range = np.atleast_1d(np.asarray(lambda_range, dtype=np.float64))
@@ -178,7 +185,49 @@ def single_grid_search(S, lambda_range, N, method='eBIC', gamma=0.3, latent=Fals
                                   lambda1_mask=lambda1_mask, max_iter=max_iter, **kw)
                 Om0 = sol['Omega'].copy()
                 sols.append(sol)
-    return _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma, gammas, store_all, lambda1_mask)
+    return _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma, gammas, store_all, lambda1_mask,
+                        thresholding)
+
+
+def _K_single_grid_dict(S, lambda_range, N, method, gamma, latent, mu_range, thresholding, use_block, store_all, tol,
+                        rtol, max_iter):
+    """K_single_grid for a dict of instances of DIFFERENT dimension (model_selection.py:300-503 with dict S): every
+    instance's (lambda1, mu1) grid is its own batch (``single_grid_search``); the selection across instances follows
+    the reference (:443-466)."""
+    K = len(S.keys())
+    assert len(N) == K, f"N must be given as array, is given as {N}."
+    lambda_range = np.atleast_1d(np.asarray(lambda_range, dtype=np.float64))
+    mu_r = np.atleast_1d(np.asarray(mu_range, dtype=np.float64)) if latent else np.array([0])
+    nl, nm = len(lambda_range), len(mu_r)
+    MU, LAMB = np.meshgrid(mu_r, lambda_range)
+    BIC, AIC = np.full((K, nl, nm), np.nan), np.full((K, nl, nm), np.nan)
+    SP, RANK = np.full((K, nl, nm), np.nan), np.zeros((K, nl, nm))
+    estimates, lowrank, indv_T, indv_L = dict(), dict(), dict(), dict()
+    for k in range(K):
+        best, estimates[k], lowrank[k], st = single_grid_search(S[k], lambda_range, N[k], method, gamma, latent, mu_range,
+                                                                thresholding, use_block, True, tol, rtol, None, max_iter)
+        indv_T[k] = best['Theta']
+        if latent:
+            indv_L[k] = best['L']
+        BIC[k], AIC[k], SP[k], RANK[k] = st['BIC'][gamma], st['AIC'], st['SP'], st['RANK']
+    table = AIC if method == 'AIC' else BIC
+    ix_mu = np.zeros((K, nl), dtype=int)
+    score = np.full((K, nl), np.nan)
+    for k in range(K):
+        for j in range(nl):
+            ix_mu[k, j] = np.nanargmin(table[k, j, :])
+            score[k, j] = table[k, j, ix_mu[k, j]]
+    score[score == -np.inf] = np.nan
+    ix_uniform = np.nanargmin(score.sum(axis=0))
+    ix_indv = np.nanargmin(score, axis=1)
+    est_indv = {'Theta': indv_T}
+    est_uniform = {'Theta': {k: estimates[k][ix_uniform, ix_mu[k, ix_uniform]] for k in range(K)}}
+    if latent:
+        est_indv['L'] = indv_L
+        est_uniform['L'] = {k: lowrank[k][ix_uniform, ix_mu[k, ix_uniform]] for k in range(K)}
+    statistics = {'BIC': BIC, 'AIC': AIC, 'SP': SP, 'RANK': RANK, 'LAMB': LAMB, 'MU': MU, 'ix_uniform': ix_uniform,
+                  'ix_indv': ix_indv, 'ix_mu': ix_mu}
+    return est_uniform, est_indv, statistics
 
 
 def K_single_grid(S, lambda_range, N, method='eBIC', gamma=0.3, latent=False, mu_range=None, thresholding=False,
@@ -189,10 +238,9 @@ def K_single_grid(S, lambda_range, N, method='eBIC', gamma=0.3, latent=False, mu
     The reference runs ``single_grid_search`` instance after instance; here the K x L x M problems are the
     instances of as few batches as ``max_batch_bytes`` of device stacks allow (one, typically)."""
     assert method in ('AIC', 'eBIC')
-    if thresholding:
-        raise NotImplementedError("thresholded estimators are outside the accelerated path")
-    if not isinstance(S, np.ndarray):
-        raise NotImplementedError("dictionary input (instances of different dimension) is not on the batched path")
+    if isinstance(S, dict):
+        return _K_single_grid_dict(S, lambda_range, N, method, gamma, latent, mu_range, thresholding, use_block, store_all,
+                                   tol, rtol, max_iter)
     S = np.ascontiguousarray(S, dtype=np.float64)
     K, p = S.shape[0], S.shape[1]
     assert len(N) == K, f"N must be given as array, is given as {N}."
@@ -228,7 +276,7 @@ def K_single_grid(S, lambda_range, N, method='eBIC', gamma=0.3, latent=False, mu
     for k in range(K):
         sl = slice(k * per_k, (k + 1) * per_k)
         best, est_k, lr_k, st = _grid_tables(S[k], N[k], sols[sl], dev[sl], lambda_range, mu_range, latent, method, gamma,
-                                             gammas, store_all, None)
+                                             gammas, store_all, None, thresholding)
         indv_T.append(best['Theta'])
         if latent:
             indv_L.append(best['L'])
@@ -261,3 +309,215 @@ def K_single_grid(S, lambda_range, N, method='eBIC', gamma=0.3, latent=False, mu
     statistics = {'BIC': BIC[gamma], 'AIC': AIC, 'SP': SP, 'RANK': RANK, 'LAMB': LAMB, 'MU': MU,
                   'ix_uniform': ix_uniform, 'ix_indv': ix_indv, 'ix_mu': ix_mu}
     return est_uniform, est_indv, statistics
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# lambda1 x lambda2 grid for the multiple-graph problems
+# -----------------------------------------------------------------------------------------------------------------
+N_TAU = 20      # model_selection.py:18
+
+
+def lambda_parametrizer(l1=0.05, w2=0.5):
+    """model_selection.py:20-25."""
+    a = 1 / np.sqrt(2)
+    return (w2 * l1) / (a * (1 - w2))
+
+
+def lambda_grid(l1, l2=None, w2=None):
+    """model_selection.py:32-52: lambda1 changes over the columns, lambda2 over the rows.  (The reference squeezes
+    the meshgrid, which breaks its own MAIN LOOP for one-row or one-column grids; the grids stay 2-D here.)"""
+    assert np.all(l2 is not None) | np.all(w2 is not None), \
+        "Either a range of lambda2 or w2 values have to be specified"
+    if np.all(l2 is not None):
+        L1, L2 = np.meshgrid(l1, l2)
+    else:
+        l1grid, w2grid = np.meshgrid(l1, w2)
+        L2 = lambda_parametrizer(l1grid, w2grid)
+        L1 = l1grid.copy()
+    return np.atleast_2d(L1), np.atleast_2d(L2)
+
+
+def mean_sparsity(Theta):
+    """helper/utils.py:25-31."""
+    if isinstance(Theta, dict):
+        return np.mean([sparsity(Theta[k]) for k in Theta.keys()])
+    return np.mean([sparsity(Theta[k]) for k in range(Theta.shape[0])])
+
+
+def thresholding(A, tau):
+    """model_selection.py:698-705: entries with |a| <= tau are set to zero, the diagonal is kept."""
+    mask = (np.abs(A) > tau)
+    np.fill_diagonal(mask, 1.)
+    return A * mask
+
+
+def tune_threshold(Theta, S, N, tau_range=None, method='eBIC', gamma=0.1):
+    """model_selection.py:707-737."""
+    if tau_range is None:
+        tau_range = np.logspace(-12, -1, N_TAU)
+    assert np.all(tau_range > 0)
+    scores = np.zeros(len(tau_range))
+    for j in range(len(tau_range)):
+        T = thresholding(Theta, tau_range[j])
+        scores[j] = ebic_single(S, T, N, gamma) if method == 'eBIC' else aic_single(S, T, N)
+    scores[scores == np.inf] = np.nan
+    opt_tau = tau_range[np.nanargmin(scores)]
+    return thresholding(Theta, opt_tau), opt_tau, scores
+
+
+def tune_multiple_threshold(Theta, S, N, tau_range, method='eBIC', gamma=0.1):
+    """model_selection.py:739-765 (arrays or dicts)."""
+    K = len(S.keys()) if isinstance(S, dict) else S.shape[0]
+    t_Theta = Theta.copy()
+    score = dict()
+    tau = np.zeros(K)
+    for k in range(K):
+        t_Theta[k], tau[k], score[k] = tune_threshold(Theta[k], S[k], N[k], tau_range, method, gamma)
+    return t_Theta, tau, score
+
+
+def _criteria(S, Theta, N, K):
+    """Per-instance fit term N (<S,Theta> - log det Theta) and edge count of aic_single / ebic_single (:812-856)."""
+    fit = np.array([N[k] * np.sum(S[k] * Theta[k]) - N[k] * robust_logdet(Theta[k]) for k in range(K)])
+    E = np.array([_edges(Theta[k]) for k in range(K)])
+    return fit, E
+
+
+def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma=0.3, G=None, latent=False,
+                mu_range=None, ix_mu=None, thresholding=False, tol=1e-7, rtol=1e-7, verbose=False, group=None,
+                max_batch_bytes=8 << 30, batched=None):
+    """Model selection for the multiple-graph problems over a lambda1 x lambda2 grid with AIC / eBIC -- arguments and
+    the returned ``(stats, ix, curr_best)`` as the reference's ``grid_search`` (helper/model_selection.py:55-298).
+
+    With ``solver`` = ``gglasso_amd.ADMM_MGL`` and S an array, the WHOLE grid is solved as one batch on the GPU
+    (``gglasso_amd.batch.ADMM_MGL_batch``: grid points are independent problems on the same S; one batched Omega-step
+    over all (grid points x K) matrices and one Theta-step launch per iteration, every point with its own rho and
+    stopping decision) from the identity start, and the criteria's expensive terms <S,Theta>, log det Theta,
+    count_nonzero come from the device.  The reference walks the grid column by column with a warm start from the
+    previous point (:208-224); the optimum of a point does not depend on its start, so tables and selection agree
+    to the solver tolerance.  ``group``: a torch.distributed process group -- the grid points are dealt round-robin
+    over its ranks (``gglasso_amd.dist.shard_grid``; replicas only, results gathered on every rank).
+    Any other solver callable (``ext_ADMM_MGL`` with dict S and G, the reference's own solvers) and ``batched=False``
+    take the reference's sequential warm-started walk with that callable.  ``thresholding`` tunes a thresholded
+    estimator per grid point on the host (tune_multiple_threshold, :739-765) in either mode."""
+    from .solver import ADMM_MGL
+    assert method in ['AIC', 'eBIC']
+    assert reg in ['FGL', 'GGL']
+    if isinstance(S, dict):
+        K = len(S.keys())
+    elif isinstance(S, np.ndarray):
+        K = S.shape[0]
+    else:
+        raise Exception("S must be specified either as array or dict.")
+    assert len(N) == K, f"N must be given as array, is given as {N}."
+    if latent:
+        assert np.all(mu_range > 0)
+    L1, L2 = lambda_grid(l1, l2, w2)
+    if verbose:
+        print("Grid of lambda1/lambda2:")
+        print(L1)
+        print(L2)
+    grid1, grid2 = L1.shape
+    gammas = sorted(set(DEFAULT_GAMMAS) | {gamma})
+    AIC = np.nan * np.zeros((grid1, grid2))
+    BIC = {g: np.nan * np.zeros((grid1, grid2)) for g in gammas}
+    SP = np.nan * np.zeros((grid1, grid2))
+    RANK = np.nan * np.zeros((K, grid1, grid2))
+    TAU = np.zeros((K, grid1, grid2)) if thresholding else None
+    if batched is None:
+        batched = (solver is ADMM_MGL) and isinstance(S, np.ndarray) and (reg == 'FGL' or K <= 32)
+    order = [(g1, g2) for g2 in range(grid2) for g1 in range(grid1)]       # down the columns, as the reference
+
+    sols = {}
+    dev = {}
+    if batched:
+        from .batch import ADMM_MGL_batch
+        pdim = S.shape[1]
+        mine = list(range(len(order)))
+        if group is not None:
+            import torch.distributed as dist
+            from .dist import shard_grid
+            mine = shard_grid(len(order), dist.get_world_size(group), dist.get_rank(group))
+        per_batch = max(1, int(max_batch_bytes // (14 * K * pdim * pdim * 8)))
+        local = []
+        for b0 in range(0, len(mine), per_batch):
+            idx = mine[b0:b0 + per_batch]
+            lam1 = np.array([L1[order[i]] for i in idx])
+            lam2 = np.array([L2[order[i]] for i in idx])
+            mu = np.stack([mu_range[ix_mu[:, order[i][1]]] for i in idx]) if latent else None
+            res = ADMM_MGL_batch(S, lam1, lam2, reg, tol=tol, rtol=rtol, latent=latent, mu1=mu, selection_stats=True)
+            local += [(i, r) for i, r in zip(idx, res)]
+        if group is not None:
+            gathered = [None] * dist.get_world_size(group)
+            dist.all_gather_object(gathered, local, group=group)
+            local = [x for part in gathered for x in part]
+        for i, (sol, info) in local:
+            sols[order[i]] = sol
+            dev[order[i]] = info['selection']
+    else:
+        from .ext_solver import ext_ADMM_MGL   # noqa: F401  (documented alternative solver callable)
+        kwargs = {'reg': reg, 'S': S, 'tol': tol, 'rtol': rtol, 'verbose': False, 'measure': False}
+        if isinstance(S, dict):
+            kwargs['Omega_0'] = {k: np.eye(S[k].shape[0]) for k in range(K)}      # id_dict, ext_admm_helper.py:9-16
+            kwargs['G'] = G
+        else:
+            kwargs['Omega_0'] = np.stack([np.eye(S.shape[1])] * K)               # id_array, utils.py:10-15
+        for (g1, g2) in order:
+            kwargs['lambda1'], kwargs['lambda2'] = L1[g1, g2], L2[g1, g2]
+            if latent:
+                kwargs['latent'] = True
+                kwargs['mu1'] = mu_range[ix_mu[:, g2]].copy()
+            sol, info = solver(**kwargs)
+            kwargs['Omega_0'] = sol['Omega'].copy()                               # warm start (:224)
+            sols[(g1, g2)] = sol
+
+    curr_min, curr_best = np.inf, None
+    no_thr_min, no_thr_params, no_thr_best = np.inf, None, None
+    for (g1, g2) in order:
+        sol = sols[(g1, g2)]
+        d = dev.get((g1, g2))
+        if d is not None and not thresholding:
+            fit = N * d[:, 0] - N * d[:, 1]
+            E = (d[:, 2] - S.shape[1]) / 2
+            SP[g1, g2] = np.mean((d[:, 2] - S.shape[1]) / (S.shape[1] ** 2 - S.shape[1]))
+        else:
+            if thresholding:
+                fit0, E0 = _criteria(S, sol['Theta'], N, K)
+                pk = np.array([S[k].shape[0] for k in range(K)])
+                score0 = np.sum(fit0 + E0 * (np.log(N) + 4 * np.log(pk) * gamma))
+                if score0 < no_thr_min:
+                    no_thr_min, no_thr_best = score0, sol.copy()
+                    no_thr_params = {'lambda1': L1[g1, g2], 'lambda2': L2[g1, g2]}
+                sol['Theta'], TAU[:, g1, g2], _ = tune_multiple_threshold(sol['Theta'], S, N, tau_range=None,
+                                                                          method=method, gamma=gamma)
+            fit, E = _criteria(S, sol['Theta'], N, K)
+            SP[g1, g2] = mean_sparsity(sol['Theta'])
+        pk = np.array([S[k].shape[0] for k in range(K)])
+        Nk = np.asarray(N, dtype=np.float64)
+        AIC[g1, g2] = np.sum(fit + E)
+        for g in gammas:
+            BIC[g][g1, g2] = np.sum(fit + E * (np.log(Nk) + 4 * np.log(pk) * g))
+        if latent:
+            RANK[:, g1, g2] = [np.linalg.matrix_rank(sol['L'][k]) for k in range(K)]
+        score = BIC[gamma][g1, g2] if method == 'eBIC' else AIC[g1, g2]
+        if score < curr_min:
+            curr_min = score
+            curr_best = sol.copy()
+        if verbose:
+            print(f"Grid point: (l1,l2): {(L1[g1, g2], L2[g1, g2])}, sparsity: {np.round(SP[g1, g2], 3)}, "
+                  f"best score: {np.round(curr_min, 1)}")
+    if method == 'AIC':
+        AIC[AIC == -np.inf] = np.nan
+        ix = np.unravel_index(np.nanargmin(AIC), AIC.shape)
+    else:
+        for g in gammas:
+            BIC[g][BIC[g] == -np.inf] = np.nan
+        ix = np.unravel_index(np.nanargmin(BIC[gamma]), BIC[gamma].shape)
+    if verbose:
+        print(f"Best regularization parameters: (l1,l2): {(L1[ix], L2[ix])}")
+    stats = {'BIC': BIC, 'AIC': AIC, 'SP': SP, 'RANK': RANK, 'TAU': TAU, 'L1': L1, 'L2': L2,
+             'BEST': {'lambda1': L1[ix], 'lambda2': L2[ix]}, 'GAMMA': gammas}
+    if thresholding:
+        stats['NO_THRESHOLDING_SOL'] = no_thr_best
+        stats['NO_THRESHOLDING_BEST'] = no_thr_params
+    return stats, ix, curr_best

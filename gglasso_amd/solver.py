@@ -123,6 +123,18 @@ class HipEngine:
     def scale_X_batch(self, factors):
         check(self.lib.ggl_scale_X_batch(self.h, ptr(as_c(factors))))
 
+    # -- G independent multiple-graph problems in one stack (batched lambda1 x lambda2 grid) -------------------
+    def mgl_batch_step(self, G, rho, lambda1, lambda2, reg, latent, mu1, nk):
+        """One ADMM_MGL iteration of all G problems (problem g = instances g*K/G ..); returns the (G,5) sums."""
+        out = np.zeros((int(G), 5))
+        rc = self.lib.ggl_mgl_batch_step(self.h, int(G), ptr(as_c(rho)), ptr(as_c(lambda1)), ptr(as_c(lambda2)),
+                                         _REG[reg], int(latent), ptr(None if mu1 is None else as_c(mu1)),
+                                         ptr(None if nk is None else as_c(nk)), ptr(out))
+        if rc > 0:
+            raise RuntimeError(f"ggl_mgl_batch_step: unexpected return code {rc} (speculative step rejected twice)")
+        check(rc)
+        return out
+
     def state_k(self, k, latent=False):
         shape = (self.p, self.p)
         Om, Th, X = np.empty(shape), np.empty(shape), np.empty(shape)

@@ -158,6 +158,17 @@ int ggl_sgl_batch_step(ggl_ctx *ctx, const double *rho, const double *lambda1, i
 int ggl_scale_X_batch(ggl_ctx *ctx, const double *factor);
 int ggl_get_state_k(ggl_ctx *ctx, int k, double *Omega, double *Theta, double *L, double *X);
 
+/* ---- G independent multiple-graph problems on the same S (batched lambda1 x lambda2 grid) -----------
+ * What the MAIN LOOP of grid_search (helper/model_selection.py:208-224) solves one (lambda1, lambda2) point after the
+ * other: here the ctx stack holds G problems of K/G instances each, problem g in the slots g*K/G .., every problem with
+ * its own rho_g, lambda1_g, lambda2_g; one call = one ADMM_MGL iteration (admm_solver.py:179-224) of all of them
+ * (batched Omega-/L-step over all G*K/G matrices, one Theta-step launch with a grid-point dimension).  mu1: (K total)
+ * per instance; nk: (K/G) per instance of a problem or NULL; out_norms (G,5).  The caller keeps per-problem rho updates
+ * and stopping decisions (ggl_scale_X_batch takes one factor per instance; ggl_get_state_k / ggl_snapshot_k per instance).
+ * GGL: K/G <= 32; state exactly symmetric. */
+int ggl_mgl_batch_step(ggl_ctx *ctx, int G, const double *rho, const double *lambda1, const double *lambda2,
+                       int reg, int latent, const double *mu1, const double *nk, double *out_norms);
+
 /* X <- factor * X : dual rescale after a rho update (admm_solver.py:236). */
 int ggl_scale_X(ggl_ctx *ctx, double factor);
 

@@ -89,6 +89,26 @@ class OracleEngine:
     def scale_X_batch(self, factors):
         self.X = np.asarray(factors)[:, None, None] * self.X
 
+    # G independent multiple-graph problems, problem g = instances g*K/G .. (batched lambda1 x lambda2 grid)
+    def mgl_batch_step(self, G, rho, lambda1, lambda2, reg, latent, mu1, nk):
+        Kp = self.K // G
+        out = np.zeros((G, 5))
+        Om_new = np.empty_like(self.Om)
+        nkv = np.ones(Kp) if nk is None else np.asarray(nk, dtype=np.float64)
+        for g in range(G):
+            sl = slice(g * Kp, (g + 1) * Kp)
+            W = self.Th[sl] - self.L[sl] - self.X[sl] - (nkv[:, None, None] / rho[g]) * self.S[sl]
+            om, _ = orc.phiplus_stack(W, nkv / rho[g])
+            th = orc.prox_p(om + self.L[sl] + self.X[sl], lambda1[g] / rho[g], lambda2[g] / rho[g], reg)
+            if latent:
+                self.L[sl] = orc.rank_stack(th - self.X[sl] - om, np.asarray(mu1)[sl] / rho[g])
+            x = self.X[sl] + om - th + self.L[sl]
+            out[g] = [np.sum(om ** 2), np.sum((th - self.L[sl]) ** 2), np.sum(x ** 2),
+                      np.sum((om - th + self.L[sl]) ** 2), np.sum((om - self.Om[sl]) ** 2)]
+            Om_new[sl], self.Th[sl], self.X[sl] = om, th, x
+        self.Om_prev, self.Om = self.Om, Om_new
+        return out
+
     def state_k(self, k, latent=False):
         sol = {'Omega': self.Om[k].copy(), 'Theta': self.Th[k].copy(), 'X': self.X[k].copy()}
         if latent:

@@ -369,3 +369,10 @@ def test_ext_asserts_like_reference(oracle_engine):
         ext_solver.ext_ADMM_MGL(S, 0.1, 0.1, 'GGL', Om0, Gbad)
     with pytest.raises(AssertionError, match="integer"):
         ext_solver.ext_ADMM_MGL(S, 0.1, 0.1, 'GGL', Om0, G.astype(float))
+
+
+def test_batched_mgl_grid_search_matches_reference_tables(oracle_engine):
+    """gglasso_amd.model_selection.grid_search (lambda1 x lambda2 grid as one batch, per-point rho / stopping, criteria,
+    selection, thresholding, sequential mode) over the test-only oracle engine against the reference's tables G16."""
+    from grid_checks import check_mgl_grid_search
+    _quiet(check_mgl_grid_search, load_golden)

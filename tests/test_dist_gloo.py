@@ -134,3 +134,44 @@ def test_lambda_path_sharded_over_two_ranks(tmp_path):
         ref, rinfo = orc.ADMM_SGL(S[0], lam, np.eye(18), tol=1e-9, rtol=1e-9)
         assert int(a["iters"][i]) == rinfo["iterations"]
         assert np.abs(a["thetas"][i] - ref["Theta"]).max() <= 1e-10
+
+
+def _grid_worker(rank, world, port, out_dir):
+    import contextlib
+    import io
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gglasso_amd import solver
+    from oracle_engine import OracleEngine
+    from conftest import load_golden
+    from grid_checks import check_mgl_grid_search
+    solver.ENGINE = OracleEngine
+    solved = []
+
+    class Counting(OracleEngine):
+        def __init__(self, S, *a, **k):
+            super().__init__(S, *a, **k)
+            solved.append(self.K)
+    solver.ENGINE = Counting
+    with contextlib.redirect_stdout(io.StringIO()):
+        # the 3 x 2 grid (6 points) dealt over two ranks: every rank must end with the reference's full tables
+        check_mgl_grid_search(load_golden, group=dist.group.WORLD, tags=("GGL_plain", "GGL_latent"))
+    np.savez(os.path.join(out_dir, f"grid{rank}.npz"), batch_instances=np.array(solved[:2]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mgl_grid_search_sharded_over_two_ranks(tmp_path):
+    """The model-selection grid axis over ranks (independent units, replicas only): 6 grid points x K=3
+    instances, 3 points per rank as one batch each, results gathered on every rank; tables and selection equal the
+    reference's (fixture G16)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_grid_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        d = np.load(os.path.join(str(tmp_path), f"grid{r}.npz"))
+        assert list(d["batch_instances"]) == [9, 9]           # each rank solved 3 of the 6 points (x K = 3) per search

@@ -359,3 +359,56 @@ def test_speculative_omega_step_hit_and_miss(sol, reg, K, p, monkeypatch):
         else:
             # from the identity start the spectrum still grows in the first iterations: a natural miss may occur
             assert stats["spec_misses"] < stats["spec_calls"], (env, stats)
+
+
+# ---- batched lambda1 x lambda2 grid of the multiple-graph problems (G problems x K instances in one ctx) -----------
+
+def test_g16_batched_mgl_grid_search(sol):
+    """grid_search with the whole grid as one batch on the GPU against the reference's tables (GGL / FGL, AIC, w2,
+    latent with ix_mu, thresholding, sequential mode, one-row grid)."""
+    from grid_checks import check_mgl_grid_search
+    quiet(check_mgl_grid_search, load_golden)
+
+
+@pytest.mark.parametrize("reg,K,p,latent", [("GGL", 4, 40, False), ("GGL", 3, 150, False), ("FGL", 5, 140, True),
+                                            ("GGL", 4, 200, True), ("FGL", 36, 36, False)])
+def test_mgl_batch_equals_independent_solves(reg, K, p, latent):
+    """Every problem of the batch must follow the trajectory of its own ADMM_MGL call (own rho, own stopping
+    iteration) -- against the CPU oracle, below and above the LDS-Jacobi limit, both penalties, latent or not."""
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_MGL_batch
+    S, _ = synth.make_problem(reg, K, p, N=2 * p, seed=41)
+    Om0 = np.stack([np.eye(p)] * K)
+    l1 = np.array([0.2, 0.08, 0.05, 0.03])
+    l2 = np.array([0.05, 0.02, 0.03, 0.004])
+    mu = np.linspace(0.2, 0.4, K) if latent else None
+    res = ADMM_MGL_batch(S, l1, l2, reg, tol=1e-8, rtol=1e-8, latent=latent, mu1=mu, selection_stats=True)
+    assert len(res) == 4
+    for g in range(4):
+        ref, rinfo = orc.ADMM_MGL(S, l1[g], l2[g], reg, Om0, tol=1e-8, rtol=1e-8, latent=latent, mu1=mu)
+        out, info = res[g]
+        assert info['status'] == rinfo['status'] == 'optimal'
+        assert info['iterations'] == rinfo['iterations'], (g, info['iterations'], rinfo['iterations'])
+        assert info['rho'] == rinfo['rho']
+        for nm in ('Omega', 'Theta', 'L', 'X'):
+            assert np.abs(out[nm] - ref[nm]).max() <= 1e-9, (g, nm)
+        st = info['selection']
+        assert np.allclose(st[:, 0], [np.sum(S[k] * ref['Theta'][k]) for k in range(K)], rtol=1e-9)
+        assert np.allclose(st[:, 1], [np.linalg.slogdet(ref['Theta'][k])[1] for k in range(K)], rtol=1e-9, atol=1e-9)
+        assert np.array_equal(st[:, 2], [np.count_nonzero(ref['Theta'][k]) for k in range(K)])
+
+
+def test_mgl_batch_max_iter_and_nsamples():
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_MGL_batch
+    K, p = 3, 30
+    S, _ = synth.make_problem("GGL", K, p, N=90, seed=9)
+    Om0 = np.stack([np.eye(p)] * K)
+    nk = np.array([2.0, 3.0, 1.5])
+    res = ADMM_MGL_batch(S, [0.05, 0.1], [0.02, 0.01], "GGL", max_iter=7, tol=1e-20, rtol=1e-20, n_samples=nk)
+    for g, (l1, l2) in enumerate(((0.05, 0.02), (0.1, 0.01))):
+        ref, _ = orc.ADMM_MGL(S, l1, l2, "GGL", Om0, max_iter=7, tol=1e-20, rtol=1e-20, n_samples=nk)
+        out, info = res[g]
+        assert info['status'] == 'max iterations reached' and info['iterations'] == 7
+        for nm in ('Omega', 'Theta', 'X'):
+            assert np.abs(out[nm] - ref[nm]).max() <= 1e-10
