@@ -18,6 +18,10 @@ namespace ggl {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// second output of a product launch, C2 = dI I + dC C + dE E: one fixed evaluation order at every store site (upper
+// triangle, diagonal-tile mirror, LDS-transposed mirror), so that the output is bitwise symmetric
+__device__ __forceinline__ double c2val(double dC, double v, double dE, double e) { return __builtin_fma(dE, e, dC * v); }
+
 template <int BM, int BK, int WM, int WN, bool LM>
 struct SymCfg {
     static constexpr int NWR = BM / WM, NWC = BM / WN, NW = NWR * NWC, NT = NW * 64;
@@ -184,8 +188,8 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
     if (ABL == 3) t_loop_end = clock64();
 #endif
     // epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-    const double cI = coef[k * 5 + 0], cAcc = coef[k * 5 + 1], cE = coef[k * 5 + 2];
-    const double dI = coef[k * 5 + 3], dC = coef[k * 5 + 4];
+    const double cI = coef[k * NS_NCOEF + 0], cAcc = coef[k * NS_NCOEF + 1], cE = coef[k * NS_NCOEF + 2];
+    const double dI = coef[k * NS_NCOEF + 3], dC = coef[k * NS_NCOEF + 4], dE = coef[k * NS_NCOEF + 5];
     double* Ck = (second ? C1 : C) + (size_t)kk * pp;
     double* C2k = (C2 && !second) ? C2 + (size_t)kk * pp : nullptr;
     const double* Ek = (E && !second) ? E + (size_t)kk * pp : nullptr;
@@ -202,15 +206,16 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
                 const bool in = gi < p && gj < p;
                 if (in && (I != J || gi <= gj)) {
                     if (gi == gj) v += cI;
-                    if (Ek) v += cE * Ek[(size_t)gi * p + gj];
+                    const double e0 = Ek ? Ek[(size_t)gi * p + gj] : 0.0;
+                    v += cE * e0;
                     Ck[(size_t)gi * p + gj] = v;
-                    if (C2k) C2k[(size_t)gi * p + gj] = dC * v + (gi == gj ? dI : 0.0);
+                    if (C2k) C2k[(size_t)gi * p + gj] = c2val(dC, v, dE, e0) + (gi == gj ? dI : 0.0);
                     // mirrored store.  Diagonal tiles: only the upper triangle is kept, so the result is
                     // bitwise symmetric even though A != B.  Off-diagonal tiles without the LDS transpose:
                     // the four r-values of a lane quad complete a 128-B line.
                     if ((I == J && gi != gj) || (!LM && I != J)) {
                         Ck[(size_t)gj * p + gi] = v;
-                        if (C2k) C2k[(size_t)gj * p + gi] = dC * v;
+                        if (C2k) C2k[(size_t)gj * p + gi] = c2val(dC, v, dE, e0);
                     }
                 }
                 if (LM && I != J) smem[row * Cfg::CLD + col] = v;
@@ -242,7 +247,11 @@ __global__ __launch_bounds__(sym_nt(BM, WM, WN)) void k_symm_tn(
             if (J0 + a < p && I0 + c < p) {
                 const double v = smem[c * Cfg::CLD + a];
                 Ck[(size_t)(J0 + a) * p + I0 + c] = v;
-                if (C2k) C2k[(size_t)(J0 + a) * p + I0 + c] = dC * v;
+                if (C2k) {
+                    // E is bitwise symmetric (an output of this kernel family): its mirrored entry IS the upper one
+                    const double e0 = (dE != 0.0 && Ek) ? Ek[(size_t)(J0 + a) * p + I0 + c] : 0.0;
+                    C2k[(size_t)(J0 + a) * p + I0 + c] = c2val(dC, v, dE, e0);
+                }
             }
         }
     }
@@ -408,8 +417,8 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
     }
     __syncthreads();     // all fragment reads done before the slabs are reused as the mirror tile
 
-    const double cI = coef[k * 5 + 0], cAcc = coef[k * 5 + 1], cE = coef[k * 5 + 2];
-    const double dI = coef[k * 5 + 3], dC = coef[k * 5 + 4];
+    const double cI = coef[k * NS_NCOEF + 0], cAcc = coef[k * NS_NCOEF + 1], cE = coef[k * NS_NCOEF + 2];
+    const double dI = coef[k * NS_NCOEF + 3], dC = coef[k * NS_NCOEF + 4], dE = coef[k * NS_NCOEF + 5];
     double* Ck = (second ? C1 : C) + (size_t)kk * pp;
     double* C2k = (C2 && !second) ? C2 + (size_t)kk * pp : nullptr;
     const double* Ek = (E && !second) ? E + (size_t)kk * pp : nullptr;
@@ -426,13 +435,14 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
                 double v = cAcc * acc[ti][tj][r];
                 if (gi < p && gj < p && (I != J || gi <= gj)) {
                     if (gi == gj) v += cI;
-                    if (Ek) v += cE * Ek[(size_t)gi * p + gj];
+                    const double e0 = Ek ? Ek[(size_t)gi * p + gj] : 0.0;
+                    v += cE * e0;
                     dev = fmax(dev, fabs(v - (gi == gj ? 1.0 : 0.0)));
                     Ck[(size_t)gi * p + gj] = v;
-                    if (C2k) C2k[(size_t)gi * p + gj] = dC * v + (gi == gj ? dI : 0.0);
+                    if (C2k) C2k[(size_t)gi * p + gj] = c2val(dC, v, dE, e0) + (gi == gj ? dI : 0.0);
                     if (I == J && gi != gj) {
                         Ck[(size_t)gj * p + gi] = v;
-                        if (C2k) C2k[(size_t)gj * p + gi] = dC * v;
+                        if (C2k) C2k[(size_t)gj * p + gi] = c2val(dC, v, dE, e0);
                     }
                 }
                 if (I != J && ABL != 1) smem[row * BM + (col ^ row)] = v;        // XOR-swizzled BM x BM mirror tile
@@ -449,7 +459,11 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
             if (J0 + a < p && I0 + c < p) {
                 const double v = smem[c * BM + (a ^ c)];
                 Ck[(size_t)(J0 + a) * p + I0 + c] = v;
-                if (C2k) C2k[(size_t)(J0 + a) * p + I0 + c] = dC * v;
+                if (C2k) {
+                    // E is bitwise symmetric (an output of this kernel family): its mirrored entry IS the upper one
+                    const double e0 = (dE != 0.0 && Ek) ? Ek[(size_t)(J0 + a) * p + I0 + c] : 0.0;
+                    C2k[(size_t)(J0 + a) * p + I0 + c] = c2val(dC, v, dE, e0);
+                }
             }
         }
     }

@@ -98,7 +98,7 @@ struct ggl_ctx {
     int* sweeps = nullptr;
     long long ns_stable_calls = 0;
     int last_parts = 0, last_variant = -1;     // concurrent parts / product-kernel variant of the last matrix-function step
-    double *coef = nullptr, *coef_h = nullptr; // [3*NS_MAX_STEPS][K][5]
+    double *coef = nullptr, *coef_h = nullptr; // [NS_MAX_LAUNCHES][2K][NS_NCOEF]
     double* bounds_h = nullptr;                // pinned: spectral / norm bound per instance, written by k_bound_final
 
     // ext_ADMM_MGL (instances of different dimension, ggl_ext_*): lazy
@@ -621,10 +621,10 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         // phase A: A' = W^2 + 4 beta I, B' = A'^2 (both needed anyway), then the bound from B'
         double* pre = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 2) * NS_SLOT(K);
         for (int k = 0; k < K; ++k) {
-            double* o0 = pre + (size_t)k * 5;
-            double* o1 = pre + NS_SLOT(K) + (size_t)k * 5;
-            o0[0] = 4.0 * c->par_h[k]; o0[1] = 1.0; o0[2] = o0[3] = o0[4] = 0.0;
-            o1[0] = 0.0; o1[1] = 1.0; o1[2] = o1[3] = o1[4] = 0.0;
+            double* o0 = pre + (size_t)k * NS_NCOEF;
+            double* o1 = pre + NS_SLOT(K) + (size_t)k * NS_NCOEF;
+            o0[0] = 4.0 * c->par_h[k]; o0[1] = 1.0; o0[2] = o0[3] = o0[4] = o0[5] = 0.0;
+            o1[0] = 0.0; o1[1] = 1.0; o1[2] = o1[3] = o1[4] = o1[5] = 0.0;
         }
         double* pre_d = c->coef + (size_t)(NS_MAX_LAUNCHES - 2) * NS_SLOT(K);
         // Parts of the batch on concurrent streams: while one part's product drains its output and the next
@@ -660,6 +660,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         bool spec = allow_spec && c->spec_enable && c->spec_have && !latent && c->spec_cool == 0;
         if (allow_spec && c->spec_cool > 0) c->spec_cool -= 1;
         for (int k = 0; spec && k < K; ++k) spec = (c->par_h[k] == c->spec_beta[k]);
+        double* fused[ggl_ctx::MAX_PARTS] = {};      // speculative step: the first step's start as 2nd output of the B' launch
         if (spec) {
             for (int k = 0; k < K; ++k) c->cuse_h[k] = c->spec_c[k] * c->spec_factor;
             for (int h = 0; spec && h < nh; ++h) {
@@ -667,6 +668,11 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 const int prc = ns_plan(c->cuse_h + k0, c->par_h + k0, Kh[h], c->coef_h + h * region,
                                         start_base_h + 5 * k0, &plans[h], c->ns_force, c->ns_degrees);
                 spec = (prc == 0) && !plans[h].stable;
+                for (int k = k0; spec && k < k0 + Kh[h]; ++k) {
+                    // the bound is assumed known, so the start is a fixed combination of A' and B': {dI, dC, dE} of B' launch
+                    fused[h] = ns_fused_start(plans[h], start_base_h + 5 * (size_t)k, c->nsYP[1] + k0 * pp, c->nsT + k0 * pp,
+                                              nh > 1 ? c->n : (size_t)K * pp, pre + NS_SLOT(K) + (size_t)k * NS_NCOEF + 3);
+                }
             }
         }
         if (nh > 1) {
@@ -678,8 +684,9 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             const int k0 = k0h[h];
             // the pending parameter transfers are repeated on every part's stream (identical values, a few KB)
             CopySegs sg = first;
-            sg.add(pre_d + 5 * (size_t)k0, pre + 5 * (size_t)k0, (size_t)Kh[h] * 5 * sizeof(double));
-            sg.add(pre_d + NS_SLOT(K) + 5 * (size_t)k0, pre + NS_SLOT(K) + 5 * (size_t)k0, (size_t)Kh[h] * 5 * sizeof(double));
+            sg.add(pre_d + NS_NCOEF * (size_t)k0, pre + NS_NCOEF * (size_t)k0, (size_t)Kh[h] * NS_NCOEF * sizeof(double));
+            sg.add(pre_d + NS_SLOT(K) + NS_NCOEF * (size_t)k0, pre + NS_SLOT(K) + NS_NCOEF * (size_t)k0,
+                   (size_t)Kh[h] * NS_NCOEF * sizeof(double));
             // validation flags of this step: this part's slot, and (part 0) the slot of the all-reduced flag of K-sharded
             // runs, where a rank must skip and repeat the step when ANY rank's speculation failed -- also a rank that
             // did not speculate itself
@@ -704,8 +711,8 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             if (h == 0) { PE(c, GGL_PH_FORM_W); PB(c, GGL_PH_EIG_OMEGA); }
             double* Ap = c->nsYP[0] + k0 * pp;
             double* Bp = c->nsYP[0] + c->n + k0 * pp;
-            ns_prepare(sh, pre_d + 5 * (size_t)k0, pre_d + NS_SLOT(K) + 5 * (size_t)k0, c->W + k0 * pp, Ap, Bp, Kh[h], c->p,
-                       var_parts);
+            ns_prepare(sh, pre_d + NS_NCOEF * (size_t)k0, pre_d + NS_SLOT(K) + NS_NCOEF * (size_t)k0, c->W + k0 * pp, Ap, Bp, Kh[h], c->p,
+                       var_parts, spec ? fused[h] : nullptr);
             // lambda_max(A')^2 = lambda_max(B') <= min(|B'|_inf, |B'|_F, Collatz-Wielandt ratio), reduced on the
             // device; only the K_part bounds travel to the (pinned, device-visible) host array
             double* nb2 = c->nbpart + 2 * (size_t)k0 * nbb;
@@ -717,7 +724,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             if (spec) {
                 ns_run(sh, plans[h], c->coef + h * region, start_base_d + 5 * k0, c->W + k0 * pp, c->nsYP[0] + k0 * pp,
                        c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kh[h], c->p,
-                       (c->symm_variant < 0 && nh > 1) ? 17 : c->symm_variant, nh > 1 ? c->n : 0);
+                       (c->symm_variant < 0 && nh > 1) ? 17 : c->symm_variant, nh > 1 ? c->n : 0, fused[h] != nullptr);
                 c->ns_launches_total += plans[h].products;
                 const double frac = (double)Kh[h] / K;
                 c->ns_units_frac += frac * plans[h].units;
@@ -943,7 +950,7 @@ static int rank_step(ggl_ctx* c)
         for (int h = 0, k0 = 0; h < nh; ++h) {
             const int Kr = K / nh + (h < K % nh ? 1 : 0);
             // scratch: Xa = nsYP[0], Xb = nsYP[0] + n, P2 = nsYP[1], T = nsT
-            rank_ns_run(h == 0 ? c->stream : c->streamx[h - 1], plan, c->coef + 5 * (size_t)k0, c->W + k0 * pp,
+            rank_ns_run(h == 0 ? c->stream : c->streamx[h - 1], plan, c->coef + NS_NCOEF * (size_t)k0, c->W + k0 * pp,
                         c->nsYP[0] + k0 * pp, c->nsYP[0] + c->n + k0 * pp, c->nsT + k0 * pp, c->nsYP[1] + k0 * pp,
                         c->L + k0 * pp, c->maxdev + k0, Kr, c->p, (c->symm_variant < 0 && nh > 1) ? 17 : c->symm_variant,
                         NS_SLOT(K));
@@ -1851,10 +1858,12 @@ extern "C" int ggl_dev_symm(int K, int p, const double* A, const double* B, cons
     HIPCHK(dA.alloc(n));
     HIPCHK(dB.alloc(n));
     HIPCHK(dC.alloc(n));
-    HIPCHK(dcoef.alloc((size_t)K * 5));
+    std::vector<double> cw((size_t)K * NS_NCOEF, 0.0);     // rows {cI,cAcc,cE,dI,dC} widened by dE = 0
+    for (int k = 0; k < K; ++k) std::copy(coef5K + (size_t)k * 5, coef5K + (size_t)k * 5 + 5, cw.begin() + (size_t)k * NS_NCOEF);
+    HIPCHK(dcoef.alloc(cw.size()));
     UP(dA.p, A, n);
     UP(dB.p, B, n);
-    UP(dcoef.p, coef5K, (size_t)K * 5);
+    UP(dcoef.p, cw.data(), cw.size());
     if (E) { HIPCHK(dE.alloc(n)); UP(dE.p, E, n); }
     if (C2) HIPCHK(dC2.alloc(n));
     launch_symm(nullptr, dA.p, dB.p, dC.p, C2 ? dC2.p : nullptr, E ? dE.p : nullptr, dcoef.p, K, p, variant);
@@ -1870,21 +1879,21 @@ extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* 
     ARGCHK(K >= 1 && p >= 1 && iters >= 1 && ms_out, "arguments");
     ARGCHK(variant < 0 || symm_variant_built(variant), "product-kernel variant not in this build");
     const size_t n = (size_t)K * p * p;
-    std::vector<double> h(n), coef((size_t)K * 5, 0.0);
+    std::vector<double> h(n), coef((size_t)K * NS_NCOEF, 0.0);
     unsigned long long s = 88172645463325252ull;
     for (size_t i = 0; i < n; ++i) {
         s ^= s << 13; s ^= s >> 7; s ^= s << 17;
         h[i] = (double)(s >> 11) / 9007199254740992.0 - 0.5;
     }
-    for (int k = 0; k < K; ++k) coef[(size_t)k * 5 + 1] = 1.0 / p;
+    for (int k = 0; k < K; ++k) coef[(size_t)k * NS_NCOEF + 1] = 1.0 / p;
     DevBuf dA, dB, dC, dcoef;
     HIPCHK(dA.alloc(n));
     HIPCHK(dB.alloc(n));
     HIPCHK(dC.alloc(n));
-    HIPCHK(dcoef.alloc((size_t)K * 5));
+    HIPCHK(dcoef.alloc(coef.size()));
     UP(dA.p, h.data(), n);
     UP(dB.p, h.data(), n);
-    UP(dcoef.p, coef.data(), (size_t)K * 5);
+    UP(dcoef.p, coef.data(), coef.size());
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -1908,8 +1917,8 @@ extern "C" int ggl_dev_symm_timeline(int K, int p, long long* out, int max_block
 {
     ARGCHK(K >= 1 && p >= 1 && out && nblocks_out, "arguments");
     const size_t n = (size_t)K * p * p;
-    std::vector<double> h(n, 0.25), coef((size_t)K * 5, 0.0);
-    for (int k = 0; k < K; ++k) coef[(size_t)k * 5 + 1] = 1.0 / p;
+    std::vector<double> h(n, 0.25), coef((size_t)K * NS_NCOEF, 0.0);
+    for (int k = 0; k < K; ++k) coef[(size_t)k * NS_NCOEF + 1] = 1.0 / p;
     const int T = (p + 63) / 64;
     const int nb = (K >= 8 ? 8 * ((K + 7) / 8) : K) * (T * (T + 1) / 2);
     ARGCHK(nb <= max_blocks, "max_blocks too small");
@@ -1917,11 +1926,11 @@ extern "C" int ggl_dev_symm_timeline(int K, int p, long long* out, int max_block
     HIPCHK(dA.alloc(n));
     HIPCHK(dB.alloc(n));
     HIPCHK(dC.alloc(n));
-    HIPCHK(dcoef.alloc((size_t)K * 5));
+    HIPCHK(dcoef.alloc(coef.size()));
     HIPCHK(dT.alloc((size_t)nb * 5));
     UP(dA.p, h.data(), n);
     UP(dB.p, h.data(), n);
-    UP(dcoef.p, coef.data(), (size_t)K * 5);
+    UP(dcoef.p, coef.data(), coef.size());
     HIPCHK(hipMemset(dT.p, 0, (size_t)nb * 5 * sizeof(double)));
     for (int i = 0; i < 3; ++i) launch_symm(nullptr, dA.p, dB.p, dC.p, nullptr, nullptr, dcoef.p, K, p, 0);
     launch_symm(nullptr, dA.p, dB.p, dC.p, nullptr, nullptr, dcoef.p, K, p, 10, dT.p);

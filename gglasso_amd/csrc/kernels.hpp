@@ -147,8 +147,9 @@ void launch_recon(hipStream_t st, double* out, const double* R, const double* D,
                   int map, int K, int p, double* scale_work);
 
 // ---- gemm_sym.hip -----------------------------------------------------------------------
-// C[k] = cI*I + cAcc*(A[k]*B[k]) + cE*E[k]  and optionally  C2[k] = dI*I + dC*C[k]  for commuting
-// symmetric A, B (so that A*B = A^T*B is symmetric).  coef: device [K][5] = {cI,cAcc,cE,dI,dC}.
+// C[k] = cI*I + cAcc*(A[k]*B[k]) + cE*E[k]  and optionally  C2[k] = dI*I + dC*C[k] + dE*E[k]  for commuting
+// symmetric A, B (so that A*B = A^T*B is symmetric).  coef: device [K][NS_NCOEF] = {cI,cAcc,cE,dI,dC,dE}.
+static constexpr int NS_NCOEF = 6;
 // variant < 0: pick by problem size.  FP64 MFMA.
 int symm_variants();
 bool symm_variant_built(int v);          // the shipped library holds the dispatched instances only (gemm_sym.hip)
@@ -164,7 +165,7 @@ double mfma_valu_mix_tflops(hipStream_t st, double* scratch, int blocks, int ite
 void launch_gemm_right(hipStream_t st, const double* A, const double* T, double* C, const double* scal,
                        int nbatch, int K, int p, int variant);
 
-// two independent symmetric products in one launch; coef2K: [2K][5] (second half for the second product)
+// two independent symmetric products in one launch; coef2K: [2K][NS_NCOEF] (second half for the second product)
 void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
                       double* C1, const double* coef2K, int K, int p, int variant);
 
@@ -173,7 +174,7 @@ static constexpr int NS_MAX_STEPS = 24;        // square-root schedule (conditio
 static constexpr int NS_RANK_MAX_STEPS = 40;   // sign schedule (resolution down to ~1e-13)
 static constexpr int NS_MAX_LAUNCHES = 2 * NS_RANK_MAX_STEPS + 1 + 3;   // + start table + two pre-bound slots
 // doubles per launch slot of the coefficient table (a pair launch carries 2K rows of 5)
-static inline size_t NS_SLOT(int K) { return (size_t)K * 10; }
+static inline size_t NS_SLOT(int K) { return (size_t)K * 2 * NS_NCOEF; }
 // all-symmetric products are only accurate while the condition number of W^2 + 4 beta I is small
 static constexpr double NS_SYM_KAPPA_MAX = 300.0;
 // above this condition number of W^2 + 4 beta I the Omega-step uses the eigendecomposition instead
@@ -201,9 +202,13 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
 // the schedule alone (host): returns steps, fills deg[max_steps], coef[max_steps*6] = {t0..t4,l_after}
 int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units);
 void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, const double* W, double* Ap, double* Bp,
-                int K, int p, int variant);
+                int K, int p, int variant, double* start2 = nullptr);
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
-            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride = 0);
+            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride = 0,
+            bool fused_start = false);
+// speculative step (bound known before B' exists): target buffer and {dI, dC, dE} of the start the B' launch can emit
+// as its second output; null if the schedule's first step has none.  start_hk: row k of ns_plan's start table.
+double* ns_fused_start(const NsPlan& plan, const double* start_hk, double* YP, double* Tb, size_t n1, double out3[3]);
 
 // L-step (C - mu I)_+ by a sign-function Newton-Schulz iteration (newton_schulz.hip)
 int norm_bounds_blocks(int p);

@@ -408,8 +408,10 @@ int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* co
 // that is 2-3x tighter than |W|_inf and saves one to two Newton-Schulz steps.  st[k] = {y1a, y1b, z1i, z1a, h}
 // with h = 0.5 sqrt(c) when the start is already the end (one step: Omega = W/2 + h Y1); mode 2 reads
 // {-, z1b, z1i, z1a, -}.
-// degree-nine first step (mode 3):  Y1 <- Q = (1/c^2) B' + (a/c) A',  Z1 <- Q + d I   {qa, qb, d, -, -};
-// T1 = f I + t4 Q (Q + d I) + (e/c) A' and Y1 = A' T1 / c are products.
+// degree-nine first step (mode 3):  Y1 <- U = (t3/c) A' + (t4/c^2) B' + t2 I   {ua, ub, ui, -, -};
+// T1 = t0 I + (t1/c) A' + U B'/c^2  (the quartic t(m), m = A'/c, as t0 + t1 m + (t2 + t3 m + t4 m^2) m^2) and
+// Y1 = A' T1 / c are products.  When the bound c is known before B' is formed (speculative step), U (degree nine) or
+// Z1 (quintic) is the SECOND OUTPUT of the launch that forms B' and this kernel does not run at all.
 __global__ __launch_bounds__(256) void k_ns_start(double* __restrict__ Y1, double* __restrict__ Z1,
                                                   const double* __restrict__ Ap, const double* __restrict__ Bp,
                                                   const double* __restrict__ W, const double* __restrict__ st, int p,
@@ -425,13 +427,11 @@ __global__ __launch_bounds__(256) void k_ns_start(double* __restrict__ Y1, doubl
             const double a = Ap[base + i], b2 = Bp[base + i];
             const int r = (int)(i / p), c = (int)(i - (size_t)r * p);
             if (mode == 2) {
-                Z1[base + i] = (z1a * a + y1b * b2) + (r == c ? z1i : 0.0);
+                Z1[base + i] = __builtin_fma(z1a, a, y1b * b2) + (r == c ? z1i : 0.0);     // same order as c2val()
                 continue;
             }
             if (mode == 3) {
-                const double q = y1a * a + y1b * b2;
-                Y1[base + i] = q;
-                Z1[base + i] = q + (r == c ? z1i : 0.0);
+                Y1[base + i] = __builtin_fma(y1a, a, y1b * b2) + (r == c ? z1i : 0.0);     // same order as c2val()
                 continue;
             }
             const double y = y1a * a + y1b * b2;
@@ -467,9 +467,9 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
     const double lmin = 1.0 / std::sqrt(kappa);
     plan->stable = stable;
     plan->kappa = kappa;
-    auto put = [&](int g, int k, double cI, double cAcc, double cE, double dI = 0.0, double dC = 0.0) {
-        double* o = coef_h + (size_t)g * NS_SLOT(K) + (size_t)k * 5;
-        o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = dI; o[4] = dC;
+    auto put = [&](int g, int k, double cI, double cAcc, double cE, double dI = 0.0, double dC = 0.0, double dE = 0.0) {
+        double* o = coef_h + (size_t)g * NS_SLOT(K) + (size_t)k * NS_NCOEF;
+        o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = dI; o[4] = dC; o[5] = dE;
     };
     if (!stable) {
         const NsSeq& sq = ns_mixed_schedule(lmin, degrees);
@@ -490,10 +490,9 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
                 if (sq.deg[0] == 5) {
                     s[0] = 0.0; s[1] = t[2] / (ck * ck); s[2] = t[0]; s[3] = t[1] / ck; s[4] = 0.0;
                 } else {
-                    // t(m) = t4 Q (Q + d) + e m + f,  Q = m^2 + a m,  m = A'/c
-                    const double a = t[3] / (2.0 * t[4]), d = t[2] / t[4] - a * a, e = t[1] - t[4] * d * a;
-                    s[0] = a / ck; s[1] = 1.0 / (ck * ck); s[2] = d; s[3] = 0.0; s[4] = 0.0;
-                    put(g++, k, t[0], t[4], e / ck);                  // Z1 = f I + t4 Q (Q + d I) + (e/c) A'
+                    // t(m) = t0 + t1 m + (t2 + t3 m + t4 m^2) m^2,  m = A'/c,  m^2 = B'/c^2
+                    s[0] = t[3] / ck; s[1] = t[4] / (ck * ck); s[2] = t[2]; s[3] = 0.0; s[4] = 0.0;
+                    put(g++, k, t[0], 1.0 / (ck * ck), t[1] / ck);    // Z1 = t0 I + (U B')/c^2 + (t1/c) A'
                 }
                 if (n == 1) put(g++, k, 0.0, 0.5 * sc / ck, 0.5);     // Omega = W/2 + sqrt(c)/2 (A'/c) Z1
                 else put(g++, k, 0.0, 1.0 / ck, 0.0);                 // Y1 = (A'/c) Z1
@@ -563,10 +562,22 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
 // Phase A (before the bound is known): A' = W^2 + 4 beta I -> Ap, B' = A'^2 -> Bp.
 // pre0_d / pre1_d: the coefficient rows {4 beta, 1, 0, 0, 0} and {0, 1, 0, 0, 0} of the K instances.
 void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, const double* W, double* Ap, double* Bp, int K,
-                int p, int variant)
+                int p, int variant, double* start2)
 {
+    // start2 != null (the bound is already known): the B' launch also writes start2 = dI I + dC B' + dE A' -- the
+    // first step's U (degree nine) or Z1 (quintic) -- with {dI, dC, dE} in pre1_d
     launch_symm(st, W, W, Ap, nullptr, nullptr, pre0_d, K, p, variant);
-    launch_symm(st, Ap, Ap, Bp, nullptr, nullptr, pre1_d, K, p, variant);
+    launch_symm(st, Ap, Ap, Bp, start2, start2 ? Ap : nullptr, pre1_d, K, p, variant);
+}
+
+// where the first step's elementwise start goes (ns_run's layout) and its coefficients {dI, dC, dE} from the start
+// table of ns_plan; null when the first step has no single-matrix start (cubic first step, stable schedule)
+double* ns_fused_start(const NsPlan& plan, const double* start_hk, double* YP, double* Tb, size_t n1, double out3[3])
+{
+    if (plan.stable || plan.deg[0] < 5) return nullptr;
+    if (plan.deg[0] == 5) { out3[0] = start_hk[2]; out3[1] = start_hk[1]; out3[2] = start_hk[3]; return YP + n1; }   // Z1
+    out3[0] = start_hk[2]; out3[1] = start_hk[1]; out3[2] = start_hk[0];                                              // U
+    return Tb;
 }
 
 // Phase B.  AB = [A' | B'] from ns_prepare (free afterwards), YP = the other [Y | Z] scratch pair, Tb one stack,
@@ -579,8 +590,9 @@ void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, cons
 // exactly, which is what makes the coupled iteration insensitive to rounding (the symmetrised form
 // amplifies commutator errors by ~sqrt(kappa)/4 per step).
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
-            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride)
+            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride, bool fused_start)
 {
+    // fused_start: the first step's elementwise start (ns_fused_start) was written by ns_prepare's B' launch
     // pstride: distance (doubles) between the two stacks of a [Y|Z] pair; 0 = contiguous (K*p*p).  A sub-batch
     // of a larger ctx (two-stream execution) passes the full-stack stride.
     const size_t cs = NS_SLOT(K), n1 = pstride ? pstride : (size_t)K * p * p;
@@ -591,11 +603,13 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
     if (plan.deg[0] >= 5 && !plan.stable) {
         if (plan.deg[0] == 5) {
             // quintic first step: Z1 = T1 elementwise
-            hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, nullptr, YP + n1, AB, AB + n1, W, start_d, p, 2);
+            if (!fused_start)
+                hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, nullptr, YP + n1, AB, AB + n1, W, start_d, p, 2);
         } else {
-            // degree nine: Q -> Tb and Q + d I -> Y slot elementwise, Z1 = T1 = f I + t4 Q (Q + d I) + (e/c) A'
-            hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, Tb, YP, AB, AB + n1, W, start_d, p, 3);
-            launch_symm(st, Tb, YP, YP + n1, nullptr, AB, coef_d + cs * g++, K, p, variant);
+            // degree nine: U -> Tb elementwise, Z1 = T1 = t0 I + U B'/c^2 + (t1/c) A'
+            if (!fused_start)
+                hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, Tb, nullptr, AB, AB + n1, W, start_d, p, 3);
+            launch_symm(st, Tb, AB + n1, YP + n1, nullptr, AB, coef_d + cs * g++, K, p, variant);
         }
         // Y1 = (A'/c) Z1 (or Omega directly when it is the only step)
         if (n == 1) {
@@ -807,8 +821,8 @@ int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, do
         const double nb = (cnorm_h[k] + mu) * (1.0 + 1e-10);      // |C - mu I| <= |C| + mu
         if (!(nb > 0.0) || !std::isfinite(nb)) return -1;
         auto put = [&](int gg, double cI, double cAcc, double cE, double dI, double dC) {
-            double* o = coef_h + (size_t)gg * NS_SLOT(K) + (size_t)k * 5;
-            o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = dI; o[4] = dC;
+            double* o = coef_h + (size_t)gg * NS_SLOT(K) + (size_t)k * NS_NCOEF;
+            o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = dI; o[4] = dC; o[5] = 0.0;
         };
         g = 0;
         const double s2 = a0 * a0 / (nb * nb);

@@ -172,9 +172,12 @@ def test_g14_prox_2norm_G():
     orc.check_G(G, g["p"])
     for n in range(2):
         res = orc.prox_2norm_G({k: g[f"proxG_in_{k}"].copy() for k in range(K)}, G, float(g[f"proxG{n}_lam"]))
+        vec = orc.prox_2norm_G_vectorized({k: g[f"proxG_in_{k}"].copy() for k in range(K)}, G, float(g[f"proxG{n}_lam"]))
         for k in range(K):
             assert np.abs(res[k] - g[f"proxG{n}_out_{k}"]).max() <= 1e-15
             assert np.array_equal(res[k], res[k].T)
+            assert np.abs(vec[k] - g[f"proxG{n}_out_{k}"]).max() <= 1e-15       # all groups at once == the loop
+    assert orc._G_entries_distinct(G, g["p"])
 
 
 @pytest.mark.parametrize("latent", [False, True])
