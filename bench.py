@@ -4,10 +4,14 @@ workload BASELINE.json quotes the metric on, (K=32, p=500), fp64.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One "step" = one full ADMM iteration (Omega-step: W formation + batched eigen/phiplus; Theta-step:
+One "step" = one full ADMM iteration (Omega-step: W formation + matrix-function products; Theta-step:
 group prox over the (K,p,p) stack; dual update; the five stopping-test norms; rho rule on the host)
 driven by the same host loop ``ADMM_MGL`` uses (gglasso_amd/solver.py::_run_admm) with tol=rtol=1e-20
 so that it cannot exit early.  S, Omega, Theta, X are resident in HBM before the timed region starts.
+
+The timed region is EXACTLY ``steps`` iterations between barrier + synchronize on both sides; it is run
+``--regions`` times back to back (default 7; 20 iterations are only ~20 ms of wall clock) and ``value`` /
+``ms_per_step`` are those of the MEDIAN region, with the fastest and slowest one reported next to it.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the K=32 stack is sharded into K/N slabs
 (strong scaling); per iteration one (p,p) fp64 all-reduce of the group sums of squares and one
@@ -22,6 +26,7 @@ import contextlib
 import io
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -44,6 +49,11 @@ WORKLOADS = {
     "ggl_K4_p500": ("GGL", 4, 500, False, 0.05, 0.01, 1239),
     "ggl_K32_p1000": ("GGL", 32, 1000, False, 0.05, 0.01, 1238),   # per-GPU slab of C5 at 8 GPUs
 }
+
+# product-kernel instances of csrc/gemm_sym.hip by the variant number ggl_ns_stats reports
+VARIANT_NAMES = {0: "k_symm_tn<64,16,32,32> (register-staged)", 9: "k_symm_tn<32,32,16,16> (register-staged)",
+                 16: "k_symm_dl<16,2,0,64> (direct-to-LDS)", 17: "k_symm_dl<16,3,0,64> (direct-to-LDS)",
+                 20: "k_symm_dl<32,4,0,32> (direct-to-LDS)"}
 
 
 def phase_model(phase, reg, K, p, latent, eig_jacobi, omega_ns=False):
@@ -69,35 +79,30 @@ def phase_model(phase, reg, K, p, latent, eig_jacobi, omega_ns=False):
     return "hbm", 0.0, "GB/s"
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the PMC passes of this same command
-    (tools/profile_round.sh -> tools/summarize_pmc.py -> profiles/*_pmc_summary.json; FETCH_SIZE and
-    WRITE_SIZE are collected in separate rocprofv3 runs).  None when no summary is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if not files:
-        return None
-    data = json.load(open(files[-1]))
-    key = kernel_name.split(" ")[0]
-    for name, c in data.items():
-        if name.startswith(key) and "hbm_bytes_per_launch" in c:
-            return c["hbm_bytes_per_launch"]
-    return None
-
-
-def rocprof_kernel_avg_ms(kernel_name):
-    """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of this
-    same command (profiles/*_bench_kernel_stats.csv), for comparison with the live figure.  None when absent."""
+def committed_profile(kernel_key):
+    """What the committed rocprofv3 runs of this same command say about the dominant kernel -- NOT measured by this
+    run: HBM bytes per launch from the two PMC passes (tools/profile_round.sh -> tools/summarize_pmc.py, FETCH_SIZE
+    doubled for the 16-byte-per-lane DMA kernel as MI355X_MICROARCH.md prescribes) and the kernel's average duration
+    in the --kernel-trace --stats summary.  Returns {} when nothing is committed."""
     import csv
     import glob
+    out = {}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if files:
+        data = json.load(open(files[-1]))
+        for name, c in data.items():
+            if name.startswith(kernel_key) and "hbm_bytes_per_launch" in c:
+                out["profiled_traffic_bytes"] = c["hbm_bytes_per_launch"]
+                out["profiled_traffic_source"] = "profiles/" + os.path.basename(files[-1])
+                break
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_kernel_stats.csv")))
-    if not files:
-        return None
-    key = kernel_name.split(" ")[0]
-    for row in csv.DictReader(open(files[-1])):
-        if key in row["Name"]:
-            return float(row["AverageNs"]) * 1e-6
-    return None
+    if files:
+        for row in csv.DictReader(open(files[-1])):
+            if kernel_key in row["Name"]:
+                out["profiled_kernel_avg_ms"] = float(row["AverageNs"]) * 1e-6
+                out["profiled_kernel_source"] = "profiles/" + os.path.basename(files[-1])
+                break
+    return out
 
 
 def quiet(fn, *a, **k):
@@ -105,23 +110,27 @@ def quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
-def cpu_baseline(S, reg, lambda1, lambda2, latent, mu1, iters):
-    """CPU oracle (a port: NumPy eigh + C prox), bounded sample of the same workload."""
+def cpu_baseline(S, reg, lambda1, lambda2, latent, mu1, iters, threads):
+    """CPU oracle (a port: NumPy eigh + C prox), bounded sample of the same workload, on `threads` BLAS threads
+    (LAPACK's eigh at p = 500 gets SLOWER beyond a few threads; all 128 of the box's cores is a strawman)."""
     from oracle import ggl_oracle as orc
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
-    except Exception:  # noqa: BLE001
-        threads = os.cpu_count() or 1
     K, p, _ = S.shape
     Om0 = np.repeat(np.eye(p)[None], K, axis=0)
-    orc.ADMM_MGL(S, lambda1, lambda2, reg, Om0, max_iter=1, tol=1e-20, rtol=1e-20, latent=latent, mu1=mu1)
-    t0 = time.perf_counter()
-    orc.ADMM_MGL(S, lambda1, lambda2, reg, Om0, max_iter=iters, tol=1e-20, rtol=1e-20, latent=latent, mu1=mu1)
-    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:  # noqa: BLE001
+        limiter = contextlib.nullcontext()
+        threads = os.cpu_count() or 1
+    with limiter:
+        orc.ADMM_MGL(S, lambda1, lambda2, reg, Om0, max_iter=1, tol=1e-20, rtol=1e-20, latent=latent, mu1=mu1)
+        t0 = time.perf_counter()
+        orc.ADMM_MGL(S, lambda1, lambda2, reg, Om0, max_iter=iters, tol=1e-20, rtol=1e-20, latent=latent, mu1=mu1)
+        dt = time.perf_counter() - t0
     return {"value": iters / dt, "unit": "ADMM iters/s", "cores": int(threads), "kind": "port",
             "sample": f"{iters} ADMM iterations of the same ({reg}, K={K}, p={p}) problem from the identity start "
-                      f"(oracle/ggl_oracle.py: numpy.linalg.eigh + C prox_p), {dt:.1f} s"}
+                      f"(oracle/ggl_oracle.py: numpy.linalg.eigh + C prox_p) on {threads} BLAS threads of the box's "
+                      f"{os.cpu_count()} cores, {dt:.1f} s"}
 
 
 def main():
@@ -129,10 +138,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--regions", type=int, default=7, help="how often the timed region of `steps` iterations is run")
     ap.add_argument("--workload", default="ggl_K32_p500", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eig", type=int, default=0, help="GGL_EIG_* selector (0 auto)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="ctx option (gglasso_amd._lib.OPTIONS), e.g. --opt pipeline=0; repeatable")
     args = ap.parse_args()
 
     import torch
@@ -148,15 +161,11 @@ def main():
     comm = None
     if distributed:
         if world == 1:      # GGL_BENCH_FORCE_DIST=1 without a launcher: single-rank rendezvous on the loopback
-            for kk, vv in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"),
-                           ("MASTER_PORT", "29511")):
-                os.environ.setdefault(kk, vv)
-        import torch.distributed as dist
-        from gglasso_amd.dist import TorchComm, shard_bounds
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if world == 1:      # GGL_BENCH_FORCE_DIST=1 without a launcher: single-rank rendezvous on the loopback
             for kk, vv in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29511")):
                 os.environ.setdefault(kk, vv)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch.distributed as dist
+        from gglasso_amd.dist import TorchComm, shard_bounds
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         comm = TorchComm(device=f"cuda:{local_rank}")
 
@@ -172,7 +181,9 @@ def main():
     Kl = k1 - k0
     Om0 = np.repeat(np.eye(p)[None], Kl, axis=0)
     stream = comm.stream_handle if distributed else None      # the communicator's dedicated stream (gglasso_amd/dist.py)
-    eng = solver.HipEngine(S_loc, Om0, Om0, np.zeros_like(S_loc), eig=args.eig, device=local_rank, stream=stream)
+    options = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in args.opt}
+    eng = solver.HipEngine(S_loc, Om0, Om0, np.zeros_like(S_loc), eig=args.eig, device=local_rank, stream=stream,
+                           options=options)
     nk = np.ones(Kl)
     mu_loc = None if mu1 is None else mu1[k0:k1]
 
@@ -190,20 +201,25 @@ def main():
     rho = 1.0
     if args.warmup > 0:
         rho = run(args.warmup, rho)
-    ns0 = eng.ns_stats()
-    # live HIP-event timing of the dominant (eigen / matrix-function) phases only during the timed region:
+    # live HIP-event timing of the dominant (eigen / matrix-function) phases only during the timed regions:
     # every extra event pair costs a few microseconds of host time per iteration
     eng.profile(2)
     eng.profile_read(reset=True)
-    fence()
-    t0 = time.perf_counter()
-    rho = run(args.steps, rho)
-    fence()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    ns0 = eng.ns_stats()
+    region_s = []
+    for _ in range(max(1, args.regions)):
+        fence()
+        t0 = time.perf_counter()
+        rho = run(args.steps, rho)
+        fence()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        region_s.append(dt)
+    dt = statistics.median(region_s)
+    timed_iters = args.steps * len(region_s)
     prof = eng.profile_read(reset=True)
     ns1 = eng.ns_stats()
     # untimed extra pass with every phase instrumented, for the per-phase breakdown
@@ -229,42 +245,63 @@ def main():
             phases.pop("eig_omega2", None)
         hot = ("eig_omega", "eig_L")
 
-        def per_iter(ph):   # hot phases were timed over the timed region, the others over the extra pass
-            return phases[ph]["ms_per_launch"] * phases[ph]["launches"] / (args.steps if ph in hot else extra_iters)
+        def per_iter(ph):   # hot phases were timed over the timed regions, the others over the extra pass
+            return phases[ph]["ms_per_launch"] * phases[ph]["launches"] / (timed_iters if ph in hot else extra_iters)
 
         dom = max(phases, key=per_iter)
         omega_ns = (args.eig == _lib.EIG_NEWTON_SCHULZ) or (args.eig == _lib.EIG_AUTO and not eig_jacobi)
         bound, amount, unit = phase_model(dom, reg, Kl, p, latent, eig_jacobi, omega_ns)
-        t64 = (p + 63) // 64
-        ns_kernel = "k_symm_dl" if (p % 2 == 0 and (t64 * (t64 + 1) // 2 * Kl > 400 or p >= 384)) else "k_symm_tn"
-        kernel_name = {"eig_omega": ns_kernel + " (Newton-Schulz product)" if omega_ns else
+        # what the library dispatched in its last matrix-function step (ggl_ns_stats), not a copy of its rules
+        parts, variant = ns1["last_parts"], ns1["last_variant"]
+        ns_kernel = VARIANT_NAMES.get(variant, f"product-kernel variant {variant}")
+        kernel_name = {"eig_omega": ns_kernel + " -- Newton-Schulz product" if omega_ns else
                        ("k_jacobi" if eig_jacobi else "rocsolver_dsyevd (library, many kernels)"),
                        "theta": "k_theta_ggl" if reg == "GGL" else ("k_theta_fgl" if reg == "FGL" else "k_theta_sgl"),
                        "recon_omega": "k_recon", "recon_L": "k_recon", "form_W": "k_form_W",
                        "dual": "k_dual_update", "eig_L": "k_jacobi" if eig_jacobi else "rocsolver_dsyevd"}.get(dom, dom)
         sec = phases[dom]["ms_per_launch"] * 1e-3
+        step_amount = None
         if dom == "eig_L" and omega_ns and ns1["rank_launches"] > ns0["rank_launches"]:
             # L-step by sign Newton-Schulz: the phase is (2n+1) symmetric products of K p^3 flop each
             launches = ns1["rank_launches"] - ns0["rank_launches"]
-            kernel_name = ns_kernel + " (sign Newton-Schulz product, L-step)"
+            kernel_name = ns_kernel + " -- sign Newton-Schulz product, L-step"
             bound, unit = "mfma", "TFLOP/s"
             amount = 1.0 * Kl * p ** 3
             sec = phases[dom]["ms_per_launch"] * phases[dom]["launches"] * 1e-3 / launches
             phases[dom] = {"ms_per_launch": sec * 1e3, "launches": launches}
+            step_amount = amount * launches / timed_iters
         if dom == "eig_omega" and omega_ns:
             # the Omega-step's launches differ in size (a pair launch carries two products): average over
             # the step = algorithmic flop of all its launches / their total duration (HIP events)
             units = ns1["units"] - ns0["units"]
             launches = ns1["launches"] - ns0["launches"]
             amount = units * 1.0 * Kl * p ** 3 / launches
+            step_amount = units * 1.0 * Kl * p ** 3 / timed_iters
         if bound == "hbm":
-            achieved, peak = amount / sec / 1e9, HBM_PEAK_GBS
+            achieved, peak, scale = amount / sec / 1e9, HBM_PEAK_GBS, 1e9
         else:
-            achieved, peak = amount / sec / 1e12, FP64_MFMA_PEAK_TF
+            achieved, peak, scale = amount / sec / 1e12, FP64_MFMA_PEAK_TF, 1e12
+        if step_amount is None:
+            step_amount = amount * phases[dom]["launches"] / (timed_iters if dom in hot else extra_iters)
         its = args.steps / dt
-        # the committed rocprofv3 / PMC summaries are of the default command only
-        profiled_cfg = (args.workload == "ggl_K32_p500" and args.eig == 0 and not os.environ.get("GGL_NS_MODE"))
         iter_bytes = (120.0 if latent else 72.0) * Kl * p * p          # SURVEY.md 8(d), per GPU
+        default_cfg = (args.workload == "ggl_K32_p500" and args.eig == 0 and not args.opt)
+        roof = {"kernel": kernel_name, "phase": dom, "launches_per_step": phases[dom]["launches"] / timed_iters,
+                "bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+                # the same algorithmic amount against the WHOLE iteration's wall time (everything that is not this
+                # phase counts as zero work): the figure a reader can check against ms_per_step alone
+                "frac_of_step": step_amount / (dt / args.steps) / scale / peak,
+                "traffic": None,      # HBM counters need separate rocprofv3 --pmc passes: see profiled_* below
+                "ms_per_launch": phases[dom]["ms_per_launch"],
+                "concurrent_launch_sequences": parts if dom in hot else 1,
+                "note": "achieved = algorithmic amount of the phase / its elapsed time (HIP events on the ctx stream, "
+                        "all timed regions); ms_per_launch = that time / the phase's kernel launches"
+                        + ("; the parts of the batch run their launch sequences concurrently, so one kernel's own "
+                           "duration in a rocprofv3 trace is about concurrent_launch_sequences x ms_per_launch"
+                           if (dom in hot and parts > 1) else "")}
+        if default_cfg:
+            # labelled as what they are: numbers of the committed rocprofv3 runs of this command, not of this run
+            roof.update(committed_profile(ns_kernel.split("<")[0]))
         out = {
             "metric": "ADMM iters/sec on (K=32,p=500) GGL at 1/2/4/8 GPUs; eigh HBM GB/s vs peak", "value": its, "unit": "ADMM iters/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -274,20 +311,12 @@ def main():
                                    f"rho0=1 update_rho, fixed iteration count",
                        "sharding": f"K-slabs of {Kl} per GPU" if distributed else "single GPU",
                        "omega_step": "lds_jacobi" if eig_jacobi else ("newton_schulz_fp64_mfma" if omega_ns
-                                                                         else "rocsolver_dsyevd+mfma_recon")},
-            "roofline": {"kernel": kernel_name, "phase": dom, "launches_per_step": phases[dom]["launches"] / args.steps,
-                         "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": pmc_traffic(kernel_name) if profiled_cfg else None,
-                         "ms_per_launch": phases[dom]["ms_per_launch"],
-                         "rocprof_kernel_avg_ms": rocprof_kernel_avg_ms(kernel_name) if profiled_cfg else None,
-                         "concurrent_launch_sequences": 2 if (omega_ns and dom in ("eig_omega", "eig_L") and Kl >= 16
-                                                              and 600 <= t64 * (t64 + 1) // 2 * Kl <= 2048) else 1,
-                         "note": ("ms_per_launch = elapsed time of the phase / its kernel launches; at this size two parts "
-                                  "of the batch run their launch sequences concurrently on two streams, so a single "
-                                  "kernel's own duration (rocprof_kernel_avg_ms, rocprofv3) is about "
-                                  "concurrent_launch_sequences x ms_per_launch") if (omega_ns and dom == "eig_omega"
-                                                                                        and Kl >= 16 and 600 <= t64 * (t64 + 1) // 2 * Kl <= 2048)
-                         else "elapsed time of the phase / its kernel launches"},
+                                                                         else "rocsolver_dsyevd+mfma_recon"),
+                       "options": options or None},
+            "timed_regions": {"count": len(region_s), "steps_each": args.steps, "statistic": "median",
+                              "ms_per_step_min": min(region_s) / args.steps * 1e3,
+                              "ms_per_step_max": max(region_s) / args.steps * 1e3},
+            "roofline": roof,
             "iteration_hbm_roofline": {"algorithmic_bytes": iter_bytes, "achieved_GBs": its * iter_bytes / 1e9,
                                        "frac": its * iter_bytes / 1e9 / HBM_PEAK_GBS},
             "phases_ms": {ph: round(v["ms_per_launch"], 4) for ph, v in phases.items()},
@@ -298,10 +327,13 @@ def main():
                               "lstep_retries": ns1["rank_retries"] - ns0["rank_retries"],
                               "lstep_eigh_fallbacks": ns1["rank_fallbacks"] - ns0["rank_fallbacks"],
                               "speculative_omega_steps": ns1["spec_calls"] - ns0["spec_calls"],
-                              "speculation_misses": ns1["spec_misses"] - ns0["spec_misses"]} if omega_ns else None,
+                              "speculation_misses": ns1["spec_misses"] - ns0["spec_misses"],
+                              "prelaunched_chains_dropped": ns1["pre_dropped"] - ns0["pre_dropped"],
+                              "end_of_iteration_poll_timeouts": ns1["spin_timeouts"] - ns0["spin_timeouts"]}
+            if omega_ns else None,
         }
         if not distributed and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, reg, l1, l2, latent, mu1, args.cpu_iters)
+            out["cpu_baseline"] = cpu_baseline(S, reg, l1, l2, latent, mu1, args.cpu_iters, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if distributed:
         torch.distributed.barrier()

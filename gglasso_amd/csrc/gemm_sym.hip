@@ -314,8 +314,12 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
                                                  double* __restrict__ C, double* __restrict__ C2,
                                                  const double* __restrict__ E, const double* __restrict__ coef, int K,
                                                  int p, const double* __restrict__ A1, const double* __restrict__ B1,
-                                                 double* __restrict__ C1, int K1, double* __restrict__ maxdev)
+                                                 double* __restrict__ C1, int K1, double* __restrict__ maxdev,
+                                                 double* __restrict__ rowpart, double* __restrict__ fropart)
 {
+    // rowpart / fropart != null: the launch also leaves what a spectral bound of C needs, with no pass over C --
+    // rowpart[k][s][i] = sum over the columns of tile-column s of |C[i][.]| (summed over s: the row sums of |C|) and
+    // fropart[k][tile] = the tile's share of |C|_F^2 (mirror included), every slot written by exactly one workgroup
     constexpr int WM = BM / 2, WN = BM / 2, TI = BM / 32, TJ = BM / 32;
     constexpr int RPI = 128 / BM;                        // slab rows per DMA instruction (1 KiB)
     constexpr int LPR = 64 / RPI;                        // lanes per row
@@ -328,6 +332,7 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
     const int T = (p + BM - 1) / BM;
     int k, b;
     if (!decode_block_xcd(T * (T + 1) / 2, K + K1, k, b)) return;
+    const int blockTile = b;
     const bool second = k >= K;
     const int kk = second ? k - K : k;
     int I = 0;
@@ -433,7 +438,8 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
                 const int col = wc + tj * 16 + (lane & 15);
                 const int gi = I0 + row, gj = J0 + col;
                 double v = cAcc * acc[ti][tj][r];
-                if (gi < p && gj < p && (I != J || gi <= gj)) {
+                const bool keep = gi < p && gj < p && (I != J || gi <= gj);
+                if (keep) {
                     if (gi == gj) v += cI;
                     const double e0 = Ek ? Ek[(size_t)gi * p + gj] : 0.0;
                     v += cE * e0;
@@ -445,15 +451,55 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
                         if (C2k) C2k[(size_t)gj * p + gi] = c2val(dC, v, dE, e0);
                     }
                 }
-                if (I != J && ABL != 1) smem[row * BM + (col ^ row)] = v;        // XOR-swizzled BM x BM mirror tile
+                // XOR-swizzled BM x BM tile in LDS: the mirror pass of an off-diagonal tile reads it transposed; with
+                // bound partials every tile is staged (entries that are not stored count as zero)
+                if ((I != J || rowpart) && ABL != 1) smem[row * BM + (col ^ row)] = (rowpart && !keep) ? 0.0 : v;
             }
     if (maxdev) {
         dev = wave_max(dev);
         if (lane == 0 && dev > 0.0)
             atomicMax(reinterpret_cast<unsigned long long*>(maxdev + k), (unsigned long long)__double_as_longlong(dev));
     }
+    if ((I != J || rowpart) && ABL != 1) __syncthreads();
+    if (rowpart && ABL != 1 && tid < 2 * BM) {
+        // threads 0..BM-1: row t of the staged tile; threads BM..2BM-1 (off-diagonal tiles): column t of it, i.e. row
+        // J0+t of the mirrored tile.  A diagonal tile holds its upper triangle U only: row t of the full symmetric tile
+        // is row t of U plus column t of U minus the diagonal entry.
+        const int t = tid & (BM - 1);
+        const bool second = tid >= BM;
+        const size_t slot_stride = (size_t)p;
+        double rs = 0.0, sq = 0.0;
+        if (!second) {
+#pragma unroll 8
+            for (int c = 0; c < BM; ++c) { const double x = smem[t * BM + (c ^ t)]; rs += fabs(x); sq += x * x; }
+        }
+        if (second || I == J) {
+            double cs = 0.0;
+#pragma unroll 8
+            for (int r = 0; r < BM; ++r) cs += fabs(smem[r * BM + (t ^ r)]);
+            if (I == J) {
+                if (!second) {
+                    const double dg = smem[t * BM];
+                    rs = (rs + cs) - fabs(dg);
+                    sq = 2.0 * sq - dg * dg;
+                }
+            } else {
+                rs = cs;
+            }
+        } else {
+            sq *= 2.0;            // off-diagonal tile: its mirror has the same squares
+        }
+        if (I != J || !second) {
+            const int T2 = (p + BM - 1) / BM;
+            const int slot = second ? I : J, gi = (second ? J0 : I0) + t;
+            if (gi < p) rowpart[((size_t)k * T2 + slot) * slot_stride + gi] = rs;
+        }
+        if (tid < 64) {                      // wave 0 holds the BM row threads
+            sq = wave_sum((tid < BM) ? sq : 0.0);
+            if (tid == 0) fropart[(size_t)k * (T * (T + 1) / 2) + blockTile] = sq;
+        }
+    }
     if (I != J && ABL != 1) {
-        __syncthreads();
         for (int e = tid; e < BM * BM; e += 256) {
             const int a = e / BM, c = e % BM;   // out[J0+a][I0+c] = tile[c][a]
             if (J0 + a < p && I0 + c < p) {
@@ -471,9 +517,9 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
 
 static void launch_dl(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                       const double* coef, int K, int p, const double* A1, const double* B1, double* C1, int K1,
-                      double* maxdev, int dl_cfg = 0)
+                      double* maxdev, int dl_cfg = 0, double* rowpart = nullptr, double* fropart = nullptr)
 {
-#define GGL_DL(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev)
+#define GGL_DL(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart)
     if (dl_cfg == 4) {
         const int T32 = (p + 31) / 32;
         const dim3 grid(xcd_grid(T32 * (T32 + 1) / 2, K + K1));
@@ -761,8 +807,19 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
     }
 }
 
+// tile edge of the direct-to-LDS kernel a variant resolves to, or 0 if the variant (or an odd p) runs the register-staged
+// kernel, which does not produce bound partials
+int symm_bounds_tile(int K, int p, int variant)
+{
+    if (variant < 0) variant = symm_auto_variant(K, p);
+    if ((p & 1) != 0 || p < 2) return 0;
+    if (variant == 20) return 32;
+    if (variant >= 16 && variant <= 19) return 64;
+    return 0;
+}
+
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
-                 const double* coef, int K, int p, int variant, double* maxdev)
+                 const double* coef, int K, int p, int variant, double* maxdev, double* rowpart, double* fropart)
 {
     if (variant < 0) variant = symm_auto_variant(K, p);
 #define GGL_TN(BM, BK, WM, WN, LM) \
@@ -770,7 +827,7 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
     switch (variant) {
         case 16: case 17: case 18: case 19: case 20: case 21:
             if ((p & 1) == 0 && p >= 2) {
-                launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16);
+                launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16, rowpart, fropart);
                 break;
             }
             if (variant == 20) GGL_TN(32, 32, 16, 16, true);

@@ -73,6 +73,15 @@ struct ggl_ctx {
     static constexpr int MAX_PARTS = 4;
     hipStream_t streamx[MAX_PARTS - 1] = {};   // extra streams: the parts of the batch run their
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS - 1] = {};   // Newton-Schulz launch sequences concurrently
+    // Pipelining across iterations: right after an iteration has been validated, ggl_admm_step launches the NEXT iteration's
+    // (speculative) Omega-step chain for the same beta before it returns, so the GPU works through the host's round trip
+    // (norms -> rho rule -> next call).  The chain only writes scratch and Omega[cur^1]; it is consumed by the next call if
+    // beta is unchanged and dropped otherwise (every other entry point drops it first).
+    bool pipeline = true, pre_valid = false, pre_spec_pending = false;
+    double* pre_beta = nullptr;                // host: beta the pre-launched chain was built for (K)
+    long long pre_launched = 0, pre_dropped = 0;
+    bool fused_start = true;                   // speculative step: first step's start matrix as 2nd output of the B' launch
+    bool fused_bounds = true;                  // spectral-bound partials from the epilogue of the B' launch (GGL_OPT_FUSED_BOUNDS)
     bool theta_flat = true;                    // GGL Theta-step: per-element kernel when the state is symmetric
     bool state_symmetric = true;               // X and L exactly symmetric (checked when the state is set)
     // speculative Omega-step: the schedule is built from the PREVIOUS iteration's spectral bounds (inflated) and the
@@ -108,6 +117,11 @@ struct ggl_ctx {
     int ext_L = -1;                            // -1: ggl_ext_setup not called
     double* snapT = nullptr;                   // per-instance snapshots of Theta (model selection), lazy
     double* nbrow = nullptr;                   // [K][p] row abs-sums of B' (Collatz-Wielandt weight vector)
+    // bound partials written by the epilogue of the B' product launch (no norm pass over B'): row sums per tile column,
+    // Frobenius shares per tile, block maxima of the row sums; merge cells of the Collatz-Wielandt kernel
+    double *rowpart = nullptr, *fropart = nullptr, *infpart = nullptr;
+    unsigned long long* cwmax = nullptr;
+    unsigned* cwcnt = nullptr;
     double* nbpart = nullptr;                  // [K][blocks][2] + [K][blocks]: norm / Collatz-Wielandt partials
     double *maxdev = nullptr, *maxdev_h = nullptr;   // [K] residual of the sign iteration
     bool rank_ns = false;                            // L-step by sign Newton-Schulz (else eigendecomposition)
@@ -218,6 +232,14 @@ static int ctx_alloc(ggl_ctx* c)
         const size_t nbl = 3 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);   // + Collatz-Wielandt maxima
         HIPCHK(hipMalloc(&c->nbrow, (size_t)c->K * c->p * sizeof(double)));
         HIPCHK(hipMalloc(&c->nbpart, nbl));
+        const size_t t32 = (c->p + 31) / 32;
+        HIPCHK(hipMalloc(&c->rowpart, (size_t)c->K * t32 * c->p * sizeof(double)));
+        HIPCHK(hipMalloc(&c->fropart, (size_t)c->K * (t32 * (t32 + 1) / 2) * sizeof(double)));
+        HIPCHK(hipMalloc(&c->infpart, (size_t)c->K * bound_rows_blocks(c->p) * sizeof(double)));
+        HIPCHK(hipMalloc(&c->cwmax, c->K * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&c->cwcnt, c->K * sizeof(unsigned)));
+        HIPCHK(hipMemsetAsync(c->cwmax, 0, c->K * sizeof(unsigned long long), c->stream));
+        HIPCHK(hipMemsetAsync(c->cwcnt, 0, c->K * sizeof(unsigned), c->stream));
         HIPCHK(hipMalloc(&c->cuse, c->K * sizeof(double)));
         HIPCHK(hipHostMalloc(&c->cuse_h, c->K * sizeof(double)));
         // the words the host polls / reads right after the poll: explicitly coherent (fine-grained) pinned memory, so a
@@ -230,6 +252,7 @@ static int ctx_alloc(ggl_ctx* c)
         memset(c->spec_flag_h, 0, ggl_ctx::MAX_PARTS * sizeof(int));
         c->spec_c = (double*)malloc(c->K * sizeof(double));
         c->spec_beta = (double*)malloc(c->K * sizeof(double));
+        c->pre_beta = (double*)malloc(c->K * sizeof(double));
         HIPCHK(hipMalloc(&c->maxdev, c->K * sizeof(double)));
         HIPCHK(hipHostMalloc(&c->maxdev_h, c->K * sizeof(double)));
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -242,8 +265,12 @@ static int ctx_alloc(ggl_ctx* c)
     return GGL_OK;
 }
 
+static int drop_prelaunch(ggl_ctx* c);
+
 static int set_option(ggl_ctx* c, int opt, double v)
 {
+    int rcd = drop_prelaunch(c);
+    if (rcd) return rcd;
     switch (opt) {
         case GGL_OPT_SPECULATE: c->spec_enable = v != 0.0; break;
         case GGL_OPT_SPEC_FACTOR:
@@ -265,6 +292,9 @@ static int set_option(ggl_ctx* c, int opt, double v)
             c->symm_variant = (int)v;
             break;
         case GGL_OPT_SPIN_WAIT: c->spin_wait = v != 0.0; break;
+        case GGL_OPT_FUSED_BOUNDS: c->fused_bounds = v != 0.0; break;
+        case GGL_OPT_PIPELINE: c->pipeline = v != 0.0; break;
+        case GGL_OPT_FUSED_START: c->fused_start = v != 0.0; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
     }
     c->spec_have = false;      // a schedule built under other settings is not reused
@@ -291,6 +321,9 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_PARTS_MAX_TILES: *value = (double)c->parts_max_tiles; break;
         case GGL_OPT_SYMM_VARIANT: *value = c->symm_variant; break;
         case GGL_OPT_SPIN_WAIT: *value = c->spin_wait; break;
+        case GGL_OPT_FUSED_BOUNDS: *value = c->fused_bounds; break;
+        case GGL_OPT_PIPELINE: *value = c->pipeline; break;
+        case GGL_OPT_FUSED_START: *value = c->fused_start; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
     }
     return GGL_OK;
@@ -304,7 +337,9 @@ static void dev_env_options(ggl_ctx* c)
         {"GGL_SPECULATE", GGL_OPT_SPECULATE}, {"GGL_SPEC_FACTOR", GGL_OPT_SPEC_FACTOR}, {"GGL_NS_MODE", GGL_OPT_NS_MODE},
         {"GGL_NS_DEGREES", GGL_OPT_NS_DEGREES}, {"GGL_THETA_FLAT", GGL_OPT_THETA_FLAT}, {"GGL_RANK_EIG", GGL_OPT_RANK_EIG},
         {"GGL_TWO_STREAM", GGL_OPT_PARTS}, {"GGL_PARTS_MAX_TILES", GGL_OPT_PARTS_MAX_TILES},
-        {"GGL_SYMM_VARIANT", GGL_OPT_SYMM_VARIANT}, {"GGL_SPIN_WAIT", GGL_OPT_SPIN_WAIT}};
+        {"GGL_SYMM_VARIANT", GGL_OPT_SYMM_VARIANT}, {"GGL_SPIN_WAIT", GGL_OPT_SPIN_WAIT},
+        {"GGL_FUSED_BOUNDS", GGL_OPT_FUSED_BOUNDS}, {"GGL_PIPELINE", GGL_OPT_PIPELINE},
+        {"GGL_FUSED_START", GGL_OPT_FUSED_START}};
     for (const auto& t : tab)
         if (const char* v = getenv(t.name)) (void)set_option(c, t.opt, atof(v));
     if (const char* v = getenv("GGL_ROCSOLVER_SYEVJ")) c->use_syevj = atoi(v) != 0;
@@ -371,12 +406,15 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
                       c->Lam[1], c->X1};
     for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize})
         if (b) (void)hipFree(b);
+    for (void* b : {(void*)c->rowpart, (void*)c->fropart, (void*)c->infpart, (void*)c->cwmax, (void*)c->cwcnt})
+        if (b) (void)hipFree(b);
     if (c->spec_flag) (void)hipFree(c->spec_flag);
     if (c->cuse_h) (void)hipHostFree(c->cuse_h);
     if (c->seq_h) (void)hipHostFree(c->seq_h);
     if (c->spec_flag_h) (void)hipHostFree(c->spec_flag_h);
     free(c->spec_c);
     free(c->spec_beta);
+    free(c->pre_beta);
     if (c->maxdev_h) (void)hipHostFree(c->maxdev_h);
     if (c->coef_h) (void)hipHostFree(c->coef_h);
     if (c->bounds_h) (void)hipHostFree(c->bounds_h);
@@ -407,6 +445,20 @@ extern "C" int ggl_ctx_sync(ggl_ctx* c)
     return GGL_OK;
 }
 
+// A pre-launched Omega-step chain (see ggl_ctx::pipeline) uses W, the Newton-Schulz scratch and Omega[cur^1]; whoever
+// touches the state or that scratch outside ggl_admm_step waits for it and forgets it.
+static int drop_prelaunch(ggl_ctx* c)
+{
+    if (!c->pre_valid) return GGL_OK;
+    c->pre_valid = false;
+    c->pre_dropped += 1;
+    c->spec_have = false;          // the bounds of a chain that was never validated are not carried over
+    HIPCHK(hipStreamSynchronize(c->stream));      // the chain's parts were joined into the main stream when it was launched
+    for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) c->spec_flag_h[h] = 0;
+    return GGL_OK;
+}
+#define DROP_PRE(c) do { int rc_ = drop_prelaunch(c); if (rc_) return rc_; } while (0)
+
 extern "C" void* ggl_device_ptr(ggl_ctx* c, int which)
 {
     if (!c) return nullptr;
@@ -431,6 +483,7 @@ extern "C" int ggl_set_S(ggl_ctx* c, const double* S)
     ARGCHK(c && S, "ctx, S");
     c->spec_have = false;
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     HIPCHK(hipMemcpyAsync(c->S, S, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return GGL_OK;
@@ -443,6 +496,7 @@ extern "C" int ggl_set_state(ggl_ctx* c, const double* Omega, const double* Thet
     ARGCHK(c, "ctx");
     c->spec_have = false;      // bounds of another iterate say nothing about this one
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const size_t nb = c->n * sizeof(double);
     if (Omega) HIPCHK(hipMemcpyAsync(c->Om[c->cur], Omega, nb, hipMemcpyHostToDevice, c->stream));
     if (Theta) HIPCHK(hipMemcpyAsync(c->Theta, Theta, nb, hipMemcpyHostToDevice, c->stream));
@@ -469,6 +523,7 @@ extern "C" int ggl_get_state(ggl_ctx* c, double* Omega, double* Theta, double* L
 {
     ARGCHK(c, "ctx");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const size_t nb = c->n * sizeof(double);
     if (Omega) HIPCHK(hipMemcpyAsync(Omega, c->Om[c->cur], nb, hipMemcpyDeviceToHost, c->stream));
     if (Theta) HIPCHK(hipMemcpyAsync(Theta, c->Theta, nb, hipMemcpyDeviceToHost, c->stream));
@@ -582,13 +637,15 @@ static int upload_par(ggl_ctx* c, int slot, const double* vals, double scalar, d
 // ---------------------------------------------------------------------------------------------
 static constexpr int GGL_SPIN_LIMIT_MS = 2000;
 static constexpr int GGL_SPEC_RETRY = 1;     // internal: a speculative step failed validation, repeat it
-static int omega_step(ggl_ctx* c, int latent, CopySegs* pending = nullptr, bool allow_spec = false);
+static constexpr int GGL_NOT_LAUNCHED = 2;   // internal: omega_step(only_spec) found no speculative schedule and launched nothing
+static int omega_step(ggl_ctx* c, int latent, CopySegs* pending = nullptr, bool allow_spec = false, bool only_spec = false);
 
 extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* nk)
 {
     ARGCHK(c, "ctx");
     ARGCHK(rho > 0, "rho must be positive");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     // the previous step's pinned parameters are consumed: every step ends with a stream sync
     CopySegs sg;
     int rc = upload_par(c, 0, nk, 1.0, rho, &sg);   // beta_k = nk/rho    (admm_solver.py:180,184)
@@ -601,6 +658,7 @@ extern "C" int ggl_step_omega_spec(ggl_ctx* c, double rho, int latent, const dou
     ARGCHK(c, "ctx");
     ARGCHK(rho > 0, "rho must be positive");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     CopySegs sg;
     int rc = upload_par(c, 0, nk, 1.0, rho, &sg);
     if (rc) return rc;
@@ -609,8 +667,9 @@ extern "C" int ggl_step_omega_spec(ggl_ctx* c, double rho, int latent, const dou
 }
 
 // Omega-step with beta_k in parameter slot 0 (already on the device, or part of the pending transfer)
-static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec)
+static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec, bool only_spec)
 {
+    // only_spec: launch the chain only if it can run speculatively (no host synchronisation inside); else do nothing
     int rc;
     const double* beta = c->par;
     const int nxt = c->cur ^ 1;
@@ -668,13 +727,14 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 const int prc = ns_plan(c->cuse_h + k0, c->par_h + k0, Kh[h], c->coef_h + h * region,
                                         start_base_h + 5 * k0, &plans[h], c->ns_force, c->ns_degrees);
                 spec = (prc == 0) && !plans[h].stable;
-                for (int k = k0; spec && k < k0 + Kh[h]; ++k) {
+                for (int k = k0; spec && c->fused_start && k < k0 + Kh[h]; ++k) {
                     // the bound is assumed known, so the start is a fixed combination of A' and B': {dI, dC, dE} of B' launch
                     fused[h] = ns_fused_start(plans[h], start_base_h + 5 * (size_t)k, c->nsYP[1] + k0 * pp, c->nsT + k0 * pp,
                                               nh > 1 ? c->n : (size_t)K * pp, pre + NS_SLOT(K) + (size_t)k * NS_NCOEF + 3);
                 }
             }
         }
+        if (only_spec && !spec) return GGL_NOT_LAUNCHED;
         if (nh > 1) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
             for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
@@ -711,16 +771,30 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             if (h == 0) { PE(c, GGL_PH_FORM_W); PB(c, GGL_PH_EIG_OMEGA); }
             double* Ap = c->nsYP[0] + k0 * pp;
             double* Bp = c->nsYP[0] + c->n + k0 * pp;
-            ns_prepare(sh, pre_d + NS_NCOEF * (size_t)k0, pre_d + NS_SLOT(K) + NS_NCOEF * (size_t)k0, c->W + k0 * pp, Ap, Bp, Kh[h], c->p,
-                       var_parts, spec ? fused[h] : nullptr);
             // lambda_max(A')^2 = lambda_max(B') <= min(|B'|_inf, |B'|_F, Collatz-Wielandt ratio), reduced on the
-            // device; only the K_part bounds travel to the (pinned, device-visible) host array
-            double* nb2 = c->nbpart + 2 * (size_t)k0 * nbb;
-            double* nbc = c->nbpart + 2 * (size_t)K * nbb + (size_t)k0 * nbb;
-            launch_norm_bounds(sh, Bp, Kh[h], c->p, nb2, c->nbrow + (size_t)k0 * c->p);
-            launch_cw_bounds(sh, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p, nbc);
-            launch_bound_final(sh, nb2, nbc, nbb, Kh[h], c->bounds_h + k0, 0, spec ? c->cuse + k0 : nullptr,
-                               spec ? c->spec_flag + h : nullptr, spec ? c->spec_flag_h + h : nullptr);
+            // device; only the K_part bounds travel to the (pinned, device-visible) host array.  Where the B' launch is
+            // the direct-to-LDS kernel, its epilogue leaves the row sums and Frobenius shares of B' behind (no norm pass
+            // over B'), and the Collatz-Wielandt pass finishes the bound itself.
+            const int btile = c->fused_bounds ? symm_bounds_tile(Kh[h], c->p, var_parts) : 0;
+            const int bT = btile ? (c->p + btile - 1) / btile : 0;
+            double* rowp = btile ? c->rowpart + (size_t)k0 * bT * c->p : nullptr;
+            double* frop = btile ? c->fropart + (size_t)k0 * (bT * (bT + 1) / 2) : nullptr;
+            ns_prepare(sh, pre_d + NS_NCOEF * (size_t)k0, pre_d + NS_SLOT(K) + NS_NCOEF * (size_t)k0, c->W + k0 * pp, Ap, Bp, Kh[h], c->p,
+                       var_parts, spec ? fused[h] : nullptr, rowp, frop);
+            if (btile) {
+                const int nib = bound_rows_blocks(c->p);
+                launch_bound_rows(sh, rowp, bT, Kh[h], c->p, c->nbrow + (size_t)k0 * c->p, c->infpart + (size_t)k0 * nib);
+                launch_cw_final(sh, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p, c->infpart + (size_t)k0 * nib, frop,
+                                bT * (bT + 1) / 2, c->cwmax + k0, c->cwcnt + k0, c->bounds_h + k0, spec ? c->cuse + k0 : nullptr,
+                                spec ? c->spec_flag : nullptr, spec ? c->spec_flag_h : nullptr, h);
+            } else {
+                double* nb2 = c->nbpart + 2 * (size_t)k0 * nbb;
+                double* nbc = c->nbpart + 2 * (size_t)K * nbb + (size_t)k0 * nbb;
+                launch_norm_bounds(sh, Bp, Kh[h], c->p, nb2, c->nbrow + (size_t)k0 * c->p);
+                launch_cw_bounds(sh, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p, nbc);
+                launch_bound_final(sh, nb2, nbc, nbb, Kh[h], c->bounds_h + k0, 0, spec ? c->cuse + k0 : nullptr,
+                                   spec ? c->spec_flag + h : nullptr, spec ? c->spec_flag_h + h : nullptr);
+            }
             if (spec) {
                 ns_run(sh, plans[h], c->coef + h * region, start_base_d + 5 * k0, c->W + k0 * pp, c->nsYP[0] + k0 * pp,
                        c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kh[h], c->p,
@@ -817,6 +891,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         c->cur = nxt;
         return GGL_OK;
     }
+    if (only_spec) return GGL_NOT_LAUNCHED;
     launch_copy_small(c->stream, first);
     PB(c, GGL_PH_FORM_W);
     launch_form_W(c->stream, c->W, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->K, c->p);
@@ -984,8 +1059,19 @@ static int rank_step(ggl_ctx* c)
     return eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)K, -1, GGL_PH_RECON_L);
 }
 
+static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double lambda2, int reg, int latent,
+                                const double* mu1, int groupsq_ready, double out_norms[5]);
+
 extern "C" int ggl_step_finish(ggl_ctx* c, double rho, double lambda1, double lambda2, int reg, int latent,
                                const double* mu1, int groupsq_ready, double out_norms[5])
+{
+    ARGCHK(c, "ctx");
+    DROP_PRE(c);
+    return ggl_step_finish_impl(c, rho, lambda1, lambda2, reg, latent, mu1, groupsq_ready, out_norms);
+}
+
+static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double lambda2, int reg, int latent,
+                                const double* mu1, int groupsq_ready, double out_norms[5])
 {
     ARGCHK(c && out_norms, "ctx, out_norms");
     ARGCHK(rho > 0, "rho must be positive");
@@ -1085,14 +1171,43 @@ extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lamb
     CopySegs sg;
     int rc = upload_par(c, 0, nk, 1.0, rho, &sg);   // beta_k = nk/rho    (admm_solver.py:180,184)
     if (rc) return rc;
-    rc = omega_step(c, latent, &sg, /*allow_spec=*/true);
+    bool have = c->pre_valid && !latent;
+    for (int k = 0; have && k < c->K; ++k) have = (c->par_h[k] == c->pre_beta[k]);
+    if (have) {
+        // the chain launched at the end of the previous call was built for exactly this beta: take it over
+        c->pre_valid = false;
+        c->cur ^= 1;
+        c->spec_pending = c->pre_spec_pending;
+    } else {
+        // (a chain for another beta may still be running: the new one follows it on the same streams, zeroes its
+        // validation flags again and overwrites everything it wrote)
+        if (c->pre_valid) { c->pre_valid = false; c->pre_dropped += 1; c->spec_have = false; }
+        rc = omega_step(c, latent, &sg, /*allow_spec=*/true);
+        if (rc) return rc;
+    }
+    rc = ggl_step_finish_impl(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
+    if (rc == GGL_SPEC_RETRY) {
+        // the speculative schedule did not cover this iteration's spectrum: same step again, bounds first
+        rc = omega_step(c, latent, nullptr, false);
+        if (rc) return rc;
+        rc = ggl_step_finish_impl(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
+    }
+    if (rc != GGL_OK || !c->pipeline || latent || !c->omega_ns || c->prof_on == 1) return rc;
+    // Keep the GPU busy through the host's round trip: if the reference's rho rule (admm_solver.py:227-233) leaves rho
+    // alone for these residuals, the next call will ask for the same beta -- launch its Omega-step chain now.
+    const double r_t = std::sqrt(out_norms[3]), s_t = rho * std::sqrt(out_norms[4]);
+    if (r_t >= 10.0 * s_t || s_t >= 10.0 * r_t) return GGL_OK;
+    const int cur0 = c->cur;
+    rc = omega_step(c, 0, nullptr, /*allow_spec=*/true, /*only_spec=*/true);     // beta is in parameter slot 0 already
+    if (rc == GGL_NOT_LAUNCHED) return GGL_OK;
     if (rc) return rc;
-    rc = ggl_step_finish(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
-    if (rc != GGL_SPEC_RETRY) return rc;
-    // the speculative schedule did not cover this iteration's spectrum: same step again, bounds first
-    rc = omega_step(c, latent, nullptr, false);
-    if (rc) return rc;
-    return ggl_step_finish(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
+    c->cur = cur0;                               // Omega_t stays the current iterate until the chain is taken over
+    c->pre_spec_pending = c->spec_pending;
+    c->spec_pending = false;
+    c->pre_valid = true;
+    c->pre_launched += 1;
+    memcpy(c->pre_beta, c->par_h, c->K * sizeof(double));
+    return GGL_OK;
 }
 
 // ---- K independent single problems with their own rho / lambda1 (batched lambda path) ----------
@@ -1102,6 +1217,7 @@ extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* l
     ARGCHK(c && rho && lambda1 && out_norms, "ctx, rho, lambda1, out_norms");
     ARGCHK(!latent || mu1, "latent needs mu1");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const int K = c->K;
     for (int k = 0; k < K; ++k) ARGCHK(rho[k] > 0, "rho must be positive");
     double* h = c->par_h;
@@ -1202,6 +1318,7 @@ extern "C" int ggl_mgl_batch_step(ggl_ctx* c, int G, const double* rho, const do
     ARGCHK(!latent || mu1, "latent needs mu1");
     ARGCHK(c->state_symmetric, "the batched Theta-step needs exactly symmetric dual / latent start points");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const int K = c->K, Kp = K / G;
     if (reg == GGL_REG_GGL && Kp > GGL_FLAT_MAX_K)
         return fail(GGL_E_ARG, "batched GGL grid: %d instances per problem exceed the %d of the per-element Theta kernel", Kp,
@@ -1239,6 +1356,7 @@ extern "C" int ggl_scale_X_batch(ggl_ctx* c, const double* factor)
 {
     ARGCHK(c && factor, "ctx, factor");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     double* h = c->par_h + 5 * (size_t)c->K;
     memcpy(h, factor, c->K * sizeof(double));
     CopySegs sg;
@@ -1254,6 +1372,7 @@ extern "C" int ggl_get_state_k(ggl_ctx* c, int k, double* Omega, double* Theta, 
 {
     ARGCHK(c && k >= 0 && k < c->K, "ctx, k");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const size_t pp = (size_t)c->p * c->p, nb = pp * sizeof(double), off = (size_t)k * pp;
     if (Omega) HIPCHK(hipMemcpyAsync(Omega, c->Om[c->cur] + off, nb, hipMemcpyDeviceToHost, c->stream));
     if (Theta) HIPCHK(hipMemcpyAsync(Theta, c->Theta + off, nb, hipMemcpyDeviceToHost, c->stream));
@@ -1267,6 +1386,7 @@ extern "C" int ggl_scale_X(ggl_ctx* c, double factor)
 {
     ARGCHK(c, "ctx");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     launch_scale(c->stream, c->X, factor, c->n);
     HIPCHK(hipGetLastError());
     return GGL_OK;
@@ -1302,7 +1422,7 @@ extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[16])
     out[12] = c->last_parts;
     out[13] = c->last_variant;
     out[14] = c->ns_eigh_fallbacks;
-    out[15] = 0;
+    out[15] = c->pre_dropped;
     return GGL_OK;
 }
 
@@ -1354,6 +1474,7 @@ extern "C" int ggl_exit_checks_k(ggl_ctx* c, int latent, double* out /*(K,5)*/)
 {
     ARGCHK(c && out, "ctx, out");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const int K = c->K;
     const double* stacks[3] = {c->Om[c->cur], c->Theta, c->L};
     for (int i = 0; i < 3; ++i) {
@@ -1396,6 +1517,7 @@ extern "C" int ggl_snapshot_k(ggl_ctx* c, int k)
     ARGCHK(c, "ctx");
     ARGCHK(k >= 0 && k < c->K, "instance index");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const size_t pp = (size_t)c->p * c->p, nb = pp * sizeof(double);
     if (!c->snapT) {
         HIPCHK(hipMalloc(&c->snapT, c->n * sizeof(double)));
@@ -1410,6 +1532,7 @@ extern "C" int ggl_selection_stats(ggl_ctx* c, double* out)
     ARGCHK(c && out, "ctx, out");
     ARGCHK(c->snapT, "no snapshot taken (ggl_snapshot_k)");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const int K = c->K, p = c->p;
     const size_t kp = (size_t)K * p;
     const int nblk = elementwise_blocks(p);
@@ -1452,6 +1575,7 @@ extern "C" int ggl_objective(ggl_ctx* c, double lambda1, double lambda2, int reg
     ARGCHK(c && out, "ctx, out");
     ARGCHK(reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     // -log det Omega_k = -sum_m log phip(d_m): eigenvalues of the last Omega-step (ggl_helper.py:266-270);
     // the Newton-Schulz Omega-step has none, so there the eigenvalues of Omega itself are computed.
     const size_t kp = (size_t)c->K * c->p;
@@ -1498,6 +1622,7 @@ extern "C" int ggl_kkt_residual(ggl_ctx* c, double rho, double lambda1, double l
     ARGCHK(c && out, "ctx, out");
     ARGCHK(!latent || mu1, "latent needs mu1");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     double* Om = c->Om[c->cur];
     double* T1 = c->W;             // scratch
     double* T2 = c->Om[c->cur ^ 1]; // Omega_{t-1} is dead once the step's norms are out
@@ -1554,6 +1679,7 @@ extern "C" int ggl_ext_setup(ggl_ctx* c, const int* pk, const int* G, int L)
     ARGCHK(c && pk, "ctx, pk");
     ARGCHK(L >= 0 && (L == 0 || G), "G, L");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const int K = c->K, p = c->p;
     for (int k = 0; k < K; ++k) ARGCHK(pk[k] >= 1 && pk[k] <= p, "1 <= p_k <= p (the padded dimension of the ctx)");
     // the checks of helper/ext_admm_helper.py:82-102 (check_G) plus: no entry listed twice (the groups are then
@@ -1609,6 +1735,7 @@ extern "C" int ggl_ext_set_state(ggl_ctx* c, const double* Lambda, const double*
 {
     ARGCHK(c && c->ext_L >= 0, "ctx (ggl_ext_setup first)");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const size_t nb = c->n * sizeof(double);
     if (Lambda) HIPCHK(hipMemcpyAsync(c->Lam[c->lcur], Lambda, nb, hipMemcpyHostToDevice, c->stream));
     if (X1) HIPCHK(hipMemcpyAsync(c->X1, X1, nb, hipMemcpyHostToDevice, c->stream));
@@ -1621,6 +1748,7 @@ extern "C" int ggl_ext_get_state(ggl_ctx* c, double* Lambda, double* X1)
 {
     ARGCHK(c && c->ext_L >= 0, "ctx (ggl_ext_setup first)");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const size_t nb = c->n * sizeof(double);
     if (Lambda) HIPCHK(hipMemcpyAsync(Lambda, c->Lam[c->lcur], nb, hipMemcpyDeviceToHost, c->stream));
     if (X1) HIPCHK(hipMemcpyAsync(X1, c->X1, nb, hipMemcpyDeviceToHost, c->stream));
@@ -1679,6 +1807,7 @@ extern "C" int ggl_ext_admm_step(ggl_ctx* c, double rho, const double* lambda1K,
     ARGCHK(rho > 0 && lambda2 > 0, "rho, lambda2 must be positive");
     ARGCHK(!latent || mu1, "latent needs mu1");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     CopySegs sg;
     int rc = upload_par(c, 0, nullptr, 1.0, rho, &sg);     // beta = 1/rho for every instance   (:203)
     if (rc) return rc;
@@ -1711,6 +1840,7 @@ extern "C" int ggl_ext_kkt_residual(ggl_ctx* c, double rho, const double* lambda
     ARGCHK(c->ext_L >= 0, "ggl_ext_setup first");
     ARGCHK(!latent || mu1, "latent needs mu1");
     HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
     const int K = c->K;
     double* Om = c->Om[c->cur];
     double* Lam = c->Lam[c->lcur];
@@ -1871,6 +2001,54 @@ extern "C" int ggl_dev_symm(int K, int p, const double* A, const double* B, cons
     HIPCHK(hipDeviceSynchronize());
     DOWN(C, dC.p, n);
     if (C2) DOWN(C2, dC2.p, n);
+    return GGL_OK;
+}
+
+// kernel unit test of the bound partials: C = A B with the product kernel's epilogue partials, then the row sums of
+// |C| (K,p), |C|_F^2 (K) and the spectral bound sqrt(min(|C|_inf, Collatz-Wielandt, |C|_F)) (K) from them
+extern "C" int ggl_dev_symm_bounds(int K, int p, const double* A, const double* B, int variant, double* C,
+                                   double* rowsum_out, double* fro2_out, double* bound_out)
+{
+    ARGCHK(K >= 1 && p >= 1 && A && B && C && rowsum_out && fro2_out && bound_out, "arguments");
+    ARGCHK(variant < 0 || symm_variant_built(variant), "product-kernel variant not in this build");
+    const int tile = symm_bounds_tile(K, p, variant);
+    ARGCHK(tile != 0, "this variant / p has no bound partials (direct-to-LDS kernels, even p)");
+    const int T = (p + tile - 1) / tile, ntile = T * (T + 1) / 2, nib = bound_rows_blocks(p);
+    const size_t n = (size_t)K * p * p;
+    DevBuf dA, dB, dC, dcoef, drow, dfro, dd, dinf, dout;
+    unsigned long long* cw = nullptr;
+    unsigned* cnt = nullptr;
+    HIPCHK(dA.alloc(n)); HIPCHK(dB.alloc(n)); HIPCHK(dC.alloc(n));
+    HIPCHK(drow.alloc((size_t)K * T * p)); HIPCHK(dfro.alloc((size_t)K * ntile)); HIPCHK(dd.alloc((size_t)K * p));
+    HIPCHK(dinf.alloc((size_t)K * nib)); HIPCHK(dout.alloc(K));
+    HIPCHK(hipMalloc(&cw, K * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&cnt, K * sizeof(unsigned)));
+    struct Free2 { void *a, *b; ~Free2() { (void)hipFree(a); (void)hipFree(b); } } free2{cw, cnt};
+    HIPCHK(hipMemset(cw, 0, K * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(cnt, 0, K * sizeof(unsigned)));
+    HIPCHK(hipMemset(drow.p, 0xff, (size_t)K * T * p * sizeof(double)));      // every slot must be written by the kernel
+    HIPCHK(hipMemset(dfro.p, 0xff, (size_t)K * ntile * sizeof(double)));
+    std::vector<double> coef((size_t)K * NS_NCOEF, 0.0);
+    for (int k = 0; k < K; ++k) coef[(size_t)k * NS_NCOEF + 1] = 1.0;
+    HIPCHK(dcoef.alloc(coef.size()));
+    UP(dA.p, A, n);
+    UP(dB.p, B, n);
+    UP(dcoef.p, coef.data(), coef.size());
+    launch_symm(nullptr, dA.p, dB.p, dC.p, nullptr, nullptr, dcoef.p, K, p, variant, nullptr, drow.p, dfro.p);
+    launch_bound_rows(nullptr, drow.p, T, K, p, dd.p, dinf.p);
+    launch_cw_final(nullptr, dC.p, dd.p, K, p, dinf.p, dfro.p, ntile, cw, cnt, dout.p, nullptr, nullptr, nullptr, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(C, dC.p, n);
+    DOWN(rowsum_out, dd.p, (size_t)K * p);
+    DOWN(bound_out, dout.p, K);
+    std::vector<double> fr((size_t)K * ntile);
+    DOWN(fr.data(), dfro.p, fr.size());
+    for (int k = 0; k < K; ++k) {
+        double sq = 0.0;
+        for (int t = 0; t < ntile; ++t) sq += fr[(size_t)k * ntile + t];
+        fro2_out[k] = sq;
+    }
     return GGL_OK;
 }
 

@@ -155,8 +155,12 @@ int symm_variants();
 bool symm_variant_built(int v);          // the shipped library holds the dispatched instances only (gemm_sym.hip)
 int symm_auto_variant(int nprod, int p); // what variant < 0 resolves to for nprod products of p x p matrices in a launch
 // maxdev (optional, device [K], zeroed by the caller): max |C - I| per instance.
+// rowpart / fropart (optional, only where symm_bounds_tile() != 0): partial row sums of |C| per tile column,
+// [K][T][p] with T = ceil(p / tile), and the tiles' shares of |C|_F^2, [K][T(T+1)/2] -- what launch_bound_rows sums up
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
-                 const double* coef, int K, int p, int variant, double* maxdev = nullptr);
+                 const double* coef, int K, int p, int variant, double* maxdev = nullptr, double* rowpart = nullptr,
+                 double* fropart = nullptr);
+int symm_bounds_tile(int K, int p, int variant);
 
 // measured FP64 matrix-core ceiling (MFMA-only probe kernel; GGL_DEV builds)
 double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nacc);
@@ -202,7 +206,7 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
 // the schedule alone (host): returns steps, fills deg[max_steps], coef[max_steps*6] = {t0..t4,l_after}
 int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units);
 void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, const double* W, double* Ap, double* Bp,
-                int K, int p, int variant, double* start2 = nullptr);
+                int K, int p, int variant, double* start2 = nullptr, double* rowpart = nullptr, double* fropart = nullptr);
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
             double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride = 0,
             bool fused_start = false);
@@ -222,6 +226,14 @@ void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int
 // to 1 if some out[k] exceeds cuse[k] or is not finite
 void launch_bound_final(hipStream_t st, const double* part2, const double* cwpart, int nbb, int K, double* out, int mode,
                         const double* cuse = nullptr, int* flag = nullptr, int* flag_host = nullptr);
+// the same bound without a pass over B' for the norms: from the partials of the product launch (launch_symm rowpart /
+// fropart with tile edge symm_bounds_tile()): d = row sums, infpart[K][bound_rows_blocks(p)] = block maxima; then the
+// Collatz-Wielandt pass with the final reduction done by the last workgroup of every instance
+int bound_rows_blocks(int p);
+void launch_bound_rows(hipStream_t st, const double* rowpart, int T, int K, int p, double* d, double* infpart);
+void launch_cw_final(hipStream_t st, const double* B, const double* d, int K, int p, const double* infpart,
+                     const double* fropart, int ntile, unsigned long long* cwmax, unsigned* cnt, double* out,
+                     const double* cuse, int* flag, int* flag_host, int flag_slot);
 int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan,
                  int degrees = 9);
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,

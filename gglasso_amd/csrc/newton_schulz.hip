@@ -562,12 +562,12 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
 // Phase A (before the bound is known): A' = W^2 + 4 beta I -> Ap, B' = A'^2 -> Bp.
 // pre0_d / pre1_d: the coefficient rows {4 beta, 1, 0, 0, 0} and {0, 1, 0, 0, 0} of the K instances.
 void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, const double* W, double* Ap, double* Bp, int K,
-                int p, int variant, double* start2)
+                int p, int variant, double* start2, double* rowpart, double* fropart)
 {
     // start2 != null (the bound is already known): the B' launch also writes start2 = dI I + dC B' + dE A' -- the
     // first step's U (degree nine) or Z1 (quintic) -- with {dI, dC, dE} in pre1_d
     launch_symm(st, W, W, Ap, nullptr, nullptr, pre0_d, K, p, variant);
-    launch_symm(st, Ap, Ap, Bp, start2, start2 ? Ap : nullptr, pre1_d, K, p, variant);
+    launch_symm(st, Ap, Ap, Bp, start2, start2 ? Ap : nullptr, pre1_d, K, p, variant, nullptr, rowpart, fropart);
 }
 
 // where the first step's elementwise start goes (ns_run's layout) and its coefficients {dI, dC, dE} from the start
@@ -786,6 +786,93 @@ void launch_bound_final(hipStream_t st, const double* part2, const double* cwpar
 {
     hipLaunchKernelGGL(k_bound_final, dim3((K + 255) / 256), dim3(256), 0, st, part2, cwpart, nbb, K, out, mode, cuse,
                        flag, flag_host);
+}
+
+// ---- the same bound from the partials the product launch leaves behind (launch_symm rowpart / fropart) -------------
+// d[k][i] = sum_s rowpart[k][s][i] (row sums of |B'|, fixed order) and infpart[k][blk] = max of d over the block's rows
+__global__ __launch_bounds__(256) void k_bound_rows(const double* __restrict__ rowpart, int T, int p,
+                                                     double* __restrict__ d, double* __restrict__ infpart)
+{
+    __shared__ double sh[4];
+    const int k = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (i < p) {
+        const double* rp = rowpart + (size_t)k * T * p + i;
+        for (int s2 = 0; s2 < T; ++s2) v += rp[(size_t)s2 * p];
+        d[(size_t)k * p + i] = v;
+    }
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) infpart[(size_t)k * gridDim.x + blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+int bound_rows_blocks(int p) { return (p + 255) / 256; }
+
+void launch_bound_rows(hipStream_t st, const double* rowpart, int T, int K, int p, double* d, double* infpart)
+{
+    hipLaunchKernelGGL(k_bound_rows, dim3(bound_rows_blocks(p), K), dim3(256), 0, st, rowpart, T, p, d, infpart);
+}
+
+// Collatz-Wielandt ratios max_i (|B'| d)_i / d_i, one row per wave, and -- by the last workgroup of an instance to finish --
+// the bound itself: out[k] = sqrt(min(|B'|_inf, cw (1 + 1e-12), |B'|_F)), compared with the bound the running schedule
+// assumes (cuse).  The maximum over the row blocks is an atomic max on the bit pattern of a non-negative double (order
+// independent, hence deterministic); |B'|_F^2 is summed in tile order.  cwmax / cnt: [K], zero on entry, left zero.
+__global__ __launch_bounds__(256) void k_cw_final(const double* __restrict__ B, const double* __restrict__ d, int p,
+                                                   const double* __restrict__ infpart, int ninf,
+                                                   const double* __restrict__ fropart, int ntile,
+                                                   unsigned long long* __restrict__ cwmax, unsigned* __restrict__ cnt,
+                                                   double* __restrict__ out, const double* __restrict__ cuse,
+                                                   int* __restrict__ flag, int* __restrict__ flag_host, int flag_slot)
+{
+    const int k = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    const double* dk = d + (size_t)k * p;
+    if (row < p) {
+        const double* w = B + (size_t)k * p * p + (size_t)row * p;
+        double a0 = 0.0, a1 = 0.0;
+        int j = lane;
+        for (; j + 64 < p; j += 128) {
+            a0 += fabs(w[j]) * dk[j];
+            a1 += fabs(w[j + 64]) * dk[j + 64];
+        }
+        if (j < p) a0 += fabs(w[j]) * dk[j];
+        const double y = wave_sum(a0 + a1);
+        if (lane == 0) {
+            double ratio = y / dk[row];
+            if (!(ratio == ratio)) ratio = 0.0;               // zero row: contributes nothing
+            if (ratio > 0.0) atomicMax(cwmax + k, (unsigned long long)__double_as_longlong(ratio));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    __threadfence();
+    if (atomicAdd(cnt + k, 1u) != gridDim.x - 1) return;
+    // last workgroup of instance k: every ratio has been merged
+    __threadfence();
+    const double cw = __longlong_as_double((long long)atomicExch(cwmax + k, 0ull));
+    atomicExch(cnt + k, 0u);
+    double mx = 0.0, sq = 0.0;
+    for (int b2 = 0; b2 < ninf; ++b2) mx = fmax(mx, infpart[(size_t)k * ninf + b2]);
+    for (int t = 0; t < ntile; ++t) sq += fropart[(size_t)k * ntile + t];
+    const double fr = sqrt(sq);
+    if (isfinite(cw) && cw > 0.0) { const double wv = cw * (1.0 + 1e-12); mx = (wv < mx) ? wv : mx; }
+    const double b = sqrt((fr < mx) ? fr : mx);
+    out[k] = b;
+    if (flag && !(b <= cuse[k])) {
+        atomicOr(flag + flag_slot, 1);
+        flag_host[flag_slot] = 1;
+    }
+}
+
+void launch_cw_final(hipStream_t st, const double* B, const double* d, int K, int p, const double* infpart,
+                     const double* fropart, int ntile, unsigned long long* cwmax, unsigned* cnt, double* out,
+                     const double* cuse, int* flag, int* flag_host, int flag_slot)
+{
+    hipLaunchKernelGGL(k_cw_final, dim3((p + 3) / 4, K), dim3(256), 0, st, B, d, p, infpart, bound_rows_blocks(p), fropart,
+                       ntile, cwmax, cnt, out, cuse, flag, flag_host, flag_slot);
 }
 
 void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int K, int p, double* part)

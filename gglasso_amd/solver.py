@@ -232,7 +232,7 @@ class HipEngine:
         check(self.lib.ggl_ns_stats(self.h, out))
         return dict(zip(("calls", "steps", "stable_calls", "units", "launches", "rank_calls", "rank_retries",
                          "rank_fallbacks", "rank_launches", "spec_calls", "spec_misses", "spin_timeouts", "last_parts",
-                         "last_variant", "eigh_fallbacks"), (int(v) for v in out)))
+                         "last_variant", "eigh_fallbacks", "pre_dropped"), (int(v) for v in out)))
 
     def device_ptr(self, which):
         return self.lib.ggl_device_ptr(self.h, which)

@@ -84,7 +84,8 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
  * problem shape and of these options (defaults in brackets).  None of them changes what is computed, only how; the
  * parity tests run the iteration under each setting.  (A GGL_DEV build of the library -- libggl_hip_dev.so, used by
  * tools/ -- additionally maps the environment variables GGL_SPECULATE, GGL_SPEC_FACTOR, GGL_NS_MODE, GGL_NS_DEGREES,
- * GGL_THETA_FLAT, GGL_RANK_EIG, GGL_TWO_STREAM, GGL_PARTS_MAX_TILES, GGL_SYMM_VARIANT, GGL_SPIN_WAIT onto them.) */
+ * GGL_THETA_FLAT, GGL_RANK_EIG, GGL_TWO_STREAM, GGL_PARTS_MAX_TILES, GGL_SYMM_VARIANT, GGL_SPIN_WAIT,
+ * GGL_FUSED_BOUNDS, GGL_PIPELINE, GGL_FUSED_START onto them.) */
 #define GGL_OPT_SPECULATE 1        /* [1] speculative Omega-step (schedule from the previous iteration's bounds)     */
 #define GGL_OPT_SPEC_FACTOR 2      /* [1.02] inflation of the previous bounds; < 1 forces validation misses (tests)  */
 #define GGL_OPT_NS_MODE 3          /* [0] as GGL_EIG_NS_MODE                                                          */
@@ -95,6 +96,9 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_PARTS_MAX_TILES 8  /* [2048] concurrent parts only up to this many 64x64 tile pairs in the batch     */
 #define GGL_OPT_SYMM_VARIANT 9     /* [-1 = by size] product-kernel instance, see csrc/gemm_sym.hip                   */
 #define GGL_OPT_SPIN_WAIT 10       /* [1] wait for the end of an iteration by polling a pinned sequence number       */
+#define GGL_OPT_FUSED_BOUNDS 11    /* [1] spectral-bound partials from the epilogue of the product launch (no norm pass) */
+#define GGL_OPT_PIPELINE 12        /* [1] ggl_admm_step launches the next iteration's Omega-step chain before it returns     */
+#define GGL_OPT_FUSED_START 13     /* [1] speculative step: the first step's start matrix is the B' launch's second output   */
 int ggl_ctx_set_option(ggl_ctx *ctx, int option, double value);
 int ggl_ctx_get_option(ggl_ctx *ctx, int option, double *value);
 
@@ -122,7 +126,10 @@ int ggl_set_lambda1_mask(ggl_ctx *ctx, const double *lam_pp_host);
  * For p > 128 the Omega- and L-steps are matrix-function iterations on the FP64 matrix cores; with
  * the same rho as in the previous call the Omega-step runs on a schedule built from that call's spectral bounds
  * and is validated on the device -- a rejected step leaves the iterate untouched and is repeated inside this call
- * (GGL_SPECULATE=0 switches that off).  One host synchronisation per call in the common case. */
+ * (GGL_OPT_SPECULATE 0 switches that off).  One host synchronisation per call in the common case.  With GGL_OPT_PIPELINE
+ * the call also launches the NEXT iteration's Omega-step chain for the same rho before it returns whenever the
+ * reference's rho rule (admm_solver.py:227-233) would keep rho for the residuals just computed; the next call takes the
+ * chain over if its rho (and nk) are the same and drops it otherwise, and every other entry point drops it first. */
 int ggl_admm_step(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int reg, int latent,
                   const double *mu1, const double *nk, double out_norms[5]);
 
@@ -239,7 +246,8 @@ int ggl_profile_read(ggl_ctx *ctx, double ms[GGL_NPHASE], long long count[GGL_NP
  * finer resolution, fallbacks to the eigendecomposition, kernel launches (each K*p^3 flop)}; speculative
  * Omega-steps {taken, failed validation and repeated}; [11] end-of-iteration polls that timed out and fell back to a
  * stream synchronisation; what the LAST matrix-function step dispatched: [12] concurrent parts, [13] product-kernel
- * variant (csrc/gemm_sym.hip); [14] Omega-steps that fell back to the eigendecomposition; [15] reserved. */
+ * variant (csrc/gemm_sym.hip); [14] Omega-steps that fell back to the eigendecomposition; [15] pre-launched Omega-step
+ * chains (GGL_OPT_PIPELINE) that were dropped unused. */
 int ggl_ns_stats(ggl_ctx *ctx, long long out[16]);
 
 /* ---- kernel-level test / measurement entry points (not used by the solvers) --------------------
@@ -249,6 +257,11 @@ int ggl_ns_stats(ggl_ctx *ctx, long long out[16]);
 int ggl_dev_symm(int K, int p, const double *A, const double *B, const double *E, const double *coef5K,
                  double *C, double *C2, int variant);
 int ggl_dev_symm_bench(int K, int p, int variant, int iters, double *ms_out);
+/* ggl_dev_symm_bounds: C = A B on the direct-to-LDS product kernel with the bound partials of its epilogue, reduced to
+ * the row sums of |C| (K,p), |C|_F^2 (K) and the spectral bound sqrt(min(|C|_inf, Collatz-Wielandt ratio, |C|_F)) (K)
+ * that the Omega-step takes from B' = (W^2 + 4 beta I)^2 (kernel unit test; even p, variants 16 / 17 / 20). */
+int ggl_dev_symm_bounds(int K, int p, const double *A, const double *B, int variant, double *C,
+                        double *rowsum_out, double *fro2_out, double *bound_out);
 /* host only (no GPU needed): the Newton-Schulz step schedule the Omega-step would run for a spectrum in [l,1]
  * (x = sqrt(eig(Z Y))).  degrees 3 = cubic steps, 5 = cubic/quintic mix, 9 = cubic/quintic/degree-nine mix.
  * deg_out[max_steps] receives 3, 5 or 9 per step, coef_out[max_steps*6] = {t0..t4,l_after} of

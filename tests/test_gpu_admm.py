@@ -412,3 +412,21 @@ def test_mgl_batch_max_iter_and_nsamples():
         assert info['status'] == 'max iterations reached' and info['iterations'] == 7
         for nm in ('Omega', 'Theta', 'X'):
             assert np.abs(out[nm] - ref[nm]).max() <= 1e-10
+
+
+@pytest.mark.parametrize("K,p", [(4, 160), (16, 200), (6, 400)])
+def test_fused_bound_partials_vs_norm_passes(sol, K, p, monkeypatch):
+    """Spectral bounds from the epilogue partials of the B' launch (default) and from the separate norm passes over
+    B' must drive the Omega-step to the same iterates (the bounds agree to rounding; both tracks follow the oracle)."""
+    from gglasso_amd import synth
+    S, _ = synth.make_problem("GGL", K=K, p=p, N=2 * p, seed=37)
+    Om0 = np.stack([np.eye(p)] * K)
+    ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, max_iter=8, tol=1e-20, rtol=1e-20)
+    outs = []
+    for fused in (1, 0):
+        monkeypatch.setattr(sol, "ENGINE_OPTIONS", {"fused_bounds": fused})
+        (s, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, max_iter=8, tol=1e-20, rtol=1e-20)
+        for nm in ('Omega', 'Theta', 'X'):
+            assert np.abs(s[nm] - ref[nm]).max() <= 1e-9, (fused, nm)
+        outs.append(s)
+    assert np.abs(outs[0]['Omega'] - outs[1]['Omega']).max() <= 1e-11

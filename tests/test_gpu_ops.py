@@ -360,3 +360,33 @@ def test_phiplus_newton_schulz_extreme_scaling_falls_back(ops):
     ref, _ = orc.phiplus_stack(W, beta)
     out = ops.phiplus_matrix(W, beta, method=3)
     assert np.abs(out - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("variant", [16, 17, 20])
+@pytest.mark.parametrize("K,p", [(2, 40), (3, 130), (9, 70), (2, 500), (16, 500), (2, 1000)])
+def test_product_epilogue_bound_partials(variant, K, p):
+    """The spectral bound of the Omega-step without a norm pass over B': the product kernel's epilogue leaves the row
+    sums of |C| per tile column and the tiles' Frobenius shares (every tile shape, diagonal tiles from their upper
+    triangle, ragged last tiles), k_bound_rows / k_cw_final reduce them to sqrt(min(|C|_inf, Collatz-Wielandt, |C|_F))."""
+    from gglasso_amd import _lib
+    from gglasso_amd._lib import ptr
+    lib = _lib.load()
+    rng = np.random.default_rng(variant * 1000 + p)
+    A, B = _commuting_pair(rng, K, p)
+    C, rows, fro2, bound = np.empty_like(A), np.empty((K, p)), np.empty(K), np.empty(K)
+    _lib.check(lib.ggl_dev_symm_bounds(K, p, ptr(A), ptr(B), variant, ptr(C), ptr(rows), ptr(fro2), ptr(bound)))
+    assert np.array_equal(C, C.transpose(0, 2, 1))
+    assert np.abs(C - A @ B).max() <= 1e-12 * np.abs(C).max() * p
+    absC = np.abs(C)
+    d = absC.sum(axis=2)
+    assert np.allclose(rows, d, rtol=1e-13, atol=0)
+    assert np.allclose(fro2, (C ** 2).sum(axis=(1, 2)), rtol=1e-13)
+    cw = ((absC @ d[:, :, None])[:, :, 0] / d).max(axis=1)
+    want = np.sqrt(np.minimum(np.minimum(d.max(axis=1), cw * (1 + 1e-12)), np.sqrt((C ** 2).sum(axis=(1, 2)))))
+    assert np.allclose(bound, want, rtol=1e-12)
+    lam = np.abs(np.linalg.eigvalsh(C)).max(axis=1)
+    assert np.all(bound ** 2 >= lam * (1 - 1e-12))                 # it IS a bound: bound = sqrt(bound of rho(|C|))
+    # a second call must find the merge cells clean (they are reset by the finishing workgroup)
+    bound2 = np.empty(K)
+    _lib.check(lib.ggl_dev_symm_bounds(K, p, ptr(A), ptr(B), variant, ptr(C), ptr(rows), ptr(fro2), ptr(bound2)))
+    assert np.array_equal(bound, bound2)

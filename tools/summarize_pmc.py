@@ -38,15 +38,20 @@ for sub in ("fetch", "write", "sq", "tcc"):
     for kname, ctrs in agg.items():
         for c, vals in ctrs.items():
             out.setdefault(kname, {})[c] = {"mean_per_launch": sum(vals) / len(vals), "launches": len(vals)}
-# HBM traffic per launch in bytes.  FETCH_SIZE / WRITE_SIZE are in KiB.  Calibration for THIS access pattern
-# (8-byte-per-lane row reads): the dev bench of k_symm_tn with A == B (64.0 MB of unique operand bytes at
-# K=32,p=500) reads FETCH_SIZE = 72.2e3 and WRITE_SIZE = 64.7e3 for a 64.0 MB output, i.e. both counters
-# report true bytes here (the 1/2 factor of the guide applies to 16-byte-per-lane streams, which these
-# kernels do not issue), so no correction is applied.
+# HBM traffic per launch in bytes.  FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md (section HBM): on gfx950
+# FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced stream of 16 B per lane -- `global_load_dwordx4` and
+# `global_load_lds_dwordx4` alike.  k_symm_dl moves its operands with 16-byte-per-lane DMA, so its FETCH_SIZE is doubled
+# (calibration on k_symm_dl itself: ggl_dev_symm_bench at K=32, p=500 with A == B reads 64.0 MB of unique operand bytes
+# and reports FETCH_SIZE = 31.5e3 KiB).  The 8-byte-per-lane kernels (k_symm_tn, the elementwise and Theta kernels) were
+# calibrated the same way at a factor of 1: k_symm_tn with A == B reports 72.2e3 KiB for the same 64.0 MB, WRITE_SIZE
+# 64.7e3 KiB for a 64.0 MB output.
+FETCH_FACTOR = {"k_symm_dl": 2.0}
 for kname, c in out.items():
     f = c.get("FETCH_SIZE", {}).get("mean_per_launch")
     w = c.get("WRITE_SIZE", {}).get("mean_per_launch")
     if f is not None and w is not None:
-        c["hbm_bytes_per_launch"] = (f + w) * 1024.0
+        fac = next((v for k, v in FETCH_FACTOR.items() if kname.startswith(k)), 1.0)
+        c["fetch_correction_factor"] = fac
+        c["hbm_bytes_per_launch"] = (fac * f + w) * 1024.0
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v.get("hbm_bytes_per_launch") for k, v in out.items()}, indent=1))
