@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eig", type=int, default=0, help="GGL_EIG_* selector (0 auto)")
+    ap.add_argument("--comm", default="capi", choices=["capi", "torch"],
+                    help="N > 1: RCCL behind the C ABI (one call per iteration) or torch.distributed collectives")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="ctx option (gglasso_amd._lib.OPTIONS), e.g. --opt pipeline=0; repeatable")
     args = ap.parse_args()
@@ -165,9 +167,9 @@ def main():
                 os.environ.setdefault(kk, vv)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch.distributed as dist
-        from gglasso_amd.dist import TorchComm, shard_bounds
+        from gglasso_amd.dist import RcclComm, TorchComm, shard_bounds
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        comm = TorchComm(device=f"cuda:{local_rank}")
+        comm = RcclComm() if args.comm == "capi" else TorchComm(device=f"cuda:{local_rank}")
 
     reg, K, p, latent, l1, l2, seed = WORKLOADS[args.workload]
     S, _ = synth.make_problem(reg, K, p, N=2 * p, seed=seed)
@@ -184,6 +186,8 @@ def main():
     options = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in args.opt}
     eng = solver.HipEngine(S_loc, Om0, Om0, np.zeros_like(S_loc), eig=args.eig, device=local_rank, stream=stream,
                            options=options)
+    if distributed and args.comm == "capi":
+        comm.attach(eng)
     nk = np.ones(Kl)
     mu_loc = None if mu1 is None else mu1[k0:k1]
 
@@ -309,7 +313,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{reg} K={K} p={p} lambda1={l1} lambda2={l2} latent={latent}, identity start, "
                                    f"rho0=1 update_rho, fixed iteration count",
-                       "sharding": f"K-slabs of {Kl} per GPU" if distributed else "single GPU",
+                       "sharding": (f"K-slabs of {Kl} per GPU, collectives: " + ("RCCL behind the C ABI" if args.comm == "capi"
+                                                                                  else "torch.distributed (RCCL)"))
+                       if distributed else "single GPU",
                        "omega_step": "lds_jacobi" if eig_jacobi else ("newton_schulz_fp64_mfma" if omega_ns
                                                                          else "rocsolver_dsyevd+mfma_recon"),
                        "options": options or None},

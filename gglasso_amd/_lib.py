@@ -24,7 +24,7 @@ def eig_flags(method=EIG_AUTO, ns_mode=0, ns_degrees=0):
 
 JACOBI_MAX_P = 128
 BUF_S, BUF_OMEGA, BUF_THETA, BUF_L, BUF_X, BUF_GROUPSQ, BUF_NORMS, BUF_OMEGA_PREV = range(8)
-E_ARG, E_HIP, E_SOLVER, E_ALLOC = -1, -2, -3, -4
+E_ARG, E_HIP, E_SOLVER, E_ALLOC, E_COMM = -1, -2, -3, -4, -5
 PHASES = ("form_W", "eig_omega", "recon_omega", "theta", "eig_L", "recon_L", "dual", "reduce", "eig_omega2", "bound")
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -52,6 +52,12 @@ _SIGNATURES = {
     "ggl_step_group_partial": ([_vp, _d, _d], _i),
     "ggl_step_finish": ([_vp, _d, _d, _d, _i, _i, _dp, _i, _dp], _i),
     "ggl_norms_read": ([_vp, _dp], _i),
+    "ggl_comm_unique_id": ([ctypes.c_char_p], _i),
+    "ggl_comm_init": ([_vp, _i, _i, ctypes.c_char_p], _i),
+    "ggl_comm_destroy": ([_vp], _i),
+    "ggl_allreduce_groupsq": ([_vp], _i),
+    "ggl_allreduce_norms": ([_vp], _i),
+    "ggl_admm_step_sharded": ([_vp, _d, _d, _d, _dp, _dp], _i),
     "ggl_scale_X": ([_vp, _d], _i),
     "ggl_sgl_batch_step": ([_vp, _dp, _dp, _i, _dp, _dp], _i),
     "ggl_mgl_batch_step": ([_vp, _i, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp], _i),

@@ -17,6 +17,7 @@
 
 #include "../../include/ggl_hip.h"
 #include "kernels.hpp"
+#include "ggl_comm.hpp"
 
 using namespace ggl;
 
@@ -110,6 +111,9 @@ struct ggl_ctx {
     double *coef = nullptr, *coef_h = nullptr; // [NS_MAX_LAUNCHES][2K][NS_NCOEF]
     double* bounds_h = nullptr;                // pinned: spectral / norm bound per instance, written by k_bound_final
 
+    // K-sharded runs: RCCL communicator of this rank (ggl_comm_init), collectives go on `stream`
+    void* comm = nullptr;
+    int comm_rank = 0, comm_nranks = 1;
     // ext_ADMM_MGL (instances of different dimension, ggl_ext_*): lazy
     double *Lam[2] = {nullptr, nullptr}, *X1 = nullptr;   // Lambda ping-pong (Lam[lcur] current) and the second dual
     int lcur = 0;
@@ -399,6 +403,10 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (!c) return GGL_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);      // also valid for the NULL (legacy default) stream
+    if (c->comm) {
+        if (const RcclApi* api = rccl_api(nullptr)) (void)api->CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
     if (c->blas) rocblas_destroy_handle(c->blas);
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
@@ -1669,6 +1677,113 @@ extern "C" int ggl_kkt_residual(ggl_ctx* c, double rho, double lambda1, double l
     if ((rc = check_info(c, "kkt residual"))) return rc;
     *out = res;
     return GGL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RCCL behind the ABI: the K-sharded GGL iteration as ONE call
+// ---------------------------------------------------------------------------------------------
+#define NCCLCHK(api, expr)                                                                              \
+    do {                                                                                                \
+        int r_ = (expr);                                                                                \
+        if (r_ != 0) return fail(GGL_E_COMM, "%s failed: %s", #expr, (api)->GetErrorString(r_));      \
+    } while (0)
+
+extern "C" int ggl_comm_unique_id(char id_out[128])
+{
+    ARGCHK(id_out, "id_out");
+    const char* err = nullptr;
+    const RcclApi* api = rccl_api(&err);
+    if (!api) return fail(GGL_E_COMM, "RCCL unavailable: %s", err ? err : "?");
+    RcclApi::UniqueId id;
+    NCCLCHK(api, api->GetUniqueId(&id));
+    memcpy(id_out, id.internal, RcclApi::UNIQUE_ID_BYTES);
+    return GGL_OK;
+}
+
+extern "C" int ggl_comm_init(ggl_ctx* c, int rank, int nranks, const char id[128])
+{
+    ARGCHK(c && id, "ctx, id");
+    ARGCHK(nranks >= 1 && rank >= 0 && rank < nranks, "0 <= rank < nranks");
+    ARGCHK(c->comm == nullptr, "the ctx already has a communicator");
+    HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
+    const char* err = nullptr;
+    const RcclApi* api = rccl_api(&err);
+    if (!api) return fail(GGL_E_COMM, "RCCL unavailable: %s", err ? err : "?");
+    RcclApi::UniqueId uid;
+    memcpy(uid.internal, id, RcclApi::UNIQUE_ID_BYTES);
+    RcclApi::Comm comm = nullptr;
+    NCCLCHK(api, api->CommInitRank(&comm, nranks, uid, rank));
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_nranks = nranks;
+    return GGL_OK;
+}
+
+extern "C" int ggl_comm_destroy(ggl_ctx* c)
+{
+    ARGCHK(c, "ctx");
+    if (!c->comm) return GGL_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const RcclApi* api = rccl_api(nullptr);
+    if (api) NCCLCHK(api, api->CommDestroy(c->comm));
+    c->comm = nullptr;
+    return GGL_OK;
+}
+
+// sum over ranks of GROUPSQ (p*p sums of squares + the speculation flag) / of the five local sums, in place, on the ctx stream
+extern "C" int ggl_allreduce_groupsq(ggl_ctx* c)
+{
+    ARGCHK(c && c->comm, "ctx with a communicator (ggl_comm_init)");
+    const RcclApi* api = rccl_api(nullptr);
+    NCCLCHK(api, api->AllReduce(c->groupsq, c->groupsq, (size_t)c->p * c->p + 1, RcclApi::Float64, RcclApi::Sum, c->comm, c->stream));
+    return GGL_OK;
+}
+
+extern "C" int ggl_allreduce_norms(ggl_ctx* c)
+{
+    ARGCHK(c && c->comm, "ctx with a communicator (ggl_comm_init)");
+    const RcclApi* api = rccl_api(nullptr);
+    NCCLCHK(api, api->AllReduce(c->norms, c->norms, GGL_NNORM, RcclApi::Float64, RcclApi::Sum, c->comm, c->stream));
+    return GGL_OK;
+}
+
+static int sharded_pass(ggl_ctx* c, double rho, double lambda1, double lambda2, const double* nk, bool speculate,
+                        double out_norms[5])
+{
+    CopySegs sg;
+    int rc = upload_par(c, 0, nk, 1.0, rho, &sg);
+    if (rc) return rc;
+    // with MAX_PARTS parts there is no flag slot left for the all-reduced flag
+    rc = omega_step(c, 0, &sg, speculate && c->ns_parts < ggl_ctx::MAX_PARTS);
+    if (rc) return rc;
+    launch_group_partial(c->stream, c->sqwork, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
+    launch_sum_chunks(c->stream, c->groupsq, c->sqwork, ggl_chunks(c->K, c->p), c->p);
+    launch_spec_pack(c->stream, c->spec_pending ? c->spec_flag : nullptr, c->groupsq + (size_t)c->p * c->p);
+    HIPCHK(hipGetLastError());
+    if ((rc = ggl_allreduce_groupsq(c))) return rc;
+    rc = ggl_step_finish_impl(c, rho, lambda1, lambda2, GGL_REG_GGL, 0, nullptr, 1 | 2, out_norms);   // norms stay on the device
+    if (rc) return rc;
+    if ((rc = ggl_allreduce_norms(c))) return rc;
+    return finish_norms(c, 1, out_norms);
+}
+
+extern "C" int ggl_admm_step_sharded(ggl_ctx* c, double rho, double lambda1, double lambda2, const double* nk,
+                                     double out_norms[5])
+{
+    ARGCHK(c && out_norms, "ctx, out_norms");
+    ARGCHK(c->comm, "ggl_comm_init first");
+    ARGCHK(rho > 0 && lambda1 > 0 && lambda2 > 0, "rho, lambda1, lambda2 must be positive");
+    HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
+    int rc = sharded_pass(c, rho, lambda1, lambda2, nk, true, out_norms);
+    if (rc != GGL_SPEC_RETRY) return rc;
+    // the reduced validation flag says some rank's schedule did not cover its spectrum: every rank left its iterate alone
+    // and repeats the iteration bounds-first (all ranks take this branch together: the flag is the all-reduced one)
+    rc = sharded_pass(c, rho, lambda1, lambda2, nk, false, out_norms);
+    if (rc == GGL_SPEC_RETRY) return fail(GGL_E_SOLVER, "K-sharded step: the non-speculative repeat was rejected");
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -843,17 +843,23 @@ __global__ __launch_bounds__(256) void k_cw_final(const double* __restrict__ B, 
         if (lane == 0) {
             double ratio = y / dk[row];
             if (!(ratio == ratio)) ratio = 0.0;               // zero row: contributes nothing
-            if (ratio > 0.0) atomicMax(cwmax + k, (unsigned long long)__double_as_longlong(ratio));
+            if (ratio > 0.0)
+                __hip_atomic_fetch_max(cwmax + k, (unsigned long long)__double_as_longlong(ratio), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // Everything the workgroups exchange travels in agent-scope atomics (performed at the memory side, coherent across
+    // the XCDs' L2s): no cache write-back / invalidate fences.  The barrier below waits for this workgroup's atomic max
+    // operations (hipcc drains vmcnt(0) at __syncthreads) before its arrival is counted.  (A __threadfence() here costs a
+    // write-back of the whole XCD L2 per workgroup -- with the product kernels of the other part dirtying it all the time
+    // that was measured as +150 us per iteration.)
     __syncthreads();
     if (threadIdx.x != 0) return;
-    __threadfence();
-    if (atomicAdd(cnt + k, 1u) != gridDim.x - 1) return;
+    if (__hip_atomic_fetch_add(cnt + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
     // last workgroup of instance k: every ratio has been merged
-    __threadfence();
-    const double cw = __longlong_as_double((long long)atomicExch(cwmax + k, 0ull));
-    atomicExch(cnt + k, 0u);
+    const double cw = __longlong_as_double((long long)__hip_atomic_exchange(cwmax + k, 0ull, __ATOMIC_RELAXED,
+                                                                            __HIP_MEMORY_SCOPE_AGENT));
+    __hip_atomic_store(cnt + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double mx = 0.0, sq = 0.0;
     for (int b2 = 0; b2 < ninf; ++b2) mx = fmax(mx, infpart[(size_t)k * ninf + b2]);
     for (int t = 0; t < ntile; ++t) sq += fropart[(size_t)k * ntile + t];

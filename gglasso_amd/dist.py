@@ -104,6 +104,43 @@ class TorchComm:
             return t.cpu().numpy()
 
 
+class RcclComm:
+    """RCCL behind the C ABI (include/ggl_hip.h, ggl_comm_* / ggl_admm_step_sharded): the library itself issues the
+    two all-reduces of a K-sharded GGL iteration on the ctx stream, so an iteration is ONE C call and the host
+    program needs no torch tensors at all.  torch.distributed is used here for exactly one thing: shipping RCCL's
+    128-byte unique id from rank 0 to the other ranks (any broadcast would do: MPI, a file, a socket)."""
+    capi = True
+    backend = "rccl-capi"
+    device_norms = True
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.stream_handle = None           # the ctx creates its own stream; the collectives are issued on it in C
+
+    def attach(self, eng):
+        """Create this rank's communicator inside the engine's ctx (collective: every rank calls it)."""
+        import ctypes
+        box = [None]
+        if self.rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(_lib.load().ggl_comm_unique_id(buf))
+            box[0] = buf.raw
+        self.dist.broadcast_object_list(box, src=0, group=self.group)
+        eng.comm_init(self.rank, self.world, box[0])
+
+    def allreduce_norms(self, arr):
+        """Host-side sum over ranks (objective values with measure=True; not on the iteration path)."""
+        import torch
+        t = torch.as_tensor(np.asarray(arr, dtype=np.float64))
+        if self.dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+
 def _hip_groupsq_tensor(self, torch, device):
     # (p,p) sums + the trailing speculation flag (include/ggl_hip.h, ggl_step_omega_spec): one flat vector
     ptr = self.device_ptr(_lib.BUF_GROUPSQ)
@@ -147,13 +184,17 @@ def ADMM_MGL_sharded(S_local, lambda1, lambda2, reg, Omega_0, K_total, comm, The
     if len(X_0) == 0:
         X_0 = np.zeros((Kl, p, p))
     kw = dict(engine_kwargs or {})
-    if comm.backend == "nccl":
+    if getattr(comm, "capi", False):
+        kw.setdefault("device", device)
+    elif comm.backend == "nccl":
         # the ctx runs on the communicator's dedicated stream: RCCL orders a collective against the stream it is
         # issued on, so kernels and all-reduces need no host synchronisation on either side (TorchComm checks it)
         kw.setdefault("stream", comm.stream_handle)
         kw.setdefault("device", device)
     eng = _solver.ENGINE(S_local, Omega_0, Theta_0, X_0, **kw)
     try:
+        if getattr(comm, "capi", False):
+            comm.attach(eng)
         info, _ = _run_admm(eng, reg, K_total, p, float(lambda1), float(lambda2), False, None, nk, float(rho),
                             tol, rtol, 'boyd', update_rho, max_iter, verbose and comm.rank == 0, measure,
                             "Multiple", comm=comm, want_objective=False)

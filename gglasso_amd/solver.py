@@ -113,6 +113,15 @@ class HipEngine:
     def scale_X(self, f):
         check(self.lib.ggl_scale_X(self.h, f))
 
+    # -- RCCL behind the C ABI (K-sharded GGL: the whole iteration incl. both all-reduces is one call) -----------
+    def comm_init(self, rank, nranks, unique_id):
+        check(self.lib.ggl_comm_init(self.h, int(rank), int(nranks), bytes(unique_id)))
+
+    def step_sharded(self, rho, lambda1, lambda2, nk):
+        """One K-sharded GGL iteration on this rank's slab; returns the five GLOBAL sums (same on every rank)."""
+        check(self.lib.ggl_admm_step_sharded(self.h, rho, lambda1, lambda2, self._cptr(nk), self._norms_p))
+        return self._norms
+
     # -- K independent single problems (batched lambda path) ----------------------------------
     def sgl_batch_step(self, rho, lambda1, latent, mu1):
         out = np.zeros((self.K, 5))
@@ -298,7 +307,10 @@ def _run_admm(eng, reg, K_total, p, lambda1, lambda2, latent, mu1, nk, rho, tol,
     for iter_t in range(max_iter):
         if measure:
             start = time.time()
-        if sharded_ggl:
+        if sharded_ggl and getattr(comm, "capi", False):
+            # RCCL behind the C ABI: Omega-step, both all-reduces, Theta-step and the norms in one call
+            sq = eng.step_sharded(rho, lambda1, lambda2, nk)
+        elif sharded_ggl:
             # device_norms: HIP engine over RCCL.  The Omega-step may then run speculatively; its validation flag
             # rides on the (p,p) all-reduce, so either every rank accepts the step or every rank repeats it.
             def sharded_pass(speculate):

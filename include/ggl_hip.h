@@ -29,6 +29,7 @@ extern "C" {
 #define GGL_E_HIP (-2)      /* HIP runtime error */
 #define GGL_E_SOLVER (-3)   /* rocSOLVER / eigensolver did not converge */
 #define GGL_E_ALLOC (-4)
+#define GGL_E_COMM (-5)     /* RCCL error, or librccl could not be loaded */
 
 /* penalty selector: reg argument of ADMM_MGL (solver/admm_solver.py:13-31) / ADMM_SGL */
 #define GGL_REG_SGL 0       /* K independent single problems: prox_od_1norm (ggl_helper.py:16-27) */
@@ -153,6 +154,26 @@ int ggl_step_finish(ggl_ctx *ctx, double rho, double lambda1, double lambda2, in
  * a K-sharded run can all-reduce them on the device (no host round trip); ggl_norms_read then copies them out
  * (one stream sync), exactly what ggl_step_finish does itself without the bit. */
 int ggl_norms_read(ggl_ctx *ctx, double out_norms[5]);
+
+/* ---- RCCL behind the ABI: the K-sharded GGL iteration as one call -------------------------------
+ * One process per GPU, each with a ctx over its K-slab.  librccl.so.1 is resolved at run time
+ * (dlopen), libggl_hip.so does not link it.
+ *   ggl_comm_unique_id  ncclGetUniqueId on one rank; the host program distributes the 128 bytes by its own means
+ *                       (MPI_Bcast, a file, torch.distributed's store -- gglasso_amd/dist.py uses broadcast_object_list)
+ *   ggl_comm_init       ncclCommInitRank for this ctx's device; the collectives run on the ctx stream
+ *   ggl_admm_step_sharded  the whole iteration of admm_solver.py:179-224 on this rank's slab with its two exchanges:
+ *                       Omega-step (speculative) | local sum_k u^2 -> ncclAllReduce of GROUPSQ (p*p + 1 doubles: the
+ *                       validation flag rides along) | Theta-step, dual update, five local sums -> ncclAllReduce (5
+ *                       doubles) | one host synchronisation.  out_norms are the GLOBAL sums: every rank takes the same
+ *                       rho / stopping decision.  A rejected speculative step is repeated inside the call on all ranks.
+ *   ggl_allreduce_groupsq / ggl_allreduce_norms  the two collectives alone, for callers that use the split entry points. */
+int ggl_comm_unique_id(char id_out[128]);
+int ggl_comm_init(ggl_ctx *ctx, int rank, int nranks, const char id[128]);
+int ggl_comm_destroy(ggl_ctx *ctx);
+int ggl_allreduce_groupsq(ggl_ctx *ctx);
+int ggl_allreduce_norms(ggl_ctx *ctx);
+int ggl_admm_step_sharded(ggl_ctx *ctx, double rho, double lambda1, double lambda2, const double *nk,
+                          double out_norms[5]);
 
 /* ---- K independent single problems (batched lambda path) ---------------------------------------
  * The ctx stack is used as K separate ADMM_SGL problems (single_admm_solver.py:157-214), each with its

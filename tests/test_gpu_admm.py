@@ -430,3 +430,32 @@ def test_fused_bound_partials_vs_norm_passes(sol, K, p, monkeypatch):
             assert np.abs(s[nm] - ref[nm]).max() <= 1e-9, (fused, nm)
         outs.append(s)
     assert np.abs(outs[0]['Omega'] - outs[1]['Omega']).max() <= 1e-11
+
+
+def test_sharded_driver_rccl_behind_the_c_abi_single_rank(sol):
+    """ggl_comm_init / ggl_admm_step_sharded: RCCL resolved by the library itself (dlopen), both all-reduces issued in C
+    on the ctx stream, one call per iteration; world size 1 (the 1-GPU box), hits, forced misses and no speculation.
+    torch.distributed (gloo) only ships the unique id."""
+    import socket
+    import torch.distributed as dist
+    from gglasso_amd import synth
+    from gglasso_amd.dist import ADMM_MGL_sharded, RcclComm
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        for (K, p, env) in ((5, 40, {}), (3, 150, {}), (3, 150, {"spec_factor": 0.9}), (3, 150, {"speculate": 0}), (4, 500, {})):
+            S, _ = synth.make_problem("GGL", K, p, seed=31)
+            Om0 = np.stack([np.eye(p)] * K)
+            kw = dict(tol=1e-9, rtol=1e-9) if p < 500 else dict(tol=1e-20, rtol=1e-20, max_iter=6)
+            (a, ia), _ = quiet(ADMM_MGL_sharded, S, 0.05, 0.02, "GGL", Om0, K, RcclComm(), measure=True,
+                               engine_kwargs={"options": env}, **kw)
+            (b, ib), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.02, "GGL", Om0, measure=True, **kw)
+            assert ia["status"] == ib["status"]
+            assert len(ia["residual"]) == len(ib["residual"])
+            for nm in ("Omega", "Theta", "X"):
+                assert np.abs(a[nm] - b[nm]).max() <= 1e-10, (nm, env)
+    finally:
+        dist.destroy_process_group()
