@@ -44,9 +44,14 @@ constexpr int sym_nt(int BM, int WM, int WN) { return (BM / WM) * (BM / WN) * 64
 // are then fetched into ONE L2 once and reused by all of its tiles, instead of being streamed
 // into all eight.  Batches smaller than 8 keep the plain (tile, k) order so that every XCD has work.
 static constexpr int NXCD = 8;
+// batches of 1, 2 or 4 instances: 8 / K XCDs share one instance (its tiles interleaved over them), so an XCD's L2 still
+// holds the operands of ONE instance only instead of slices of all of them
+__host__ __device__ inline int xcd_share(int K) { return (K == 1 || K == 2 || K == 4) ? NXCD / K : 0; }
 __host__ __device__ inline int xcd_grid(int ntiles, int K)
 {
-    return (K >= NXCD) ? NXCD * ((K + NXCD - 1) / NXCD) * ntiles : ntiles * K;
+    if (K >= NXCD) return NXCD * ((K + NXCD - 1) / NXCD) * ntiles;
+    const int g = xcd_share(K);
+    return g ? NXCD * ((ntiles + g - 1) / g) : ntiles * K;
 }
 __device__ __forceinline__ bool decode_block_xcd(int ntiles, int K, int& k, int& tile)
 {
@@ -56,6 +61,13 @@ __device__ __forceinline__ bool decode_block_xcd(int ntiles, int K, int& k, int&
         k = (slot / ntiles) * NXCD + xcd;
         tile = slot % ntiles;
         return k < K;
+    }
+    const int g = xcd_share(K);
+    if (g) {
+        const int xcd = L % NXCD, slot = L / NXCD;
+        k = xcd / g;
+        tile = slot * g + xcd % g;
+        return tile < ntiles;
     }
     k = L / ntiles;
     tile = L % ntiles;

@@ -83,7 +83,7 @@ struct ggl_ctx {
     long long pre_launched = 0, pre_dropped = 0;
     bool fused_start = true;                   // speculative step: first step's start matrix as 2nd output of the B' launch
     bool fused_bounds = true;                  // spectral-bound partials from the epilogue of the B' launch (GGL_OPT_FUSED_BOUNDS)
-    bool theta_flat = true;                    // GGL Theta-step: per-element kernel when the state is symmetric
+    int theta_flat = 1;                        // GGL Theta-step for symmetric states: 0 tile pairs, 1 per-element kernel, 2 per-element with the K-column over four waves
     bool state_symmetric = true;               // X and L exactly symmetric (checked when the state is set)
     // speculative Omega-step: the schedule is built from the PREVIOUS iteration's spectral bounds (inflated) and the
     // products are launched without waiting for this iteration's bounds; a device-side check sets spec_flag when a
@@ -217,6 +217,7 @@ static int ctx_alloc(ggl_ctx* c)
     pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_GGL, c->K) * GGL_NNORM);
     pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_FGL, c->K) * GGL_NNORM);
     pl = std::max(pl, (size_t)theta_partial_blocks(c->p, GGL_REG_GGL, c->K, 1) * GGL_NNORM);
+    pl = std::max(pl, (size_t)theta_partial_blocks(c->p, GGL_REG_GGL, c->K, 2) * GGL_NNORM);
     c->partials_len = pl;
     HIPCHK(hipMalloc(&c->partials, pl * sizeof(double)));
     HIPCHK(hipMalloc(&c->norms, (size_t)c->K * 8 * sizeof(double)));
@@ -286,7 +287,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
             c->ns_force = (int)v;
             break;
         case GGL_OPT_NS_DEGREES: c->ns_degrees = v >= 9 ? 9 : (v >= 5 ? 5 : 3); break;
-        case GGL_OPT_THETA_FLAT: c->theta_flat = v != 0.0; break;
+        case GGL_OPT_THETA_FLAT: c->theta_flat = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
         case GGL_OPT_RANK_EIG: c->rank_eig = v != 0.0; c->rank_ns = c->omega_ns && !c->rank_eig; break;
         case GGL_OPT_PARTS: c->ns_parts = std::min(std::max((int)v, 1), (int)ggl_ctx::MAX_PARTS); break;
         case GGL_OPT_PARTS_MAX_TILES: c->parts_max_tiles = (long)v; break;
@@ -1127,7 +1128,7 @@ static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double l
             c->sharded_check = true;
         }
         // the flat GGL kernel computes every (i,j) from its own inputs: only for an exactly symmetric state
-        const int flat = (c->theta_flat && c->state_symmetric && !groupsq_ready) ? 1 : 0;
+        const int flat = (c->theta_flat && c->state_symmetric && !groupsq_ready) ? c->theta_flat : 0;
         HIPCHK(launch_theta_pair(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, l1, l2,
                                  groupsq_ready ? c->groupsq : nullptr, c->sqwork, latent ? 0 : 1, c->partials, c->K,
                                  c->p, flat, (c->spec_pending || c->sharded_check) ? c->spec_flag : nullptr));

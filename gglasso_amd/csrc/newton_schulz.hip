@@ -815,7 +815,7 @@ void launch_bound_rows(hipStream_t st, const double* rowpart, int T, int K, int 
     hipLaunchKernelGGL(k_bound_rows, dim3(bound_rows_blocks(p), K), dim3(256), 0, st, rowpart, T, p, d, infpart);
 }
 
-// Collatz-Wielandt ratios max_i (|B'| d)_i / d_i, one row per wave, and -- by the last workgroup of an instance to finish --
+// Collatz-Wielandt ratios max_i (|B'| d)_i / d_i and -- by the last workgroup of an instance to finish --
 // the bound itself: out[k] = sqrt(min(|B'|_inf, cw (1 + 1e-12), |B'|_F)), compared with the bound the running schedule
 // assumes (cuse).  The maximum over the row blocks is an atomic max on the bit pattern of a non-negative double (order
 // independent, hence deterministic); |B'|_F^2 is summed in tile order.  cwmax / cnt: [K], zero on entry, left zero.
@@ -826,46 +826,55 @@ __global__ __launch_bounds__(256) void k_cw_final(const double* __restrict__ B, 
                                                    double* __restrict__ out, const double* __restrict__ cuse,
                                                    int* __restrict__ flag, int* __restrict__ flag_host, int flag_slot)
 {
+    // 16 rows per workgroup, 4 per wave, all four streamed together (independent loads in flight)
+    __shared__ double sh[4];
     const int k = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
+    const int r0 = blockIdx.x * 16 + wave * 4;
+    const double* w = B + (size_t)k * p * p;
     const double* dk = d + (size_t)k * p;
-    if (row < p) {
-        const double* w = B + (size_t)k * p * p + (size_t)row * p;
-        double a0 = 0.0, a1 = 0.0;
-        int j = lane;
-        for (; j + 64 < p; j += 128) {
-            a0 += fabs(w[j]) * dk[j];
-            a1 += fabs(w[j + 64]) * dk[j + 64];
-        }
-        if (j < p) a0 += fabs(w[j]) * dk[j];
-        const double y = wave_sum(a0 + a1);
-        if (lane == 0) {
-            double ratio = y / dk[row];
-            if (!(ratio == ratio)) ratio = 0.0;               // zero row: contributes nothing
-            if (ratio > 0.0)
-                __hip_atomic_fetch_max(cwmax + k, (unsigned long long)__double_as_longlong(ratio), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-        }
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    size_t ro[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ok[q] = (r0 + q) < p;
+        ro[q] = (size_t)min(r0 + q, p - 1) * p;
     }
-    // Everything the workgroups exchange travels in agent-scope atomics (performed at the memory side, coherent across
-    // the XCDs' L2s): no cache write-back / invalidate fences.  The barrier below waits for this workgroup's atomic max
-    // operations (hipcc drains vmcnt(0) at __syncthreads) before its arrival is counted.  (A __threadfence() here costs a
-    // write-back of the whole XCD L2 per workgroup -- with the product kernels of the other part dirtying it all the time
-    // that was measured as +150 us per iteration.)
+    for (int j = lane; j < p; j += 64) {
+        const double dj = dk[j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] += fabs(w[ro[q] + j]) * dj;
+    }
+    double mx = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double y = wave_sum(a[q]);
+        if (ok[q]) mx = fmax(mx, y / dk[r0 + q]);       // a zero row gives 0/0: fmax drops the NaN
+    }
+    if (lane == 0) sh[wave] = mx;
     __syncthreads();
     if (threadIdx.x != 0) return;
-    if (__hip_atomic_fetch_add(cnt + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
-    // last workgroup of instance k: every ratio has been merged
+    mx = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    // Everything the workgroups exchange travels in agent-scope atomics (performed at the memory side, coherent across
+    // the XCDs' L2s) -- no cache write-back / invalidate fences: a __threadfence() per workgroup writes back the whole XCD
+    // L2, which the product kernels of the other part keep dirtying (measured: +150 us per iteration).  One atomic max
+    // and one arrival per workgroup (thousands of atomics on sixteen addresses serialise: measured 74 us for one per
+    // row).  The arrival depends on the RETURNED value of the max, so it cannot be performed before it.
+    const unsigned long long old =
+        __hip_atomic_fetch_max(cwmax + k, (unsigned long long)__double_as_longlong(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned arrive = 1u + (unsigned)(old >> 63);                   // old is a non-negative double: + 0
+    if (__hip_atomic_fetch_add(cnt + k, arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
+    // last workgroup of instance k: every block maximum has been merged
     const double cw = __longlong_as_double((long long)__hip_atomic_exchange(cwmax + k, 0ull, __ATOMIC_RELAXED,
                                                                             __HIP_MEMORY_SCOPE_AGENT));
     __hip_atomic_store(cnt + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    double mx = 0.0, sq = 0.0;
-    for (int b2 = 0; b2 < ninf; ++b2) mx = fmax(mx, infpart[(size_t)k * ninf + b2]);
+    double inf = 0.0, sq = 0.0;
+    for (int b2 = 0; b2 < ninf; ++b2) inf = fmax(inf, infpart[(size_t)k * ninf + b2]);
     for (int t = 0; t < ntile; ++t) sq += fropart[(size_t)k * ntile + t];
     const double fr = sqrt(sq);
-    if (isfinite(cw) && cw > 0.0) { const double wv = cw * (1.0 + 1e-12); mx = (wv < mx) ? wv : mx; }
-    const double b = sqrt((fr < mx) ? fr : mx);
+    if (isfinite(cw) && cw > 0.0) { const double wv = cw * (1.0 + 1e-12); inf = (wv < inf) ? wv : inf; }
+    const double b = sqrt((fr < inf) ? fr : inf);
     out[k] = b;
     if (flag && !(b <= cuse[k])) {
         atomicOr(flag + flag_slot, 1);
@@ -877,7 +886,7 @@ void launch_cw_final(hipStream_t st, const double* B, const double* d, int K, in
                      const double* fropart, int ntile, unsigned long long* cwmax, unsigned* cnt, double* out,
                      const double* cuse, int* flag, int* flag_host, int flag_slot)
 {
-    hipLaunchKernelGGL(k_cw_final, dim3((p + 3) / 4, K), dim3(256), 0, st, B, d, p, infpart, bound_rows_blocks(p), fropart,
+    hipLaunchKernelGGL(k_cw_final, dim3((p + 15) / 16, K), dim3(256), 0, st, B, d, p, infpart, bound_rows_blocks(p), fropart,
                        ntile, cwmax, cnt, out, cuse, flag, flag_host, flag_slot);
 }
 

@@ -44,9 +44,14 @@ int pval_blocks(int p)
 
 static inline int flat_blocks(int p) { return (int)(((size_t)p * p + 255) / 256); }
 
+// flat: 0 tile-pair kernels, 1 per-element kernel, 2 per-element kernel with the K-column split over the four waves of a
+// workgroup where that pays (K > FLAT4_MIN_K)
+static constexpr int FLAT4_MIN_K = 8;
+static inline bool use_flat4(int K, int flat) { return flat == 2 && K > FLAT4_MIN_K; }
+
 int theta_partial_blocks(int p, int reg, int K, int flat)
 {
-    if (reg == 1 && flat && K <= GGL_FLAT_MAX_K) return flat_blocks(p);
+    if (reg == 1 && flat && K <= GGL_FLAT_MAX_K) return use_flat4(K, flat) ? (int)(((size_t)p * p + 63) / 64) : flat_blocks(p);
     return pair_blocks(p, reg, K);
 }
 
@@ -574,6 +579,120 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
     }
 }
 
+// The same per-element Theta-step with the K-column of an element split over the four waves of a workgroup: wave w holds
+// the instances w*KQ .. (w+1)*KQ-1 of 64 consecutive elements (KQ values of Omega and X per lane instead of K: 8 waves
+// per SIMD instead of 3 at K = 32, and four times the workgroups, so the tail of the last round of workgroups is short),
+// the four partial sums of squares meet in LDS (fixed order).  Every access is still a full 512-byte wave row.
+template <int KQ, bool FUSE_DUAL>
+__global__ __launch_bounds__(256) void k_theta_ggl_flat4(double* __restrict__ Theta, double* __restrict__ X,
+                                                         double* __restrict__ C, const double* __restrict__ Omega,
+                                                         const double* __restrict__ OmegaPrev,
+                                                         const double* __restrict__ L, double l1, double l2,
+                                                         double* __restrict__ partials, int K, int p,
+                                                         const int* __restrict__ skip, const double* __restrict__ l1G,
+                                                         const double* __restrict__ l2G)
+{
+    __shared__ double ssh[4][64];
+    __shared__ double scratch[GGL_NNORM * 4];
+    if (spec_failed(skip)) return;
+    const size_t pp = (size_t)p * p;
+    {   // grid-point dimension of a batch of independent problems (see k_theta_fgl)
+        const size_t goff = (size_t)blockIdx.y * K * pp;
+        Theta += goff; Omega += goff;
+        if (X) X += goff;
+        if (C) C += goff;
+        if (OmegaPrev) OmegaPrev += goff;
+        if (L) L += goff;
+        if (l1G) { l1 = l1G[(size_t)blockIdx.y * K]; l2 = l2G[(size_t)blockIdx.y * K]; }
+        if (partials) partials += (size_t)blockIdx.y * gridDim.x * GGL_NNORM;
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const size_t e = (size_t)blockIdx.x * 64 + lane;
+    const int kb = wid * KQ;
+    const bool live = e < pp;
+    double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
+    double om[KQ], x[KQ], u[KQ];
+    double ss = 0.0;
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            if (kb + q < K) {
+                const size_t o = (size_t)(kb + q) * pp + e;
+                om[q] = Omega[o];
+                x[q] = X ? X[o] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            if (kb + q < K) {
+                const double l = L ? L[(size_t)(kb + q) * pp + e] : 0.0;
+                u[q] = (om[q] + l) + x[q];
+                const double sv = soft(u[q], l1);
+                ss += sv * sv;
+            }
+        }
+    }
+    ssh[wid][lane] = ss;
+    __syncthreads();
+    if (live) {
+        const double tot = (ssh[0][lane] + ssh[1][lane]) + (ssh[2][lane] + ssh[3][lane]);
+        const double a = fmax(sqrt(tot), l2);
+        const double amul = a - l2;
+        const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
+        const bool offd = (i != j);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            if (kb + q < K) {
+                const size_t o = (size_t)(kb + q) * pp + e;
+                const double v = u[q];
+                const double th = offd ? soft(v, l1) * amul / a : v;
+                Theta[o] = th;
+                if (FUSE_DUAL) {
+                    const double xn = x[q] + (om[q] - th);
+                    X[o] = xn;
+                    const double dp = om[q] - OmegaPrev[o];
+                    acc[0] += om[q] * om[q];
+                    acc[1] += th * th;
+                    acc[2] += xn * xn;
+                    acc[3] += (om[q] - th) * (om[q] - th);
+                    acc[4] += dp * dp;
+                } else if (C) {
+                    C[o] = (th - x[q]) - om[q];
+                }
+            }
+        }
+    }
+    if (FUSE_DUAL) {
+#pragma unroll
+        for (int v = 0; v < GGL_NNORM; ++v) acc[v] = wave_sum(acc[v]);
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) scratch[wid * GGL_NNORM + v] = acc[v];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double* o = partials + (size_t)blockIdx.x * GGL_NNORM;
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v)
+                o[v] = (scratch[v] + scratch[GGL_NNORM + v]) + (scratch[2 * GGL_NNORM + v] + scratch[3 * GGL_NNORM + v]);
+        }
+    }
+}
+
+static inline int flat4_blocks(int p) { return (int)(((size_t)p * p + 63) / 64); }
+
+template <int KQ>
+static void launch_flat4(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
+                         const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual, double* partials,
+                         int K, int p, const int* skip, int G = 1, const double* l1G = nullptr, const double* l2G = nullptr)
+{
+    dim3 grid(flat4_blocks(p), G), blk(256);
+    if (fuse_dual)
+        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
+    else
+        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
+}
+
 template <int KMAX>
 static void launch_flat(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                         const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual, double* partials,
@@ -591,6 +710,11 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
                              const double* groupsq, double* sqwork, int fuse_dual, double* partials, int K, int p,
                              int flat, const int* skip)
 {
+    if (reg == 1 && !groupsq && K <= GGL_FLAT_MAX_K && use_flat4(K, flat)) {
+        if (K <= 16) launch_flat4<4>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
+        else launch_flat4<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
+        return hipGetLastError();
+    }
     if (reg == 1 && flat && !groupsq && K <= GGL_FLAT_MAX_K) {
         if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
         else if (K <= 16) launch_flat<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);

@@ -51,6 +51,11 @@ class HipEngine:
         self._norms_p = ptr(self._norms)
         self._ptr_cache = {}
 
+    def set_state(self, Omega, Theta, X, L=None):
+        """Overwrite the iterate (admm_solver.py:142-150 semantics: L None zeroes it)."""
+        check(self.lib.ggl_set_state(self.h, ptr(as_c(Omega)), ptr(as_c(Theta)), ptr(None if L is None else as_c(L)),
+                                     ptr(as_c(X))))
+
     def set_option(self, name, value):
         check(self.lib.ggl_ctx_set_option(self.h, _lib.OPTIONS[name], float(value)))
 

@@ -165,3 +165,78 @@ def test_seam3a_glasso_problem_model_selection_with_the_batched_grid(ref, ours, 
         assert np.allclose(P1.modelselect_stats['BIC'][0.3], P0.modelselect_stats['BIC'][0.3], rtol=1e-7)
         assert np.array_equal(P1.modelselect_stats['SP'], P0.modelselect_stats['SP'])
         assert np.array_equal(P1.modelselect_stats['RANK'], P0.modelselect_stats['RANK'])
+
+
+def test_seam2_ext_admm_nonconforming_through_glasso_problem(ref, ours, monkeypatch):
+    """problem.py:12,468 -- a dict S with a bookkeeping array G makes glasso_problem.solve() call ext_ADMM_MGL; swapping
+    the name for gglasso_amd.ext_ADMM_MGL (instances padded into one stack) must give the reference's solution, with and
+    without latent variables (reference tests/test_problem.py:117-138)."""
+    import pandas as pd
+    import gglasso.helper.ext_admm_helper as eh
+    from gglasso_amd import ext_solver
+    problem = ref["problem"]
+    rng = np.random.default_rng(5)
+    K, N = 4, 200
+    all_obs, S = {}, {}
+    for k in range(K):
+        X = rng.random((5 + k, N))
+        all_obs[k] = pd.DataFrame(X)
+        S[k] = np.cov(X, bias=True)
+    ix_exist, ix_location = eh.construct_indexer(list(all_obs.values()))
+    G = quiet(eh.create_group_array, ix_exist, ix_location, 2)
+
+    def solve(latent):
+        P = problem.glasso_problem(S={k: v.copy() for k, v in S.items()}, N=N, reg="GGL", latent=latent, G=G,
+                                   reg_params={'lambda1': 0.01, 'lambda2': 0.001, 'mu1': 0.05}, do_scaling=True)
+        quiet(P.solve, tol=1e-9, rtol=1e-9)
+        return P
+
+    for latent in (False, True):
+        monkeypatch.undo()
+        P0 = solve(latent)
+        from gglasso_amd import solver
+        from oracle_engine import OracleEngine
+        monkeypatch.setattr(solver, "ENGINE", OracleEngine)
+        monkeypatch.setattr(problem, "ext_ADMM_MGL", ext_solver.ext_ADMM_MGL)
+        P1 = solve(latent)
+        assert P1.solver_info['status'] == P0.solver_info['status']
+        for k in range(K):
+            assert np.abs(P1.solution.precision_[k] - P0.solution.precision_[k]).max() <= 1e-8
+            if latent:
+                assert np.abs(P1.solution.lowrank_[k] - P0.solution.lowrank_[k]).max() <= 1e-8
+
+
+def test_seam3b_glasso_problem_model_selection_mgl_with_the_batched_grid(ref, ours, monkeypatch):
+    """problem.py:14,626-654: model_selection() of a multiple-graph problem calls K_single_grid (latent, stage one) and
+    grid_search(solver=ADMM_MGL, ...); swapping in gglasso_amd's ADMM_MGL, grid_search and K_single_grid (every grid a
+    batch) must select the same (lambda1, lambda2) and the same estimate as the reference's sequential walks."""
+    dg, problem = ref["dg"], ref["problem"]
+    from gglasso_amd import model_selection as ours_ms
+    K, p, N = 3, 16, 200
+    Sig, _ = dg.group_power_network(p, K=K, M=2, seed=17)
+    S, _ = dg.sample_covariance_matrix(Sig, N, seed=17)
+
+    def select(latent):
+        P = problem.glasso_problem(S.copy(), N, reg='GGL', latent=latent, do_scaling=False)
+        P.set_modelselect_params({'lambda1_range': np.logspace(-0.5, -1.5, 3), 'lambda2_range': np.array([0.1, 0.02]),
+                                  'mu1_range': np.array([1.0, 0.4])})
+        quiet(P.model_selection, method='eBIC', gamma=0.1, tol=1e-9, rtol=1e-9)
+        return P
+
+    for latent in (False, True):
+        monkeypatch.undo()
+        P0 = select(latent)
+        from gglasso_amd import solver
+        from oracle_engine import OracleEngine
+        monkeypatch.setattr(solver, "ENGINE", OracleEngine)
+        monkeypatch.setattr(problem, "ADMM_MGL", solver.ADMM_MGL)
+        monkeypatch.setattr(problem, "grid_search", ours_ms.grid_search)
+        monkeypatch.setattr(problem, "K_single_grid", ours_ms.K_single_grid)
+        P1 = select(latent)
+        assert P1.reg_params['lambda1'] == P0.reg_params['lambda1'] and P1.reg_params['lambda2'] == P0.reg_params['lambda2']
+        assert np.abs(P1.solution.precision_ - P0.solution.precision_).max() <= 1e-6
+        assert np.allclose(P1.modelselect_stats['BIC'][0.1], P0.modelselect_stats['BIC'][0.1], rtol=1e-7)
+        assert np.array_equal(P1.modelselect_stats['SP'], P0.modelselect_stats['SP'])
+        if latent:
+            assert np.abs(P1.solution.lowrank_ - P0.solution.lowrank_).max() <= 1e-6
+            assert np.array_equal(P1.modelselect_stats['RANK'], P0.modelselect_stats['RANK'])
