@@ -171,30 +171,39 @@ void launch_dual_update(hipStream_t st, double* X, const double* Omega, const do
 }
 
 // ---------------------------------------------------------------------------------------------
-// out[k][v] = sum_b partials[k][b][v]; one block per k, fixed summation tree.
+// out[k][v] = sum_b partials[k][b][v]; one block per k, all nv (<= 8) sums in ONE pass over the partials: strided
+// per-thread sums, wave shuffles, four wave results added in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partials, int nblk, int nv,
                                                          double* __restrict__ out, unsigned long long* seq,
                                                          unsigned long long seq_val)
 {
-    __shared__ double sh[256];
+    __shared__ double sh[4][8];
     const int k = blockIdx.x;
-    for (int v = 0; v < nv; ++v) {
-        double s = 0.0;
-        for (int b = threadIdx.x; b < nblk; b += 256) s += partials[((size_t)k * nblk + b) * nv + v];
-        sh[threadIdx.x] = s;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[(size_t)k * nv + v] = sh[0];
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double* base = partials + (size_t)k * nblk * nv;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+            if (v < nv) acc[v] += base[(size_t)b * nv + v];
     }
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        if (v < nv) {
+            const double s = wave_sum(acc[v]);
+            if (lane == 0) sh[wid][v] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nv) out[(size_t)k * nv + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
     // single-row reductions into pinned host memory: publish a sequence number AFTER the sums, so that the host can
     // wait for this kernel by polling one word instead of a stream synchronisation
-    if (seq != nullptr && threadIdx.x == 0 && blockIdx.x == 0) {
-        __threadfence_system();
-        *(volatile unsigned long long*)seq = seq_val;
+    if (seq != nullptr && blockIdx.x == 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            *(volatile unsigned long long*)seq = seq_val;
+        }
     }
 }
 

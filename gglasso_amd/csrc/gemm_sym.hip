@@ -321,8 +321,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 // BK: k-slab depth (16 or 32); NSTG: slabs resident in LDS (2 = double buffer; more = deeper DMA prefetch)
 // BM: tile edge (64, or 32 for under-filled batches: 4x the workgroups, and with NSTG = 4 enough slabs in flight to
 // cover the load latency that bounds the small-batch regime); ABL 1: no mirror write (timing ablation)
-template <int BK, int NSTG, int ABL = 0, int BM = 64>
-__global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, const double* __restrict__ B,
+// NW: waves per workgroup (4: 2 x 2 waves of BM/2 x BM/2; 8: 4 x 2 waves of BM/4 x BM/2 -- two waves per SIMD, for batches
+// so small that only one workgroup lands on a CU and a lone wave per SIMD cannot hide its LDS round trips and barriers)
+template <int BK, int NSTG, int ABL = 0, int BM = 64, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ A, const double* __restrict__ B,
                                                  double* __restrict__ C, double* __restrict__ C2,
                                                  const double* __restrict__ E, const double* __restrict__ coef, int K,
                                                  int p, const double* __restrict__ A1, const double* __restrict__ B1,
@@ -332,11 +334,15 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
     // rowpart / fropart != null: the launch also leaves what a spectral bound of C needs, with no pass over C --
     // rowpart[k][s][i] = sum over the columns of tile-column s of |C[i][.]| (summed over s: the row sums of |C|) and
     // fropart[k][tile] = the tile's share of |C|_F^2 (mirror included), every slot written by exactly one workgroup
-    constexpr int WM = BM / 2, WN = BM / 2, TI = BM / 32, TJ = BM / 32;
+    constexpr int NT = NW * 64;
+    constexpr int WM = BM / (NW / 2), WN = BM / 2, TI = WM / 16, TJ = WN / 16;
     constexpr int RPI = 128 / BM;                        // slab rows per DMA instruction (1 KiB)
     constexpr int LPR = 64 / RPI;                        // lanes per row
     constexpr int SLAB = BK * BM;                        // doubles per operand slab (8 KiB at BK = 16)
-    constexpr int IPW = BK / (4 * RPI);                  // DMA instructions per wave, operand and slab
+    constexpr int IPW = BK / (NW * RPI);                 // DMA instructions per wave, operand and slab
+    constexpr int RPW = BK / NW;                         // slab rows a wave's DMA writes
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
+    static_assert(TI >= 1 && TJ >= 1, "wave tile");
     static_assert(BM == 64 || BM == 32, "tile edge");
     static_assert(IPW >= 1, "k-slab too shallow for this tile");
     static_assert(NSTG * 2 * SLAB >= BM * BM, "the mirror tile reuses the slab storage");
@@ -395,8 +401,8 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
         const int valid = p - s * BK;                          // k-rows of this slab inside the matrix
         if (valid < BK) {
             // zero the rows beyond the matrix (each wave cleans the rows its own DMA wrote)
-            for (int e = lane; e < (BK / 4) * BM; e += 64) {
-                const int row = wave * (BK / 4) + e / BM;
+            for (int e = lane; e < RPW * BM; e += 64) {
+                const int row = wave * RPW + e / BM;
                 if (row >= valid) {
                     smem[(size_t)buf * 2 * SLAB + row * BM + (e % BM)] = 0.0;
                     smem[(size_t)buf * 2 * SLAB + SLAB + row * BM + (e % BM)] = 0.0;
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(256) void k_symm_dl(const double* __restrict__ A, c
         }
     }
     if (I != J && ABL != 1) {
-        for (int e = tid; e < BM * BM; e += 256) {
+        for (int e = tid; e < BM * BM; e += NT) {
             const int a = e / BM, c = e % BM;   // out[J0+a][I0+c] = tile[c][a]
             if (J0 + a < p && I0 + c < p) {
                 const double v = smem[c * BM + (a ^ c)];
@@ -540,6 +546,14 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
     }
     const int T = (p + 63) / 64;
     const dim3 grid(xcd_grid(T * (T + 1) / 2, K + K1));
+    if (dl_cfg == 6 || dl_cfg == 7) {
+        // eight waves per workgroup (two per SIMD) for batches that leave one workgroup per CU
+#define GGL_DL8(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(512), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart)
+        if (dl_cfg == 6) GGL_DL8(16, 4, 0, 64, 8);
+        else GGL_DL8(32, 3, 0, 64, 8);
+#undef GGL_DL8
+        return;
+    }
     if (dl_cfg == 1) GGL_DL(16, 3);
 #ifdef GGL_DEV
     else if (dl_cfg == 2) GGL_DL(16, 4);
@@ -771,15 +785,16 @@ static constexpr long SMALL_BATCH_TILES = 400;   // up to here the 32x32-tile ke
 //    9  k_symm_tn 32x32 tile, k-slab 32 (small batches below p = 384)
 //   16  k_symm_dl 64x64, double-buffered DMA      17  k_symm_dl 64x64, three DMA stages (concurrent parts)
 //   20  k_symm_dl 32x32, four DMA stages (small batches from p = 384)
+//   22 / 23  k_symm_dl 64x64 with EIGHT waves per workgroup (k-slab 16, four stages / k-slab 32, three stages)
 // A GGL_DEV build (libggl_hip_dev.so) adds the measured alternatives 1-5, 8, 11-13, 18, 19 and the ablations 6, 7, 10,
 // 14, 15, 21 (tools/bench_*.py).
-int symm_variants() { return 21; }
+int symm_variants() { return 23; }
 bool symm_variant_built(int v)
 {
 #ifdef GGL_DEV
-    return v >= 0 && v <= 21;
+    return v >= 0 && v <= 23;
 #else
-    return v == 0 || v == 9 || v == 16 || v == 17 || v == 20;
+    return v == 0 || v == 9 || v == 16 || v == 17 || v == 20 || v == 22 || v == 23;
 #endif
 }
 
@@ -800,7 +815,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 {
     if (variant < 0) variant = symm_auto_variant(2 * K, p);
     switch (variant) {
-        case 16: case 17: case 18: case 19: case 20:
+        case 16: case 17: case 18: case 19: case 20: case 22: case 23:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K, nullptr, variant - 16);
                 break;
@@ -826,7 +841,7 @@ int symm_bounds_tile(int K, int p, int variant)
     if (variant < 0) variant = symm_auto_variant(K, p);
     if ((p & 1) != 0 || p < 2) return 0;
     if (variant == 20) return 32;
-    if (variant >= 16 && variant <= 19) return 64;
+    if ((variant >= 16 && variant <= 19) || variant == 22 || variant == 23) return 64;
     return 0;
 }
 
@@ -837,7 +852,7 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
 #define GGL_TN(BM, BK, WM, WN, LM) \
     launch_cfg<BM, BK, WM, WN, LM>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev)
     switch (variant) {
-        case 16: case 17: case 18: case 19: case 20: case 21:
+        case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16, rowpart, fropart);
                 break;

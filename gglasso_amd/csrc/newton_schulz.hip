@@ -445,6 +445,13 @@ __global__ __launch_bounds__(256) void k_ns_start(double* __restrict__ Y1, doubl
     }
 }
 
+static void launch_ns_start(hipStream_t st, double* Y1, double* Z1, const double* Ap, const double* Bp, const double* W,
+                            const double* stt, int K, int p, int mode)
+{
+    dim3 grid((unsigned)(((size_t)p * p + 1023) / 1024), K);
+    hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, Y1, Z1, Ap, Bp, W, stt, p, mode);
+}
+
 // cbound_h[k] >= lambda_max(A'_k).  Returns 0, -1 (non-finite) or -2 (condition number above NS_KAPPA_LIMIT).
 // Coefficient slots are numbered from the first launch AFTER the start kernel; start_h: [K][5].
 // One schedule for the whole batch, built for the smallest l_k = sqrt(4 beta_k / c_k) (every spectrum lies in
@@ -597,18 +604,17 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
     // of a larger ctx (two-stream execution) passes the full-stack stride.
     const size_t cs = NS_SLOT(K), n1 = pstride ? pstride : (size_t)K * p * p;
     const int n = plan.steps;
-    dim3 grid((unsigned)(((size_t)p * p + 1023) / 1024), K);
     int g = 0;
     double *cur = YP, *nxt = AB;      // cur = [Y | Z]
     if (plan.deg[0] >= 5 && !plan.stable) {
         if (plan.deg[0] == 5) {
             // quintic first step: Z1 = T1 elementwise
             if (!fused_start)
-                hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, nullptr, YP + n1, AB, AB + n1, W, start_d, p, 2);
+                launch_ns_start(st, nullptr, YP + n1, AB, AB + n1, W, start_d, K, p, 2);
         } else {
             // degree nine: U -> Tb elementwise, Z1 = T1 = t0 I + U B'/c^2 + (t1/c) A'
             if (!fused_start)
-                hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, Tb, nullptr, AB, AB + n1, W, start_d, p, 3);
+                launch_ns_start(st, Tb, nullptr, AB, AB + n1, W, start_d, K, p, 3);
             launch_symm(st, Tb, AB + n1, YP + n1, nullptr, AB, coef_d + cs * g++, K, p, variant);
         }
         // Y1 = (A'/c) Z1 (or Omega directly when it is the only step)
@@ -619,10 +625,10 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
         launch_symm(st, AB, YP + n1, YP, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
     } else {
         if (n == 1) {
-            hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, out, nullptr, AB, AB + n1, W, start_d, p, 1);
+            launch_ns_start(st, out, nullptr, AB, AB + n1, W, start_d, K, p, 1);
             return;
         }
-        hipLaunchKernelGGL(k_ns_start, grid, dim3(256), 0, st, YP, YP + n1, AB, AB + n1, W, start_d, p, 0);
+        launch_ns_start(st, YP, YP + n1, AB, AB + n1, W, start_d, K, p, 0);
     }
     for (int it = 1; it < n; ++it) {
         if (plan.deg[it] == 5 && !plan.stable) {

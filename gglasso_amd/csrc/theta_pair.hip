@@ -47,11 +47,12 @@ static inline int flat_blocks(int p) { return (int)(((size_t)p * p + 255) / 256)
 // flat: 0 tile-pair kernels, 1 per-element kernel, 2 per-element kernel with the K-column split over the four waves of a
 // workgroup where that pays (K > FLAT4_MIN_K)
 static constexpr int FLAT4_MIN_K = 8;
+static constexpr int FLAT4_CHUNKS = 2;     // 64-element chunks per workgroup (halves the partial-sum rows of the reduction)
 static inline bool use_flat4(int K, int flat) { return flat == 2 && K > FLAT4_MIN_K; }
 
 int theta_partial_blocks(int p, int reg, int K, int flat)
 {
-    if (reg == 1 && flat && K <= GGL_FLAT_MAX_K) return use_flat4(K, flat) ? (int)(((size_t)p * p + 63) / 64) : flat_blocks(p);
+    if (reg == 1 && flat && K <= GGL_FLAT_MAX_K) return use_flat4(K, flat) ? (int)(((size_t)p * p + 64 * FLAT4_CHUNKS - 1) / (64 * FLAT4_CHUNKS)) : flat_blocks(p);
     return pair_blocks(p, reg, K);
 }
 
@@ -607,57 +608,60 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4(double* __restrict__ Th
         if (partials) partials += (size_t)blockIdx.y * gridDim.x * GGL_NNORM;
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const size_t e = (size_t)blockIdx.x * 64 + lane;
     const int kb = wid * KQ;
-    const bool live = e < pp;
     double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
-    double om[KQ], x[KQ], u[KQ];
-    double ss = 0.0;
-    if (live) {
+    for (int chunk = 0; chunk < FLAT4_CHUNKS; ++chunk) {
+        const size_t e = ((size_t)blockIdx.x * FLAT4_CHUNKS + chunk) * 64 + lane;
+        const bool live = e < pp;
+        double om[KQ], x[KQ], u[KQ];
+        double ss = 0.0;
+        if (live) {
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            if (kb + q < K) {
-                const size_t o = (size_t)(kb + q) * pp + e;
-                om[q] = Omega[o];
-                x[q] = X ? X[o] : 0.0;
+            for (int q = 0; q < KQ; ++q) {
+                if (kb + q < K) {
+                    const size_t o = (size_t)(kb + q) * pp + e;
+                    om[q] = Omega[o];
+                    x[q] = X ? X[o] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                if (kb + q < K) {
+                    const double l = L ? L[(size_t)(kb + q) * pp + e] : 0.0;
+                    u[q] = (om[q] + l) + x[q];
+                    const double sv = soft(u[q], l1);
+                    ss += sv * sv;
+                }
             }
         }
+        if (chunk) __syncthreads();          // the previous chunk's sums have been read
+        ssh[wid][lane] = ss;
+        __syncthreads();
+        if (live) {
+            const double tot = (ssh[0][lane] + ssh[1][lane]) + (ssh[2][lane] + ssh[3][lane]);
+            const double a = fmax(sqrt(tot), l2);
+            const double amul = a - l2;
+            const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
+            const bool offd = (i != j);
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            if (kb + q < K) {
-                const double l = L ? L[(size_t)(kb + q) * pp + e] : 0.0;
-                u[q] = (om[q] + l) + x[q];
-                const double sv = soft(u[q], l1);
-                ss += sv * sv;
-            }
-        }
-    }
-    ssh[wid][lane] = ss;
-    __syncthreads();
-    if (live) {
-        const double tot = (ssh[0][lane] + ssh[1][lane]) + (ssh[2][lane] + ssh[3][lane]);
-        const double a = fmax(sqrt(tot), l2);
-        const double amul = a - l2;
-        const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
-        const bool offd = (i != j);
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            if (kb + q < K) {
-                const size_t o = (size_t)(kb + q) * pp + e;
-                const double v = u[q];
-                const double th = offd ? soft(v, l1) * amul / a : v;
-                Theta[o] = th;
-                if (FUSE_DUAL) {
-                    const double xn = x[q] + (om[q] - th);
-                    X[o] = xn;
-                    const double dp = om[q] - OmegaPrev[o];
-                    acc[0] += om[q] * om[q];
-                    acc[1] += th * th;
-                    acc[2] += xn * xn;
-                    acc[3] += (om[q] - th) * (om[q] - th);
-                    acc[4] += dp * dp;
-                } else if (C) {
-                    C[o] = (th - x[q]) - om[q];
+            for (int q = 0; q < KQ; ++q) {
+                if (kb + q < K) {
+                    const size_t o = (size_t)(kb + q) * pp + e;
+                    const double v = u[q];
+                    const double th = offd ? soft(v, l1) * amul / a : v;
+                    Theta[o] = th;
+                    if (FUSE_DUAL) {
+                        const double xn = x[q] + (om[q] - th);
+                        X[o] = xn;
+                        const double dp = om[q] - OmegaPrev[o];
+                        acc[0] += om[q] * om[q];
+                        acc[1] += th * th;
+                        acc[2] += xn * xn;
+                        acc[3] += (om[q] - th) * (om[q] - th);
+                        acc[4] += dp * dp;
+                    } else if (C) {
+                        C[o] = (th - x[q]) - om[q];
+                    }
                 }
             }
         }
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4(double* __restrict__ Th
     }
 }
 
-static inline int flat4_blocks(int p) { return (int)(((size_t)p * p + 63) / 64); }
+static inline int flat4_blocks(int p) { return (int)(((size_t)p * p + 64 * FLAT4_CHUNKS - 1) / (64 * FLAT4_CHUNKS)); }
 
 template <int KQ>
 static void launch_flat4(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,

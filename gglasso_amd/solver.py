@@ -300,6 +300,11 @@ def _run_admm(eng, reg, K_total, p, lambda1, lambda2, latent, mu1, nk, rho, tol,
     sharded_ggl = comm is not None and reg == 'GGL'
     device_norms = sharded_ggl and getattr(comm, "device_norms", False) and hasattr(eng, "read_norms")
 
+    if ((measure and want_objective) or stopping_criterion != 'boyd') and hasattr(eng, "set_option") and comm is None:
+        # the objective / the KKT residual are evaluated between the iterations and use the scratch a pre-launched
+        # Omega-step chain would be working in: no pipelining across iterations here (include/ggl_hip.h, GGL_OPT_PIPELINE)
+        eng.set_option("pipeline", 0)
+
     if verbose:
         print(f"------------ADMM Algorithm for {title} Graphical Lasso----------------")
         if stopping_criterion == 'boyd':

@@ -91,7 +91,7 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_SPEC_FACTOR 2      /* [1.02] inflation of the previous bounds; < 1 forces validation misses (tests)  */
 #define GGL_OPT_NS_MODE 3          /* [0] as GGL_EIG_NS_MODE                                                          */
 #define GGL_OPT_NS_DEGREES 4       /* [9] as GGL_EIG_NS_DEGREES                                                       */
-#define GGL_OPT_THETA_FLAT 5       /* [1] GGL Theta-step for exactly symmetric states, K <= 32: 0 tile-pair kernels, 1 per-element
+#define GGL_OPT_THETA_FLAT 5       /* [2] GGL Theta-step for exactly symmetric states, K <= 32: 0 tile-pair kernels, 1 per-element
                                     * kernel, 2 per-element kernel with the K-column split over the four waves of a workgroup */
 #define GGL_OPT_RANK_EIG 6         /* [0] L-step by eigendecomposition instead of the sign iteration                 */
 #define GGL_OPT_PARTS 7            /* [2] parts of the batch that run their launch sequences concurrently (1..4)     */

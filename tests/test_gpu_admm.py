@@ -139,15 +139,14 @@ def test_oracle_trajectory_mid_sizes(sol, reg, K, p, latent):
     assert np.linalg.norm(s['Theta'] - ref['Theta']) <= 1e-8
 
 
-@pytest.mark.parametrize("p", [60, 160])
-def test_asymmetric_dual_start_takes_the_mirroring_kernels(sol, p, monkeypatch):
+@pytest.mark.parametrize("p,K", [(60, 4), (160, 4), (70, 12), (150, 20), (66, 32)])
+def test_asymmetric_dual_start_takes_the_mirroring_kernels(sol, p, K, monkeypatch):
     """The per-element GGL Theta-step is only valid for a bitwise symmetric state.  A dual start X_0 that is
     symmetric only to ~1e-8 (inside the reference's own 1e-5 assert, ggl_helper.py:193) must follow the
     reference's 'upper triangle, then mirror' semantics: the ctx detects the asymmetry when the state is set and
     runs the tile-pair kernels.  Both dispatches agree with the oracle; for a symmetric start they agree with
     each other to rounding."""
     from gglasso_amd import synth
-    K = 4
     S, _ = synth.make_problem("GGL", K=K, p=p, N=2 * p, seed=23)
     Om0 = np.stack([np.eye(p)] * K)
     rng = np.random.default_rng(5)
@@ -160,11 +159,13 @@ def test_asymmetric_dual_start_takes_the_mirroring_kernels(sol, p, monkeypatch):
         for nm in ('Omega', 'Theta', 'X'):
             assert np.abs(s[nm] - ref[nm]).max() <= 1e-9, nm
         assert np.array_equal(s['Theta'], s['Theta'].transpose(0, 2, 1))
-    monkeypatch.setitem(sol.ENGINE_OPTIONS, "theta_flat", 0)
-    (s0, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, X_0=X0, max_iter=10, tol=1e-20, rtol=1e-20)
-    monkeypatch.setitem(sol.ENGINE_OPTIONS, "theta_flat", 1)
-    (s1, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, X_0=X0, max_iter=10, tol=1e-20, rtol=1e-20)
-    assert np.abs(s0['Theta'] - s1['Theta']).max() <= 1e-12
+    outs = []
+    for flat in (0, 1, 2):      # tile-pair kernels / per-element kernel / per-element with the K-column over four waves
+        monkeypatch.setitem(sol.ENGINE_OPTIONS, "theta_flat", flat)
+        (sx, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, X_0=X0, max_iter=10, tol=1e-20, rtol=1e-20)
+        outs.append(sx)
+    assert np.abs(outs[0]['Theta'] - outs[1]['Theta']).max() <= 1e-12
+    assert np.abs(outs[0]['Theta'] - outs[2]['Theta']).max() <= 1e-12
 
 
 def test_inputs_not_mutated_and_asserts(sol):

@@ -161,7 +161,7 @@ def test_c5_slab_dispatch_ggl_K32_p1000(stats):
     assert np.array_equal(out["Theta"], out["Theta"].transpose(0, 2, 1))
     st = stats[-1]
     assert st["last_parts"] == 1 and st["last_variant"] == 16, st
-    assert st["spec_calls"] == 1, st
+    assert st["spec_calls"] >= 1, st          # iteration 2 (and the chain pre-launched behind it) ran speculatively
 
 
 @pytest.mark.parametrize("K", [4, 8, 16])
