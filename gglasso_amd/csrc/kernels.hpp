@@ -88,7 +88,7 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
 // largest K the FGL Theta-step kernel serves (K-vectors of an 8x8 tile pair in one workgroup's LDS)
 int fgl_max_K();
 // G independent problems of K instances each in one launch: stacks (G*K,p,p), thresholds of problem g at l1G[g*K] /
-// l2G[g*K], partial sums [g][theta_partial_blocks(p,reg,K,1)].  GGL: K <= GGL_FLAT_MAX_K; symmetric states only.
+// l2G[g*K], partial sums [g][theta_partial_blocks(p,reg,K,2)].  GGL: K <= GGL_FLAT_MAX_K; symmetric states only.
 hipError_t launch_theta_batch(hipStream_t st, int reg, double* Theta, double* X, double* C, const double* Omega,
                               const double* OmegaPrev, const double* L, const double* l1G, const double* l2G,
                               int fuse_dual, double* partials, int G, int K, int p, const int* skip);

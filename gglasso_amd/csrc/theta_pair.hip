@@ -758,6 +758,11 @@ hipError_t launch_theta_batch(hipStream_t st, int reg, double* Theta, double* X,
 {
     if (reg == 1) {
         if (K > GGL_FLAT_MAX_K) return hipErrorInvalidValue;
+        if (use_flat4(K, 2)) {       // partial-sum rows: theta_partial_blocks(p, reg, K, 2) per problem
+            if (K <= 16) launch_flat4<4>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
+            else launch_flat4<8>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
+            return hipGetLastError();
+        }
         if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
         else if (K <= 16) launch_flat<16>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
         else launch_flat<32>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);

@@ -372,7 +372,8 @@ def test_g16_batched_mgl_grid_search(sol):
 
 
 @pytest.mark.parametrize("reg,K,p,latent", [("GGL", 4, 40, False), ("GGL", 3, 150, False), ("FGL", 5, 140, True),
-                                            ("GGL", 4, 200, True), ("FGL", 36, 36, False)])
+                                            ("GGL", 4, 200, True), ("FGL", 36, 36, False), ("GGL", 12, 60, False),
+                                            ("GGL", 20, 50, True)])
 def test_mgl_batch_equals_independent_solves(reg, K, p, latent):
     """Every problem of the batch must follow the trajectory of its own ADMM_MGL call (own rho, own stopping
     iteration) -- against the CPU oracle, below and above the LDS-Jacobi limit, both penalties, latent or not."""
