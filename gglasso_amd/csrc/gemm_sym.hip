@@ -546,14 +546,18 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
     }
     const int T = (p + 63) / 64;
     const dim3 grid(xcd_grid(T * (T + 1) / 2, K + K1));
+#ifdef GGL_DEV
     if (dl_cfg == 6 || dl_cfg == 7) {
-        // eight waves per workgroup (two per SIMD) for batches that leave one workgroup per CU
+        // eight waves per workgroup (two per SIMD) for batches that leave one workgroup per CU.  Measured (MI355X, p = 500):
+        // K = 4: 27.0 / 26.3 us vs 26.6 us for the 32x32 kernel; K = 8: 43.9 / 49.3 vs 40.4; K = 16: 68.6 / 74.9 vs 63.9 --
+        // no gain anywhere, so the shipped library does not carry them
 #define GGL_DL8(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(512), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart)
         if (dl_cfg == 6) GGL_DL8(16, 4, 0, 64, 8);
         else GGL_DL8(32, 3, 0, 64, 8);
 #undef GGL_DL8
         return;
     }
+#endif
     if (dl_cfg == 1) GGL_DL(16, 3);
 #ifdef GGL_DEV
     else if (dl_cfg == 2) GGL_DL(16, 4);
@@ -785,7 +789,7 @@ static constexpr long SMALL_BATCH_TILES = 400;   // up to here the 32x32-tile ke
 //    9  k_symm_tn 32x32 tile, k-slab 32 (small batches below p = 384)
 //   16  k_symm_dl 64x64, double-buffered DMA      17  k_symm_dl 64x64, three DMA stages (concurrent parts)
 //   20  k_symm_dl 32x32, four DMA stages (small batches from p = 384)
-//   22 / 23  k_symm_dl 64x64 with EIGHT waves per workgroup (k-slab 16, four stages / k-slab 32, three stages)
+// A GGL_DEV build also has 22 / 23: k_symm_dl 64x64 with EIGHT waves per workgroup (no gain measured, see launch_dl).
 // A GGL_DEV build (libggl_hip_dev.so) adds the measured alternatives 1-5, 8, 11-13, 18, 19 and the ablations 6, 7, 10,
 // 14, 15, 21 (tools/bench_*.py).
 int symm_variants() { return 23; }
@@ -794,7 +798,7 @@ bool symm_variant_built(int v)
 #ifdef GGL_DEV
     return v >= 0 && v <= 23;
 #else
-    return v == 0 || v == 9 || v == 16 || v == 17 || v == 20 || v == 22 || v == 23;
+    return v == 0 || v == 9 || v == 16 || v == 17 || v == 20;
 #endif
 }
 

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <numeric>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <vector>
 
@@ -81,6 +82,8 @@ struct ggl_ctx {
     bool pipeline = true, pre_valid = false, pre_spec_pending = false;
     double* pre_beta = nullptr;                // host: beta the pre-launched chain was built for (K)
     long long pre_launched = 0, pre_dropped = 0;
+    int parts_small = 8;                       // smallest K (< 16, p >= 384) that is split into two concurrent parts; 0 = never
+                                               // (measured at p = 500: K = 8 +7.6 % iterations/s as 4 + 4, K = 4 -2.4 % as 2 + 2)
     bool fused_start = true;                   // speculative step: first step's start matrix as 2nd output of the B' launch
     bool fused_bounds = true;                  // spectral-bound partials from the epilogue of the B' launch (GGL_OPT_FUSED_BOUNDS)
     int theta_flat = 2;                        // GGL Theta-step for symmetric states: 0 tile pairs, 1 per-element kernel, 2 per-element with the K-column over four waves
@@ -160,6 +163,28 @@ static void prof_collect(ggl_ctx* c)   // call after a stream sync
         }
         c->ev_used[ph] = false;
     }
+}
+
+// rocSOLVER needs a rocBLAS handle; creating one costs ~0.1-0.3 s (library initialisation), and the eigendecomposition
+// route is only taken off the per-iteration path (exit checks, KKT, objective, fallbacks).  One handle per device for
+// the whole process, created on first use and re-pointed at the calling ctx's stream (a ctx is used by one host thread
+// at a time; the mutex only guards creation).
+static int blas_handle(ggl_ctx* c, rocblas_handle* out)
+{
+    static std::mutex mu;
+    static rocblas_handle handles[64] = {};
+    if (c->device < 0 || c->device >= 64) return fail(GGL_E_ARG, "bad argument: device index");
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!handles[c->device] && rocblas_create_handle(&handles[c->device]) != rocblas_status_success) {
+            handles[c->device] = nullptr;
+            return fail(GGL_E_SOLVER, "rocblas_create_handle failed");
+        }
+    }
+    if (rocblas_set_stream(handles[c->device], c->stream) != rocblas_status_success)
+        return fail(GGL_E_SOLVER, "rocblas_set_stream failed");
+    *out = handles[c->device];
+    return GGL_OK;
 }
 
 static bool use_jacobi(const ggl_ctx* c)
@@ -300,6 +325,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_FUSED_BOUNDS: c->fused_bounds = v != 0.0; break;
         case GGL_OPT_PIPELINE: c->pipeline = v != 0.0; break;
         case GGL_OPT_FUSED_START: c->fused_start = v != 0.0; break;
+        case GGL_OPT_PARTS_SMALL: c->parts_small = (int)v; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
     }
     c->spec_have = false;      // a schedule built under other settings is not reused
@@ -329,6 +355,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_FUSED_BOUNDS: *value = c->fused_bounds; break;
         case GGL_OPT_PIPELINE: *value = c->pipeline; break;
         case GGL_OPT_FUSED_START: *value = c->fused_start; break;
+        case GGL_OPT_PARTS_SMALL: *value = c->parts_small; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
     }
     return GGL_OK;
@@ -344,7 +371,7 @@ static void dev_env_options(ggl_ctx* c)
         {"GGL_TWO_STREAM", GGL_OPT_PARTS}, {"GGL_PARTS_MAX_TILES", GGL_OPT_PARTS_MAX_TILES},
         {"GGL_SYMM_VARIANT", GGL_OPT_SYMM_VARIANT}, {"GGL_SPIN_WAIT", GGL_OPT_SPIN_WAIT},
         {"GGL_FUSED_BOUNDS", GGL_OPT_FUSED_BOUNDS}, {"GGL_PIPELINE", GGL_OPT_PIPELINE},
-        {"GGL_FUSED_START", GGL_OPT_FUSED_START}};
+        {"GGL_FUSED_START", GGL_OPT_FUSED_START}, {"GGL_PARTS_SMALL", GGL_OPT_PARTS_SMALL}};
     for (const auto& t : tab)
         if (const char* v = getenv(t.name)) (void)set_option(c, t.opt, atof(v));
     if (const char* v = getenv("GGL_ROCSOLVER_SYEVJ")) c->use_syevj = atoi(v) != 0;
@@ -388,13 +415,6 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
 #endif
     int rc = ctx_alloc(c);
     if (rc != GGL_OK) { ggl_ctx_destroy(c); return rc; }
-    if (!use_jacobi(c)) {
-        if (rocblas_create_handle(&c->blas) != rocblas_status_success) {
-            ggl_ctx_destroy(c);
-            return fail(GGL_E_SOLVER, "rocblas_create_handle failed");
-        }
-        rocblas_set_stream(c->blas, c->stream);
-    }
     *out = c;
     return GGL_OK;
 }
@@ -408,7 +428,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
         if (const RcclApi* api = rccl_api(nullptr)) (void)api->CommDestroy(c->comm);
         c->comm = nullptr;
     }
-    if (c->blas) rocblas_destroy_handle(c->blas);
+    // (the rocBLAS handle is the process-wide one of blas_handle(): never destroyed here)
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
                       c->nsT, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->cuse, c->Lam[0],
@@ -569,6 +589,10 @@ static int eig_recon(ggl_ctx* c, double* A, double* out, double* Dv, int map, co
         return GGL_OK;
     }
     if (ph_eig >= 0) PB(c, ph_eig);
+    {
+        int rcb = blas_handle(c, &c->blas);
+        if (rcb) return rcb;
+    }
     if (c->use_syevj) {
         // experiment: rocSOLVER's Jacobi driver instead of syevd (GGL_ROCSOLVER_SYEVJ=1)
         rocblas_status sj = rocsolver_dsyevj_strided_batched(c->blas, rocblas_esort_none, rocblas_evect_original,
@@ -604,6 +628,10 @@ static int eigvals_only(ggl_ctx* c, double* A, double* Dv)
     if (use_jacobi(c)) {
         HIPCHK(launch_jacobi(c->stream, A, Dv, nullptr, nullptr, MAP_IDENT, nullptr, c->info, c->K, c->p));
         return GGL_OK;
+    }
+    {
+        int rcb = blas_handle(c, &c->blas);
+        if (rcb) return rcb;
     }
     rocblas_status st = rocsolver_dsyevd_strided_batched(c->blas, rocblas_evect_none, rocblas_fill_upper, c->p, A, c->p,
                                                          (rocblas_stride)c->p * c->p, Dv, c->p, c->E, c->p, c->info,
@@ -706,6 +734,9 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         const long t64 = (c->p + 63) / 64;
         const long ntile = t64 * (t64 + 1) / 2 * K;
         int nh = (K >= 16 && ntile >= 600 && ntile <= c->parts_max_tiles) ? std::min(c->ns_parts, K / 8) : 1;
+        // small batches of large matrices (the per-GPU slabs of a K-sharded run): one launch keeps the matrix cores ~40 %
+        // busy whatever the tile shape, two concurrent launch sequences of K/2 instances each overlap their bubbles
+        if (nh == 1 && c->parts_small && K >= c->parts_small && K < 16 && c->p >= 384 && c->ns_parts >= 2) nh = 2;
         nh = std::max(nh, 1);
         int Kh[ggl_ctx::MAX_PARTS], k0h[ggl_ctx::MAX_PARTS];
         for (int h = 0, k0 = 0; h < nh; ++h) {
@@ -715,7 +746,8 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         }
         const size_t pp = (size_t)c->p * c->p;
         const int nbb = norm_bounds_blocks(c->p);
-        const int var_parts = (c->symm_variant < 0 && nh > 1) ? 17 : c->symm_variant;
+        // concurrent parts of a large batch: the 3-stage 64x64 DMA kernel; parts of a small batch: the size rule
+        const int var_parts = (c->symm_variant < 0 && nh > 1 && K >= 16) ? 17 : c->symm_variant;
         c->last_parts = nh;
         c->last_variant = var_parts >= 0 ? var_parts : symm_auto_variant(Kh[0], c->p);
         const size_t region = (size_t)(NS_MAX_LAUNCHES - 4) / nh * NS_SLOT(K);      // coefficient slots per part
@@ -810,7 +842,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             if (spec) {
                 ns_run(sh, plans[h], c->coef + h * region, start_base_d + 5 * k0, c->W + k0 * pp, c->nsYP[0] + k0 * pp,
                        c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kh[h], c->p,
-                       (c->symm_variant < 0 && nh > 1) ? 17 : c->symm_variant, nh > 1 ? c->n : 0, fused[h] != nullptr);
+                       var_parts, nh > 1 ? c->n : 0, fused[h] != nullptr);
                 c->ns_launches_total += plans[h].products;
                 const double frac = (double)Kh[h] / K;
                 c->ns_units_frac += frac * plans[h].units;
@@ -864,7 +896,8 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         const int nrun = (nh > 1 && !any_stable) ? nh : 1;
         if (nrun == 1) { Kh[0] = K; k0h[0] = 0; }
         c->last_parts = nrun;
-        c->last_variant = (c->symm_variant >= 0) ? c->symm_variant : (nrun > 1 ? 17 : symm_auto_variant(K, c->p));
+        c->last_variant = (nrun > 1 && var_parts >= 0) ? var_parts
+                          : (c->symm_variant >= 0 ? c->symm_variant : symm_auto_variant(Kh[0], c->p));
         PB(c, GGL_PH_EIG_OMEGA2);
         for (int h = 0; h < nrun; ++h) {
             const int Kr = Kh[h], k0 = k0h[h];
@@ -881,7 +914,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                    c->p,
                    // tile choice by the work of the WHOLE batch: the other parts share the chip (measured +6.7 %);
                    // with parts, the 3-stage DMA pipeline is 2.8 % ahead of the double buffer (4 % behind without)
-                   (c->symm_variant < 0 && nrun > 1) ? 17 : c->symm_variant, nrun > 1 ? c->n : 0);
+                   nrun > 1 ? var_parts : c->symm_variant, nrun > 1 ? c->n : 0);
             c->ns_stable_calls += plans[h].stable ? 1 : 0;
             c->ns_launches_total += plans[h].products;
             // algorithmic work in units of (whole-stack) K p^3 flop

@@ -86,7 +86,7 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
  * parity tests run the iteration under each setting.  (A GGL_DEV build of the library -- libggl_hip_dev.so, used by
  * tools/ -- additionally maps the environment variables GGL_SPECULATE, GGL_SPEC_FACTOR, GGL_NS_MODE, GGL_NS_DEGREES,
  * GGL_THETA_FLAT, GGL_RANK_EIG, GGL_TWO_STREAM, GGL_PARTS_MAX_TILES, GGL_SYMM_VARIANT, GGL_SPIN_WAIT,
- * GGL_FUSED_BOUNDS, GGL_PIPELINE, GGL_FUSED_START onto them.) */
+ * GGL_FUSED_BOUNDS, GGL_PIPELINE, GGL_FUSED_START, GGL_PARTS_SMALL onto them.) */
 #define GGL_OPT_SPECULATE 1        /* [1] speculative Omega-step (schedule from the previous iteration's bounds)     */
 #define GGL_OPT_SPEC_FACTOR 2      /* [1.02] inflation of the previous bounds; < 1 forces validation misses (tests)  */
 #define GGL_OPT_NS_MODE 3          /* [0] as GGL_EIG_NS_MODE                                                          */
@@ -101,6 +101,7 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_FUSED_BOUNDS 11    /* [1] spectral-bound partials from the epilogue of the product launch (no norm pass) */
 #define GGL_OPT_PIPELINE 12        /* [1] ggl_admm_step launches the next iteration's Omega-step chain before it returns     */
 #define GGL_OPT_FUSED_START 13     /* [1] speculative step: the first step's start matrix is the B' launch's second output   */
+#define GGL_OPT_PARTS_SMALL 14     /* [8] smallest batch below 16 (p >= 384) that still runs as two concurrent parts; 0 = none */
 int ggl_ctx_set_option(ggl_ctx *ctx, int option, double value);
 int ggl_ctx_get_option(ggl_ctx *ctx, int option, double *value);
 

@@ -166,8 +166,9 @@ def test_c5_slab_dispatch_ggl_K32_p1000(stats):
 
 @pytest.mark.parametrize("K", [4, 8, 16])
 def test_headline_slab_dispatch(stats, K):
-    """Per-GPU slabs of the headline under K-sharding at 8 / 4 / 2 GPUs (what decides strong scaling): K = 4 and 8
-    take the 32x32 four-stage DMA kernel (variant 20), K = 16 (576 tile pairs) the double-buffered 64x64 one."""
+    """Per-GPU slabs of the headline under K-sharding at 8 / 4 / 2 GPUs (what decides strong scaling): K = 4 takes the
+    32x32 four-stage DMA kernel (variant 20), K = 8 the same as two concurrent parts of four, K = 16 (576 tile pairs) the
+    double-buffered 64x64 one."""
     from gglasso_amd import solver
     S, Om0 = _problem("GGL", K, 500, 1239)
     kw = dict(max_iter=5, tol=1e-20, rtol=1e-20)
@@ -176,4 +177,4 @@ def test_headline_slab_dispatch(stats, K):
     out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
     _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
     st = stats[-1]
-    assert (st["last_parts"], st["last_variant"]) == {4: (1, 20), 8: (1, 20), 16: (1, 16)}[K], st
+    assert (st["last_parts"], st["last_variant"]) == {4: (1, 20), 8: (2, 20), 16: (1, 16)}[K], st

@@ -86,8 +86,9 @@ def test_padded_stack_vs_oracle_mid_sizes(ext, sizes, latent):
         for k in range(K):
             assert np.abs(sol[nm][k] - ref[nm][k]).max() <= 1e-9, (nm, k)
     assert np.allclose(info['residual'], rinfo['residual'], rtol=1e-8)
-    ref, rinfo = orc.ext_ADMM_MGL(S, lam1, 0.03, 'GGL', Om0, G, tol=1e-8, rtol=1e-8, **kw)
-    (sol, info), _ = ext_checks.quiet(ext, S, lam1, 0.03, 'GGL', Om0, G, tol=1e-8, rtol=1e-8, measure=True, **kw)
+    # (looser tolerances than the fixtures' 1e-9: the oracle walks the instances in Python, ~0.1 s per iteration here)
+    ref, rinfo = orc.ext_ADMM_MGL(S, lam1, 0.03, 'GGL', Om0, G, tol=1e-6, rtol=1e-5, **kw)
+    (sol, info), _ = ext_checks.quiet(ext, S, lam1, 0.03, 'GGL', Om0, G, tol=1e-6, rtol=1e-5, measure=True, **kw)
     assert info['status'] == rinfo['status'] and len(info['residual']) == rinfo['iterations']
     for k in range(K):
         assert np.linalg.norm(sol['Theta'][k] - ref['Theta'][k]) <= 1e-8
