@@ -47,6 +47,7 @@ _SIGNATURES = {
     "ggl_get_state": ([_vp, _dp, _dp, _dp, _dp], _i),
     "ggl_set_lambda1_mask": ([_vp, _dp], _i),
     "ggl_admm_step": ([_vp, _d, _d, _d, _i, _i, _dp, _dp, _dp], _i),
+    "ggl_hint_last_step": ([_vp], _i),
     "ggl_step_omega": ([_vp, _d, _i, _dp], _i),
     "ggl_step_omega_spec": ([_vp, _d, _i, _dp], _i),
     "ggl_step_group_partial": ([_vp, _d, _d], _i),

@@ -80,6 +80,7 @@ struct ggl_ctx {
     // (norms -> rho rule -> next call).  The chain only writes scratch and Omega[cur^1]; it is consumed by the next call if
     // beta is unchanged and dropped otherwise (every other entry point drops it first).
     bool pipeline = true, pre_valid = false, pre_spec_pending = false;
+    bool last_step_hint = false;               // ggl_hint_last_step: the next ggl_admm_step is the caller's last one
     double* pre_beta = nullptr;                // host: beta the pre-launched chain was built for (K)
     long long pre_launched = 0, pre_dropped = 0;
     int parts_small = 8;                       // smallest K (< 16, p >= 384) that is split into two concurrent parts; 0 = never
@@ -1207,6 +1208,13 @@ extern "C" int ggl_norms_read(ggl_ctx* c, double out_norms[5])
     return finish_norms(c, 1, out_norms);      // 1 = a speculative step failed validation on some rank: repeat it
 }
 
+extern "C" int ggl_hint_last_step(ggl_ctx* c)
+{
+    ARGCHK(c, "ctx");
+    c->last_step_hint = true;
+    return GGL_OK;
+}
+
 extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lambda2, int reg, int latent,
                              const double* mu1, const double* nk, double out_norms[5])
 {
@@ -1237,7 +1245,9 @@ extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lamb
         if (rc) return rc;
         rc = ggl_step_finish_impl(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
     }
-    if (rc != GGL_OK || !c->pipeline || latent || !c->omega_ns || c->prof_on == 1) return rc;
+    const bool last = c->last_step_hint;
+    c->last_step_hint = false;
+    if (rc != GGL_OK || !c->pipeline || last || latent || !c->omega_ns || c->prof_on == 1) return rc;
     // Keep the GPU busy through the host's round trip: if the reference's rho rule (admm_solver.py:227-233) leaves rho
     // alone for these residuals, the next call will ask for the same beta -- launch its Omega-step chain now.
     const double r_t = std::sqrt(out_norms[3]), s_t = rho * std::sqrt(out_norms[4]);

@@ -89,6 +89,10 @@ class HipEngine:
             check(rc)
         return self._norms
 
+    def hint_last_step(self):
+        """The next ``step`` is the last one of the caller's loop: no chain is pre-launched behind it."""
+        self.lib.ggl_hint_last_step(self.h)
+
     def step_omega(self, rho, latent, nk, speculate=False):
         fn = self.lib.ggl_step_omega_spec if speculate else self.lib.ggl_step_omega
         check(fn(self.h, rho, int(latent), ptr(nk)))
@@ -342,6 +346,8 @@ def _run_admm(eng, reg, K_total, p, lambda1, lambda2, latent, mu1, nk, rho, tol,
                 if sq is None:
                     raise RuntimeError("K-sharded ADMM: the non-speculative repeat of an iteration was rejected")
         else:
+            if iter_t == max_iter - 1 and hasattr(eng, "hint_last_step"):
+                eng.hint_last_step()
             sq = eng.step(rho, lambda1, lambda2, reg, latent, mu1, nk)
             if comm is not None:
                 sq = comm.allreduce_norms(sq)

@@ -135,6 +135,10 @@ int ggl_set_lambda1_mask(ggl_ctx *ctx, const double *lam_pp_host);
  * chain over if its rho (and nk) are the same and drops it otherwise, and every other entry point drops it first. */
 int ggl_admm_step(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int reg, int latent,
                   const double *mu1, const double *nk, double out_norms[5]);
+/* The caller's loop ends after the next ggl_admm_step (max_iter reached, admm_solver.py:172): that call does not
+ * pre-launch a chain nobody would take over.  One-shot; without it the unused chain is merely dropped by the next
+ * entry point. */
+int ggl_hint_last_step(ggl_ctx *ctx);
 
 /* The same iteration split at the one point where a K-sharded GGL run has to exchange data
  * (sum_k u^2 couples the shards, ggl_helper.py:38-43):

@@ -3,22 +3,33 @@
 #   tools/round_artifacts.sh <tag>
 # -> gpurun_out/<tag>/bench_final.json, workload_*.json, pytest_gpu.txt and gpurun_out/prof_<tag>/ (rocprofv3)
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1
-tail -3 $O/pytest_gpu.txt
+( time python -m pytest tests -m gpu -x -q --durations=10 ) > $O/pytest_gpu.txt 2>&1
+tail -4 $O/pytest_gpu.txt
 bash tools/profile_round.sh $TAG > $O/profile.log 2>&1
 cd $R
 python bench.py > $O/bench_final.log 2>&1
 grep "^{" $O/bench_final.log > $O/bench_final.json
-for w in ggl_K20_p200 ggl_K4_p500 ggl_K32_p1000 fgl_K50_p500_latent ggl_K256_p1000; do
-  python bench.py --workload $w --steps 30 --warmup 8 --no-cpu-baseline 2>&1 | grep "^{" > $O/workload_$w.json
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep "^{" > $O/bench_driver_args.json
+for w in ggl_K20_p200 ggl_K4_p500 ggl_K8_p500 ggl_K16_p500 ggl_K32_p1000 fgl_K50_p500_latent ggl_K256_p1000; do
+  python bench.py --workload $w --steps 30 --warmup 8 --regions 5 --no-cpu-baseline 2>&1 | grep "^{" > $O/workload_$w.json
 done
-GGL_NS_MODE=2 python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>&1 | grep "^{" > $O/workload_ggl_K32_p500_stable.json
-python bench.py --eig 2 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep "^{" > $O/workload_ggl_K32_p500_rocsolver.json
-python tools/gap_analysis.py $(find $R/gpurun_out/prof_$TAG/stats -name "*kernel_trace.csv" | head -1) 4 > $O/timeline.txt 2>&1
+python bench.py --opt ns_mode=2 --steps 40 --warmup 10 --no-cpu-baseline 2>&1 | grep "^{" > $O/workload_ggl_K32_p500_stable.json
+python bench.py --eig 2 --steps 10 --warmup 3 --regions 3 --no-cpu-baseline 2>&1 | grep "^{" > $O/workload_ggl_K32_p500_rocsolver.json
+for w in ggl_K4_p500 ggl_K8_p500; do
+  GGL_BENCH_FORCE_DIST=1 python bench.py --workload $w --steps 30 --warmup 8 --regions 5 --no-cpu-baseline --comm capi 2>&1 | grep "^{" > $O/workload_${w}_sharded_1rank_rccl_capi.json
+done
+GGL_BENCH_FORCE_DIST=1 python bench.py --workload ggl_K4_p500 --steps 30 --warmup 8 --regions 5 --no-cpu-baseline --comm torch 2>&1 | grep "^{" > $O/workload_ggl_K4_p500_sharded_1rank_torch.json
+T=$(find $R/gpurun_out/prof_$TAG/stats -name "*kernel_trace.csv" | head -1)
+python tools/gap_analysis.py $T 8 > $O/timeline.txt 2>&1
 python tools/bench_grid.py 2>&1 | grep "^{" > $O/workload_sgl_grid_p1000_L20.json
-head -c 600 $O/bench_final.json
+python tools/bench_mgl_grid.py 2>&1 | grep "^{" > $O/workload_mgl_grid_8x1_K4_p500.json
+python tools/bench_mgl_grid.py --reg FGL --K 6 --p 300 --l1 4 --l2 3 2>&1 | grep "^{" > $O/workload_mgl_grid_4x3_fgl_K6_p300.json
+K=32 TOL=1e-10 python tools/parity_headline.py > $O/parity_headline.txt 2>&1
+head -c 700 $O/bench_final.json
+rm -rf $R/gpurun_out/prof_$TAG/*/*.db 2>/dev/null
+find $R/gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete
