@@ -461,3 +461,39 @@ def test_sharded_driver_rccl_behind_the_c_abi_single_rank(sol):
                 assert np.abs(a[nm] - b[nm]).max() <= 1e-10, (nm, env)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("reg,K,p", [("GGL", 4, 160), ("GGL", 16, 200), ("FGL", 3, 150), ("GGL", 8, 400)])
+def test_pipelined_iterations_are_bitwise_the_unpipelined_ones(sol, reg, K, p, monkeypatch):
+    """GGL_OPT_PIPELINE: ggl_admm_step launches the next iteration's Omega-step chain before it returns.  The chain only
+    touches scratch and Omega[cur^1], so the iterates must be BITWISE those of the unpipelined run -- with rho changes
+    (chains dropped), with the state read in the middle of the loop (chain dropped by ggl_get_state), and at the end."""
+    from gglasso_amd import synth, solver
+    S, _ = synth.make_problem(reg, K=K, p=p, N=2 * p, seed=43)
+    Om0 = np.stack([np.eye(p)] * K)
+    outs, stats = [], []
+    for pipe in (0, 1):
+        eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"pipeline": pipe})
+        nk = np.ones(K)
+        rho, mid = 1.0, None
+        for it in range(16):
+            sq = eng.step(rho, 0.05, 0.01, reg, False, None, nk).copy()
+            r_t, s_t, _, _ = solver.residuals_from_norms(sq, rho, 1e-20, 1e-20, 1.0)
+            new = solver.next_rho(rho, r_t, s_t)
+            if new != rho:
+                eng.scale_X(rho / new)
+            rho = new
+            if it == 9:
+                mid = eng.state()          # any entry point other than the step drops a pre-launched chain first
+        outs.append((mid, eng.state(), rho))
+        stats.append(eng.ns_stats())
+        eng.close()
+    for a, b in zip(outs[0][:2], outs[1][:2]):
+        for nm in ("Omega", "Theta", "X"):
+            assert np.array_equal(a[nm], b[nm]), nm
+    assert outs[0][2] == outs[1][2]
+    assert stats[0]["pre_dropped"] == 0 and stats[1]["spec_calls"] > stats[0]["spec_calls"]
+    assert stats[1]["pre_dropped"] >= 1                      # the chain behind iteration 10 was dropped by state()
+    ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, reg, Om0, max_iter=16, tol=1e-20, rtol=1e-20)
+    for nm in ("Omega", "Theta", "X"):
+        assert np.abs(outs[1][1][nm] - ref[nm]).max() <= 1e-9, nm
