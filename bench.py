@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--regions", type=int, default=7, help="how often the timed region of `steps` iterations is run")
     ap.add_argument("--workload", default="ggl_K32_p500", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=24)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eig", type=int, default=0, help="GGL_EIG_* selector (0 auto)")

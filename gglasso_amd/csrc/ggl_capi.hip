@@ -482,7 +482,8 @@ static int drop_prelaunch(ggl_ctx* c)
     if (!c->pre_valid) return GGL_OK;
     c->pre_valid = false;
     c->pre_dropped += 1;
-    c->spec_have = false;          // the bounds of a chain that was never validated are not carried over
+    // (spec_c still holds the bounds of the last VALIDATED chain: the replacement chain is built from them exactly as
+    // the dropped one was, so dropping changes no iterate)
     HIPCHK(hipStreamSynchronize(c->stream));      // the chain's parts were joined into the main stream when it was launched
     for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) c->spec_flag_h[h] = 0;
     return GGL_OK;
@@ -759,7 +760,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         // bounds (W moves little between ADMM iterations and the spectrum usually shrinks); the schedule is built
         // from them NOW and the products follow the bound kernels without the host round trip.
         bool spec = allow_spec && c->spec_enable && c->spec_have && !latent && c->spec_cool == 0;
-        if (allow_spec && c->spec_cool > 0) c->spec_cool -= 1;
+        if (allow_spec && !only_spec && c->spec_cool > 0) c->spec_cool -= 1;      // one tick per iteration, not per attempt
         for (int k = 0; spec && k < K; ++k) spec = (c->par_h[k] == c->spec_beta[k]);
         double* fused[ggl_ctx::MAX_PARTS] = {};      // speculative step: the first step's start as 2nd output of the B' launch
         if (spec) {
@@ -1208,6 +1209,48 @@ extern "C" int ggl_norms_read(ggl_ctx* c, double out_norms[5])
     return finish_norms(c, 1, out_norms);      // 1 = a speculative step failed validation on some rank: repeat it
 }
 
+// Pipelining across iterations (ggl_ctx::pipeline).  take_prelaunched: beta_k = nk/rho of the step about to run is in
+// par_h slot 0; if the chain launched at the end of the previous call was built for exactly this beta it becomes this
+// iteration's Omega-step, otherwise it is forgotten (the chain the caller launches next follows it on the same streams,
+// zeroes its validation flags again and overwrites everything it wrote).
+static bool take_prelaunched(ggl_ctx* c, int latent)
+{
+    if (!c->pre_valid) return false;
+    bool have = !latent;
+    for (int k = 0; have && k < c->K; ++k) have = (c->par_h[k] == c->pre_beta[k]);
+    c->pre_valid = false;
+    if (!have) {
+        c->pre_dropped += 1;
+        return false;
+    }
+    c->cur ^= 1;
+    c->spec_pending = c->pre_spec_pending;
+    return true;
+}
+
+// After a validated iteration: keep the GPU busy through the host's round trip.  If the reference's rho rule
+// (admm_solver.py:227-233) leaves rho alone for these residuals, the next call will ask for the same beta -- launch its
+// Omega-step chain now (beta is in parameter slot 0 already).  out_norms are the sums the caller is about to see.
+static int maybe_prelaunch(ggl_ctx* c, double rho, const double out_norms[5])
+{
+    const bool last = c->last_step_hint;
+    c->last_step_hint = false;
+    if (!c->pipeline || last || !c->omega_ns || c->prof_on == 1) return GGL_OK;
+    const double r_t = std::sqrt(out_norms[3]), s_t = rho * std::sqrt(out_norms[4]);
+    if (r_t >= 10.0 * s_t || s_t >= 10.0 * r_t) return GGL_OK;
+    const int cur0 = c->cur;
+    int rc = omega_step(c, 0, nullptr, /*allow_spec=*/true, /*only_spec=*/true);
+    if (rc == GGL_NOT_LAUNCHED) return GGL_OK;
+    if (rc) return rc;
+    c->cur = cur0;                               // Omega_t stays the current iterate until the chain is taken over
+    c->pre_spec_pending = c->spec_pending;
+    c->spec_pending = false;
+    c->pre_valid = true;
+    c->pre_launched += 1;
+    memcpy(c->pre_beta, c->par_h, c->K * sizeof(double));
+    return GGL_OK;
+}
+
 extern "C" int ggl_hint_last_step(ggl_ctx* c)
 {
     ARGCHK(c, "ctx");
@@ -1224,17 +1267,7 @@ extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lamb
     CopySegs sg;
     int rc = upload_par(c, 0, nk, 1.0, rho, &sg);   // beta_k = nk/rho    (admm_solver.py:180,184)
     if (rc) return rc;
-    bool have = c->pre_valid && !latent;
-    for (int k = 0; have && k < c->K; ++k) have = (c->par_h[k] == c->pre_beta[k]);
-    if (have) {
-        // the chain launched at the end of the previous call was built for exactly this beta: take it over
-        c->pre_valid = false;
-        c->cur ^= 1;
-        c->spec_pending = c->pre_spec_pending;
-    } else {
-        // (a chain for another beta may still be running: the new one follows it on the same streams, zeroes its
-        // validation flags again and overwrites everything it wrote)
-        if (c->pre_valid) { c->pre_valid = false; c->pre_dropped += 1; c->spec_have = false; }
+    if (!take_prelaunched(c, latent)) {
         rc = omega_step(c, latent, &sg, /*allow_spec=*/true);
         if (rc) return rc;
     }
@@ -1245,24 +1278,8 @@ extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lamb
         if (rc) return rc;
         rc = ggl_step_finish_impl(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
     }
-    const bool last = c->last_step_hint;
-    c->last_step_hint = false;
-    if (rc != GGL_OK || !c->pipeline || last || latent || !c->omega_ns || c->prof_on == 1) return rc;
-    // Keep the GPU busy through the host's round trip: if the reference's rho rule (admm_solver.py:227-233) leaves rho
-    // alone for these residuals, the next call will ask for the same beta -- launch its Omega-step chain now.
-    const double r_t = std::sqrt(out_norms[3]), s_t = rho * std::sqrt(out_norms[4]);
-    if (r_t >= 10.0 * s_t || s_t >= 10.0 * r_t) return GGL_OK;
-    const int cur0 = c->cur;
-    rc = omega_step(c, 0, nullptr, /*allow_spec=*/true, /*only_spec=*/true);     // beta is in parameter slot 0 already
-    if (rc == GGL_NOT_LAUNCHED) return GGL_OK;
-    if (rc) return rc;
-    c->cur = cur0;                               // Omega_t stays the current iterate until the chain is taken over
-    c->pre_spec_pending = c->spec_pending;
-    c->spec_pending = false;
-    c->pre_valid = true;
-    c->pre_launched += 1;
-    memcpy(c->pre_beta, c->par_h, c->K * sizeof(double));
-    return GGL_OK;
+    if (rc != GGL_OK || latent) return rc;
+    return maybe_prelaunch(c, rho, out_norms);
 }
 
 // ---- K independent single problems with their own rho / lambda1 (batched lambda path) ----------
@@ -1802,9 +1819,11 @@ static int sharded_pass(ggl_ctx* c, double rho, double lambda1, double lambda2, 
     CopySegs sg;
     int rc = upload_par(c, 0, nk, 1.0, rho, &sg);
     if (rc) return rc;
-    // with MAX_PARTS parts there is no flag slot left for the all-reduced flag
-    rc = omega_step(c, 0, &sg, speculate && c->ns_parts < ggl_ctx::MAX_PARTS);
-    if (rc) return rc;
+    if (!(speculate && take_prelaunched(c, 0))) {
+        // with MAX_PARTS parts there is no flag slot left for the all-reduced flag
+        rc = omega_step(c, 0, &sg, speculate && c->ns_parts < ggl_ctx::MAX_PARTS);
+        if (rc) return rc;
+    }
     launch_group_partial(c->stream, c->sqwork, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
     launch_sum_chunks(c->stream, c->groupsq, c->sqwork, ggl_chunks(c->K, c->p), c->p);
     launch_spec_pack(c->stream, c->spec_pending ? c->spec_flag : nullptr, c->groupsq + (size_t)c->p * c->p);
@@ -1823,14 +1842,16 @@ extern "C" int ggl_admm_step_sharded(ggl_ctx* c, double rho, double lambda1, dou
     ARGCHK(c->comm, "ggl_comm_init first");
     ARGCHK(rho > 0 && lambda1 > 0 && lambda2 > 0, "rho, lambda1, lambda2 must be positive");
     HIPCHK(hipSetDevice(c->device));
-    DROP_PRE(c);
     int rc = sharded_pass(c, rho, lambda1, lambda2, nk, true, out_norms);
-    if (rc != GGL_SPEC_RETRY) return rc;
-    // the reduced validation flag says some rank's schedule did not cover its spectrum: every rank left its iterate alone
-    // and repeats the iteration bounds-first (all ranks take this branch together: the flag is the all-reduced one)
-    rc = sharded_pass(c, rho, lambda1, lambda2, nk, false, out_norms);
-    if (rc == GGL_SPEC_RETRY) return fail(GGL_E_SOLVER, "K-sharded step: the non-speculative repeat was rejected");
-    return rc;
+    if (rc == GGL_SPEC_RETRY) {
+        // the reduced validation flag says some rank's schedule did not cover its spectrum: every rank left its iterate
+        // alone and repeats the iteration bounds-first (all ranks take this branch together: the flag is the all-reduced one)
+        rc = sharded_pass(c, rho, lambda1, lambda2, nk, false, out_norms);
+        if (rc == GGL_SPEC_RETRY) return fail(GGL_E_SOLVER, "K-sharded step: the non-speculative repeat was rejected");
+    }
+    if (rc != GGL_OK) return rc;
+    // the sums are the GLOBAL ones: every rank takes the same decision here (and the chain is local work anyway)
+    return (c->ns_parts < ggl_ctx::MAX_PARTS) ? maybe_prelaunch(c, rho, out_norms) : GGL_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -323,6 +323,8 @@ def _run_admm(eng, reg, K_total, p, lambda1, lambda2, latent, mu1, nk, rho, tol,
             start = time.time()
         if sharded_ggl and getattr(comm, "capi", False):
             # RCCL behind the C ABI: Omega-step, both all-reduces, Theta-step and the norms in one call
+            if iter_t == max_iter - 1:
+                eng.hint_last_step()
             sq = eng.step_sharded(rho, lambda1, lambda2, nk)
         elif sharded_ggl:
             # device_norms: HIP engine over RCCL.  The Omega-step may then run speculatively; its validation flag
