@@ -956,8 +956,7 @@ extern "C" int ggl_step_group_partial(ggl_ctx* c, double rho, double lambda1)
     ARGCHK(c, "ctx");
     ARGCHK(rho > 0, "rho must be positive");
     HIPCHK(hipSetDevice(c->device));
-    launch_group_partial(c->stream, c->sqwork, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
-    launch_sum_chunks(c->stream, c->groupsq, c->sqwork, ggl_chunks(c->K, c->p), c->p);
+    launch_group_sums_full(c->stream, c->groupsq, c->sqwork, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
     launch_spec_pack(c->stream, c->spec_pending ? c->spec_flag : nullptr, c->groupsq + (size_t)c->p * c->p);
     HIPCHK(hipGetLastError());
     return GGL_OK;
@@ -1166,7 +1165,7 @@ static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double l
             c->sharded_check = true;
         }
         // the flat GGL kernel computes every (i,j) from its own inputs: only for an exactly symmetric state
-        const int flat = (c->theta_flat && c->state_symmetric && !groupsq_ready) ? c->theta_flat : 0;
+        const int flat = (c->theta_flat && c->state_symmetric) ? c->theta_flat : 0;
         HIPCHK(launch_theta_pair(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, l1, l2,
                                  groupsq_ready ? c->groupsq : nullptr, c->sqwork, latent ? 0 : 1, c->partials, c->K,
                                  c->p, flat, (c->spec_pending || c->sharded_check) ? c->spec_flag : nullptr));
@@ -1824,8 +1823,7 @@ static int sharded_pass(ggl_ctx* c, double rho, double lambda1, double lambda2, 
         rc = omega_step(c, 0, &sg, speculate && c->ns_parts < ggl_ctx::MAX_PARTS);
         if (rc) return rc;
     }
-    launch_group_partial(c->stream, c->sqwork, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
-    launch_sum_chunks(c->stream, c->groupsq, c->sqwork, ggl_chunks(c->K, c->p), c->p);
+    launch_group_sums_full(c->stream, c->groupsq, c->sqwork, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
     launch_spec_pack(c->stream, c->spec_pending ? c->spec_flag : nullptr, c->groupsq + (size_t)c->p * c->p);
     HIPCHK(hipGetLastError());
     if ((rc = ggl_allreduce_groupsq(c))) return rc;

@@ -78,7 +78,7 @@ int theta_partial_blocks(int p, int reg, int K, int flat);
 // GGL/FGL Theta-step on upper-triangle K-vectors (prox_p, ggl_helper.py:190-207), mirrored.
 //   fuse_dual != 0 (non-latent): also X += Omega - Theta and norms partials [K][nblk][5].
 //   fuse_dual == 0 (latent): writes Theta and C = (Theta - X) - Omega  (admm_solver.py:198).
-// groupsq != null (GGL only): use this (p,p) array as sum_k u^2 instead of computing it (K-sharded).
+// groupsq != null (GGL only): use this FULL symmetric (p,p) array as sum_k u^2 instead of computing it (K-sharded).
 // Returns hipErrorInvalidValue if K is beyond what the FGL kernel's LDS scan buffer holds.
 // sqwork: ggl_chunks(K,p)*p*p doubles of scratch for the GGL sums of squares (unused when groupsq is given).
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C,
@@ -97,8 +97,12 @@ int ggl_chunks(int K, int p);
 // GGL pass 1 only: sq[c](p,p)[i<j] = sum_{k in chunk c} soft(Omega+L+X, l1)^2,  c < ggl_chunks(K,p)
 void launch_group_partial(hipStream_t st, double* sq, const double* Omega, const double* L,
                           const double* X, double l1, int K, int p);
-// out(p,p) = sum_c sq[c]
+// out(p,p) = sum_c sq[c], mirrored into the FULL symmetric matrix (diagonal 0)
 void launch_sum_chunks(hipStream_t st, double* out, const double* sq, int nsq, int p);
+// GROUPSQ of a K-sharded run: the full symmetric (p,p) matrix of this rank's sum_k soft(Omega+L+X, l1)^2 (per-element
+// kernel for K <= GGL_FLAT_MAX_K, tile pairs + launch_sum_chunks beyond; sqwork: ggl_chunks(K,p)*p*p doubles)
+void launch_group_sums_full(hipStream_t st, double* out, double* sqwork, const double* Omega, const double* L,
+                            const double* X, double l1, int K, int p);
 // stateless prox_p: out = prox_p(V)   (V symmetric stack; upper triangle decides)
 hipError_t launch_prox_p(hipStream_t st, int reg, double* out, const double* V, double l1, double l2,
                          int K, int p, double* sqwork);

@@ -129,15 +129,46 @@ __global__ __launch_bounds__(256) void k_group_partial(double* __restrict__ sq, 
         if (ok[q]) sq[(size_t)blockIdx.y * pp + off[q]] = ss[q];
 }
 
-// out[i][j] = sum_c sq[c][i][j]   (upper triangle entries only matter)
+// out = the FULL symmetric (p,p) matrix of sum_c sq[c][i][j] (sq holds the strict upper triangle; diagonal 0): what the
+// ranks of a K-sharded run all-reduce, whichever Theta kernel each of them runs afterwards
 __global__ __launch_bounds__(256) void k_sum_chunks(double* __restrict__ out, const double* __restrict__ sq, int nsq,
-                                                    size_t pp)
+                                                    int p)
 {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pp; i += (size_t)gridDim.x * 256) {
+    const size_t pp = (size_t)p * p;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < pp; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
         double s = 0.0;
-        for (int c = 0; c < nsq; ++c) s += sq[(size_t)c * pp + i];
-        out[i] = s;
+        if (i != j) {
+            const size_t src = (i < j) ? e : (size_t)j * p + i;
+            for (int c = 0; c < nsq; ++c) s += sq[(size_t)c * pp + src];
+        }
+        out[e] = s;
     }
+}
+
+// the same matrix from one thread per element (K <= GGL_FLAT_MAX_K): sum_k soft(Omega + L + X, l1)^2 of the element's own
+// K-column, no tile pairs, no chunk buffer
+__global__ __launch_bounds__(256) void k_group_partial_flat(double* __restrict__ out, const double* __restrict__ Omega,
+                                                            const double* __restrict__ L, const double* __restrict__ X,
+                                                            double l1, int K, int p)
+{
+    const size_t pp = (size_t)p * p;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= pp) return;
+    const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
+    double ss = 0.0;
+    if (i != j) {
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const size_t o = (size_t)k * pp + e;
+            double v = Omega[o];
+            if (L) v += L[o];
+            if (X) v += X[o];
+            const double u = soft(v, l1);
+            ss += u * u;
+        }
+    }
+    out[e] = ss;
 }
 
 template <bool FUSE_DUAL>
@@ -275,7 +306,19 @@ void launch_sum_chunks(hipStream_t st, double* out, const double* sq, int nsq, i
     const size_t pp = (size_t)p * p;
     int blocks = (int)((pp + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_sum_chunks, dim3(blocks), dim3(256), 0, st, out, sq, nsq, pp);
+    hipLaunchKernelGGL(k_sum_chunks, dim3(blocks), dim3(256), 0, st, out, sq, nsq, p);
+}
+
+// GROUPSQ of a K-sharded run: the full symmetric (p,p) matrix of this rank's sum_k u^2
+void launch_group_sums_full(hipStream_t st, double* out, double* sqwork, const double* Omega, const double* L,
+                            const double* X, double l1, int K, int p)
+{
+    if (K <= GGL_FLAT_MAX_K) {
+        hipLaunchKernelGGL(k_group_partial_flat, dim3(flat_blocks(p)), dim3(256), 0, st, out, Omega, L, X, l1, K, p);
+        return;
+    }
+    launch_group_partial(st, sqwork, Omega, L, X, l1, K, p);
+    launch_sum_chunks(st, out, sqwork, ggl_chunks(K, p), p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -500,8 +543,9 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
                                                         const double* __restrict__ L, double l1, double l2,
                                                         double* __restrict__ partials, int K, int p,
                                                         const int* __restrict__ skip, const double* __restrict__ l1G,
-                                                        const double* __restrict__ l2G)
+                                                        const double* __restrict__ l2G, const double* __restrict__ gsq)
 {
+    // gsq != null (K-sharded run): the full (p,p) matrix of sum_k u^2 over ALL ranks' instances replaces the local sum
     __shared__ double scratch[GGL_NNORM * 4];
     if (spec_failed(skip)) return;
     const size_t pp = (size_t)p * p;
@@ -529,12 +573,16 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
             }
         }
         double ss = 0.0;
+        if (gsq) {
+            ss = gsq[e];
+        } else {
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (k < K) {
-                const double l = L ? L[(size_t)k * pp + e] : 0.0;
-                const double u = soft((om[k] + l) + x[k], l1);
-                ss += u * u;
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K) {
+                    const double l = L ? L[(size_t)k * pp + e] : 0.0;
+                    const double u = soft((om[k] + l) + x[k], l1);
+                    ss += u * u;
+                }
             }
         }
         const double a = fmax(sqrt(ss), l2);
@@ -591,7 +639,7 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4(double* __restrict__ Th
                                                          const double* __restrict__ L, double l1, double l2,
                                                          double* __restrict__ partials, int K, int p,
                                                          const int* __restrict__ skip, const double* __restrict__ l1G,
-                                                         const double* __restrict__ l2G)
+                                                         const double* __restrict__ l2G, const double* __restrict__ gsq)
 {
     __shared__ double ssh[4][64];
     __shared__ double scratch[GGL_NNORM * 4];
@@ -638,7 +686,7 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4(double* __restrict__ Th
         ssh[wid][lane] = ss;
         __syncthreads();
         if (live) {
-            const double tot = (ssh[0][lane] + ssh[1][lane]) + (ssh[2][lane] + ssh[3][lane]);
+            const double tot = gsq ? gsq[e] : (ssh[0][lane] + ssh[1][lane]) + (ssh[2][lane] + ssh[3][lane]);
             const double a = fmax(sqrt(tot), l2);
             const double amul = a - l2;
             const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
@@ -688,25 +736,27 @@ static inline int flat4_blocks(int p) { return (int)(((size_t)p * p + 64 * FLAT4
 template <int KQ>
 static void launch_flat4(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                          const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual, double* partials,
-                         int K, int p, const int* skip, int G = 1, const double* l1G = nullptr, const double* l2G = nullptr)
+                         int K, int p, const int* skip, int G = 1, const double* l1G = nullptr, const double* l2G = nullptr,
+                         const double* gsq = nullptr)
 {
     dim3 grid(flat4_blocks(p), G), blk(256);
     if (fuse_dual)
-        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
+        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
     else
-        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
+        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
 }
 
 template <int KMAX>
 static void launch_flat(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                         const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual, double* partials,
-                        int K, int p, const int* skip, int G = 1, const double* l1G = nullptr, const double* l2G = nullptr)
+                        int K, int p, const int* skip, int G = 1, const double* l1G = nullptr, const double* l2G = nullptr,
+                        const double* gsq = nullptr)
 {
     dim3 grid(flat_blocks(p), G), blk(256);
     if (fuse_dual)
-        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
+        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
     else
-        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
+        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
 }
 
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C, const double* Omega,
@@ -714,15 +764,17 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
                              const double* groupsq, double* sqwork, int fuse_dual, double* partials, int K, int p,
                              int flat, const int* skip)
 {
-    if (reg == 1 && !groupsq && K <= GGL_FLAT_MAX_K && use_flat4(K, flat)) {
-        if (K <= 16) launch_flat4<4>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
-        else launch_flat4<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
+    // per-element kernels (exactly symmetric state): the group sums are the element's own K-column, or -- K-sharded run --
+    // the all-reduced FULL matrix `groupsq` (launch_group_sums_full on every rank)
+    if (reg == 1 && K <= GGL_FLAT_MAX_K && use_flat4(K, flat)) {
+        if (K <= 16) launch_flat4<4>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
+        else launch_flat4<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
         return hipGetLastError();
     }
-    if (reg == 1 && flat && !groupsq && K <= GGL_FLAT_MAX_K) {
-        if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
-        else if (K <= 16) launch_flat<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
-        else launch_flat<32>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
+    if (reg == 1 && flat && K <= GGL_FLAT_MAX_K) {
+        if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
+        else if (K <= 16) launch_flat<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
+        else launch_flat<32>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
         return hipGetLastError();
     }
     if (reg == 1) {

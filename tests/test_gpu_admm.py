@@ -459,6 +459,20 @@ def test_sharded_driver_rccl_behind_the_c_abi_single_rank(sol):
             assert len(ia["residual"]) == len(ib["residual"])
             for nm in ("Omega", "Theta", "X"):
                 assert np.abs(a[nm] - b[nm]).max() <= 1e-10, (nm, env)
+        # a dual start that is symmetric only to ~1e-8: the mirroring tile-pair Theta kernel reads the upper triangle of
+        # the all-reduced FULL group-sum matrix (the per-element kernels would read both triangles)
+        K, p = 4, 150
+        S, _ = synth.make_problem("GGL", K, p, seed=33)
+        Om0 = np.stack([np.eye(p)] * K)
+        rng = np.random.default_rng(6)
+        X0 = 0.01 * rng.standard_normal((K, p, p))
+        X0 = 0.5 * (X0 + X0.transpose(0, 2, 1)) + 1e-8 * np.triu(rng.standard_normal((K, p, p)), 1)
+        (a, _), _ = quiet(ADMM_MGL_sharded, S, 0.05, 0.02, "GGL", Om0, K, RcclComm(), X_0=X0, max_iter=8, tol=1e-20, rtol=1e-20)
+        (b, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.02, "GGL", Om0, X_0=X0, max_iter=8, tol=1e-20, rtol=1e-20)
+        ref, _ = orc.ADMM_MGL(S, 0.05, 0.02, "GGL", Om0, X_0=X0, max_iter=8, tol=1e-20, rtol=1e-20)
+        for nm in ("Omega", "Theta", "X"):
+            assert np.abs(a[nm] - b[nm]).max() <= 1e-10, nm
+            assert np.abs(a[nm] - ref[nm]).max() <= 1e-9, nm
     finally:
         dist.destroy_process_group()
 
@@ -497,3 +511,17 @@ def test_pipelined_iterations_are_bitwise_the_unpipelined_ones(sol, reg, K, p, m
     ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, reg, Om0, max_iter=16, tol=1e-20, rtol=1e-20)
     for nm in ("Omega", "Theta", "X"):
         assert np.abs(outs[1][1][nm] - ref[nm]).max() <= 1e-9, nm
+
+
+def test_fgl_K_beyond_the_scan_buffer_is_refused_with_a_message(sol):
+    """FGL with more instances than fit one workgroup's LDS scan buffer (Condat's scan is serial
+    along K) used to surface as a bare hipErrorInvalidValue; it is an argument error with a message now."""
+    from gglasso_amd import ops
+    K, p = 330, 6
+    S = np.stack([np.eye(p)] * K)
+    with pytest.raises(AssertionError, match="exceeds the 318 instances"):
+        quiet(sol.ADMM_MGL, S, 0.05, 0.01, "FGL", S.copy(), max_iter=2)
+    with pytest.raises(AssertionError, match="exceeds the 318 instances"):
+        ops.prox_p(S, 0.1, 0.1, "FGL")
+    (s, info), _ = quiet(sol.ADMM_MGL, S[:318], 0.05, 0.01, "FGL", S[:318].copy(), max_iter=2)      # the limit itself works
+    assert info["status"] == "max iterations reached" and np.isfinite(s["Theta"]).all()
