@@ -524,4 +524,4 @@ def test_fgl_K_beyond_the_scan_buffer_is_refused_with_a_message(sol):
     with pytest.raises(AssertionError, match="exceeds the 318 instances"):
         ops.prox_p(S, 0.1, 0.1, "FGL")
     (s, info), _ = quiet(sol.ADMM_MGL, S[:318], 0.05, 0.01, "FGL", S[:318].copy(), max_iter=2)      # the limit itself works
-    assert info["status"] == "max iterations reached" and np.isfinite(s["Theta"]).all()
+    assert info["status"] in ("optimal", "max iterations reached") and np.isfinite(s["Theta"]).all()
