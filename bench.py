@@ -53,7 +53,7 @@ WORKLOADS = {
 # product-kernel instances of csrc/gemm_sym.hip by the variant number ggl_ns_stats reports
 VARIANT_NAMES = {0: "k_symm_tn<64,16,32,32> (register-staged)", 9: "k_symm_tn<32,32,16,16> (register-staged)",
                  16: "k_symm_dl<16,2,0,64> (direct-to-LDS)", 17: "k_symm_dl<16,3,0,64> (direct-to-LDS)",
-                 20: "k_symm_dl<32,4,0,32> (direct-to-LDS)"}
+                 20: "k_symm_dl<32,2,0,32> (direct-to-LDS, 32x32 tiles)"}
 
 
 def phase_model(phase, reg, K, p, latent, eig_jacobi, omega_ns=False):

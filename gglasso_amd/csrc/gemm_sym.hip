@@ -53,9 +53,8 @@ __host__ __device__ inline int xcd_grid(int ntiles, int K)
     const int g = xcd_share(K);
     return g ? NXCD * ((ntiles + g - 1) / g) : ntiles * K;
 }
-__device__ __forceinline__ bool decode_block_xcd(int ntiles, int K, int& k, int& tile)
+__device__ __forceinline__ bool decode_block_xcd(int ntiles, int K, int& k, int& tile, int L)
 {
-    const int L = blockIdx.x;
     if (K >= NXCD) {
         const int xcd = L % NXCD, slot = L / NXCD;
         k = (slot / ntiles) * NXCD + xcd;
@@ -72,6 +71,11 @@ __device__ __forceinline__ bool decode_block_xcd(int ntiles, int K, int& k, int&
     k = L / ntiles;
     tile = L % ntiles;
     return true;
+}
+
+__device__ __forceinline__ bool decode_block_xcd(int ntiles, int K, int& k, int& tile)
+{
+    return decode_block_xcd(ntiles, K, k, tile, (int)blockIdx.x);
 }
 
 // ABL != 0: timing ablations and the timeline probe, instantiated by GGL_DEV builds only (tools/bench_tail.py)
@@ -311,6 +315,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -323,13 +328,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 // cover the load latency that bounds the small-batch regime); ABL 1: no mirror write (timing ablation)
 // NW: waves per workgroup (4: 2 x 2 waves of BM/2 x BM/2; 8: 4 x 2 waves of BM/4 x BM/2 -- two waves per SIMD, for batches
 // so small that only one workgroup lands on a CU and a lone wave per SIMD cannot hide its LDS round trips and barriers)
-template <int BK, int NSTG, int ABL = 0, int BM = 64, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ A, const double* __restrict__ B,
-                                                 double* __restrict__ C, double* __restrict__ C2,
-                                                 const double* __restrict__ E, const double* __restrict__ coef, int K,
-                                                 int p, const double* __restrict__ A1, const double* __restrict__ B1,
-                                                 double* __restrict__ C1, int K1, double* __restrict__ maxdev,
-                                                 double* __restrict__ rowpart, double* __restrict__ fropart)
+// symm_dl_tile: one output tile (instance k of the combined batch, tile pair b) -- the whole body of k_symm_dl
+template <int BK, int NSTG, int ABL, int BM, int NW>
+__device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const double* __restrict__ B,
+                                             double* __restrict__ C, double* __restrict__ C2,
+                                             const double* __restrict__ E, const double* __restrict__ coef, int K,
+                                             int p, const double* __restrict__ A1, const double* __restrict__ B1,
+                                             double* __restrict__ C1, int K1, double* __restrict__ maxdev,
+                                             double* __restrict__ rowpart, double* __restrict__ fropart, int k, int b)
 {
     // rowpart / fropart != null: the launch also leaves what a spectral bound of C needs, with no pass over C --
     // rowpart[k][s][i] = sum over the columns of tile-column s of |C[i][.]| (summed over s: the row sums of |C|) and
@@ -348,8 +354,6 @@ __global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ 
     static_assert(NSTG * 2 * SLAB >= BM * BM, "the mirror tile reuses the slab storage");
     __shared__ __attribute__((aligned(16))) double smem[NSTG * 2 * SLAB];   // [buf][A|B][BK][64]; later the mirror tile
     const int T = (p + BM - 1) / BM;
-    int k, b;
-    if (!decode_block_xcd(T * (T + 1) / 2, K + K1, k, b)) return;
     const int blockTile = b;
     const bool second = k >= K;
     const int kk = second ? k - K : k;
@@ -395,7 +399,9 @@ __global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ 
         const int buf = s % NSTG;
         // this wave's DMA of slab s has landed: at most the later slabs' instructions may still be in flight
         const int ahead = min(NSTG - 2, S - 1 - s);
-        if (NSTG >= 4 && ahead >= 2) wait_vmcnt<4 * IPW>();
+        if (NSTG >= 6 && ahead >= 4) wait_vmcnt<(NSTG >= 6 ? 8 * IPW : 0)>();
+        else if (NSTG >= 5 && ahead >= 3) wait_vmcnt<(NSTG >= 5 ? 6 * IPW : 0)>();
+        else if (NSTG >= 4 && ahead >= 2) wait_vmcnt<4 * IPW>();
         else if (NSTG >= 3 && ahead >= 1) wait_vmcnt<2 * IPW>();
         else wait_vmcnt<0>();
         const int valid = p - s * BK;                          // k-rows of this slab inside the matrix
@@ -533,15 +539,148 @@ __global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ 
     }
 }
 
+template <int BK, int NSTG, int ABL = 0, int BM = 64, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ A, const double* __restrict__ B,
+                                                 double* __restrict__ C, double* __restrict__ C2,
+                                                 const double* __restrict__ E, const double* __restrict__ coef, int K,
+                                                 int p, const double* __restrict__ A1, const double* __restrict__ B1,
+                                                 double* __restrict__ C1, int K1, double* __restrict__ maxdev,
+                                                 double* __restrict__ rowpart, double* __restrict__ fropart)
+{
+    const int T = (p + BM - 1) / BM;
+    int k, b;
+    if (!decode_block_xcd(T * (T + 1) / 2, K + K1, k, b)) return;
+    symm_dl_tile<BK, NSTG, ABL, BM, NW>(A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, k, b);
+}
+
+#ifdef GGL_DEV
+// ---- persistent-chain probe: nprod DEPENDENT products X <- X * X of a K-batch inside ONE cooperative
+// launch, a grid-wide barrier between products, against the same chain as nprod launches.  What it prices is exactly the
+// trade a persistent Omega-chain kernel would make: a kernel boundary (drain, launch, L2 write-back/invalidate by the
+// command processor) against agent-scope release -> counter -> acquire by the workgroups themselves.
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target, unsigned* err)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this XCD's dirty L2 lines out to memory
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1L << 22)) {                              // ~0.3 s: a lost workgroup must not hang the GPU
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // this CU's L1 (and stale L2 lines) dropped
+    }
+    __syncthreads();
+}
+
+// two-level form: the workgroups of an XCD count themselves in on a per-XCD counter (their stores are in that XCD's L2 once
+// the __syncthreads() has drained them); the LAST one writes the L2 back -- one buffer_wbl2 per XCD and barrier instead of one
+// per workgroup -- and arrives at the global counter for the XCD.  bar: [0] global, [1] error, [8..15] per-XCD counters.
+__device__ __forceinline__ void grid_barrier_xcd(unsigned* bar, unsigned phase, unsigned per_xcd, unsigned xcd)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(bar + 8 + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == phase * per_xcd) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        long spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase * NXCD) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1L << 22)) {
+                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+template <int BK, int NSTG, int BM>
+__global__ __launch_bounds__(256) void k_symm_chain_probe(double* X0, double* X1, const double* coef, int K, int p,
+                                                          int nprod, unsigned* bar, unsigned* err, int two_level)
+{
+    const int T = (p + BM - 1) / BM, ntiles = T * (T + 1) / 2;
+    const int total = xcd_grid(ntiles, K);
+    unsigned xcd = blockIdx.x % NXCD;
+    if (two_level) {
+        // the per-XCD counters need the XCD a workgroup REALLY runs on; the round-robin placement is observed, not promised
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if ((xcc & 0xf) != xcd && threadIdx.x == 0)
+            __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int j = 0; j < nprod; ++j) {
+        const double* src = (j & 1) ? X1 : X0;
+        double* dst = (j & 1) ? X0 : X1;
+        for (int L = blockIdx.x; L < total; L += gridDim.x) {       // gridDim.x is a multiple of 8: L % 8 = this XCD
+            int k, b;
+            if (decode_block_xcd(ntiles, K, k, b, L))
+                symm_dl_tile<BK, NSTG, 0, BM, 4>(src, src, dst, nullptr, nullptr, coef, K, p, nullptr, nullptr, nullptr, 0,
+                                                 nullptr, nullptr, nullptr, k, b);
+            __syncthreads();                                         // the slab storage is reused by the next tile
+        }
+        if (j + 1 < nprod) {
+            if (two_level) grid_barrier_xcd(bar, (unsigned)(j + 1), gridDim.x / NXCD, xcd);
+            else grid_barrier(bar, (unsigned)(j + 1) * gridDim.x, err);
+        }
+    }
+}
+
+// returns the grid used (0: the variant has no probe instance, < 0: HIP error)
+int launch_chain_probe(hipStream_t st, double* X0, double* X1, const double* coef, int K, int p, int nprod, int variant,
+                       unsigned* bar, unsigned* err, int two_level)
+{
+    const void* fn = nullptr;
+    int BM = 64;
+    if (variant == 16) fn = (const void*)k_symm_chain_probe<16, 2, 64>;
+    else if (variant == 17) fn = (const void*)k_symm_chain_probe<16, 3, 64>;
+    else if (variant == 20) { fn = (const void*)k_symm_chain_probe<32, 2, 32>; BM = 32; }
+    else return 0;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) return -1;
+    const int T = (p + BM - 1) / BM;
+    const int total = xcd_grid(T * (T + 1) / 2, K);
+    if (per_cu > 4) per_cu = 4;     // the occupancy query promised 5 (32 KiB of LDS) but 1088 / 1152 workgroups were not co-resident
+    int grid = per_cu * prop.multiProcessorCount;
+    if (grid > total) grid = total;
+    grid -= grid % NXCD;
+    if (grid < NXCD) return -1;
+    void* args[] = {&X0, &X1, &coef, &K, &p, &nprod, &bar, &err, &two_level};
+    if (hipLaunchCooperativeKernel(fn, dim3(grid), dim3(256), args, 0, st) != hipSuccess) return -1;
+    return grid;
+}
+#endif
+
 static void launch_dl(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                       const double* coef, int K, int p, const double* A1, const double* B1, double* C1, int K1,
                       double* maxdev, int dl_cfg = 0, double* rowpart = nullptr, double* fropart = nullptr)
 {
 #define GGL_DL(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart)
-    if (dl_cfg == 4) {
+    if (dl_cfg == 4 || (dl_cfg >= 8 && dl_cfg <= 13)) {
         const int T32 = (p + 31) / 32;
         const dim3 grid(xcd_grid(T32 * (T32 + 1) / 2, K + K1));
-        GGL_DL(32, 4, 0, 32);
+        // 32x32 tiles, k-slab 32, double buffer: 32 KiB of LDS, five workgroups per CU.  Measured (MI355X, p = 500, us per
+        // launch at K = 2 / 4 / 8 / 16): 15.9 / 21.8 / 35.0 / 58.6, against 16.3 / 26.4 / 40.2 / 70.3 with four slabs in
+        // flight (64 KiB, two workgroups per CU: residency, not prefetch depth, is what the small batches lack)
+        if (dl_cfg == 4) GGL_DL(32, 2, 0, 32);
+#ifdef GGL_DEV
+        // other slab / prefetch depths of the 32x32 kernel (LDS per workgroup: 32 / 48 / 48 / 64 / 16 / 24 KiB)
+        else if (dl_cfg == 8) GGL_DL(16, 4, 0, 32);
+        else if (dl_cfg == 9) GGL_DL(32, 3, 0, 32);
+        else if (dl_cfg == 10) GGL_DL(16, 6, 0, 32);
+        else if (dl_cfg == 11) GGL_DL(32, 4, 0, 32);
+        else if (dl_cfg == 12) GGL_DL(16, 2, 0, 32);
+        else if (dl_cfg == 13) GGL_DL(16, 3, 0, 32);
+#endif
         return;
     }
     const int T = (p + 63) / 64;
@@ -781,32 +920,33 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
 }
 #endif   // GGL_DEV
 
-static constexpr int SMALL_DL_MIN_P = 384;        // below: too few k-slabs for the four-stage 32x32 kernel
-static constexpr long SMALL_BATCH_TILES = 400;   // up to here the 32x32-tile kernel, above the 64x64 direct-to-LDS one
+static constexpr int SMALL_DL_MIN_P = 130;        // the Newton-Schulz path starts above p = 128 (below: LDS Jacobi)
+static constexpr long SMALL_BATCH_TILES = 800;   // up to here the 32x32-tile kernel, above the 64x64 direct-to-LDS one
 
 // Product-kernel variants.  The shipped library holds the instances the solvers dispatch to:
 //    0  k_symm_tn 64x64 tile, k-slab 16 (register-staged; odd p, where the DMA kernel's 16-byte rows do not exist)
-//    9  k_symm_tn 32x32 tile, k-slab 32 (small batches below p = 384)
+//    9  k_symm_tn 32x32 tile, k-slab 32 (register-staged; small batches of odd p)
 //   16  k_symm_dl 64x64, double-buffered DMA      17  k_symm_dl 64x64, three DMA stages (concurrent parts)
-//   20  k_symm_dl 32x32, four DMA stages (small batches from p = 384)
-// A GGL_DEV build also has 22 / 23: k_symm_dl 64x64 with EIGHT waves per workgroup (no gain measured, see launch_dl).
-// A GGL_DEV build (libggl_hip_dev.so) adds the measured alternatives 1-5, 8, 11-13, 18, 19 and the ablations 6, 7, 10,
+//   20  k_symm_dl 32x32, k-slab 32, double-buffered DMA (small batches)
+// A GGL_DEV build (libggl_hip_dev.so) adds the measured alternatives 1-5, 8, 11-13, 18, 19, 22 / 23 (64x64 with EIGHT
+// waves per workgroup), 24-29 (other slab / prefetch depths of the 32x32 kernel, see launch_dl) and the ablations 6, 7, 10,
 // 14, 15, 21 (tools/bench_*.py).
-int symm_variants() { return 23; }
+int symm_variants() { return 29; }
 bool symm_variant_built(int v)
 {
 #ifdef GGL_DEV
-    return v >= 0 && v <= 23;
+    return v >= 0 && v <= 29;
 #else
     return v == 0 || v == 9 || v == 16 || v == 17 || v == 20;
 #endif
 }
 
-// Measured on MI355X (tools/bench_small_batches.py, p = 500): with few 64x64 tile pairs in the batch the chip is
-// under-filled and 32x32 tiles (4x the workgroups) win -- 288 tiles (K=8): 39.5 (direct-to-LDS) / 41.5
-// (register-staged) vs 44.4 us; at 576 tiles (K=16) the 64x64 direct-to-LDS kernel is ahead, 63.3 vs 71.9 us.
-// 20 / 16 = direct-to-LDS with 32x32 / 64x64 tiles (odd p: the register-staged kernels 9 / 0); few k-slabs
-// (p = 200): the four-stage prologue does not pay, 9 is 3 % ahead of 20.
+// Measured on MI355X (tools/bench_small_batches.py, profiles/r2_small_batches_product_kernel.txt), us per launch,
+// 32x32 (20) against 64x64 (16) direct-to-LDS tiles: p = 500: K = 2: 16.1 / 28.3, K = 4: 21.6 / 29.7, K = 8: 34.7 / 44.7,
+// K = 16 (576 64x64 tile pairs): 59.5 / 63.5; p = 1000: K = 4 (544): 111.5 / 116.4, K = 8 (1088): 220.5 / 199.8;
+// p = 200, K = 20: 11.8 / 16.4 (register-staged 32x32: 14.7).  Four times the workgroups and five of them resident per CU
+// fill the chip where the 64x64 tiles leave it waiting; from ~1000 tile pairs on the 64x64 tiles' halved L2 -> LDS
+// traffic wins.  Odd p: the register-staged kernels 9 / 0.
 int symm_auto_variant(int nprod, int p)
 {
     const long T64 = (p + 63) / 64;
@@ -819,12 +959,12 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 {
     if (variant < 0) variant = symm_auto_variant(2 * K, p);
     switch (variant) {
-        case 16: case 17: case 18: case 19: case 20: case 22: case 23:
+        case 16: case 17: case 18: case 19: case 20: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K, nullptr, variant - 16);
                 break;
             }
-            if (variant == 20) launch_cfg<32, 32, 16, 16, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K);
+            if (variant == 20 || variant >= 24) launch_cfg<32, 32, 16, 16, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K);
             else launch_cfg<64, 16, 32, 32, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K);
             break;
         case 9: launch_cfg<32, 32, 16, 16, true>(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K); break;
@@ -844,7 +984,7 @@ int symm_bounds_tile(int K, int p, int variant)
 {
     if (variant < 0) variant = symm_auto_variant(K, p);
     if ((p & 1) != 0 || p < 2) return 0;
-    if (variant == 20) return 32;
+    if (variant == 20 || (variant >= 24 && variant <= 29)) return 32;
     if ((variant >= 16 && variant <= 19) || variant == 22 || variant == 23) return 64;
     return 0;
 }
@@ -856,12 +996,12 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
 #define GGL_TN(BM, BK, WM, WN, LM) \
     launch_cfg<BM, BK, WM, WN, LM>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev)
     switch (variant) {
-        case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23:
+        case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16, rowpart, fropart);
                 break;
             }
-            if (variant == 20) GGL_TN(32, 32, 16, 16, true);
+            if (variant == 20 || variant >= 24) GGL_TN(32, 32, 16, 16, true);
             else GGL_TN(64, 16, 32, 32, true);
             break;
         case 9: GGL_TN(32, 32, 16, 16, true); break;

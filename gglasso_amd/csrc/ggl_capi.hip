@@ -738,6 +738,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         int nh = (K >= 16 && ntile >= 600 && ntile <= c->parts_max_tiles) ? std::min(c->ns_parts, K / 8) : 1;
         // small batches of large matrices (the per-GPU slabs of a K-sharded run): one launch keeps the matrix cores ~40 %
         // busy whatever the tile shape, two concurrent launch sequences of K/2 instances each overlap their bubbles
+        // (K = 8, p = 500: +2 %; K = 16 on the 32x32 kernel: -13 %, K = 4: -16 % -- so only the narrow band below 16)
         if (nh == 1 && c->parts_small && K >= c->parts_small && K < 16 && c->p >= 384 && c->ns_parts >= 2) nh = 2;
         nh = std::max(nh, 1);
         int Kh[ggl_ctx::MAX_PARTS], k0h[ggl_ctx::MAX_PARTS];
@@ -2271,6 +2272,92 @@ extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* 
 }
 
 #ifdef GGL_DEV
+// persistent-chain probe (gemm_sym.hip): out = {ms per chain as nprod launches, ms per chain as one cooperative launch,
+// grid of the cooperative launch, max |difference| between the two chains' results (same tile code: 0 unless a workgroup
+// read stale data across a grid barrier), barrier time-out flag}.  The chain is X <- I - 1.5 X^2 on a dense symmetric
+// start of norm <= 1/2 (the quadratic map keeps the spectrum in [-1, 1], so it can run for any number of products).
+extern "C" int ggl_dev_chain_probe(int K, int p, int variant, int nprod, int iters, int two_level, double* out)
+{
+    ARGCHK(K >= 1 && p >= 2 && (p & 1) == 0 && nprod >= 1 && iters >= 1 && out, "arguments (p even)");
+    const size_t n = (size_t)K * p * p;
+    std::vector<double> h(n, 0.0), coef((size_t)K * NS_NCOEF, 0.0);
+    unsigned long long s = 88172645463325252ull;
+    for (int k = 0; k < K; ++k) {
+        double* M = h.data() + (size_t)k * p * p;
+        for (int i = 0; i < p; ++i)
+            for (int j = i; j < p; ++j) {
+                s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+                M[(size_t)i * p + j] = M[(size_t)j * p + i] = ((double)(s >> 11) / 9007199254740992.0 - 0.5) / p;
+            }
+        coef[(size_t)k * NS_NCOEF + 0] = 1.0;
+        coef[(size_t)k * NS_NCOEF + 1] = -1.5;
+    }
+    DevBuf dX0, dX1, dcoef, dbar;
+    HIPCHK(dX0.alloc(n));
+    HIPCHK(dX1.alloc(n));
+    HIPCHK(dcoef.alloc(coef.size()));
+    HIPCHK(dbar.alloc(8));
+    UP(dcoef.p, coef.data(), coef.size());
+    unsigned* bar = reinterpret_cast<unsigned*>(dbar.p);
+    double* last = (nprod & 1) ? dX1.p : dX0.p;
+    auto chain_launches = [&]() {
+        for (int j = 0; j < nprod; ++j)
+            launch_symm(nullptr, (j & 1) ? dX1.p : dX0.p, (j & 1) ? dX1.p : dX0.p, (j & 1) ? dX0.p : dX1.p, nullptr, nullptr,
+                        dcoef.p, K, p, variant);
+    };
+    int grid = 0;
+    auto chain_persistent = [&]() -> int {
+        hipError_t e = hipMemsetAsync(dbar.p, 0, 8 * sizeof(double), nullptr);
+        if (e != hipSuccess) return -1;
+        grid = launch_chain_probe(nullptr, dX0.p, dX1.p, dcoef.p, K, p, nprod, variant, bar, bar + 1, two_level);
+        return grid;
+    };
+    // the two chains from the same start must agree bit for bit
+    std::vector<double> r1(n), r2(n);
+    UP(dX0.p, h.data(), n);
+    chain_launches();
+    DOWN(r1.data(), last, n);
+    UP(dX0.p, h.data(), n);
+    HIPCHK(hipMemset(dX1.p, 0, n * sizeof(double)));
+    int g = chain_persistent();
+    ARGCHK(g != 0, "no probe instance of this variant (16, 17, 20)");
+    if (g < 0) return fail(GGL_E_HIP, "cooperative launch of the chain probe failed: %s", hipGetErrorString(hipGetLastError()));
+    DOWN(r2.data(), last, n);
+    double dev = 0.0;
+    for (size_t i = 0; i < n; ++i) dev = std::max(dev, std::fabs(r1[i] - r2[i]));
+    out[3] = dev;
+    unsigned flags[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(flags, dbar.p, sizeof(flags), hipMemcpyDeviceToHost));
+    out[4] = flags[1];
+    out[2] = grid;
+    if (flags[1]) return GGL_OK;          // a barrier timed out: do not time it
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int i = 0; i < 3; ++i) chain_launches();
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) chain_launches();
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    out[0] = ms / iters;
+    for (int i = 0; i < 3 + iters; ++i) {
+        if (i == 3) HIPCHK(hipEventRecord(e0, nullptr));
+        if (chain_persistent() <= 0) return fail(GGL_E_HIP, "cooperative launch of the chain probe failed");
+    }
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    out[1] = ms / iters;
+    HIPCHK(hipMemcpy(flags, dbar.p, sizeof(flags), hipMemcpyDeviceToHost));
+    out[4] = flags[1];
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    return GGL_OK;
+}
+
 // timeline probe: one launch of variant 10; out = [nblocks][5] long long {start, loop, loop_end, end, xcc}
 extern "C" int ggl_dev_symm_timeline(int K, int p, long long* out, int max_blocks, int* nblocks_out)
 {

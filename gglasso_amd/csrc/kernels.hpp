@@ -166,6 +166,11 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
                  double* fropart = nullptr);
 int symm_bounds_tile(int K, int p, int variant);
 
+#ifdef GGL_DEV
+// persistent-chain probe: nprod dependent products X <- X * X in one cooperative launch with grid barriers (gemm_sym.hip)
+int launch_chain_probe(hipStream_t st, double* X0, double* X1, const double* coef, int K, int p, int nprod, int variant,
+                       unsigned* bar, unsigned* err, int two_level);
+#endif
 // measured FP64 matrix-core ceiling (MFMA-only probe kernel; GGL_DEV builds)
 double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nacc);
 double mfma_valu_mix_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nv);

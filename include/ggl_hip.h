@@ -303,6 +303,11 @@ int ggl_dev_ns_schedule(double l, int degrees, int max_steps, int *deg_out, doub
  * 64x64 kernel */
 int ggl_dev_mfma_f64_peak(double *tflops_out);
 int ggl_dev_symm_timeline(int K, int p, long long *out, int max_blocks, int *nblocks_out);
+/* persistent-chain probe: nprod dependent products X <- X X of a K-batch as nprod launches (out[0], ms) and as ONE cooperative
+ * launch with grid-wide barriers between the products (out[1], ms); out[2] grid of the latter, out[3] max |difference| of
+ * the two chains' results (must be 0), out[4] barrier flag (1 time-out, 2 a workgroup not on XCD blockIdx % 8).  variant: 16, 17
+ * (64x64 tiles), 20 (32x32).  two_level: one L2 write-back per XCD and barrier instead of one per workgroup. */
+int ggl_dev_chain_probe(int K, int p, int variant, int nprod, int iters, int two_level, double *out);
 #endif
 
 /* ---- stateless operator entry points (host buffers; used for operator-level parity) ---------- */

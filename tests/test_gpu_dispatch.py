@@ -5,7 +5,7 @@ properties (exact symmetry, positive definiteness, norm identities) for what the
 
   headline  GGL K=32, p=500            two concurrent parts, direct-to-LDS 64x64 kernel with 3 DMA stages (variant 17),
                                        speculative Omega-step, per-element Theta kernel <32>
-  C3        GGL K=20, p=200            single launch sequence, 32x32 register-staged product kernel (variant 9)
+  C3        GGL K=20, p=200            single launch sequence, 32x32 direct-to-LDS product kernel (variant 20)
   C4        FGL K=50, p=500, latent    TD=8 Condat tile, two-part sign iteration of the L-step
   C2        SGL p=1000, 20-point grid  batched lambda path, 64x64 DMA kernel over several rounds of tiles
   C5 slab   GGL K=32, p=1000           per-GPU slab of C5 at 8 GPUs: unsplit launch sequence above 2048 tile pairs
@@ -101,7 +101,7 @@ def test_c3_dispatch_ggl_K20_p200(stats):
     out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
     _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
     st = stats[-1]
-    assert st["last_parts"] == 1 and st["last_variant"] == 9, st
+    assert st["last_parts"] == 1 and st["last_variant"] == 20, st
     assert st["spec_calls"] >= 1, st
 
 
@@ -166,9 +166,9 @@ def test_c5_slab_dispatch_ggl_K32_p1000(stats):
 
 @pytest.mark.parametrize("K", [4, 8, 16])
 def test_headline_slab_dispatch(stats, K):
-    """Per-GPU slabs of the headline under K-sharding at 8 / 4 / 2 GPUs (what decides strong scaling): K = 4 takes the
-    32x32 four-stage DMA kernel (variant 20), K = 8 the same as two concurrent parts of four, K = 16 (576 tile pairs) the
-    double-buffered 64x64 one."""
+    """Per-GPU slabs of the headline under K-sharding at 8 / 4 / 2 GPUs (what decides strong scaling): K = 4 and K = 16
+    (576 64x64 tile pairs) take the 32x32 direct-to-LDS kernel (variant 20) as one launch sequence, K = 8 the same kernel as
+    two concurrent parts of four."""
     from gglasso_amd import solver
     S, Om0 = _problem("GGL", K, 500, 1239)
     kw = dict(max_iter=5, tol=1e-20, rtol=1e-20)
@@ -177,4 +177,4 @@ def test_headline_slab_dispatch(stats, K):
     out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
     _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
     st = stats[-1]
-    assert (st["last_parts"], st["last_variant"]) == {4: (1, 20), 8: (2, 20), 16: (1, 16)}[K], st
+    assert (st["last_parts"], st["last_variant"]) == {4: (1, 20), 8: (2, 20), 16: (1, 20)}[K], st
