@@ -107,6 +107,7 @@ struct ggl_ctx {
     bool norms_host = false;                   // the last norm reduction wrote straight into norms_h
     int spec_cool = 0;                         // iterations without speculation left after a failed one
     int ns_degrees = 9;                        // highest Newton-Schulz step degree: 3, 5 or 9
+    double ns_tol = NS_TOL_DEFAULT;            // Omega-step schedules end with the spectrum inside [1 - ns_tol, 1]
     long parts_max_tiles = 2048;               // concurrent parts only up to this many 64x64 tile pairs in the batch
     int ns_parts = 1;                          // concurrent launch sequences (parts of the batch) wanted
     int* sweeps = nullptr;
@@ -125,6 +126,11 @@ struct ggl_ctx {
     int ext_L = -1;                            // -1: ggl_ext_setup not called
     double* snapT = nullptr;                   // per-instance snapshots of Theta (model selection), lazy
     double* nbrow = nullptr;                   // [K][p] row abs-sums of B' (Collatz-Wielandt weight vector)
+    // the Collatz-Wielandt vector carried across iterations (k_cw_final): [cw_cur] was left behind by the last ACCEPTED
+    // bound pass, the other one is what the pass in flight writes; cw_have: there is an accepted one
+    double* cwvec[2] = {nullptr, nullptr};
+    int cw_cur = 0;
+    bool cw_have = false, cw_warm = true, cw_pending = false, pre_cw_pending = false;
     // bound partials written by the epilogue of the B' product launch (no norm pass over B'): row sums per tile column,
     // Frobenius shares per tile, block maxima of the row sums; merge cells of the Collatz-Wielandt kernel
     double *rowpart = nullptr, *fropart = nullptr, *infpart = nullptr;
@@ -262,6 +268,8 @@ static int ctx_alloc(ggl_ctx* c)
         HIPCHK(hipHostMalloc(&c->bounds_h, bl, hipHostMallocCoherent));
         const size_t nbl = 3 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);   // + Collatz-Wielandt maxima
         HIPCHK(hipMalloc(&c->nbrow, (size_t)c->K * c->p * sizeof(double)));
+        HIPCHK(hipMalloc(&c->cwvec[0], (size_t)c->K * c->p * sizeof(double)));
+        HIPCHK(hipMalloc(&c->cwvec[1], (size_t)c->K * c->p * sizeof(double)));
         HIPCHK(hipMalloc(&c->nbpart, nbl));
         const size_t t32 = (c->p + 31) / 32;
         HIPCHK(hipMalloc(&c->rowpart, (size_t)c->K * t32 * c->p * sizeof(double)));
@@ -327,9 +335,15 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_PIPELINE: c->pipeline = v != 0.0; break;
         case GGL_OPT_FUSED_START: c->fused_start = v != 0.0; break;
         case GGL_OPT_PARTS_SMALL: c->parts_small = (int)v; break;
+        case GGL_OPT_CW_WARM: c->cw_warm = v != 0.0; break;
+        case GGL_OPT_NS_TOL:
+            if (!(v >= 0.0) || v > 1e-6) return fail(GGL_E_ARG, "bad argument: GGL_OPT_NS_TOL is in [0, 1e-6]");
+            c->ns_tol = std::max(v, NS_TOL_EXACT);
+            break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
     }
     c->spec_have = false;      // a schedule built under other settings is not reused
+    c->cw_have = false;
     return GGL_OK;
 }
 
@@ -357,6 +371,8 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_PIPELINE: *value = c->pipeline; break;
         case GGL_OPT_FUSED_START: *value = c->fused_start; break;
         case GGL_OPT_PARTS_SMALL: *value = c->parts_small; break;
+        case GGL_OPT_NS_TOL: *value = c->ns_tol; break;
+        case GGL_OPT_CW_WARM: *value = c->cw_warm; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
     }
     return GGL_OK;
@@ -433,7 +449,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
                       c->nsT, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->cuse, c->Lam[0],
-                      c->Lam[1], c->X1};
+                      c->Lam[1], c->X1, c->cwvec[0], c->cwvec[1]};
     for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize})
         if (b) (void)hipFree(b);
     for (void* b : {(void*)c->rowpart, (void*)c->fropart, (void*)c->infpart, (void*)c->cwmax, (void*)c->cwcnt})
@@ -486,6 +502,7 @@ static int drop_prelaunch(ggl_ctx* c)
     // the dropped one was, so dropping changes no iterate)
     HIPCHK(hipStreamSynchronize(c->stream));      // the chain's parts were joined into the main stream when it was launched
     for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) c->spec_flag_h[h] = 0;
+    c->pre_cw_pending = false;      // its Collatz-Wielandt vector is never flipped in: the replacement rewrites it
     return GGL_OK;
 }
 #define DROP_PRE(c) do { int rc_ = drop_prelaunch(c); if (rc_) return rc_; } while (0)
@@ -513,6 +530,7 @@ extern "C" int ggl_set_S(ggl_ctx* c, const double* S)
 {
     ARGCHK(c && S, "ctx, S");
     c->spec_have = false;
+    c->cw_have = false;
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
     HIPCHK(hipMemcpyAsync(c->S, S, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -526,6 +544,7 @@ extern "C" int ggl_set_state(ggl_ctx* c, const double* Omega, const double* Thet
 {
     ARGCHK(c, "ctx");
     c->spec_have = false;      // bounds of another iterate say nothing about this one
+    c->cw_have = false;        // (any positive vector would do, but every solve shall start the same way)
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
     const size_t nb = c->n * sizeof(double);
@@ -764,12 +783,13 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         if (allow_spec && !only_spec && c->spec_cool > 0) c->spec_cool -= 1;      // one tick per iteration, not per attempt
         for (int k = 0; spec && k < K; ++k) spec = (c->par_h[k] == c->spec_beta[k]);
         double* fused[ggl_ctx::MAX_PARTS] = {};      // speculative step: the first step's start as 2nd output of the B' launch
+        bool cw_written = false;                     // this step's bound pass left a Collatz-Wielandt vector behind
         if (spec) {
             for (int k = 0; k < K; ++k) c->cuse_h[k] = c->spec_c[k] * c->spec_factor;
             for (int h = 0; spec && h < nh; ++h) {
                 const int k0 = k0h[h];
                 const int prc = ns_plan(c->cuse_h + k0, c->par_h + k0, Kh[h], c->coef_h + h * region,
-                                        start_base_h + 5 * k0, &plans[h], c->ns_force, c->ns_degrees);
+                                        start_base_h + 5 * k0, &plans[h], c->ns_force, c->ns_degrees, c->ns_tol);
                 spec = (prc == 0) && !plans[h].stable;
                 for (int k = k0; spec && c->fused_start && k < k0 + Kh[h]; ++k) {
                     // the bound is assumed known, so the start is a fixed combination of A' and B': {dI, dC, dE} of B' launch
@@ -833,7 +853,10 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 launch_bound_rows(sh, rowp, bT, Kh[h], c->p, c->nbrow + (size_t)k0 * c->p, c->infpart + (size_t)k0 * nib);
                 launch_cw_final(sh, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p, c->infpart + (size_t)k0 * nib, frop,
                                 bT * (bT + 1) / 2, c->cwmax + k0, c->cwcnt + k0, c->bounds_h + k0, spec ? c->cuse + k0 : nullptr,
-                                spec ? c->spec_flag : nullptr, spec ? c->spec_flag_h : nullptr, h);
+                                spec ? c->spec_flag : nullptr, spec ? c->spec_flag_h : nullptr, h,
+                                (c->cw_warm && c->cw_have) ? c->cwvec[c->cw_cur] + (size_t)k0 * c->p : nullptr,
+                                c->cw_warm ? c->cwvec[c->cw_cur ^ 1] + (size_t)k0 * c->p : nullptr);
+                cw_written = c->cw_warm;
             } else {
                 double* nb2 = c->nbpart + 2 * (size_t)k0 * nbb;
                 double* nbc = c->nbpart + 2 * (size_t)K * nbb + (size_t)k0 * nbb;
@@ -865,6 +888,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             c->ns_calls += 1;
             c->spec_calls += 1;
             c->spec_pending = true;        // validated by the caller after its stream sync (finish_norms)
+            c->cw_pending = cw_written;
             if (c->info_dirty) { memset(c->info_h, 0, K * sizeof(int)); c->info_dirty = false; }
             c->dvo_valid = false;
             c->cur = nxt;
@@ -874,11 +898,12 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         // validated bounds: the next step may speculate on them
         for (int k = 0; k < K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
         c->spec_have = true;
+        if (cw_written) { c->cw_cur ^= 1; c->cw_have = true; }
         bool any_stable = false;
         for (int h = 0; h < nh; ++h) {
             const int k0 = k0h[h];
             const int prc = ns_plan(c->bounds_h + k0, c->par_h + k0, Kh[h], c->coef_h + h * region, start_base_h + 5 * k0,
-                                    &plans[h], c->ns_force, c->ns_degrees);
+                                    &plans[h], c->ns_force, c->ns_degrees, c->ns_tol);
             if (prc == -1) return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");
             if (prc == -2) {
                 // pathological scaling (|W|^2 rho / nk > 1e12): eigendecomposition of the (still intact) W
@@ -893,7 +918,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         }
         if (nh > 1 && any_stable) {
             // the stable schedule multiplies a contiguous [Y|P] pair: run the whole batch as one sequence
-            const int prc = ns_plan(c->bounds_h, c->par_h, K, c->coef_h, start_base_h, &plans[0], c->ns_force, c->ns_degrees);
+            const int prc = ns_plan(c->bounds_h, c->par_h, K, c->coef_h, start_base_h, &plans[0], c->ns_force, c->ns_degrees, c->ns_tol);
             if (prc != 0) return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: plan failed (%d)", prc);
         }
         const int nrun = (nh > 1 && !any_stable) ? nh : 1;
@@ -1010,13 +1035,17 @@ static int finish_norms(ggl_ctx* c, int rows, double* out_norms, int group = 0)
         if (bad) {
             // no: the Theta-step kernels saw the flag and left the iterate alone; un-flip Omega and tell the caller
             if (mine) c->spec_misses += 1;
+            c->cw_pending = false;
             c->spec_have = false;
             c->spec_cool = 4;
             c->cur ^= 1;
             return GGL_SPEC_RETRY;
         }
-        if (mine)
+        if (mine) {
             for (int k = 0; k < c->K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
+            if (c->cw_pending) { c->cw_cur ^= 1; c->cw_have = true; }
+        }
+        c->cw_pending = false;
     }
     int rc = check_info(c, "ADMM step");
     if (rc) return rc;
@@ -1225,6 +1254,7 @@ static bool take_prelaunched(ggl_ctx* c, int latent)
     }
     c->cur ^= 1;
     c->spec_pending = c->pre_spec_pending;
+    c->cw_pending = c->pre_cw_pending;
     return true;
 }
 
@@ -1245,6 +1275,8 @@ static int maybe_prelaunch(ggl_ctx* c, double rho, const double out_norms[5])
     c->cur = cur0;                               // Omega_t stays the current iterate until the chain is taken over
     c->pre_spec_pending = c->spec_pending;
     c->spec_pending = false;
+    c->pre_cw_pending = c->cw_pending;
+    c->cw_pending = false;
     c->pre_valid = true;
     c->pre_launched += 1;
     memcpy(c->pre_beta, c->par_h, c->K * sizeof(double));
@@ -2272,6 +2304,8 @@ extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* 
 }
 
 #ifdef GGL_DEV
+namespace ggl { extern double g_ns_tol; }
+extern "C" int ggl_dev_ns_set_tol(double t) { ggl::g_ns_tol = t; return 0; }
 // persistent-chain probe (gemm_sym.hip): out = {ms per chain as nprod launches, ms per chain as one cooperative launch,
 // grid of the cooperative launch, max |difference| between the two chains' results (same tile code: 0 unless a workgroup
 // read stale data across a grid barrier), barrier time-out flag}.  The chain is X <- I - 1.5 X^2 on a dense symmetric
@@ -2440,6 +2474,7 @@ extern "C" int ggl_phiplus_matrix(int K, int p, const double* beta, const double
         ggl_ctx* c = nullptr;
         int rc = ggl_ctx_create(0, K, p, (eig_method & ~0xff) | GGL_EIG_NEWTON_SCHULZ, nullptr, &c);
         if (rc) return rc;
+        c->ns_tol = NS_TOL_EXACT;          // the operator-level entry point iterates to fp64 resolution
         std::vector<double> zero((size_t)K * p * p, 0.0);
         rc = ggl_set_S(c, zero.data());
         if (!rc) rc = ggl_set_state(c, zero.data(), W, nullptr, zero.data());

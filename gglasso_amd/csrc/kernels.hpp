@@ -183,6 +183,12 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
                       double* C1, const double* coef2K, int K, int p, int variant);
 
 // ---- newton_schulz.hip ------------------------------------------------------------------
+static constexpr double NS_TOL_EXACT = 4e-16;  // schedules end with the spectrum inside [1 - tol, 1]; this is "all fp64 has"
+// what a ctx iterates the Omega-step to unless told otherwise (GGL_OPT_NS_TOL): |Omega - phiplus(W)|_2 <= 2e-12 |sqrt(W^2 +
+// 4 beta I)|_2 / 2.  Measured at GGL (32,500), solved to 1e-10 on both sides: |Theta - reference|_F = 1.3e-10 on a stack of
+// norm 128 (max entry 2.4e-12) against 2.8e-13 in exact mode -- 75x inside the 1e-8 the comparison asks for -- for 7 instead
+// of 8 products per iteration (+10 % iterations/s)
+static constexpr double NS_TOL_DEFAULT = 2e-12;
 static constexpr int NS_MAX_STEPS = 24;        // square-root schedule (condition number up to ~1e18)
 static constexpr int NS_RANK_MAX_STEPS = 40;   // sign schedule (resolution down to ~1e-13)
 static constexpr int NS_MAX_LAUNCHES = 2 * NS_RANK_MAX_STEPS + 1 + 3;   // + start table + two pre-bound slots
@@ -211,9 +217,9 @@ void launch_form_W_sym(hipStream_t st, double* W, const double* Theta, const dou
 // eigendecomposition); fills coef_h[launch slots] and start_h[K][5].
 // degrees: highest step degree of the fast schedule: 3 = cubic only, 5 = cubic/quintic mix, 9 = + degree nine.
 int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h, double* start_h, NsPlan* plan,
-            int force_mode, int degrees = 9);
+            int force_mode, int degrees = 9, double tol = NS_TOL_EXACT);
 // the schedule alone (host): returns steps, fills deg[max_steps], coef[max_steps*6] = {t0..t4,l_after}
-int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units);
+int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units, double tol = NS_TOL_EXACT);
 void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, const double* W, double* Ap, double* Bp,
                 int K, int p, int variant, double* start2 = nullptr, double* rowpart = nullptr, double* fropart = nullptr);
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
@@ -242,7 +248,8 @@ int bound_rows_blocks(int p);
 void launch_bound_rows(hipStream_t st, const double* rowpart, int T, int K, int p, double* d, double* infpart);
 void launch_cw_final(hipStream_t st, const double* B, const double* d, int K, int p, const double* infpart,
                      const double* fropart, int ntile, unsigned long long* cwmax, unsigned* cnt, double* out,
-                     const double* cuse, int* flag, int* flag_host, int flag_slot);
+                     const double* cuse, int* flag, int* flag_host, int flag_slot, const double* dprev = nullptr,
+                     double* dnext = nullptr);
 int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan,
                  int degrees = 9);
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,

@@ -317,7 +317,17 @@ struct NsPlanner {
         const NsStep s = (d == 3) ? ns_cubic_step(q.l) : (d == 5 ? ns_quintic_step(q.l) : ns_nonic_step(q.l));
         return steps.emplace(id, s).first->second;
     }
-    static bool converged(const NsStep& s) { return 1.0 - s.lnew < 4e-16; }
+    // a schedule ends when the spectrum is inside [1 - tol, 1]: tol = NS_TOL_EXACT drives it to what fp64 can represent;
+    // a larger tol (GGL_OPT_NS_TOL) is the relative spectral accuracy of the matrix function the caller asks for
+    double tol = NS_TOL_EXACT;
+    bool converged(const NsStep& s) const { return 1.0 - s.lnew < tol; }
+    void set_tol(double t)
+    {
+        if (t == tol) return;
+        togo.clear();                 // the steps themselves do not depend on the tolerance, the plans do
+        plans.clear();
+        tol = t;
+    }
     Node best_from(const NsKey& q, int depth)
     {
         // the cost-to-go of a key must not depend on how deep the query was that first reached it (it is memoised):
@@ -374,10 +384,12 @@ struct NsPlanner {
     }
 };
 
-static const NsSeq& ns_mixed_schedule(double l, int degrees)
+static const NsSeq& ns_mixed_schedule(double l, int degrees, double tol)
 {
     static thread_local NsPlanner planners[3] = {{3, 0}, {5, 0}, {9, 0}};
-    return planners[degrees >= 9 ? 2 : (degrees >= 5 ? 1 : 0)].plan(l);
+    NsPlanner& pl = planners[degrees >= 9 ? 2 : (degrees >= 5 ? 1 : 0)];
+    pl.set_tol(std::fmin(std::fmax(tol, NS_TOL_EXACT), 1e-6));
+    return pl.plan(l);
 }
 
 static const NsSeq& ns_sign_schedule(double l, int degrees)
@@ -386,10 +398,10 @@ static const NsSeq& ns_sign_schedule(double l, int degrees)
     return planners[degrees >= 9 ? 2 : (degrees >= 5 ? 1 : 0)].plan(l);
 }
 
-int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units)
+int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units, double tol)
 {
     if (!(l > 0.0) || !(l <= 1.0)) return -1;
-    const NsSeq& sq = (degrees >= 100) ? ns_sign_schedule(l, degrees - 100) : ns_mixed_schedule(l, degrees);
+    const NsSeq& sq = (degrees >= 100) ? ns_sign_schedule(l, degrees - 100) : ns_mixed_schedule(l, degrees, tol);
     if (sq.n < 1 || sq.n > max_steps || sq.cost >= (1 << 29)) return -1;
     for (int i = 0; i < sq.n; ++i) {
         deg[i] = sq.deg[i];
@@ -457,7 +469,7 @@ static void launch_ns_start(hipStream_t st, double* Y1, double* Z1, const double
 // One schedule for the whole batch, built for the smallest l_k = sqrt(4 beta_k / c_k) (every spectrum lies in
 // [l_k, 1] after scaling by c_k, so the polynomials of the widest interval converge for all of them).
 int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h, double* start_h, NsPlan* plan,
-            int force_mode, int degrees)
+            int force_mode, int degrees, double tol)
 {
     std::vector<double> c(K);
     double kappa = 1.0;
@@ -479,7 +491,7 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
         o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = dI; o[4] = dC; o[5] = dE;
     };
     if (!stable) {
-        const NsSeq& sq = ns_mixed_schedule(lmin, degrees);
+        const NsSeq& sq = ns_mixed_schedule(lmin, degrees, tol);
         if (sq.n < 1 || sq.n > NS_MAX_STEPS || sq.cost >= (1 << 29)) return -2;
         const int n = sq.n;
         plan->steps = n;
@@ -825,7 +837,13 @@ void launch_bound_rows(hipStream_t st, const double* rowpart, int T, int K, int 
 // the bound itself: out[k] = sqrt(min(|B'|_inf, cw (1 + 1e-12), |B'|_F)), compared with the bound the running schedule
 // assumes (cuse).  The maximum over the row blocks is an atomic max on the bit pattern of a non-negative double (order
 // independent, hence deterministic); |B'|_F^2 is summed in tile order.  cwmax / cnt: [K], zero on entry, left zero.
-__global__ __launch_bounds__(256) void k_cw_final(const double* __restrict__ B, const double* __restrict__ d, int p,
+// dprev / dnext (optional): the Collatz-Wielandt ratio max_i (|B'| v)_i / v_i bounds the Perron root of |B'| from above for
+// ANY positive v; with v = the row sums it is one power step away from the infinity norm, with v = the Perron vector it IS
+// the root.  B' moves little between ADMM iterations, so the ctx keeps v across them: this pass reads the previous
+// iteration's vector (dprev, if there is one) and leaves (|B'| v) / |B'|_inf behind for the next (dnext) -- a power
+// iteration at one step per ADMM iteration and no extra pass, still a rigorous bound at every step.
+__global__ __launch_bounds__(256) void k_cw_final(const double* __restrict__ B, const double* __restrict__ d,
+                                                   const double* __restrict__ dprev, double* __restrict__ dnext, int p,
                                                    const double* __restrict__ infpart, int ninf,
                                                    const double* __restrict__ fropart, int ntile,
                                                    unsigned long long* __restrict__ cwmax, unsigned* __restrict__ cnt,
@@ -838,7 +856,12 @@ __global__ __launch_bounds__(256) void k_cw_final(const double* __restrict__ B, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * 16 + wave * 4;
     const double* w = B + (size_t)k * p * p;
-    const double* dk = d + (size_t)k * p;
+    const double* dk = (dprev ? dprev : d) + (size_t)k * p;
+    double scale = 0.0;
+    if (dnext) {
+        for (int b2 = 0; b2 < ninf; ++b2) scale = fmax(scale, infpart[(size_t)k * ninf + b2]);
+        scale = 1.0 / scale;
+    }
     double a[4] = {0.0, 0.0, 0.0, 0.0};
     size_t ro[4];
     bool ok[4];
@@ -856,7 +879,13 @@ __global__ __launch_bounds__(256) void k_cw_final(const double* __restrict__ B, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const double y = wave_sum(a[q]);
-        if (ok[q]) mx = fmax(mx, y / dk[r0 + q]);       // a zero row gives 0/0: fmax drops the NaN
+        if (ok[q]) {
+            mx = fmax(mx, y / dk[r0 + q]);              // a zero row gives 0/0: fmax drops the NaN
+            if (dnext && lane == 0) {
+                const double v = y * scale;             // anything positive keeps the bound rigorous
+                dnext[(size_t)k * p + r0 + q] = (v > 0.0 && isfinite(v)) ? v : 1.0;
+            }
+        }
     }
     if (lane == 0) sh[wave] = mx;
     __syncthreads();
@@ -890,10 +919,10 @@ __global__ __launch_bounds__(256) void k_cw_final(const double* __restrict__ B, 
 
 void launch_cw_final(hipStream_t st, const double* B, const double* d, int K, int p, const double* infpart,
                      const double* fropart, int ntile, unsigned long long* cwmax, unsigned* cnt, double* out,
-                     const double* cuse, int* flag, int* flag_host, int flag_slot)
+                     const double* cuse, int* flag, int* flag_host, int flag_slot, const double* dprev, double* dnext)
 {
-    hipLaunchKernelGGL(k_cw_final, dim3((p + 15) / 16, K), dim3(256), 0, st, B, d, p, infpart, bound_rows_blocks(p), fropart,
-                       ntile, cwmax, cnt, out, cuse, flag, flag_host, flag_slot);
+    hipLaunchKernelGGL(k_cw_final, dim3((p + 15) / 16, K), dim3(256), 0, st, B, d, dprev, dnext, p, infpart,
+                       bound_rows_blocks(p), fropart, ntile, cwmax, cnt, out, cuse, flag, flag_host, flag_slot);
 }
 
 void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int K, int p, double* part)

@@ -102,6 +102,15 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_PIPELINE 12        /* [1] ggl_admm_step launches the next iteration's Omega-step chain before it returns     */
 #define GGL_OPT_FUSED_START 13     /* [1] speculative step: the first step's start matrix is the B' launch's second output   */
 #define GGL_OPT_PARTS_SMALL 14     /* [8] smallest batch below 16 (p >= 384) that still runs as two concurrent parts; 0 = none */
+#define GGL_OPT_NS_TOL 15          /* [2e-12] relative spectral accuracy the Omega-step's matrix square root is iterated to:
+                                    * |Omega - phiplus(W)|_2 <= tol * |sqrt(W^2 + 4 beta I)|_2 / 2 (+ rounding).  0 (or anything
+                                    * below 4e-16) iterates to fp64 resolution: results then agree with eigh to ~1e-13 at one
+                                    * more product per iteration around condition number 2.  Measured at GGL (32,500), solved
+                                    * to 1e-10: |Theta - reference|_F = 1.3e-10 (default) / 2.8e-13 (exact) on a stack of norm
+                                    * 128; the reference comparison asks for 1e-8.  The stateless ggl_phiplus_matrix is exact. */
+#define GGL_OPT_CW_WARM 16         /* [1] the Collatz-Wielandt weight vector of the spectral bound is carried from one iteration to
+                                    * the next (a power iteration at no extra pass; the bound stays rigorous and tightens
+                                    * towards the Perron root of |B'|); 0: the row sums of |B'| every time                  */
 int ggl_ctx_set_option(ggl_ctx *ctx, int option, double value);
 int ggl_ctx_get_option(ggl_ctx *ctx, int option, double *value);
 

@@ -525,3 +525,35 @@ def test_fgl_K_beyond_the_scan_buffer_is_refused_with_a_message(sol):
         ops.prox_p(S, 0.1, 0.1, "FGL")
     (s, info), _ = quiet(sol.ADMM_MGL, S[:318], 0.05, 0.01, "FGL", S[:318].copy(), max_iter=2)      # the limit itself works
     assert info["status"] in ("optimal", "max iterations reached") and np.isfinite(s["Theta"]).all()
+
+
+def test_omega_step_tolerance_and_carried_bound_vector(sol):
+    """GGL_OPT_NS_TOL / GGL_OPT_CW_WARM.  The Omega-step's square-root iteration stops at a relative spectral accuracy
+    (default 2e-12; 0 = fp64 resolution): the default must never cost more products than the exact mode, the exact mode
+    must reproduce the reference's eigendecomposition route to ~1e-12 and the default must stay orders of magnitude
+    inside the 1e-8 of the reference comparison.  The Collatz-Wielandt vector carried across iterations only tightens a
+    bound that is rigorous for any positive vector: same iterates to rounding, no speculation miss, no more work."""
+    from gglasso_amd import synth, solver
+    K, p = 6, 384
+    S, _ = synth.make_problem("GGL", K=K, p=p, N=2 * p, seed=47)
+    Om0 = np.stack([np.eye(p)] * K)
+    ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, max_iter=14, tol=1e-20, rtol=1e-20, update_rho=False)
+    res = {}
+    for name, opts in (("default", {}), ("exact", {"ns_tol": 0.0}), ("cold", {"cw_warm": 0}), ("loose", {"ns_tol": 1e-9})):
+        eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options=opts)
+        for it in range(14):
+            eng.step(1.0, 0.05, 0.01, "GGL", False, None, np.ones(K))
+        res[name] = (eng.state(), eng.ns_stats(), eng.get_option("ns_tol"))
+        eng.close()
+    assert res["default"][2] == 2e-12 and res["exact"][2] == 4e-16
+    err = {n: max(np.abs(res[n][0][nm] - ref[nm]).max() for nm in ("Omega", "Theta", "X")) for n in res}
+    assert err["exact"] <= 2e-12, err
+    assert err["default"] <= 1e-10 and err["cold"] <= 1e-10, err
+    assert err["loose"] <= 1e-6, err
+    units = {n: res[n][1]["units"] for n in res}
+    assert units["loose"] <= units["default"] <= units["exact"], units
+    assert units["default"] <= units["cold"], units
+    for n in res:
+        assert res[n][1]["spec_misses"] == 0 and res[n][1]["eigh_fallbacks"] == 0, (n, res[n][1])
+    with pytest.raises(AssertionError):
+        solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"ns_tol": 1e-3})
