@@ -18,6 +18,7 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep "^{" > $O/be
 for w in ggl_K20_p200 ggl_K4_p500 ggl_K8_p500 ggl_K16_p500 ggl_K32_p1000 fgl_K50_p500_latent ggl_K256_p1000; do
   python bench.py --workload $w --steps 30 --warmup 8 --regions 5 --no-cpu-baseline 2>&1 | grep "^{" > $O/workload_$w.json
 done
+python bench.py --opt ns_tol=0 --no-cpu-baseline 2>&1 | grep "^{" > $O/workload_ggl_K32_p500_exact_omega_step.json
 python bench.py --opt ns_mode=2 --steps 40 --warmup 10 --no-cpu-baseline 2>&1 | grep "^{" > $O/workload_ggl_K32_p500_stable.json
 python bench.py --eig 2 --steps 10 --warmup 3 --regions 3 --no-cpu-baseline 2>&1 | grep "^{" > $O/workload_ggl_K32_p500_rocsolver.json
 for w in ggl_K4_p500 ggl_K8_p500; do
@@ -29,7 +30,9 @@ python tools/gap_analysis.py $T 8 > $O/timeline.txt 2>&1
 python tools/bench_grid.py 2>&1 | grep "^{" > $O/workload_sgl_grid_p1000_L20.json
 python tools/bench_mgl_grid.py 2>&1 | grep "^{" > $O/workload_mgl_grid_8x1_K4_p500.json
 python tools/bench_mgl_grid.py --reg FGL --K 6 --p 300 --l1 4 --l2 3 2>&1 | grep "^{" > $O/workload_mgl_grid_4x3_fgl_K6_p300.json
-K=32 TOL=1e-10 python tools/parity_headline.py > $O/parity_headline.txt 2>&1
+K=32 TOL=1e-10 python tools/parity_headline.py ns_tol=2e-12,0 > $O/parity_headline.txt 2>&1
+python tools/bench_chain_probe.py > $O/persistent_chain_probe.txt 2>&1
+python tools/bench_small_batches.py > $O/small_batches_product_kernel.txt 2>&1
 head -c 700 $O/bench_final.json
 rm -rf $R/gpurun_out/prof_$TAG/*/*.db 2>/dev/null
 find $R/gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete
