@@ -2304,8 +2304,6 @@ extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* 
 }
 
 #ifdef GGL_DEV
-namespace ggl { extern double g_ns_tol; }
-extern "C" int ggl_dev_ns_set_tol(double t) { ggl::g_ns_tol = t; return 0; }
 // persistent-chain probe (gemm_sym.hip): out = {ms per chain as nprod launches, ms per chain as one cooperative launch,
 // grid of the cooperative launch, max |difference| between the two chains' results (same tile code: 0 unless a workgroup
 // read stale data across a grid barrier), barrier time-out flag}.  The chain is X <- I - 1.5 X^2 on a dense symmetric
