@@ -380,6 +380,7 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
     const unsigned cpos = (unsigned)((lane % LPR) * 2) ^ (unsigned)(16 * (lrow & 1));
     const unsigned ca = min((unsigned)I0 + cpos, pm2), cb = min((unsigned)J0 + cpos, pm2);
     auto issue = [&](int m0, int buf) {
+        if (ABL == 2) return;                                            // timing ablation: no operand loads at all
 #pragma unroll
         for (int j = 0; j < IPW; ++j) {
             const int i = wave * IPW + j;
@@ -419,7 +420,7 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
         // make hipcc drain vmcnt(0) here, i.e. wait for the slabs prefetched AHEAD as well and collapse the pipeline
         // to one slab of overlap whatever NSTG is (this wave's own slab-s DMA was waited for by the counted vmcnt above)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (ABL != 5) __builtin_amdgcn_s_barrier();                      // ABL 5: no slab barrier (timing ablation)
         asm volatile("" ::: "memory");
         if (s + NSTG - 1 < S) issue((s + NSTG - 1) * BK, (s + NSTG - 1) % NSTG);
         if (!dead_wave) {
@@ -439,12 +440,23 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < TJ; ++j)
+                    for (int j = 0; j < TJ; ++j) {
+                        if (ABL == 3) { acc[i][j][0] += af[i] * bf[j]; continue; }   // timing ablation: no MFMA
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
             }
         }
     }
     __syncthreads();     // all fragment reads done before the slabs are reused as the mirror tile
+    if (ABL == 4) {                                                      // timing ablation: no epilogue
+        double keepalive = 0.0;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) keepalive += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keepalive == 1234.5678) C[0] = keepalive;
+        return;
+    }
 
     const double cI = coef[k * NS_NCOEF + 0], cAcc = coef[k * NS_NCOEF + 1], cE = coef[k * NS_NCOEF + 2];
     const double dI = coef[k * NS_NCOEF + 3], dC = coef[k * NS_NCOEF + 4], dE = coef[k * NS_NCOEF + 5];
@@ -665,7 +677,7 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
                       double* maxdev, int dl_cfg = 0, double* rowpart = nullptr, double* fropart = nullptr)
 {
 #define GGL_DL(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart)
-    if (dl_cfg == 4 || (dl_cfg >= 8 && dl_cfg <= 13)) {
+    if (dl_cfg == 4 || (dl_cfg >= 8 && dl_cfg <= 13) || (dl_cfg >= 18 && dl_cfg <= 21)) {
         const int T32 = (p + 31) / 32;
         const dim3 grid(xcd_grid(T32 * (T32 + 1) / 2, K + K1));
         // 32x32 tiles, k-slab 32, double buffer: 32 KiB of LDS, five workgroups per CU.  Measured (MI355X, p = 500, us per
@@ -680,6 +692,11 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
         else if (dl_cfg == 11) GGL_DL(32, 4, 0, 32);
         else if (dl_cfg == 12) GGL_DL(16, 2, 0, 32);
         else if (dl_cfg == 13) GGL_DL(16, 3, 0, 32);
+        // the same four timing ablations of the 32x32 kernel
+        else if (dl_cfg == 18) GGL_DL(32, 2, 2, 32);
+        else if (dl_cfg == 19) GGL_DL(32, 2, 3, 32);
+        else if (dl_cfg == 20) GGL_DL(32, 2, 4, 32);
+        else if (dl_cfg == 21) GGL_DL(32, 2, 5, 32);
 #endif
         return;
     }
@@ -702,6 +719,11 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
     else if (dl_cfg == 2) GGL_DL(16, 4);
     else if (dl_cfg == 3) GGL_DL(32, 2);
     else if (dl_cfg == 5) GGL_DL(16, 2, 1);      // no mirror write: timing ablation, wrong results
+    // timing ablations of the three-stage 64x64 kernel (wrong results): no operand loads / no MFMA / no epilogue / no barrier
+    else if (dl_cfg == 14) GGL_DL(16, 3, 2);
+    else if (dl_cfg == 15) GGL_DL(16, 3, 3);
+    else if (dl_cfg == 16) GGL_DL(16, 3, 4);
+    else if (dl_cfg == 17) GGL_DL(16, 3, 5);
 #endif
     else GGL_DL(16, 2);
 #undef GGL_DL
@@ -931,11 +953,11 @@ static constexpr long SMALL_BATCH_TILES = 800;   // up to here the 32x32-tile ke
 // A GGL_DEV build (libggl_hip_dev.so) adds the measured alternatives 1-5, 8, 11-13, 18, 19, 22 / 23 (64x64 with EIGHT
 // waves per workgroup), 24-29 (other slab / prefetch depths of the 32x32 kernel, see launch_dl) and the ablations 6, 7, 10,
 // 14, 15, 21 (tools/bench_*.py).
-int symm_variants() { return 29; }
+int symm_variants() { return 37; }
 bool symm_variant_built(int v)
 {
 #ifdef GGL_DEV
-    return v >= 0 && v <= 29;
+    return v >= 0 && v <= 37;
 #else
     return v == 0 || v == 9 || v == 16 || v == 17 || v == 20;
 #endif
@@ -959,7 +981,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 {
     if (variant < 0) variant = symm_auto_variant(2 * K, p);
     switch (variant) {
-        case 16: case 17: case 18: case 19: case 20: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29:
+        case 16: case 17: case 18: case 19: case 20: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K, nullptr, variant - 16);
                 break;
@@ -984,8 +1006,8 @@ int symm_bounds_tile(int K, int p, int variant)
 {
     if (variant < 0) variant = symm_auto_variant(K, p);
     if ((p & 1) != 0 || p < 2) return 0;
-    if (variant == 20 || (variant >= 24 && variant <= 29)) return 32;
-    if ((variant >= 16 && variant <= 19) || variant == 22 || variant == 23) return 64;
+    if (variant == 20 || (variant >= 24 && variant <= 29) || (variant >= 34 && variant <= 37)) return 32;
+    if ((variant >= 16 && variant <= 19) || variant == 22 || variant == 23 || (variant >= 30 && variant <= 33)) return 64;
     return 0;
 }
 
@@ -996,7 +1018,7 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
 #define GGL_TN(BM, BK, WM, WN, LM) \
     launch_cfg<BM, BK, WM, WN, LM>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev)
     switch (variant) {
-        case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29:
+        case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16, rowpart, fropart);
                 break;
