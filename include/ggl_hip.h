@@ -306,6 +306,9 @@ int ggl_dev_symm_bounds(int K, int p, const double *A, const double *B, int vari
  * instead (every step costs X^2, [t], X t: 2 / 3 / 4 products; *units_out without the first and the last product).
  * Returns the number of steps or GGL_E_ARG. */
 int ggl_dev_ns_schedule(double l, int degrees, int max_steps, int *deg_out, double *coef_out, int *units_out);
+/* the same for the Omega-step at a stopping tolerance (GGL_OPT_NS_TOL; 0 = fp64 resolution, what the call above plans for) */
+int ggl_dev_ns_schedule_tol(double l, int degrees, double tol, int max_steps, int *deg_out, double *coef_out,
+                            int *units_out);
 #ifdef GGL_DEV
 /* libggl_hip_dev.so only (python -m gglasso_amd.build --dev): measured FP64 matrix-core ceiling of this GPU in TFLOP/s
  * (MFMA-only probe kernel); per-workgroup timestamps {start, loop begin, loop end, end, XCC id} of one launch of the

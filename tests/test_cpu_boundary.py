@@ -219,6 +219,35 @@ def _ns_schedule(lib, l, degrees):
     return list(deg)[:n], np.array(co[:6 * n]).reshape(n, 6), units.value
 
 
+def test_newton_schulz_schedule_at_a_stopping_tolerance(lib):
+    """GGL_OPT_NS_TOL (host logic, no GPU): a schedule planned for tolerance tol maps [l,1] into [1 - tol, 1] (to rounding),
+    never costs more than the fp64-resolution schedule, and at the headline's l (0.70-0.72 from the carried bound vector)
+    the default 2e-12 is what buys the seventh-instead-of-eighth product."""
+    import ctypes
+    def plan(l, tol):
+        deg = (ctypes.c_int * 24)()
+        co = (ctypes.c_double * (24 * 6))()
+        units = ctypes.c_int()
+        n = lib.load().ggl_dev_ns_schedule_tol(float(l), 9, float(tol), 24, deg, co, ctypes.byref(units))
+        assert n > 0, (l, tol, n)
+        return list(deg)[:n], np.array(co[:6 * n]).reshape(n, 6), units.value
+    for l in np.concatenate([np.geomspace(1e-4, 0.99, 40), [0.70, 0.715, 0.72]]):
+        exact = plan(l, 0.0)[2]
+        assert exact == _ns_schedule(lib, l, 9)[2]
+        last = exact
+        for tol in (1e-14, 2e-12, 1e-9, 1e-6):
+            deg, co, units = plan(l, tol)
+            assert units <= last, (l, tol, units, last)
+            last = units
+            x = np.unique(np.concatenate([np.linspace(l, 1, 20001), np.geomspace(l, 1, 20001)])).astype(np.longdouble)
+            for i in range(len(deg)):
+                x2 = x * x
+                x = x * (co[i, 0] + x2 * (co[i, 1] + x2 * (co[i, 2] + x2 * (co[i, 3] + x2 * co[i, 4]))))
+            assert float(np.abs(1 - x).max()) <= tol * 1.001 + 2e-15, (l, tol, deg)
+    assert plan(0.70, 0.0)[2] == 8 and plan(0.70, 2e-12)[2] == 7 and plan(0.72, 1e-12)[2] == 7
+    assert plan(0.66, 2e-12)[2] == 8          # without the carried bound vector (l ~ 0.64-0.67) the default saves nothing
+
+
 @pytest.mark.parametrize("degrees", [3, 5, 9])
 def test_newton_schulz_schedule_converges_on_its_interval(lib, degrees):
     """Host logic of the eigendecomposition-free Omega-step (no GPU): composing the planned step polynomials
