@@ -2435,7 +2435,7 @@ extern "C" int ggl_dev_ns_schedule_tol(double l, int degrees, double tol, int ma
 {
     ARGCHK(deg_out && coef_out && units_out, "output pointers");
     ARGCHK(l > 0.0 && l <= 1.0, "l must be in (0,1]");
-    ARGCHK(tol >= 0.0 && tol <= 1e-6 && degrees < 100, "tol in [0, 1e-6], Omega-step schedules only");
+    ARGCHK(tol >= 0.0 && tol <= 1e-6, "tol in [0, 1e-6]");
     const int n = ns_schedule_query(l, degrees, max_steps, deg_out, coef_out, units_out, std::max(tol, NS_TOL_EXACT));
     if (n < 0) return fail(GGL_E_ARG, "no schedule within %d steps", max_steps);
     return n;

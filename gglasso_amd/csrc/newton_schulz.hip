@@ -392,16 +392,18 @@ static const NsSeq& ns_mixed_schedule(double l, int degrees, double tol)
     return pl.plan(l);
 }
 
-static const NsSeq& ns_sign_schedule(double l, int degrees)
+static const NsSeq& ns_sign_schedule(double l, int degrees, double tol = NS_TOL_EXACT)
 {
     static thread_local NsPlanner planners[3] = {{3, 1}, {5, 1}, {9, 1}};
-    return planners[degrees >= 9 ? 2 : (degrees >= 5 ? 1 : 0)].plan(l);
+    NsPlanner& pl = planners[degrees >= 9 ? 2 : (degrees >= 5 ? 1 : 0)];
+    pl.set_tol(std::fmin(std::fmax(tol, NS_TOL_EXACT), 1e-6));
+    return pl.plan(l);
 }
 
 int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units, double tol)
 {
     if (!(l > 0.0) || !(l <= 1.0)) return -1;
-    const NsSeq& sq = (degrees >= 100) ? ns_sign_schedule(l, degrees - 100) : ns_mixed_schedule(l, degrees, tol);
+    const NsSeq& sq = (degrees >= 100) ? ns_sign_schedule(l, degrees - 100, tol) : ns_mixed_schedule(l, degrees, tol);
     if (sq.n < 1 || sq.n > max_steps || sq.cost >= (1 << 29)) return -1;
     for (int i = 0; i < sq.n; ++i) {
         deg[i] = sq.deg[i];
