@@ -192,7 +192,9 @@ def _commuting_pair(rng, K, p):
 # 16 / 17 direct-to-LDS 64x64 with 2 / 3 DMA stages (17 = the headline's concurrent parts), 20 direct-to-LDS 32x32;
 # -1 = the size rule itself.  (16, 500) is one concurrent part of the headline batch: 576 tile pairs, > 1 round of tiles.
 @pytest.mark.parametrize("variant", [-1, 0, 9, 16, 17, 20])
-@pytest.mark.parametrize("K,p", [(2, 40), (3, 129), (2, 200), (1, 333), (9, 70), (2, 500), (16, 500), (3, 1000)])
+# K = 9, 11, 13, 20: whole rounds of eight instances over the XCDs plus a remainder of 1 / 3 / 5 / 4 dealt as a small batch
+@pytest.mark.parametrize("K,p", [(2, 40), (3, 129), (2, 200), (1, 333), (9, 70), (11, 96), (13, 130), (20, 200), (2, 500),
+                                 (16, 500), (3, 1000)])
 def test_symm_product_kernel(variant, K, p):
     """C = cI*I + cAcc*A*B + cE*E and C2 = dI*I + dC*C for commuting symmetric A, B (every tile shape)."""
     from gglasso_amd import _lib
