@@ -731,6 +731,122 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4(double* __restrict__ Th
     }
 }
 
+// The same with 16-byte accesses: a lane holds TWO consecutive elements (p^2 even), a wave row is 1 KiB.  8-byte
+// accesses run at 0.54-0.70x the 16-byte rate on this chip (MI355X_MICROARCH.md), and this kernel is nothing but accesses.
+// Same 128 elements per workgroup as the scalar form (one chunk of 2 x 64), so the partial-sum layout is unchanged.
+template <int KQ, bool FUSE_DUAL>
+__global__ __launch_bounds__(256) void k_theta_ggl_flat4v(double* __restrict__ Theta, double* __restrict__ X,
+                                                          double* __restrict__ C, const double* __restrict__ Omega,
+                                                          const double* __restrict__ OmegaPrev,
+                                                          const double* __restrict__ L, double l1, double l2,
+                                                          double* __restrict__ partials, int K, int p,
+                                                          const int* __restrict__ skip, const double* __restrict__ l1G,
+                                                          const double* __restrict__ l2G, const double* __restrict__ gsq)
+{
+    static_assert(FLAT4_CHUNKS == 2, "128 elements per workgroup");
+    __shared__ double2 ssh[4][64];
+    __shared__ double scratch[GGL_NNORM * 4];
+    if (spec_failed(skip)) return;
+    const size_t pp = (size_t)p * p;
+    {
+        const size_t goff = (size_t)blockIdx.y * K * pp;
+        Theta += goff; Omega += goff;
+        if (X) X += goff;
+        if (C) C += goff;
+        if (OmegaPrev) OmegaPrev += goff;
+        if (L) L += goff;
+        if (l1G) { l1 = l1G[(size_t)blockIdx.y * K]; l2 = l2G[(size_t)blockIdx.y * K]; }
+        if (partials) partials += (size_t)blockIdx.y * gridDim.x * GGL_NNORM;
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int kb = wid * KQ;
+    double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
+    const size_t e = ((size_t)blockIdx.x * 64 + lane) * 2;
+    const bool live = e < pp;                  // pp even: e + 1 < pp as well
+    double2 om[KQ], x[KQ], u[KQ];
+    double2 ss = {0.0, 0.0};
+    auto ld2 = [](const double* q) { return *reinterpret_cast<const double2*>(q); };
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            if (kb + q < K) {
+                const size_t o = (size_t)(kb + q) * pp + e;
+                om[q] = ld2(Omega + o);
+                x[q] = X ? ld2(X + o) : double2{0.0, 0.0};
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            if (kb + q < K) {
+                const double2 l = L ? ld2(L + (size_t)(kb + q) * pp + e) : double2{0.0, 0.0};
+                u[q].x = (om[q].x + l.x) + x[q].x;
+                u[q].y = (om[q].y + l.y) + x[q].y;
+                const double s0 = soft(u[q].x, l1), s1 = soft(u[q].y, l1);
+                ss.x += s0 * s0;
+                ss.y += s1 * s1;
+            }
+        }
+    }
+    ssh[wid][lane] = ss;
+    __syncthreads();
+    if (live) {
+        double2 tot;
+        if (gsq) tot = ld2(gsq + e);
+        else {
+            tot.x = (ssh[0][lane].x + ssh[1][lane].x) + (ssh[2][lane].x + ssh[3][lane].x);
+            tot.y = (ssh[0][lane].y + ssh[1][lane].y) + (ssh[2][lane].y + ssh[3][lane].y);
+        }
+        const double a0 = fmax(sqrt(tot.x), l2), a1 = fmax(sqrt(tot.y), l2);
+        const double m0 = a0 - l2, m1 = a1 - l2;
+        const int i0 = (int)(e / p), j0 = (int)(e - (size_t)i0 * p);
+        const bool off0 = (i0 != j0);
+        const bool off1 = (i0 != j0 + 1);          // p even and e even: e + 1 is the next column of the same row
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            if (kb + q < K) {
+                const size_t o = (size_t)(kb + q) * pp + e;
+                double2 th;
+                th.x = off0 ? soft(u[q].x, l1) * m0 / a0 : u[q].x;
+                th.y = off1 ? soft(u[q].y, l1) * m1 / a1 : u[q].y;
+                *reinterpret_cast<double2*>(Theta + o) = th;
+                if (FUSE_DUAL) {
+                    double2 xn;
+                    xn.x = x[q].x + (om[q].x - th.x);
+                    xn.y = x[q].y + (om[q].y - th.y);
+                    *reinterpret_cast<double2*>(X + o) = xn;
+                    const double2 op = ld2(OmegaPrev + o);
+                    const double d0 = om[q].x - op.x, d1 = om[q].y - op.y;
+                    acc[0] += om[q].x * om[q].x + om[q].y * om[q].y;
+                    acc[1] += th.x * th.x + th.y * th.y;
+                    acc[2] += xn.x * xn.x + xn.y * xn.y;
+                    acc[3] += (om[q].x - th.x) * (om[q].x - th.x) + (om[q].y - th.y) * (om[q].y - th.y);
+                    acc[4] += d0 * d0 + d1 * d1;
+                } else if (C) {
+                    double2 cv;
+                    cv.x = (th.x - x[q].x) - om[q].x;
+                    cv.y = (th.y - x[q].y) - om[q].y;
+                    *reinterpret_cast<double2*>(C + o) = cv;
+                }
+            }
+        }
+    }
+    if (FUSE_DUAL) {
+#pragma unroll
+        for (int v = 0; v < GGL_NNORM; ++v) acc[v] = wave_sum(acc[v]);
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) scratch[wid * GGL_NNORM + v] = acc[v];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double* o = partials + (size_t)blockIdx.x * GGL_NNORM;
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v)
+                o[v] = (scratch[v] + scratch[GGL_NNORM + v]) + (scratch[2 * GGL_NNORM + v] + scratch[3 * GGL_NNORM + v]);
+        }
+    }
+}
+
 static inline int flat4_blocks(int p) { return (int)(((size_t)p * p + 64 * FLAT4_CHUNKS - 1) / (64 * FLAT4_CHUNKS)); }
 
 template <int KQ>
@@ -740,6 +856,13 @@ static void launch_flat4(hipStream_t st, double* Theta, double* X, double* C, co
                          const double* gsq = nullptr)
 {
     dim3 grid(flat4_blocks(p), G), blk(256);
+    if ((p & 1) == 0) {          // p^2 even: two consecutive elements per lane, 16-byte accesses
+        if (fuse_dual)
+            hipLaunchKernelGGL((k_theta_ggl_flat4v<KQ, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+        else
+            hipLaunchKernelGGL((k_theta_ggl_flat4v<KQ, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+        return;
+    }
     if (fuse_dual)
         hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
     else
