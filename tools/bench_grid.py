@@ -27,7 +27,7 @@ def main():
     S = S[0]
     lam = np.logspace(0, -2, a.points)
     eye = np.eye(p)
-    batch.ADMM_SGL_batch(S, lam[:2], Omega_0=eye, X_0=eye, max_iter=3)            # warm-up (library load, plans)
+    batch.ADMM_SGL_batch(S, lam[:2], Omega_0=eye, X_0=eye, max_iter=3, selection_stats=True)   # warm-up (library load: HIP code objects, rocSOLVER behind the criteria)
     t0 = time.perf_counter()
     res = batch.ADMM_SGL_batch(S, lam, Omega_0=eye, X_0=eye, tol=a.tol, rtol=a.tol)
     t_batch = time.perf_counter() - t0

@@ -40,7 +40,7 @@ def main():
     Nk = np.full(K, N)
     L1, L2 = ms.lambda_grid(l1, l2)
     lam1, lam2 = L1.T.ravel(), L2.T.ravel()
-    quiet(batch.ADMM_MGL_batch, S, lam1[:2], lam2[:2], a.reg, max_iter=3)           # warm-up (library load, plans)
+    quiet(batch.ADMM_MGL_batch, S, lam1[:2], lam2[:2], a.reg, max_iter=3, selection_stats=True)   # warm-up (library load: HIP code objects, rocSOLVER behind the criteria)
     t0 = time.perf_counter()
     res = quiet(batch.ADMM_MGL_batch, S, lam1, lam2, a.reg, tol=a.tol, rtol=a.tol)
     t_batch = time.perf_counter() - t0
