@@ -21,7 +21,9 @@ def main():
     ap.add_argument("--points", type=int, default=20)
     ap.add_argument("--tol", type=float, default=1e-7)
     ap.add_argument("--no-sequential", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="ctx option for every engine")
     a = ap.parse_args()
+    solver.ENGINE_OPTIONS.update({kv.split("=")[0]: float(kv.split("=")[1]) for kv in a.opt})
     p, N = a.p, 2 * a.p
     S, _ = synth.make_problem("GGL", 1, p, N=N, seed=1235)
     S = S[0]
