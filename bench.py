@@ -13,9 +13,12 @@ The timed region is EXACTLY ``steps`` iterations between barrier + synchronize o
 ``--regions`` times back to back (default 7; 20 iterations are only ~20 ms of wall clock) and ``value`` /
 ``ms_per_step`` are those of the MEDIAN region, with the fastest and slowest one reported next to it.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the K=32 stack is sharded into K/N slabs
-(strong scaling); per iteration one (p,p) fp64 all-reduce of the group sums of squares and one
-5-scalar all-reduce of the residual norms go over RCCL.
+N > 1, one rank per GPU: the K=32 stack is sharded into K/N slabs (strong scaling); per iteration one (p,p) fp64
+all-reduce of the group sums of squares and one 5-scalar all-reduce of the residual norms go over RCCL.  Started either
+by a launcher (``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: RANK / WORLD_SIZE in the
+environment) or bare (``python bench.py --gpus N``): the bare process then starts the N ranks ITSELF as a child
+``torch.distributed.run`` on 127.0.0.1 before anything in it has touched the GPU (it never does), relays rank 0's JSON
+line and exits with the child's code.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the phase that dominates the iteration, timed live with HIP events on the ctx stream
@@ -125,12 +128,38 @@ def cpu_baseline(S, reg, lambda1, lambda2, latent, mu1, iters, threads):
     with limiter:
         orc.ADMM_MGL(S, lambda1, lambda2, reg, Om0, max_iter=1, tol=1e-20, rtol=1e-20, latent=latent, mu1=mu1)
         t0 = time.perf_counter()
-        orc.ADMM_MGL(S, lambda1, lambda2, reg, Om0, max_iter=iters, tol=1e-20, rtol=1e-20, latent=latent, mu1=mu1)
+        sol, _ = orc.ADMM_MGL(S, lambda1, lambda2, reg, Om0, max_iter=iters, tol=1e-20, rtol=1e-20, latent=latent, mu1=mu1)
         dt = time.perf_counter() - t0
     return {"value": iters / dt, "unit": "ADMM iters/s", "cores": int(threads), "kind": "port",
             "sample": f"{iters} ADMM iterations of the same ({reg}, K={K}, p={p}) problem from the identity start "
                       f"(oracle/ggl_oracle.py: numpy.linalg.eigh + C prox_p) on {threads} BLAS threads of the box's "
-                      f"{os.cpu_count()} cores, {dt:.1f} s"}
+                      f"{os.cpu_count()} cores, {dt:.1f} s"}, sol
+
+
+def spawn_command(gpus, argv, port=None):
+    """The child launcher a bare ``python bench.py --gpus N`` (N > 1, no WORLD_SIZE in the environment) starts."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(gpus, argv, runner=None):
+    """Run the N ranks as a child process group and relay their output.  The calling process has not initialised the
+    GPU (nothing here imports torch or loads the HIP library) and does not exec: it waits for the child and returns its
+    exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = spawn_command(gpus, argv)
+    proc = (runner or subprocess.run)(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in (proc.stdout or "").splitlines():
+        print(line, flush=True)
+    return proc.returncode
 
 
 def main():
@@ -148,7 +177,13 @@ def main():
                     help="N > 1: RCCL behind the C ABI (one call per iteration) or torch.distributed collectives")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="ctx option (gglasso_amd._lib.OPTIONS), e.g. --opt pipeline=0; repeatable")
+    ap.add_argument("--no-exact-region", action="store_true",
+                    help="skip the one extra timed region at ns_tol=0 (value_exact)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare start on a multi-GPU node: become the launcher (before any GPU call; never re-exec)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     from gglasso_amd import synth, solver, _lib
@@ -158,7 +193,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # GGL_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (1-GPU dev boxes)
     distributed = world > 1 or bool(os.environ.get("GGL_BENCH_FORCE_DIST"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it bare (it launches its own ranks) "
+                         "or under torch.distributed.run with --nproc-per-node equal to --gpus")
+    if torch.cuda.device_count() < world:       # device_count() does not initialise the GPU
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     comm = None
     if distributed:
@@ -169,7 +208,7 @@ def main():
         import torch.distributed as dist
         from gglasso_amd.dist import RcclComm, TorchComm, shard_bounds
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        comm = RcclComm() if args.comm == "capi" else TorchComm(device=f"cuda:{local_rank}")
+        comm = RcclComm(device=local_rank) if args.comm == "capi" else TorchComm(device=f"cuda:{local_rank}")
 
     reg, K, p, latent, l1, l2, seed = WORKLOADS[args.workload]
     S, _ = synth.make_problem(reg, K, p, N=2 * p, seed=seed)
@@ -205,11 +244,8 @@ def main():
     # Every timed region is the SAME piece of work: back to the identity start, `warmup` untimed iterations, then exactly
     # `steps` timed ones.  (The solve converges to the 1e-20 tolerances' floor after ~150 iterations and would stop by
     # itself, so the regions cannot simply follow each other.)
-    eng.profile(0)
-    region_s = []
-    ns0 = ns1 = None
-    rho = 1.0
-    for _ in range(max(1, args.regions)):
+    def one_region():
+        """-> (seconds of the timed `steps` iterations, max over ranks; ns_stats before; ns_stats after; rho)"""
         eng.profile(0)
         eng.set_state(Om0, Om0, np.zeros_like(S_loc))
         rho = 1.0
@@ -218,9 +254,6 @@ def main():
         # live HIP-event timing of the dominant (eigen / matrix-function) phases only during the timed regions:
         # every extra event pair costs a few microseconds of host time per iteration
         eng.profile(2)
-        if ns0 is None:
-            eng.profile_read(reset=True)
-            ns0 = eng.ns_stats()
         na = eng.ns_stats()
         fence()
         t0 = time.perf_counter()
@@ -228,12 +261,23 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         nb = eng.ns_stats()
-        ns1 = nb if ns1 is None else {k: (ns1[k] + nb[k] - na[k]) if k not in ("last_parts", "last_variant") else nb[k]
-                                      for k in nb}
         if distributed:
             t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
+        return dt, na, nb, rho
+
+    effective_options = {name: eng.get_option(name) for name in _lib.OPTIONS}      # what the library actually runs with
+    eng.profile_read(reset=True)
+    region_s = []
+    ns0 = ns1 = None
+    rho = 1.0
+    for _ in range(max(1, args.regions)):
+        dt, na, nb, rho = one_region()
+        if ns0 is None:
+            ns0 = na
+        ns1 = nb if ns1 is None else {k: (ns1[k] + nb[k] - na[k]) if k not in ("last_parts", "last_variant") else nb[k]
+                                      for k in nb}
         region_s.append(dt)
     dt = statistics.median(region_s)
     timed_iters = args.steps * len(region_s)
@@ -246,6 +290,34 @@ def main():
     for ph, v in prof_all.items():
         if ph not in ("eig_omega", "eig_omega2", "eig_L"):
             prof[ph] = v
+    # one more region with the Omega-step iterated to fp64 resolution (GGL_OPT_NS_TOL = 0): the same record then carries
+    # the rate at the accuracy of an eigendecomposition next to the rate at the default stopping tolerance
+    exact = None
+    omega_is_ns = (args.eig == _lib.EIG_NEWTON_SCHULZ) or (args.eig == _lib.EIG_AUTO and p > _lib.JACOBI_MAX_P)
+    if omega_is_ns and not args.no_exact_region and effective_options["ns_tol"] > 5e-16:
+        eng.set_option("ns_tol", 0.0)
+        dte, na, nb, _ = one_region()
+        eng.profile(0)
+        eng.profile_read(reset=True)
+        exact = {"value": args.steps / dte, "ms_per_step": dte / args.steps * 1e3, "ns_tol": 0.0, "regions": 1,
+                 "products_per_step": (nb["units"] - na["units"]) / max(1, nb["calls"] - na["calls"])}
+        eng.set_option("ns_tol", effective_options["ns_tol"])
+    # CPU oracle on this box's host cores (bounded sample) -- and, from the SAME oracle run, the parity of this engine
+    # after the same number of iterations of the same problem (outside every timed region)
+    cpu = parity = None
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        cpu, ref = cpu_baseline(S, reg, l1, l2, latent, mu1, args.cpu_iters, args.cpu_threads)
+        eng.profile(0)
+        eng.set_state(Om0, Om0, np.zeros_like(S_loc))
+        run(args.cpu_iters, 1.0)
+        got = eng.state()
+        names = ("Omega", "Theta", "X") + (("L",) if latent else ())
+        parity = {"iters": args.cpu_iters, "against": "oracle/ggl_oracle.py (the cpu_baseline run), identity start, rho rule on",
+                  "max_abs_vs_oracle": max(float(np.abs(got[nm] - ref[nm]).max()) for nm in names),
+                  "theta_fro_vs_oracle": float(np.linalg.norm(got["Theta"] - ref["Theta"])),
+                  "theta_fro": float(np.linalg.norm(ref["Theta"])), "ns_tol": effective_options["ns_tol"],
+                  "tolerance": "north_star: Theta within 1e-8 Frobenius of the reference"}
+    n_ranks_seen = eng.comm_count() if (distributed and args.comm == "capi") else (world if distributed else 1)
     eng.close()
 
     if rank == 0:
@@ -330,7 +402,9 @@ def main():
                        if distributed else "single GPU",
                        "omega_step": "lds_jacobi" if eig_jacobi else ("newton_schulz_fp64_mfma" if omega_ns
                                                                          else "rocsolver_dsyevd+mfma_recon"),
-                       "options": options or None},
+                       # every ctx option as the library ran it (include/ggl_hip.h GGL_OPT_*): ns_tol is the relative
+                       # spectral accuracy the Omega-step's matrix square root is iterated to (0 = fp64 resolution)
+                       "options": effective_options, "options_overridden": sorted(options) or None},
             "timed_regions": {"count": len(region_s), "steps_each": args.steps, "statistic": "median",
                               "ms_per_step_min": min(region_s) / args.steps * 1e3,
                               "ms_per_step_max": max(region_s) / args.steps * 1e3},
@@ -350,8 +424,14 @@ def main():
                               "end_of_iteration_poll_timeouts": ns1["spin_timeouts"] - ns0["spin_timeouts"]}
             if omega_ns else None,
         }
-        if not distributed and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, reg, l1, l2, latent, mu1, args.cpu_iters, args.cpu_threads)
+        if exact is not None:
+            out["value_exact"] = exact
+        if distributed:
+            out["n_ranks_seen"] = n_ranks_seen      # ncclCommCount of the engine's communicator (capi) / the process group's size
+        if parity is not None:
+            out["parity"] = parity
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if distributed:
         torch.distributed.barrier()

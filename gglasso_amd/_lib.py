@@ -36,6 +36,7 @@ _SIGNATURES = {
     "ggl_version": ([], _i),
     "ggl_last_error": ([], ctypes.c_char_p),
     "ggl_device_count": ([], _i),
+    "ggl_theta_limits": ([ctypes.POINTER(_i)], _i),
     "ggl_ctx_create": ([_i, _i, _i, _i, _vp, ctypes.POINTER(_vp)], _i),
     "ggl_ctx_destroy": ([_vp], _i),
     "ggl_ctx_sync": ([_vp], _i),
@@ -56,6 +57,7 @@ _SIGNATURES = {
     "ggl_comm_unique_id": ([ctypes.c_char_p], _i),
     "ggl_comm_init": ([_vp, _i, _i, ctypes.c_char_p], _i),
     "ggl_comm_destroy": ([_vp], _i),
+    "ggl_comm_count": ([_vp, ctypes.POINTER(_i)], _i),
     "ggl_allreduce_groupsq": ([_vp], _i),
     "ggl_allreduce_norms": ([_vp], _i),
     "ggl_admm_step_sharded": ([_vp, _d, _d, _d, _dp, _dp], _i),
@@ -145,6 +147,13 @@ def load_dev():
     if not os.path.exists(DEV_LIB_PATH):
         raise RuntimeError(f"{DEV_LIB_PATH} is missing: python -m gglasso_amd.build --dev")
     return _bind(_bind(ctypes.CDLL(DEV_LIB_PATH), _SIGNATURES), _DEV_SIGNATURES)
+
+
+def theta_limits():
+    """{'GGL': largest K/G of the batched GGL grid, 'FGL': largest K of the FGL Theta-step} (host only, no GPU)."""
+    out = (_i * 2)()
+    check(load().ggl_theta_limits(out))
+    return {"GGL": int(out[0]), "FGL": int(out[1])}
 
 
 def last_error():

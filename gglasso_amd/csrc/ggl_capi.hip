@@ -210,6 +210,14 @@ static bool use_ns(int eig, int p)
 extern "C" int ggl_version(void) { return GGL_VERSION; }
 extern "C" const char* ggl_last_error(void) { return g_err; }
 
+extern "C" int ggl_theta_limits(int out[2])
+{
+    ARGCHK(out, "out");
+    out[0] = GGL_FLAT_MAX_K;      // batched GGL grid: instances per problem the per-element Theta kernel takes
+    out[1] = fgl_max_K();         // FGL: K-vectors that fit the LDS scan buffer of the Condat tile kernel
+    return GGL_OK;
+}
+
 extern "C" int ggl_device_count(void)
 {
     int n = 0;
@@ -501,7 +509,11 @@ static int drop_prelaunch(ggl_ctx* c)
     // (spec_c still holds the bounds of the last VALIDATED chain: the replacement chain is built from them exactly as
     // the dropped one was, so dropping changes no iterate)
     HIPCHK(hipStreamSynchronize(c->stream));      // the chain's parts were joined into the main stream when it was launched
+    // the dropped chain may have failed its validation: clear BOTH copies of every flag slot.  (omega_step re-zeroes only
+    // the slots of the parts it launches; a part count changed after the drop would otherwise leave a stale 1 on the
+    // device that every later speculative step's Theta / dual kernels read as "skip" -- ADVICE r2.)
     for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) c->spec_flag_h[h] = 0;
+    if (c->spec_flag) HIPCHK(hipMemsetAsync(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int), c->stream));
     c->pre_cw_pending = false;      // its Collatz-Wielandt vector is never flipped in: the replacement rewrites it
     return GGL_OK;
 }
@@ -1247,11 +1259,14 @@ static bool take_prelaunched(ggl_ctx* c, int latent)
     if (!c->pre_valid) return false;
     bool have = !latent;
     for (int k = 0; have && k < c->K; ++k) have = (c->par_h[k] == c->pre_beta[k]);
-    c->pre_valid = false;
     if (!have) {
-        c->pre_dropped += 1;
+        // wait for the forgotten chain before the replacement rewrites the pinned coefficient / bound / flag tables its
+        // copy kernels and k_cw_final may still be reading or writing (timing-safe is not safe); rare -- a
+        // rho change the rho rule did not predict -- so the synchronisation costs nothing measurable
+        (void)drop_prelaunch(c);
         return false;
     }
+    c->pre_valid = false;
     c->cur ^= 1;
     c->spec_pending = c->pre_spec_pending;
     c->cw_pending = c->pre_cw_pending;
@@ -1813,6 +1828,16 @@ extern "C" int ggl_comm_init(ggl_ctx* c, int rank, int nranks, const char id[128
     c->comm = comm;
     c->comm_rank = rank;
     c->comm_nranks = nranks;
+    return GGL_OK;
+}
+
+extern "C" int ggl_comm_count(ggl_ctx* c, int* nranks_out)
+{
+    ARGCHK(c && nranks_out, "ctx, nranks_out");
+    ARGCHK(c->comm, "ggl_comm_init first");
+    const RcclApi* api = rccl_api(nullptr);
+    if (!api || !api->CommCount) return fail(GGL_E_COMM, "RCCL unavailable: ncclCommCount");
+    NCCLCHK(api, api->CommCount(c->comm, nranks_out));
     return GGL_OK;
 }
 

@@ -24,6 +24,7 @@ const RcclApi* rccl_api(const char** err)
             api.CommDestroy = (int (*)(RcclApi::Comm))dlsym(h, "ncclCommDestroy");
             api.AllReduce = (int (*)(const void*, void*, size_t, int, int, RcclApi::Comm, hipStream_t))dlsym(h, "ncclAllReduce");
             api.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+            api.CommCount = (int (*)(RcclApi::Comm, int*))dlsym(h, "ncclCommCount");
             ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString;
             if (!ok) api.load_error = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
         }

@@ -15,6 +15,7 @@ struct RcclApi {
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommCount)(Comm, int*) = nullptr;      // optional (ggl_comm_count)
     int (*AllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, Comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     static constexpr int Float64 = 8, Sum = 0;

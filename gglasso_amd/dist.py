@@ -113,32 +113,48 @@ class RcclComm:
     backend = "rccl-capi"
     device_norms = True
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, device=None):
+        """device: the GPU index of this rank's engine.  torch's own collectives below (the object broadcast of the
+        unique id, the host-side sum) run on torch's CURRENT device, which is cuda:0 in every rank of a caller that never
+        called torch.cuda.set_device -- so they are issued under ``torch.cuda.device(device)``; None: taken from the
+        engine in ``attach``."""
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.device = None if device is None else int(device)
         self.stream_handle = None           # the ctx creates its own stream; the collectives are issued on it in C
+
+    def _on_device(self):
+        import contextlib
+        if self.dist.get_backend(self.group) != "nccl" or self.device is None:
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.device(self.device)
 
     def attach(self, eng):
         """Create this rank's communicator inside the engine's ctx (collective: every rank calls it)."""
         import ctypes
+        if self.device is None:
+            self.device = getattr(eng, "device", None)
         box = [None]
         if self.rank == 0:
             buf = ctypes.create_string_buffer(128)
             _lib.check(_lib.load().ggl_comm_unique_id(buf))
             box[0] = buf.raw
-        self.dist.broadcast_object_list(box, src=0, group=self.group)
+        with self._on_device():
+            self.dist.broadcast_object_list(box, src=0, group=self.group)
         eng.comm_init(self.rank, self.world, box[0])
 
     def allreduce_norms(self, arr):
         """Host-side sum over ranks (objective values with measure=True; not on the iteration path)."""
         import torch
         t = torch.as_tensor(np.asarray(arr, dtype=np.float64))
-        if self.dist.get_backend(self.group) == "nccl":
-            t = t.cuda()
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return t.cpu().numpy()
+        with self._on_device():
+            if self.dist.get_backend(self.group) == "nccl":
+                t = t.to("cuda" if self.device is None else f"cuda:{self.device}")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            return t.cpu().numpy()
 
 
 def _hip_groupsq_tensor(self, torch, device):

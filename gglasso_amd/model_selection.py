@@ -425,7 +425,10 @@ def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma
     RANK = np.nan * np.zeros((K, grid1, grid2))
     TAU = np.zeros((K, grid1, grid2)) if thresholding else None
     if batched is None:
-        batched = (solver is ADMM_MGL) and isinstance(S, np.ndarray) and (reg == 'FGL' or K <= 32)
+        # both penalties fall back to the sequential walk beyond what their batched Theta kernel takes (the library
+        # exports the limits; ADVICE r2: FGL used to surface the limit as an AssertionError instead)
+        from ._lib import theta_limits
+        batched = (solver is ADMM_MGL) and isinstance(S, np.ndarray) and K <= theta_limits()[reg]
     order = [(g1, g2) for g2 in range(grid2) for g1 in range(grid1)]       # down the columns, as the reference
 
     sols = {}

@@ -41,6 +41,7 @@ class HipEngine:
         flags = int(eig) | (0 if stream is None else _lib.CTX_STREAM_GIVEN)
         check(self.lib.ggl_ctx_create(int(device), self.K, self.p, flags, stream, h))
         self.h = h
+        self.device = int(device)
         self.stream_handle = None if stream is None else int(stream)
         for name, value in {**ENGINE_OPTIONS, **(options or {})}.items():
             self.set_option(name, value)
@@ -125,6 +126,13 @@ class HipEngine:
     # -- RCCL behind the C ABI (K-sharded GGL: the whole iteration incl. both all-reduces is one call) -----------
     def comm_init(self, rank, nranks, unique_id):
         check(self.lib.ggl_comm_init(self.h, int(rank), int(nranks), bytes(unique_id)))
+
+    def comm_count(self):
+        """ncclCommCount of the ctx's communicator: the ranks RCCL itself sees."""
+        import ctypes
+        n = ctypes.c_int(0)
+        check(self.lib.ggl_comm_count(self.h, ctypes.byref(n)))
+        return int(n.value)
 
     def step_sharded(self, rho, lambda1, lambda2, nk):
         """One K-sharded GGL iteration on this rank's slab; returns the five GLOBAL sums (same on every rank)."""

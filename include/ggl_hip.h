@@ -185,6 +185,8 @@ int ggl_norms_read(ggl_ctx *ctx, double out_norms[5]);
 int ggl_comm_unique_id(char id_out[128]);
 int ggl_comm_init(ggl_ctx *ctx, int rank, int nranks, const char id[128]);
 int ggl_comm_destroy(ggl_ctx *ctx);
+/* ncclCommCount of the ctx's communicator: the number of ranks RCCL itself sees (bench.py reports it as n_ranks_seen) */
+int ggl_comm_count(ggl_ctx *ctx, int *nranks_out);
 int ggl_allreduce_groupsq(ggl_ctx *ctx);
 int ggl_allreduce_norms(ggl_ctx *ctx);
 int ggl_admm_step_sharded(ggl_ctx *ctx, double rho, double lambda1, double lambda2, const double *nk,
@@ -211,6 +213,10 @@ int ggl_get_state_k(ggl_ctx *ctx, int k, double *Omega, double *Theta, double *L
  * GGL: K/G <= 32; state exactly symmetric. */
 int ggl_mgl_batch_step(ggl_ctx *ctx, int G, const double *rho, const double *lambda1, const double *lambda2,
                        int reg, int latent, const double *mu1, const double *nk, double *out_norms);
+
+/* host only: out = {largest K/G of the batched GGL grid (per-element Theta kernel), largest K of the FGL Theta-step (the
+ * K-vectors of a tile of pairs live in LDS)}; callers choose between the batched grid and the sequential walk with it */
+int ggl_theta_limits(int out[2]);
 
 /* X <- factor * X : dual rescale after a rho update (admm_solver.py:236). */
 int ggl_scale_X(ggl_ctx *ctx, double factor);

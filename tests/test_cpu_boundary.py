@@ -405,3 +405,35 @@ def test_batched_mgl_grid_search_matches_reference_tables(oracle_engine):
     selection, thresholding, sequential mode) over the test-only oracle engine against the reference's tables G16."""
     from grid_checks import check_mgl_grid_search
     _quiet(check_mgl_grid_search, load_golden)
+
+
+def test_bench_bare_multi_gpu_start_launches_its_own_ranks():
+    """``python bench.py --gpus N`` without a launcher must start its N ranks itself -- as a CHILD
+    ``torch.distributed.run`` on 127.0.0.1, from a process that has not touched the GPU (no torch, no HIP library
+    loaded) -- relay the child's output and return its exit code."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, types
+sys.argv = ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"]
+import bench
+seen = {}
+def runner(cmd, env=None, stdout=None, text=None):
+    seen["cmd"], seen["env"] = cmd, env
+    return types.SimpleNamespace(stdout='{"metric": "x", "n_gpus": 4}\n', returncode=7)
+rc = bench.spawn_ranks(4, sys.argv[1:], runner=runner)
+assert rc == 7, rc
+cmd = seen["cmd"]
+assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"], cmd
+assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1", cmd
+assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py"), cmd
+assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+assert "torch" not in sys.modules and "gglasso_amd" not in sys.modules, "the launcher process must stay off the GPU"
+print("ok")
+"""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().split("\n")
+    assert lines[-1] == "ok" and lines[0].startswith('{"metric"'), out.stdout     # the child's JSON line is relayed

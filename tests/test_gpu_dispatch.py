@@ -92,6 +92,25 @@ def test_headline_dispatch_ggl_K32_p500(stats):
     assert st["last_parts"] == 2 and st["last_variant"] == 17, st
 
 
+def test_headline_dispatch_exact_omega_step(stats, monkeypatch):
+    """The headline at its real dispatch with the Omega-step iterated to fp64 resolution (GGL_OPT_NS_TOL = 0): the
+    two-part chains then run the 8-product schedule (two degree-nine steps) and the iterates agree with the oracle's
+    eigendecomposition to 2e-12."""
+    from gglasso_amd import solver
+    monkeypatch.setitem(solver.ENGINE_OPTIONS, "ns_tol", 0.0)
+    S, Om0 = _problem("GGL", 32, 500, 1239)
+    kw = dict(max_iter=4, tol=1e-20, rtol=1e-20, update_rho=False, rho=2.0)
+    with oracle_threads():
+        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
+    out, info = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
+    _check_state(out, ref, ("Omega", "Theta", "X"), 2e-12)
+    st = stats[-1]
+    assert st["last_parts"] == 2 and st["last_variant"] == 17, st
+    assert st["spec_calls"] >= 1 and st["stable_calls"] == 0, st
+    # every Omega-step (incl. a pre-launched chain that was dropped) ran 8 symmetric products of the stack
+    assert st["units"] == 8 * st["calls"], st
+
+
 def test_c3_dispatch_ggl_K20_p200(stats):
     from gglasso_amd import solver
     S, Om0 = _problem("GGL", 20, 200, 1236)

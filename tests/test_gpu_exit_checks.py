@@ -1,0 +1,162 @@
+"""a18: the exit checks after the ADMM loop -- solver/admm_solver.py:284-301, solver/single_admm_solver.py:244-263,
+solver/ext_admm_solver.py:290-311 -- as VALUES: ``ggl_exit_checks`` / ``ggl_exit_checks_k`` (asymmetry maxima through
+``k_asym_max``, ``eigvalsh(Theta - L).min()`` and ``eigvalsh(L).min()`` through the LDS Jacobi kernel for p <= 128 and
+rocSOLVER above) against NumPy on states with a KNOWN asymmetry and a KNOWN indefinite Theta - L / L, and then the three
+warning branches of every solver on the real engine.
+"""
+import contextlib
+import io
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _capture(fn, *a, **k):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = fn(*a, **k)
+    return res, buf.getvalue()
+
+
+def _sym_with_spectrum(rng, p, eigs):
+    Q, _ = np.linalg.qr(rng.standard_normal((p, p)))
+    A = (Q * eigs) @ Q.T
+    return 0.5 * (A + A.T)
+
+
+def _known_state(p, K, seed):
+    """Omega SPD; L symmetric with smallest eigenvalue -0.3 (instance 1) and 0.05 elsewhere; Theta = L + M with
+    min eig(M) = -0.2 in instance 2 (0.4 elsewhere); then ONE entry of each stack moved by 1e-4 / 2e-4 / 3e-4 in the
+    upper triangle only (numpy.linalg.eigvalsh, like the device eigensolvers, reads the lower one)."""
+    rng = np.random.default_rng(seed)
+    Om = np.stack([_sym_with_spectrum(rng, p, np.linspace(0.5, 3.0, p)) for _ in range(K)])
+    L = np.stack([_sym_with_spectrum(rng, p, np.linspace(-0.3 if k == 1 else 0.05, 1.0, p)) for k in range(K)])
+    M = np.stack([_sym_with_spectrum(rng, p, np.linspace(-0.2 if k == 2 else 0.4, 2.0, p)) for k in range(K)])
+    Th = L + M
+    Om[0, 3, 7] += 1e-4
+    Th[K - 1, 1, p - 2] -= 2e-4
+    L[1, 0, 5] += 3e-4
+    X = np.zeros_like(Om)
+    return Om, Th, L, X
+
+
+def _numpy_checks_k(Om, Th, L, latent):
+    K = Om.shape[0]
+    out = np.zeros((K, 5))
+    for k in range(K):
+        out[k, 0] = np.abs(Om[k] - Om[k].T).max()
+        out[k, 1] = np.abs(Th[k] - Th[k].T).max()
+        out[k, 2] = np.abs(L[k] - L[k].T).max()
+        out[k, 3] = np.linalg.eigvalsh(Th[k] - L[k]).min()
+        out[k, 4] = np.linalg.eigvalsh(L[k]).min() if latent else 0.0
+    return out
+
+
+@pytest.mark.parametrize("p", [60, 200])
+@pytest.mark.parametrize("latent", [True, False])
+def test_exit_check_values_against_numpy(p, latent):
+    from gglasso_amd import solver
+    K = 3
+    Om, Th, L, X = _known_state(p, K, 40 + p)
+    if not latent:
+        L = np.zeros_like(L)
+    eng = solver.HipEngine(np.repeat(np.eye(p)[None], K, axis=0), Om, Th, X, L_0=L)
+    try:
+        per = eng.exit_checks_k(latent)
+        tot = eng.exit_checks(latent)
+    finally:
+        eng.close()
+    want = _numpy_checks_k(Om, Th, L, latent)
+    assert np.abs(per - want).max() <= 1e-10, (per, want)
+    want_tot = np.concatenate([want[:, :3].max(axis=0), want[:, 3:].min(axis=0)])
+    assert np.abs(tot - want_tot).max() <= 1e-10, (tot, want_tot)
+    # the known numbers themselves (guards the construction)
+    assert abs(want[0, 0] - 1e-4) <= 1e-12 and abs(want[K - 1, 1] - 2e-4) <= 1e-12
+    if latent:
+        assert abs(want[1, 2] - 3e-4) <= 1e-12
+        assert abs(want_tot[4] + 0.3) <= 1e-3 and want_tot[3] < -0.15
+
+
+@pytest.mark.parametrize("p", [60, 200])
+def test_exit_report_branches_on_the_real_engine(p):
+    """_exit_report (the host half, admm_solver.py:284-301) fed by the REAL engine: three asymmetry warnings with the
+    reference's numbers, both definiteness prints; and a clean state prints and warns nothing."""
+    from gglasso_amd import solver
+    K = 3
+    Om, Th, L, X = _known_state(p, K, 7 + p)
+    eng = solver.HipEngine(np.repeat(np.eye(p)[None], K, axis=0), Om, Th, X, L_0=L)
+    try:
+        with pytest.warns(UserWarning) as rec:
+            _, out = _capture(solver._exit_report, eng, True, 1e-5, True)
+    finally:
+        eng.close()
+    msgs = [str(w.message) for w in rec]
+    assert [m.split(" variable")[0] for m in msgs] == ["Omega", "Theta", "L"]
+    for m, dev in zip(msgs, (1e-4, 2e-4, 3e-4)):
+        got = float(m.split("largest deviation is ")[1].rstrip("."))
+        assert abs(got - dev) <= 1e-12, m
+    mn_tl = min(np.linalg.eigvalsh(Th[k] - L[k]).min() for k in range(K))
+    mn_l = min(np.linalg.eigvalsh(L[k]).min() for k in range(K))
+    lines = out.strip().split("\n")
+    assert lines[0].startswith("WARNING: Theta (Theta - L resp.) is not positive definite. Solve to higher accuracy! (min EV is ")
+    assert abs(float(lines[0].split("min EV is ")[1].rstrip(")")) - mn_tl) <= 1e-10
+    assert lines[1].startswith("WARNING: L is not positive semidefinite. Solve to higher accuracy! (min EV is ")
+    assert abs(float(lines[1].split("min EV is ")[1].rstrip(")")) - mn_l) <= 1e-10
+    # clean state: symmetric, Theta - L and L positive definite
+    rng = np.random.default_rng(3)
+    A = np.stack([_sym_with_spectrum(rng, p, np.linspace(0.5, 2.0, p)) for _ in range(K)])
+    eng = solver.HipEngine(np.repeat(np.eye(p)[None], K, axis=0), A, 2.0 * A, np.zeros_like(A), L_0=A)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            _, out = _capture(solver._exit_report, eng, True, 1e-5, True)
+    finally:
+        eng.close()
+    assert out == ""
+
+
+def _indefinite_start(p, K, seed):
+    """A dual start that makes Theta = prox(Omega + X) indefinite after ONE iteration: X_0 = -3 I + small symmetric noise."""
+    rng = np.random.default_rng(seed)
+    N = rng.standard_normal((K, p, p)) * 0.01
+    return -3.0 * np.repeat(np.eye(p)[None], K, axis=0) + 0.5 * (N + N.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("p", [60, 200])
+def test_solvers_reach_the_definiteness_warnings(p):
+    """ADMM_MGL, ADMM_SGL and ext_ADMM_MGL driven into their 'not positive (semi)definite' prints on the real engine by
+    one iteration from an indefinite dual start; the printed decision must be the one NumPy takes on the RETURNED
+    solution (admm_solver.py:294-301, single_admm_solver.py:255-263, ext_admm_solver.py:300-311)."""
+    from gglasso_amd import solver, synth
+    from gglasso_amd.ext_solver import ext_ADMM_MGL
+    K = 3
+    S, _ = synth.make_problem("GGL", K, p, seed=5)
+    S = 4.0 * S          # Theta_1 ~ prox(I - S + ...): eigenvalues of S well above 1 make it indefinite (checked with the oracle)
+    Om0 = np.repeat(np.eye(p)[None], K, axis=0)
+    X0 = _indefinite_start(p, K, 9)
+    # --- ADMM_MGL (latent: both checks run) ---
+    (sol, info), out = _capture(solver.ADMM_MGL, S, 0.05, 0.02, "GGL", Om0, X_0=X0, max_iter=1, latent=True, mu1=0.2)
+    mn_tl = min(np.linalg.eigvalsh(sol["Theta"][k] - sol["L"][k]).min() for k in range(K))
+    mn_l = min(np.linalg.eigvalsh(sol["L"][k]).min() for k in range(K))
+    assert mn_tl < -0.1, mn_tl          # the start does what it is meant to
+    assert ("Theta (Theta - L resp.) is not positive definite" in out) == (mn_tl <= 0)
+    assert ("L is not positive semidefinite" in out) == (mn_l < -1e-5)
+    # --- ADMM_SGL: prints the eigenvalue itself ---
+    (sol1, _), out = _capture(solver.ADMM_SGL, S[0], 0.05, Om0[0], X_0=X0[0], max_iter=1, latent=True, mu1=0.2)
+    mn = np.linalg.eigvalsh(sol1["Theta"] - sol1["L"]).min()
+    assert mn < -0.1
+    line = [ln for ln in out.split("\n") if "not positive definite" in ln][0]
+    assert abs(float(line.split("min EV is ")[1].rstrip(")")) - mn) <= 1e-10, line
+    # --- ext_ADMM_MGL on instances of equal dimension (trivial G: one group holding entry (0,1) of every instance) ---
+    G = np.zeros((2, 1, K), dtype=int)
+    G[1] = 1
+    Sd = {k: S[k] for k in range(K)}
+    Od = {k: Om0[k] for k in range(K)}
+    Xd = {k: X0[k] for k in range(K)}
+    (sole, _), out = _capture(ext_ADMM_MGL, Sd, 0.05, 0.02, "GGL", Od, G, X0=Xd, max_iter=1)
+    n_bad = sum(np.linalg.eigvalsh(sole["Theta"][k] - sole["L"][k]).min() <= 1e-5 for k in range(K))
+    assert n_bad >= 1
+    assert out.count("Theta (Theta-L resp.) may be not positive definite") == n_bad

@@ -1,13 +1,17 @@
 #!/bin/bash
 # Runs on the GPU box: interleaved A/B of two BUILDS of libggl_hip.so inside ONE box (box-to-box noise is ~2 %).
 #   tools/ab_lib.sh <tag> <rounds> <libA.so> <libB.so> ["<bench args>" ...]
-# The libraries are copied over gglasso_amd/lib/libggl_hip.so in turn (the box copy of the repo is scratch).
+# The libraries are copied over gglasso_amd/lib/libggl_hip.so in turn; the library that was installed before the run is
+# restored on exit (whatever the exit path), so later pytest / bench runs in the same tree measure what build.py built.
 set -u
 TAG=$1; ROUNDS=$2; LA=$3; LB=$4; shift 4
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
+ORIG=$(mktemp /tmp/libggl_hip.orig.XXXXXX)
+cp gglasso_amd/lib/libggl_hip.so $ORIG
+trap 'cp $ORIG gglasso_amd/lib/libggl_hip.so; rm -f $ORIG' EXIT
 [ $# -eq 0 ] && set -- ""
 for r in $(seq 1 $ROUNDS); do
   for side in A B; do
