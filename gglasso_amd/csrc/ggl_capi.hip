@@ -2467,6 +2467,16 @@ extern "C" int ggl_dev_ns_schedule_tol(double l, int degrees, double tol, int ma
 }
 
 #ifdef GGL_DEV
+extern "C" int ggl_dev_coissue_probe(double* out12)
+{
+    ARGCHK(out12, "out");
+    DevBuf d;
+    HIPCHK(d.alloc((size_t)512 * 512));
+    coissue_probe(nullptr, d.p, out12);
+    HIPCHK(hipGetLastError());
+    return GGL_OK;
+}
+
 extern "C" int ggl_dev_mfma_f64_peak(double* tflops_out)
 {
     ARGCHK(tflops_out, "tflops_out");

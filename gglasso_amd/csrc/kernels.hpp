@@ -171,6 +171,10 @@ int symm_bounds_tile(int K, int p, int variant);
 int launch_chain_probe(hipStream_t st, double* X0, double* X1, const double* coef, int K, int p, int nprod, int variant,
                        unsigned* bar, unsigned* err, int two_level);
 #endif
+#ifdef GGL_DEV
+// FP64 VALU || MFMA co-issue probe (probes_dev.hip): out[12] TF/s pairs, see there
+void coissue_probe(hipStream_t st, double* scratch, double* out);
+#endif
 // measured FP64 matrix-core ceiling (MFMA-only probe kernel; GGL_DEV builds)
 double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nacc);
 double mfma_valu_mix_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nv);

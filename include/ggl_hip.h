@@ -320,6 +320,9 @@ int ggl_dev_ns_schedule_tol(double l, int degrees, double tol, int max_steps, in
  * (MFMA-only probe kernel); per-workgroup timestamps {start, loop begin, loop end, end, XCC id} of one launch of the
  * 64x64 kernel */
 int ggl_dev_mfma_f64_peak(double *tflops_out);
+/* FP64 VALU || FP64 MFMA co-issue probe (csrc/probes_dev.hip), TF/s: {MFMA only, v_fma_f64 only, waves split per SIMD:
+ * MFMA, DFMA, one wave with 4 / 8 / 16 / 32 v_fma_f64 behind every MFMA: MFMA, DFMA each} */
+int ggl_dev_coissue_probe(double *out12);
 int ggl_dev_symm_timeline(int K, int p, long long *out, int max_blocks, int *nblocks_out);
 /* persistent-chain probe: nprod dependent products X <- X X of a K-batch as nprod launches (out[0], ms) and as ONE cooperative
  * launch with grid-wide barriers between the products (out[1], ms); out[2] grid of the latter, out[3] max |difference| of
