@@ -55,6 +55,7 @@ WORKLOADS = {
 
 # product-kernel instances of csrc/gemm_sym.hip by the variant number ggl_ns_stats reports
 VARIANT_NAMES = {0: "k_symm_tn<64,16,32,32> (register-staged)", 9: "k_symm_tn<32,32,16,16> (register-staged)",
+                 40: "k_omega_chain<16,3,64> (persistent product chain, per-instance dependencies; 64x64 direct-to-LDS tiles)",
                  16: "k_symm_dl<16,2,0,64> (direct-to-LDS)", 17: "k_symm_dl<16,3,0,64> (direct-to-LDS)",
                  20: "k_symm_dl<32,2,0,32> (direct-to-LDS, 32x32 tiles)"}
 

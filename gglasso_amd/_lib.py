@@ -15,7 +15,7 @@ EIG_AUTO, EIG_JACOBI, EIG_ROCSOLVER, EIG_NEWTON_SCHULZ = 0, 1, 2, 3
 CTX_STREAM_GIVEN = 1 << 16
 # ggl_ctx_set_option ids (GGL_OPT_*)
 OPTIONS = {"speculate": 1, "spec_factor": 2, "ns_mode": 3, "ns_degrees": 4, "theta_flat": 5, "rank_eig": 6, "parts": 7,
-           "parts_max_tiles": 8, "symm_variant": 9, "spin_wait": 10, "fused_bounds": 11, "pipeline": 12, "fused_start": 13, "parts_small": 14, "ns_tol": 15, "cw_warm": 16}
+           "parts_max_tiles": 8, "symm_variant": 9, "spin_wait": 10, "fused_bounds": 11, "pipeline": 12, "fused_start": 13, "parts_small": 14, "ns_tol": 15, "cw_warm": 16, "chain": 17}
 
 
 def eig_flags(method=EIG_AUTO, ns_mode=0, ns_degrees=0):
@@ -103,6 +103,7 @@ _DEV_SIGNATURES = {
     "ggl_dev_symm_timeline": ([_i, _i, ctypes.POINTER(ctypes.c_longlong), _i, ctypes.POINTER(_i)], _i),
     "ggl_dev_chain_probe": ([_i, _i, _i, _i, _i, _i, _dp], _i),
     "ggl_dev_coissue_probe": ([_dp], _i),
+    "ggl_dev_chain_run": ([_i, _i, _i, _i, _dp], _i),
 }
 
 EXPORTS = tuple(_SIGNATURES)

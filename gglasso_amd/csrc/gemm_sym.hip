@@ -11,6 +11,8 @@
 // Tiling: BM x BM block tile, NW waves as a (BM/WM) x (BM/WN) grid, each wave WM x WN = (WM/16) x
 // (WN/16) MFMA tiles; k-slab BK.  The next slab is fetched from HBM/L2 into registers while the
 // current one is consumed from LDS (software prefetch), one barrier pair per slab.
+#include <algorithm>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -345,7 +347,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 // NW: waves per workgroup (4: 2 x 2 waves of BM/2 x BM/2; 8: 4 x 2 waves of BM/4 x BM/2 -- two waves per SIMD, for batches
 // so small that only one workgroup lands on a CU and a lone wave per SIMD cannot hide its LDS round trips and barriers)
 // symm_dl_tile: one output tile (instance k of the combined batch, tile pair b) -- the whole body of k_symm_dl
-template <int BK, int NSTG, int ABL, int BM, int NW>
+// AUX: cache policy of every global READ of the tile body (operand DMA and the E term): 0 = default; 16 = sc1, i.e. served by
+// the XCD's L2 past this CU's vector L1 -- what a persistent kernel needs to read tiles that ANOTHER CU of the same XCD
+// wrote earlier in the same launch (a CU's L1 is never refreshed by other CUs' stores; MI355X_MICROARCH.md).
+template <int AUX> __device__ __forceinline__ double ld_pol(const double* p)
+{
+    if constexpr (AUX == 0) return *p;
+    else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_load_dwordx2 ... sc1
+}
+
+template <int BK, int NSTG, int ABL, int BM, int NW, int AUX = 0>
 __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const double* __restrict__ B,
                                              double* __restrict__ C, double* __restrict__ C2,
                                              const double* __restrict__ E, const double* __restrict__ coef, int K,
@@ -403,8 +414,8 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
             const unsigned ro = min((unsigned)(m0 + RPI * i + lrow), pm1) * pu;
             double* la = smem + (size_t)buf * 2 * SLAB + i * 128;            // wave-uniform LDS base
             double* lb = la + SLAB;
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ak + ro + ca), (lptr_t)la, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(Bk + ro + cb), (lptr_t)lb, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ak + ro + ca), (lptr_t)la, 16, 0, AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Bk + ro + cb), (lptr_t)lb, 16, 0, AUX);
         }
     };
     const bool dead_wave = (I == J) && (wr >= wc + WN);
@@ -493,7 +504,7 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
                 const bool keep = gi < p && gj < p && (I != J || gi <= gj);
                 if (keep) {
                     if (gi == gj) v += cI;
-                    const double e0 = Ek ? Ek[(size_t)gi * p + gj] : 0.0;
+                    const double e0 = Ek ? ld_pol<AUX>(Ek + (size_t)gi * p + gj) : 0.0;
                     v += cE * e0;
                     dev = fmax(dev, fabs(v - (gi == gj ? 1.0 : 0.0)));
                     Ck[(size_t)gi * p + gj] = v;
@@ -559,7 +570,7 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
                 Ck[(size_t)(J0 + a) * p + I0 + c] = v;
                 if (C2k) {
                     // E is bitwise symmetric (an output of this kernel family): its mirrored entry IS the upper one
-                    const double e0 = (dE != 0.0 && Ek) ? Ek[(size_t)(J0 + a) * p + I0 + c] : 0.0;
+                    const double e0 = (dE != 0.0 && Ek) ? ld_pol<AUX>(Ek + (size_t)(J0 + a) * p + I0 + c) : 0.0;
                     C2k[(size_t)(J0 + a) * p + I0 + c] = c2val(dC, v, dE, e0);
                 }
             }
@@ -579,6 +590,153 @@ __global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ 
     int k, b;
     if (!decode_block_xcd(T * (T + 1) / 2, K + K1, k, b)) return;
     symm_dl_tile<BK, NSTG, ABL, BM, NW>(A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, k, b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_omega_chain: the WHOLE product chain of an Omega-step (A', B', the Newton-Schulz products, Omega) of a batch in ONE
+// persistent launch, with the dependencies kept where they are: per INSTANCE.  Product s+1 of instance k needs product s of
+// instance k and nothing else, yet a launch boundary makes every instance wait for the slowest tile of all of them, 7 times
+// per iteration (a K = 32, p = 500 launch keeps the matrix pipes ~52 % busy, two concurrent half-batch launch sequences
+// ~57 %).  Here the workgroups are persistent (as many as are resident: 3 per CU with 48 KiB of LDS), each serves the
+// instances of the XCD it REALLY runs on (HW_REG_XCC_ID; instance k lives on XCD k % 8, so its operands stay in one L2 and
+// every hand-off is XCD-local), and pulls tiles through two counters per instance:
+//     next[k]  tickets handed out (ticket t = product s, tile t - begin[s])      done[k]  tiles completed
+// A ticket of product s is handed out only when done[k] >= begin[s], i.e. all tiles of the products before it are complete.
+// While one instance drains the last tiles of a product, the workgroups run the other instances of the XCD: fixed priority
+// by instance index, so the instances drift apart instead of marching in lockstep.
+// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility): producer = plain stores (they stay in the XCD's L2) ->
+// every wave s_waitcnt vmcnt(0) -> barrier -> one relaxed agent-scope fetch_add on done[k]; consumer = relaxed agent-scope
+// (sc1) load of done[k] -> every global READ of the tile with sc1 (L2-served, never this CU's L1).  No L2 write-back and no
+// L1 invalidate anywhere: producer and consumer share one L2 by construction (a workgroup only serves its own XCD's list).
+// Should the hardware ever place no workgroup on an XCD, that XCD's instances stay unfinished: k_chain_check raises the
+// step's validation flag and the host repeats the step on the launch-per-product path (correct either way).
+// ---------------------------------------------------------------------------------------------
+// state of instance k: one 128-byte line of CHAIN_CNT_STRIDE words -- [0] tiles completed (all products), [1 + s] tickets
+// handed out of product s.  A claim is ONE fetch_add on the ticket word of the product the workgroup last saw ready for
+// that instance (a ticket beyond the product's tiles is void: nothing is lost, nobody waits); only when a product is
+// exhausted does the workgroup read the completion word to see whether the next one may start.
+template <int BK, int NSTG, int BM, int AUX>
+__global__ __launch_bounds__(256) void k_omega_chain(const ChainProg P, unsigned* __restrict__ state)
+{
+    __shared__ int sh_job[3];
+    __shared__ unsigned char sh_step[CHAIN_MAX_INST];         // per instance of this XCD: the product last seen ready
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int x = (int)(xcc & 0xfu) % NXCD;
+    const int ninst = min((P.K - x + NXCD - 1) / NXCD, CHAIN_MAX_INST);   // instances x, x + 8, ...
+    const int rot = ninst > 0 ? (int)(blockIdx.x / NXCD) % ninst : 0;     // claims start at different instances
+    unsigned backoff = 4;
+    if (threadIdx.x < CHAIN_MAX_INST) sh_step[threadIdx.x] = 0;           // product 0 has no predecessor: ready
+#ifdef GGL_DEV
+    long long t_claim = 0, t_idle = 0, t_tile = 0, n_tile = 0, t_prev = wall_clock64(), t_first = t_prev;
+#endif
+    __syncthreads();
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int jk = -2, js = 0, jb = 0;                      // -2: every product of every instance of this XCD is handed out
+            for (int ii = 0; ii < ninst && jk < 0; ++ii) {
+                const int i = (ii + rot) % ninst;
+                const int k = x + NXCD * i;
+                unsigned* w = state + (size_t)k * CHAIN_CNT_STRIDE;
+                int s = sh_step[i];
+                while (s < P.nops) {
+                    // L2-scope read-modify-write (no sc1): every workgroup that touches this line runs on THIS XCD (it
+                    // serves the XCD it really sits on), so the XCD's L2 is the one place the line lives and its atomic
+                    // unit the one place it changes -- a device-scope (memory-side) atomic cost ~26 us per claim under 96
+                    // claimers per XCD
+                    const unsigned nt = (unsigned)(P.begin[s + 1] - P.begin[s]);
+                    const unsigned t = __hip_atomic_fetch_add(w + 1 + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (t < nt) { jk = k; js = s; jb = (int)t; break; }
+                    // product s is handed out completely: may s + 1 start?  (sc1 load: served by the XCD's L2, never by this
+                    // CU's L1 -- a workgroup-scope load would be an L1-hitting sc0 load)
+                    const unsigned d = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (d < (unsigned)P.begin[s + 1]) { jk = max(jk, -1); break; }      // not yet: something is left, later
+                    ++s;
+                }
+                sh_step[i] = (unsigned char)s;
+            }
+            sh_job[0] = jk; sh_job[1] = js; sh_job[2] = jb;
+        }
+        __syncthreads();
+        const int jk = __builtin_amdgcn_readfirstlane(sh_job[0]);
+        const int js = __builtin_amdgcn_readfirstlane(sh_job[1]);
+        int jb = __builtin_amdgcn_readfirstlane(sh_job[2]);
+        __syncthreads();                                      // everyone has read the slot before it is rewritten
+#ifdef GGL_DEV
+        if (jk == -2 && P.prof && threadIdx.x == 0) {
+            long long* o = P.prof + (size_t)blockIdx.x * 8;
+            o[0] = t_claim; o[1] = t_idle; o[2] = t_tile; o[3] = n_tile; o[4] = t_first; o[5] = wall_clock64(); o[6] = x;
+        }
+#endif
+        if (jk == -2) return;
+        if (jk == -1) {
+            // nothing ready on this XCD: back off (0.2 .. 3 us) so that idle workgroups do not crowd the lines the working
+            // ones need
+            for (unsigned q = 0; q < backoff; ++q) __builtin_amdgcn_s_sleep(8);
+            backoff = min(backoff * 2u, 64u);
+#ifdef GGL_DEV
+            { const long long t = wall_clock64(); t_idle += t - t_prev; t_prev = t; }
+#endif
+            continue;
+        }
+        backoff = 4;
+#ifdef GGL_DEV
+        { const long long t = wall_clock64(); t_claim += t - t_prev; t_prev = t; }
+#endif
+        const SymmOp& o = P.op[js];
+        int kk = jk;
+        if (o.pair && jb >= P.ntiles) { kk = P.K + jk; jb -= P.ntiles; }
+        symm_dl_tile<BK, NSTG, 0, BM, 4, AUX>(o.A, o.B, o.C, o.C2, o.E, o.coef, P.K, P.p, o.A1, o.B1, o.C1, o.pair ? P.K : 0,
+                                               nullptr, o.rowpart, o.fropart, kk, jb);
+        // this tile's stores are in the XCD's L2 before the arrival is counted; the barrier also frees the LDS image
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_fetch_add(state + (size_t)jk * CHAIN_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef GGL_DEV
+        { const long long t = wall_clock64(); t_tile += t - t_prev; t_prev = t; n_tile += 1; }
+#endif
+    }
+}
+
+// flag[0] / flag_h[0] = 1 unless every instance completed all of its tiles
+__global__ __launch_bounds__(64) void k_chain_check(const unsigned* __restrict__ state, int K, unsigned total,
+                                                    int* __restrict__ flag, int* __restrict__ flag_h)
+{
+    bool bad = false;
+    for (int k = threadIdx.x; k < K; k += 64) bad = bad || (state[(size_t)k * CHAIN_CNT_STRIDE] != total);
+    if (__any(bad) && threadIdx.x == 0) { *flag = 1; *flag_h = 1; }
+}
+
+int chain_tile(int K, int p, bool force)
+{
+    // the chain kernel is built on the 64x64 three-stage DMA tile; it needs 16-byte rows (even p), a batch that covers the
+    // XCDs (instance k lives on XCD k % 8) and enough tiles per XCD to keep its 96 workgroup slots busy across the
+    // instances' seams
+    if ((p & 1) != 0 || K < NXCD || K > NXCD * CHAIN_MAX_INST) return 0;
+    const long T = (p + 63) / 64;
+    return (force || T * (T + 1) / 2 * K >= 1100) ? 64 : 0;
+}
+
+int launch_omega_chain(hipStream_t st, const ChainProg& P, unsigned* state, int* flag, int* flag_h, int aux)
+{
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_omega_chain<16, 3, 64, 16>, 256, 0) != hipSuccess || per_cu < 1)
+            return -1;
+        slots = std::min(per_cu, 3) * prop.multiProcessorCount;
+        slots -= slots % NXCD;
+    }
+#ifdef GGL_DEV
+    if (aux == 0) hipLaunchKernelGGL((k_omega_chain<16, 3, 64, 0>), dim3(slots), dim3(256), 0, st, P, state);   // measurement only
+    else
+#endif
+    hipLaunchKernelGGL((k_omega_chain<16, 3, 64, 16>), dim3(slots), dim3(256), 0, st, P, state);
+    hipLaunchKernelGGL(k_chain_check, dim3(1), dim3(64), 0, st, state, P.K, (unsigned)P.begin[P.nops], flag, flag_h);
+    return slots;
 }
 
 #ifdef GGL_DEV

@@ -70,6 +70,12 @@ struct ggl_ctx {
     bool dvo_valid = false;                    // DvO holds the eigenvalues of the last Omega-step
     int symm_variant = -1;
     double *nsYP[2] = {nullptr, nullptr}, *nsT = nullptr;   // [Y|Z] scratch pairs (2 stacks each), T
+    // the Omega-step's product chain as ONE persistent launch with per-instance dependencies (k_omega_chain, gemm_sym.hip)
+    int chain_mode = 0;                        // GGL_OPT_CHAIN: 0 never (default: measured slower), 1 where chain_tile() says so, 2 wherever it can run
+    double* nsNX = nullptr;                    // third [Y|Z] pair: the chain leaves A', B' intact for the bound kernels (lazy)
+    unsigned* chain_cnt = nullptr;             // per-instance completion / ticket words, one 128-byte line each (lazy)
+    long long chain_calls = 0;
+    bool flags_dirty = false;                  // a validation flag was raised: clear ALL device slots before the next step
     int ns_force = 0;                          // 0 auto, 1 symmetric products, 2 stable products
     bool use_syevj = false;
     static constexpr int MAX_PARTS = 4;
@@ -344,6 +350,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_FUSED_START: c->fused_start = v != 0.0; break;
         case GGL_OPT_PARTS_SMALL: c->parts_small = (int)v; break;
         case GGL_OPT_CW_WARM: c->cw_warm = v != 0.0; break;
+        case GGL_OPT_CHAIN: c->chain_mode = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
         case GGL_OPT_NS_TOL:
             if (!(v >= 0.0) || v > 1e-6) return fail(GGL_E_ARG, "bad argument: GGL_OPT_NS_TOL is in [0, 1e-6]");
             c->ns_tol = std::max(v, NS_TOL_EXACT);
@@ -381,6 +388,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_PARTS_SMALL: *value = c->parts_small; break;
         case GGL_OPT_NS_TOL: *value = c->ns_tol; break;
         case GGL_OPT_CW_WARM: *value = c->cw_warm; break;
+        case GGL_OPT_CHAIN: *value = c->chain_mode; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
     }
     return GGL_OK;
@@ -396,7 +404,7 @@ static void dev_env_options(ggl_ctx* c)
         {"GGL_TWO_STREAM", GGL_OPT_PARTS}, {"GGL_PARTS_MAX_TILES", GGL_OPT_PARTS_MAX_TILES},
         {"GGL_SYMM_VARIANT", GGL_OPT_SYMM_VARIANT}, {"GGL_SPIN_WAIT", GGL_OPT_SPIN_WAIT},
         {"GGL_FUSED_BOUNDS", GGL_OPT_FUSED_BOUNDS}, {"GGL_PIPELINE", GGL_OPT_PIPELINE},
-        {"GGL_FUSED_START", GGL_OPT_FUSED_START}, {"GGL_PARTS_SMALL", GGL_OPT_PARTS_SMALL}};
+        {"GGL_FUSED_START", GGL_OPT_FUSED_START}, {"GGL_PARTS_SMALL", GGL_OPT_PARTS_SMALL}, {"GGL_CHAIN", GGL_OPT_CHAIN}};
     for (const auto& t : tab)
         if (const char* v = getenv(t.name)) (void)set_option(c, t.opt, atof(v));
     if (const char* v = getenv("GGL_ROCSOLVER_SYEVJ")) c->use_syevj = atoi(v) != 0;
@@ -456,13 +464,14 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     // (the rocBLAS handle is the process-wide one of blas_handle(): never destroyed here)
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
-                      c->nsT, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->cuse, c->Lam[0],
+                      c->nsT, c->nsNX, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->cuse, c->Lam[0],
                       c->Lam[1], c->X1, c->cwvec[0], c->cwvec[1]};
     for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize})
         if (b) (void)hipFree(b);
     for (void* b : {(void*)c->rowpart, (void*)c->fropart, (void*)c->infpart, (void*)c->cwmax, (void*)c->cwcnt})
         if (b) (void)hipFree(b);
     if (c->spec_flag) (void)hipFree(c->spec_flag);
+    if (c->chain_cnt) (void)hipFree(c->chain_cnt);
     if (c->cuse_h) (void)hipHostFree(c->cuse_h);
     if (c->seq_h) (void)hipHostFree(c->seq_h);
     if (c->spec_flag_h) (void)hipHostFree(c->spec_flag_h);
@@ -796,6 +805,85 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         for (int k = 0; spec && k < K; ++k) spec = (c->par_h[k] == c->spec_beta[k]);
         double* fused[ggl_ctx::MAX_PARTS] = {};      // speculative step: the first step's start as 2nd output of the B' launch
         bool cw_written = false;                     // this step's bound pass left a Collatz-Wielandt vector behind
+        if (c->flags_dirty) {
+            // a step was rejected since the flags were last cleared wholesale: whatever slot carried the 1 (a part that does
+            // not exist in this step's split, the chain's completion check) must not outlive it.  On the main stream BEFORE
+            // the fork, so it is ordered ahead of every part's own zeroing and kernels.
+            HIPCHK(hipMemsetAsync(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int), c->stream));
+            for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) c->spec_flag_h[h] = 0;
+            c->flags_dirty = false;
+        }
+        // ---- the whole product chain as ONE persistent launch with per-instance dependencies (k_omega_chain) ----------
+        if (spec && c->chain_mode && c->fused_start && c->fused_bounds && (c->symm_variant < 0 || c->symm_variant == 17) &&
+            chain_tile(K, c->p, c->chain_mode == 2) == 64) {
+            if (!c->nsNX) HIPCHK(hipMalloc(&c->nsNX, 2 * c->n * sizeof(double)));
+            if (!c->chain_cnt) HIPCHK(hipMalloc(&c->chain_cnt, (size_t)K * CHAIN_CNT_STRIDE * sizeof(unsigned)));
+            for (int k = 0; k < K; ++k) c->cuse_h[k] = c->spec_c[k] * c->spec_factor;
+            NsPlan& pl = plans[0];
+            SymmOp ops[CHAIN_MAX_OPS];
+            int nops = 0;
+            const int bT = (c->p + 63) / 64;
+            if (ns_plan(c->cuse_h, c->par_h, K, c->coef_h, start_base_h, &pl, c->ns_force, c->ns_degrees, c->ns_tol) == 0 &&
+                !pl.stable) {
+                double* f0 = nullptr;
+                for (int k = 0; k < K; ++k)
+                    f0 = ns_fused_start(pl, start_base_h + 5 * (size_t)k, c->nsYP[1], c->nsT, (size_t)K * pp,
+                                        pre + NS_SLOT(K) + (size_t)k * NS_NCOEF + 3);
+                if (f0)
+                    nops = ns_chain_ops(pl, pre_d, pre_d + NS_SLOT(K), c->coef, c->W, c->nsYP[0], c->nsYP[1], c->nsNX, c->nsT,
+                                        c->Om[nxt], K, c->p, 0, f0, c->rowpart, c->fropart, ops, CHAIN_MAX_OPS);
+            }
+            if (nops > 0) {
+                CopySegs sg = first;
+                sg.add(pre_d, pre, (size_t)K * NS_NCOEF * sizeof(double));
+                sg.add(pre_d + NS_SLOT(K), pre + NS_SLOT(K), (size_t)K * NS_NCOEF * sizeof(double));
+                // validation flags of this step: slot 0 the bound check, slot 1 the chain's completion check, last slot the
+                // all-reduced flag of K-sharded runs
+                sg.add(c->spec_flag, nullptr, 2 * sizeof(int));
+                sg.add(c->spec_flag + ggl_ctx::MAX_PARTS - 1, nullptr, sizeof(int));
+                c->spec_flag_h[0] = c->spec_flag_h[1] = c->spec_flag_h[ggl_ctx::MAX_PARTS - 1] = 0;
+                const int nb_launch = pl.products - 2;
+                if (nb_launch > 0) sg.add(c->coef, c->coef_h, (size_t)nb_launch * NS_SLOT(K) * sizeof(double));
+                sg.add(c->cuse, c->cuse_h, (size_t)K * sizeof(double));
+                if (c->info_dirty) sg.add(c->info, nullptr, K * sizeof(int));
+                sg.add(c->chain_cnt, nullptr, (size_t)K * CHAIN_CNT_STRIDE * sizeof(unsigned));
+                launch_copy_small(c->stream, sg);
+                PB(c, GGL_PH_FORM_W);
+                launch_form_W_sym(c->stream, c->W, c->Theta, nullptr, c->X, c->S, beta, K, c->p);
+                PE(c, GGL_PH_FORM_W);
+                PB(c, GGL_PH_EIG_OMEGA);
+                ChainProg P;
+                P.nops = nops; P.K = K; P.p = c->p; P.ntiles = bT * (bT + 1) / 2;
+                P.begin[0] = 0;
+                for (int i = 0; i < nops; ++i) { P.op[i] = ops[i]; P.begin[i + 1] = P.begin[i] + P.ntiles * (ops[i].pair ? 2 : 1); }
+                if (launch_omega_chain(c->stream, P, c->chain_cnt, c->spec_flag + 1, c->spec_flag_h + 1) < 0)
+                    return fail(GGL_E_HIP, "k_omega_chain: launch failed (%s)", hipGetErrorString(hipGetLastError()));
+                // the bound of THIS iteration's A' (validation of the assumed one; next iteration's schedule): B' is intact
+                launch_bound_rows(c->stream, c->rowpart, bT, K, c->p, c->nbrow, c->infpart);
+                launch_cw_final(c->stream, c->nsYP[0] + c->n, c->nbrow, K, c->p, c->infpart, c->fropart, bT * (bT + 1) / 2,
+                                c->cwmax, c->cwcnt, c->bounds_h, c->cuse, c->spec_flag, c->spec_flag_h, 0,
+                                (c->cw_warm && c->cw_have) ? c->cwvec[c->cw_cur] : nullptr,
+                                c->cw_warm ? c->cwvec[c->cw_cur ^ 1] : nullptr);
+                PE(c, GGL_PH_EIG_OMEGA);
+                HIPCHK(hipGetLastError());
+                c->last_parts = 1;
+                c->last_variant = 40;
+                c->chain_calls += 1;
+                c->ns_launches_total += pl.products;
+                c->ns_units_frac += pl.units;
+                c->ns_steps_frac += pl.steps;
+                c->ns_units_total = (long long)(c->ns_units_frac + 0.5);
+                c->ns_steps_total = (long long)(c->ns_steps_frac + 0.5);
+                c->ns_calls += 1;
+                c->spec_calls += 1;
+                c->spec_pending = true;
+                c->cw_pending = c->cw_warm;
+                if (c->info_dirty) { memset(c->info_h, 0, K * sizeof(int)); c->info_dirty = false; }
+                c->dvo_valid = false;
+                c->cur = nxt;
+                return GGL_OK;
+            }
+        }
         if (spec) {
             for (int k = 0; k < K; ++k) c->cuse_h[k] = c->spec_c[k] * c->spec_factor;
             for (int h = 0; spec && h < nh; ++h) {
@@ -1047,6 +1135,7 @@ static int finish_norms(ggl_ctx* c, int rows, double* out_norms, int group = 0)
         if (bad) {
             // no: the Theta-step kernels saw the flag and left the iterate alone; un-flip Omega and tell the caller
             if (mine) c->spec_misses += 1;
+            c->flags_dirty = true;
             c->cw_pending = false;
             c->spec_have = false;
             c->spec_cool = 4;
@@ -2409,6 +2498,127 @@ extern "C" int ggl_dev_chain_probe(int K, int p, int variant, int nprod, int ite
     out[1] = ms / iters;
     HIPCHK(hipMemcpy(flags, dbar.p, sizeof(flags), hipMemcpyDeviceToHost));
     out[4] = flags[1];
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    return GGL_OK;
+}
+
+// k_omega_chain on a synthetic program: nprod dependent products X <- I - 1.5 X^2 (ping-pong between two stacks) as nprod
+// launches of the three-stage 64x64 kernel (out[0], ms per chain) and as ONE persistent launch with per-instance
+// dependencies (out[1]); out[2] = persistent workgroups, out[3] = max |difference| of the results (same tile code: 0 unless
+// a hand-off delivered stale data), out[4] = completion flag of k_chain_check, out[5..5+K) = done counters after the run
+extern "C" int ggl_dev_chain_run(int K, int p, int nprod, int iters, double* out)
+{
+    ARGCHK(K >= 1 && p >= 2 && (p & 1) == 0 && nprod >= 1 && nprod <= CHAIN_MAX_OPS && iters >= 1 && out, "arguments (p even)");
+    const size_t n = (size_t)K * p * p;
+    std::vector<double> h(n, 0.0), coef((size_t)K * NS_NCOEF, 0.0);
+    unsigned long long s = 88172645463325252ull;
+    for (int k = 0; k < K; ++k) {
+        double* M = h.data() + (size_t)k * p * p;
+        for (int i = 0; i < p; ++i)
+            for (int j = i; j < p; ++j) {
+                s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+                M[(size_t)i * p + j] = M[(size_t)j * p + i] = ((double)(s >> 11) / 9007199254740992.0 - 0.5) / p;
+            }
+        coef[(size_t)k * NS_NCOEF + 0] = 1.0;
+        coef[(size_t)k * NS_NCOEF + 1] = -1.5;
+    }
+    DevBuf dX0, dX1, dcoef, dcnt;
+    HIPCHK(dX0.alloc(n));
+    HIPCHK(dX1.alloc(n));
+    HIPCHK(dcoef.alloc(coef.size()));
+    const size_t ncw = (size_t)K * CHAIN_CNT_STRIDE;          // 32-bit words
+    HIPCHK(dcnt.alloc(ncw / 2 + 8));
+    UP(dcoef.p, coef.data(), coef.size());
+    unsigned* cnt = reinterpret_cast<unsigned*>(dcnt.p);
+    int* flag = reinterpret_cast<int*>(cnt + ncw);
+    const int aux = getenv("GGL_CHAIN_AUX") ? atoi(getenv("GGL_CHAIN_AUX")) : 16;
+    double* last = (nprod & 1) ? dX1.p : dX0.p;
+    const int T = (p + 63) / 64;
+    ChainProg P;
+    P.nops = nprod; P.K = K; P.p = p; P.ntiles = T * (T + 1) / 2;
+    P.begin[0] = 0;
+    for (int j = 0; j < nprod; ++j) {
+        SymmOp o{};
+        o.A = o.B = (j & 1) ? dX1.p : dX0.p;
+        o.C = (j & 1) ? dX0.p : dX1.p;
+        o.coef = dcoef.p;
+        P.op[j] = o;
+        P.begin[j + 1] = P.begin[j] + P.ntiles;
+    }
+    auto chain_launches = [&]() {
+        for (int j = 0; j < nprod; ++j)
+            launch_symm(nullptr, (j & 1) ? dX1.p : dX0.p, (j & 1) ? dX1.p : dX0.p, (j & 1) ? dX0.p : dX1.p, nullptr, nullptr,
+                        dcoef.p, K, p, 17);
+    };
+    int grid = 0;
+    auto chain_persistent = [&]() -> int {
+        if (hipMemsetAsync(dcnt.p, 0, (ncw / 2 + 8) * sizeof(double), nullptr) != hipSuccess) return -1;
+        grid = launch_omega_chain(nullptr, P, cnt, flag, flag + 1, aux);
+        return grid;
+    };
+    std::vector<double> r1(n), r2(n);
+    UP(dX0.p, h.data(), n);
+    chain_launches();
+    DOWN(r1.data(), last, n);
+    UP(dX0.p, h.data(), n);
+    HIPCHK(hipMemset(dX1.p, 0, n * sizeof(double)));
+    if (chain_persistent() <= 0) return fail(GGL_E_HIP, "k_omega_chain launch failed");
+    DOWN(r2.data(), last, n);
+    if (getenv("GGL_CHAIN_PROF")) {
+        // one more run with the per-workgroup time accounting: claim / idle / tile time (100 MHz ticks) and tiles served
+        DevBuf dprof;
+        HIPCHK(dprof.alloc((size_t)grid * 8));
+        HIPCHK(hipMemset(dprof.p, 0, (size_t)grid * 8 * sizeof(double)));
+        P.prof = reinterpret_cast<long long*>(dprof.p);
+        UP(dX0.p, h.data(), n);
+        if (chain_persistent() <= 0) return fail(GGL_E_HIP, "k_omega_chain launch failed");
+        std::vector<long long> hp((size_t)grid * 8);
+        HIPCHK(hipMemcpy(hp.data(), dprof.p, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        P.prof = nullptr;
+        double cl = 0, id = 0, ti = 0, nt = 0, span = 0;
+        long long t0 = hp[4], t1 = hp[5];
+        int perx[8] = {};
+        for (int g = 0; g < grid; ++g) {
+            const long long* o = hp.data() + (size_t)g * 8;
+            cl += o[0]; id += o[1]; ti += o[2]; nt += o[3]; span += o[5] - o[4];
+            t0 = std::min(t0, o[4]); t1 = std::max(t1, o[5]);
+            perx[o[6] & 7] += 1;
+        }
+        fprintf(stderr, "chain prof: kernel span %.1f us; per workgroup (avg over %d): claim %.1f us, idle %.1f us, tile %.1f us, "
+                "%.2f tiles, %.1f us per tile, alive %.1f us; workgroups per XCD:", (t1 - t0) * 0.01, grid, cl * 0.01 / grid,
+                id * 0.01 / grid, ti * 0.01 / grid, nt / grid, ti * 0.01 / std::max(nt, 1.0), span * 0.01 / grid);
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %d", perx[x]);
+        fprintf(stderr, "\n");
+    }
+    double dev = 0.0;
+    for (size_t i = 0; i < n; ++i) dev = std::max(dev, std::fabs(r1[i] - r2[i]));
+    out[3] = dev;
+    out[2] = grid;
+    std::vector<unsigned> hc(ncw + 2);
+    HIPCHK(hipMemcpy(hc.data(), dcnt.p, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    out[4] = (double)hc[ncw];
+    for (int k = 0; k < K; ++k) out[5 + k] = (double)hc[(size_t)k * CHAIN_CNT_STRIDE];
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int i = 0; i < 3; ++i) chain_launches();
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) chain_launches();
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    out[0] = ms / iters;
+    for (int i = 0; i < 3 + iters; ++i) {
+        if (i == 3) HIPCHK(hipEventRecord(e0, nullptr));
+        if (chain_persistent() <= 0) return fail(GGL_E_HIP, "k_omega_chain launch failed");
+    }
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    out[1] = ms / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     HIPCHK(hipGetLastError());

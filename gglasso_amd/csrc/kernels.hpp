@@ -38,7 +38,7 @@ void launch_scale(hipStream_t st, double* X, double f, size_t n);
 // a hipMemcpyAsync of a few KB costs ~15 us of queue idle time around its blit (measured, rocprofv3), this
 // costs a launch.  Up to 10 segments of 32-bit words per launch; src == nullptr zero-fills.
 struct CopySegs {
-    static constexpr int MAX = 10;
+    static constexpr int MAX = 12;
     int n = 0;
     void* dst[MAX];
     const void* src[MAX];
@@ -166,6 +166,33 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
                  double* fropart = nullptr);
 int symm_bounds_tile(int K, int p, int variant);
 
+// ---- the Omega-step's product chain as one persistent launch (gemm_sym.hip, k_omega_chain) ----
+// one product of the chain: C = coef-affine(A B) [+ C2] for all K instances (stack base pointers; instance k at + k p^2);
+// pair: a second, independent product C1 = A1 B1 with the coefficient rows K + k rides in the same step
+struct SymmOp {
+    const double *A, *B, *E, *A1, *B1;
+    double *C, *C2, *C1;
+    const double* coef;
+    double *rowpart, *fropart;
+    int pair, pad_;
+};
+static constexpr int CHAIN_MAX_OPS = 16;
+struct ChainProg {
+    int nops, K, p, ntiles;                 // ntiles: 64x64 tile pairs of one product
+    int begin[CHAIN_MAX_OPS + 1];           // tickets [begin[s], begin[s+1]) of an instance belong to op s
+    SymmOp op[CHAIN_MAX_OPS];
+    long long* prof = nullptr;              // GGL_DEV builds: [grid][8] per-workgroup time accounting (100 MHz ticks)
+};
+// tile edge of the chain kernel for this batch, 0 = the launch-per-product path serves it
+int chain_tile(int K, int p, bool force = false);      // force: without the batch-size threshold (tests, measurements)
+// state: K lines of CHAIN_CNT_STRIDE 32-bit words (128 bytes per instance: completion count + one ticket word per product),
+// zeroed by the caller in the stream ahead of this; flag / flag_h: raised when an instance is left incomplete.  Returns the
+// grid (persistent workgroups) or < 0.
+static constexpr int CHAIN_CNT_STRIDE = 32;
+static constexpr int CHAIN_MAX_INST = 64;       // instances per XCD (K <= 512)
+static_assert(CHAIN_MAX_OPS + 1 <= CHAIN_CNT_STRIDE, "one line holds the completion word and the ticket words");
+int launch_omega_chain(hipStream_t st, const ChainProg& P, unsigned* state, int* flag, int* flag_h, int aux = 16);
+
 #ifdef GGL_DEV
 // persistent-chain probe: nprod dependent products X <- X * X in one cooperative launch with grid barriers (gemm_sym.hip)
 int launch_chain_probe(hipStream_t st, double* X0, double* X1, const double* coef, int K, int p, int nprod, int variant,
@@ -229,6 +256,10 @@ void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, cons
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
             double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride = 0,
             bool fused_start = false);
+// the same launches as a product list for k_omega_chain; NX: an extra [Y|Z] pair (A', B' survive); 0 = not a pure chain
+int ns_chain_ops(const NsPlan& plan, const double* pre0_d, const double* pre1_d, const double* coef_d, const double* W,
+                 double* AB, double* YP, double* NX, double* Tb, double* out, int K, int p, size_t pstride, double* start2,
+                 double* rowpart, double* fropart, SymmOp* ops, int max_ops);
 // speculative step (bound known before B' exists): target buffer and {dI, dC, dE} of the start the B' launch can emit
 // as its second output; null if the schedule's first step has none.  start_hk: row k of ns_plan's start table.
 double* ns_fused_start(const NsPlan& plan, const double* start_hk, double* YP, double* Tb, size_t n1, double out3[3]);

@@ -671,6 +671,61 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
     }
 }
 
+// The launches of ns_prepare + ns_run (all-symmetric schedule, first step's start fused into the B' launch) as a list of
+// product descriptors for k_omega_chain (gemm_sym.hip) -- same operands, same coefficient slots, same order, hence the same
+// bits.  One difference in WHERE things live: the iteration ping-pongs between YP and the extra pair NX instead of YP and
+// AB, so A' and B' survive the chain and the bound kernels can read B' after it.  Returns the number of ops, 0 when the
+// plan is not a pure chain of symmetric products (stable schedule, cubic first step) or does not fit max_ops.
+int ns_chain_ops(const NsPlan& plan, const double* pre0_d, const double* pre1_d, const double* coef_d, const double* W,
+                 double* AB, double* YP, double* NX, double* Tb, double* out, int K, int p, size_t pstride, double* start2,
+                 double* rowpart, double* fropart, SymmOp* ops, int max_ops)
+{
+    if (plan.stable || plan.deg[0] < 5 || !start2) return 0;
+    const size_t cs = NS_SLOT(K), n1 = pstride ? pstride : (size_t)K * p * p;
+    const int n = plan.steps;
+    int no = 0, g = 0;
+    bool ok = true;
+    auto add = [&](const double* A, const double* B, double* C, double* C2, const double* E, const double* coef,
+                   double* rp = nullptr, double* fp = nullptr) -> SymmOp* {
+        if (no >= max_ops) { ok = false; return nullptr; }
+        SymmOp& o = ops[no++];
+        o = SymmOp{};
+        o.A = A; o.B = B; o.C = C; o.C2 = C2; o.E = E; o.coef = coef; o.rowpart = rp; o.fropart = fp;
+        return &o;
+    };
+    double* Ap = AB;
+    double* Bp = AB + n1;
+    add(W, W, Ap, nullptr, nullptr, pre0_d);
+    add(Ap, Ap, Bp, start2, Ap, pre1_d, rowpart, fropart);
+    double *cur = YP, *nxt = NX;
+    if (plan.deg[0] == 9) add(Tb, Bp, YP + n1, nullptr, Ap, coef_d + cs * g++);
+    if (n == 1) {
+        add(Ap, YP + n1, out, nullptr, W, coef_d + cs * g++);
+        return ok ? no : 0;
+    }
+    add(Ap, YP + n1, YP, nullptr, nullptr, coef_d + cs * g++);
+    for (int it = 1; it < n; ++it) {
+        if (plan.deg[it] == 5) {
+            add(cur + n1, cur, nxt, nullptr, nullptr, coef_d + cs * g++);
+            add(nxt, nxt, Tb, nullptr, nxt, coef_d + cs * g++);
+        } else if (plan.deg[it] == 9) {
+            add(cur + n1, cur, out, nullptr, nullptr, coef_d + cs * g++);
+            add(out, out, nxt, nxt + n1, out, coef_d + cs * g++);
+            add(nxt, nxt + n1, Tb, nullptr, out, coef_d + cs * g++);
+        } else {
+            add(cur + n1, cur, Tb, nullptr, nullptr, coef_d + cs * g++);
+        }
+        if (it == n - 1) {
+            add(cur, Tb, out, nullptr, W, coef_d + cs * g++);
+        } else {
+            SymmOp* o = add(cur, Tb, nxt, nullptr, nullptr, coef_d + cs * g++);
+            if (o) { o->A1 = Tb; o->B1 = cur + n1; o->C1 = nxt + n1; o->pair = 1; }
+            std::swap(cur, nxt);
+        }
+    }
+    return ok ? no : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // L-step without an eigendecomposition:  L = (C - mu I)_+ = (C - mu I)(I + sign(C - mu I))/2
 // (prox_rank_norm, solver/ggl_helper.py:29-36 with D,Q from eigh, admm_solver.py:197-205).

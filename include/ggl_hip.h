@@ -111,6 +111,12 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_CW_WARM 16         /* [1] the Collatz-Wielandt weight vector of the spectral bound is carried from one iteration to
                                     * the next (a power iteration at no extra pass; the bound stays rigorous and tightens
                                     * towards the Perron root of |B'|); 0: the row sums of |B'| every time                  */
+#define GGL_OPT_CHAIN 17           /* [0] 1: speculative Omega-steps of batches that cover the XCDs (K >= 8, even p, >= 1100 64x64 tile
+                                    * pairs) run their whole product chain as ONE persistent launch with per-instance
+                                    * dependencies (k_omega_chain, csrc/gemm_sym.hip) instead of one launch per product in
+                                    * concurrent parts; 2: wherever it can run (any K >= 8, even p).  Same products, same bits
+                                    * (tests/test_gpu_chain.py).  Off by default: measured SLOWER on MI355X (headline Omega
+                                    * phase 0.89 vs 0.72 ms; DESIGN.md section 8.1, profiles/r3_omega_chain_*.txt)           */
 int ggl_ctx_set_option(ggl_ctx *ctx, int option, double value);
 int ggl_ctx_get_option(ggl_ctx *ctx, int option, double *value);
 
@@ -323,6 +329,9 @@ int ggl_dev_mfma_f64_peak(double *tflops_out);
 /* FP64 VALU || FP64 MFMA co-issue probe (csrc/probes_dev.hip), TF/s: {MFMA only, v_fma_f64 only, waves split per SIMD:
  * MFMA, DFMA, one wave with 4 / 8 / 16 / 32 v_fma_f64 behind every MFMA: MFMA, DFMA each} */
 int ggl_dev_coissue_probe(double *out12);
+/* k_omega_chain on a synthetic chain of nprod dependent products X <- I - 1.5 X^2: out = {ms as nprod launches, ms as one
+ * persistent launch, persistent workgroups, max |difference| of the results, completion flag, done counters [K]} */
+int ggl_dev_chain_run(int K, int p, int nprod, int iters, double *out);
 int ggl_dev_symm_timeline(int K, int p, long long *out, int max_blocks, int *nblocks_out);
 /* persistent-chain probe: nprod dependent products X <- X X of a K-batch as nprod launches (out[0], ms) and as ONE cooperative
  * launch with grid-wide barriers between the products (out[1], ms); out[2] grid of the latter, out[3] max |difference| of
