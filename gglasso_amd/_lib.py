@@ -61,6 +61,7 @@ _SIGNATURES = {
     "ggl_allreduce_groupsq": ([_vp], _i),
     "ggl_allreduce_norms": ([_vp], _i),
     "ggl_admm_step_sharded": ([_vp, _d, _d, _d, _dp, _dp], _i),
+    "ggl_admm_step_sharded_latent": ([_vp, _d, _d, _d, _i, _dp, _dp, _dp], _i),
     "ggl_scale_X": ([_vp, _d], _i),
     "ggl_sgl_batch_step": ([_vp, _dp, _dp, _i, _dp, _dp], _i),
     "ggl_mgl_batch_step": ([_vp, _i, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp], _i),

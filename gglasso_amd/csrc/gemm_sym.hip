@@ -629,6 +629,7 @@ __global__ __launch_bounds__(256) void k_omega_chain(const ChainProg P, unsigned
     if (threadIdx.x < CHAIN_MAX_INST) sh_step[threadIdx.x] = 0;           // product 0 has no predecessor: ready
 #ifdef GGL_DEV
     long long t_claim = 0, t_idle = 0, t_tile = 0, n_tile = 0, t_prev = wall_clock64(), t_first = t_prev;
+    const long long c_first = clock64();
 #endif
     __syncthreads();
     for (;;) {
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(256) void k_omega_chain(const ChainProg P, unsigned
 #ifdef GGL_DEV
         if (jk == -2 && P.prof && threadIdx.x == 0) {
             long long* o = P.prof + (size_t)blockIdx.x * 8;
-            o[0] = t_claim; o[1] = t_idle; o[2] = t_tile; o[3] = n_tile; o[4] = t_first; o[5] = wall_clock64(); o[6] = x;
+            o[0] = t_claim; o[1] = t_idle; o[2] = t_tile; o[3] = n_tile; o[4] = t_first; o[5] = wall_clock64(); o[6] = x; o[7] = clock64() - c_first;
         }
 #endif
         if (jk == -2) return;
@@ -898,6 +899,9 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
     else if (dl_cfg == 15) GGL_DL(16, 3, 3);
     else if (dl_cfg == 16) GGL_DL(16, 3, 4);
     else if (dl_cfg == 17) GGL_DL(16, 3, 5);
+    // shallower slabs, more of them in flight: 32 KiB (4 x 8 KiB) / 48 KiB (6 x 8 KiB) of LDS
+    else if (dl_cfg == 22) GGL_DL(8, 4);
+    else if (dl_cfg == 23) GGL_DL(8, 6);
 #endif
     else GGL_DL(16, 2);
 #undef GGL_DL
@@ -1127,11 +1131,11 @@ static constexpr long SMALL_BATCH_TILES = 800;   // up to here the 32x32-tile ke
 // A GGL_DEV build (libggl_hip_dev.so) adds the measured alternatives 1-5, 8, 11-13, 18, 19, 22 / 23 (64x64 with EIGHT
 // waves per workgroup), 24-29 (other slab / prefetch depths of the 32x32 kernel, see launch_dl) and the ablations 6, 7, 10,
 // 14, 15, 21 (tools/bench_*.py).
-int symm_variants() { return 37; }
+int symm_variants() { return 39; }
 bool symm_variant_built(int v)
 {
 #ifdef GGL_DEV
-    return v >= 0 && v <= 37;
+    return v >= 0 && v <= 39;
 #else
     return v == 0 || v == 9 || v == 16 || v == 17 || v == 20;
 #endif
@@ -1155,7 +1159,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 {
     if (variant < 0) variant = symm_auto_variant(2 * K, p);
     switch (variant) {
-        case 16: case 17: case 18: case 19: case 20: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:
+        case 16: case 17: case 18: case 19: case 20: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K, nullptr, variant - 16);
                 break;
@@ -1181,7 +1185,7 @@ int symm_bounds_tile(int K, int p, int variant)
     if (variant < 0) variant = symm_auto_variant(K, p);
     if ((p & 1) != 0 || p < 2) return 0;
     if (variant == 20 || (variant >= 24 && variant <= 29) || (variant >= 34 && variant <= 37)) return 32;
-    if ((variant >= 16 && variant <= 19) || variant == 22 || variant == 23 || (variant >= 30 && variant <= 33)) return 64;
+    if ((variant >= 16 && variant <= 19) || variant == 22 || variant == 23 || (variant >= 30 && variant <= 33) || variant == 38 || variant == 39) return 64;
     return 0;
 }
 
@@ -1192,7 +1196,7 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
 #define GGL_TN(BM, BK, WM, WN, LM) \
     launch_cfg<BM, BK, WM, WN, LM>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev)
     switch (variant) {
-        case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:
+        case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
             if ((p & 1) == 0 && p >= 2) {
                 launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16, rowpart, fropart);
                 break;

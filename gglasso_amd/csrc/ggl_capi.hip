@@ -75,7 +75,8 @@ struct ggl_ctx {
     double* nsNX = nullptr;                    // third [Y|Z] pair: the chain leaves A', B' intact for the bound kernels (lazy)
     unsigned* chain_cnt = nullptr;             // per-instance completion / ticket words, one 128-byte line each (lazy)
     long long chain_calls = 0;
-    bool flags_dirty = false;                  // a validation flag was raised: clear ALL device slots before the next step
+    bool flags_dirty = false;
+    int step_latent = 0;                       // latent flag of the last Omega-step (the split entry points that follow it)                  // a validation flag was raised: clear ALL device slots before the next step
     int ns_force = 0;                          // 0 auto, 1 symmetric products, 2 stable products
     bool use_syevj = false;
     static constexpr int MAX_PARTS = 4;
@@ -752,6 +753,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
     int rc;
     const double* beta = c->par;
     const int nxt = c->cur ^ 1;
+    c->step_latent = latent;
     CopySegs first;
     if (pending) first = *pending;
     if (c->omega_ns) {
@@ -1082,7 +1084,9 @@ extern "C" int ggl_step_group_partial(ggl_ctx* c, double rho, double lambda1)
     ARGCHK(c, "ctx");
     ARGCHK(rho > 0, "rho must be positive");
     HIPCHK(hipSetDevice(c->device));
-    launch_group_sums_full(c->stream, c->groupsq, c->sqwork, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
+    // u = soft(Omega + L + X, l1/rho) (admm_solver.py:190-191): L only takes part in the latent model (it is zero otherwise)
+    launch_group_sums_full(c->stream, c->groupsq, c->sqwork, c->Om[c->cur], c->step_latent ? c->L : nullptr, c->X,
+                           (1.0 / rho) * lambda1, c->K, c->p);
     launch_spec_pack(c->stream, c->spec_pending ? c->spec_flag : nullptr, c->groupsq + (size_t)c->p * c->p);
     HIPCHK(hipGetLastError());
     return GGL_OK;
@@ -1254,7 +1258,6 @@ static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double l
     ARGCHK(rho > 0, "rho must be positive");
     ARGCHK(reg == GGL_REG_SGL || reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
     ARGCHK(!latent || mu1, "latent needs mu1");
-    ARGCHK(!(groupsq_ready && latent), "K-sharded GGL with latent variables is not supported");
     HIPCHK(hipSetDevice(c->device));
     const bool defer_norms = (groupsq_ready & 2) != 0;
     groupsq_ready &= 1;
@@ -1319,9 +1322,16 @@ static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double l
         launch_dual_update(c->stream, c->X, Om, OmPrev, c->Theta, c->L, c->partials, c->K, c->p);
         PE(c, GGL_PH_DUAL);
         PB(c, GGL_PH_REDUCE);
-        launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), GGL_NNORM, norms_dst);
+        if (defer_norms) {
+            // K-sharded latent run: ONE row of sums over the whole local slab, so that the all-reduce over ranks covers 5
+            // doubles as in the non-latent case (the unsharded path keeps per-instance rows and adds them on the host)
+            launch_reduce_partials(c->stream, c->partials, 1, c->K * elementwise_blocks(c->p), GGL_NNORM, norms_dst);
+            rows = 1;
+        } else {
+            launch_reduce_partials(c->stream, c->partials, c->K, elementwise_blocks(c->p), GGL_NNORM, norms_dst);
+            rows = c->K;
+        }
         PE(c, GGL_PH_REDUCE);
-        rows = c->K;
     }
     HIPCHK(hipGetLastError());
     if (defer_norms) {
@@ -1959,44 +1969,55 @@ extern "C" int ggl_allreduce_norms(ggl_ctx* c)
     return GGL_OK;
 }
 
-static int sharded_pass(ggl_ctx* c, double rho, double lambda1, double lambda2, const double* nk, bool speculate,
-                        double out_norms[5])
+static int sharded_pass(ggl_ctx* c, double rho, double lambda1, double lambda2, int latent, const double* mu1,
+                        const double* nk, bool speculate, double out_norms[5])
 {
     CopySegs sg;
     int rc = upload_par(c, 0, nk, 1.0, rho, &sg);
     if (rc) return rc;
-    if (!(speculate && take_prelaunched(c, 0))) {
+    if (latent) DROP_PRE(c);       // (a latent step never speculates and never takes over a pre-launched chain)
+    if (latent || !(speculate && take_prelaunched(c, 0))) {
         // with MAX_PARTS parts there is no flag slot left for the all-reduced flag
-        rc = omega_step(c, 0, &sg, speculate && c->ns_parts < ggl_ctx::MAX_PARTS);
+        rc = omega_step(c, latent, &sg, speculate && !latent && c->ns_parts < ggl_ctx::MAX_PARTS);
         if (rc) return rc;
     }
-    launch_group_sums_full(c->stream, c->groupsq, c->sqwork, c->Om[c->cur], nullptr, c->X, (1.0 / rho) * lambda1, c->K, c->p);
+    launch_group_sums_full(c->stream, c->groupsq, c->sqwork, c->Om[c->cur], latent ? c->L : nullptr, c->X,
+                           (1.0 / rho) * lambda1, c->K, c->p);
     launch_spec_pack(c->stream, c->spec_pending ? c->spec_flag : nullptr, c->groupsq + (size_t)c->p * c->p);
     HIPCHK(hipGetLastError());
     if ((rc = ggl_allreduce_groupsq(c))) return rc;
-    rc = ggl_step_finish_impl(c, rho, lambda1, lambda2, GGL_REG_GGL, 0, nullptr, 1 | 2, out_norms);   // norms stay on the device
+    // latent: Theta from the reduced sums, then the L-step and the dual update on the local slab (admm_solver.py:197-208:
+    // per instance, no exchange), one row of local sums; norms stay on the device
+    rc = ggl_step_finish_impl(c, rho, lambda1, lambda2, GGL_REG_GGL, latent, mu1, 1 | 2, out_norms);
     if (rc) return rc;
     if ((rc = ggl_allreduce_norms(c))) return rc;
     return finish_norms(c, 1, out_norms);
 }
 
-extern "C" int ggl_admm_step_sharded(ggl_ctx* c, double rho, double lambda1, double lambda2, const double* nk,
-                                     double out_norms[5])
+extern "C" int ggl_admm_step_sharded_latent(ggl_ctx* c, double rho, double lambda1, double lambda2, int latent,
+                                            const double* mu1, const double* nk, double out_norms[5])
 {
     ARGCHK(c && out_norms, "ctx, out_norms");
     ARGCHK(c->comm, "ggl_comm_init first");
     ARGCHK(rho > 0 && lambda1 > 0 && lambda2 > 0, "rho, lambda1, lambda2 must be positive");
+    ARGCHK(!latent || mu1, "latent needs mu1");
     HIPCHK(hipSetDevice(c->device));
-    int rc = sharded_pass(c, rho, lambda1, lambda2, nk, true, out_norms);
+    int rc = sharded_pass(c, rho, lambda1, lambda2, latent, mu1, nk, true, out_norms);
     if (rc == GGL_SPEC_RETRY) {
         // the reduced validation flag says some rank's schedule did not cover its spectrum: every rank left its iterate
         // alone and repeats the iteration bounds-first (all ranks take this branch together: the flag is the all-reduced one)
-        rc = sharded_pass(c, rho, lambda1, lambda2, nk, false, out_norms);
+        rc = sharded_pass(c, rho, lambda1, lambda2, latent, mu1, nk, false, out_norms);
         if (rc == GGL_SPEC_RETRY) return fail(GGL_E_SOLVER, "K-sharded step: the non-speculative repeat was rejected");
     }
-    if (rc != GGL_OK) return rc;
+    if (rc != GGL_OK || latent) return rc;
     // the sums are the GLOBAL ones: every rank takes the same decision here (and the chain is local work anyway)
     return (c->ns_parts < ggl_ctx::MAX_PARTS) ? maybe_prelaunch(c, rho, out_norms) : GGL_OK;
+}
+
+extern "C" int ggl_admm_step_sharded(ggl_ctx* c, double rho, double lambda1, double lambda2, const double* nk,
+                                     double out_norms[5])
+{
+    return ggl_admm_step_sharded_latent(c, rho, lambda1, lambda2, 0, nullptr, nk, out_norms);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2577,12 +2598,12 @@ extern "C" int ggl_dev_chain_run(int K, int p, int nprod, int iters, double* out
         std::vector<long long> hp((size_t)grid * 8);
         HIPCHK(hipMemcpy(hp.data(), dprof.p, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
         P.prof = nullptr;
-        double cl = 0, id = 0, ti = 0, nt = 0, span = 0;
+        double cl = 0, id = 0, ti = 0, nt = 0, span = 0, cyc = 0;
         long long t0 = hp[4], t1 = hp[5];
         int perx[8] = {};
         for (int g = 0; g < grid; ++g) {
             const long long* o = hp.data() + (size_t)g * 8;
-            cl += o[0]; id += o[1]; ti += o[2]; nt += o[3]; span += o[5] - o[4];
+            cl += o[0]; id += o[1]; ti += o[2]; nt += o[3]; span += o[5] - o[4]; cyc += o[7];
             t0 = std::min(t0, o[4]); t1 = std::max(t1, o[5]);
             perx[o[6] & 7] += 1;
         }
@@ -2590,7 +2611,7 @@ extern "C" int ggl_dev_chain_run(int K, int p, int nprod, int iters, double* out
                 "%.2f tiles, %.1f us per tile, alive %.1f us; workgroups per XCD:", (t1 - t0) * 0.01, grid, cl * 0.01 / grid,
                 id * 0.01 / grid, ti * 0.01 / grid, nt / grid, ti * 0.01 / std::max(nt, 1.0), span * 0.01 / grid);
         for (int x = 0; x < 8; ++x) fprintf(stderr, " %d", perx[x]);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "; clock64 ticks per us of wall_clock64 while alive: %.1f\n", cyc / (span * 0.01));
     }
     double dev = 0.0;
     for (size_t i = 0; i < n; ++i) dev = std::max(dev, std::fabs(r1[i] - r2[i]));

@@ -73,7 +73,7 @@ void launch_prox_od(hipStream_t st, double* out, const double* A, double lam, co
 int pair_blocks(int p, int reg, int K);
 // flat != 0 and K <= GGL_FLAT_MAX_K (GGL only): one thread per element with its K-column in registers; valid for an
 // exactly symmetric state only.  theta_partial_blocks: norms partial rows written by launch_theta_pair.
-static constexpr int GGL_FLAT_MAX_K = 32;
+static constexpr int GGL_FLAT_MAX_K = 256;     // K-column over up to 16 waves of 16 instances each (theta_pair.hip, launch_flat4_any)
 int theta_partial_blocks(int p, int reg, int K, int flat);
 // GGL/FGL Theta-step on upper-triangle K-vectors (prox_p, ggl_helper.py:190-207), mirrored.
 //   fuse_dual != 0 (non-latent): also X += Omega - Theta and norms partials [K][nblk][5].

@@ -48,7 +48,8 @@ static inline int flat_blocks(int p) { return (int)(((size_t)p * p + 255) / 256)
 // workgroup where that pays (K > FLAT4_MIN_K)
 static constexpr int FLAT4_MIN_K = 8;
 static constexpr int FLAT4_CHUNKS = 2;     // 64-element chunks per workgroup (halves the partial-sum rows of the reduction)
-static inline bool use_flat4(int K, int flat) { return flat == 2 && K > FLAT4_MIN_K; }
+static constexpr int GGL_FLAT1_MAX_K = 32;   // the one-thread-per-element kernel keeps the whole K-column in ONE lane's registers
+static inline bool use_flat4(int K, int flat) { return (flat == 2 && K > FLAT4_MIN_K) || (flat != 0 && K > GGL_FLAT1_MAX_K); }
 
 int theta_partial_blocks(int p, int reg, int K, int flat)
 {
@@ -632,8 +633,21 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
 // the instances w*KQ .. (w+1)*KQ-1 of 64 consecutive elements (KQ values of Omega and X per lane instead of K: 8 waves
 // per SIMD instead of 3 at K = 32, and four times the workgroups, so the tail of the last round of workgroups is short),
 // the four partial sums of squares meet in LDS (fixed order).  Every access is still a full 512-byte wave row.
-template <int KQ, bool FUSE_DUAL>
-__global__ __launch_bounds__(256) void k_theta_ggl_flat4(double* __restrict__ Theta, double* __restrict__ X,
+// NW waves per workgroup (4, 8 or 16): K <= NW * KQ.  The partial sums of squares of the NW waves are added as a fixed
+// balanced tree (for NW = 4 the order it always had)
+template <int NW> __device__ __forceinline__ double tree_sum(const double (&v)[NW])
+{
+    if constexpr (NW == 4) return (v[0] + v[1]) + (v[2] + v[3]);
+    else {
+        double h0[NW / 2], h1[NW / 2];
+#pragma unroll
+        for (int i = 0; i < NW / 2; ++i) { h0[i] = v[i]; h1[i] = v[NW / 2 + i]; }
+        return tree_sum<NW / 2>(h0) + tree_sum<NW / 2>(h1);
+    }
+}
+
+template <int KQ, bool FUSE_DUAL, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4(double* __restrict__ Theta, double* __restrict__ X,
                                                          double* __restrict__ C, const double* __restrict__ Omega,
                                                          const double* __restrict__ OmegaPrev,
                                                          const double* __restrict__ L, double l1, double l2,
@@ -641,8 +655,8 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4(double* __restrict__ Th
                                                          const int* __restrict__ skip, const double* __restrict__ l1G,
                                                          const double* __restrict__ l2G, const double* __restrict__ gsq)
 {
-    __shared__ double ssh[4][64];
-    __shared__ double scratch[GGL_NNORM * 4];
+    __shared__ double ssh[NW][64];
+    __shared__ double scratch[GGL_NNORM * NW];
     if (spec_failed(skip)) return;
     const size_t pp = (size_t)p * p;
     {   // grid-point dimension of a batch of independent problems (see k_theta_fgl)
@@ -686,7 +700,10 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4(double* __restrict__ Th
         ssh[wid][lane] = ss;
         __syncthreads();
         if (live) {
-            const double tot = gsq ? gsq[e] : (ssh[0][lane] + ssh[1][lane]) + (ssh[2][lane] + ssh[3][lane]);
+            double sv[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sv[w] = ssh[w][lane];
+            const double tot = gsq ? gsq[e] : tree_sum<NW>(sv);
             const double a = fmax(sqrt(tot), l2);
             const double amul = a - l2;
             const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
@@ -725,8 +742,12 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4(double* __restrict__ Th
         if (threadIdx.x == 0) {
             double* o = partials + (size_t)blockIdx.x * GGL_NNORM;
 #pragma unroll
-            for (int v = 0; v < GGL_NNORM; ++v)
-                o[v] = (scratch[v] + scratch[GGL_NNORM + v]) + (scratch[2 * GGL_NNORM + v] + scratch[3 * GGL_NNORM + v]);
+            for (int v = 0; v < GGL_NNORM; ++v) {
+                double sv[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sv[w] = scratch[w * GGL_NNORM + v];
+                o[v] = tree_sum<NW>(sv);
+            }
         }
     }
 }
@@ -734,8 +755,8 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4(double* __restrict__ Th
 // The same with 16-byte accesses: a lane holds TWO consecutive elements (p^2 even), a wave row is 1 KiB.  8-byte
 // accesses run at 0.54-0.70x the 16-byte rate on this chip (MI355X_MICROARCH.md), and this kernel is nothing but accesses.
 // Same 128 elements per workgroup as the scalar form (one chunk of 2 x 64), so the partial-sum layout is unchanged.
-template <int KQ, bool FUSE_DUAL>
-__global__ __launch_bounds__(256) void k_theta_ggl_flat4v(double* __restrict__ Theta, double* __restrict__ X,
+template <int KQ, bool FUSE_DUAL, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4v(double* __restrict__ Theta, double* __restrict__ X,
                                                           double* __restrict__ C, const double* __restrict__ Omega,
                                                           const double* __restrict__ OmegaPrev,
                                                           const double* __restrict__ L, double l1, double l2,
@@ -744,8 +765,8 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4v(double* __restrict__ T
                                                           const double* __restrict__ l2G, const double* __restrict__ gsq)
 {
     static_assert(FLAT4_CHUNKS == 2, "128 elements per workgroup");
-    __shared__ double2 ssh[4][64];
-    __shared__ double scratch[GGL_NNORM * 4];
+    __shared__ double2 ssh[NW][64];
+    __shared__ double scratch[GGL_NNORM * NW];
     if (spec_failed(skip)) return;
     const size_t pp = (size_t)p * p;
     {
@@ -793,8 +814,11 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4v(double* __restrict__ T
         double2 tot;
         if (gsq) tot = ld2(gsq + e);
         else {
-            tot.x = (ssh[0][lane].x + ssh[1][lane].x) + (ssh[2][lane].x + ssh[3][lane].x);
-            tot.y = (ssh[0][lane].y + ssh[1][lane].y) + (ssh[2][lane].y + ssh[3][lane].y);
+            double sx[NW], sy[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { sx[w] = ssh[w][lane].x; sy[w] = ssh[w][lane].y; }
+            tot.x = tree_sum<NW>(sx);
+            tot.y = tree_sum<NW>(sy);
         }
         const double a0 = fmax(sqrt(tot.x), l2), a1 = fmax(sqrt(tot.y), l2);
         const double m0 = a0 - l2, m1 = a1 - l2;
@@ -841,32 +865,55 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat4v(double* __restrict__ T
         if (threadIdx.x == 0) {
             double* o = partials + (size_t)blockIdx.x * GGL_NNORM;
 #pragma unroll
-            for (int v = 0; v < GGL_NNORM; ++v)
-                o[v] = (scratch[v] + scratch[GGL_NNORM + v]) + (scratch[2 * GGL_NNORM + v] + scratch[3 * GGL_NNORM + v]);
+            for (int v = 0; v < GGL_NNORM; ++v) {
+                double sv[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sv[w] = scratch[w * GGL_NNORM + v];
+                o[v] = tree_sum<NW>(sv);
+            }
         }
     }
 }
 
 static inline int flat4_blocks(int p) { return (int)(((size_t)p * p + 64 * FLAT4_CHUNKS - 1) / (64 * FLAT4_CHUNKS)); }
 
-template <int KQ>
+template <int KQ, int NW = 4, bool VEC_OK = true>
 static void launch_flat4(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                          const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual, double* partials,
                          int K, int p, const int* skip, int G = 1, const double* l1G = nullptr, const double* l2G = nullptr,
                          const double* gsq = nullptr)
 {
-    dim3 grid(flat4_blocks(p), G), blk(256);
-    if ((p & 1) == 0) {          // p^2 even: two consecutive elements per lane, 16-byte accesses
-        if (fuse_dual)
-            hipLaunchKernelGGL((k_theta_ggl_flat4v<KQ, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
-        else
-            hipLaunchKernelGGL((k_theta_ggl_flat4v<KQ, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
-        return;
+    dim3 grid(flat4_blocks(p), G), blk(NW * 64);
+    if constexpr (VEC_OK) {
+        if ((p & 1) == 0) {          // p^2 even: two consecutive elements per lane, 16-byte accesses
+            if (fuse_dual)
+                hipLaunchKernelGGL((k_theta_ggl_flat4v<KQ, true, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+            else
+                hipLaunchKernelGGL((k_theta_ggl_flat4v<KQ, false, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+            return;
+        }
     }
     if (fuse_dual)
-        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, true, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
     else
-        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, false, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+}
+
+// the K-column of an element over 4, 8 or 16 waves: K <= 16: 4 x 4, <= 32: 4 x 8, <= 64: 8 x 8, <= 128: 16 x 8 (16-byte
+// accesses throughout), <= 256: 16 x 16 with 8-byte accesses (two elements per lane would need 192 registers per lane, a
+// 16-wave workgroup has 128)
+static void launch_flat4_any(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
+                             const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual,
+                             double* partials, int K, int p, const int* skip, int G, const double* l1G, const double* l2G,
+                             const double* gsq)
+{
+#define GGL_F4(...) launch_flat4<__VA_ARGS__>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, G, l1G, l2G, gsq)
+    if (K <= 16) GGL_F4(4);
+    else if (K <= 32) GGL_F4(8);
+    else if (K <= 64) GGL_F4(8, 8);
+    else if (K <= 128) GGL_F4(8, 16);
+    else GGL_F4(16, 16, false);
+#undef GGL_F4
 }
 
 template <int KMAX>
@@ -890,11 +937,10 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
     // per-element kernels (exactly symmetric state): the group sums are the element's own K-column, or -- K-sharded run --
     // the all-reduced FULL matrix `groupsq` (launch_group_sums_full on every rank)
     if (reg == 1 && K <= GGL_FLAT_MAX_K && use_flat4(K, flat)) {
-        if (K <= 16) launch_flat4<4>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
-        else launch_flat4<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
+        launch_flat4_any(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
         return hipGetLastError();
     }
-    if (reg == 1 && flat && K <= GGL_FLAT_MAX_K) {
+    if (reg == 1 && flat && K <= GGL_FLAT1_MAX_K) {
         if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
         else if (K <= 16) launch_flat<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
         else launch_flat<32>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
@@ -934,8 +980,7 @@ hipError_t launch_theta_batch(hipStream_t st, int reg, double* Theta, double* X,
     if (reg == 1) {
         if (K > GGL_FLAT_MAX_K) return hipErrorInvalidValue;
         if (use_flat4(K, 2)) {       // partial-sum rows: theta_partial_blocks(p, reg, K, 2) per problem
-            if (K <= 16) launch_flat4<4>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
-            else launch_flat4<8>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
+            launch_flat4_any(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G, nullptr);
             return hipGetLastError();
         }
         if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);

@@ -178,16 +178,27 @@ _solver.HipEngine.norms_tensor = _hip_norms_tensor
 
 def ADMM_MGL_sharded(S_local, lambda1, lambda2, reg, Omega_0, K_total, comm, Theta_0=np.array([]),
                      X_0=np.array([]), n_samples=None, tol=1e-5, rtol=1e-4, update_rho=True, rho=1.,
-                     max_iter=1000, verbose=False, measure=False, device=0, engine_kwargs=None):
+                     max_iter=1000, verbose=False, measure=False, device=0, engine_kwargs=None, latent=False, mu1=None):
     """K-sharded Group Graphical Lasso: this rank owns the slab ``S_local`` (K_local,p,p) of a problem
     with ``K_total`` instances; arguments otherwise as ADMM_MGL (solver/admm_solver.py:13-31).  Every
     rank executes the same host loop and sees the same residuals, so the rho updates and the stopping
-    decision agree without any further communication.  Returns this rank's slab of the solution."""
+    decision agree without any further communication.  Returns this rank's slab of the solution.
+    ``latent`` / ``mu1`` (this rank's (K_local,) slab of it, or a float): the L-step (admm_solver.py:197-205) is per
+    instance and runs on the local slab; the group sums use Omega + L + X."""
     assert reg == 'GGL', "only the GGL penalty shards across K (FGL scans along K; use grid sharding)"
     assert Omega_0.shape == S_local.shape
     assert min(lambda1, lambda2) > 0
     assert rho > 0
     Kl, p, _ = S_local.shape
+    if latent:
+        if isinstance(mu1, float):
+            mu1 = mu1 * np.ones(Kl)
+        assert mu1 is not None
+        assert np.all(mu1 > 0)
+        mu1 = as_c(mu1)
+        assert len(mu1) == Kl
+    else:
+        mu1 = None
     if n_samples is None:
         nk = np.ones(Kl)
     elif isinstance(n_samples, (int, np.integer)):
@@ -211,10 +222,10 @@ def ADMM_MGL_sharded(S_local, lambda1, lambda2, reg, Omega_0, K_total, comm, The
     try:
         if getattr(comm, "capi", False):
             comm.attach(eng)
-        info, _ = _run_admm(eng, reg, K_total, p, float(lambda1), float(lambda2), False, None, nk, float(rho),
+        info, _ = _run_admm(eng, reg, K_total, p, float(lambda1), float(lambda2), bool(latent), mu1, nk, float(rho),
                             tol, rtol, 'boyd', update_rho, max_iter, verbose and comm.rank == 0, measure,
                             "Multiple", comm=comm, want_objective=False)
-        _exit_report(eng, False, 1e-5, False)
+        _exit_report(eng, bool(latent), 1e-5, False)
         sol = eng.state()
     finally:
         eng.close()

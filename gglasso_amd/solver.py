@@ -134,9 +134,10 @@ class HipEngine:
         check(self.lib.ggl_comm_count(self.h, ctypes.byref(n)))
         return int(n.value)
 
-    def step_sharded(self, rho, lambda1, lambda2, nk):
+    def step_sharded(self, rho, lambda1, lambda2, nk, latent=False, mu1=None):
         """One K-sharded GGL iteration on this rank's slab; returns the five GLOBAL sums (same on every rank)."""
-        check(self.lib.ggl_admm_step_sharded(self.h, rho, lambda1, lambda2, self._cptr(nk), self._norms_p))
+        check(self.lib.ggl_admm_step_sharded_latent(self.h, rho, lambda1, lambda2, int(latent), self._cptr(mu1),
+                                                    self._cptr(nk), self._norms_p))
         return self._norms
 
     # -- K independent single problems (batched lambda path) ----------------------------------
@@ -333,7 +334,7 @@ def _run_admm(eng, reg, K_total, p, lambda1, lambda2, latent, mu1, nk, rho, tol,
             # RCCL behind the C ABI: Omega-step, both all-reduces, Theta-step and the norms in one call
             if iter_t == max_iter - 1:
                 eng.hint_last_step()
-            sq = eng.step_sharded(rho, lambda1, lambda2, nk)
+            sq = eng.step_sharded(rho, lambda1, lambda2, nk, latent, mu1)
         elif sharded_ggl:
             # device_norms: HIP engine over RCCL.  The Omega-step may then run speculatively; its validation flag
             # rides on the (p,p) all-reduce, so either every rank accepts the step or every rank repeats it.

@@ -197,6 +197,11 @@ int ggl_allreduce_groupsq(ggl_ctx *ctx);
 int ggl_allreduce_norms(ggl_ctx *ctx);
 int ggl_admm_step_sharded(ggl_ctx *ctx, double rho, double lambda1, double lambda2, const double *nk,
                           double out_norms[5]);
+/* the same with latent variables (admm_solver.py:197-208): the L-step and the dual update are per instance, so they run on
+ * the local slab between the Theta-step (reduced group sums) and the all-reduce of the five sums; mu1 (K_local,).  A latent
+ * step neither speculates nor pre-launches (the L-step has its own verification synchronisation). */
+int ggl_admm_step_sharded_latent(ggl_ctx *ctx, double rho, double lambda1, double lambda2, int latent,
+                                 const double *mu1, const double *nk, double out_norms[5]);
 
 /* ---- K independent single problems (batched lambda path) ---------------------------------------
  * The ctx stack is used as K separate ADMM_SGL problems (single_admm_solver.py:157-214), each with its

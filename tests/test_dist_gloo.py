@@ -19,7 +19,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, K, p, out_dir, miss=""):
+def _worker(rank, world, port, K, p, out_dir, miss="", latent=False):
     import contextlib
     import io
     sys.path.insert(0, ROOT)
@@ -47,28 +47,32 @@ def _worker(rank, world, port, K, p, out_dir, miss=""):
             def close(self):
                 retries.append(self.retries)
         solver.ENGINE = Eng
+    extra = dict(latent=True, mu1=np.linspace(0.1, 0.2, K)[k0:k1]) if latent else {}
     with contextlib.redirect_stdout(io.StringIO()):
-        sol, info = ADMM_MGL_sharded(S[k0:k1], 0.05, 0.02, "GGL", Om0, K, comm, tol=1e-9, rtol=1e-9, measure=True)
+        sol, info = ADMM_MGL_sharded(S[k0:k1], 0.05, 0.02, "GGL", Om0, K, comm, tol=1e-9, rtol=1e-9, measure=True, **extra)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), k0=k0, k1=k1, status=info["status"],
              iters=len(info["residual"]), retries=np.array(retries[-1] if retries else 0), **sol)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,world,miss", [(5, 2, ""), (4, 2, ""), (5, 2, "1:2,0:5,1:5,0:9")])
-def test_k_sharded_ggl_equals_single_process(tmp_path, K, world, miss):
+@pytest.mark.parametrize("K,world,miss,latent", [(5, 2, "", False), (4, 2, "", False), (5, 2, "1:2,0:5,1:5,0:9", False),
+                                                 (5, 2, "", True), (5, 2, "1:3,0:4", True)])
+def test_k_sharded_ggl_equals_single_process(tmp_path, K, world, miss, latent):
     """miss != "": the device protocol of the HIP engine with scripted speculation misses (rank:call) -- rank 1 alone at
     its 2nd speculative step, both ranks at their 5th, rank 0 alone at its 9th.  Every rank must repeat exactly those
-    steps (three repeats each), stay in lockstep with the collectives, and end with the unsharded solution."""
+    steps (three repeats each), stay in lockstep with the collectives, and end with the unsharded solution.
+    latent: the L-step (admm_solver.py:197-205) on every rank's own slab, per-instance mu1, group sums over Omega + L + X."""
     import torch.multiprocessing as mp
     from oracle import ggl_oracle as orc
     from gglasso_amd import synth
     p = 24
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, K, p, str(tmp_path), miss), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, K, p, str(tmp_path), miss, latent), nprocs=world, join=True)
     S, _ = synth.make_problem("GGL", K, p, seed=21)
     Om0 = np.repeat(np.eye(p)[None], K, axis=0)
-    ref, rinfo = orc.ADMM_MGL(S, 0.05, 0.02, "GGL", Om0, tol=1e-9, rtol=1e-9)
+    extra = dict(latent=True, mu1=np.linspace(0.1, 0.2, K)) if latent else {}
+    ref, rinfo = orc.ADMM_MGL(S, 0.05, 0.02, "GGL", Om0, tol=1e-9, rtol=1e-9, **extra)
     covered = 0
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
@@ -76,10 +80,11 @@ def test_k_sharded_ggl_equals_single_process(tmp_path, K, world, miss):
         covered += k1 - k0
         assert str(z["status"]) == rinfo["status"]
         assert int(z["iters"]) == rinfo["iterations"]
-        for nm in ("Omega", "Theta", "X"):
+        for nm in ("Omega", "Theta", "X") + (("L",) if latent else ()):
             assert np.abs(z[nm] - ref[nm][k0:k1]).max() <= 1e-10, (r, nm)
         if miss:
-            assert int(z["retries"]) == 3, (r, int(z["retries"]))
+            # every rank repeats every step at which ANY rank missed (the speculative-call numbers agree across ranks)
+            assert int(z["retries"]) == len({t.split(":")[1] for t in miss.split(",")}), (r, int(z["retries"]))
     assert covered == K
 
 

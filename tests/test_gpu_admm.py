@@ -139,7 +139,10 @@ def test_oracle_trajectory_mid_sizes(sol, reg, K, p, latent):
     assert np.linalg.norm(s['Theta'] - ref['Theta']) <= 1e-8
 
 
-@pytest.mark.parametrize("p,K", [(60, 4), (160, 4), (70, 12), (150, 20), (66, 32)])
+@pytest.mark.parametrize("p,K", [(60, 4), (160, 4), (70, 12), (150, 20), (66, 32),
+                                 # K > 32: the K-column of an element over 8 / 16 waves (theta_pair.hip, launch_flat4_any):
+                                 # 8 x 8 (K <= 64), 16 x 8 (<= 128), 16 x 16 with 8-byte accesses (<= 256); even and odd p
+                                 (40, 40), (33, 64), (36, 100), (31, 128), (30, 200), (25, 256)])
 def test_asymmetric_dual_start_takes_the_mirroring_kernels(sol, p, K, monkeypatch):
     """The per-element GGL Theta-step is only valid for a bitwise symmetric state.  A dual start X_0 that is
     symmetric only to ~1e-8 (inside the reference's own 1e-5 assert, ggl_helper.py:193) must follow the
@@ -283,17 +286,20 @@ def test_sharded_driver_on_rccl_single_rank(sol):
         # p = 150 takes the Newton-Schulz Omega-step, speculative after the first iteration: its validation flag rides
         # on the (p,p) all-reduce.  spec_factor 0.9 deflates the assumed bounds so that every speculative step
         # is rejected (by the all-reduced flag) and repeated; speculate 0 switches speculation off.
-        for (K, p, env) in ((5, 40, {}), (3, 150, {}), (3, 150, {"spec_factor": 0.9}), (3, 150, {"speculate": 0})):
+        for (K, p, env) in ((5, 40, {}), (3, 150, {}), (3, 150, {"spec_factor": 0.9}), (3, 150, {"speculate": 0}),
+                            (4, 40, {"latent": 1}), (3, 150, {"latent": 1})):
             S, _ = synth.make_problem("GGL", K, p, seed=31)
             Om0 = np.stack([np.eye(p)] * K)
             comm = TorchComm(device="cuda:0")
             assert comm.stream_handle not in (None, 0)       # a dedicated stream, never the NULL handle
-            (a, ia), _ = quiet(ADMM_MGL_sharded, S, 0.05, 0.02, "GGL", Om0, K, comm, tol=1e-9, rtol=1e-9,
-                               measure=True, engine_kwargs={"options": env})
-            (b, ib), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.02, "GGL", Om0, tol=1e-9, rtol=1e-9, measure=True)
-            assert ia["status"] == ib["status"] == "optimal"
+            kw = dict(tol=1e-9, rtol=1e-9, measure=True)
+            if env.pop("latent", 0):      # latent variables under K-sharding: deferred norms as ONE row of local sums
+                kw.update(latent=True, mu1=np.linspace(0.1, 0.2, K), max_iter=40)
+            (a, ia), _ = quiet(ADMM_MGL_sharded, S, 0.05, 0.02, "GGL", Om0, K, comm, engine_kwargs={"options": env}, **kw)
+            (b, ib), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.02, "GGL", Om0, **kw)
+            assert ia["status"] == ib["status"]
             assert len(ia["residual"]) == len(ib["residual"])
-            for nm in ("Omega", "Theta", "X"):
+            for nm in ("Omega", "Theta", "X", "L"):
                 assert np.abs(a[nm] - b[nm]).max() <= 1e-10, (nm, env)
     finally:
         dist.destroy_process_group()
@@ -448,16 +454,20 @@ def test_sharded_driver_rccl_behind_the_c_abi_single_rank(sol):
     s.close()
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     try:
-        for (K, p, env) in ((5, 40, {}), (3, 150, {}), (3, 150, {"spec_factor": 0.9}), (3, 150, {"speculate": 0}), (4, 500, {})):
+        for (K, p, env) in ((5, 40, {}), (3, 150, {}), (3, 150, {"spec_factor": 0.9}), (3, 150, {"speculate": 0}), (4, 500, {}),
+                            (4, 40, {"latent": 1}), (3, 150, {"latent": 1})):
             S, _ = synth.make_problem("GGL", K, p, seed=31)
             Om0 = np.stack([np.eye(p)] * K)
             kw = dict(tol=1e-9, rtol=1e-9) if p < 500 else dict(tol=1e-20, rtol=1e-20, max_iter=6)
+            if env.pop("latent", 0):
+                # K-sharded run with latent variables (ggl_admm_step_sharded_latent): L-step on the slab, per-instance mu1
+                kw.update(latent=True, mu1=np.linspace(0.1, 0.2, K), max_iter=40)
             (a, ia), _ = quiet(ADMM_MGL_sharded, S, 0.05, 0.02, "GGL", Om0, K, RcclComm(), measure=True,
                                engine_kwargs={"options": env}, **kw)
             (b, ib), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.02, "GGL", Om0, measure=True, **kw)
             assert ia["status"] == ib["status"]
             assert len(ia["residual"]) == len(ib["residual"])
-            for nm in ("Omega", "Theta", "X"):
+            for nm in ("Omega", "Theta", "X", "L"):
                 assert np.abs(a[nm] - b[nm]).max() <= 1e-10, (nm, env)
         # a dual start that is symmetric only to ~1e-8: the mirroring tile-pair Theta kernel reads the upper triangle of
         # the all-reduced FULL group-sum matrix (the per-element kernels would read both triangles)
@@ -557,3 +567,17 @@ def test_omega_step_tolerance_and_carried_bound_vector(sol):
         assert res[n][1]["spec_misses"] == 0 and res[n][1]["eigh_fallbacks"] == 0, (n, res[n][1])
     with pytest.raises(AssertionError):
         solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"ns_tol": 1e-3})
+
+
+@pytest.mark.parametrize("K,p", [(48, 40), (130, 28)])
+def test_large_K_latent_and_fgl_free_paths_of_the_wide_theta_kernel(sol, K, p):
+    """K > 32 through the per-element Theta kernel without the fused dual update (latent: Theta and C = Theta - X - Omega
+    are written, the dual update follows the L-step), against the oracle (admm_solver.py:190-208)."""
+    from gglasso_amd import synth
+    S, _ = synth.make_problem("GGL", K=K, p=p, N=2 * p, seed=41)
+    Om0 = np.stack([np.eye(p)] * K)
+    kw = dict(max_iter=6, tol=1e-20, rtol=1e-20, latent=True, mu1=0.2)
+    ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
+    (s, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
+    for nm in ('Omega', 'Theta', 'L', 'X'):
+        assert np.abs(s[nm] - ref[nm]).max() <= 1e-9, nm
