@@ -47,6 +47,8 @@ _SIGNATURES = {
     "ggl_set_state": ([_vp, _dp, _dp, _dp, _dp], _i),
     "ggl_get_state": ([_vp, _dp, _dp, _dp, _dp], _i),
     "ggl_set_lambda1_mask": ([_vp, _dp], _i),
+    "ggl_set_lambda1_mask_k": ([_vp, _dp], _i),
+    "ggl_set_instance_dims": ([_vp, ctypes.POINTER(_i)], _i),
     "ggl_admm_step": ([_vp, _d, _d, _d, _i, _i, _dp, _dp, _dp], _i),
     "ggl_hint_last_step": ([_vp], _i),
     "ggl_step_omega": ([_vp, _d, _i, _dp], _i),

@@ -18,7 +18,7 @@ from .solver import as_c, residuals_from_norms, next_rho
 
 def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max_iter=1000, tol=1e-7,
                    rtol=1e-4, update_rho=True, verbose=False, latent=False, mu1=None, lambda1_mask=None,
-                   selection_stats=False):
+                   selection_stats=False, dims=None):
     """Solve ``ADMM_SGL(S, lambda1[k], ...)`` for every k of the 1-D array ``lambda1`` at once.
 
     S: (p,p) shared by all instances, or (K,p,p) with one covariance matrix per instance (what
@@ -27,7 +27,12 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     Returns a list of K ``(sol, info)`` pairs with the reference's keys; ``info`` additionally carries
     ``'iterations'`` and the final ``'rho'``.  ``selection_stats``: also keep a device snapshot of every instance's
     solution's Theta and attach ``info['selection'] = {'Sdot','logdet','nnz','lambda_min'}`` computed on the GPU
-    (what the AIC / eBIC tables of model selection are made of)."""
+    (what the AIC / eBIC tables of model selection are made of).
+    ``dims`` (K,) ints: problems of DIFFERENT dimension in one batch -- instance k is the leading (dims[k], dims[k]) block
+    of its slot and the caller has padded S / Omega_0 / Theta_0 with an identity block and X_0 with zeros behind it (a
+    decoupled fixed point of the iteration; ``pad_blocks`` builds such stacks).  Residuals, ``dim`` and the stopping
+    decision of an instance are those of its block alone, and its solution is returned un-padded.  ``lambda1_mask`` may
+    then be (K,p,p): one mask per instance (with one lambda1 per instance)."""
     S = as_c(S)
     assert S.ndim in (2, 3) and S.shape[-1] == S.shape[-2]
     p = S.shape[-1]
@@ -40,10 +45,14 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     assert rho > 0
     lam_pp = None
     if lambda1_mask is not None:
-        assert lambda1_mask.shape == (p, p)
+        assert lambda1_mask.shape in ((p, p), (K, p, p))
         assert np.all(lambda1_mask >= 0)
-        assert np.all(np.abs(lambda1_mask.T - lambda1_mask) <= 1e-5)
+        assert np.all(np.abs(np.swapaxes(lambda1_mask, -1, -2) - lambda1_mask) <= 1e-5)
         lam_pp = as_c(lambda1_mask)          # the per-instance factor lambda1[k] multiplies it on the device
+    if dims is not None:
+        dims = np.asarray(dims, dtype=np.int64).reshape(-1)
+        assert len(dims) == K and S.ndim == 3 and not latent
+        assert np.all((dims >= 1) & (dims <= p))
     if latent:
         assert mu1 is not None
         mu = as_c(np.broadcast_to(np.asarray(mu1, dtype=np.float64), (K,)))
@@ -62,23 +71,32 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     X0 = stack(X_0, np.zeros((p, p)))
     eng = _solver.ENGINE(np.broadcast_to(S, (K, p, p)), Om0, Th0, X0)
     try:
-        if lam_pp is not None:
+        if lam_pp is not None and lam_pp.ndim == 3:
+            eng.set_lambda1_mask_k(lam[:, None, None] * lam_pp)        # single_admm_solver.py:114, per instance
+        elif lam_pp is not None:
             # threshold (1/rho_k) * lambda1_k * mask: the kernel multiplies 1/rho_k by the (p,p) array, so
             # the per-instance lambda1 factor has to be the same for all k, or folded per instance
-            assert np.all(lam == lam[0]), "lambda1_mask with different lambda1 per instance is not supported"
+            assert np.all(lam == lam[0]), "a shared lambda1_mask needs one lambda1 (pass a (K,p,p) mask otherwise)"
             eng.set_lambda1_mask(lam[0] * lam_pp)
+        if dims is not None:
+            eng.set_instance_dims(dims)
+        pk = np.full(K, p) if dims is None else dims
         rhos = np.full(K, float(rho))
         done = np.zeros(K, dtype=bool)
         results = [None] * K
         last = [None] * K
-        dim = (p ** 2 + p) / 2
+        dimk = (pk ** 2 + pk) / 2                                       # single_admm_solver.py:279, of the block itself
+
+        def state_of(k):
+            st = eng.state_k(k, latent)
+            return st if dims is None else {nm: np.ascontiguousarray(A[:pk[k], :pk[k]]) for nm, A in st.items()}
         for it in range(max_iter):
             sq = eng.sgl_batch_step(rhos, lam, latent, mu)
             fac = np.ones(K)
             for k in range(K):
                 if done[k]:
                     continue
-                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[k], rhos[k], tol, rtol, dim)
+                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[k], rhos[k], tol, rtol, dimk[k])
                 if update_rho:
                     rn = next_rho(rhos[k], r_t, s_t)
                     fac[k] = rhos[k] / rn
@@ -92,7 +110,7 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                 eng.scale_X_batch(fac)
             for k in range(K):
                 if done[k] and results[k] is None:
-                    results[k] = (eng.state_k(k, latent), {'status': 'optimal', 'iterations': it + 1, 'rho': rhos[k]})
+                    results[k] = (state_of(k), {'status': 'optimal', 'iterations': it + 1, 'rho': rhos[k]})
                     if selection_stats:
                         eng.snapshot_k(k)
             if done.all():
@@ -102,10 +120,11 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                 r_t, s_t, e_pri, e_dual = last[k]
                 status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
                                                                 else 'max iterations reached')
-                results[k] = (eng.state_k(k, latent), {'status': status, 'iterations': max_iter, 'rho': rhos[k]})
+                results[k] = (state_of(k), {'status': status, 'iterations': max_iter, 'rho': rhos[k]})
                 if selection_stats:
                     eng.snapshot_k(k)
         if selection_stats:
+            assert dims is None, "selection statistics are taken over whole slots"
             st = eng.selection_stats()
             for k in range(K):
                 results[k][1]['selection'] = {'Sdot': st[k, 0], 'logdet': st[k, 1], 'nnz': st[k, 2],
@@ -113,6 +132,18 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     finally:
         eng.close()
     return results
+
+
+def pad_blocks(blocks, P, identity):
+    """(p_k,p_k) arrays -> (K,P,P) stack: block k in the leading corner of slot k, an identity block (or zeros) behind it."""
+    out = np.zeros((len(blocks), P, P))
+    for k, B in enumerate(blocks):
+        q = B.shape[0]
+        out[k, :q, :q] = B
+        if identity and q < P:
+            d = np.arange(q, P)
+            out[k, d, d] = 1.0
+    return out
 
 
 def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1e-5, rtol=1e-4, update_rho=True,

@@ -59,13 +59,19 @@ __global__ __launch_bounds__(EW_THREADS) void k_theta_sgl(double* __restrict__ T
                                                           const double* __restrict__ mask,
                                                           const double* __restrict__ invrhoK,
                                                           double* __restrict__ partials, int p,
-                                                          const int* __restrict__ skip)
+                                                          const int* __restrict__ skip, const int* __restrict__ pk,
+                                                          size_t mask_stride)
 {
+    // pk != null: instance k is the leading (pk[k], pk[k]) block of its slot (identity padding behind it, a fixed point of
+    // the iteration): the stopping-test sums run over that block only (single_admm_solver.py:277-291 on the block itself)
+    // mask_stride: 0 = one (p,p) threshold array for all instances, p*p = one per instance
     __shared__ double scratch[GGL_NNORM * (EW_THREADS / 64)];
     if (spec_failed(skip)) return;
     const int k = blockIdx.y;
     const size_t pp = (size_t)p * p;
     const size_t base = (size_t)k * pp;
+    const int pin = pk ? pk[k] : p;
+    if (MASK) mask += (size_t)k * mask_stride;
     const double lk = MASK ? 0.0 : l1K[k];
     const double inv_rho = MASK ? invrhoK[k] : 0.0;
     double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
@@ -87,11 +93,13 @@ __global__ __launch_bounds__(EW_THREADS) void k_theta_sgl(double* __restrict__ T
                 const double xn = (x + om) - th;   // single_admm_solver.py:178
                 X[base + i] = xn;
                 const double dp = om - OmegaPrev[base + i];
-                acc[0] += om * om;
-                acc[1] += th * th;
-                acc[2] += xn * xn;
-                acc[3] += (om - th) * (om - th);
-                acc[4] += dp * dp;
+                if (r < pin && c < pin) {
+                    acc[0] += om * om;
+                    acc[1] += th * th;
+                    acc[2] += xn * xn;
+                    acc[3] += (om - th) * (om - th);
+                    acc[4] += dp * dp;
+                }
             }
         }
     }
@@ -107,12 +115,13 @@ __global__ __launch_bounds__(EW_THREADS) void k_theta_sgl(double* __restrict__ T
 
 void launch_theta_sgl(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                       const double* OmegaPrev, const double* L, const double* l1K, const double* mask,
-                      const double* invrhoK, int latent, double* partials, int K, int p, const int* skip)
+                      const double* invrhoK, int latent, double* partials, int K, int p, const int* skip, const int* pk,
+                      size_t mask_stride)
 {
     dim3 grid(elementwise_blocks(p), K), blk(EW_THREADS);
 #define GGL_TS(LAT, MSK)                                                                              \
     hipLaunchKernelGGL((k_theta_sgl<LAT, MSK>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1K, \
-                       mask, invrhoK, partials, p, skip)
+                       mask, invrhoK, partials, p, skip, pk, mask_stride)
     if (latent) {
         if (mask) GGL_TS(true, true); else GGL_TS(true, false);
     } else {

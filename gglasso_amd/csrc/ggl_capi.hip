@@ -58,6 +58,10 @@ struct ggl_ctx {
     double* par = nullptr;    // device: beta[K] | l1[K] | mu[K] | nk[K] | 1/rho[K] | X scale[K] | l2[K] | spare
     double* par_h = nullptr;  // pinned mirror
     double *mask = nullptr, *groupsq = nullptr;   // (p,p)
+    double* maskK = nullptr;                      // (K,p,p) per-instance thresholds (ggl_set_lambda1_mask_k), lazy
+    bool has_maskK = false;
+    int* inst_pk = nullptr;                       // (K) instance dimensions of a padded batch of single problems, lazy
+    bool has_dims = false;
     double* sqwork = nullptr;                     // (ggl_chunks, p, p) per-chunk sums of squares
     bool has_mask = false;
     double* partials = nullptr;
@@ -467,8 +471,9 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
                       c->nsT, c->nsNX, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->cuse, c->Lam[0],
                       c->Lam[1], c->X1, c->cwvec[0], c->cwvec[1]};
-    for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize})
+    for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize, c->inst_pk})
         if (b) (void)hipFree(b);
+    if (c->maskK) (void)hipFree(c->maskK);
     for (void* b : {(void*)c->rowpart, (void*)c->fropart, (void*)c->infpart, (void*)c->cwmax, (void*)c->cwcnt})
         if (b) (void)hipFree(b);
     if (c->spec_flag) (void)hipFree(c->spec_flag);
@@ -612,6 +617,33 @@ extern "C" int ggl_set_lambda1_mask(ggl_ctx* c, const double* lam)
     c->has_mask = (lam != nullptr);
     if (lam) {
         HIPCHK(hipMemcpyAsync(c->mask, lam, (size_t)c->p * c->p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return GGL_OK;
+}
+
+extern "C" int ggl_set_lambda1_mask_k(ggl_ctx* c, const double* lam)
+{
+    ARGCHK(c, "ctx");
+    HIPCHK(hipSetDevice(c->device));
+    c->has_maskK = (lam != nullptr);
+    if (lam) {
+        if (!c->maskK) HIPCHK(hipMalloc(&c->maskK, c->n * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(c->maskK, lam, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return GGL_OK;
+}
+
+extern "C" int ggl_set_instance_dims(ggl_ctx* c, const int* pk)
+{
+    ARGCHK(c, "ctx");
+    HIPCHK(hipSetDevice(c->device));
+    c->has_dims = (pk != nullptr);
+    if (pk) {
+        for (int k = 0; k < c->K; ++k) ARGCHK(pk[k] >= 1 && pk[k] <= c->p, "1 <= p_k <= p (the padded dimension of the ctx)");
+        if (!c->inst_pk) HIPCHK(hipMalloc(&c->inst_pk, c->K * sizeof(int)));
+        HIPCHK(hipMemcpyAsync(c->inst_pk, pk, c->K * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     return GGL_OK;
@@ -1453,8 +1485,10 @@ extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* l
     double* Om = c->Om[c->cur];
     double* OmPrev = c->Om[c->cur ^ 1];
     PB(c, GGL_PH_THETA);
+    ARGCHK(!(c->has_dims && latent), "padded instances of different dimension: not with latent variables");
     launch_theta_sgl(c->stream, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, c->par + K,
-                     c->has_mask ? c->mask : nullptr, c->par + 4 * (size_t)K, latent, c->partials, K, c->p);
+                     c->has_maskK ? c->maskK : (c->has_mask ? c->mask : nullptr), c->par + 4 * (size_t)K, latent, c->partials,
+                     K, c->p, nullptr, c->has_dims ? c->inst_pk : nullptr, c->has_maskK ? (size_t)c->p * c->p : 0);
     PE(c, GGL_PH_THETA);
     HIPCHK(hipGetLastError());
     if (latent) {

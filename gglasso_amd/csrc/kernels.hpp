@@ -25,7 +25,8 @@ void launch_form_W(hipStream_t st, double* W, const double* Theta, const double*
 // partials [K][nblk][5].  latent != 0: writes Theta and C = (Theta - X) - Omega.
 void launch_theta_sgl(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                       const double* OmegaPrev, const double* L, const double* l1K,
-                      const double* mask, const double* invrhoK, int latent, double* partials, int K, int p, const int* skip = nullptr);
+                      const double* mask, const double* invrhoK, int latent, double* partials, int K, int p, const int* skip = nullptr,
+                      const int* pk = nullptr, size_t mask_stride = 0);     // pk: sums over the leading (pk[k],pk[k]) blocks only
 // X += (Omega - Theta) + L and the norms partials (latent path, admm_solver.py:208)
 void launch_dual_update(hipStream_t st, double* X, const double* Omega, const double* OmegaPrev,
                         const double* Theta, const double* L, double* partials, int K, int p);

@@ -69,6 +69,21 @@ class HipEngine:
     def set_lambda1_mask(self, lam_pp):
         check(self.lib.ggl_set_lambda1_mask(self.h, ptr(None if lam_pp is None else as_c(lam_pp))))
 
+    def set_lambda1_mask_k(self, lam_Kpp):
+        """One (p,p) threshold array lambda1 * lambda1_mask per instance (K,p,p); None clears it."""
+        check(self.lib.ggl_set_lambda1_mask_k(self.h, ptr(None if lam_Kpp is None else as_c(lam_Kpp))))
+
+    def set_instance_dims(self, pk):
+        """Instances of different dimension in identity-padded slots: the stopping-test sums of ``sgl_batch_step`` run
+        over the leading (pk[k],pk[k]) blocks only; None: all of dimension p."""
+        import ctypes
+        if pk is None:
+            check(self.lib.ggl_set_instance_dims(self.h, None))
+            return
+        pk = np.ascontiguousarray(pk, dtype=np.int32)
+        assert pk.shape == (self.K,)
+        check(self.lib.ggl_set_instance_dims(self.h, pk.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+
     def _cptr(self, a):
         """ctypes pointer of a parameter vector, cached per array object (this sits on the per-iteration path)."""
         if a is None:
@@ -533,6 +548,18 @@ def get_connected_components(S, lambda1):
     return numC, [np.flatnonzero(labels == i) for i in range(numC)]
 
 
+# upper edges of the size classes whose connected components share one padded stack in block_SGL (ratio ~1.5: a component
+# is padded by at most that factor; 128 is the LDS-Jacobi limit, so small components never leave that kernel)
+BLOCK_BUCKETS = (4, 6, 9, 13, 19, 28, 42, 63, 94, 128, 192, 288, 432, 648, 972, 1458, 2187, 3281, 4922, 7383, 11075)
+
+
+def block_bucket(size):
+    for edge in BLOCK_BUCKETS:
+        if size <= edge:
+            return edge
+    return int(size)
+
+
 def block_SGL(S, lambda1, Omega_0, Theta_0=None, X_0=None, rho=1., max_iter=1000, tol=1e-7, rtol=1e-3,
               stopping_criterion="boyd", update_rho=True, verbose=False, measure=False, lambda1_mask=None):
     """The reference's ``block_SGL`` (solver/single_admm_solver.py:326-475; what ``glasso_problem.solve()``
@@ -540,10 +567,13 @@ def block_SGL(S, lambda1, Omega_0, Theta_0=None, X_0=None, rho=1., max_iter=1000
     solve singletons in closed form 1/S_ii and every larger block with ADMM, reassemble.  Returns ``sol`` only,
     like the reference.
 
-    The graph split stays on the host (SciPy).  Blocks of equal size are solved TOGETHER as one batch on the
-    GPU (gglasso_amd.batch.ADMM_SGL_batch: each block keeps its own rho and stopping iteration, so the
-    result equals the reference's block-by-block loop); with a ``lambda1_mask``, the KKT criterion or
-    ``measure`` the blocks go through ``ADMM_SGL`` one by one exactly as in the reference."""
+    The graph split stays on the host (SciPy).  The components are solved TOGETHER on the GPU: every component is the
+    leading block of an identity-padded slot of one stack (gglasso_amd.batch.ADMM_SGL_batch with ``dims``: each component
+    keeps its own rho, residuals over its own block and stopping iteration, its own slice of ``lambda1_mask``, so the
+    result equals the reference's component-by-component loop).  Components of very different size do not share a stack
+    (padding a 5 x 5 block to 900 x 900 would cost more than it saves): sizes are bucketed geometrically (edges
+    ``BLOCK_BUCKETS``, ratio 1.5), one batch per bucket.  With the KKT criterion or ``measure`` the components go through
+    ``ADMM_SGL`` one by one exactly as in the reference."""
     from scipy.linalg import block_diag
     from .batch import ADMM_SGL_batch
     assert Omega_0.shape == S.shape
@@ -565,23 +595,27 @@ def block_SGL(S, lambda1, Omega_0, Theta_0=None, X_0=None, rho=1., max_iter=1000
 
     numC, allC = get_connected_components(S, lambda1 * lambda1_mask)
     sols = [None] * numC
-    by_size = {}
+    by_bucket = {}
     for i, C in enumerate(allC):
         if len(C) == 1:
             v = 1 / S[C, C]                     # off-diagonal penalty: 1/S_ii, not 1/(S_ii + lambda1)
             sols[i] = (v, v, np.array([0]))
         else:
-            by_size.setdefault(len(C), []).append(i)
+            by_bucket.setdefault(block_bucket(len(C)), []).append(i)
 
-    batched = (not has_mask) and stopping_criterion == "boyd" and not measure
-    for size, idx in by_size.items():
+    batched = stopping_criterion == "boyd" and not measure
+    for _, idx in sorted(by_bucket.items()):
         if batched:
+            from .batch import pad_blocks
             ixs = [np.ix_(allC[i], allC[i]) for i in idx]
-            res = ADMM_SGL_batch(np.stack([S[ix] for ix in ixs]), lambda1,
-                                 Omega_0=np.stack([Omega_0[ix] for ix in ixs]),
-                                 Theta_0=np.stack([Theta_0[ix] for ix in ixs]),
-                                 X_0=np.stack([X_0[ix] for ix in ixs]), rho=rho, max_iter=max_iter, tol=tol,
-                                 rtol=rtol, update_rho=update_rho, verbose=verbose)
+            dims = np.array([len(allC[i]) for i in idx])
+            P = int(dims.max())
+            res = ADMM_SGL_batch(pad_blocks([S[ix] for ix in ixs], P, True), lambda1,
+                                 Omega_0=pad_blocks([Omega_0[ix] for ix in ixs], P, True),
+                                 Theta_0=pad_blocks([Theta_0[ix] for ix in ixs], P, True),
+                                 X_0=pad_blocks([X_0[ix] for ix in ixs], P, False), rho=rho, max_iter=max_iter, tol=tol,
+                                 rtol=rtol, update_rho=update_rho, verbose=verbose, dims=dims,
+                                 lambda1_mask=pad_blocks([lambda1_mask[ix] for ix in ixs], P, False) if has_mask else None)
             for i, (bs, binfo) in zip(idx, res):
                 print(f"ADMM terminated after {binfo['iterations']} iterations with status: {binfo['status']}.")
                 sols[i] = (bs['Omega'], bs['Theta'], bs['X'])

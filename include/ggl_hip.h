@@ -211,6 +211,15 @@ int ggl_admm_step_sharded_latent(ggl_ctx *ctx, double rho, double lambda1, doubl
  * iteration it converged). */
 int ggl_sgl_batch_step(ggl_ctx *ctx, const double *rho, const double *lambda1, int latent,
                        const double *mu1, double *out_norms);
+/* The batch as problems of DIFFERENT dimension -- the connected components block_SGL solves one after the other
+ * (single_admm_solver.py:422-459): instance k is the leading (pk[k],pk[k]) block of its (p,p) slot, the caller pads the rest of
+ * S, Omega, Theta with an identity block and X with zeros (a decoupled fixed point of the iteration, as for ggl_ext_*);
+ * ggl_sgl_batch_step's five sums then run over the block only, so every instance stops exactly where its own ADMM_SGL
+ * would.  NULL: all instances have dimension p again.  Not with latent variables.
+ * ggl_set_lambda1_mask_k: one (p,p) threshold array lambda1 * lambda1_mask PER INSTANCE, (K,p,p) (block_SGL hands every
+ * component its own slice of the mask, :447); NULL clears it (the shared mask of ggl_set_lambda1_mask applies again). */
+int ggl_set_instance_dims(ggl_ctx *ctx, const int *pk);
+int ggl_set_lambda1_mask_k(ggl_ctx *ctx, const double *lam_Kpp_host);
 int ggl_scale_X_batch(ggl_ctx *ctx, const double *factor);
 int ggl_get_state_k(ggl_ctx *ctx, int k, double *Omega, double *Theta, double *L, double *X);
 

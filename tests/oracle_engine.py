@@ -23,6 +23,12 @@ class OracleEngine:
     def set_lambda1_mask(self, lam_pp):
         self.mask = lam_pp
 
+    def set_lambda1_mask_k(self, lam_Kpp):
+        self.maskK = lam_Kpp
+
+    def set_instance_dims(self, pk):
+        self.dims = None if pk is None else np.asarray(pk, dtype=int)
+
     def step_omega(self, rho, latent, nk):
         nk = np.ones(self.K) if nk is None else np.asarray(nk, dtype=np.float64)
         W = self.Th - self.L - self.X - (nk[:, None, None] / rho) * self.S
@@ -73,15 +79,21 @@ class OracleEngine:
             W = self.Th[k] - self.L[k] - self.X[k] - (1 / rho[k]) * self.S[k]
             D, Q = np.linalg.eigh(W)
             om = orc.phiplus(1 / rho[k], D, Q)
+            maskK = getattr(self, "maskK", None)
             lam = (1 / rho[k]) * lambda1[k] if self.mask is None else (1 / rho[k]) * self.mask
+            if maskK is not None:
+                lam = (1 / rho[k]) * maskK[k]
             th = orc.prox_od_1norm(om + self.L[k] + self.X[k], lam)
             if latent:
                 C = th - self.X[k] - om
                 D1, Q1 = np.linalg.eigh(C)
                 self.L[k] = orc.prox_rank_norm(C, mu1[k] / rho[k], D1, Q1)
             x = self.X[k] + om - th + self.L[k]
-            out[k] = [np.sum(om ** 2), np.sum((th - self.L[k]) ** 2), np.sum(x ** 2),
-                      np.sum((om - th + self.L[k]) ** 2), np.sum((om - self.Om[k]) ** 2)]
+            dims = getattr(self, "dims", None)
+            q = self.p if dims is None else dims[k]        # padded instance: sums over its own block only
+            b = lambda A: A[:q, :q]
+            out[k] = [np.sum(b(om) ** 2), np.sum(b(th - self.L[k]) ** 2), np.sum(b(x) ** 2),
+                      np.sum(b(om - th + self.L[k]) ** 2), np.sum(b(om - self.Om[k]) ** 2)]
             Om_new[k], self.Th[k], self.X[k] = om, th, x
         self.Om_prev, self.Om = self.Om, Om_new
         return out

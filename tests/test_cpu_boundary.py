@@ -437,3 +437,48 @@ print("ok")
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().split("\n")
     assert lines[-1] == "ok" and lines[0].startswith('{"metric"'), out.stdout     # the child's JSON line is relayed
+
+
+def test_block_sgl_ragged_components_share_padded_batches(oracle_engine):
+    """block_SGL (single_admm_solver.py:326-475) on a covariance whose graph |S| > lambda1 splits into components of
+    MANY different sizes, with and without a lambda1_mask: every component rides in an identity-padded slot of a batch
+    of its size class (gglasso_amd.batch.ADMM_SGL_batch(dims=...)), with residuals, dim and stopping decision over its own
+    block -- the result must be the oracle's component-by-component solve, and the number of engines the number of size
+    classes, not of sizes (host logic + padding; array work: test-only oracle engine)."""
+    from scipy.linalg import block_diag
+    from gglasso_amd import solver, synth
+    rng = np.random.default_rng(12)
+    sizes = [2, 3, 3, 5, 7, 8, 11, 14, 1, 1, 20]
+    blocks = []
+    for q in sizes:
+        A = rng.standard_normal((q, 3 * q))
+        C = A @ A.T / (3 * q) + 0.5 * np.eye(q)
+        blocks.append(C)
+    S = block_diag(*blocks)
+    perm = rng.permutation(S.shape[0])
+    S = S[np.ix_(perm, perm)]
+    p = S.shape[0]
+    lam = 0.02
+    made = []
+
+    class Counting(solver.ENGINE):
+        def __init__(self, S_, *a, **k):
+            super().__init__(S_, *a, **k)
+            made.append(tuple(S_.shape))
+    solver.ENGINE, keep = Counting, solver.ENGINE
+    try:
+        (sol, out) = _quiet(oracle_engine.block_SGL, S, lam, np.eye(p), tol=1e-10, rtol=1e-10)
+        ref = orc.block_SGL(S, lam, np.eye(p), tol=1e-10, rtol=1e-10)
+        for nm in ("Omega", "Theta", "X"):
+            assert np.abs(sol[nm] - ref[nm]).max() <= 1e-10, nm
+        # 9 non-singleton components of 8 distinct sizes in the classes <=4, <=6, <=9, <=13, <=19, <=28: six batches
+        assert len(made) == len({solver.block_bucket(q) for q in sizes if q > 1}) == 6, made
+        assert out.count("ADMM terminated after") == sum(q > 1 for q in sizes)
+        mask = rng.uniform(0.5, 1.5, (p, p))
+        mask = 0.5 * (mask + mask.T)
+        (solm, _) = _quiet(oracle_engine.block_SGL, S, lam, np.eye(p), tol=1e-10, rtol=1e-10, lambda1_mask=mask)
+        refm = orc.block_SGL(S, lam, np.eye(p), tol=1e-10, rtol=1e-10, lambda1_mask=mask)
+        for nm in ("Omega", "Theta", "X"):
+            assert np.abs(solm[nm] - refm[nm]).max() <= 1e-10, nm
+    finally:
+        solver.ENGINE = keep

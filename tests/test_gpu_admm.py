@@ -263,6 +263,36 @@ def test_block_sgl_like_reference_test(sol):
     assert np.abs(out["Theta"] - full["Theta"]).max() <= 1e-3
 
 
+def test_block_sgl_ragged_components_in_padded_batches(sol):
+    """Components of many different sizes -- below and above the LDS-Jacobi limit (p <= 128), so that both the Jacobi and
+    the Newton-Schulz Omega-step see identity-padded slots -- each in the padded batch of its size class, with and without
+    a lambda1_mask (one mask slice per instance, ggl_set_lambda1_mask_k): must equal the oracle's component-by-component
+    loop (single_admm_solver.py:422-459), every component with its own iteration count."""
+    from scipy.linalg import block_diag
+    rng = np.random.default_rng(12)
+    sizes = [2, 3, 3, 5, 8, 11, 14, 1, 30, 36, 40, 150, 170, 1]
+    blocks = []
+    for q in sizes:
+        A = rng.standard_normal((q, 3 * q))
+        blocks.append(A @ A.T / (3 * q) + 0.5 * np.eye(q))
+    S = block_diag(*blocks)
+    perm = rng.permutation(S.shape[0])
+    S = S[np.ix_(perm, perm)]
+    p = S.shape[0]
+    lam = 0.02
+    (out, text) = quiet(sol.block_SGL, S, lam, np.eye(p), tol=1e-9, rtol=1e-9)
+    ref = orc.block_SGL(S, lam, np.eye(p), tol=1e-9, rtol=1e-9)
+    for nm in ("Omega", "Theta", "X"):
+        assert np.abs(out[nm] - ref[nm]).max() <= 1e-9, nm
+    assert text.count("ADMM terminated after") == sum(q > 1 for q in sizes)
+    mask = rng.uniform(0.5, 1.5, (p, p))
+    mask = 0.5 * (mask + mask.T)
+    (outm, _) = quiet(sol.block_SGL, S, lam, np.eye(p), tol=1e-9, rtol=1e-9, lambda1_mask=mask)
+    refm = orc.block_SGL(S, lam, np.eye(p), tol=1e-9, rtol=1e-9, lambda1_mask=mask)
+    for nm in ("Omega", "Theta", "X"):
+        assert np.abs(outm[nm] - refm[nm]).max() <= 1e-9, nm
+
+
 # ---- K-sharded driver on the real RCCL backend (single rank: exercises the device all-reduce path) -----------
 
 def test_sharded_driver_on_rccl_single_rank(sol):
