@@ -76,6 +76,8 @@ _SIGNATURES = {
     "ggl_ext_get_state": ([_vp, _dp, _dp], _i),
     "ggl_ext_admm_step": ([_vp, _d, _dp, _d, _i, _dp, _dp], _i),
     "ggl_ext_kkt_residual": ([_vp, _d, _dp, _d, _i, _dp, _dp], _i),
+    "ggl_ext_setup_batch": ([_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), _i], _i),
+    "ggl_ext_batch_step": ([_vp, _d, _dp, _dp, _i, _dp, _dp], _i),
     "ggl_objective": ([_vp, _d, _d, _i, _dp], _i),
     "ggl_kkt_residual": ([_vp, _d, _d, _d, _i, _i, _dp, _dp, _dp], _i),
     "ggl_profile_enable": ([_vp, _i], _i),

@@ -95,14 +95,18 @@ void launch_ext_theta(hipStream_t st, double* Theta, double* X0, double* Znew, d
 // Gt: [2][K][L] (instance-major, groups contiguous: neighbouring threads read neighbouring words); -1 = the instance does
 // not hold the pair.  gsize[l] = instances that do.  One thread per group; the listed entries are distinct over the
 // whole array (checked on the host), so the groups are independent.
+// blockIdx.y: problem g of a batch of independent problems with the SAME group structure (a model-selection grid): its K
+// instances are the slots g*K .. of the stack, its threshold l2K[g*K] (one value per instance slot, equal within a problem)
 __global__ __launch_bounds__(256) void k_ext_group(double* __restrict__ Lam, const int* __restrict__ Gt,
-                                                   const int* __restrict__ gsize, double l2, int L, int K, int p,
-                                                   const int* __restrict__ skip)
+                                                   const int* __restrict__ gsize, const double* __restrict__ l2K, int L, int K,
+                                                   int p, const int* __restrict__ skip)
 {
     if (spec_failed(skip)) return;
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= L) return;
     const size_t pp = (size_t)p * p;
+    Lam += (size_t)blockIdx.y * K * pp;
+    const double l2 = l2K[(size_t)blockIdx.y * K];
     const int* gi = Gt + l;
     const int* gj = Gt + (size_t)K * L + l;
     double ss = 0.0;
@@ -126,11 +130,11 @@ __global__ __launch_bounds__(256) void k_ext_group(double* __restrict__ Lam, con
     }
 }
 
-void launch_ext_group(hipStream_t st, double* Lam, const int* Gt, const int* gsize, double l2, int L, int K, int p,
-                      const int* skip)
+void launch_ext_group(hipStream_t st, double* Lam, const int* Gt, const int* gsize, const double* l2K, int L, int K, int p,
+                      const int* skip, int nprob)
 {
     if (L <= 0) return;
-    hipLaunchKernelGGL(k_ext_group, dim3((L + 255) / 256), dim3(256), 0, st, Lam, Gt, gsize, l2, L, K, p, skip);
+    hipLaunchKernelGGL(k_ext_group, dim3((L + 255) / 256, nprob), dim3(256), 0, st, Lam, Gt, gsize, l2K, L, K, p, skip);
 }
 
 template <bool LATENT>

@@ -135,6 +135,7 @@ struct ggl_ctx {
     int lcur = 0;
     int *ext_pk = nullptr, *ext_Gt = nullptr, *ext_gsize = nullptr;   // p_k [K]; G transposed [2][K][L]; group sizes [L]
     int ext_L = -1;                            // -1: ggl_ext_setup not called
+    int ext_nprob = 1;                         // independent problems in the stack (ggl_ext_setup_batch), K / ext_nprob instances each
     double* snapT = nullptr;                   // per-instance snapshots of Theta (model selection), lazy
     double* nbrow = nullptr;                   // [K][p] row abs-sums of B' (Collatz-Wielandt weight vector)
     // the Collatz-Wielandt vector carried across iterations (k_cw_final): [cw_cur] was left behind by the last ACCEPTED
@@ -2057,13 +2058,31 @@ extern "C" int ggl_admm_step_sharded(ggl_ctx* c, double rho, double lambda1, dou
 // ---------------------------------------------------------------------------------------------
 // ext_ADMM_MGL: instances of different dimension (solver/ext_admm_solver.py:18-323), csrc/ext_group.hip
 // ---------------------------------------------------------------------------------------------
+static int ext_setup_impl(ggl_ctx* c, int nprob, const int* pk, const int* G, int L);
+
 extern "C" int ggl_ext_setup(ggl_ctx* c, const int* pk, const int* G, int L)
 {
-    ARGCHK(c && pk, "ctx, pk");
+    ARGCHK(c, "ctx");
+    return ext_setup_impl(c, 1, pk, G, L);
+}
+
+extern "C" int ggl_ext_setup_batch(ggl_ctx* c, int nprob, const int* pk, const int* G, int L)
+{
+    ARGCHK(c, "ctx");
+    ARGCHK(nprob >= 1 && c->K % nprob == 0, "the ctx holds nprob problems of K/nprob instances each");
+    return ext_setup_impl(c, nprob, pk, G, L);
+}
+
+static int ext_setup_impl(ggl_ctx* c, int nprob, const int* pk_all, const int* G, int L)
+{
+    // nprob > 1: the stack holds nprob independent problems with the same instance dimensions and the same bookkeeping array
+    // G (a model-selection grid); pk_all lists the dimensions of ONE problem's instances, G covers those instances
+    ARGCHK(c && pk_all, "ctx, pk");
     ARGCHK(L >= 0 && (L == 0 || G), "G, L");
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
-    const int K = c->K, p = c->p;
+    const int Ktot = c->K, K = Ktot / nprob, p = c->p;
+    const int* pk = pk_all;
     for (int k = 0; k < K; ++k) ARGCHK(pk[k] >= 1 && pk[k] <= p, "1 <= p_k <= p (the padded dimension of the ctx)");
     // the checks of helper/ext_admm_helper.py:82-102 (check_G) plus: no entry listed twice (the groups are then
     // independent, which is what lets them run in parallel; the reference processes them one after the other)
@@ -2092,10 +2111,12 @@ extern "C" int ggl_ext_setup(ggl_ctx* c, const int* pk, const int* G, int L)
     for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize})
         if (b) (void)hipFree(b);
     c->ext_pk = c->ext_Gt = c->ext_gsize = nullptr;
-    HIPCHK(hipMalloc(&c->ext_pk, K * sizeof(int)));
+    std::vector<int> pkrep((size_t)Ktot);
+    for (int k = 0; k < Ktot; ++k) pkrep[k] = pk[k % K];
+    HIPCHK(hipMalloc(&c->ext_pk, Ktot * sizeof(int)));
     HIPCHK(hipMalloc(&c->ext_Gt, Gt.size() * sizeof(int)));
     HIPCHK(hipMalloc(&c->ext_gsize, gs.size() * sizeof(int)));
-    HIPCHK(hipMemcpyAsync(c->ext_pk, pk, K * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->ext_pk, pkrep.data(), Ktot * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->ext_Gt, Gt.data(), Gt.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->ext_gsize, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     const size_t nb = c->n * sizeof(double);
@@ -2103,12 +2124,13 @@ extern "C" int ggl_ext_setup(ggl_ctx* c, const int* pk, const int* G, int L)
         for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->Lam[i], nb));
         HIPCHK(hipMalloc(&c->X1, nb));
         // the ext kernels write GGL_NNORM sums per (instance, chunk) twice per iteration
-        int rcp = ensure_partials(c, 2 * (size_t)K * ext_blocks(p) * GGL_NNORM);
+        int rcp = ensure_partials(c, 2 * (size_t)Ktot * ext_blocks(p) * GGL_NNORM);
         if (rcp) return rcp;
     }
     HIPCHK(hipMemsetAsync(c->X1, 0, nb, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));      // Gt / gs are host temporaries
+    HIPCHK(hipStreamSynchronize(c->stream));      // Gt / gs / pkrep are host temporaries
     c->ext_L = L;
+    c->ext_nprob = nprob;
     c->lcur = 0;
     c->spec_have = false;
     return GGL_OK;
@@ -2140,10 +2162,11 @@ extern "C" int ggl_ext_get_state(ggl_ctx* c, double* Lambda, double* X1)
 }
 
 // everything of one iteration after the Omega-step
-static int ext_finish(ggl_ctx* c, double rho, const double* lambda1K, double lambda2, int latent, const double* mu1,
-                      double out_norms[5])
+static int ext_finish(ggl_ctx* c, double rho, const double* lambda1K, const double* lambda2G, int latent, const double* mu1,
+                      double* out_norms)
 {
-    const int K = c->K, p = c->p;
+    // lambda2G: one value per problem (ext_nprob of them); out_norms: (ext_nprob, 5)
+    const int K = c->K, p = c->p, nprob = c->ext_nprob, Kp = K / nprob;
     double* Om = c->Om[c->cur];
     double* OmPrev = c->Om[c->cur ^ 1];
     double* LamOld = c->Lam[c->lcur];
@@ -2151,6 +2174,13 @@ static int ext_finish(ggl_ctx* c, double rho, const double* lambda1K, double lam
     const int* skip = c->spec_pending ? c->spec_flag : nullptr;
     int rc = upload_par(c, 1, lambda1K, 0.0, 2.0 * rho);      // lambda1_k / (2 rho)     (ext_admm_solver.py:210)
     if (rc) return rc;
+    {   // lambda2 / rho of every instance slot's problem (:225)
+        double* h = c->par_h + 6 * (size_t)K;
+        for (int k = 0; k < K; ++k) h[k] = lambda2G[k / Kp] / rho;
+        CopySegs sg;
+        sg.add(c->par + 6 * (size_t)K, h, (size_t)K * sizeof(double));
+        launch_copy_small(c->stream, sg);
+    }
     const int nblk = ext_blocks(p);
     double* partA = c->partials;
     double* partB = c->partials + (size_t)K * nblk * GGL_NNORM;
@@ -2166,18 +2196,31 @@ static int ext_finish(ggl_ctx* c, double rho, const double* lambda1K, double lam
         if (rc) return rc;
     }
     PB(c, GGL_PH_DUAL);
-    launch_ext_group(c->stream, LamNew, c->ext_Gt, c->ext_gsize, lambda2 / rho, c->ext_L, K, p, skip);   // :225
+    launch_ext_group(c->stream, LamNew, c->ext_Gt, c->ext_gsize, c->par + 6 * (size_t)K, c->ext_L, Kp, p, skip, nprob);   // :225
     launch_ext_dual(c->stream, c->X, c->X1, Om, OmPrev, c->Theta, c->L, LamNew, LamOld, c->ext_pk, latent,
                     latent ? partA : partB, K, p, skip);
     PE(c, GGL_PH_DUAL);
     PB(c, GGL_PH_REDUCE);
     c->norms_host = true;
-    if (c->seq_h && c->spin_wait) c->seq_wait = ++c->seq_next;
-    launch_reduce_partials(c->stream, c->partials, 1, (latent ? 1 : 2) * K * nblk, GGL_NNORM, c->norms_h,
-                           c->seq_wait ? c->seq_h : nullptr, c->seq_wait);
-    PE(c, GGL_PH_REDUCE);
-    HIPCHK(hipGetLastError());
-    rc = finish_norms(c, 1, out_norms);
+    if (nprob == 1) {
+        if (c->seq_h && c->spin_wait) c->seq_wait = ++c->seq_next;
+        launch_reduce_partials(c->stream, c->partials, 1, (latent ? 1 : 2) * K * nblk, GGL_NNORM, c->norms_h,
+                               c->seq_wait ? c->seq_h : nullptr, c->seq_wait);
+        PE(c, GGL_PH_REDUCE);
+        HIPCHK(hipGetLastError());
+        rc = finish_norms(c, 1, out_norms);
+    } else {
+        // per problem: the rows of its Kp instances in the Theta-step's partials and (not latent) in the dual update's
+        launch_reduce_partials(c->stream, partA, nprob, Kp * nblk, GGL_NNORM, c->norms_h);
+        if (!latent) launch_reduce_partials(c->stream, partB, nprob, Kp * nblk, GGL_NNORM, c->norms_h + (size_t)nprob * GGL_NNORM);
+        PE(c, GGL_PH_REDUCE);
+        HIPCHK(hipGetLastError());
+        std::vector<double> tmp((size_t)2 * nprob * GGL_NNORM, 0.0);
+        rc = finish_norms(c, (latent ? 1 : 2) * nprob, tmp.data(), 1);
+        for (int g = 0; rc == GGL_OK && g < nprob; ++g)
+            for (int v = 0; v < GGL_NNORM; ++v)
+                out_norms[(size_t)g * GGL_NNORM + v] = tmp[(size_t)g * GGL_NNORM + v] + (latent ? 0.0 : tmp[(size_t)(nprob + g) * GGL_NNORM + v]);
+    }
     if (rc == GGL_OK) c->lcur ^= 1;        // a rejected speculative step leaves Lambda where it was
     return rc;
 }
@@ -2186,8 +2229,18 @@ extern "C" int ggl_ext_admm_step(ggl_ctx* c, double rho, const double* lambda1K,
                                  const double* mu1, double out_norms[5])
 {
     ARGCHK(c && lambda1K && out_norms, "ctx, lambda1, out_norms");
-    ARGCHK(c->ext_L >= 0, "ggl_ext_setup first");
+    ARGCHK(c->ext_L >= 0 && c->ext_nprob == 1, "ggl_ext_setup first");
     ARGCHK(rho > 0 && lambda2 > 0, "rho, lambda2 must be positive");
+    return ggl_ext_batch_step(c, rho, lambda1K, &lambda2, latent, mu1, out_norms);
+}
+
+extern "C" int ggl_ext_batch_step(ggl_ctx* c, double rho, const double* lambda1K, const double* lambda2G, int latent,
+                                  const double* mu1, double* out_norms)
+{
+    ARGCHK(c && lambda1K && lambda2G && out_norms, "ctx, lambda1, lambda2, out_norms");
+    ARGCHK(c->ext_L >= 0, "ggl_ext_setup / ggl_ext_setup_batch first");
+    ARGCHK(rho > 0, "rho must be positive");
+    for (int g = 0; g < c->ext_nprob; ++g) ARGCHK(lambda2G[g] > 0, "lambda2 must be positive");
     ARGCHK(!latent || mu1, "latent needs mu1");
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
@@ -2196,11 +2249,11 @@ extern "C" int ggl_ext_admm_step(ggl_ctx* c, double rho, const double* lambda1K,
     if (rc) return rc;
     rc = omega_step(c, latent, &sg, /*allow_spec=*/true);
     if (rc) return rc;
-    rc = ext_finish(c, rho, lambda1K, lambda2, latent, mu1, out_norms);
+    rc = ext_finish(c, rho, lambda1K, lambda2G, latent, mu1, out_norms);
     if (rc != GGL_SPEC_RETRY) return rc;
     rc = omega_step(c, latent, nullptr, false);
     if (rc) return rc;
-    return ext_finish(c, rho, lambda1K, lambda2, latent, mu1, out_norms);
+    return ext_finish(c, rho, lambda1K, lambda2G, latent, mu1, out_norms);
 }
 
 // out[k] = sum over the leading (p_k,p_k) block of ((A - B) + C)^2
@@ -2263,7 +2316,8 @@ extern "C" int ggl_ext_kkt_residual(ggl_ctx* c, double rho, const double* lambda
     }
     // term4: prox_2norm_G(Lambda + rho X1, G, lambda2) - Lambda
     launch_lin3(c->stream, T1, 1.0, Lam, rho, c->X1, 0.0, nullptr, c->n);
-    launch_ext_group(c->stream, T1, c->ext_Gt, c->ext_gsize, lambda2, c->ext_L, K, c->p, nullptr);
+    if ((rc = upload_par(c, 6, nullptr, lambda2, 1.0))) return rc;      // the group shrink reads its threshold per instance slot
+    launch_ext_group(c->stream, T1, c->ext_Gt, c->ext_gsize, c->par + 6 * (size_t)K, c->ext_L, K, c->p, nullptr);
     if ((rc = ext_sq_k(c, T1, Lam, nullptr, v.data()))) return rc;
     add(3, nLam);
     // term5 / term6: the two equality constraints

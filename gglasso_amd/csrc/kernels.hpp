@@ -122,8 +122,10 @@ void launch_ext_theta(hipStream_t st, double* Theta, double* X0, double* Znew, d
                       const double* OmegaPrev, const double* L, const double* Lambda, const double* X1, const double* l1K,
                       const int* pk, int latent, double* partials, int K, int p, const int* skip);
 // prox_2norm_G in place on Lam (holding Z): Gt [2][K][L] int32 (-1 = pair absent), gsize [L]
-void launch_ext_group(hipStream_t st, double* Lam, const int* Gt, const int* gsize, double l2, int L, int K, int p,
-                      const int* skip);
+// nprob independent problems of K instances each with the same group structure (stack slots g*K ..); l2K: device, one
+// threshold per instance slot (lambda2/rho of the slot's problem)
+void launch_ext_group(hipStream_t st, double* Lam, const int* Gt, const int* gsize, const double* l2K, int L, int K, int p,
+                      const int* skip, int nprob = 1);
 // X1 += Theta - Lambda [latent: X0 += Omega - Theta + L] and the remaining stopping-test sums
 void launch_ext_dual(hipStream_t st, double* X0, double* X1, const double* Omega, const double* OmegaPrev,
                      const double* Theta, const double* L, const double* Lam, const double* LamPrev, const int* pk,

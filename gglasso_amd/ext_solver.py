@@ -148,3 +148,85 @@ def ext_ADMM_MGL(S, lambda1, lambda2, reg, Omega_0, G, X0=None, X1=None, tol=1e-
     else:
         info = {'status': status}
     return sol, info
+
+
+def ext_ADMM_MGL_batch(S, lambda1, lambda2, reg, G, tol=1e-5, rtol=1e-4, rho=1., max_iter=1000, latent=False, mu1=None,
+                       verbose=False):
+    """``ext_ADMM_MGL(S, lambda1[g], lambda2[g], reg, Omega_0 = identity, G, ...)`` for every g of the 1-D arrays
+    ``lambda1`` / ``lambda2`` at once -- the grid points the MAIN LOOP of the reference's ``grid_search``
+    (helper/model_selection.py:208-224) hands to ``ext_ADMM_MGL`` one after the other.  The points are independent
+    problems on the same data and the same bookkeeping array G: they live as the slabs of ONE padded (ngrid*K, P, P)
+    stack, one batched Omega-step (and L-step) over all ngrid*K matrices, one Theta-step, one group shrink (with a
+    grid-point dimension) and one dual update per iteration.  The solver has no rho update (ext_admm_solver.py), so all
+    points share rho; every point keeps its own residuals and stopping iteration and is snapshotted when it converges
+    (it keeps iterating harmlessly until the batch is done).  lambda1[g]: scalar or (K,); mu1: (K,) shared or (ngrid,K).
+    Returns a list of ``(sol, info)`` as ``ext_ADMM_MGL`` (Boyd criterion), ``info`` with 'iterations' added."""
+    K = len(S.keys())
+    p = np.array([S[k].shape[0] for k in range(K)], dtype=int)
+    lam2 = as_c(np.atleast_1d(lambda2)).reshape(-1)
+    ng = len(lam2)
+    lam1 = np.stack([np.broadcast_to(np.asarray(l, dtype=np.float64), (K,)) for l in lambda1]) if not np.isscalar(lambda1) \
+        else np.full((ng, K), float(lambda1))
+    assert lam1.shape == (ng, K)
+    assert min(lam1.min(), lam2.min()) > 0
+    assert reg in ['GGL']
+    check_G(G, p)
+    assert rho > 0, "ADMM penalization parameter must be positive."
+    if latent:
+        assert mu1 is not None
+        mu = np.asarray(mu1, dtype=np.float64)
+        if mu.ndim == 0:
+            mu = mu * np.ones(K)
+        mu = as_c(np.broadcast_to(mu, (ng, K))).reshape(-1)
+        assert np.all(mu > 0)
+    else:
+        mu = None
+    P = int(p.max())
+    Sp = _pad(S, K, p, P, True)
+    Om0 = _pad({k: np.eye(p[k]) for k in range(K)}, K, p, P, True)
+    rep = lambda A: as_c(np.broadcast_to(A, (ng,) + A.shape)).reshape(ng * K, P, P)
+    eng = _solver.ENGINE(rep(Sp), rep(Om0), rep(Om0), np.zeros((ng * K, P, P)))
+    try:
+        eng.ext_setup_batch(ng, p, G)
+        eng.ext_set_state(rep(Om0), None)
+        dim = ((p ** 2 + p) / 2).sum()
+        rho = float(rho)
+        lam1f = as_c(lam1.reshape(-1))
+        done = np.zeros(ng, dtype=bool)
+        results = [None] * ng
+        last = [None] * ng
+
+        def collect(g, status, iters):
+            parts = [eng.state_k(g * K + k, True) for k in range(K)]
+            xs = eng.ext_state()
+            cut = lambda A, k: np.ascontiguousarray(A[:p[k], :p[k]])
+            sol = {'Omega': {k: cut(parts[k]['Omega'], k) for k in range(K)},
+                   'Theta': {k: cut(parts[k]['Theta'], k) for k in range(K)},
+                   'L': {k: cut(parts[k]['L'], k) for k in range(K)},
+                   'X0': {k: cut(parts[k]['X'], k) for k in range(K)},
+                   'X1': {k: cut(xs['X1'][g * K + k], k) for k in range(K)}}
+            results[g] = (sol, {'status': status, 'iterations': iters})
+
+        for it in range(max_iter):
+            sq = eng.ext_batch_step(ng, rho, lam1f, lam2, bool(latent), mu)
+            for g in range(ng):
+                if done[g]:
+                    continue
+                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[g], rho, tol, rtol, dim)
+                last[g] = (r_t, s_t, e_pri, e_dual)
+                if verbose:
+                    print("%4d\t%3d\t%10.4g\t%10.4g\t%10.4g\t%10.4g" % (it, g, r_t, s_t, e_pri, e_dual))
+                if (r_t <= e_pri) and (s_t <= e_dual):
+                    done[g] = True
+                    collect(g, 'optimal', it + 1)
+            if done.all():
+                break
+        for g in range(ng):
+            if results[g] is None:
+                r_t, s_t, e_pri, e_dual = last[g]
+                status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
+                                                                else 'max iterations reached')
+                collect(g, status, max_iter)
+    finally:
+        eng.close()
+    return results

@@ -397,8 +397,10 @@ def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma
     previous point (:208-224); the optimum of a point does not depend on its start, so tables and selection agree
     to the solver tolerance.  ``group``: a torch.distributed process group -- the grid points are dealt round-robin
     over its ranks (``gglasso_amd.dist.shard_grid``; replicas only, results gathered on every rank).
-    Any other solver callable (``ext_ADMM_MGL`` with dict S and G, the reference's own solvers) and ``batched=False``
-    take the reference's sequential warm-started walk with that callable.  ``thresholding`` tunes a thresholded
+    ``solver`` = ``gglasso_amd.ext_ADMM_MGL`` with dict S and G (instances of different dimension) is batched the same way
+    (``gglasso_amd.ext_solver.ext_ADMM_MGL_batch``; the criteria then come from the host, per instance dimension).
+    Any other solver callable (the reference's own solvers) and ``batched=False`` take the reference's sequential
+    warm-started walk with that callable.  ``thresholding`` tunes a thresholded
     estimator per grid point on the host (tune_multiple_threshold, :739-765) in either mode."""
     from .solver import ADMM_MGL
     assert method in ['AIC', 'eBIC']
@@ -424,6 +426,11 @@ def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma
     SP = np.nan * np.zeros((grid1, grid2))
     RANK = np.nan * np.zeros((K, grid1, grid2))
     TAU = np.zeros((K, grid1, grid2)) if thresholding else None
+    from .ext_solver import ext_ADMM_MGL as _ext_solver
+    ext_batched = (batched is None or batched) and (solver is _ext_solver) and isinstance(S, dict) and reg == 'GGL' \
+        and G is not None and group is None
+    if ext_batched:
+        batched = False
     if batched is None:
         # both penalties fall back to the sequential walk beyond what their batched Theta kernel takes (the library
         # exports the limits; ADVICE r2: FGL used to surface the limit as an AssertionError instead)
@@ -457,8 +464,19 @@ def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma
         for i, (sol, info) in local:
             sols[order[i]] = sol
             dev[order[i]] = info['selection']
+    elif ext_batched:
+        from .ext_solver import ext_ADMM_MGL_batch
+        pmax = max(S[k].shape[0] for k in range(K))
+        per_batch = max(1, int(max_batch_bytes // (17 * K * pmax * pmax * 8)))
+        for b0 in range(0, len(order), per_batch):
+            idx = order[b0:b0 + per_batch]
+            lam1 = [L1[g] for g in idx]
+            lam2 = np.array([L2[g] for g in idx])
+            mu = np.stack([mu_range[ix_mu[:, g[1]]] for g in idx]) if latent else None
+            res = ext_ADMM_MGL_batch(S, lam1, lam2, reg, G, tol=tol, rtol=rtol, latent=latent, mu1=mu)
+            for g, (sol, info) in zip(idx, res):
+                sols[g] = sol
     else:
-        from .ext_solver import ext_ADMM_MGL   # noqa: F401  (documented alternative solver callable)
         kwargs = {'reg': reg, 'S': S, 'tol': tol, 'rtol': rtol, 'verbose': False, 'measure': False}
         if isinstance(S, dict):
             kwargs['Omega_0'] = {k: np.eye(S[k].shape[0]) for k in range(K)}      # id_dict, ext_admm_helper.py:9-16

@@ -227,6 +227,30 @@ class HipEngine:
         ip = ctypes.POINTER(ctypes.c_int)
         check(self.lib.ggl_ext_setup(self.h, pk.ctypes.data_as(ip), G.ctypes.data_as(ip), int(G.shape[1])))
 
+    def ext_setup_batch(self, nprob, pk, G):
+        """nprob problems of K/nprob instances each with the dimensions pk and the bookkeeping array G of ONE problem."""
+        import ctypes
+        pk = np.ascontiguousarray(pk, dtype=np.int32)
+        G = np.ascontiguousarray(G, dtype=np.int32)
+        assert self.K % int(nprob) == 0 and G.ndim == 3 and G.shape[0] == 2 and G.shape[2] == self.K // int(nprob)
+        ip = ctypes.POINTER(ctypes.c_int)
+        check(self.lib.ggl_ext_setup_batch(self.h, int(nprob), pk.ctypes.data_as(ip), G.ctypes.data_as(ip), int(G.shape[1])))
+
+    def ext_batch_step(self, nprob, rho, lambda1K, lambda2G, latent, mu1):
+        """One iteration of all problems; returns the (nprob,5) sums."""
+        out = np.zeros((int(nprob), 5))
+        rc = self.lib.ggl_ext_batch_step(self.h, rho, ptr(as_c(lambda1K)), ptr(as_c(lambda2G)), int(latent),
+                                         ptr(None if mu1 is None else as_c(mu1)), ptr(out))
+        if rc > 0:
+            raise RuntimeError(f"ggl_ext_batch_step: unexpected return code {rc} (speculative step rejected twice)")
+        check(rc)
+        return out
+
+    def ext_state_k(self, k):
+        """Lambda and X1 of one instance slot (snapshot of a converged problem of a batch)."""
+        st = self.ext_state()          # (the ext state has no per-slot download; batches are small)
+        return {'Lambda': st['Lambda'][k], 'X1': st['X1'][k]}
+
     def ext_set_state(self, Lambda, X1):
         check(self.lib.ggl_ext_set_state(self.h, ptr(as_c(Lambda)), ptr(None if X1 is None else as_c(X1))))
 

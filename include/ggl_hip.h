@@ -268,6 +268,16 @@ int ggl_ext_admm_step(ggl_ctx *ctx, double rho, const double *lambda1K, double l
                       const double *mu1, double out_norms[5]);
 int ggl_ext_kkt_residual(ggl_ctx *ctx, double rho, const double *lambda1K, double lambda2, int latent,
                          const double *mu1, double *out);
+/* nprob independent ext_ADMM_MGL problems with the SAME instance dimensions and bookkeeping array in one ctx -- the
+ * (lambda1, lambda2) points the MAIN LOOP of grid_search (helper/model_selection.py:208-224) hands to ext_ADMM_MGL one after
+ * the other: the ctx stack holds nprob * K instances, problem g in the slots g*K .. (the caller replicates the padded S).
+ *   ggl_ext_setup_batch  pk (K) and G (2,L,K) of ONE problem
+ *   ggl_ext_batch_step   one iteration of all problems: lambda1 (nprob*K) per instance slot, lambda2 (nprob) per problem, one
+ *                        rho (this solver has no rho update), mu1 (nprob*K); out_norms (nprob,5): the five sums per problem.
+ * The caller keeps the stopping decision per problem (ggl_get_state_k / ggl_ext_get_state per instance slot). */
+int ggl_ext_setup_batch(ggl_ctx *ctx, int nprob, const int *pk, const int *G, int L);
+int ggl_ext_batch_step(ggl_ctx *ctx, double rho, const double *lambda1K, const double *lambda2G, int latent,
+                       const double *mu1, double *out_norms);
 
 /* Model selection over a batch of independent problems (reference: single_grid_search,
  * helper/model_selection.py:505-692; criteria :812-856; robust_logdet :884-894).

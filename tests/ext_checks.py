@@ -100,3 +100,43 @@ def check_g15(load_golden, ext_ADMM_MGL, latent):
         Ls = np.stack([sol['L'][k] for k in range(K)])
         assert np.abs(Ls - g[f"{tag}_ext_L"]).max() <= 1e-7
         assert np.abs(Ls - g[f"{tag}_mgl_L"]).max() <= 1e-2
+
+
+def check_ext_batch(load_golden, ext_ADMM_MGL, ext_ADMM_MGL_batch, grid_search, latent):
+    """ext_ADMM_MGL_batch: a 3 x 2 grid of (lambda1, lambda2) points of the non-conforming fixture problem (G14's S and G) as
+    ONE batch -- every point must end where its own ext_ADMM_MGL call from the identity start ends (same status, same
+    iteration count, same solution), and grid_search(solver=ext_ADMM_MGL, S dict, G) built on it must select what the
+    reference's sequential warm-started walk with the same solver selects (helper/model_selection.py:208-224)."""
+    g = load_golden("g14_ext_admm_nonconforming")
+    K, p, S, G, Om0 = g14_inputs(g)
+    l1s, l2s = [0.2, 0.08, 0.03], [0.1, 0.02]
+    pts = [(a, b) for b in l2s for a in l1s]
+    mu1 = 0.3 * np.ones(K) if latent else None
+    res, _ = quiet(ext_ADMM_MGL_batch, S, [a for a, _ in pts], [b for _, b in pts], 'GGL', G, tol=1e-8, rtol=1e-8,
+                   latent=latent, mu1=mu1)
+    assert len(res) == len(pts)
+    for (a, b), (sol, info) in zip(pts, res):
+        (ref, rinfo), _ = quiet(ext_ADMM_MGL, S, a, b, 'GGL', {k: v.copy() for k, v in Om0.items()}, G, tol=1e-8, rtol=1e-8,
+                                latent=latent, mu1=mu1, measure=True)
+        assert info['status'] == rinfo['status'], (a, b)
+        assert info['iterations'] == len(rinfo['residual']), (a, b, info['iterations'], len(rinfo['residual']))
+        for nm in NAMES:
+            for k in range(K):
+                assert sol[nm][k].shape == ref[nm][k].shape
+                assert np.abs(sol[nm][k] - ref[nm][k]).max() <= 1e-9, (a, b, nm, k)
+    if grid_search is None:
+        return
+    N = 50 * np.ones(K)
+    kw = dict(l1=np.array(l1s), l2=np.array(l2s), method='eBIC', gamma=0.3, G=G, tol=1e-8, rtol=1e-8)
+    (stats_b, ix_b, best_b), _ = quiet(grid_search, ext_ADMM_MGL, S, N, p, 'GGL', **kw)
+    (stats_s, ix_s, best_s), _ = quiet(grid_search, ext_ADMM_MGL, S, N, p, 'GGL', batched=False, **kw)
+    # same selection, same selected estimate; the tables agree where the edge COUNT agrees (count_nonzero of an estimate
+    # solved to 1e-8 from another start can differ by a few entries that sit at the threshold -- the reference's own table
+    # depends on its warm-start order in the same way)
+    assert tuple(ix_b) == tuple(ix_s)
+    same_edges = np.isclose(stats_b['SP'], stats_s['SP'], atol=1e-12)
+    assert same_edges.sum() >= same_edges.size - 2
+    assert np.allclose(stats_b['BIC'][0.3][same_edges], stats_s['BIC'][0.3][same_edges], rtol=1e-6, atol=1e-4)
+    assert np.allclose(stats_b['BIC'][0.3], stats_s['BIC'][0.3], rtol=5e-2)
+    for k in range(K):
+        assert np.abs(best_b["Theta"][k] - best_s["Theta"][k]).max() <= 1e-4      # two solves to dim*tol ~ 5e-6 from different starts

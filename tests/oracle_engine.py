@@ -172,6 +172,32 @@ class OracleEngine:
         self.Lam = None
         self.X1 = np.zeros_like(self.S)
 
+    def ext_setup_batch(self, nprob, pk, G):
+        self.nprob = int(nprob)
+        self.pk = np.tile(np.asarray(pk, dtype=int), self.nprob)
+        self.G = np.asarray(G, dtype=int)
+        self.Lam = None
+        self.X1 = np.zeros_like(self.S)
+
+    def ext_batch_step(self, nprob, rho, lambda1K, lambda2G, latent, mu1):
+        # problem by problem with the single-problem step on views of the slots (the products must agree with this)
+        Kp = self.K // int(nprob)
+        out = np.zeros((int(nprob), 5))
+        full = (self.S, self.Om, self.Om_prev, self.Th, self.X, self.L, self.Lam, self.X1, self.pk, self.K)
+        new = {nm: np.empty_like(self.S) for nm in ("Om", "Om_prev", "Th", "X", "L", "Lam", "X1")}
+        for g in range(int(nprob)):
+            sl = slice(g * Kp, (g + 1) * Kp)
+            self.S, self.Om, self.Om_prev, self.Th, self.X, self.L, self.Lam, self.X1 = (A[sl].copy() for A in full[:8])
+            self.pk, self.K = full[8][sl], Kp
+            out[g] = self.ext_step(rho, np.asarray(lambda1K)[sl], float(lambda2G[g]), latent,
+                                   None if mu1 is None else np.asarray(mu1)[sl])
+            for nm in new:
+                new[nm][sl] = getattr(self, nm)
+        self.S, self.pk, self.K = full[0], full[8], full[9]
+        for nm in new:
+            setattr(self, nm, new[nm])
+        return out
+
     def ext_set_state(self, Lambda, X1):
         self.Lam = np.array(Lambda, dtype=np.float64)
         self.X1 = np.zeros_like(self.S) if X1 is None else np.array(X1, dtype=np.float64)

@@ -381,6 +381,16 @@ def test_ext_host_loop_and_padding_match_reference(oracle_engine, latent):
     ext_checks.check_g15(load_golden, ext_solver.ext_ADMM_MGL, latent)
 
 
+@pytest.mark.parametrize("latent", [False, True])
+def test_ext_batched_grid_host_logic(oracle_engine, latent):
+    """ext_ADMM_MGL_batch / grid_search(solver=ext_ADMM_MGL, dict S): grid points as slabs of one padded stack, per-point
+    stopping, un-padding, selection equal to the sequential walk (host logic over the test-only oracle engine)."""
+    import ext_checks
+    from gglasso_amd import ext_solver, model_selection
+    ext_checks.check_ext_batch(load_golden, ext_solver.ext_ADMM_MGL, ext_solver.ext_ADMM_MGL_batch,
+                               None if latent else model_selection.grid_search, latent)
+
+
 def test_ext_asserts_like_reference(oracle_engine):
     from gglasso_amd import ext_solver
     g = load_golden("g14_ext_admm_nonconforming")

@@ -27,6 +27,16 @@ def test_g14_kkt_criterion(ext, latent):
 
 
 @pytest.mark.parametrize("latent", [False, True])
+def test_ext_batched_grid(ext, latent):
+    """The (lambda1, lambda2) grid of an ext_ADMM_MGL problem as ONE batch on the GPU (ggl_ext_setup_batch /
+    ggl_ext_batch_step: group shrink with a grid-point dimension, per-problem sums), every point against its own
+    ext_ADMM_MGL solve; grid_search on top of it against the sequential walk."""
+    from gglasso_amd import ext_solver, model_selection
+    ext_checks.check_ext_batch(load_golden, ext, ext_solver.ext_ADMM_MGL_batch,
+                               None if latent else model_selection.grid_search, latent)
+
+
+@pytest.mark.parametrize("latent", [False, True])
 def test_g15_conforming_equals_admm_mgl(ext, latent):
     """reference tests/test_solvers.py:71-120: trivial G with lambda2/sqrt(K) solves ADMM_MGL's problem."""
     ext_checks.check_g15(load_golden, ext, latent)
