@@ -31,7 +31,8 @@ python tools/bench_grid.py 2>&1 | grep "^{" > $O/workload_sgl_grid_p1000_L20.jso
 python tools/bench_mgl_grid.py 2>&1 | grep "^{" > $O/workload_mgl_grid_8x1_K4_p500.json
 python tools/bench_mgl_grid.py --reg FGL --K 6 --p 300 --l1 4 --l2 3 2>&1 | grep "^{" > $O/workload_mgl_grid_4x3_fgl_K6_p300.json
 K=32 TOL=1e-10 python tools/parity_headline.py ns_tol=2e-12,0 > $O/parity_headline.txt 2>&1
-python tools/bench_chain_probe.py > $O/persistent_chain_probe.txt 2>&1
+python tools/bench_chain.py > $O/omega_chain.txt 2>&1
+python tools/bench_tile_variants.py > $O/tile_variants.txt 2>&1
 python tools/bench_small_batches.py > $O/small_batches_product_kernel.txt 2>&1
 head -c 700 $O/bench_final.json
 rm -rf $R/gpurun_out/prof_$TAG/*/*.db 2>/dev/null
