@@ -245,10 +245,16 @@ def main():
     # Every timed region is the SAME piece of work: back to the identity start, `warmup` untimed iterations, then exactly
     # `steps` timed ones.  (The solve converges to the 1e-20 tolerances' floor after ~150 iterations and would stop by
     # itself, so the regions cannot simply follow each other.)
+    # The start point is restored DEVICE TO DEVICE (a copy kept in HBM): re-uploading it from the host leaves the GPU idle for
+    # ~20 ms per region, after which the chip needs ~15 iterations to come back to its loaded clock state -- measured with
+    # tools/iter_profile.py: iterations 5..24 take 0.863 ms each after an upload and 0.811 ms after a device-side restore,
+    # 0.800 ms in the steady state.  A solve (or a grid of them) keeps the GPU busy; so do the regions now.
+    eng.save_state()
+
     def one_region():
         """-> (seconds of the timed `steps` iterations, max over ranks; ns_stats before; ns_stats after; rho)"""
         eng.profile(0)
-        eng.set_state(Om0, Om0, np.zeros_like(S_loc))
+        eng.restore_state()
         rho = 1.0
         if args.warmup > 0:
             rho = run(args.warmup, rho)
@@ -407,6 +413,8 @@ def main():
                        # spectral accuracy the Omega-step's matrix square root is iterated to (0 = fp64 resolution)
                        "options": effective_options, "options_overridden": sorted(options) or None},
             "timed_regions": {"count": len(region_s), "steps_each": args.steps, "statistic": "median",
+                              "start_point": "identity start restored device-to-device before every region (no idle GPU "
+                                             "between regions), then `warmup` untimed iterations",
                               "ms_per_step_min": min(region_s) / args.steps * 1e3,
                               "ms_per_step_max": max(region_s) / args.steps * 1e3},
             "roofline": roof,

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "ggl_set_S": ([_vp, _dp], _i),
     "ggl_set_state": ([_vp, _dp, _dp, _dp, _dp], _i),
     "ggl_get_state": ([_vp, _dp, _dp, _dp, _dp], _i),
+    "ggl_state_snapshot": ([_vp, _i], _i),
     "ggl_set_lambda1_mask": ([_vp, _dp], _i),
     "ggl_set_lambda1_mask_k": ([_vp, _dp], _i),
     "ggl_set_instance_dims": ([_vp, ctypes.POINTER(_i)], _i),

@@ -58,6 +58,8 @@ struct ggl_ctx {
     double* par = nullptr;    // device: beta[K] | l1[K] | mu[K] | nk[K] | 1/rho[K] | X scale[K] | l2[K] | spare
     double* par_h = nullptr;  // pinned mirror
     double *mask = nullptr, *groupsq = nullptr;   // (p,p)
+    double* snap[4] = {nullptr, nullptr, nullptr, nullptr};   // device copy of a start point (ggl_state_snapshot), lazy
+    bool snap_symmetric = true;
     double* maskK = nullptr;                      // (K,p,p) per-instance thresholds (ggl_set_lambda1_mask_k), lazy
     bool has_maskK = false;
     int* inst_pk = nullptr;                       // (K) instance dimensions of a padded batch of single problems, lazy
@@ -475,6 +477,8 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize, c->inst_pk})
         if (b) (void)hipFree(b);
     if (c->maskK) (void)hipFree(c->maskK);
+    for (double* b : c->snap)
+        if (b) (void)hipFree(b);
     for (void* b : {(void*)c->rowpart, (void*)c->fropart, (void*)c->infpart, (void*)c->cwmax, (void*)c->cwcnt})
         if (b) (void)hipFree(b);
     if (c->spec_flag) (void)hipFree(c->spec_flag);
@@ -594,6 +598,33 @@ extern "C" int ggl_set_state(ggl_ctx* c, const double* Omega, const double* Thet
         if (rc) return rc;
         if (!(asym == 0.0)) c->state_symmetric = false;
     }
+    return GGL_OK;
+}
+
+extern "C" int ggl_state_snapshot(ggl_ctx* c, int restore)
+{
+    // restore == 0: keep a device copy of the iterate (Omega, Theta, L, X); != 0: make that copy the iterate again -- what
+    // ggl_set_state does with the host arrays it was given, without the trip over PCIe (repeated solves from one start point:
+    // benchmark regions, restarts).  Like ggl_set_state it forgets everything carried from earlier iterations.
+    ARGCHK(c, "ctx");
+    HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
+    const size_t nb = c->n * sizeof(double);
+    double* cur[4] = {c->Om[c->cur], c->Theta, c->L, c->X};
+    if (!restore) {
+        for (int i = 0; i < 4; ++i) {
+            if (!c->snap[i]) HIPCHK(hipMalloc(&c->snap[i], nb));
+            HIPCHK(hipMemcpyAsync(c->snap[i], cur[i], nb, hipMemcpyDeviceToDevice, c->stream));
+        }
+        c->snap_symmetric = c->state_symmetric;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return GGL_OK;
+    }
+    ARGCHK(c->snap[0], "no snapshot taken");
+    for (int i = 0; i < 4; ++i) HIPCHK(hipMemcpyAsync(cur[i], c->snap[i], nb, hipMemcpyDeviceToDevice, c->stream));
+    c->state_symmetric = c->snap_symmetric;
+    c->spec_have = false;
+    c->cw_have = false;
     return GGL_OK;
 }
 

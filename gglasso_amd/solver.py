@@ -57,6 +57,14 @@ class HipEngine:
         check(self.lib.ggl_set_state(self.h, ptr(as_c(Omega)), ptr(as_c(Theta)), ptr(None if L is None else as_c(L)),
                                      ptr(as_c(X))))
 
+    def save_state(self):
+        """Keep a device copy of the iterate (a start point several solves / benchmark regions return to)."""
+        check(self.lib.ggl_state_snapshot(self.h, 0))
+
+    def restore_state(self):
+        """Back to the saved iterate, device to device (set_state with the same arrays, without the upload)."""
+        check(self.lib.ggl_state_snapshot(self.h, 1))
+
     def set_option(self, name, value):
         check(self.lib.ggl_ctx_set_option(self.h, _lib.OPTIONS[name], float(value)))
 

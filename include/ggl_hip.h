@@ -128,6 +128,9 @@ int ggl_set_S(ggl_ctx *ctx, const double *S_host);
 int ggl_set_state(ggl_ctx *ctx, const double *Omega, const double *Theta, const double *L,
                   const double *X);
 int ggl_get_state(ggl_ctx *ctx, double *Omega, double *Theta, double *L, double *X);
+/* restore == 0: keep a device copy of the iterate; != 0: make it the iterate again (ggl_set_state with the arrays of that
+ * moment, without the host round trip; everything carried from earlier iterations is forgotten, as in ggl_set_state). */
+int ggl_state_snapshot(ggl_ctx *ctx, int restore);
 /* lambda1 * lambda1_mask as a (p,p) array (single_admm_solver.py:114); NULL clears it. */
 int ggl_set_lambda1_mask(ggl_ctx *ctx, const double *lam_pp_host);
 

@@ -611,3 +611,31 @@ def test_large_K_latent_and_fgl_free_paths_of_the_wide_theta_kernel(sol, K, p):
     (s, _), _ = quiet(sol.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
     for nm in ('Omega', 'Theta', 'L', 'X'):
         assert np.abs(s[nm] - ref[nm]).max() <= 1e-9, nm
+
+
+def test_state_snapshot_restore_equals_a_fresh_upload(sol):
+    """ggl_state_snapshot: a solve restarted from the device copy of its start point runs the iterations a solve from the
+    re-uploaded start point runs -- bit for bit (everything carried across iterations is forgotten both ways)."""
+    from gglasso_amd import synth
+    K, p = 6, 180
+    S, _ = synth.make_problem("GGL", K, p, N=2 * p, seed=3)
+    Om0 = np.stack([np.eye(p)] * K)
+    X0 = np.zeros_like(S)
+    nk = np.ones(K)
+    eng = sol.HipEngine(S, Om0, Om0, X0)
+    try:
+        eng.save_state()
+        outs = []
+        for mode in ("first", "restore", "upload"):
+            if mode == "restore":
+                eng.restore_state()
+            elif mode == "upload":
+                eng.set_state(Om0, Om0, X0)
+            for _ in range(7):
+                eng.step(1.3, 0.05, 0.01, "GGL", False, None, nk)
+            outs.append(eng.state())
+    finally:
+        eng.close()
+    for nm in ("Omega", "Theta", "X"):
+        assert np.array_equal(outs[0][nm], outs[1][nm]), nm
+        assert np.array_equal(outs[0][nm], outs[2][nm]), nm
