@@ -395,7 +395,9 @@ __device__ __forceinline__ void condat_inplace(double* y, const int s, const int
 // A batch of G independent problems of K instances each (model-selection grid, ggl_mgl_batch_step): blockIdx.y = g,
 // the stacks are (G*K,p,p), l1G / l2G hold the thresholds of instance g*K (null: the scalars l1 / l2, G = 1), the
 // partial sums are rows [g][blocks].
-template <int TD, bool FUSE_DUAL>
+// ABL (GGL_DEV builds, timing ablations with wrong results): 1 no Condat scan, 2 no scan and no soft-threshold pass,
+// 3 scan only (no global loads / stores)
+template <int TD, bool FUSE_DUAL, int ABL = 0>
 __global__ __launch_bounds__(TD * TD) void k_theta_fgl(double* __restrict__ Theta, double* __restrict__ X,
                                                        double* __restrict__ C, const double* __restrict__ Omega,
                                                        const double* __restrict__ OmegaPrev,
@@ -435,7 +437,25 @@ __global__ __launch_bounds__(TD * TD) void k_theta_fgl(double* __restrict__ Thet
     const size_t lo_off = (size_t)(J0 + ty) * p + (I0 + tx);
 
     if (up_ok) {
-        for (int k = 0; k < K; ++k) {
+        // eight instances' loads in flight per thread: with one wave per workgroup and ~6 workgroups per CU (the K-vectors
+        // fill the LDS) nothing else hides the latency of these loads
+        int k = 0;
+        for (; k + 8 <= K; k += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = Omega[(size_t)(k + q) * pp + up_off];
+            if (L) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += L[(size_t)(k + q) * pp + up_off];
+            }
+            if (X) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += X[(size_t)(k + q) * pp + up_off];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ycol[(k + q) * NT] = v[q];
+        }
+        for (; k < K; ++k) {
             const size_t o = (size_t)k * pp + up_off;
             double v = Omega[o];
             if (L) v += L[o];
@@ -444,12 +464,15 @@ __global__ __launch_bounds__(TD * TD) void k_theta_fgl(double* __restrict__ Thet
         }
     }
     if (pr_ok) {
-        condat_inplace(ycol, NT, K, l2);
-        for (int k = 0; k < K; ++k) ycol[k * NT] = soft(ycol[k * NT], l1);
+        if (ABL != 1 && ABL != 2) condat_inplace(ycol, NT, K, l2);
+        if (ABL != 2)
+            for (int k = 0; k < K; ++k) ycol[k * NT] = soft(ycol[k * NT], l1);
     }
     __syncthreads();
+    if (ABL == 3) { if (tid == 0 && ycol[0] == 1.2345e300) Theta[0] = 0.0; return; }
 
     double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
+#pragma unroll 4
     for (int k = 0; k < K; ++k) {
         const size_t base = (size_t)k * pp;
         if (up_ok) {
@@ -518,6 +541,19 @@ static hipError_t launch_fgl_td(hipStream_t st, double* Theta, double* X, double
 {
     const int T = ntiles(p, TD);
     const size_t lds = ((size_t)K * TD * TD + GGL_NNORM * 4) * sizeof(double);
+#ifdef GGL_DEV
+    if (const char* ab = getenv("GGL_FGL_ABL")) {
+        const int a = atoi(ab);
+        dim3 grid(T * (T + 1) / 2, G), blk(TD, TD);
+#define GGL_FA(N) do { (void)hipFuncSetAttribute((const void*)k_theta_fgl<TD, true, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_theta_fgl<TD, true, N>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G); } while (0)
+        if (fuse_dual && a >= 1 && a <= 3) {
+            if (a == 1) GGL_FA(1); else if (a == 2) GGL_FA(2); else GGL_FA(3);
+            return hipGetLastError();
+        }
+#undef GGL_FA
+    }
+#endif
     dim3 grid(T * (T + 1) / 2, G), blk(TD, TD);
     hipError_t e;
     if (fuse_dual) {
