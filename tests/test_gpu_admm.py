@@ -484,11 +484,12 @@ def test_sharded_driver_rccl_behind_the_c_abi_single_rank(sol):
     s.close()
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     try:
+        # (8, 500): a slab that runs as TWO concurrent parts inside ggl_admm_step_sharded (the 4-GPU slab of the headline)
         for (K, p, env) in ((5, 40, {}), (3, 150, {}), (3, 150, {"spec_factor": 0.9}), (3, 150, {"speculate": 0}), (4, 500, {}),
-                            (4, 40, {"latent": 1}), (3, 150, {"latent": 1})):
+                            (8, 500, {}), (8, 500, {"spec_factor": 0.9}), (4, 40, {"latent": 1}), (3, 150, {"latent": 1})):
             S, _ = synth.make_problem("GGL", K, p, seed=31)
             Om0 = np.stack([np.eye(p)] * K)
-            kw = dict(tol=1e-9, rtol=1e-9) if p < 500 else dict(tol=1e-20, rtol=1e-20, max_iter=6)
+            kw = dict(tol=1e-9, rtol=1e-9) if p < 500 else dict(tol=1e-20, rtol=1e-20, max_iter=8)
             if env.pop("latent", 0):
                 # K-sharded run with latent variables (ggl_admm_step_sharded_latent): L-step on the slab, per-instance mu1
                 kw.update(latent=True, mu1=np.linspace(0.1, 0.2, K), max_iter=40)
