@@ -388,7 +388,8 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
     while (b >= T - I) { b -= T - I; ++I; }
     const int J = I + b;
     const int I0 = I * BM, J0 = J * BM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: everything derived from it is scalar
     const int wr = (wave >> 1) * WM, wc = (wave & 1) * WN;
     const size_t pp = (size_t)p * p;
     const double* Ak = (second ? A1 : A) + (size_t)kk * pp;
@@ -402,27 +403,53 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
 
     // DMA geometry: wave w issues instructions i = 2w, 2w+1 per operand; instruction i covers slab rows
     // 2i, 2i+1; lane l -> row 2i + (l >> 5), LDS position (l & 31) * 2, source column position ^ 16*(row & 1).
+    // The per-lane source pointers are kept for the NEXT slab to be issued and advanced by BK rows per slab: every vector
+    // instruction beside an MFMA takes matrix-pipe issue slots (tools/probe_mfma_mix.py: 2 integer VALU per MFMA cost 11 % of
+    // the FP64 MFMA rate, 8 cost 17 %), and recomputing min / mul / 64-bit adds per instruction was ~25 of them per slab.
+    // Only the last, partial slab (rows beyond the matrix clamped to its last row) goes the long way.
     const unsigned pu = (unsigned)p, pm1 = (unsigned)(p - 1), pm2 = (unsigned)(p - 2);
     const int lrow = lane / LPR;
     const unsigned cpos = (unsigned)((lane % LPR) * 2) ^ (unsigned)(16 * (lrow & 1));
     const unsigned ca = min((unsigned)I0 + cpos, pm2), cb = min((unsigned)J0 + cpos, pm2);
-    auto issue = [&](int m0, int buf) {
-        if (ABL == 2) return;                                            // timing ablation: no operand loads at all
+    const double* pa[IPW];
+    const double* pb[IPW];
 #pragma unroll
-        for (int j = 0; j < IPW; ++j) {
-            const int i = wave * IPW + j;
-            const unsigned ro = min((unsigned)(m0 + RPI * i + lrow), pm1) * pu;
-            double* la = smem + (size_t)buf * 2 * SLAB + i * 128;            // wave-uniform LDS base
-            double* lb = la + SLAB;
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ak + ro + ca), (lptr_t)la, 16, 0, AUX);
-            __builtin_amdgcn_global_load_lds((gptr_t)(Bk + ro + cb), (lptr_t)lb, 16, 0, AUX);
+    for (int j = 0; j < IPW; ++j) {
+        const unsigned r0 = min((unsigned)(RPI * (wave * IPW + j) + lrow), pm1);
+        pa[j] = Ak + (size_t)r0 * pu + ca;
+        pb[j] = Bk + (size_t)r0 * pu + cb;
+    }
+    const size_t slab_step = (size_t)BK * pu;
+    const int Sfull = p / BK;                                            // slabs that lie inside the matrix entirely
+    auto issue = [&](int sidx, int buf) {                                // slabs are issued in increasing order
+        if (ABL == 2) return;                                            // timing ablation: no operand loads at all
+        double* base = smem + (size_t)buf * 2 * SLAB + (wave * IPW) * 128;   // wave-uniform LDS base
+        if (sidx < Sfull) {
+#pragma unroll
+            for (int j = 0; j < IPW; ++j) {
+                double* la = base + j * 128;
+                __builtin_amdgcn_global_load_lds((gptr_t)pa[j], (lptr_t)la, 16, 0, AUX);
+                __builtin_amdgcn_global_load_lds((gptr_t)pb[j], (lptr_t)(la + SLAB), 16, 0, AUX);
+                pa[j] += slab_step;
+                pb[j] += slab_step;
+            }
+        } else {
+            const int m0 = sidx * BK;
+#pragma unroll
+            for (int j = 0; j < IPW; ++j) {
+                const int i = wave * IPW + j;
+                const unsigned ro = min((unsigned)(m0 + RPI * i + lrow), pm1) * pu;
+                double* la = base + j * 128;
+                __builtin_amdgcn_global_load_lds((gptr_t)(Ak + ro + ca), (lptr_t)la, 16, 0, AUX);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Bk + ro + cb), (lptr_t)(la + SLAB), 16, 0, AUX);
+            }
         }
     };
     const bool dead_wave = (I == J) && (wr >= wc + WN);
     const int S = (p + BK - 1) / BK;
 #pragma unroll
     for (int q = 0; q < NSTG - 1; ++q)
-        if (q < S) issue(q * BK, q);
+        if (q < S) issue(q, q);
     for (int s = 0; s < S; ++s) {
         const int buf = s % NSTG;
         // this wave's DMA of slab s has landed: at most the later slabs' instructions may still be in flight
@@ -449,7 +476,7 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (ABL != 5) __builtin_amdgcn_s_barrier();                      // ABL 5: no slab barrier (timing ablation)
         asm volatile("" ::: "memory");
-        if (s + NSTG - 1 < S) issue((s + NSTG - 1) * BK, (s + NSTG - 1) % NSTG);
+        if (s + NSTG - 1 < S) issue(s + NSTG - 1, (s + NSTG - 1) % NSTG);
         if (!dead_wave) {
             const double* As = smem + (size_t)buf * 2 * SLAB;
             const double* Bs = As + SLAB;
