@@ -109,6 +109,7 @@ _DEV_SIGNATURES = {
     "ggl_dev_symm_timeline": ([_i, _i, ctypes.POINTER(ctypes.c_longlong), _i, ctypes.POINTER(_i)], _i),
     "ggl_dev_chain_probe": ([_i, _i, _i, _i, _i, _i, _dp], _i),
     "ggl_dev_coissue_probe": ([_dp], _i),
+    "ggl_dev_mfma_lds_probe": ([_dp], _i),
     "ggl_dev_chain_run": ([_i, _i, _i, _i, _dp], _i),
 }
 

@@ -12,6 +12,8 @@
 // (WN/16) MFMA tiles; k-slab BK.  The next slab is fetched from HBM/L2 into registers while the
 // current one is consumed from LDS (software prefetch), one barrier pair per slab.
 #include <algorithm>
+#include <initializer_list>
+#include <type_traits>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -450,8 +452,19 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
 #pragma unroll
     for (int q = 0; q < NSTG - 1; ++q)
         if (q < S) issue(q, q);
-    for (int s = 0; s < S; ++s) {
-        const int buf = s % NSTG;
+    // per-lane LDS positions of the wave's fragments in k-quad 0 of a slab image: row (lane >> 4), column XOR-swizzled by the
+    // row's parity -- rows of k-quad q are 4q + (lane >> 4), same parity -- so every fragment read of the slab loop is one
+    // of these bases plus a COMPILE-TIME offset (stage, operand, k-quad): the loop is unrolled over the NSTG stages to make
+    // the stage a constant, and the fragment reads carry no address arithmetic at all (see the note on issue slots above)
+    const int fg = lane >> 4, fsw = 16 * (fg & 1);
+    const double* pfa[TI];
+    const double* pfb[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) pfa[i] = smem + fg * BM + ((wr + i * 16 + (lane & 15)) ^ fsw);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) pfb[j] = smem + SLAB + fg * BM + ((wc + j * 16 + (lane & 15)) ^ fsw);
+    auto slab = [&](const int s, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
         // this wave's DMA of slab s has landed: at most the later slabs' instructions may still be in flight
         const int ahead = min(NSTG - 2, S - 1 - s);
         if (NSTG >= 6 && ahead >= 4) wait_vmcnt<(NSTG >= 6 ? 8 * IPW : 0)>();
@@ -476,21 +489,18 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (ABL != 5) __builtin_amdgcn_s_barrier();                      // ABL 5: no slab barrier (timing ablation)
         asm volatile("" ::: "memory");
-        if (s + NSTG - 1 < S) issue(s + NSTG - 1, (s + NSTG - 1) % NSTG);
+        if (s + NSTG - 1 < S) issue(s + NSTG - 1, (buf + NSTG - 1) % NSTG);
         if (!dead_wave) {
-            const double* As = smem + (size_t)buf * 2 * SLAB;
-            const double* Bs = As + SLAB;
             const int nq = min(BK / 4, (valid + 3) / 4);      // k-quads inside the matrix (last slab: 1 of 4 at p = 500)
 #pragma unroll
             for (int kq4 = 0; kq4 < BK / 4; ++kq4) {
                 if (kq4 >= nq) break;
-                const int row = kq4 * 4 + (lane >> 4);
-                const int sw = 16 * (row & 1);
+                constexpr int so = buf * 2 * SLAB;
                 double af[TI], bf[TJ];
 #pragma unroll
-                for (int i = 0; i < TI; ++i) af[i] = As[row * BM + ((wr + i * 16 + (lane & 15)) ^ sw)];
+                for (int i = 0; i < TI; ++i) af[i] = pfa[i][so + kq4 * 4 * BM];
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) bf[j] = Bs[row * BM + ((wc + j * 16 + (lane & 15)) ^ sw)];
+                for (int j = 0; j < TJ; ++j) bf[j] = pfb[j][so + kq4 * 4 * BM];
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -500,6 +510,16 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
                     }
             }
         }
+    };
+    auto stages = [&](const int s0, auto... bufs) {
+        (void)std::initializer_list<int>{((s0 + (int)decltype(bufs)::value < S) ? (slab(s0 + (int)decltype(bufs)::value, bufs), 0) : 0)...};
+    };
+    static_assert(NSTG == 2 || NSTG == 3 || NSTG == 4 || NSTG == 6, "stage counts with an unrolled slab loop");
+    for (int s0 = 0; s0 < S; s0 += NSTG) {
+        if constexpr (NSTG == 2) stages(s0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        else if constexpr (NSTG == 3) stages(s0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+        else if constexpr (NSTG == 4) stages(s0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+        else stages(s0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
     }
     __syncthreads();     // all fragment reads done before the slabs are reused as the mirror tile
     if (ABL == 4) {                                                      // timing ablation: no epilogue

@@ -2827,6 +2827,16 @@ extern "C" int ggl_dev_coissue_probe(double* out12)
     return GGL_OK;
 }
 
+extern "C" int ggl_dev_mfma_lds_probe(double* out6)
+{
+    ARGCHK(out6, "out");
+    DevBuf d;
+    HIPCHK(d.alloc((size_t)2048 * 256));
+    mfma_lds_probe(nullptr, d.p, out6);
+    HIPCHK(hipGetLastError());
+    return GGL_OK;
+}
+
 extern "C" int ggl_dev_mfma_f64_peak(double* tflops_out)
 {
     ARGCHK(tflops_out, "tflops_out");

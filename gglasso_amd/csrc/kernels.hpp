@@ -204,6 +204,7 @@ int launch_chain_probe(hipStream_t st, double* X0, double* X1, const double* coe
 #ifdef GGL_DEV
 // FP64 VALU || MFMA co-issue probe (probes_dev.hip): out[12] TF/s pairs, see there
 void coissue_probe(hipStream_t st, double* scratch, double* out);
+void mfma_lds_probe(hipStream_t st, double* scratch, double* out);      // MFMA fed from LDS at several read : MFMA ratios
 #endif
 // measured FP64 matrix-core ceiling (MFMA-only probe kernel; GGL_DEV builds)
 double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int iters, int nacc);

@@ -113,5 +113,77 @@ void coissue_probe(hipStream_t st, double* scratch, double* out)
     same(std::integral_constant<int, 32>{}, 32, 10);
 }
 
+// ---- MFMA fed from LDS: what fragment-read : MFMA ratio does the matrix pipe tolerate? ----------------------------------
+// The product kernel's inner loop without everything else (no DMA, no barriers, no epilogue): per k-quad a wave reads TI
+// A-fragments and TJ B-fragments (ds_read_b64, immediate offsets off two base registers) and issues TI x TJ MFMAs.
+// Workgroups of 4 waves with LDSB bytes of (static) LDS each, so that the residency per CU is the kernel's.
+template <int TI, int TJ, int LDSB>
+__global__ __launch_bounds__(256) void k_mfma_lds(double* __restrict__ out, int iters)
+{
+    __shared__ __attribute__((aligned(16))) double smem[LDSB / 8];
+    const int lane = threadIdx.x & 63;
+    for (int e = threadIdx.x; e < LDSB / 8; e += 256) smem[e] = 1.0 + 1e-9 * e;
+    __syncthreads();
+    v4d acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* As = smem + (lane >> 4) * 64 + (lane & 15);
+    const double* Bs = As + 1024;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {                  // one 16-row slab: 4 k-quads at compile-time offsets
+            double af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = As[kq * 256 + i * 16];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = Bs[kq * 256 + j * 16];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");                    // the reads are re-issued every slab
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int TI, int TJ, int LDSB>
+static double mfma_lds_tf(hipStream_t st, double* scratch, int blocks, int iters)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_mfma_lds<TI, TJ, LDSB>), dim3(blocks), dim3(256), 0, st, scratch, 8);
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL((k_mfma_lds<TI, TJ, LDSB>), dim3(blocks), dim3(256), 0, st, scratch, iters);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return (double)blocks * 4.0 * iters * 4.0 * TI * TJ * 2048.0 / (ms * 1e-3) / 1e12;
+}
+
+// out[0..]: TF/s for {2x2 at 3 workgroups/CU (48 KiB), 2x2 at 5/CU (32 KiB), 2x4 at 3/CU, 4x4 at 2/CU (64 KiB), 4x4 at 3/CU
+// (48 KiB; needs <= 170 registers), 1x1 at 5/CU}
+void mfma_lds_probe(hipStream_t st, double* scratch, double* out)
+{
+    const int it = 1500;
+    out[0] = mfma_lds_tf<2, 2, 49152>(st, scratch, 256 * 3, it);
+    out[1] = mfma_lds_tf<2, 2, 32768>(st, scratch, 256 * 5, it);
+    out[2] = mfma_lds_tf<2, 4, 49152>(st, scratch, 256 * 3, it);
+    out[3] = mfma_lds_tf<4, 4, 65536>(st, scratch, 256 * 2, it);
+    out[4] = mfma_lds_tf<4, 4, 49152>(st, scratch, 256 * 3, it);
+    out[5] = mfma_lds_tf<1, 1, 32768>(st, scratch, 256 * 5, it);
+}
+
 }  // namespace ggl
 #endif   // GGL_DEV

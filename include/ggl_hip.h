@@ -356,6 +356,8 @@ int ggl_dev_mfma_f64_peak(double *tflops_out);
 /* FP64 VALU || FP64 MFMA co-issue probe (csrc/probes_dev.hip), TF/s: {MFMA only, v_fma_f64 only, waves split per SIMD:
  * MFMA, DFMA, one wave with 4 / 8 / 16 / 32 v_fma_f64 behind every MFMA: MFMA, DFMA each} */
 int ggl_dev_coissue_probe(double *out12);
+/* MFMA fed from LDS (the product kernel's inner loop alone), TF/s for wave tiles {2x2 @3 WG/CU, 2x2 @5, 2x4 @3, 4x4 @2, 4x4 @3, 1x1 @5} */
+int ggl_dev_mfma_lds_probe(double *out6);
 /* k_omega_chain on a synthetic chain of nprod dependent products X <- I - 1.5 X^2: out = {ms as nprod launches, ms as one
  * persistent launch, persistent workgroups, max |difference| of the results, completion flag, done counters [K]} */
 int ggl_dev_chain_run(int K, int p, int nprod, int iters, double *out);
