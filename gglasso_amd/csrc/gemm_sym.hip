@@ -538,6 +538,58 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
     double* C2k = (C2 && !second) ? C2 + (size_t)kk * pp : nullptr;
     const double* Ek = (E && !second) ? E + (size_t)kk * pp : nullptr;
     double dev = 0.0;
+    // Off-diagonal tiles: the accumulators go to the (XOR-swizzled) LDS tile first and BOTH copies -- the tile and its
+    // mirror -- are written from there with 16-byte accesses, two consecutive columns per lane (p is even, tile columns start
+    // on even indices): half the global store / E-load instructions of the layout the MFMA leaves the values in (one column
+    // per lane: 8-byte accesses, which run at 0.54-0.70x the 16-byte rate on this chip).  Same arithmetic per element
+    // (cAcc * acc, then + cE * E): same bits.  Diagonal tiles keep the direct path (upper triangle only, in-tile mirror).
+    const bool wide = (I != J) && ABL != 1;
+    if (wide) {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wr + ti * 16 + (lane >> 4) + 4 * r;
+                    const int col = wc + tj * 16 + (lane & 15);
+                    smem[row * BM + (col ^ row)] = cAcc * acc[ti][tj][r];
+                }
+        __syncthreads();
+        auto ld2 = [](const double* q) { return *reinterpret_cast<const double2*>(q); };
+        auto lde2 = [&](const double* q) {
+            if constexpr (AUX == 0) return *reinterpret_cast<const double2*>(q);
+            else { double2 e; e.x = ld_pol<AUX>(q); e.y = ld_pol<AUX>(q + 1); return e; }
+        };
+        for (int e2 = tid; e2 < BM * BM / 2; e2 += NT) {
+            const int row = e2 / (BM / 2), c2 = (e2 % (BM / 2)) * 2;
+            const int gi = I0 + row, gj = J0 + c2;
+            // columns c2, c2 + 1 of row `row` sit at (c2 ^ row), (c2 ^ row) ^ 1: one aligned pair, swapped for odd rows
+            double2 t = ld2(smem + row * BM + ((c2 ^ row) & ~1));
+            if (row & 1) { const double h = t.x; t.x = t.y; t.y = h; }
+            if (gi < p && gj < p) {
+                double2 e = {0.0, 0.0};
+                if (Ek) e = lde2(Ek + (size_t)gi * p + gj);
+                double2 v;
+                v.x = t.x + cE * e.x;
+                v.y = t.y + cE * e.y;
+                dev = fmax(dev, fmax(fabs(v.x), fabs(v.y)));
+                *reinterpret_cast<double2*>(Ck + (size_t)gi * p + gj) = v;
+                if (C2k) {
+                    double2 w;
+                    w.x = c2val(dC, v.x, dE, e.x);
+                    w.y = c2val(dC, v.y, dE, e.y);
+                    *reinterpret_cast<double2*>(C2k + (size_t)gi * p + gj) = w;
+                }
+                if (rowpart) {          // the bound partials (and then the mirror) read the FINAL values from the tile
+                    if (row & 1) { const double h = v.x; v.x = v.y; v.y = h; }
+                    *reinterpret_cast<double2*>(smem + row * BM + ((c2 ^ row) & ~1)) = v;
+                }
+            } else if (rowpart) {
+                *reinterpret_cast<double2*>(smem + row * BM + ((c2 ^ row) & ~1)) = double2{0.0, 0.0};
+            }
+        }
+    } else {
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -565,12 +617,13 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
                 // bound partials every tile is staged (entries that are not stored count as zero)
                 if ((I != J || rowpart) && ABL != 1) smem[row * BM + (col ^ row)] = (rowpart && !keep) ? 0.0 : v;
             }
+    }
     if (maxdev) {
         dev = wave_max(dev);
         if (lane == 0 && dev > 0.0)
             atomicMax(reinterpret_cast<unsigned long long*>(maxdev + k), (unsigned long long)__double_as_longlong(dev));
     }
-    if ((I != J || rowpart) && ABL != 1) __syncthreads();
+    if (((I != J && !wide) || rowpart) && ABL != 1) __syncthreads();
     if (rowpart && ABL != 1 && tid < 2 * BM) {
         // threads 0..BM-1: row t of the staged tile; threads BM..2BM-1 (off-diagonal tiles): column t of it, i.e. row
         // J0+t of the mirrored tile.  A diagonal tile holds its upper triangle U only: row t of the full symmetric tile
@@ -609,16 +662,30 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
             if (tid == 0) fropart[(size_t)k * (T * (T + 1) / 2) + blockTile] = sq;
         }
     }
-    if (I != J && ABL != 1) {
-        for (int e = tid; e < BM * BM; e += NT) {
-            const int a = e / BM, c = e % BM;   // out[J0+a][I0+c] = tile[c][a]
-            if (J0 + a < p && I0 + c < p) {
-                const double v = smem[c * BM + (a ^ c)];
-                Ck[(size_t)(J0 + a) * p + I0 + c] = v;
+    if (wide) {
+        // the mirror: row a of it is column a of the staged tile; two consecutive columns c2, c2 + 1 per lane.  Without bound
+        // partials the tile still holds cAcc * acc and the E term is added here as well (E is bitwise symmetric -- an output
+        // of this kernel family -- so its mirrored entries ARE the upper ones); with them it holds the final values.
+        auto lde2 = [&](const double* q) {
+            if constexpr (AUX == 0) return *reinterpret_cast<const double2*>(q);
+            else { double2 e; e.x = ld_pol<AUX>(q); e.y = ld_pol<AUX>(q + 1); return e; }
+        };
+        for (int e2 = tid; e2 < BM * BM / 2; e2 += NT) {
+            const int a = e2 / (BM / 2), c2 = (e2 % (BM / 2)) * 2;      // out[J0+a][I0+c2 .. +1] = tile[c2 .. +1][a]
+            if (J0 + a < p && I0 + c2 < p) {
+                double2 v;
+                v.x = smem[c2 * BM + (a ^ c2)];
+                v.y = smem[(c2 + 1) * BM + (a ^ (c2 + 1))];
+                double2 e = {0.0, 0.0};
+                const bool need_e = Ek && (!rowpart || (C2k && dE != 0.0));
+                if (need_e) e = lde2(Ek + (size_t)(J0 + a) * p + I0 + c2);
+                if (!rowpart) { v.x += cE * e.x; v.y += cE * e.y; }
+                *reinterpret_cast<double2*>(Ck + (size_t)(J0 + a) * p + I0 + c2) = v;
                 if (C2k) {
-                    // E is bitwise symmetric (an output of this kernel family): its mirrored entry IS the upper one
-                    const double e0 = (dE != 0.0 && Ek) ? ld_pol<AUX>(Ek + (size_t)(J0 + a) * p + I0 + c) : 0.0;
-                    C2k[(size_t)(J0 + a) * p + I0 + c] = c2val(dC, v, dE, e0);
+                    double2 w;
+                    w.x = c2val(dC, v.x, dE, e.x);
+                    w.y = c2val(dC, v.y, dE, e.y);
+                    *reinterpret_cast<double2*>(C2k + (size_t)(J0 + a) * p + I0 + c2) = w;
                 }
             }
         }
