@@ -492,6 +492,10 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
         if (s + NSTG - 1 < S) issue(s + NSTG - 1, (buf + NSTG - 1) % NSTG);
         if (!dead_wave) {
             const int nq = min(BK / 4, (valid + 3) / 4);      // k-quads inside the matrix (last slab: 1 of 4 at p = 500)
+            // (The exit check between the k-quads stays even for slabs that lie inside the matrix.  Straight-line code --
+            // with the compiler's own order, ds_read2st64 pairs ahead of 8 back-to-back MFMAs, or with a scheduling barrier
+            // per k-quad that keeps read 4 / issue 4 -- measured 8-9 % SLOWER at the headline, in-box A/B: the scalar
+            // branch is where a wave lets the other waves of its SIMD in.)
 #pragma unroll
             for (int kq4 = 0; kq4 < BK / 4; ++kq4) {
                 if (kq4 >= nq) break;
