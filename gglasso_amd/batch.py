@@ -18,7 +18,7 @@ from .solver import as_c, residuals_from_norms, next_rho
 
 def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max_iter=1000, tol=1e-7,
                    rtol=1e-4, update_rho=True, verbose=False, latent=False, mu1=None, lambda1_mask=None,
-                   selection_stats=False, dims=None):
+                   selection_stats=False, dims=None, tau_range=None):
     """Solve ``ADMM_SGL(S, lambda1[k], ...)`` for every k of the 1-D array ``lambda1`` at once.
 
     S: (p,p) shared by all instances, or (K,p,p) with one covariance matrix per instance (what
@@ -27,7 +27,11 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     Returns a list of K ``(sol, info)`` pairs with the reference's keys; ``info`` additionally carries
     ``'iterations'`` and the final ``'rho'``.  ``selection_stats``: also keep a device snapshot of every instance's
     solution's Theta and attach ``info['selection'] = {'Sdot','logdet','nnz','lambda_min'}`` computed on the GPU
-    (what the AIC / eBIC tables of model selection are made of).
+    (what the AIC / eBIC tables of model selection are made of); with ``latent`` also ``'rank'``: the row
+    ``HipEngine.selection_rank`` returns for the instance's L (rank at ``solver.RANK_REL_TOL``, max|lambda|,
+    and the two eigenvalue magnitudes either side of the cut); with ``tau_range`` also ``'threshold'``: the
+    (len(tau_range), 4) table of the same four statistics for the estimate thresholded at every tau (tune_threshold,
+    helper/model_selection.py:707-737).
     ``dims`` (K,) ints: problems of DIFFERENT dimension in one batch -- instance k is the leading (dims[k], dims[k]) block
     of its slot and the caller has padded S / Omega_0 / Theta_0 with an identity block and X_0 with zeros behind it (a
     decoupled fixed point of the iteration; ``pad_blocks`` builds such stacks).  Residuals, ``dim`` and the stopping
@@ -129,6 +133,15 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
             for k in range(K):
                 results[k][1]['selection'] = {'Sdot': st[k, 0], 'logdet': st[k, 1], 'nnz': st[k, 2],
                                               'lambda_min': st[k, 3]}
+            if latent:
+                rk = eng.selection_rank(_solver.RANK_REL_TOL)
+                for k in range(K):
+                    results[k][1]['selection']['rank'] = rk[k].copy()
+            if tau_range is not None:
+                tab, n_eig = eng.threshold_scan(tau_range)
+                for k in range(K):
+                    results[k][1]['selection']['threshold'] = tab[k].copy()
+                    results[k][1]['selection']['threshold_eig_problems'] = n_eig
     finally:
         eng.close()
     return results
@@ -147,7 +160,8 @@ def pad_blocks(blocks, P, identity):
 
 
 def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1e-5, rtol=1e-4, update_rho=True,
-                   rho=1., max_iter=1000, verbose=False, latent=False, mu1=None, selection_stats=False):
+                   rho=1., max_iter=1000, verbose=False, latent=False, mu1=None, selection_stats=False,
+                   tau_range=None):
     """Solve ``ADMM_MGL(S, lambda1[g], lambda2[g], reg, Omega_0, ...)`` (solver/admm_solver.py:13-313) for every
     g of the 1-D arrays ``lambda1`` / ``lambda2`` at once: the G problems are the slabs of one (G*K,p,p) stack on
     the GPU, one batched Omega-step (and L-step) over all G*K matrices and one Theta-step launch per iteration.
@@ -240,6 +254,14 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
             st = eng.selection_stats()
             for g in range(G):
                 results[g][1]['selection'] = st[g * K:(g + 1) * K].copy()
+            if latent:
+                rk = eng.selection_rank(_solver.RANK_REL_TOL)
+                for g in range(G):
+                    results[g][1]['rank'] = rk[g * K:(g + 1) * K].copy()
+            if tau_range is not None:
+                tab, _ = eng.threshold_scan(tau_range)
+                for g in range(G):
+                    results[g][1]['threshold'] = tab[g * K:(g + 1) * K].copy()
     finally:
         eng.close()
     return results

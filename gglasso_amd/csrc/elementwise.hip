@@ -380,6 +380,62 @@ void launch_dot(hipStream_t st, const double* A, const double* B, int K, int p, 
     hipLaunchKernelGGL(k_dot, dim3(elementwise_blocks(p), K), dim3(EW_THREADS), 0, st, A, B, pp, partials);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Thresholded estimates of the model selection (helper/model_selection.py:698-705: off-diagonal entries with
+// |a| <= tau are zeroed, the diagonal is kept).  Slot s of the launch reads instance src[s] with threshold tauS[s]:
+// SUMS: partials[s][b] = { <S_src, T>, count_nonzero(T) } (the terms of aic_single / ebic_single, :812-856);
+// WRITE: T is stored to out[s] (input of the eigenvalue pass for log det T).
+template <bool SUMS, bool WRITE>
+__global__ __launch_bounds__(EW_THREADS) void k_threshold(const double* __restrict__ A, const double* __restrict__ S,
+                                                          const int* __restrict__ src, const double* __restrict__ tauS,
+                                                          int p, size_t pp, double* __restrict__ out,
+                                                          double* __restrict__ partials)
+{
+    __shared__ double scratch[2 * (EW_THREADS / 64)];
+    const int s = blockIdx.y;
+    const size_t base = (size_t)src[s] * pp;
+    const double tau = tauS[s];
+    double acc[2] = {0.0, 0.0};
+    size_t i = (size_t)blockIdx.x * EW_CHUNK + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < EW_EPT; ++e, i += EW_THREADS) {
+        if (i < pp) {
+            const double a = A[base + i];
+            const bool keep = fabs(a) > tau || i % ((size_t)p + 1) == 0;
+            const double t = keep ? a : 0.0;
+            if (WRITE) out[(size_t)s * pp + i] = t;
+            if (SUMS) {
+                acc[0] += t * S[base + i];
+                acc[1] += (t != 0.0) ? 1.0 : 0.0;
+            }
+        }
+    }
+    if (SUMS) {
+        block_sum<2>(acc, scratch);
+        if (threadIdx.x == 0) {
+            double* o = partials + ((size_t)s * gridDim.x + blockIdx.x) * 2;
+            o[0] = acc[0];
+            o[1] = acc[1];
+        }
+    }
+}
+
+void launch_threshold_sums(hipStream_t st, const double* A, const double* S, const int* src, const double* tauS,
+                           int nslot, int p, double* partials)
+{
+    size_t pp = (size_t)p * p;
+    hipLaunchKernelGGL((k_threshold<true, false>), dim3(elementwise_blocks(p), nslot), dim3(EW_THREADS), 0, st, A, S, src,
+                       tauS, p, pp, (double*)nullptr, partials);
+}
+
+void launch_threshold_write(hipStream_t st, const double* A, const int* src, const double* tauS, int nslot, int p,
+                            double* out)
+{
+    size_t pp = (size_t)p * p;
+    hipLaunchKernelGGL((k_threshold<false, true>), dim3(elementwise_blocks(p), nslot), dim3(EW_THREADS), 0, st, A,
+                       (const double*)nullptr, src, tauS, p, pp, out, (double*)nullptr);
+}
+
 __global__ __launch_bounds__(256) void k_axpy(double* __restrict__ out, const double* __restrict__ A, double c,
                                               const double* __restrict__ B, size_t n)
 {

@@ -139,6 +139,7 @@ struct ggl_ctx {
     int ext_L = -1;                            // -1: ggl_ext_setup not called
     int ext_nprob = 1;                         // independent problems in the stack (ggl_ext_setup_batch), K / ext_nprob instances each
     double* snapT = nullptr;                   // per-instance snapshots of Theta (model selection), lazy
+    double* snapL = nullptr;                   // ... and of L once a latent step has run
     double* nbrow = nullptr;                   // [K][p] row abs-sums of B' (Collatz-Wielandt weight vector)
     // the Collatz-Wielandt vector carried across iterations (k_cw_final): [cw_cur] was left behind by the last ACCEPTED
     // bound pass, the other one is what the pass in flight writes; cw_have: there is an accepted one
@@ -472,7 +473,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     // (the rocBLAS handle is the process-wide one of blas_handle(): never destroyed here)
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
-                      c->nsT, c->nsNX, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->cuse, c->Lam[0],
+                      c->nsT, c->nsNX, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->snapL, c->cuse, c->Lam[0],
                       c->Lam[1], c->X1, c->cwvec[0], c->cwvec[1]};
     for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize, c->inst_pk})
         if (b) (void)hipFree(b);
@@ -584,6 +585,7 @@ extern "C" int ggl_set_state(ggl_ctx* c, const double* Omega, const double* Thet
     if (Theta) HIPCHK(hipMemcpyAsync(c->Theta, Theta, nb, hipMemcpyHostToDevice, c->stream));
     if (L) HIPCHK(hipMemcpyAsync(c->L, L, nb, hipMemcpyHostToDevice, c->stream));
     else HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
+    c->step_latent = (L != nullptr);          // a snapshot taken before any step keeps an uploaded L as well
     if (X) HIPCHK(hipMemcpyAsync(c->X, X, nb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     // exact symmetry of the dual and latent stacks decides whether the per-element Theta-step may be used
@@ -1808,6 +1810,13 @@ extern "C" int ggl_snapshot_k(ggl_ctx* c, int k)
         HIPCHK(hipMemsetAsync(c->snapT, 0, c->n * sizeof(double), c->stream));
     }
     HIPCHK(hipMemcpyAsync(c->snapT + k * pp, c->Theta + k * pp, nb, hipMemcpyDeviceToDevice, c->stream));
+    if (c->step_latent) {
+        if (!c->snapL) {
+            HIPCHK(hipMalloc(&c->snapL, c->n * sizeof(double)));
+            HIPCHK(hipMemsetAsync(c->snapL, 0, c->n * sizeof(double), c->stream));
+        }
+        HIPCHK(hipMemcpyAsync(c->snapL + k * pp, c->L + k * pp, nb, hipMemcpyDeviceToDevice, c->stream));
+    }
     return GGL_OK;
 }
 
@@ -2378,6 +2387,164 @@ struct DevBuf {
 
 #define UP(dst, src, n) HIPCHK(hipMemcpy(dst, src, (size_t)(n) * sizeof(double), hipMemcpyHostToDevice))
 #define DOWN(dst, src, n) HIPCHK(hipMemcpy(dst, src, (size_t)(n) * sizeof(double), hipMemcpyDeviceToHost))
+
+// ---------------------------------------------------------------------------------------------
+// model selection on the snapshots: thresholded estimates and the rank of the latent component
+// ---------------------------------------------------------------------------------------------
+// tune_threshold (helper/model_selection.py:707-737) scores every tau of a range by AIC / eBIC of the thresholded
+// estimate.  Two passes over the snapshots: (1) <S,T> and count_nonzero(T) of every (instance, tau) -- one light
+// launch per tau; (2) log det T needs eigenvalues, but a larger tau zeroes a superset of entries, so two thresholds with
+// the same non-zero count give the SAME matrix: only the distinct (instance, count) pairs are materialised, K at a time,
+// and sent through the batched eigenvalue kernel.
+extern "C" int ggl_threshold_scan(ggl_ctx* c, const double* tau, int ntau, double* out, int* n_eig)
+{
+    ARGCHK(c && tau && out, "ctx, tau, out");
+    ARGCHK(ntau >= 1 && ntau <= 4096, "ntau in 1..4096");
+    ARGCHK(c->snapT, "no snapshot taken (ggl_snapshot_k)");
+    for (int j = 0; j < ntau; ++j) ARGCHK(tau[j] > 0.0, "thresholds must be positive (model_selection.py:716)");
+    HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
+    const int K = c->K, p = c->p;
+    const int nblk = elementwise_blocks(p);
+    // ---- pass 1: sums of every (k, j)
+    std::vector<int> src((size_t)K);
+    for (int k = 0; k < K; ++k) src[k] = k;
+    std::vector<double> tauK((size_t)ntau * K);
+    for (int j = 0; j < ntau; ++j)
+        for (int k = 0; k < K; ++k) tauK[(size_t)j * K + k] = tau[j];
+    DevBuf dtau, dsums;
+    int* dsrc = nullptr;
+    HIPCHK(dtau.alloc(tauK.size()));
+    HIPCHK(dsums.alloc((size_t)ntau * K * 2));
+    HIPCHK(hipMalloc(&dsrc, (size_t)K * sizeof(int)));
+    struct IntFree { int* p; ~IntFree() { (void)hipFree(p); } } srcfree{dsrc};
+    HIPCHK(hipMemcpyAsync(dtau.p, tauK.data(), tauK.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dsrc, src.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    for (int j = 0; j < ntau; ++j) {
+        launch_threshold_sums(c->stream, c->snapT, c->S, dsrc, dtau.p + (size_t)j * K, K, p, c->partials);
+        launch_reduce_partials(c->stream, c->partials, K, nblk, 2, dsums.p + (size_t)j * K * 2);
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<double> sums((size_t)ntau * K * 2);
+    HIPCHK(hipMemcpyAsync(sums.data(), dsums.p, sums.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // ---- pass 2: one eigenvalue problem per distinct thresholded matrix
+    struct Item { int k, j; };
+    std::vector<Item> work;
+    std::vector<int> rep((size_t)K * ntau, -1);          // (k, j) -> index into work
+    for (int k = 0; k < K; ++k) {
+        std::vector<std::pair<double, int>> seen;       // (non-zero count, work index) of this instance
+        for (int j = 0; j < ntau; ++j) {
+            const double cnt = sums[((size_t)j * K + k) * 2 + 1];
+            int w = -1;
+            for (auto& sc : seen)
+                if (sc.first == cnt) w = sc.second;
+            if (w < 0) {
+                w = (int)work.size();
+                work.push_back({k, j});
+                seen.push_back({cnt, w});
+            }
+            rep[(size_t)k * ntau + j] = w;
+        }
+    }
+    const int nwork = (int)work.size();
+    const int nchunk = (nwork + K - 1) / K;
+    std::vector<int> wsrc((size_t)nchunk * K);
+    std::vector<double> wtau((size_t)nchunk * K);
+    for (int i = 0; i < nchunk * K; ++i) {
+        const Item& it = work[i < nwork ? i : 0];        // the tail of the last chunk repeats a valid problem
+        wsrc[i] = it.k;
+        wtau[i] = tau[it.j];
+    }
+    DevBuf dwtau;
+    int* dwsrc = nullptr;
+    HIPCHK(dwtau.alloc(wtau.size()));
+    HIPCHK(hipMalloc(&dwsrc, wsrc.size() * sizeof(int)));
+    IntFree wsrcfree{dwsrc};
+    HIPCHK(hipMemcpyAsync(dwtau.p, wtau.data(), wtau.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dwsrc, wsrc.data(), wsrc.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    std::vector<double> d((size_t)nchunk * K * p);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        launch_threshold_write(c->stream, c->snapT, dwsrc + (size_t)ch * K, dwtau.p + (size_t)ch * K, K, p, c->W);
+        HIPCHK(hipGetLastError());
+        int rc = eigvals_only(c, c->W, c->DvO);
+        if (rc) return rc;
+        c->dvo_valid = false;
+        HIPCHK(hipMemcpyAsync(d.data() + (size_t)ch * K * p, c->DvO, (size_t)K * p * sizeof(double), hipMemcpyDeviceToHost,
+                              c->stream));
+        HIPCHK(hipMemcpyAsync(c->info_h, c->info, K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rc = check_info(c, "threshold scan");
+        if (rc) return rc;
+    }
+    if (n_eig) *n_eig = nwork;
+    std::vector<double> ld((size_t)nwork), mn((size_t)nwork);
+    for (int w = 0; w < nwork; ++w) {
+        double m = INFINITY, l = 0.0;
+        for (int e = 0; e < p; ++e) {
+            const double v = d[(size_t)w * p + e];
+            m = std::min(m, v);
+            l += std::log(v);
+        }
+        mn[w] = m;
+        ld[w] = (m <= 1e-12 || !(m == m)) ? -INFINITY : l;      // robust_logdet, model_selection.py:884-894
+    }
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < ntau; ++j) {
+            double* o = out + ((size_t)k * ntau + j) * 4;
+            const int w = rep[(size_t)k * ntau + j];
+            o[0] = sums[((size_t)j * K + k) * 2 + 0];
+            o[1] = ld[w];
+            o[2] = sums[((size_t)j * K + k) * 2 + 1];
+            o[3] = mn[w];
+        }
+    return GGL_OK;
+}
+
+// numpy.linalg.matrix_rank of the snapshot of L_k (model_selection.py:256, :638): the number of eigenvalues with
+// |lambda| > rel_tol * max|lambda|; rel_tol <= 0 selects numpy's p * eps.  out[k*4..] = { rank, max|lambda|,
+// largest |lambda| NOT counted, smallest |lambda| counted } (0 where there is none): the caller sees how far the
+// decision was from the tolerance.
+extern "C" int ggl_selection_rank(ggl_ctx* c, double rel_tol, double* out)
+{
+    ARGCHK(c && out, "ctx, out");
+    ARGCHK(c->snapL, "no snapshot of L (ggl_snapshot_k after a latent step)");
+    HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
+    const int K = c->K, p = c->p;
+    const size_t kp = (size_t)K * p;
+    if (!(rel_tol > 0.0)) rel_tol = (double)p * 2.220446049250313e-16;
+    HIPCHK(hipMemcpyAsync(c->W, c->snapL, c->n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    int rc = eigvals_only(c, c->W, c->DvO);
+    if (rc) return rc;
+    c->dvo_valid = false;
+    std::vector<double> d(kp);
+    HIPCHK(hipMemcpyAsync(d.data(), c->DvO, kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->info_h, c->info, K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = check_info(c, "rank of the latent component");
+    if (rc) return rc;
+    for (int k = 0; k < K; ++k) {
+        double mx = 0.0;
+        for (int e = 0; e < p; ++e) mx = std::max(mx, std::fabs(d[(size_t)k * p + e]));
+        const double tol = mx * rel_tol;
+        int r = 0;
+        double below = 0.0, above = INFINITY;
+        for (int e = 0; e < p; ++e) {
+            const double a = std::fabs(d[(size_t)k * p + e]);
+            if (a > tol) {
+                r += 1;
+                above = std::min(above, a);
+            } else
+                below = std::max(below, a);
+        }
+        out[k * 4 + 0] = r;
+        out[k * 4 + 1] = mx;
+        out[k * 4 + 2] = below;
+        out[k * 4 + 3] = (r > 0) ? above : 0.0;
+    }
+    return GGL_OK;
+}
 
 static int eig_common(int K, int p, const double* A, const double* beta, double* D, double* Q, double* out, int map,
                       int eig_method)

@@ -60,6 +60,12 @@ void launch_count_nonzero(hipStream_t st, const double* A, int K, int p, double*
 void launch_sub(hipStream_t st, double* D, const double* A, const double* B, size_t n);
 // out[k][0] = sum A*B
 void launch_dot(hipStream_t st, const double* A, const double* B, int K, int p, double* partials);
+// thresholded estimates (helper/model_selection.py:698-705): per slot s, instance src[s] at threshold tauS[s];
+// sums: partials[s][block][2] = {<S,T>, count_nonzero(T)}; write: out[s] = T
+void launch_threshold_sums(hipStream_t st, const double* A, const double* S, const int* src, const double* tauS,
+                           int nslot, int p, double* partials);
+void launch_threshold_write(hipStream_t st, const double* A, const int* src, const double* tauS, int nslot, int p,
+                            double* out);
 // out = A + c * B
 void launch_axpy(hipStream_t st, double* out, const double* A, double c, const double* B, size_t n);
 // out = (Omega - nk_k * S) - rho * X      (argument of the log-det prox in the KKT residual)

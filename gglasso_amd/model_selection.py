@@ -17,7 +17,7 @@ as its ``solver`` argument unchanged (tests/test_reference_dropi
 import numpy as np
 
 from .batch import ADMM_SGL_batch
-from .solver import ADMM_SGL
+from .solver import ADMM_SGL, latent_rank
 
 DEFAULT_GAMMAS = (0.1, 0.3, 0.5, 0.7)        # model_selection.py:17
 _NUMBER = (int, float, np.integer, np.floating)
@@ -79,12 +79,13 @@ def ebic(S, Theta, N, gamma=0.5):
     return sum(ebic_single(S[k], Theta[k], Nk[k], gamma) for k in range(S.shape[0]))
 
 
-def _solve_grid(S, lam, mu, latent, tol, rtol, max_iter):
+def _solve_grid(S, lam, mu, latent, tol, rtol, max_iter, tau_range=None):
     """All (lambda1[, mu1]) instances as ONE batch from the reference's start (Omega_0 = X_0 = identity,
-    model_selection.py:595-596).  S: (p,p) shared, or (n,p,p) one covariance matrix per instance."""
+    model_selection.py:595-596).  S: (p,p) shared, or (n,p,p) one covariance matrix per instance.  ``tau_range``: also
+    score every instance's estimate thresholded at every tau on the GPU (tune_threshold, :707-737)."""
     eye = np.eye(S.shape[-1])
     res = ADMM_SGL_batch(S, lam, Omega_0=eye, X_0=eye, tol=tol, rtol=rtol, latent=latent, mu1=mu, max_iter=max_iter,
-                         selection_stats=True)
+                         selection_stats=True, tau_range=tau_range)
     # per instance: the solution, and <S,Theta>, log det Theta, non-zero count computed on the GPU
     return [s for s, _ in res], [info['selection'] for _, info in res]
 
@@ -112,15 +113,24 @@ def _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma,
             if latent:
                 if store_all:
                     lowrank[j, m] = sol['L']
-                # on the host: matrix_rank's tolerance p*eps*|L| (:638) is below what the device eigensolvers resolve
-                RANK[j, m] = np.linalg.matrix_rank(sol['L'], hermitian=True)
-            if thresholding:
+            d = dev[j * nm + m] if dev is not None else None
+            if latent:
+                # matrix_rank(L) of :638 at the tolerance that fits this library's L (solver.RANK_REL_TOL): from the batch's
+                # device eigenvalues, or on the host for the point-by-point walk
+                RANK[j, m] = d['rank'][0] if (d is not None and 'rank' in d) else latent_rank(sol['L'])
+            if thresholding and d is not None and 'threshold' in d:
+                # scored on the GPU for every tau of the default range; the statistics of the chosen one become the point's
+                jt = _pick_threshold(d['threshold'], N, p, method, gamma)
+                TAU[j, m] = default_tau_range()[jt]
+                sol['Theta'] = Theta = _apply_threshold(Theta, TAU[j, m])
+                d = dict(zip(('Sdot', 'logdet', 'nnz'), d['threshold'][jt, :3]))
+            elif thresholding:
                 sol['Theta'], TAU[j, m], _ = tune_threshold(Theta, S, N, tau_range=None, method=method, gamma=gamma)
                 Theta = sol['Theta']
+                d = None
             # the criteria share the expensive terms <S,Theta> and log det Theta: from the
-            # device statistics of the batch, or on the host for the point-by-point (mask) walk and thresholded estimates
-            if dev is not None and not thresholding:
-                d = dev[j * nm + m]
+            # device statistics of the batch, or on the host for the point-by-point (mask) walk
+            if d is not None:
                 fit = N * d['Sdot'] - N * d['logdet']
                 E0 = (d['nnz'] - p) / 2
                 E = E0
@@ -157,8 +167,9 @@ def single_grid_search(S, lambda_range, N, method='eBIC', gamma=0.3, latent=Fals
     All grid points are solved as ONE batch from the reference's start (Omega_0 = X_0 = identity, :595-596);
     ``use_block`` is accepted and ignored (block splitting changes how a point is solved, not its optimum).
     ``lambda1_mask`` grids run point by point with the reference's warm start (the mask is a per-problem
-    array).  ``thresholding``: each point's estimate is thresholded on the host (tune_threshold, :698-737) before the
-    criteria are taken, as in the reference."""
+    array).  ``thresholding``: each point's estimate is replaced by its best thresholded version (tune_threshold,
+    :698-737) before the criteria are taken, as in the reference; the 20 candidate thresholds of every grid point are scored
+    on the GPU (``ggl_threshold_scan``), the mask walk scores them on the host."""
     assert method in ('AIC', 'eBIC')
     S = np.ascontiguousarray(S, dtype=np.float64)
     p = S.shape[0]
@@ -174,7 +185,7 @@ def single_grid_search(S, lambda_range, N, method='eBIC', gamma=0.3, latent=Fals
     # instance j*nm + m solves (lambda_range[j], mu_range[m])
     if lambda1_mask is None:
         sols, dev = _solve_grid(S, np.repeat(lambda_range, nm), np.tile(mu_range, nl) if latent else None, latent, tol,
-                                rtol, max_iter)
+                                rtol, max_iter, default_tau_range() if thresholding else None)
     else:
         sols, dev = [], None
         Om0 = np.eye(p)
@@ -263,7 +274,7 @@ def K_single_grid(S, lambda_range, N, method='eBIC', gamma=0.3, latent=False, mu
         S_inst = np.repeat(S[list(ks)], per_k, axis=0)
         lam = np.tile(np.repeat(lambda_range, nm), len(ks))
         mu = np.tile(np.tile(mu_range, nl), len(ks)) if latent else None
-        s_, d_ = _solve_grid(S_inst, lam, mu, latent, tol, rtol, max_iter)
+        s_, d_ = _solve_grid(S_inst, lam, mu, latent, tol, rtol, max_iter, default_tau_range() if thresholding else None)
         sols += s_
         dev += d_
 
@@ -351,10 +362,26 @@ def thresholding(A, tau):
     return A * mask
 
 
+_apply_threshold = thresholding        # the functions above take a flag of that name
+
+
+def default_tau_range():
+    return np.logspace(-12, -1, N_TAU)             # model_selection.py:714
+
+
+def _pick_threshold(table, N, p, method, gamma):
+    """tune_threshold's choice (model_selection.py:718-735) from the (ntau, 4) device table of
+    {<S,T>, log det T, count_nonzero(T), lambda_min(T)}: index of the best tau (first of equals, nan = not definite)."""
+    E = (table[:, 2] - p) / 2
+    scores = N * table[:, 0] - N * table[:, 1] + E * ((np.log(N) + 4 * np.log(p) * gamma) if method == 'eBIC' else 1.0)
+    scores[scores == np.inf] = np.nan
+    return int(np.nanargmin(scores))
+
+
 def tune_threshold(Theta, S, N, tau_range=None, method='eBIC', gamma=0.1):
     """model_selection.py:707-737."""
     if tau_range is None:
-        tau_range = np.logspace(-12, -1, N_TAU)
+        tau_range = default_tau_range()
     assert np.all(tau_range > 0)
     scores = np.zeros(len(tau_range))
     for j in range(len(tau_range)):
@@ -439,7 +466,7 @@ def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma
     order = [(g1, g2) for g2 in range(grid2) for g1 in range(grid1)]       # down the columns, as the reference
 
     sols = {}
-    dev = {}
+    dev, dev_thr, dev_rank = {}, {}, {}
     if batched:
         from .batch import ADMM_MGL_batch
         pdim = S.shape[1]
@@ -455,7 +482,8 @@ def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma
             lam1 = np.array([L1[order[i]] for i in idx])
             lam2 = np.array([L2[order[i]] for i in idx])
             mu = np.stack([mu_range[ix_mu[:, order[i][1]]] for i in idx]) if latent else None
-            res = ADMM_MGL_batch(S, lam1, lam2, reg, tol=tol, rtol=rtol, latent=latent, mu1=mu, selection_stats=True)
+            res = ADMM_MGL_batch(S, lam1, lam2, reg, tol=tol, rtol=rtol, latent=latent, mu1=mu, selection_stats=True,
+                                 tau_range=default_tau_range() if thresholding else None)
             local += [(i, r) for i, r in zip(idx, res)]
         if group is not None:
             gathered = [None] * dist.get_world_size(group)
@@ -464,6 +492,10 @@ def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma
         for i, (sol, info) in local:
             sols[order[i]] = sol
             dev[order[i]] = info['selection']
+            if thresholding:
+                dev_thr[order[i]] = info['threshold']
+            if latent:
+                dev_rank[order[i]] = info['rank']
     elif ext_batched:
         from .ext_solver import ext_ADMM_MGL_batch
         pmax = max(S[k].shape[0] for k in range(K))
@@ -497,10 +529,26 @@ def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma
     for (g1, g2) in order:
         sol = sols[(g1, g2)]
         d = dev.get((g1, g2))
-        if d is not None and not thresholding:
+        if d is not None:
+            # the batch's device statistics; with thresholding also those of every instance's estimate at every tau
+            pS = S.shape[1]
             fit = N * d[:, 0] - N * d[:, 1]
-            E = (d[:, 2] - S.shape[1]) / 2
-            SP[g1, g2] = np.mean((d[:, 2] - S.shape[1]) / (S.shape[1] ** 2 - S.shape[1]))
+            nnz = d[:, 2].copy()
+            E = (nnz - pS) / 2
+            if thresholding:
+                score0 = np.sum(fit + E * (np.log(N) + 4 * np.log(pS) * gamma))
+                if score0 < no_thr_min:
+                    no_thr_min, no_thr_best = score0, sol.copy()
+                    no_thr_params = {'lambda1': L1[g1, g2], 'lambda2': L2[g1, g2]}
+                sol['Theta'] = sol['Theta'].copy()
+                for k in range(K):
+                    tab = dev_thr[(g1, g2)][k]
+                    jt = _pick_threshold(tab, N[k], pS, method, gamma)
+                    TAU[k, g1, g2] = default_tau_range()[jt]
+                    sol['Theta'][k] = _apply_threshold(sol['Theta'][k], TAU[k, g1, g2])
+                    fit[k], nnz[k] = N[k] * tab[jt, 0] - N[k] * tab[jt, 1], tab[jt, 2]
+                E = (nnz - pS) / 2
+            SP[g1, g2] = np.mean((nnz - pS) / (pS ** 2 - pS))
         else:
             if thresholding:
                 fit0, E0 = _criteria(S, sol['Theta'], N, K)
@@ -519,7 +567,10 @@ def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma
         for g in gammas:
             BIC[g][g1, g2] = np.sum(fit + E * (np.log(Nk) + 4 * np.log(pk) * g))
         if latent:
-            RANK[:, g1, g2] = [np.linalg.matrix_rank(sol['L'][k]) for k in range(K)]
+            if (g1, g2) in dev_rank:
+                RANK[:, g1, g2] = dev_rank[(g1, g2)][:, 0]
+            else:
+                RANK[:, g1, g2] = [latent_rank(sol['L'][k]) for k in range(K)]
         score = BIC[gamma][g1, g2] if method == 'eBIC' else AIC[g1, g2]
         if score < curr_min:
             curr_min = score

@@ -27,6 +27,21 @@ _REG = {"SGL": _lib.REG_SGL, "GGL": _lib.REG_GGL, "FGL": _lib.REG_FGL}
 ENGINE_OPTIONS = {}
 
 
+# Rank of the latent component in the model-selection tables (helper/model_selection.py:256, :638 call
+# numpy.linalg.matrix_rank, i.e. #{|lambda_i| > p * eps * max|lambda|}).  That tolerance fits an L rebuilt from an
+# eigendecomposition (null space at 1e-16 |L|).  Above p = 128 the L-step is the sign iteration and the null space of its L
+# carries the iteration's residual -- measured 4e-14 .. 7e-13 |L| (tools/probe_rank_noise.py), which numpy's rule counts as
+# rank (22 instead of 6 at p = 500); the device eigensolvers add ~3e-14 |L| of their own.  Every eigenvalue the prox keeps
+# is (lambda_i(C) - mu)_+: to be missed by the cut below, an eigenvalue of C has to sit within 1e-9 |L| of the threshold.
+RANK_REL_TOL = 1e-9
+
+
+def latent_rank(L, rel_tol=RANK_REL_TOL):
+    """Host counterpart of ``HipEngine.selection_rank`` for one symmetric (p,p) L."""
+    a = np.abs(np.linalg.eigvalsh(L))
+    return int(np.count_nonzero(a > a.max() * max(rel_tol, L.shape[0] * np.finfo(np.float64).eps)))
+
+
 class HipEngine:
     """Device-resident ADMM state behind the C ABI (one ggl_ctx)."""
 
@@ -203,6 +218,23 @@ class HipEngine:
         of every instance's snapshot."""
         out = np.zeros((self.K, 4))
         check(self.lib.ggl_selection_stats(self.h, ptr(out)))
+        return out
+
+    def threshold_scan(self, tau_range):
+        """(K, len(tau_range), 4): the four selection statistics of every snapshot thresholded at every tau
+        (helper/model_selection.py:698-737); second value: eigenvalue problems solved for them."""
+        import ctypes
+        tau = as_c(np.asarray(tau_range, dtype=np.float64))
+        out = np.zeros((self.K, tau.size, 4))
+        n_eig = ctypes.c_int(0)
+        check(self.lib.ggl_threshold_scan(self.h, ptr(tau), int(tau.size), ptr(out), ctypes.byref(n_eig)))
+        return out, int(n_eig.value)
+
+    def selection_rank(self, rel_tol=0.0):
+        """(K,4): rank of every L snapshot at the relative tolerance (<= 0: numpy.linalg.matrix_rank's p*eps),
+        max|lambda|, the largest |lambda| left out and the smallest one counted."""
+        out = np.zeros((self.K, 4))
+        check(self.lib.ggl_selection_rank(self.h, float(rel_tol), ptr(out)))
         return out
 
     def objective(self, lambda1, lambda2, reg):

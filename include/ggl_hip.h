@@ -287,10 +287,22 @@ int ggl_ext_batch_step(ggl_ctx *ctx, double rho, const double *lambda1K, const d
  * ggl_snapshot_k keeps a device copy of instance k's Theta at the moment the host loop declares it converged;
  * ggl_selection_stats then returns, for every instance's snapshot,
  * out[k*4..] = { <S_k,Theta_k>, log det Theta_k (-inf if lambda_min <= 1e-12), count_nonzero(Theta_k),
- * lambda_min(Theta_k) }.  (The rank of the latent component is left to the host: numpy's matrix_rank tolerance
- * p*eps*|L| is below the absolute accuracy of the device eigensolvers.) */
+ * lambda_min(Theta_k) }.  After a latent step ggl_snapshot_k keeps L_k as well.
+ *
+ * ggl_threshold_scan: tune_threshold (helper/model_selection.py:707-737, thresholding :698-705) for every snapshot at
+ * once: out[(k*ntau + j)*4..] = the same four numbers for T = Theta_k with the off-diagonal entries |t| <= tau[j]
+ * zeroed.  Thresholds that zero the same entries of an instance give the same matrix; only the distinct ones go
+ * through the eigenvalue kernel (*n_eig = how many, may be NULL).
+ *
+ * ggl_selection_rank: numpy.linalg.matrix_rank of every L_k snapshot (model_selection.py:256, :638):
+ * out[k*4..] = { #{|lambda_i| > rel_tol * max|lambda|}, max|lambda|, largest |lambda| not counted, smallest |lambda|
+ * counted }; rel_tol <= 0: numpy's p*eps.  The two neighbours of the cut let the caller see how clear the decision
+ * was: the null space of an L that came out of the sign-iteration L-step (p > GGL_JACOBI_MAX_P) carries that
+ * iteration's residual (~1e-12 |L|), far above numpy's tolerance but far below any eigenvalue the prox keeps. */
 int ggl_snapshot_k(ggl_ctx *ctx, int k);
 int ggl_selection_stats(ggl_ctx *ctx, double *out);
+int ggl_threshold_scan(ggl_ctx *ctx, const double *tau, int ntau, double *out, int *n_eig);
+int ggl_selection_rank(ggl_ctx *ctx, double rel_tol, double *out);
 /* Objective pieces for measure=True (admm_solver.py:213): out = {sum_k -logdet Omega_k,
  * <Omega,S>, P_val(Theta)} (ggl_helper.py:266-270,162-176). */
 int ggl_objective(ggl_ctx *ctx, double lambda1, double lambda2, int reg, double out[3]);

@@ -30,6 +30,7 @@ class OracleEngine:
         self.dims = None if pk is None else np.asarray(pk, dtype=int)
 
     def step_omega(self, rho, latent, nk):
+        self._latent_seen = bool(latent)
         nk = np.ones(self.K) if nk is None else np.asarray(nk, dtype=np.float64)
         W = self.Th - self.L - self.X - (nk[:, None, None] / rho) * self.S
         self.Om_prev = self.Om
@@ -72,6 +73,7 @@ class OracleEngine:
 
     # K independent single problems (batched lambda path)
     def sgl_batch_step(self, rho, lambda1, latent, mu1):
+        self._latent_seen = bool(latent)
         rho = np.asarray(rho, dtype=np.float64)
         out = np.zeros((self.K, 5))
         Om_new = np.empty_like(self.Om)
@@ -103,6 +105,7 @@ class OracleEngine:
 
     # G independent multiple-graph problems, problem g = instances g*K/G .. (batched lambda1 x lambda2 grid)
     def mgl_batch_step(self, G, rho, lambda1, lambda2, reg, latent, mu1, nk):
+        self._latent_seen = bool(latent)
         Kp = self.K // G
         out = np.zeros((G, 5))
         Om_new = np.empty_like(self.Om)
@@ -131,6 +134,38 @@ class OracleEngine:
         if not hasattr(self, "_snapT"):
             self._snapT = np.zeros_like(self.Th)
         self._snapT[k] = self.Th[k]
+        if getattr(self, "_latent_seen", False):
+            if not hasattr(self, "_snapL"):
+                self._snapL = np.zeros_like(self.L)
+            self._snapL[k] = self.L[k]
+
+    def threshold_scan(self, tau_range):
+        tau_range = np.asarray(tau_range, dtype=np.float64)
+        K = self.Th.shape[0]
+        out = np.zeros((K, tau_range.size, 4))
+        distinct = 0
+        for k in range(K):
+            counts = set()
+            for j, tau in enumerate(tau_range):
+                m = np.abs(self._snapT[k]) > tau
+                np.fill_diagonal(m, True)
+                T = self._snapT[k] * m
+                d = np.linalg.eigvalsh(T)
+                out[k, j] = [np.sum(self.S[k] * T), -np.inf if d.min() <= 1e-12 else np.linalg.slogdet(T)[1],
+                             np.count_nonzero(T), d.min()]
+                counts.add(int(out[k, j, 2]))
+            distinct += len(counts)
+        return out, distinct
+
+    def selection_rank(self, rel_tol=0.0):
+        K = self.Th.shape[0]
+        rel = rel_tol if rel_tol > 0 else self.p * np.finfo(float).eps
+        out = np.zeros((K, 4))
+        for k in range(K):
+            a = np.abs(np.linalg.eigvalsh(self._snapL[k]))
+            keep = a > a.max() * rel
+            out[k] = [keep.sum(), a.max(), a[~keep].max() if (~keep).any() else 0.0, a[keep].min() if keep.any() else 0.0]
+        return out
 
     def selection_stats(self):
         K = self.Th.shape[0]
