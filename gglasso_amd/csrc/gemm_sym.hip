@@ -447,7 +447,33 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
             }
         }
     };
-    const bool dead_wave = (I == J) && (wr >= wc + WN);
+    // Which 16x16 blocks this wave owns.  acc[i][j] belongs to rows rbk[i].., columns cbk[j].. of the tile and the MFMAs
+    // of a k-quad run in the order X = acc[0][0], Y = acc[0][1], Z = acc[1][1], U = acc[1][0].  Off-diagonal tiles: the
+    // wave's own 32x32 quadrant, all four.  A DIAGONAL tile is written from its upper triangle (in-tile mirror), i.e. 10
+    // of its 16 blocks: the two diagonal quadrants need X, Y, Z (U lies below the diagonal); the upper-right quadrant needs
+    // all four, and the wave of the lower-left quadrant would have nothing to do -- it takes that quadrant's block (1,1)
+    // instead, and the quadrant's own wave names its column blocks the other way round so that what is left to it is again
+    // X, Y, Z.  Every wave of a diagonal tile then skips U: 3 MFMAs per k-quad instead of 4 on the 8 diagonal tiles of the
+    // 36 of a p = 500 product, for ONE wave-uniform branch per k-quad (the fourth wave runs Y and Z on accumulators nobody
+    // reads: its SIMD would otherwise idle).  Where that branch sits matters more than what it saves: U is issued FIRST,
+    // straight behind the k-quad's exit check (two adjacent scalar branches: +1.9 % at the headline, 0.0 % at p = 1000);
+    // behind X, Y, Z, or as X / branch / Y Z / branch / U, the off-diagonal tiles lose 0.8-1.5 % at p = 1000, and a
+    // separate copy of the k-quad loop for the partial waves makes the allocator shuffle the accumulators between the two
+    // (-21 %).  In-box A/B: profiles/r3_product_kernel_round3.txt.  Same blocks, same k order: same bits.
+    constexpr bool REBAL = (TI == 2 && TJ == 2 && NW == 4);
+    int rbk[TI], cbk[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) rbk[i] = wr + 16 * i;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) cbk[j] = wc + 16 * j;
+    const bool skipU = REBAL && I == J;
+    int nval = TI * TJ;                                   // accumulators that hold blocks of the tile: X [, Y, Z [, U]]
+    if (skipU) {
+        nval = 3;
+        if (wave == 1) { cbk[0] = wc + 16; cbk[TJ - 1] = wc; }                                   // X=(0,3) Y=(0,2) Z=(1,2)
+        else if (wave == 2) { rbk[0] = 16; rbk[TI - 1] = 0; cbk[0] = WN + 16; cbk[TJ - 1] = WN; nval = 1; }   // X=(1,3)
+    }
+    const bool dead_wave = !REBAL && (I == J) && (wr >= wc + WN);
     const int S = (p + BK - 1) / BK;
 #pragma unroll
     for (int q = 0; q < NSTG - 1; ++q)
@@ -460,9 +486,9 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
     const double* pfa[TI];
     const double* pfb[TJ];
 #pragma unroll
-    for (int i = 0; i < TI; ++i) pfa[i] = smem + fg * BM + ((wr + i * 16 + (lane & 15)) ^ fsw);
+    for (int i = 0; i < TI; ++i) pfa[i] = smem + fg * BM + ((rbk[i] + (lane & 15)) ^ fsw);
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) pfb[j] = smem + SLAB + fg * BM + ((wc + j * 16 + (lane & 15)) ^ fsw);
+    for (int j = 0; j < TJ; ++j) pfb[j] = smem + SLAB + fg * BM + ((cbk[j] + (lane & 15)) ^ fsw);
     auto slab = [&](const int s, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         // this wave's DMA of slab s has landed: at most the later slabs' instructions may still be in flight
@@ -505,13 +531,20 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
                 for (int i = 0; i < TI; ++i) af[i] = pfa[i][so + kq4 * 4 * BM];
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) bf[j] = pfb[j][so + kq4 * 4 * BM];
+                if constexpr (REBAL && ABL != 3) {
+                    if (!skipU) acc[TI - 1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[TI - 1], bf[0], acc[TI - 1][0], 0, 0, 0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0], bf[0], acc[0][0], 0, 0, 0);
+                    acc[0][TJ - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0], bf[TJ - 1], acc[0][TJ - 1], 0, 0, 0);
+                    acc[TI - 1][TJ - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[TI - 1], bf[TJ - 1], acc[TI - 1][TJ - 1], 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int i = 0; i < TI; ++i)
+                    for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < TJ; ++j) {
-                        if (ABL == 3) { acc[i][j][0] += af[i] * bf[j]; continue; }   // timing ablation: no MFMA
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-                    }
+                        for (int j = 0; j < TJ; ++j) {
+                            if (ABL == 3) { acc[i][j][0] += af[i] * bf[j]; continue; }   // timing ablation: no MFMA
+                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        }
+                }
             }
         }
     };
@@ -594,14 +627,23 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
             }
         }
     } else {
+    if (REBAL && I == J && rowpart && ABL != 1) {
+        // the staged tile of the bound partials wants zeros below the diagonal: the six blocks no wave owns any more
+        for (int e = tid; e < 6 * 256; e += NT) {
+            const int blk = e >> 8, br = (blk < 1) ? 1 : (blk < 3 ? 2 : 3), bc = blk - (br == 1 ? 0 : (br == 2 ? 1 : 3));
+            const int row = br * 16 + ((e >> 4) & 15), col = bc * 16 + (e & 15);
+            smem[row * BM + (col ^ row)] = 0.0;
+        }
+    }
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < TJ; ++tj)
+        for (int tj = 0; tj < TJ; ++tj) {
+            if (REBAL && ((ti != tj && tj == 0 && nval <= 3) || ((ti | tj) != 0 && nval <= 1))) continue;   // not a block of the tile
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = wr + ti * 16 + (lane >> 4) + 4 * r;
-                const int col = wc + tj * 16 + (lane & 15);
+                const int row = rbk[ti] + (lane >> 4) + 4 * r;
+                const int col = cbk[tj] + (lane & 15);
                 const int gi = I0 + row, gj = J0 + col;
                 double v = cAcc * acc[ti][tj][r];
                 const bool keep = gi < p && gj < p && (I != J || gi <= gj);
@@ -621,6 +663,7 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
                 // bound partials every tile is staged (entries that are not stored count as zero)
                 if ((I != J || rowpart) && ABL != 1) smem[row * BM + (col ^ row)] = (rowpart && !keep) ? 0.0 : v;
             }
+        }
     }
     if (maxdev) {
         dev = wave_max(dev);
