@@ -13,6 +13,8 @@
 // current one is consumed from LDS (software prefetch), one barrier pair per slab.
 #include <algorithm>
 #include <initializer_list>
+#include <mutex>
+#include <unordered_map>
 #include <type_traits>
 
 #include "common.hpp"
@@ -753,6 +755,331 @@ __global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ 
     symm_dl_tile<BK, NSTG, ABL, BM, NW>(A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, k, b);
 }
 
+#ifdef GGL_DEV
+// ---------------------------------------------------------------------------------------------
+// k_symm_sk: the product for batches that leave the chip UNDER-FILLED (the K-sharded slabs K = 2..8 at p = 500, (20,200)):
+// 32x32 output tiles, and the four waves of a workgroup split the k-range of ONE tile instead of its area.
+//
+// MEASURED, NOT SHIPPED (dev build only; profiles/r3_small_batch_split_k.txt): as fast as the 32x32 direct-to-LDS kernel,
+// not faster, and slower with the k-range split over workgroups -- the under-filled launches are bound by fixed latencies
+// (launch, first DMA, epilogue: ~6.5 us) plus whole tiles per CU, not by what a wave does per k-quad.
+// The 32x32 direct-to-LDS kernel gives each wave one 16x16 block: per k-quad two fragment reads, an LDS round trip and ONE
+// MFMA, a workgroup barrier per slab.  Here every wave owns the whole tile (2x2 blocks: two + two
+// fragment reads feed FOUR independent MFMAs) over the k-slabs s = wave, wave+4, wave+8, ...; it streams ITS slabs into
+// ITS quarter of the LDS through its own DMA pipeline (NSTG stages) and waits for nobody -- no barrier in the main loop at
+// all.  The four partial tiles meet in LDS at the end (one barrier), are summed in a fixed order (wave 0..3:
+// deterministic), and the epilogue (affine terms, second output, mirror, bound partials) runs on the sums.
+// Diagonal tiles take the upper triangle's sums for both halves: the output is symmetric bit for bit.
+// ---------------------------------------------------------------------------------------------
+//
+// SPLIT > 1: the k-range of a tile is dealt over SPLIT workgroups as well (slab s goes to workgroup (s / 4) % SPLIT, wave
+// s % 4) -- 544 tiles on 256 CUs leave some CUs three tiles and the launch ends when those do; 2176 quarter-tiles pack to
+// within 6 %.  Each workgroup leaves the sum of its four waves in a global scratch tile (write-through stores), then one
+// memory-side atomic per workgroup counts the arrivals; the LAST one adds the SPLIT scratch tiles in part order (so the
+// result does not depend on who was last) and runs the epilogue.  No cache write-back / invalidate fences anywhere
+// (see k_cw_final): stores, loads and the counter are agent-scope atomics.  The counter is left at zero.
+template <int SPLIT> __device__ __forceinline__ bool sk_decode(int ntiles, int K, int L, int& k, int& tile, int& part)
+{
+    // as decode_block_xcd, over ntiles * SPLIT units per instance with the SPLIT parts of a tile in consecutive slots
+    auto small = [&](int Ks, int Ls) {
+        const int g = xcd_share(Ks);
+        if (g) {
+            const int xcd = Ls % NXCD, slot = Ls / NXCD;
+            k = xcd / g;
+            tile = (slot / SPLIT) * g + xcd % g;
+            part = slot % SPLIT;
+            return tile < ntiles;
+        }
+        const int u = Ls % (ntiles * SPLIT);
+        k = Ls / (ntiles * SPLIT);
+        tile = u / SPLIT;
+        part = u % SPLIT;
+        return k < Ks;
+    };
+    if (K < NXCD) return small(K, L);
+    const int nfull = NXCD * (K / NXCD) * ntiles * SPLIT;
+    if (L < nfull) {
+        const int xcd = L % NXCD, slot = L / NXCD, u = slot % (ntiles * SPLIT);
+        k = (slot / (ntiles * SPLIT)) * NXCD + xcd;
+        tile = u / SPLIT;
+        part = u % SPLIT;
+        return true;
+    }
+    const bool ok = small(K % NXCD, L - nfull);
+    k += (K / NXCD) * NXCD;
+    return ok;
+}
+inline int sk_grid_small(int ntiles, int K, int split)
+{
+    const int g = xcd_share(K);
+    return g ? NXCD * ((ntiles + g - 1) / g) * split : NXCD * ((ntiles * split * K + NXCD - 1) / NXCD);
+}
+inline int sk_grid(int ntiles, int K, int split)
+{
+    if (K < NXCD) return sk_grid_small(ntiles, K, split);
+    const int r = K % NXCD;
+    return NXCD * (K / NXCD) * ntiles * split + (r ? sk_grid_small(ntiles, r, split) : 0);
+}
+
+template <int BK, int NSTG, int SPLIT>
+__global__ __launch_bounds__(256) void k_symm_sk(const double* __restrict__ A, const double* __restrict__ B,
+                                                 double* __restrict__ C, double* __restrict__ C2,
+                                                 const double* __restrict__ E, const double* __restrict__ coef, int K,
+                                                 int p, double* __restrict__ maxdev, double* __restrict__ rowpart,
+                                                 double* __restrict__ fropart, double* __restrict__ scratch,
+                                                 unsigned* __restrict__ arrivals)
+{
+    constexpr int BM = 32;
+    constexpr int SLAB = BK * BM;                       // doubles per operand slab
+    constexpr int IPS = BK / 4;                         // DMA instructions per operand and slab: 4 rows x 32 doubles = 1 KiB each
+    constexpr int WREG = NSTG * 2 * SLAB;               // doubles of LDS per wave: [stage][A|B][BK][32]; later its partial tile
+    static_assert(BK % 4 == 0 && IPS >= 1, "slab depth");
+    static_assert(WREG >= BM * BM, "a wave's region takes its partial tile");
+    static_assert(NSTG >= 2 && NSTG <= 4, "stages");
+    __shared__ __attribute__((aligned(16))) double smem[4 * WREG];
+    __shared__ int last_s;
+    const int T = (p + BM - 1) / BM;
+    const int ntiles = T * (T + 1) / 2;
+    int k, b, part = 0;
+    if constexpr (SPLIT > 1) { if (!sk_decode<SPLIT>(ntiles, K, (int)blockIdx.x, k, b, part)) return; }
+    else { if (!decode_block_xcd(ntiles, K, k, b)) return; }
+    const int blockTile = b;
+    int I = 0;
+    while (b >= T - I) { b -= T - I; ++I; }
+    const int J = I + b;
+    const int I0 = I * BM, J0 = J * BM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t pp = (size_t)p * p;
+    const double* Ak = A + (size_t)k * pp;
+    const double* Bk = B + (size_t)k * pp;
+    double* wbase = smem + (size_t)wave * WREG;
+    const int sfirst = 4 * part + wave, sstep = 4 * SPLIT;          // this wave's slabs: sfirst, sfirst + sstep, ...
+
+    v4d acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    // DMA geometry (as k_symm_dl at BM = 32): lane l -> slab row 4i + (l >> 4), LDS position (l & 15) * 2, source column
+    // position ^ 16 * (row & 1) -- the XOR keeps the fragment reads of a k-quad (four consecutive rows) off each other's banks
+    const unsigned pu = (unsigned)p, pm1 = (unsigned)(p - 1), pm2 = (unsigned)(p - 2);
+    const int lrow = lane >> 4;
+    const unsigned cpos = (unsigned)((lane & 15) * 2) ^ (unsigned)(16 * (lrow & 1));
+    const unsigned ca = min((unsigned)I0 + cpos, pm2), cb = min((unsigned)J0 + cpos, pm2);
+    const int S = (p + BK - 1) / BK;                    // slabs of the whole k-range
+    const int nw = (S > sfirst) ? (S - sfirst + sstep - 1) / sstep : 0;
+    auto issue = [&](int j, int stage) {
+        const int m0 = (sfirst + sstep * j) * BK;
+        double* base = wbase + (size_t)stage * 2 * SLAB;
+#pragma unroll
+        for (int i = 0; i < IPS; ++i) {
+            const unsigned ro = min((unsigned)(m0 + 4 * i + lrow), pm1) * pu;
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ak + ro + ca), (lptr_t)(base + i * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Bk + ro + cb), (lptr_t)(base + SLAB + i * 128), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < NSTG - 1; ++q)
+        if (q < nw) issue(q, q);
+    const int fg = lane >> 4, fsw = 16 * (fg & 1);
+    int fa[2], fb[2];                                   // fragment positions in k-quad 0 of a stage image
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        fa[i] = fg * BM + ((i * 16 + (lane & 15)) ^ fsw);
+        fb[i] = SLAB + fg * BM + ((i * 16 + (lane & 15)) ^ fsw);
+    }
+    int stage = 0;
+    for (int j = 0; j < nw; ++j) {
+        // this wave's DMA of its slab j has landed: at most the slabs issued after it may still be in flight
+        const int ahead = min(NSTG - 2, nw - 1 - j);
+        if (NSTG >= 4 && ahead >= 2) wait_vmcnt<4 * IPS>();
+        else if (NSTG >= 3 && ahead >= 1) wait_vmcnt<2 * IPS>();
+        else wait_vmcnt<0>();
+        const double* st = wbase + (size_t)stage * 2 * SLAB;
+        const int valid = p - (sfirst + sstep * j) * BK;      // k-rows of this slab inside the matrix
+        if (valid < BK) {
+            double* stw = wbase + (size_t)stage * 2 * SLAB;
+            for (int e = lane; e < BK * BM; e += 64)
+                if (e / BM >= valid) { stw[e] = 0.0; stw[SLAB + e] = 0.0; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // the stage slab j-1 was read from is free: its fragment reads completed before the MFMAs that consumed them issued
+        if (j + NSTG - 1 < nw) issue(j + NSTG - 1, (stage + NSTG - 1) % NSTG);
+        const int nq = min(BK / 4, (valid + 3) / 4);
+#pragma unroll
+        for (int kq = 0; kq < BK / 4; ++kq) {
+            if (kq >= nq) break;
+            const double a0 = st[fa[0] + kq * 4 * BM], a1 = st[fa[1] + kq * 4 * BM];
+            const double b0 = st[fb[0] + kq * 4 * BM], b1 = st[fb[1] + kq * 4 * BM];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        stage = (stage + 1 == NSTG) ? 0 : stage + 1;
+    }
+    // the wave's partial tile over its own slabs, plain [row][col]
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                wbase[(ti * 16 + (lane >> 4) + 4 * r) * BM + tj * 16 + (lane & 15)] = acc[ti][tj][r];
+    __syncthreads();
+
+    const double cI = coef[k * NS_NCOEF + 0], cAcc = coef[k * NS_NCOEF + 1], cE = coef[k * NS_NCOEF + 2];
+    const double dI = coef[k * NS_NCOEF + 3], dC = coef[k * NS_NCOEF + 4], dE = coef[k * NS_NCOEF + 5];
+    double* Ck = C + (size_t)k * pp;
+    double* C2k = C2 ? C2 + (size_t)k * pp : nullptr;
+    const double* Ek = E ? E + (size_t)k * pp : nullptr;
+    // thread -> row (tid >> 3), columns c0 .. c0 + 3 of the tile; the four partials are added in wave order
+    const int row = tid >> 3, c0 = (tid & 7) * 4;
+    const int gi = I0 + row;
+    double sum[4];
+    if constexpr (SPLIT > 1) {
+        // this workgroup's share of the tile -> scratch; the last workgroup of the tile to arrive carries on with the total
+        double* mine = scratch + (((size_t)k * ntiles + blockTile) * SPLIT + part) * (BM * BM);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = row * BM + c0 + i;
+            double t = smem[o];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) t += smem[(size_t)w * WREG + o];
+            __hip_atomic_store(mine + o, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned* cell = arrivals + (size_t)k * ntiles + blockTile;
+            const unsigned old = __hip_atomic_fetch_add(cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_s = (old == SPLIT - 1);
+            if (old == SPLIT - 1) __hip_atomic_store(cell, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!last_s) return;
+        const double* all = scratch + ((size_t)k * ntiles + blockTile) * SPLIT * (BM * BM);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + i, o = (I != J || row <= c) ? row * BM + c : c * BM + row;
+            double t = __hip_atomic_load(all + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int g = 1; g < SPLIT; ++g)
+                t += __hip_atomic_load(all + (size_t)g * (BM * BM) + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum[i] = t;
+        }
+    } else if (I != J) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double2 t = *reinterpret_cast<const double2*>(smem + row * BM + c0 + 2 * h);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const double2 u = *reinterpret_cast<const double2*>(smem + (size_t)w * WREG + row * BM + c0 + 2 * h);
+                t.x += u.x;
+                t.y += u.y;
+            }
+            sum[2 * h] = t.x;
+            sum[2 * h + 1] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + i, o = (row <= c) ? row * BM + c : c * BM + row;       // the upper triangle's sums, both ways
+            double t = smem[o];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) t += smem[(size_t)w * WREG + o];
+            sum[i] = t;
+        }
+    }
+    double dev = 0.0, val[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int gj = J0 + c0 + 2 * h;
+        val[2 * h] = 0.0;
+        val[2 * h + 1] = 0.0;
+        if (gi < p && gj < p) {                         // p is even and gj is: the pair is inside or outside together
+            double2 e = {0.0, 0.0};
+            if (Ek) e = *reinterpret_cast<const double2*>(Ek + (size_t)gi * p + gj);
+            double2 v;
+            v.x = cAcc * sum[2 * h];
+            v.y = cAcc * sum[2 * h + 1];
+            if (gi == gj) v.x += cI;
+            if (gi == gj + 1) v.y += cI;
+            v.x += cE * e.x;
+            v.y += cE * e.y;
+            dev = fmax(dev, fmax(fabs(v.x - (gi == gj ? 1.0 : 0.0)), fabs(v.y - (gi == gj + 1 ? 1.0 : 0.0))));
+            *reinterpret_cast<double2*>(Ck + (size_t)gi * p + gj) = v;
+            if (C2k) {
+                double2 w2;
+                w2.x = c2val(dC, v.x, dE, e.x) + (gi == gj ? dI : 0.0);
+                w2.y = c2val(dC, v.y, dE, e.y) + (gi == gj + 1 ? dI : 0.0);
+                *reinterpret_cast<double2*>(C2k + (size_t)gi * p + gj) = w2;
+            }
+            val[2 * h] = v.x;
+            val[2 * h + 1] = v.y;
+        }
+    }
+    if (maxdev) {
+        dev = wave_max(dev);
+        if (lane == 0 && dev > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long*>(maxdev + k), (unsigned long long)__double_as_longlong(dev));
+    }
+    if (I == J && !rowpart) return;
+    // the final tile (zeros outside the matrix) for the mirror and the bound partials: over wave 0's partial, once everybody
+    // has read the partials
+    __syncthreads();
+    *reinterpret_cast<double2*>(smem + row * BM + c0) = double2{val[0], val[1]};
+    *reinterpret_cast<double2*>(smem + row * BM + c0 + 2) = double2{val[2], val[3]};
+    __syncthreads();
+    if (I != J) {
+        // mirror: row a of it is column a of the tile; E is bitwise symmetric (an output of this kernel family)
+        const int a = row, gm = J0 + a;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + 2 * h, gc = I0 + c;
+            if (gm < p && gc < p) {
+                double2 v;
+                v.x = smem[c * BM + a];
+                v.y = smem[(c + 1) * BM + a];
+                *reinterpret_cast<double2*>(Ck + (size_t)gm * p + gc) = v;
+                if (C2k) {
+                    double2 e = {0.0, 0.0};
+                    if (Ek && dE != 0.0) e = *reinterpret_cast<const double2*>(Ek + (size_t)gm * p + gc);
+                    double2 w2;
+                    w2.x = c2val(dC, v.x, dE, e.x);
+                    w2.y = c2val(dC, v.y, dE, e.y);
+                    *reinterpret_cast<double2*>(C2k + (size_t)gm * p + gc) = w2;
+                }
+            }
+        }
+    }
+    if (rowpart && tid < 2 * BM) {
+        // threads 0..31: row t of the tile; threads 32..63 (off-diagonal tiles): column t, i.e. row J0 + t of the mirror.
+        // A diagonal tile is complete (both triangles) here.
+        const int t = tid & (BM - 1);
+        const bool second = tid >= BM;
+        double rs = 0.0, sq = 0.0;
+        if (!second) {
+#pragma unroll 8
+            for (int c = 0; c < BM; ++c) { const double x = smem[t * BM + ((c + t) & (BM - 1))]; rs += fabs(x); sq += x * x; }
+        } else if (I != J) {
+#pragma unroll 8
+            for (int r = 0; r < BM; ++r) rs += fabs(smem[((r + t) & (BM - 1)) * BM + t]);
+        }
+        if (I != J) sq *= 2.0;                          // the mirror has the same squares
+        if (I != J || !second) {
+            const int slot = second ? I : J, gr = (second ? J0 : I0) + t;
+            if (gr < p) rowpart[((size_t)k * T + slot) * (size_t)p + gr] = rs;
+        }
+        sq = wave_sum(second ? 0.0 : sq);               // tid < 64: wave 0
+        if (tid == 0) fropart[(size_t)k * (T * (T + 1) / 2) + blockTile] = sq;
+    }
+}
+
+#endif   // GGL_DEV (k_symm_sk)
+
 // ---------------------------------------------------------------------------------------------
 // k_omega_chain: the WHOLE product chain of an Omega-step (A', B', the Newton-Schulz products, Omega) of a batch in ONE
 // persistent launch, with the dependencies kept where they are: per INSTANCE.  Product s+1 of instance k needs product s of
@@ -1292,15 +1619,82 @@ static constexpr long SMALL_BATCH_TILES = 800;   // up to here the 32x32-tile ke
 // A GGL_DEV build (libggl_hip_dev.so) adds the measured alternatives 1-5, 8, 11-13, 18, 19, 22 / 23 (64x64 with EIGHT
 // waves per workgroup), 24-29 (other slab / prefetch depths of the 32x32 kernel, see launch_dl) and the ablations 6, 7, 10,
 // 14, 15, 21 (tools/bench_*.py).
-int symm_variants() { return 39; }
+// 41-45: k_symm_sk, the split-K kernel of the under-filled batches: <BK, stages> = <8,3> <8,4> <16,2> <8,2> <4,4>
+// (48 / 64 / 64 / 32 / 32 KiB of LDS per workgroup); 46-50: the same with the k-range of a tile dealt over 2 / 4 workgroups.  40 is not a launch variant: ggl_ns_stats reports it for k_omega_chain.
+int symm_variants() { return 50; }
 bool symm_variant_built(int v)
 {
 #ifdef GGL_DEV
-    return v >= 0 && v <= 39;
+    return v >= 0 && v <= 50 && v != 40;
 #else
     return v == 0 || v == 9 || v == 16 || v == 17 || v == 20;
 #endif
 }
+
+#ifdef GGL_DEV
+// scratch tiles and arrival counters of the SPLIT > 1 launches, one set per stream (launches on a stream are ordered, so a
+// set is never shared by two launches in flight); grown on demand, released by symm_release_workspace()
+namespace {
+struct SkWork { double* scratch = nullptr; unsigned* arrivals = nullptr; size_t tiles = 0, units = 0; };
+std::mutex sk_mutex;
+std::unordered_map<hipStream_t, SkWork> sk_work;
+}
+static bool sk_workspace(hipStream_t st, size_t tiles, size_t units, double** scratch, unsigned** arrivals)
+{
+    std::lock_guard<std::mutex> lock(sk_mutex);
+    SkWork& w = sk_work[st];
+    if (w.tiles < tiles || w.units < units) {
+        if (w.scratch) { (void)hipStreamSynchronize(st); (void)hipFree(w.scratch); (void)hipFree(w.arrivals); w = SkWork(); }
+        if (hipMalloc(&w.scratch, units * 1024 * sizeof(double)) != hipSuccess) return false;
+        if (hipMalloc(&w.arrivals, tiles * sizeof(unsigned)) != hipSuccess) return false;
+        if (hipMemset(w.arrivals, 0, tiles * sizeof(unsigned)) != hipSuccess) return false;
+        w.tiles = tiles;
+        w.units = units;
+    }
+    *scratch = w.scratch;
+    *arrivals = w.arrivals;
+    return true;
+}
+void symm_release_workspace(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(sk_mutex);
+    auto it = sk_work.find(st);
+    if (it == sk_work.end()) return;
+    (void)hipFree(it->second.scratch);
+    (void)hipFree(it->second.arrivals);
+    sk_work.erase(it);
+}
+
+static void launch_sk(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
+                      const double* coef, int K, int p, double* maxdev, double* rowpart, double* fropart, int variant)
+{
+    const int T32 = (p + 31) / 32;
+    const int ntiles = T32 * (T32 + 1) / 2;
+    double* scratch = nullptr;
+    unsigned* arrivals = nullptr;
+#define GGL_SK(BK_, ST_, SP_)                                                                                          \
+    do {                                                                                                               \
+        if (SP_ > 1 && !sk_workspace(st, (size_t)K * ntiles, (size_t)K * ntiles * SP_, &scratch, &arrivals)) return;   \
+        hipLaunchKernelGGL((k_symm_sk<BK_, ST_, SP_>), dim3(SP_ > 1 ? sk_grid(ntiles, K, SP_) : xcd_grid(ntiles, K)),  \
+                           dim3(256), 0, st, A, B, C, C2, E, coef, K, p, maxdev, rowpart, fropart, scratch, arrivals); \
+    } while (0)
+    switch (variant) {
+        case 41: GGL_SK(8, 3, 1); break;
+        case 42: GGL_SK(8, 4, 1); break;
+        case 43: GGL_SK(16, 2, 1); break;
+        case 44: GGL_SK(8, 2, 1); break;
+        case 45: GGL_SK(4, 4, 1); break;
+        case 46: GGL_SK(8, 3, 2); break;
+        case 47: GGL_SK(8, 3, 4); break;
+        case 48: GGL_SK(8, 2, 2); break;
+        case 49: GGL_SK(8, 2, 4); break;
+        default: GGL_SK(4, 4, 4); break;
+    }
+#undef GGL_SK
+}
+#else
+void symm_release_workspace(hipStream_t) {}
+#endif
 
 // Measured on MI355X (tools/bench_small_batches.py, profiles/r2_small_batches_product_kernel.txt), us per launch,
 // 32x32 (20) against 64x64 (16) direct-to-LDS tiles: p = 500: K = 2: 16.1 / 28.3, K = 4: 21.6 / 29.7, K = 8: 34.7 / 44.7,
@@ -1319,6 +1713,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
                       double* C1, const double* coef2K, int K, int p, int variant)
 {
     if (variant < 0) variant = symm_auto_variant(2 * K, p);
+    if (variant >= 41 && variant <= 50) variant = 20;       // k_symm_sk takes single products only
     switch (variant) {
         case 16: case 17: case 18: case 19: case 20: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
             if ((p & 1) == 0 && p >= 2) {
@@ -1345,7 +1740,7 @@ int symm_bounds_tile(int K, int p, int variant)
 {
     if (variant < 0) variant = symm_auto_variant(K, p);
     if ((p & 1) != 0 || p < 2) return 0;
-    if (variant == 20 || (variant >= 24 && variant <= 29) || (variant >= 34 && variant <= 37)) return 32;
+    if (variant == 20 || (variant >= 24 && variant <= 29) || (variant >= 34 && variant <= 37) || (variant >= 41 && variant <= 50)) return 32;
     if ((variant >= 16 && variant <= 19) || variant == 22 || variant == 23 || (variant >= 30 && variant <= 33) || variant == 38 || variant == 39) return 64;
     return 0;
 }
@@ -1356,6 +1751,12 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
     if (variant < 0) variant = symm_auto_variant(K, p);
 #define GGL_TN(BM, BK, WM, WN, LM) \
     launch_cfg<BM, BK, WM, WN, LM>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev)
+#ifdef GGL_DEV
+    if (variant >= 41 && variant <= 50) {
+        if ((p & 1) == 0 && p >= 2) { launch_sk(st, A, B, C, C2, E, coef, K, p, maxdev, rowpart, fropart, variant); return; }
+        variant = 9;                                     // odd p: the register-staged 32x32 kernel
+    }
+#endif
     switch (variant) {
         case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
             if ((p & 1) == 0 && p >= 2) {

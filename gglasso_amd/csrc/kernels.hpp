@@ -174,6 +174,8 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
                  const double* coef, int K, int p, int variant, double* maxdev = nullptr, double* rowpart = nullptr,
                  double* fropart = nullptr);
 int symm_bounds_tile(int K, int p, int variant);
+// frees the split-K scratch (k_symm_sk with a tile's k-range over several workgroups) that launches on this stream allocated
+void symm_release_workspace(hipStream_t st);
 
 // ---- the Omega-step's product chain as one persistent launch (gemm_sym.hip, k_omega_chain) ----
 // one product of the chain: C = coef-affine(A B) [+ C2] for all K instances (stack base pointers; instance k at + k p^2);
