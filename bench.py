@@ -222,12 +222,36 @@ def main():
         k0, k1, S_loc = 0, K, S
     Kl = k1 - k0
     Om0 = np.repeat(np.eye(p)[None], Kl, axis=0)
-    stream = comm.stream_handle if distributed else None      # the communicator's dedicated stream (gglasso_amd/dist.py)
     options = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in args.opt}
-    eng = solver.HipEngine(S_loc, Om0, Om0, np.zeros_like(S_loc), eig=args.eig, device=local_rank, stream=stream,
-                           options=options)
+
+    def make_engine():
+        stream = comm.stream_handle if distributed else None  # the communicator's dedicated stream (gglasso_amd/dist.py)
+        return solver.HipEngine(S_loc, Om0, Om0, np.zeros_like(S_loc), eig=args.eig, device=local_rank, stream=stream,
+                                options=options)
+
+    eng = make_engine()
+    comm_note = None
     if distributed and args.comm == "capi":
-        comm.attach(eng)
+        # RCCL behind the C ABI is a second RCCL instance in this process beside torch's own.  Should its communicator not
+        # come up on SOME rank, ALL ranks fall back to torch.distributed's collectives together (and the line says so)
+        # rather than lose the run.
+        err = None
+        try:
+            if os.environ.get("GGL_BENCH_FAIL_CAPI"):
+                raise RuntimeError("GGL_BENCH_FAIL_CAPI is set (test of the fallback)")
+            comm.attach(eng)
+        except Exception as e:  # noqa: BLE001 -- anything at all: the decision has to be taken collectively
+            err = f"{type(e).__name__}: {e}"
+        flag = torch.tensor([0 if err is None else 1], device=f"cuda:{local_rank}")
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        if int(flag.item()) != 0:
+            comm_note = "RCCL behind the C ABI did not come up on every rank (" + (err or "another rank failed") + \
+                        "); fell back to torch.distributed collectives"
+            print("bench.py: " + comm_note, file=sys.stderr)
+            eng.close()
+            args.comm = "torch"
+            comm = TorchComm(device=f"cuda:{local_rank}")
+            eng = make_engine()
     nk = np.ones(Kl)
     mu_loc = None if mu1 is None else mu1[k0:k1]
 
@@ -411,7 +435,8 @@ def main():
                                                                          else "rocsolver_dsyevd+mfma_recon"),
                        # every ctx option as the library ran it (include/ggl_hip.h GGL_OPT_*): ns_tol is the relative
                        # spectral accuracy the Omega-step's matrix square root is iterated to (0 = fp64 resolution)
-                       "options": effective_options, "options_overridden": sorted(options) or None},
+                       "options": effective_options, "options_overridden": sorted(options) or None,
+                       **({"collectives_note": comm_note} if comm_note else {})},
             "timed_regions": {"count": len(region_s), "steps_each": args.steps, "statistic": "median",
                               "start_point": "identity start restored device-to-device before every region (no idle GPU "
                                              "between regions), then `warmup` untimed iterations",
