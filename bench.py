@@ -349,6 +349,7 @@ def main():
                   "theta_fro": float(np.linalg.norm(ref["Theta"])), "ns_tol": effective_options["ns_tol"],
                   "tolerance": "north_star: Theta within 1e-8 Frobenius of the reference"}
     n_ranks_seen = eng.comm_count() if (distributed and args.comm == "capi") else (world if distributed else 1)
+    rank_totals = eng.rank_stats() if latent else None
     eng.close()
 
     if rank == 0:
@@ -452,6 +453,11 @@ def main():
                               "lstep_calls": ns1["rank_calls"] - ns0["rank_calls"],
                               "lstep_retries": ns1["rank_retries"] - ns0["rank_retries"],
                               "lstep_eigh_fallbacks": ns1["rank_fallbacks"] - ns0["rank_fallbacks"],
+                              # two-tier L-step, totals since ctx creation (all regions, warm-up included): calls, calls whose
+                              # coarse first pass was continued on a compact sub-batch, instances continued
+                              "lstep_two_tier_totals": rank_totals,
+                              "lstep_products_per_call": (ns1["rank_launches"] - ns0["rank_launches"])
+                              / max(1, ns1["rank_calls"] - ns0["rank_calls"]) if latent else None,
                               "speculative_omega_steps": ns1["spec_calls"] - ns0["spec_calls"],
                               "speculation_misses": ns1["spec_misses"] - ns0["spec_misses"],
                               "prelaunched_chains_dropped": ns1["pre_dropped"] - ns0["pre_dropped"],

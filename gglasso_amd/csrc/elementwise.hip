@@ -374,6 +374,45 @@ void launch_count_nonzero(hipStream_t st, const double* A, int K, int p, double*
     hipLaunchKernelGGL(k_count_nonzero, dim3(elementwise_blocks(p), K), dim3(EW_THREADS), 0, st, A, pp, partials);
 }
 
+// out[k] = trace(A_k) - shift: one workgroup per instance, strided partial sums, then a fixed-order tree (deterministic)
+__global__ __launch_bounds__(256) void k_trace(const double* __restrict__ A, int p, double shift, double* __restrict__ out)
+{
+    __shared__ double sh[256];
+    const double* a = A + (size_t)blockIdx.x * p * p;
+    double t = 0.0;
+    for (int i = threadIdx.x; i < p; i += 256) t += a[(size_t)i * p + i];
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0] - shift;
+}
+
+void launch_trace(hipStream_t st, const double* A, int K, int p, double shift, double* out)
+{
+    hipLaunchKernelGGL(k_trace, dim3(K), dim3(256), 0, st, A, p, shift, out);
+}
+
+// instance gather / scatter between stacks (the two-tier L-step's compact sub-batch)
+__global__ __launch_bounds__(256) void k_copy_instances(double* __restrict__ dst, const double* __restrict__ src,
+                                                        const int* __restrict__ idx, size_t pp, int scatter)
+{
+    const int i = blockIdx.y;
+    const size_t so = (size_t)(scatter ? i : idx[i]) * pp, dp = (size_t)(scatter ? idx[i] : i) * pp;
+    const size_t n2 = pp / 2;                             // p even on this path: 16-byte copies
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n2; e += (size_t)gridDim.x * 256)
+        reinterpret_cast<double2*>(dst + dp)[e] = reinterpret_cast<const double2*>(src + so)[e];
+    if ((pp & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[dp + pp - 1] = src[so + pp - 1];
+}
+
+void launch_copy_instances(hipStream_t st, double* dst, const double* src, const int* idx, int m, size_t pp, bool scatter)
+{
+    const int bx = (int)std::min<size_t>((pp / 2 + 255) / 256, 256);
+    hipLaunchKernelGGL(k_copy_instances, dim3(std::max(bx, 1), m), dim3(256), 0, st, dst, src, idx, pp, scatter ? 1 : 0);
+}
+
 void launch_dot(hipStream_t st, const double* A, const double* B, int K, int p, double* partials)
 {
     size_t pp = (size_t)p * p;

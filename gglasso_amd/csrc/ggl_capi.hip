@@ -156,6 +156,10 @@ struct ggl_ctx {
     bool rank_ns = false;                            // L-step by sign Newton-Schulz (else eigendecomposition)
     bool rank_eig = false;                           // GGL_OPT_RANK_EIG: force the eigendecomposition route
     double rank_l0 = 1e-6;                           // resolution of the scaling schedule
+    double rank_l0_coarse = 2e-5;                    // two-tier L-step: resolution of the first pass over the whole batch (0: one tier)
+    int* rank_idx = nullptr;                         // [K] instances of the compact continuation batch (device), lazy
+    int* rank_idx_h = nullptr;                       // ... pinned mirror
+    long long rank_continued = 0, rank_cont_instances = 0;
     int rank_hold = 0;                               // iterations to stay at the fine resolution
     long long rank_calls = 0, rank_retries = 0, rank_fallbacks = 0, rank_launches = 0;
     long long ns_steps_total = 0, ns_calls = 0, ns_units_total = 0, ns_launches_total = 0, ns_eigh_fallbacks = 0;
@@ -315,8 +319,8 @@ static int ctx_alloc(ggl_ctx* c)
         c->spec_c = (double*)malloc(c->K * sizeof(double));
         c->spec_beta = (double*)malloc(c->K * sizeof(double));
         c->pre_beta = (double*)malloc(c->K * sizeof(double));
-        HIPCHK(hipMalloc(&c->maxdev, c->K * sizeof(double)));
-        HIPCHK(hipHostMalloc(&c->maxdev_h, c->K * sizeof(double)));
+        HIPCHK(hipMalloc(&c->maxdev, 2 * c->K * sizeof(double)));          // [K] residuals | [K] traces of the sign iterate
+        HIPCHK(hipHostMalloc(&c->maxdev_h, 2 * c->K * sizeof(double)));
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < ggl_ctx::MAX_PARTS - 1; ++i) {
             HIPCHK(hipStreamCreateWithFlags(&c->streamx[i], hipStreamNonBlocking));
@@ -360,6 +364,10 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_PARTS_SMALL: c->parts_small = (int)v; break;
         case GGL_OPT_CW_WARM: c->cw_warm = v != 0.0; break;
         case GGL_OPT_CHAIN: c->chain_mode = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
+        case GGL_OPT_RANK_L0_COARSE:
+            if (!(v >= 0.0) || v > 0.1) return fail(GGL_E_ARG, "bad argument: GGL_OPT_RANK_L0_COARSE is in [0, 0.1]");
+            c->rank_l0_coarse = v;
+            break;
         case GGL_OPT_NS_TOL:
             if (!(v >= 0.0) || v > 1e-6) return fail(GGL_E_ARG, "bad argument: GGL_OPT_NS_TOL is in [0, 1e-6]");
             c->ns_tol = std::max(v, NS_TOL_EXACT);
@@ -398,6 +406,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_NS_TOL: *value = c->ns_tol; break;
         case GGL_OPT_CW_WARM: *value = c->cw_warm; break;
         case GGL_OPT_CHAIN: *value = c->chain_mode; break;
+        case GGL_OPT_RANK_L0_COARSE: *value = c->rank_l0_coarse; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
     }
     return GGL_OK;
@@ -475,8 +484,9 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
                       c->nsT, c->nsNX, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->snapL, c->cuse, c->Lam[0],
                       c->Lam[1], c->X1, c->cwvec[0], c->cwvec[1]};
-    for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize, c->inst_pk})
+    for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize, c->inst_pk, c->rank_idx})
         if (b) (void)hipFree(b);
+    if (c->rank_idx_h) (void)hipHostFree(c->rank_idx_h);
     if (c->maskK) (void)hipFree(c->maskK);
     for (double* b : c->snap)
         if (b) (void)hipFree(b);
@@ -1249,7 +1259,25 @@ static int rank_step(ggl_ctx* c)
     c->rank_calls += 1;
     double l0 = (c->rank_hold > 0) ? 1e-10 : c->rank_l0;
     if (c->rank_hold > 0) c->rank_hold -= 1;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // Two tiers.  The schedule's length is set by the smallest gap between an eigenvalue of C and the threshold over ALL
+    // instances of the batch (C4, K = 50: 2e-6 .. 4e-5 of |C - mu I| for the worst instance, 1.5e-4 for the 10 % quantile, 1.3e-3
+    // for the median: profiles/r3_c4_lstep_threshold_gaps.txt), and the degree sequence is common to a launch.  So the first
+    // pass plans for rank_l0_coarse (29 products instead of 37), the residual check says per instance whether that was
+    // enough, and the few instances it was not enough for go on as a compact sub-batch -- from the iterate they have, with
+    // the schedule for where an eigenvalue at the FINE resolution would be by now (rank_ns_image).  Same guarantee as the
+    // one-tier run (eigenvalues at least rank_l0 |B| away from the threshold are resolved, the check catches the others).
+    const double l_fine = l0;
+    const bool two_tier = c->rank_l0_coarse > l_fine && K >= 4 && (c->p & 1) == 0;
+    // resolutions of the full-batch passes, in order: [coarse (+ continuation of the instances it left),] fine, 1e-10
+    double stages[3];
+    int nstage = 0;
+    if (two_tier) stages[nstage++] = c->rank_l0_coarse;
+    stages[nstage++] = l_fine;
+    if (l_fine > 1e-10) stages[nstage++] = 1e-10;
+    const size_t pp = (size_t)c->p * c->p;
+    for (int stage = 0; stage < nstage; ++stage) {
+        l0 = stages[stage];
+        const bool coarse = two_tier && stage == 0;
         NsPlan plan;
         if (rank_ns_plan(cn.data(), mu_h, K, l0, c->coef_h, &plan, c->ns_degrees) != 0)
             return fail(GGL_E_SOLVER, "L-step: non-finite C (diverged iterate?)");
@@ -1264,7 +1292,6 @@ static int rank_step(ggl_ctx* c)
         nh = std::max(nh, 1);
         c->last_parts = nh;
         c->last_variant = (c->symm_variant >= 0) ? c->symm_variant : (nh > 1 ? 17 : symm_auto_variant(K, c->p));
-        const size_t pp = (size_t)c->p * c->p;
         if (nh > 1) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
             for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
@@ -1284,22 +1311,119 @@ static int rank_step(ggl_ctx* c)
         }
         HIPCHK(hipGetLastError());
         c->rank_launches += plan.products;
+        // the two checks of the result (newton_schulz.hip: rank_check, rank_trace_tolerance): the entrywise residual of the
+        // last step, and the distance of trace(X_last) = trace(P2) - p from an integer
+        launch_trace(c->stream, c->nsYP[1], K, c->p, (double)c->p, c->maxdev + K);
         CopySegs dn;
-        dn.add(c->maxdev_h, c->maxdev, K * sizeof(double));
+        dn.add(c->maxdev_h, c->maxdev, 2 * K * sizeof(double));
         launch_copy_small(c->stream, dn);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
-        double dev = 0.0;
-        for (int k = 0; k < K; ++k) dev = std::max(dev, c->maxdev_h[k]);
-        // |T_last - I| = |I - X^2|/2 of the iterate BEFORE the last step; the last step squares it
-        if (std::isfinite(dev) && dev <= plan.check) {
+        const double ttol = rank_trace_tolerance(l0);
+        auto unresolved = [&](int k, int ktr, double check, double tol) {
+            const double t = c->maxdev_h[ktr];
+            return !(c->maxdev_h[k] <= check) || !(std::fabs(t - std::nearbyint(t)) <= tol);
+        };
+        bool finite = true, all_ok = true;
+        for (int k = 0; k < K; ++k) {
+            finite = finite && std::isfinite(c->maxdev_h[k]) && std::isfinite(c->maxdev_h[K + k]);
+            all_ok = all_ok && !unresolved(k, K + k, plan.check, ttol);
+        }
+        if (finite && all_ok) {
             PE(c, GGL_PH_EIG_L);
             return GGL_OK;
         }
+        if (coarse) {
+            if (!finite) continue;                                  // (next stage reports a non-finite C)
+            // the instances the first pass did not resolve go on as a compact sub-batch
+            std::vector<int> bad;
+            for (int k = 0; k < K; ++k)
+                if (unresolved(k, K + k, plan.check, ttol)) bad.push_back(k);
+            const int m = (int)bad.size();
+            const double lp = rank_ns_image(l0, c->ns_degrees, l_fine) * (1.0 - 1e-9);
+            if (2 * m > K || !(lp > 0.0) || !(lp < 0.999)) continue;   // too many for a compact batch: the whole batch at l_fine
+            if (!c->rank_idx) {
+                HIPCHK(hipMalloc(&c->rank_idx, K * sizeof(int)));
+                HIPCHK(hipHostMalloc(&c->rank_idx_h, K * sizeof(int)));
+            }
+            std::vector<double> mu2(m);
+            for (int i = 0; i < m; ++i) { c->rank_idx_h[i] = bad[i]; mu2[i] = mu_h[bad[i]]; }
+            NsPlan plan2;
+            if (rank_ns_plan_continue(mu2.data(), m, lp, c->coef_h, &plan2, c->ns_degrees, NS_SLOT(K)) != 0) continue;
+            const size_t mp = (size_t)m * pp;
+            // free after the first pass: nsT, both halves of nsYP[1]; the X buffer the last step wrote holds the iterate
+            double* Cc = c->nsT;
+            double* Xc = c->nsT + mp;
+            double* Xnc = c->nsYP[1];
+            double* Tbc = c->nsYP[1] + mp;
+            double* P2c = c->nsYP[1] + 2 * mp;
+            double* outc = c->nsYP[1] + 3 * mp;
+            const double* Xlast = ((plan.steps - 1) & 1) ? c->nsYP[0] + c->n : c->nsYP[0];
+            HIPCHK(hipMemcpyAsync(c->rank_idx, c->rank_idx_h, m * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            CopySegs up2;
+            up2.add(c->coef, c->coef_h, (size_t)plan2.products * NS_SLOT(K) * sizeof(double));
+            up2.add(c->maxdev, nullptr, m * sizeof(double));
+            launch_copy_small(c->stream, up2);
+            launch_copy_instances(c->stream, Cc, c->W, c->rank_idx, m, pp, false);
+            launch_copy_instances(c->stream, Xc, Xlast, c->rank_idx, m, pp, false);
+            rank_ns_steps(c->stream, plan2, c->coef, Cc, Xc, Xnc, Tbc, P2c, outc, c->maxdev, m, c->p, c->symm_variant,
+                          NS_SLOT(K));
+            launch_copy_instances(c->stream, c->L, outc, c->rank_idx, m, pp, true);
+            launch_trace(c->stream, P2c, m, c->p, (double)c->p, c->maxdev + K);
+            CopySegs dn2;
+            dn2.add(c->maxdev_h, c->maxdev, m * sizeof(double));
+            dn2.add(c->maxdev_h + K, c->maxdev + K, m * sizeof(double));
+            launch_copy_small(c->stream, dn2);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->rank_launches += plan2.products;
+            c->rank_continued += 1;
+            c->rank_cont_instances += m;
+            bool ok2 = true;
+            const double ttol2 = rank_trace_tolerance(l_fine);
+            for (int i = 0; i < m; ++i)
+                ok2 = ok2 && std::isfinite(c->maxdev_h[i]) && std::isfinite(c->maxdev_h[K + i]) &&
+                      !unresolved(i, K + i, plan2.check, ttol2);
+            if (ok2) {
+                PE(c, GGL_PH_EIG_L);
+                return GGL_OK;
+            }
+            // an eigenvalue within l_fine |B| of the threshold (what a failed fine pass means in the one-tier run, which then
+            // repeats the WHOLE batch at 1e-10): the compact batch again, from scratch, at 1e-10
+            c->rank_retries += 1;
+            c->rank_hold = 8;
+            if (l_fine > 1e-10) {
+                std::vector<double> cn2(m);
+                for (int i = 0; i < m; ++i) cn2[i] = cn[bad[i]];
+                NsPlan plan3;
+                if (rank_ns_plan(cn2.data(), mu2.data(), m, 1e-10, c->coef_h, &plan3, c->ns_degrees) != 0)
+                    return fail(GGL_E_SOLVER, "L-step: non-finite C (diverged iterate?)");
+                CopySegs up3;
+                up3.add(c->coef, c->coef_h, (size_t)plan3.products * NS_SLOT(m) * sizeof(double));
+                up3.add(c->maxdev, nullptr, m * sizeof(double));
+                launch_copy_small(c->stream, up3);
+                rank_ns_run(c->stream, plan3, c->coef, Cc, Xc, Xnc, Tbc, P2c, outc, c->maxdev, m, c->p, c->symm_variant,
+                            NS_SLOT(m));
+                launch_copy_instances(c->stream, c->L, outc, c->rank_idx, m, pp, true);
+                launch_trace(c->stream, P2c, m, c->p, (double)c->p, c->maxdev + K);
+                launch_copy_small(c->stream, dn2);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(c->stream));
+                c->rank_launches += plan3.products;
+                bool ok3 = true;
+                const double ttol3 = rank_trace_tolerance(1e-10);
+                for (int i = 0; i < m; ++i)
+                    ok3 = ok3 && std::isfinite(c->maxdev_h[i]) && std::isfinite(c->maxdev_h[K + i]) &&
+                          !unresolved(i, K + i, plan3.check, ttol3);
+                if (ok3) {
+                    PE(c, GGL_PH_EIG_L);
+                    return GGL_OK;
+                }
+            }
+            break;                              // -> the eigendecomposition
+        }
         c->rank_retries += 1;
         c->rank_hold = 8;       // an eigenvalue sits within l0*|B| of the threshold: stay fine for a while
-        if (l0 <= 1e-10) break;
-        l0 = 1e-10;
     }
     PE(c, GGL_PH_EIG_L);
     c->rank_fallbacks += 1;
@@ -1709,6 +1833,16 @@ extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[16])
     out[13] = c->last_variant;
     out[14] = c->ns_eigh_fallbacks;
     out[15] = c->pre_dropped;
+    return GGL_OK;
+}
+
+extern "C" int ggl_rank_stats(ggl_ctx* c, long long out[4])
+{
+    ARGCHK(c && out, "ctx, out");
+    out[0] = c->rank_calls;
+    out[1] = c->rank_continued;
+    out[2] = c->rank_cont_instances;
+    out[3] = c->rank_fallbacks;
     return GGL_OK;
 }
 
@@ -3057,15 +3191,18 @@ extern "C" int ggl_phiplus_matrix(int K, int p, const double* beta, const double
     return eig_common(K, p, W, beta, nullptr, nullptr, out, MAP_PHIPLUS, eig_method & 0xff);
 }
 
-extern "C" int ggl_rank_matrix(int K, int p, const double* beta, const double* C, double* out, int eig_method)
+extern "C" int ggl_rank_matrix_ex(int K, int p, const double* beta, const double* C, double* out, int eig_method,
+                                  double l0_coarse, long long stats[6])
 {
     ARGCHK(beta && out && C, "beta, C, out");
     ARGCHK(K >= 1 && p >= 1, "K, p");
+    if (stats) for (int i = 0; i < 6; ++i) stats[i] = 0;
     if (use_ns(eig_method & 0xff, p)) {
         // the L-step of a scratch ctx: C into the work stack, beta into the mu/rho parameter slot
         ggl_ctx* c = nullptr;
         int rc = ggl_ctx_create(0, K, p, (eig_method & ~0xff) | GGL_EIG_NEWTON_SCHULZ, nullptr, &c);
         if (rc) return rc;
+        if (l0_coarse >= 0.0) c->rank_l0_coarse = l0_coarse;
         hipError_t e = hipMemcpyAsync(c->W, C, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             rc = upload_par(c, 2, beta, 0.0, 1.0);
@@ -3073,11 +3210,20 @@ extern "C" int ggl_rank_matrix(int K, int p, const double* beta, const double* C
             if (!rc) e = hipMemcpyAsync(out, c->L, c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
             if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
+        if (stats) {
+            stats[0] = c->rank_calls; stats[1] = c->rank_continued; stats[2] = c->rank_cont_instances;
+            stats[3] = c->rank_fallbacks; stats[4] = c->rank_retries; stats[5] = c->rank_launches;
+        }
         ggl_ctx_destroy(c);
         if (e != hipSuccess) return fail(GGL_E_HIP, "ggl_rank_matrix: %s", hipGetErrorString(e));
         return rc;
     }
     return eig_common(K, p, C, beta, nullptr, nullptr, out, MAP_RANK, eig_method & 0xff);
+}
+
+extern "C" int ggl_rank_matrix(int K, int p, const double* beta, const double* C, double* out, int eig_method)
+{
+    return ggl_rank_matrix_ex(K, p, beta, C, out, eig_method, -1.0, nullptr);
 }
 
 static int recon_common(int K, int p, const double* beta, const double* D, const double* Q, double* out, int map)

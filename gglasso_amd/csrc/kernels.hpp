@@ -56,6 +56,10 @@ void launch_scale_batch(hipStream_t st, double* X, const double* fK, int K, int 
 void launch_asym_max(hipStream_t st, const double* A, int K, int p, double* out);
 // partials[K][elementwise_blocks(p)]: non-zero entries per chunk of every instance
 void launch_count_nonzero(hipStream_t st, const double* A, int K, int p, double* partials);
+// dst[i] = src[idx[i]] (gather) or dst[idx[i]] = src[i] (scatter) for m instances of pp doubles
+void launch_copy_instances(hipStream_t st, double* dst, const double* src, const int* idx, int m, size_t pp, bool scatter);
+// out[k] = trace(A_k) - shift, summed in a fixed order
+void launch_trace(hipStream_t st, const double* A, int K, int p, double shift, double* out);
 // D = A - B (B may be null)
 void launch_sub(hipStream_t st, double* D, const double* A, const double* B, size_t n);
 // out[k][0] = sum A*B
@@ -299,6 +303,14 @@ void launch_cw_final(hipStream_t st, const double* B, const double* d, int K, in
                      double* dnext = nullptr);
 int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan,
                  int degrees = 9);
+// two-tier L-step: where rank_ns_plan(l0)'s iteration leaves an eigenvalue that started at x; the continuation plan for m
+// instances whose iterate has its eigenvalues at least lp away from 0 (coefficient slots `slot` doubles apart); the steps
+// and closing product of a plan from a given iterate (the tail of rank_ns_run / a continuation's whole run)
+double rank_ns_image(double l0, int degrees, double x);
+double rank_trace_tolerance(double l0);      // accepted distance of trace(sign iterate) from an integer, plan resolution l0
+int rank_ns_plan_continue(const double* mu_h, int m, double lp, double* coef_h, NsPlan* plan, int degrees, size_t slot);
+void rank_ns_steps(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* X, double* Xn, double* Tb,
+                   double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cs);
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
                  double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot = 0);
 

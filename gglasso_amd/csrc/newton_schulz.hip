@@ -987,6 +987,27 @@ void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int
     hipLaunchKernelGGL(k_cw_bounds, dim3(norm_bounds_blocks(p), K), dim3(256), 0, st, W, rowsum, p, part);
 }
 
+// Residual check of the sign iteration's result: an eigenvalue x of the iterate before the last step shows up as
+// |t(x^2) - 1| ~ e = 1 - |x| in T_last, and the last step turns it into a sign error of 1.5 e^2 (cubic), 2.5 e^3 (quintic) or
+// 7.9 e^5 (degree nine).  An eigenvalue the schedule leaves short of convergence sits within l0 |B| of the threshold (the
+// schedule is planned for everything further away), so its contribution to L is |lambda - mu| * error <= l0 |B| * error:
+// accept a sign error of 4e-9 (e up to the values below).  NOTE what this check sees: the ENTRYWISE maximum of T_last - I,
+// which for one unresolved eigenvalue with eigenvector v is its residual times max_i v_i^2 -- ~2 ln(p) / p of it for a
+// delocalised vector.  It is a coarse net; the sharp one is rank_trace_tolerance() below.
+static double rank_check(int deg_last, double l0)
+{
+    (void)l0;
+    return (deg_last == 3) ? 5e-5 : (deg_last == 5 ? 1.1e-3 : 8e-3);
+}
+
+// The sharp check: the iterate converges to sign(C - mu I), whose trace is an INTEGER (#eigenvalues above the threshold minus
+// #below).  Eigenvalue magnitudes approach 1 from below, so an eigenvalue left with a sign error s moves the trace by s, in the
+// direction of its sign; the products' rounding moves it by ~1e-15 p.  What is left unresolved sits within l0 |B| of the
+// threshold and costs L at most l0 |B| s: tolerate s up to 1e-14 / l0 (1e-8 at the fine resolution 1e-6, 2e-10 for a first
+// pass at 5e-5).  (Two unresolved eigenvalues on opposite sides of the threshold whose errors cancel to that accuracy would
+// slip through this net -- and are left to the entrywise one.)
+double rank_trace_tolerance(double l0) { return std::min(1e-8, 1e-14 / std::max(l0, 1e-300)); }
+
 // cnorm_h[k] >= |C_k|_2, mu_h[k] = mu1_k / rho.  Fills the coefficient table; returns steps.
 int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan, int degrees)
 {
@@ -1003,12 +1024,8 @@ int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, do
     plan->stable = false;
     plan->deg[0] = 3;
     for (int i = 1; i < n; ++i) plan->deg[i] = sq->deg[i - 1];
-    // Residual check of the result: an eigenvalue x of the iterate before the last step shows up as |t(x^2) - 1| ~
-    // e = 1 - |x| in T_last, and the last step turns it into a sign error of 1.5 e^2 (cubic), 2.5 e^3 (quintic) or
-    // 7.9 e^5 (degree nine).  Accept up to a sign error of 4e-9 on such an eigenvalue -- it sits within l0 |B| of
-    // the threshold, so its contribution |lambda| * error to L is far below 1e-14 |B| -- i.e. e up to:
-    const int dl = plan->deg[n - 1];
-    plan->check = (dl == 3) ? 5e-5 : (dl == 5 ? 1.1e-3 : 8e-3);
+    // Residual check of the result: rank_check() below.
+    plan->check = rank_check(plan->deg[n - 1], l0);
     int g = 0;
     for (int k = 0; k < K; ++k) {
         const double mu = mu_h[k];
@@ -1046,6 +1063,71 @@ int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, do
     plan->products = g;
     return 0;
 }
+// Where the sign iteration of rank_ns_plan(l0) leaves an eigenvalue that started at x (|x| <= 1, relative to the norm bound):
+// the scalar image under the first cubic step and every step of the schedule.  For x below the plan's l0 this is how far the
+// first pass got with an eigenvalue it was not planned for.
+double rank_ns_image(double l0, int degrees, double x)
+{
+    const double lq = l0 < 0.5 ? l0 : 0.5;
+    const NsStep s0 = ns_cubic_step(lq);
+    const double a0 = (lq < 0.99) ? std::sqrt(3.0 / (1.0 + lq + lq * lq)) : 1.0;
+    x = a0 * x * (1.5 - 0.5 * a0 * a0 * x * x);
+    if (1.0 - s0.lnew < 4e-16) return x;
+    const NsSeq& sq = ns_sign_schedule(s0.lnew, degrees);
+    for (int i = 0; i < sq.n; ++i) {
+        const double* t = sq.st[i].t;
+        const double m = x * x;
+        const int d = sq.deg[i];
+        const double tm = (d == 3) ? t[0] + t[1] * m : (d == 5 ? t[0] + (t[1] + t[2] * m) * m
+                                                                 : t[0] + (t[1] + (t[2] + (t[3] + t[4] * m) * m) * m) * m);
+        x *= tm;
+    }
+    return x;
+}
+
+// Continuation plan for m instances whose iterate X already has its eigenvalues in [-1,1] and at least lp away from 0: the
+// schedule for [lp,1] and the closing product.  plan->steps = schedule steps + 1 (rank_ns_steps runs steps 1 .. steps-1);
+// coefficient slot g of instance i at coef_h + g * slot + i * NS_NCOEF.
+int rank_ns_plan_continue(const double* mu_h, int m, double lp, double* coef_h, NsPlan* plan, int degrees, size_t slot)
+{
+    if (!(lp > 0.0) || !(lp < 1.0)) return -1;
+    const NsSeq& sq = ns_sign_schedule(lp, degrees);
+    const int n = 1 + sq.n;
+    if (sq.n < 1 || n > NS_RANK_MAX_STEPS || sq.cost >= (1 << 29)) return -1;
+    plan->steps = n;
+    plan->stable = false;
+    plan->deg[0] = 0;
+    for (int i = 1; i < n; ++i) plan->deg[i] = sq.deg[i - 1];
+    plan->check = rank_check(plan->deg[n - 1], 1e-6);   // what is left short here started within the FINE resolution of the threshold
+    int g = 0;
+    for (int k = 0; k < m; ++k) {
+        auto put = [&](int gg, double cI, double cAcc, double cE, double dI, double dC) {
+            double* o = coef_h + (size_t)gg * slot + (size_t)k * NS_NCOEF;
+            o[0] = cI; o[1] = cAcc; o[2] = cE; o[3] = dI; o[4] = dC; o[5] = 0.0;
+        };
+        g = 0;
+        for (int it = 1; it < n; ++it) {
+            const double* t = sq.st[it - 1].t;
+            const int d = sq.deg[it - 1];
+            if (d == 3) {
+                put(g++, t[0], t[1], 0.0, 0.0, 0.0);
+            } else if (d == 5) {
+                put(g++, 0.0, 1.0, 0.0, 0.0, 0.0);
+                put(g++, t[0], t[2], t[1], 0.0, 0.0);
+            } else {
+                const double a = t[3] / (2.0 * t[4]), dl2 = t[2] / t[4] - a * a, e = t[1] - t[4] * dl2 * a;
+                put(g++, 0.0, 1.0, 0.0, 0.0, 0.0);
+                put(g++, 0.0, 1.0, a, dl2, 1.0);
+                put(g++, t[0], t[4], e, 0.0, 0.0);
+            }
+            put(g++, 0.0, 1.0, 0.0, 1.0, 1.0);
+        }
+        put(g++, 0.0, 0.5, -0.5 * mu_h[k], 0.0, 0.0);
+    }
+    plan->products = g;
+    return 0;
+}
+
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
                  double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot)
 {
@@ -1054,11 +1136,19 @@ void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const
     // scratch of the higher-degree steps: M = X^2 in `out` (free until the last launch), Q in P2 (free until the last
     // step's second output), Q + d I in the other X buffer (free until X T is written there)
     const size_t cs = cslot ? cslot : NS_SLOT(K);
+    launch_symm(st, C, C, Tb, nullptr, C, coef_d, K, p, variant);
+    launch_symm(st, C, Tb, Xa, nullptr, Tb, coef_d + cs, K, p, variant);
+    rank_ns_steps(st, plan, coef_d + 2 * cs, C, Xa, Xb, Tb, P2, out, maxdev, K, p, variant, cs);
+}
+
+// Steps 1 .. steps-1 of a plan from an iterate X (eigenvalues in [-1,1], those of interest at least the plan's l away from 0)
+// and the closing product L = (C - mu I)(I + X_last)/2: the tail of rank_ns_run, and the whole of a CONTINUATION
+// (rank_ns_plan_continue) -- more steps on the instances whose eigenvalues next to the threshold the first pass did not resolve.
+void rank_ns_steps(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* X, double* Xn, double* Tb,
+                   double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cs)
+{
     int g = 0;
     const int n = plan.steps;
-    double *X = Xa, *Xn = Xb;
-    launch_symm(st, C, C, Tb, nullptr, C, coef_d + cs * g++, K, p, variant);
-    launch_symm(st, C, Tb, X, nullptr, Tb, coef_d + cs * g++, K, p, variant);
     for (int it = 1; it < n; ++it) {
         const bool last = (it == n - 1);
         double* md = last ? maxdev : nullptr;        // max |T_last - I| = |t(X^2) - 1|: the residual check

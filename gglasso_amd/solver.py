@@ -340,6 +340,12 @@ class HipEngine:
                          "rank_fallbacks", "rank_launches", "spec_calls", "spec_misses", "spin_timeouts", "last_parts",
                          "last_variant", "eigh_fallbacks", "pre_dropped"), (int(v) for v in out)))
 
+    def rank_stats(self):
+        import ctypes
+        out = (ctypes.c_longlong * 4)()
+        check(self.lib.ggl_rank_stats(self.h, out))
+        return dict(zip(("calls", "continued_calls", "continued_instances", "eigh_fallbacks"), (int(v) for v in out)))
+
     def device_ptr(self, which):
         return self.lib.ggl_device_ptr(self.h, which)
 

@@ -117,6 +117,14 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                     * concurrent parts; 2: wherever it can run (any K >= 8, even p).  Same products, same bits
                                     * (tests/test_gpu_chain.py).  Off by default: measured SLOWER on MI355X (headline Omega
                                     * phase 0.89 vs 0.72 ms; DESIGN.md section 8.1, profiles/r3_omega_chain_*.txt)           */
+#define GGL_OPT_RANK_L0_COARSE 18  /* [2e-5] two-tier L-step (sign iteration, p > GGL_JACOBI_MAX_P): the first pass over the whole batch
+                                    * resolves eigenvalues of C down to this distance from the threshold (relative to |C - mu I|);
+                                    * the instances whose residual check says that was not enough are continued, from the iterate
+                                    * they have, as a compact sub-batch down to the resolution of the one-tier run (1e-6).  The
+                                    * schedule's length is set by the WORST instance of a batch and its degree sequence is common
+                                    * to a launch: at K = 50, p = 500 the batch needs 1e-6, nine instances in ten 1e-4
+                                    * (28 instead of 37 products).  Measured there: 117 -> 147 it/s, flat for 3e-6 .. 2e-5.
+                                    * 0: one tier.                                                                            */
 int ggl_ctx_set_option(ggl_ctx *ctx, int option, double value);
 int ggl_ctx_get_option(ggl_ctx *ctx, int option, double *value);
 
@@ -336,6 +344,9 @@ int ggl_profile_read(ggl_ctx *ctx, double ms[GGL_NPHASE], long long count[GGL_NP
  * variant (csrc/gemm_sym.hip); [14] Omega-steps that fell back to the eigendecomposition; [15] pre-launched Omega-step
  * chains (GGL_OPT_PIPELINE) that were dropped unused. */
 int ggl_ns_stats(ggl_ctx *ctx, long long out[16]);
+/* L-step (sign iteration): out = { calls, calls whose first pass was continued on a compact sub-batch, instances continued in
+ * total, calls that fell back to the eigendecomposition } */
+int ggl_rank_stats(ggl_ctx *ctx, long long out[4]);
 
 /* ---- kernel-level test / measurement entry points (not used by the solvers) --------------------
  * ggl_dev_symm: one launch of the symmetric-product kernel on host data (kernel unit test; variant < 0 = by size).
@@ -391,6 +402,11 @@ int ggl_prox_rank_norm(int K, int p, const double *beta, const double *D, const 
 /* eigh + phiplus / rank shrink fused, straight from the matrix (what the ADMM step runs). */
 int ggl_phiplus_matrix(int K, int p, const double *beta, const double *W, double *out, int eig_method);
 int ggl_rank_matrix(int K, int p, const double *beta, const double *C, double *out, int eig_method);
+/* the same with the two-tier control of the sign-iteration L-step exposed: l0_coarse as GGL_OPT_RANK_L0_COARSE (< 0: the default),
+ * stats (may be NULL) = { calls, calls continued on a compact sub-batch, instances continued, eigendecomposition fallbacks,
+ * retries of the whole batch, product launches } */
+int ggl_rank_matrix_ex(int K, int p, const double *beta, const double *C, double *out, int eig_method, double l0_coarse,
+                       long long stats[6]);
 /* prox_od_1norm(A,l), ggl_helper.py:16-27; lam_pp NULL => scalar lam. */
 int ggl_prox_od_1norm(int p, const double *A, double lam, const double *lam_pp, double *out);
 /* prox_p(X,l1,l2,reg), ggl_helper.py:190-207 (reg = GGL_REG_GGL | GGL_REG_FGL). */

@@ -392,3 +392,73 @@ def test_product_epilogue_bound_partials(variant, K, p):
     bound2 = np.empty(K)
     _lib.check(lib.ggl_dev_symm_bounds(K, p, ptr(A), ptr(B), variant, ptr(C), ptr(rows), ptr(fro2), ptr(bound2)))
     assert np.array_equal(bound, bound2)
+
+
+def _rank_ex(W, beta, l0_coarse, degrees=0):
+    import ctypes
+    from gglasso_amd import _lib
+    from gglasso_amd._lib import ptr
+    lib = _lib.load()
+    K, p, _ = W.shape
+    b = np.ascontiguousarray(np.broadcast_to(np.asarray(beta, dtype=np.float64), (K,)))
+    out = np.empty_like(W)
+    st = (ctypes.c_longlong * 6)()
+    _lib.check(lib.ggl_rank_matrix_ex(K, p, ptr(b), ptr(np.ascontiguousarray(W)), ptr(out), _lib.eig_flags(3, 0, degrees),
+                                      float(l0_coarse), st))
+    return out, dict(zip(("calls", "continued_calls", "continued_instances", "eigh_fallbacks", "retries", "launches"),
+                         (int(v) for v in st)))
+
+
+def _with_gaps(rng, p, beta, gaps, scale=1.0):
+    """Symmetric C with eigenvalues spread over [-scale, scale] and, for every g of ``gaps``, one eigenvalue at a distance
+    g * nb from the L-step's threshold beta, nb = min(|C|_inf, |C|_F) + beta being the norm bound the sign iteration scales
+    with (its resolutions are relative to nb)."""
+    Q, _ = np.linalg.qr(rng.standard_normal((p, p)))
+    d = rng.uniform(-scale, scale, p)
+    d[np.abs(d - beta) < 0.05 * scale] += 0.1 * scale            # nothing else near the threshold
+    C = (Q * d) @ Q.T
+    nb = min(np.abs(C).sum(axis=1).max(), np.linalg.norm(C)) + beta
+    for i, g in enumerate(gaps):
+        d[i] = beta + g * nb
+    C = (Q * d) @ Q.T
+    return 0.5 * (C + C.T)
+
+
+@pytest.mark.parametrize("p", [200, 500])
+def test_rank_two_tier_continues_only_the_unresolved_instances(p):
+    """Two-tier L-step (GGL_OPT_RANK_L0_COARSE): the first pass plans for eigenvalues 1e-4 |C - mu I| away from the
+    threshold; instances with a closer one (here 3e-5 and 4e-6) fail ITS residual check and are continued as a
+    compact sub-batch from the iterate they have; the others are done.  Same result as the one-tier run and as the
+    eigendecomposition, fewer product launches; an eigenvalue closer than the fine resolution still ends in the fallback."""
+    rng = np.random.default_rng(900 + p)
+    K, beta = 10, 0.4
+    gaps = {2: [3e-4], 5: [3e-5], 7: [-4e-6, 1e-3]}       # instance 5: just below the first pass's 1e-4 -- the entrywise check
+    # alone lets it through (4.8e-11 in L at p = 500); the trace of the sign iterate does not
+    W = np.stack([_with_gaps(rng, p, beta, gaps.get(k, [])) for k in range(K)])
+    ref = orc.rank_stack(W, np.full(K, beta))
+    one, st1 = _rank_ex(W, beta, 0.0)
+    two, st2 = _rank_ex(W, beta, 1e-4)
+    tol = 2e-13 * p          # ~1e-15 measured; an instance accepted short of convergence shows up at 1e-11 .. 1e-8
+    assert np.abs(one - ref).max() <= tol and np.abs(two - ref).max() <= tol
+    assert np.array_equal(two, two.transpose(0, 2, 1))
+    assert st1["continued_calls"] == 0 and st1["eigh_fallbacks"] == 0 and st1["retries"] == 0, st1
+    assert st2["continued_calls"] == 1 and st2["continued_instances"] == 2, st2
+    assert st2["eigh_fallbacks"] == 0 and st2["retries"] == 0, st2
+    # launches count products of whole-batch passes and of the continuation alike: the first pass alone is shorter
+    assert st2["launches"] < st1["launches"] + 20
+    # nothing to continue when every gap is wide
+    Wwide = np.stack([_with_gaps(rng, p, beta, [5e-3]) for _ in range(K)])
+    out, st = _rank_ex(Wwide, beta, 1e-4)
+    assert st["continued_calls"] == 0 and st["retries"] == 0, st
+    assert np.abs(out - orc.rank_stack(Wwide, np.full(K, beta))).max() <= tol
+    # more than half of the batch unresolved: no compact batch, the whole batch again at the fine resolution
+    Wmany = np.stack([_with_gaps(rng, p, beta, [2e-5] if k < 7 else []) for k in range(K)])
+    out, st = _rank_ex(Wmany, beta, 1e-4)
+    assert st["continued_calls"] == 0 and st["eigh_fallbacks"] == 0, st
+    assert np.abs(out - orc.rank_stack(Wmany, np.full(K, beta))).max() <= tol
+    # an eigenvalue 1e-12 from the threshold: the continuation's own check fails, 1e-10 pass, then the eigendecomposition
+    Wat = W.copy()
+    Wat[5] = _with_gaps(rng, p, beta, [1e-13])
+    out, st = _rank_ex(Wat, beta, 1e-4)
+    assert st["continued_calls"] == 1 and st["eigh_fallbacks"] == 1, st
+    assert np.abs(out - orc.rank_stack(Wat, np.full(K, beta))).max() <= tol
