@@ -160,6 +160,7 @@ struct ggl_ctx {
     int* rank_idx = nullptr;                         // [K] instances of the compact continuation batch (device), lazy
     int* rank_idx_h = nullptr;                       // ... pinned mirror
     long long rank_continued = 0, rank_cont_instances = 0;
+    double rank_units = 0.0;                         // product launches in units of the WHOLE batch (a compact launch of m counts m / K)
     int rank_hold = 0;                               // iterations to stay at the fine resolution
     long long rank_calls = 0, rank_retries = 0, rank_fallbacks = 0, rank_launches = 0;
     long long ns_steps_total = 0, ns_calls = 0, ns_units_total = 0, ns_launches_total = 0, ns_eigh_fallbacks = 0;
@@ -1310,7 +1311,8 @@ static int rank_step(ggl_ctx* c)
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
         }
         HIPCHK(hipGetLastError());
-        c->rank_launches += plan.products;
+        c->rank_units += plan.products;
+        c->rank_launches = (long long)(c->rank_units + 0.5);
         // the two checks of the result (newton_schulz.hip: rank_check, rank_trace_tolerance): the entrywise residual of the
         // last step, and the distance of trace(X_last) = trace(P2) - p from an integer
         launch_trace(c->stream, c->nsYP[1], K, c->p, (double)c->p, c->maxdev + K);
@@ -1319,7 +1321,7 @@ static int rank_step(ggl_ctx* c)
         launch_copy_small(c->stream, dn);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
-        const double ttol = rank_trace_tolerance(l0);
+        const double ttol = rank_trace_tolerance(l0, c->p);
         auto unresolved = [&](int k, int ktr, double check, double tol) {
             const double t = c->maxdev_h[ktr];
             return !(c->maxdev_h[k] <= check) || !(std::fabs(t - std::nearbyint(t)) <= tol);
@@ -1376,11 +1378,12 @@ static int rank_step(ggl_ctx* c)
             launch_copy_small(c->stream, dn2);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(c->stream));
-            c->rank_launches += plan2.products;
+            c->rank_units += (double)plan2.products * m / K;
+            c->rank_launches = (long long)(c->rank_units + 0.5);
             c->rank_continued += 1;
             c->rank_cont_instances += m;
             bool ok2 = true;
-            const double ttol2 = rank_trace_tolerance(l_fine);
+            const double ttol2 = rank_trace_tolerance(l_fine, c->p);
             for (int i = 0; i < m; ++i)
                 ok2 = ok2 && std::isfinite(c->maxdev_h[i]) && std::isfinite(c->maxdev_h[K + i]) &&
                       !unresolved(i, K + i, plan2.check, ttol2);
@@ -1409,9 +1412,10 @@ static int rank_step(ggl_ctx* c)
                 launch_copy_small(c->stream, dn2);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipStreamSynchronize(c->stream));
-                c->rank_launches += plan3.products;
+                c->rank_units += (double)plan3.products * m / K;
+                c->rank_launches = (long long)(c->rank_units + 0.5);
                 bool ok3 = true;
-                const double ttol3 = rank_trace_tolerance(1e-10);
+                const double ttol3 = rank_trace_tolerance(1e-10, c->p);
                 for (int i = 0; i < m; ++i)
                     ok3 = ok3 && std::isfinite(c->maxdev_h[i]) && std::isfinite(c->maxdev_h[K + i]) &&
                           !unresolved(i, K + i, plan3.check, ttol3);

@@ -307,7 +307,7 @@ int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, do
 // instances whose iterate has its eigenvalues at least lp away from 0 (coefficient slots `slot` doubles apart); the steps
 // and closing product of a plan from a given iterate (the tail of rank_ns_run / a continuation's whole run)
 double rank_ns_image(double l0, int degrees, double x);
-double rank_trace_tolerance(double l0);      // accepted distance of trace(sign iterate) from an integer, plan resolution l0
+double rank_trace_tolerance(double l0, int p);      // accepted distance of trace(sign iterate) from an integer, plan resolution l0
 int rank_ns_plan_continue(const double* mu_h, int m, double lp, double* coef_h, NsPlan* plan, int degrees, size_t slot);
 void rank_ns_steps(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* X, double* Xn, double* Tb,
                    double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cs);

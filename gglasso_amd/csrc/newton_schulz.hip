@@ -1006,7 +1006,11 @@ static double rank_check(int deg_last, double l0)
 // threshold and costs L at most l0 |B| s: tolerate s up to 1e-14 / l0 (1e-8 at the fine resolution 1e-6, 2e-10 for a first
 // pass at 5e-5).  (Two unresolved eigenvalues on opposite sides of the threshold whose errors cancel to that accuracy would
 // slip through this net -- and are left to the entrywise one.)
-double rank_trace_tolerance(double l0) { return std::min(1e-8, 1e-14 / std::max(l0, 1e-300)); }
+double rank_trace_tolerance(double l0, int p)
+{
+    // never below what the rounding of the products puts into the trace of a CONVERGED iterate (a few 1e-15 per diagonal entry)
+    return std::max(std::min(1e-8, 1e-14 / std::max(l0, 1e-300)), 2e-14 * p);
+}
 
 // cnorm_h[k] >= |C_k|_2, mu_h[k] = mu1_k / rho.  Fills the coefficient table; returns steps.
 int rank_ns_plan(const double* cnorm_h, const double* mu_h, int K, double l0, double* coef_h, NsPlan* plan, int degrees)

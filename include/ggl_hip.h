@@ -338,7 +338,8 @@ int ggl_profile_enable(ggl_ctx *ctx, int on);
 int ggl_profile_read(ggl_ctx *ctx, double ms[GGL_NPHASE], long long count[GGL_NPHASE], int reset);
 /* Newton-Schulz statistics since ctx creation: Omega-step {calls, steps, calls that took the stable
  * schedule, algorithmic work in units of K*p^3 flop, kernel launches}; L-step {calls, retries at the
- * finer resolution, fallbacks to the eigendecomposition, kernel launches (each K*p^3 flop)}; speculative
+ * finer resolution, fallbacks to the eigendecomposition, kernel launches in units of K*p^3 flop (a launch on a compact
+ * sub-batch of m instances counts m/K)}; speculative
  * Omega-steps {taken, failed validation and repeated}; [11] end-of-iteration polls that timed out and fell back to a
  * stream synchronisation; what the LAST matrix-function step dispatched: [12] concurrent parts, [13] product-kernel
  * variant (csrc/gemm_sym.hip); [14] Omega-steps that fell back to the eigendecomposition; [15] pre-launched Omega-step

@@ -444,8 +444,8 @@ def test_rank_two_tier_continues_only_the_unresolved_instances(p):
     assert st1["continued_calls"] == 0 and st1["eigh_fallbacks"] == 0 and st1["retries"] == 0, st1
     assert st2["continued_calls"] == 1 and st2["continued_instances"] == 2, st2
     assert st2["eigh_fallbacks"] == 0 and st2["retries"] == 0, st2
-    # launches count products of whole-batch passes and of the continuation alike: the first pass alone is shorter
-    assert st2["launches"] < st1["launches"] + 20
+    # launches are counted in units of the whole batch (a compact launch of m instances counts m / K): fewer than one tier's 37
+    assert st2["launches"] < st1["launches"]
     # nothing to continue when every gap is wide
     Wwide = np.stack([_with_gaps(rng, p, beta, [5e-3]) for _ in range(K)])
     out, st = _rank_ex(Wwide, beta, 1e-4)
