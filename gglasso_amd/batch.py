@@ -65,10 +65,13 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
         mu = None
 
     def stack(A, default):
+        # a shared (p,p) start stays a broadcast VIEW: the engine uploads it once and replicates it on the device
         if A is None or len(A) == 0:
             A = default
         A = np.asarray(A, dtype=np.float64)
-        return as_c(np.broadcast_to(A, (K, p, p)))
+        if A.ndim == 3 and A.strides[0] == 0:
+            return A
+        return np.broadcast_to(as_c(A), (K, p, p)) if A.ndim == 2 else as_c(A)
 
     Om0 = stack(Omega_0, np.eye(p))
     Th0 = stack(Theta_0, Om0)

@@ -42,6 +42,13 @@ def latent_rank(L, rel_tol=RANK_REL_TOL):
     return int(np.count_nonzero(a > a.max() * max(rel_tol, L.shape[0] * np.finfo(np.float64).eps)))
 
 
+def _shared_or_full(A):
+    """(C-contiguous host array to upload, is it ONE (p,p) matrix shared by all K instances?)"""
+    if A.ndim == 3 and A.shape[0] > 1 and A.strides[0] == 0:
+        return as_c(A[0]), True
+    return as_c(A), False
+
+
 class HipEngine:
     """Device-resident ADMM state behind the C ABI (one ggl_ctx)."""
 
@@ -50,7 +57,7 @@ class HipEngine:
         stream itself, not "none" (a NULL handle used to be read as "create one")."""
         _lib.require_gpu()
         self.lib = _lib.load()
-        S = as_c(S)
+        S = np.asarray(S, dtype=np.float64)
         self.K, self.p, _ = S.shape
         h = _lib._vp()
         flags = int(eig) | (0 if stream is None else _lib.CTX_STREAM_GIVEN)
@@ -60,9 +67,19 @@ class HipEngine:
         self.stream_handle = None if stream is None else int(stream)
         for name, value in {**ENGINE_OPTIONS, **(options or {})}.items():
             self.set_option(name, value)
-        check(self.lib.ggl_set_S(self.h, ptr(S)))
-        L_0 = None if L_0 is None else as_c(L_0)
-        check(self.lib.ggl_set_state(self.h, ptr(as_c(Omega_0)), ptr(as_c(Theta_0)), ptr(L_0), ptr(as_c(X_0))))
+        # a (K,p,p) BROADCAST view of one (p,p) matrix (numpy.broadcast_to: stride 0 along K -- what the batched grids pass
+        # for S, Omega_0, X_0) is uploaded once and replicated on the device instead of being materialised on the host
+        Sh, s_shared = _shared_or_full(S)
+        check(self.lib.ggl_set_S_ex(self.h, ptr(Sh), int(s_shared)))
+        arrs, mask = [], 0
+        for bit, A in enumerate((Omega_0, Theta_0, L_0, X_0)):
+            if A is None:
+                arrs.append(None)
+                continue
+            Ah, shared = _shared_or_full(np.asarray(A, dtype=np.float64))
+            arrs.append(Ah)
+            mask |= int(shared) << bit
+        check(self.lib.ggl_set_state_ex(self.h, ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3]), mask))
         self._norms = np.zeros(5)
         self._norms_p = ptr(self._norms)
         self._ptr_cache = {}

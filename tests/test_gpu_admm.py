@@ -640,3 +640,33 @@ def test_state_snapshot_restore_equals_a_fresh_upload(sol):
     for nm in ("Omega", "Theta", "X"):
         assert np.array_equal(outs[0][nm], outs[1][nm]), nm
         assert np.array_equal(outs[0][nm], outs[2][nm]), nm
+
+
+def test_shared_start_arrays_are_replicated_on_the_device():
+    """ggl_set_S_ex / ggl_set_state_ex: a (K,p,p) broadcast VIEW of one (p,p) matrix (what the batched grids pass for S,
+    Omega_0, X_0) is uploaded once and replicated on the device -- the engine's state must equal the materialised stacks',
+    for K a power of two and not, with and without L."""
+    from gglasso_amd import solver
+    rng = np.random.default_rng(12)
+    p = 70
+    A = [rng.standard_normal((p, p)) for _ in range(5)]
+    A = [0.5 * (a + a.T) for a in A]
+    for K in (1, 2, 5, 8, 13):
+        views = [np.broadcast_to(a, (K, p, p)) for a in A]
+        full = [np.ascontiguousarray(v) for v in views]
+        for with_L in (False, True):
+            e1 = solver.HipEngine(views[0], views[1], views[2], views[3], L_0=views[4] if with_L else None)
+            e2 = solver.HipEngine(full[0], full[1], full[2], full[3], L_0=full[4] if with_L else None)
+            try:
+                s1, s2 = e1.state(), e2.state()
+                for nm in ("Omega", "Theta", "X", "L"):
+                    assert np.array_equal(s1[nm], s2[nm]), (K, with_L, nm)
+                assert np.array_equal(s1["Omega"], full[1]) and np.array_equal(s1["X"], full[3])
+                # mixed: one shared, one per-instance array
+                per = np.ascontiguousarray(full[2] + np.arange(K)[:, None, None])
+                e1.close()
+                e1 = solver.HipEngine(views[0], views[1], per, views[3])
+                assert np.array_equal(e1.state()["Theta"], per) and np.array_equal(e1.state()["Omega"], full[1])
+            finally:
+                e1.close()
+                e2.close()
