@@ -392,10 +392,109 @@ __device__ __forceinline__ void condat_inplace(double* y, const int s, const int
     }
 }
 
+
+// Condat's direct 1-D TV prox (fgl_helper.py:11-68), same arithmetic in the same order as condat_inplace, restructured for a
+// wavefront: ONE loop whose body is one decision of the scan (extend the segment / negative jump / positive jump / the three
+// end-of-signal cases), no inner loops.  Closing a segment [k0 .. kminus|kplus] does not fill it: the value goes to y[k0] and
+// k0 is marked as a segment start; elements behind a closed segment are never read again, and every element is written
+// exactly once by the uniform pass at the end that carries each start's value forward (f: applied to the values on the way).
+template <int NWORDS, class F>
+__device__ __forceinline__ void condat_uniform(double* y, const int s, const int N, const double lam, F f)
+{
+    int k = 0, k0 = 0, kplus = 0, kminus = 0;
+    double vmin = y[0] - lam, vmax = y[0] + lam, umin = lam, umax = -lam;
+    unsigned long long starts[NWORDS];
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) starts[w] = 0ull;
+    auto close = [&](int a, double v) {
+        y[a * s] = v;
+#pragma unroll
+        for (int w = 0; w < NWORDS; ++w) starts[w] |= ((a >> 6) == w) ? (1ull << (a & 63)) : 0ull;
+    };
+    bool done = false;
+    while (!done) {
+        if (k == N - 1) {
+            if (umin < 0.0) {
+                close(k0, vmin);
+                kminus += 1;
+                k = k0 = kminus;
+                umin = lam;
+                vmin = y[k * s];
+                umax = vmin + lam - vmax;
+                if (k == N - 1) { close(k, vmin + umin); done = true; }
+            } else if (umax > 0.0) {
+                close(k0, vmax);
+                kplus += 1;
+                k = k0 = kplus;
+                umax = -lam;
+                vmax = y[k * s];
+                umin = vmax - lam - vmin;
+                if (k == N - 1) { close(k, vmin + umin); done = true; }
+            } else {
+                close(k0, vmin + umin / (double)(k - k0 + 1));
+                done = true;
+            }
+        } else {
+            const double yn = y[(k + 1) * s];
+            if (yn + umin - vmin < -lam) {
+                close(k0, vmin);
+                kminus += 1;
+                k = kplus = k0 = kminus;
+                vmin = y[k * s];
+                vmax = vmin + 2 * lam;
+                umin = lam;
+                umax = -lam;
+            } else if (yn + umax - vmax > lam) {
+                close(k0, vmax);
+                kplus += 1;
+                k = kminus = k0 = kplus;
+                vmax = y[k * s];
+                vmin = vmax - 2 * lam;
+                umin = lam;
+                umax = -lam;
+            } else {
+                k += 1;
+                umin = umin + yn - vmin;
+                umax = umax + yn - vmax;
+                if (umin >= lam) {
+                    vmin += (umin - lam) / (double)(k - k0 + 1);
+                    umin = lam;
+                    kminus = k;
+                }
+                if (umax <= -lam) {
+                    vmax += (umax + lam) / (double)(k - k0 + 1);
+                    umax = -lam;
+                    kplus = k;
+                }
+            }
+        }
+    }
+    double cur = 0.0;
+    for (int i = 0; i < N; ++i) {
+        bool st = false;
+#pragma unroll
+        for (int w = 0; w < NWORDS; ++w) st = st || (((i >> 6) == w) && ((starts[w] >> (i & 63)) & 1ull));
+        if (st) cur = y[i * s];
+        y[i * s] = f(cur);
+    }
+}
+
+// the scan for a K-vector of any admissible length (FGL_MAX_K_TD8 = 318 <= 5 * 64): N is uniform over the launch
+template <class F>
+__device__ __forceinline__ void condat_scan(double* y, const int s, const int N, const double lam, F f)
+{
+    if (N <= 64) condat_uniform<1>(y, s, N, lam, f);
+    else if (N <= 128) condat_uniform<2>(y, s, N, lam, f);
+    else if (N <= 192) condat_uniform<3>(y, s, N, lam, f);
+    else if (N <= 256) condat_uniform<4>(y, s, N, lam, f);
+    else condat_uniform<5>(y, s, N, lam, f);
+}
+
 // A batch of G independent problems of K instances each (model-selection grid, ggl_mgl_batch_step): blockIdx.y = g,
 // the stacks are (G*K,p,p), l1G / l2G hold the thresholds of instance g*K (null: the scalars l1 / l2, G = 1), the
 // partial sums are rows [g][blocks].
-// ABL (GGL_DEV builds, timing ablations with wrong results): 1 no Condat scan, 2 no scan and no soft-threshold pass,
+// ABL (GGL_DEV builds, timing ablations, 1-3 with wrong results): 1 no Condat scan, 2 no scan and no soft-threshold pass, 4 the
+// nested-loop scan,
 // 3 scan only (no global loads / stores)
 template <int TD, bool FUSE_DUAL, int ABL = 0>
 __global__ __launch_bounds__(TD * TD) void k_theta_fgl(double* __restrict__ Theta, double* __restrict__ X,
@@ -464,9 +563,14 @@ __global__ __launch_bounds__(TD * TD) void k_theta_fgl(double* __restrict__ Thet
         }
     }
     if (pr_ok) {
-        if (ABL != 1 && ABL != 2) condat_inplace(ycol, NT, K, l2);
-        if (ABL != 2)
+        if (ABL == 4) {                   // the nested-loop scan (what ran until round 3): timing comparison, same results
+            condat_inplace(ycol, NT, K, l2);
             for (int k = 0; k < K; ++k) ycol[k * NT] = soft(ycol[k * NT], l1);
+        } else if (ABL != 1 && ABL != 2) {
+            condat_scan(ycol, NT, K, l2, [l1](double v) { return soft(v, l1); });     // prox_phi_fgl: prox_1norm(prox_tv(v))
+        } else if (ABL != 2) {
+            for (int k = 0; k < K; ++k) ycol[k * NT] = soft(ycol[k * NT], l1);
+        }
     }
     __syncthreads();
     if (ABL == 3) { if (tid == 0 && ycol[0] == 1.2345e300) Theta[0] = 0.0; return; }
@@ -547,8 +651,8 @@ static hipError_t launch_fgl_td(hipStream_t st, double* Theta, double* X, double
         dim3 grid(T * (T + 1) / 2, G), blk(TD, TD);
 #define GGL_FA(N) do { (void)hipFuncSetAttribute((const void*)k_theta_fgl<TD, true, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_theta_fgl<TD, true, N>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G); } while (0)
-        if (fuse_dual && a >= 1 && a <= 3) {
-            if (a == 1) GGL_FA(1); else if (a == 2) GGL_FA(2); else GGL_FA(3);
+        if (fuse_dual && a >= 1 && a <= 4) {
+            if (a == 1) GGL_FA(1); else if (a == 2) GGL_FA(2); else if (a == 3) GGL_FA(3); else GGL_FA(4);
             return hipGetLastError();
         }
 #undef GGL_FA
@@ -1094,7 +1198,7 @@ __global__ __launch_bounds__(64) void k_vec_prox(int mode, const double* __restr
     double* y = lds + threadIdx.x;
     for (int k = 0; k < K; ++k) y[k * 64] = Y[(size_t)v * K + k];
     if (mode == 0) {                      // prox_tv
-        condat_inplace(y, 64, K, l1);
+        condat_scan(y, 64, K, l1, [](double v) { return v; });
     } else if (mode == 1 || mode == 2) {  // prox_2norm / prox_phi_ggl
         double ss = 0.0;
         for (int k = 0; k < K; ++k) {
@@ -1107,8 +1211,7 @@ __global__ __launch_bounds__(64) void k_vec_prox(int mode, const double* __restr
         const double a = fmax(sqrt(ss), l);
         for (int k = 0; k < K; ++k) y[k * 64] = y[k * 64] * (a - l) / a;
     } else {                              // prox_phi_fgl
-        condat_inplace(y, 64, K, l2);
-        for (int k = 0; k < K; ++k) y[k * 64] = soft(y[k * 64], l1);
+        condat_scan(y, 64, K, l2, [l1](double v) { return soft(v, l1); });
     }
     for (int k = 0; k < K; ++k) out[(size_t)v * K + k] = y[k * 64];
 }

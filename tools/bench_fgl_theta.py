@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the FGL Theta-step's time goes (GGL_DEV build; GGL_FGL_ABL = 1 no Condat scan, 2 neither scan nor soft-threshold,
-3 scan only): Theta phase of the non-latent FGL iteration, HIP events.   python tools/bench_fgl_theta.py [K p]"""
+3 scan only, 4 the nested-loop scan that ran until round 3): Theta phase of the non-latent FGL iteration, HIP events.   python tools/bench_fgl_theta.py [K p]"""
 import os
 import sys
 
@@ -19,7 +19,7 @@ nk = np.ones(K)
 for _ in range(12):
     eng.step(1.0, 0.05, 0.01, "FGL", False, None, nk)
 eng.save_state()
-for abl in ("0", "1", "2", "3"):
+for abl in ("0", "4", "1", "2", "3"):
     if abl == "0":
         os.environ.pop("GGL_FGL_ABL", None)
     else:
