@@ -45,7 +45,7 @@ _SIGNATURES = {
     "ggl_ctx_get_option": ([_vp, _i, _dp], _i),
     "ggl_set_S": ([_vp, _dp], _i),
     "ggl_set_state": ([_vp, _dp, _dp, _dp, _dp], _i),
-    "ggl_set_state_ex": ([_vp, _dp, _dp, _dp, _dp, _i], _i),
+    "ggl_set_state_ex": ([_vp, _dp, _dp, _dp, _dp, ctypes.POINTER(_i)], _i),
     "ggl_set_S_ex": ([_vp, _dp, _i], _i),
     "ggl_get_state": ([_vp, _dp, _dp, _dp, _dp], _i),
     "ggl_state_snapshot": ([_vp, _i], _i),

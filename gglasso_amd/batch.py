@@ -207,8 +207,9 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
         assert len(nk) == K
     Om0 = np.repeat(np.eye(p)[None], K, axis=0) if Omega_0 is None else as_c(Omega_0)
     assert Om0.shape == S.shape
-    rep = lambda A: as_c(np.broadcast_to(A, (G,) + A.shape)).reshape(G * K, p, p)
-    eng = _solver.ENGINE(rep(S), rep(Om0), rep(Om0), np.zeros((G * K, p, p)))
+    # (G,K,p,p) broadcast VIEWS of the one problem's stacks, and of one zero matrix: uploaded once, replicated on the device
+    rep = lambda A: np.broadcast_to(as_c(A), (G,) + A.shape)
+    eng = _solver.ENGINE(rep(S), rep(Om0), rep(Om0), np.broadcast_to(np.zeros((p, p)), (G * K, p, p)))
     try:
         rhos = np.full(G, float(rho))
         done = np.zeros(G, dtype=bool)

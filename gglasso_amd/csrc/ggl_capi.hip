@@ -570,32 +570,34 @@ extern "C" void* ggl_device_ptr(ggl_ctx* c, int which)
 // ---------------------------------------------------------------------------------------------
 // state
 // ---------------------------------------------------------------------------------------------
-// host array -> device stack; shared: the host array is ONE (p,p) matrix, replicated K times on the device (one 8 p^2-byte
-// upload and log2 K doubling copies instead of K p^2 doubles over PCIe -- the batched grids start every instance from the
-// same S, Omega_0, X_0)
-static int upload_stack(ggl_ctx* c, double* dst, const double* src, bool shared)
+// host array -> device stack; an array SHARED by the instances -- one (p,p) matrix for all of them (SGL grids: same S, Omega_0,
+// X_0), or the (K',p,p) stack of one problem for each of the G grid points of a multiple-graph grid -- is uploaded once and
+// replicated on the device by doubling copies instead of travelling K times over PCIe
+static int upload_stack(ggl_ctx* c, double* dst, const double* src, int period)
 {
+    // period 0: the host array holds all K instances; P > 0: it holds P, and instance k is its instance k % P
     const size_t pp = (size_t)c->p * c->p;
-    if (!shared) {
+    if (period <= 0 || period >= c->K) {
         HIPCHK(hipMemcpyAsync(dst, src, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         return GGL_OK;
     }
-    HIPCHK(hipMemcpyAsync(dst, src, pp * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    for (size_t have = 1; have < (size_t)c->K; have *= 2) {
+    ARGCHK(c->K % period == 0, "the period of a shared array must divide K");
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)period * pp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    for (size_t have = (size_t)period; have < (size_t)c->K; have *= 2) {
         const size_t take = std::min(have, (size_t)c->K - have);
         HIPCHK(hipMemcpyAsync(dst + have * pp, dst, take * pp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
     return GGL_OK;
 }
 
-extern "C" int ggl_set_S_ex(ggl_ctx* c, const double* S, int shared)
+extern "C" int ggl_set_S_ex(ggl_ctx* c, const double* S, int period)
 {
     ARGCHK(c && S, "ctx, S");
     c->spec_have = false;
     c->cw_have = false;
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
-    int rc = upload_stack(c, c->S, S, shared != 0);
+    int rc = upload_stack(c, c->S, S, period);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return GGL_OK;
@@ -605,31 +607,32 @@ extern "C" int ggl_set_S(ggl_ctx* c, const double* S) { return ggl_set_S_ex(c, S
 
 static int host_reduce(ggl_ctx* c, int rows, int nv, double* out /*nv*/, bool take_max);
 extern "C" int ggl_set_state_ex(ggl_ctx* c, const double* Omega, const double* Theta, const double* L, const double* X,
-                                int shared_mask);
+                                const int* periods);
 
 extern "C" int ggl_set_state(ggl_ctx* c, const double* Omega, const double* Theta, const double* L, const double* X)
 {
-    return ggl_set_state_ex(c, Omega, Theta, L, X, 0);
+    return ggl_set_state_ex(c, Omega, Theta, L, X, nullptr);
 }
 
 extern "C" int ggl_set_state_ex(ggl_ctx* c, const double* Omega, const double* Theta, const double* L, const double* X,
-                                int shared_mask)
+                                const int* periods)
 {
-    // shared_mask bit 0 / 1 / 2 / 3: Omega / Theta / L / X is ONE (p,p) matrix for all instances
+    // periods (may be null = all 0): how many instances the host array of Omega / Theta / L / X holds (0: all K)
     ARGCHK(c, "ctx");
+    const int pr[4] = {periods ? periods[0] : 0, periods ? periods[1] : 0, periods ? periods[2] : 0, periods ? periods[3] : 0};
     c->spec_have = false;      // bounds of another iterate say nothing about this one
     c->cw_have = false;        // (any positive vector would do, but every solve shall start the same way)
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
     const size_t nb = c->n * sizeof(double);
     int rc = GGL_OK;
-    if (Omega) rc = upload_stack(c, c->Om[c->cur], Omega, (shared_mask & 1) != 0);
-    if (!rc && Theta) rc = upload_stack(c, c->Theta, Theta, (shared_mask & 2) != 0);
-    if (!rc && L) rc = upload_stack(c, c->L, L, (shared_mask & 4) != 0);
+    if (Omega) rc = upload_stack(c, c->Om[c->cur], Omega, pr[0]);
+    if (!rc && Theta) rc = upload_stack(c, c->Theta, Theta, pr[1]);
+    if (!rc && L) rc = upload_stack(c, c->L, L, pr[2]);
     if (rc) return rc;
     if (!L) HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
     c->step_latent = (L != nullptr);          // a snapshot taken before any step keeps an uploaded L as well
-    if (X) { rc = upload_stack(c, c->X, X, (shared_mask & 8) != 0); if (rc) return rc; }
+    if (X) { rc = upload_stack(c, c->X, X, pr[3]); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
     // exact symmetry of the dual and latent stacks decides whether the per-element Theta-step may be used
     c->state_symmetric = true;

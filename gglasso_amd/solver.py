@@ -42,11 +42,17 @@ def latent_rank(L, rel_tol=RANK_REL_TOL):
     return int(np.count_nonzero(a > a.max() * max(rel_tol, L.shape[0] * np.finfo(np.float64).eps)))
 
 
-def _shared_or_full(A):
-    """(C-contiguous host array to upload, is it ONE (p,p) matrix shared by all K instances?)"""
+def _host_period(A):
+    """(C-contiguous host array to upload, period): a numpy.broadcast_to VIEW (stride 0 along its first axis) of one (p,p)
+    matrix as (K,p,p), or of one (K',p,p) stack as (G,K',p,p), is uploaded once -- period 1 resp. K' -- and replicated on
+    the device (ggl_set_S_ex / ggl_set_state_ex); anything else travels whole (period 0)."""
     if A.ndim == 3 and A.shape[0] > 1 and A.strides[0] == 0:
-        return as_c(A[0]), True
-    return as_c(A), False
+        return as_c(A[0]), 1
+    if A.ndim == 4:
+        if A.shape[0] > 1 and A.strides[0] == 0:
+            return as_c(A[0]), int(A.shape[1])
+        return as_c(A).reshape(-1, A.shape[2], A.shape[3]), 0
+    return as_c(A), 0
 
 
 class HipEngine:
@@ -58,7 +64,7 @@ class HipEngine:
         _lib.require_gpu()
         self.lib = _lib.load()
         S = np.asarray(S, dtype=np.float64)
-        self.K, self.p, _ = S.shape
+        self.K, self.p = int(np.prod(S.shape[:-2])), int(S.shape[-1])      # (K,p,p), or (G,K',p,p) for a grid of problems
         h = _lib._vp()
         flags = int(eig) | (0 if stream is None else _lib.CTX_STREAM_GIVEN)
         check(self.lib.ggl_ctx_create(int(device), self.K, self.p, flags, stream, h))
@@ -67,19 +73,19 @@ class HipEngine:
         self.stream_handle = None if stream is None else int(stream)
         for name, value in {**ENGINE_OPTIONS, **(options or {})}.items():
             self.set_option(name, value)
-        # a (K,p,p) BROADCAST view of one (p,p) matrix (numpy.broadcast_to: stride 0 along K -- what the batched grids pass
-        # for S, Omega_0, X_0) is uploaded once and replicated on the device instead of being materialised on the host
-        Sh, s_shared = _shared_or_full(S)
-        check(self.lib.ggl_set_S_ex(self.h, ptr(Sh), int(s_shared)))
-        arrs, mask = [], 0
-        for bit, A in enumerate((Omega_0, Theta_0, L_0, X_0)):
+        # broadcast VIEWS (what the batched grids pass for S, Omega_0, X_0) are uploaded once and replicated on the device
+        # instead of being materialised on the host: _host_period
+        import ctypes
+        Sh, s_period = _host_period(S)
+        check(self.lib.ggl_set_S_ex(self.h, ptr(Sh), s_period))
+        arrs, periods = [], (ctypes.c_int * 4)(0, 0, 0, 0)
+        for slot, A in enumerate((Omega_0, Theta_0, L_0, X_0)):
             if A is None:
                 arrs.append(None)
                 continue
-            Ah, shared = _shared_or_full(np.asarray(A, dtype=np.float64))
+            Ah, periods[slot] = _host_period(np.asarray(A, dtype=np.float64))
             arrs.append(Ah)
-            mask |= int(shared) << bit
-        check(self.lib.ggl_set_state_ex(self.h, ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3]), mask))
+        check(self.lib.ggl_set_state_ex(self.h, ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3]), periods))
         self._norms = np.zeros(5)
         self._norms_p = ptr(self._norms)
         self._ptr_cache = {}

@@ -135,12 +135,14 @@ int ggl_ctx_get_option(ggl_ctx *ctx, int option, double *value);
 int ggl_set_S(ggl_ctx *ctx, const double *S_host);
 int ggl_set_state(ggl_ctx *ctx, const double *Omega, const double *Theta, const double *L,
                   const double *X);
-/* The same with arrays SHARED by all K instances (a model-selection grid starts every instance from the same S, Omega_0, X_0):
- * `shared` / bit 0,1,2,3 of shared_mask (Omega, Theta, L, X) says the pointer is ONE (p,p) matrix, uploaded once and
- * replicated on the device. */
-int ggl_set_S_ex(ggl_ctx *ctx, const double *S_host, int shared);
+/* The same with arrays SHARED by the instances of a batch: `period` / periods[0..3] (Omega, Theta, L, X; NULL = all 0) is the
+ * number of instances the host array holds -- 0: all K; P > 0 (a divisor of K): P, and instance k of the ctx is its instance
+ * k % P.  P = 1: one (p,p) matrix for all (the grid of single_grid_search starts every instance from the same S, Omega_0, X_0);
+ * P = K': the stack of ONE multiple-graph problem for each of the G grid points of grid_search.  Uploaded once, replicated on
+ * the device. */
+int ggl_set_S_ex(ggl_ctx *ctx, const double *S_host, int period);
 int ggl_set_state_ex(ggl_ctx *ctx, const double *Omega, const double *Theta, const double *L, const double *X,
-                     int shared_mask);
+                     const int *periods);
 int ggl_get_state(ggl_ctx *ctx, double *Omega, double *Theta, double *L, double *X);
 /* restore == 0: keep a device copy of the iterate; != 0: make it the iterate again (ggl_set_state with the arrays of that
  * moment, without the host round trip; everything carried from earlier iterations is forgotten, as in ggl_set_state). */

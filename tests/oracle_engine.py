@@ -8,13 +8,14 @@ from oracle import ggl_oracle as orc
 
 class OracleEngine:
     def __init__(self, S, Omega_0, Theta_0, X_0, L_0=None, **_ignored):
-        self.S = np.array(S, dtype=np.float64)
+        flat = lambda A: np.array(A, dtype=np.float64).reshape(-1, np.shape(A)[-2], np.shape(A)[-1])   # (G,K',p,p) -> (G*K',p,p)
+        self.S = flat(S)
         self.K, self.p, _ = self.S.shape
-        self.Om = np.array(Omega_0, dtype=np.float64)
+        self.Om = flat(Omega_0)
         self.Om_prev = np.zeros_like(self.Om)
-        self.Th = np.array(Theta_0, dtype=np.float64)
-        self.X = np.array(X_0, dtype=np.float64)
-        self.L = np.zeros_like(self.S) if L_0 is None else np.array(L_0, dtype=np.float64)
+        self.Th = flat(Theta_0)
+        self.X = flat(X_0)
+        self.L = np.zeros_like(self.S) if L_0 is None else flat(L_0)
         self.groupsq = np.zeros((self.p, self.p))
         self.mask = None
         self.D = None

@@ -670,3 +670,21 @@ def test_shared_start_arrays_are_replicated_on_the_device():
             finally:
                 e1.close()
                 e2.close()
+    # (G,K',p,p) views: the stack of ONE multiple-graph problem for each of G grid points (ADMM_MGL_batch)
+    Kp = 3
+    B = [np.stack([a + k for k in range(Kp)]) for a in A[:4]]
+    for G in (2, 5, 8):
+        views = [np.broadcast_to(b, (G, Kp, p, p)) for b in B]
+        full = [np.ascontiguousarray(v).reshape(G * Kp, p, p) for v in views]
+        zero = np.broadcast_to(np.zeros((p, p)), (G * Kp, p, p))
+        e1 = solver.HipEngine(views[0], views[1], views[2], zero)
+        e2 = solver.HipEngine(full[0], full[1], full[2], np.zeros((G * Kp, p, p)))
+        try:
+            assert e1.K == G * Kp
+            s1, s2 = e1.state(), e2.state()
+            for nm in ("Omega", "Theta", "X", "L"):
+                assert np.array_equal(s1[nm], s2[nm]), (G, nm)
+            assert np.array_equal(s1["Theta"], full[2])
+        finally:
+            e1.close()
+            e2.close()
