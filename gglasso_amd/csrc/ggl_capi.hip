@@ -1298,12 +1298,12 @@ static int rank_step(ggl_ctx* c)
     // Two tiers.  The schedule's length is set by the smallest gap between an eigenvalue of C and the threshold over ALL
     // instances of the batch (C4, K = 50: 2e-6 .. 4e-5 of |C - mu I| for the worst instance, 1.5e-4 for the 10 % quantile, 1.3e-3
     // for the median: profiles/r3_c4_lstep_threshold_gaps.txt), and the degree sequence is common to a launch.  So the first
-    // pass plans for rank_l0_coarse (29 products instead of 37), the residual check says per instance whether that was
+    // pass plans for rank_l0_coarse (32 products at 2e-5 instead of 37), the checks say per instance whether that was
     // enough, and the few instances it was not enough for go on as a compact sub-batch -- from the iterate they have, with
     // the schedule for where an eigenvalue at the FINE resolution would be by now (rank_ns_image).  Same guarantee as the
     // one-tier run (eigenvalues at least rank_l0 |B| away from the threshold are resolved, the check catches the others).
     const double l_fine = l0;
-    const bool two_tier = c->rank_l0_coarse > l_fine && K >= 4 && (c->p & 1) == 0;
+    const bool two_tier = c->rank_l0_coarse > l_fine && K >= 4;
     // resolutions of the full-batch passes, in order: [coarse (+ continuation of the instances it left),] fine, 1e-10
     double stages[3];
     int nstage = 0;

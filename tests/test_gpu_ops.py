@@ -424,7 +424,7 @@ def _with_gaps(rng, p, beta, gaps, scale=1.0):
     return 0.5 * (C + C.T)
 
 
-@pytest.mark.parametrize("p", [200, 500])
+@pytest.mark.parametrize("p", [200, 333, 500])
 def test_rank_two_tier_continues_only_the_unresolved_instances(p):
     """Two-tier L-step (GGL_OPT_RANK_L0_COARSE): the first pass plans for eigenvalues 1e-4 |C - mu I| away from the
     threshold; instances with a closer one (here 3e-5 and 4e-6) fail ITS residual check and are continued as a
