@@ -156,7 +156,7 @@ struct ggl_ctx {
     bool rank_ns = false;                            // L-step by sign Newton-Schulz (else eigendecomposition)
     bool rank_eig = false;                           // GGL_OPT_RANK_EIG: force the eigendecomposition route
     double rank_l0 = 1e-6;                           // resolution of the scaling schedule
-    double rank_l0_coarse = 2e-5;                    // two-tier L-step: resolution of the first pass over the whole batch (0: one tier)
+    double rank_l0_coarse = 8e-5;                    // two-tier L-step: resolution of the first pass over the whole batch (0: one tier)
     int* rank_idx = nullptr;                         // [K] instances of the compact continuation batch (device), lazy
     int* rank_idx_h = nullptr;                       // ... pinned mirror
     long long rank_continued = 0, rank_cont_instances = 0;
@@ -1286,9 +1286,31 @@ static int rank_step(ggl_ctx* c)
     const double* mu_h = c->par_h + 2 * (size_t)K;
     if (!c->rank_ns) return eig_recon(c, c->W, c->L, c->DvL, MAP_RANK, c->par + 2 * (size_t)K, GGL_PH_EIG_L, GGL_PH_RECON_L);
     PB(c, GGL_PH_EIG_L);
-    const int nbb = norm_bounds_blocks(c->p);
-    launch_norm_bounds(c->stream, c->W, K, c->p, c->nbpart);
-    launch_bound_final(c->stream, c->nbpart, nullptr, nbb, K, c->bounds_h, 1);     // min(|C|_inf, |C|_F)
+    // |C|_2 bound.  From P = C C where the product kernel leaves bound partials (newton_schulz.hip, k_bound_sqrt_inf_fro: 2.4x
+    // the spectral radius instead of the 10x of min(|C|_inf, |C|_F) -- about three products of the schedule); P is the first
+    // product of the iteration anyway and stays in nsT for the first pass (t0_ready).
+    const int btile = c->fused_bounds ? symm_bounds_tile(K, c->p, c->symm_variant) : 0;
+    bool have_P = false;
+    if (btile) {
+        for (int k = 0; k < K; ++k) {
+            double* o = c->coef_h + (size_t)k * NS_NCOEF;
+            o[0] = 0.0; o[1] = 1.0; o[2] = o[3] = o[4] = o[5] = 0.0;
+        }
+        CopySegs upP;
+        upP.add(c->coef, c->coef_h, (size_t)K * NS_NCOEF * sizeof(double));
+        launch_copy_small(c->stream, upP);
+        const int bT = (c->p + btile - 1) / btile;
+        launch_symm(c->stream, c->W, c->W, c->nsT, nullptr, nullptr, c->coef, K, c->p, c->symm_variant, nullptr, c->rowpart,
+                    c->fropart);
+        launch_bound_rows(c->stream, c->rowpart, bT, K, c->p, c->nbrow, c->infpart);
+        launch_bound_sqrt_inf_fro(c->stream, c->infpart, bound_rows_blocks(c->p), c->fropart, bT * (bT + 1) / 2, K, c->bounds_h);
+        c->rank_units += 1.0;
+        have_P = true;
+    } else {
+        const int nbb = norm_bounds_blocks(c->p);
+        launch_norm_bounds(c->stream, c->W, K, c->p, c->nbpart);
+        launch_bound_final(c->stream, c->nbpart, nullptr, nbb, K, c->bounds_h, 1);     // min(|C|_inf, |C|_F)
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<double> cn(c->bounds_h, c->bounds_h + K);
@@ -1332,13 +1354,16 @@ static int rank_step(ggl_ctx* c)
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
             for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
         }
+        const bool t0_ready = have_P && stage == 0;       // nsT still holds P = C C of the bound: T0 in place, no first product
         for (int h = 0, k0 = 0; h < nh; ++h) {
             const int Kr = K / nh + (h < K % nh ? 1 : 0);
+            hipStream_t sh = h == 0 ? c->stream : c->streamx[h - 1];
+            if (t0_ready) launch_rank_t0(sh, c->nsT + k0 * pp, c->W + k0 * pp, c->coef + NS_NCOEF * (size_t)k0, Kr, c->p);
             // scratch: Xa = nsYP[0], Xb = nsYP[0] + n, P2 = nsYP[1], T = nsT
-            rank_ns_run(h == 0 ? c->stream : c->streamx[h - 1], plan, c->coef + NS_NCOEF * (size_t)k0, c->W + k0 * pp,
+            rank_ns_run(sh, plan, c->coef + NS_NCOEF * (size_t)k0, c->W + k0 * pp,
                         c->nsYP[0] + k0 * pp, c->nsYP[0] + c->n + k0 * pp, c->nsT + k0 * pp, c->nsYP[1] + k0 * pp,
                         c->L + k0 * pp, c->maxdev + k0, Kr, c->p, (c->symm_variant < 0 && nh > 1) ? 17 : c->symm_variant,
-                        NS_SLOT(K));
+                        NS_SLOT(K), t0_ready);
             k0 += Kr;
         }
         for (int h = 1; h < nh; ++h) {
@@ -1346,7 +1371,7 @@ static int rank_step(ggl_ctx* c)
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
         }
         HIPCHK(hipGetLastError());
-        c->rank_units += plan.products;
+        c->rank_units += plan.products - (t0_ready ? 1 : 0);      // (the C C product was counted with the bound)
         c->rank_launches = (long long)(c->rank_units + 0.5);
         // the two checks of the result (newton_schulz.hip: rank_check, rank_trace_tolerance): the entrywise residual of the
         // last step, and the distance of trace(X_last) = trace(P2) - p from an integer

@@ -311,7 +311,13 @@ double rank_trace_tolerance(double l0, int p);      // accepted distance of trac
 int rank_ns_plan_continue(const double* mu_h, int m, double lp, double* coef_h, NsPlan* plan, int degrees, size_t slot);
 void rank_ns_steps(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* X, double* Xn, double* Tb,
                    double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cs);
+// t0_ready: Tb already holds the first step's T0 (launch_rank_t0 from P = C C; the bound then came from P as well)
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
-                 double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot = 0);
+                 double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot = 0,
+                 bool t0_ready = false);
+// b_k = sqrt(min(|P_k|_inf, |P_k|_F)) >= rho(C_k) for P = C C, from the product launch's partials (launch_bound_rows first)
+void launch_bound_sqrt_inf_fro(hipStream_t st, const double* infpart, int ninf, const double* fropart, int ntile, int K,
+                               double* out);
+void launch_rank_t0(hipStream_t st, double* P, const double* C, const double* coef_d, int K, int p);
 
 }  // namespace ggl

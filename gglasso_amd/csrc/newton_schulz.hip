@@ -987,6 +987,53 @@ void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int
     hipLaunchKernelGGL(k_cw_bounds, dim3(norm_bounds_blocks(p), K), dim3(256), 0, st, W, rowsum, p, part);
 }
 
+// ---- the L-step's norm bound from C^2 -------------------------------------------------------------------------------------
+// The sign iteration scales with a bound nb >= |C - mu I|_2 and its resolution is relative to nb, so every factor 2.6 of slack
+// in the bound costs a cubic step (two products).  min(|C|_inf, |C|_F) is ~10x the spectral radius on the C = Theta - X - Omega
+// of an ADMM run (profiles/r3_two_tier_lstep.txt); sqrt(min(|C^2|_inf, |C^2|_F)) is 2.4x -- and C^2 is the iteration's first
+// product anyway.  So: P = C C as a plain product whose epilogue leaves the row sums and Frobenius shares of P behind
+// (launch_symm rowpart / fropart), launch_bound_rows + this kernel turn them into b_k >= rho(C_k), the host plans with
+// nb_k = b_k + mu_k, and T0 = cI I + cAcc P + cE C (the first launch's affine epilogue, same arithmetic) is formed in place.
+__global__ void k_bound_sqrt_inf_fro(const double* __restrict__ infpart, int ninf, const double* __restrict__ fropart,
+                                     int ntile, int K, double* __restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double inf = 0.0, sq = 0.0;
+    for (int b = 0; b < ninf; ++b) inf = fmax(inf, infpart[(size_t)k * ninf + b]);
+    for (int t = 0; t < ntile; ++t) sq += fropart[(size_t)k * ntile + t];
+    const double fr = sqrt(sq);
+    out[k] = sqrt((fr < inf ? fr : inf)) * (1.0 + 1e-12);          // rho(C)^2 = rho(C^2) <= min(|C^2|_inf, |C^2|_F)
+}
+
+void launch_bound_sqrt_inf_fro(hipStream_t st, const double* infpart, int ninf, const double* fropart, int ntile, int K,
+                               double* out)
+{
+    hipLaunchKernelGGL(k_bound_sqrt_inf_fro, dim3((K + 63) / 64), dim3(64), 0, st, infpart, ninf, fropart, ntile, K, out);
+}
+
+// T0 = cI I + cAcc P + cE C in place over P; coef: slot 0 of rank_ns_plan ({cI, cAcc, cE, ...} per instance)
+__global__ __launch_bounds__(256) void k_rank_t0(double* __restrict__ P, const double* __restrict__ C,
+                                                 const double* __restrict__ coef, int p)
+{
+    const int k = blockIdx.y;
+    const double cI = coef[k * NS_NCOEF + 0], cAcc = coef[k * NS_NCOEF + 1], cE = coef[k * NS_NCOEF + 2];
+    const size_t pp = (size_t)p * p, base = (size_t)k * pp;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < pp; e += (size_t)gridDim.x * 256) {
+        double v = cAcc * P[base + e];
+        if (e % ((size_t)p + 1) == 0) v += cI;
+        v += cE * C[base + e];
+        P[base + e] = v;
+    }
+}
+
+void launch_rank_t0(hipStream_t st, double* P, const double* C, const double* coef_d, int K, int p)
+{
+    const size_t pp = (size_t)p * p;
+    const int bx = (int)std::min<size_t>((pp + 255) / 256, 512);
+    hipLaunchKernelGGL(k_rank_t0, dim3(bx, K), dim3(256), 0, st, P, C, coef_d, p);
+}
+
 // Residual check of the sign iteration's result: an eigenvalue x of the iterate before the last step shows up as
 // |t(x^2) - 1| ~ e = 1 - |x| in T_last, and the last step turns it into a sign error of 1.5 e^2 (cubic), 2.5 e^3 (quintic) or
 // 7.9 e^5 (degree nine).  An eigenvalue the schedule leaves short of convergence sits within l0 |B| of the threshold (the
@@ -1133,14 +1180,14 @@ int rank_ns_plan_continue(const double* mu_h, int m, double lp, double* coef_h, 
 }
 
 void rank_ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* C, double* Xa, double* Xb,
-                 double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot)
+                 double* Tb, double* P2, double* out, double* maxdev, int K, int p, int variant, size_t cslot, bool t0_ready)
 {
     // maxdev must be zero on entry; cslot: doubles between the coefficient slots of successive launches
     // (0 = NS_SLOT(K); a sub-batch of a larger table passes the table's slot size).
     // scratch of the higher-degree steps: M = X^2 in `out` (free until the last launch), Q in P2 (free until the last
     // step's second output), Q + d I in the other X buffer (free until X T is written there)
     const size_t cs = cslot ? cslot : NS_SLOT(K);
-    launch_symm(st, C, C, Tb, nullptr, C, coef_d, K, p, variant);
+    if (!t0_ready) launch_symm(st, C, C, Tb, nullptr, C, coef_d, K, p, variant);     // else: Tb holds T0 (launch_rank_t0)
     launch_symm(st, C, Tb, Xa, nullptr, Tb, coef_d + cs, K, p, variant);
     rank_ns_steps(st, plan, coef_d + 2 * cs, C, Xa, Xb, Tb, P2, out, maxdev, K, p, variant, cs);
 }

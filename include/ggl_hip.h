@@ -117,13 +117,14 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                     * concurrent parts; 2: wherever it can run (any K >= 8, even p).  Same products, same bits
                                     * (tests/test_gpu_chain.py).  Off by default: measured SLOWER on MI355X (headline Omega
                                     * phase 0.89 vs 0.72 ms; DESIGN.md section 8.1, profiles/r3_omega_chain_*.txt)           */
-#define GGL_OPT_RANK_L0_COARSE 18  /* [2e-5] two-tier L-step (sign iteration, p > GGL_JACOBI_MAX_P): the first pass over the whole batch
+#define GGL_OPT_RANK_L0_COARSE 18  /* [8e-5] two-tier L-step (sign iteration, p > GGL_JACOBI_MAX_P): the first pass over the whole batch
                                     * resolves eigenvalues of C down to this distance from the threshold (relative to |C - mu I|);
                                     * the instances whose residual check says that was not enough are continued, from the iterate
                                     * they have, as a compact sub-batch down to the resolution of the one-tier run (1e-6).  The
                                     * schedule's length is set by the WORST instance of a batch and its degree sequence is common
                                     * to a launch: at K = 50, p = 500 the batch needs 1e-6, nine instances in ten 1e-4
-                                    * (28 instead of 37 products).  Measured there: 117 -> 147 it/s, flat for 3e-6 .. 2e-5.
+                                    * (28 instead of 37 products).  Measured there (with the norm bound from C^2): 154 -> 175 it/s,
+                                    * flat for 5e-5 .. 1e-4.
                                     * 0: one tier.                                                                            */
 int ggl_ctx_set_option(ggl_ctx *ctx, int option, double value);
 int ggl_ctx_get_option(ggl_ctx *ctx, int option, double *value);
