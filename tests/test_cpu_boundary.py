@@ -492,3 +492,55 @@ def test_block_sgl_ragged_components_share_padded_batches(oracle_engine):
             assert np.abs(solm[nm] - refm[nm]).max() <= 1e-10, nm
     finally:
         solver.ENGINE = keep
+
+
+def test_host_period_of_broadcast_views():
+    """solver._host_period: which host arrays travel once and are replicated on the device (ggl_set_S_ex / ggl_set_state_ex)."""
+    from gglasso_amd.solver import _host_period
+    p = 6
+    A = np.arange(p * p, dtype=np.float64).reshape(p, p)
+    h, per = _host_period(np.broadcast_to(A, (5, p, p)))
+    assert per == 1 and h.shape == (p, p) and h.flags.c_contiguous and np.array_equal(h, A)
+    full = np.ascontiguousarray(np.broadcast_to(A, (5, p, p)))
+    h, per = _host_period(full)
+    assert per == 0 and h.shape == (5, p, p)
+    h, per = _host_period(np.broadcast_to(A, (1, p, p)))            # K = 1: nothing to replicate
+    assert per == 0 and h.shape == (1, p, p)
+    B = np.stack([A, A + 1, A + 2])
+    h, per = _host_period(np.broadcast_to(B, (4, 3, p, p)))          # one problem's stacks for 4 grid points
+    assert per == 3 and h.shape == (3, p, p) and np.array_equal(h, B)
+    h, per = _host_period(np.ascontiguousarray(np.broadcast_to(B, (4, 3, p, p))))
+    assert per == 0 and h.shape == (12, p, p)
+    h, per = _host_period(np.asfortranarray(full))                   # any other layout is materialised
+    assert per == 0 and h.flags.c_contiguous
+
+
+def test_latent_rank_rule_and_threshold_choice():
+    """solver.latent_rank (the RANK tables' rule, solver.RANK_REL_TOL) and model_selection._pick_threshold (tune_threshold's
+    choice, helper/model_selection.py:718-735, from the device table) on the host."""
+    from gglasso_amd import solver, model_selection as ms
+    rng = np.random.default_rng(4)
+    p = 40
+    Q, _ = np.linalg.qr(rng.standard_normal((p, p)))
+    ev = np.zeros(p)
+    ev[:7] = rng.uniform(0.1, 2.0, 7)
+    L = (Q * ev) @ Q.T
+    L = 0.5 * (L + L.T)
+    assert solver.latent_rank(L) == 7 == np.linalg.matrix_rank(L, hermitian=True)
+    noisy = L + 1e-13 * (Q[:, 7:9] @ Q[:, 7:9].T)                    # a null space at 1e-13 |L|, as the sign iteration leaves it
+    assert np.linalg.matrix_rank(noisy, hermitian=True) > 7 and solver.latent_rank(noisy) == 7
+    assert solver.latent_rank(np.zeros((p, p))) == 0
+    # threshold choice: scores from a table {<S,T>, log det T, nnz, lambda_min} equal the host criteria; -inf log det -> nan
+    S = np.cov(rng.standard_normal((p, 4 * p)))
+    Th = np.linalg.inv(S + 0.5 * np.eye(p))
+    Th[np.abs(Th) < 0.02] *= 1e-3
+    taus = ms.default_tau_range()
+    N = 3 * p
+    tab = np.zeros((len(taus), 4))
+    for j, tau in enumerate(taus):
+        T = ms.thresholding(Th, tau)
+        d = np.linalg.eigvalsh(T)
+        tab[j] = [np.sum(S * T), -np.inf if d.min() <= 1e-12 else np.linalg.slogdet(T)[1], np.count_nonzero(T), d.min()]
+    for method in ("eBIC", "AIC"):
+        _, tau, scores = ms.tune_threshold(Th, S, N, method=method, gamma=0.3)
+        assert taus[ms._pick_threshold(tab.copy(), N, p, method, 0.3)] == tau
