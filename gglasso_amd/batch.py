@@ -174,7 +174,9 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
     Every problem keeps its OWN rho, residuals, rho updates and stopping decision, exactly as if it had been solved
     on its own from ``Omega_0`` (default: identity; Theta_0 = Omega_0, X_0 = 0 as in admm_solver.py:142-150), so each
     returned (sol, info) equals the independent solve; a problem's solution is snapshotted at the iteration it
-    converges and it keeps iterating harmlessly until the batch is done.
+    converges and it keeps iterating harmlessly until the batch is done.  (A solver error -- a non-finite iterate, an
+    eigensolver that does not converge -- in ANY point, finished or not, raises and ends the whole batch: the sequential walk
+    ``grid_search(..., batched=False)`` isolates the points.)
     mu1: (K,) shared by all problems or (G,K); n_samples as in ADMM_MGL.
     Returns a list of G ``(sol, info)``; ``info`` carries 'status', 'iterations', 'rho' (+ 'selection': per-instance
     (K,4) array of <S,Theta>, log det Theta, count_nonzero(Theta), lambda_min(Theta) from the GPU when
