@@ -232,16 +232,25 @@ def main():
     eng = make_engine()
     comm_note = None
     if distributed and args.comm == "capi":
-        # RCCL behind the C ABI is a second RCCL instance in this process beside torch's own.  Should its communicator not
-        # come up on SOME rank, ALL ranks fall back to torch.distributed's collectives together (and the line says so)
-        # rather than lose the run.
+        # RCCL behind the C ABI is a second RCCL instance in this process beside torch's own.  Should it not come up, ALL ranks
+        # fall back to torch.distributed's collectives together (and the line says so) rather than lose the run.  Only
+        # SYMMETRIC failures can be handled that way -- the library missing its RCCL symbols or rank 0 failing to create
+        # the unique id (dist.CommIdError is raised on every rank), the forced failure of the test: every rank then reaches
+        # the all-reduce of the flag below.  A rank that fails alone inside ncclCommInitRank leaves the others in RCCL's
+        # rendezvous; entering a torch collective there would only add a second hang, so it exits non-zero and
+        # the launcher tears the job down.
+        from gglasso_amd.dist import CommIdError
         err = None
         try:
             if os.environ.get("GGL_BENCH_FAIL_CAPI"):
-                raise RuntimeError("GGL_BENCH_FAIL_CAPI is set (test of the fallback)")
+                raise CommIdError("GGL_BENCH_FAIL_CAPI is set (test of the fallback)")
             comm.attach(eng)
-        except Exception as e:  # noqa: BLE001 -- anything at all: the decision has to be taken collectively
+        except CommIdError as e:
             err = f"{type(e).__name__}: {e}"
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: rank {rank}: RCCL communicator behind the C ABI failed on this rank ({type(e).__name__}: {e}); "
+                  "leaving the job", file=sys.stderr, flush=True)
+            os._exit(3)
         flag = torch.tensor([0 if err is None else 1], device=f"cuda:{local_rank}")
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
         if int(flag.item()) != 0:

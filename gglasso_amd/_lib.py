@@ -92,6 +92,8 @@ _SIGNATURES = {
     "ggl_selection_stats": ([_vp, _dp], _i),
     "ggl_threshold_scan": ([_vp, _dp, _i, _dp, ctypes.POINTER(_i)], _i),
     "ggl_selection_rank": ([_vp, _d, _dp], _i),
+    "ggl_finalize_L": ([_vp, _i, ctypes.POINTER(_i)], _i),
+    "ggl_get_snapshot_k": ([_vp, _i, _dp, _dp], _i),
     "ggl_dev_ns_schedule": ([_d, _i, _i, ctypes.POINTER(_i), _dp, ctypes.POINTER(_i)], _i),
     "ggl_dev_ns_schedule_tol": ([_d, _i, _d, _i, ctypes.POINTER(_i), _dp, ctypes.POINTER(_i)], _i),
     "ggl_ns_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),

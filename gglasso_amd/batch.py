@@ -27,9 +27,10 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     Returns a list of K ``(sol, info)`` pairs with the reference's keys; ``info`` additionally carries
     ``'iterations'`` and the final ``'rho'``.  ``selection_stats``: also keep a device snapshot of every instance's
     solution's Theta and attach ``info['selection'] = {'Sdot','logdet','nnz','lambda_min'}`` computed on the GPU
-    (what the AIC / eBIC tables of model selection are made of); with ``latent`` also ``'rank'``: the row
-    ``HipEngine.selection_rank`` returns for the instance's L (rank at ``solver.RANK_REL_TOL``, max|lambda|,
-    and the two eigenvalue magnitudes either side of the cut); with ``tau_range`` also ``'threshold'``: the
+    (what the AIC / eBIC tables of model selection are made of); with ``latent`` also ``'rank'``:
+    numpy.linalg.matrix_rank of the instance's L (an int; every returned L is rebuilt from one eigendecomposition of
+    its last L-step's input at the end of the batch, ``HipEngine.finalize_L``, and where that happened on the device the
+    count of eigenvalues above the threshold comes with it); with ``tau_range`` also ``'threshold'``: the
     (len(tau_range), 4) table of the same four statistics for the estimate thresholded at every tau (tune_threshold,
     helper/model_selection.py:707-737).
     ``dims`` (K,) ints: problems of DIFFERENT dimension in one batch -- instance k is the leading (dims[k], dims[k]) block
@@ -69,9 +70,14 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
         if A is None or len(A) == 0:
             A = default
         A = np.asarray(A, dtype=np.float64)
-        if A.ndim == 3 and A.strides[0] == 0:
+        # (p,p), (1,p,p) [shared] or (K,p,p); anything else is an error here, not a read past the end of the buffer in C
+        assert A.ndim in (2, 3) and A.shape[-2:] == (p, p) and (A.ndim == 2 or A.shape[0] in (1, K)), \
+            f"start array of shape {A.shape}: expected ({p},{p}) or ({K},{p},{p})"
+        if A.ndim == 3 and A.shape[0] == K and (A.strides[0] == 0 or K == 1):
             return A
-        return np.broadcast_to(as_c(A), (K, p, p)) if A.ndim == 2 else as_c(A)
+        if A.ndim == 3 and A.shape[0] == K:
+            return as_c(A)
+        return np.broadcast_to(as_c(A if A.ndim == 2 else A[0]), (K, p, p))
 
     Om0 = stack(Omega_0, np.eye(p))
     Th0 = stack(Theta_0, Om0)
@@ -97,6 +103,7 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
         def state_of(k):
             st = eng.state_k(k, latent)
             return st if dims is None else {nm: np.ascontiguousarray(A[:pk[k], :pk[k]]) for nm, A in st.items()}
+        keep_snapshots = selection_stats or latent
         for it in range(max_iter):
             sq = eng.sgl_batch_step(rhos, lam, latent, mu)
             fac = np.ones(K)
@@ -118,7 +125,7 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
             for k in range(K):
                 if done[k] and results[k] is None:
                     results[k] = (state_of(k), {'status': 'optimal', 'iterations': it + 1, 'rho': rhos[k]})
-                    if selection_stats:
+                    if keep_snapshots:
                         eng.snapshot_k(k)
             if done.all():
                 break
@@ -128,8 +135,9 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                 status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
                                                                 else 'max iterations reached')
                 results[k] = (state_of(k), {'status': status, 'iterations': max_iter, 'rho': rhos[k]})
-                if selection_stats:
+                if keep_snapshots:
                     eng.snapshot_k(k)
+        ranks = _final_L(eng, [results[k][0] for k in range(K)], 1) if latent else None
         if selection_stats:
             assert dims is None, "selection statistics are taken over whole slots"
             st = eng.selection_stats()
@@ -137,9 +145,8 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                 results[k][1]['selection'] = {'Sdot': st[k, 0], 'logdet': st[k, 1], 'nnz': st[k, 2],
                                               'lambda_min': st[k, 3]}
             if latent:
-                rk = eng.selection_rank(_solver.RANK_REL_TOL)
                 for k in range(K):
-                    results[k][1]['selection']['rank'] = rk[k].copy()
+                    results[k][1]['selection']['rank'] = int(ranks[k])
             if tau_range is not None:
                 tab, n_eig = eng.threshold_scan(tau_range)
                 for k in range(K):
@@ -148,6 +155,29 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     finally:
         eng.close()
     return results
+
+
+def _final_L(eng, sols, per_sol):
+    """End of a latent batch: every snapshot's L is rebuilt from one eigendecomposition of its last L-step's input where that
+    step was the sign iteration (``HipEngine.finalize_L``; solver/ggl_helper.py:29-36 is what the reference's callers get) and
+    replaces the L downloaded at the iteration the problem converged.  sols[g]['L'] is (p,p) (per_sol = 1) or (per_sol,p,p).
+    Returns the (len(sols) * per_sol,) ranks: the device's count of eigenvalues above the threshold where it rebuilt the
+    instance, numpy's rule on the (eigendecomposition's) L otherwise."""
+    n_rebuilt, rk = eng.finalize_L(1)
+    rk = np.array(rk, dtype=np.int64)
+    for g, sol in enumerate(sols):
+        for k in range(per_sol):
+            i = g * per_sol + k
+            if rk[i] >= 0:
+                L = eng.snapshot_L_k(i)
+                q = sol['L'].shape[-1]                 # (instances of a padded batch are returned un-padded)
+                if per_sol == 1 and sol['L'].ndim == 2:
+                    sol['L'] = np.ascontiguousarray(L[:q, :q])
+                else:
+                    sol['L'][k] = L[:q, :q]
+            else:
+                rk[i] = _solver.latent_rank(sol['L'] if (per_sol == 1 and sol['L'].ndim == 2) else sol['L'][k])
+    return rk
 
 
 def pad_blocks(blocks, P, identity):
@@ -180,7 +210,7 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
     mu1: (K,) shared by all problems or (G,K); n_samples as in ADMM_MGL.
     Returns a list of G ``(sol, info)``; ``info`` carries 'status', 'iterations', 'rho' (+ 'selection': per-instance
     (K,4) array of <S,Theta>, log det Theta, count_nonzero(Theta), lambda_min(Theta) from the GPU when
-    ``selection_stats``)."""
+    ``selection_stats``; with ``latent`` 'rank': (K,) numpy.linalg.matrix_rank of the problem's L_k, see ADMM_SGL_batch)."""
     S = as_c(S)
     assert S.ndim == 3 and S.shape[1] == S.shape[2]
     assert reg in ['GGL', 'FGL']
@@ -223,7 +253,7 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
             parts = [eng.state_k(g * K + k, True) for k in range(K)]
             sol = {nm: np.stack([q[nm] for q in parts]) for nm in ('Omega', 'Theta', 'L', 'X')}
             results[g] = (sol, {'status': status, 'iterations': iters, 'rho': rhos[g]})
-            if selection_stats:
+            if selection_stats or latent:
                 for k in range(K):
                     eng.snapshot_k(g * K + k)
 
@@ -256,14 +286,14 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                 status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
                                                                 else 'max iterations reached')
                 collect(g, status, max_iter)
+        if latent:
+            rk = _final_L(eng, [results[g][0] for g in range(G)], K)
+            for g in range(G):
+                results[g][1]['rank'] = rk[g * K:(g + 1) * K].copy()
         if selection_stats:
             st = eng.selection_stats()
             for g in range(G):
                 results[g][1]['selection'] = st[g * K:(g + 1) * K].copy()
-            if latent:
-                rk = eng.selection_rank(_solver.RANK_REL_TOL)
-                for g in range(G):
-                    results[g][1]['rank'] = rk[g * K:(g + 1) * K].copy()
             if tau_range is not None:
                 tab, _ = eng.threshold_scan(tau_range)
                 for g in range(G):

@@ -401,10 +401,15 @@ __global__ __launch_bounds__(256) void k_copy_instances(double* __restrict__ dst
 {
     const int i = blockIdx.y;
     const size_t so = (size_t)(scatter ? i : idx[i]) * pp, dp = (size_t)(scatter ? idx[i] : i) * pp;
-    const size_t n2 = pp / 2;                             // p even on this path: 16-byte copies
+    if (pp & 1) {
+        // odd p: every second slot offset is only 8-byte aligned -- element copies (the double2 form was a
+        // misaligned access on those slots)
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < pp; e += (size_t)gridDim.x * 256) dst[dp + e] = src[so + e];
+        return;
+    }
+    const size_t n2 = pp / 2;                             // p even: slots are 16-byte aligned, 16-byte copies
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n2; e += (size_t)gridDim.x * 256)
         reinterpret_cast<double2*>(dst + dp)[e] = reinterpret_cast<const double2*>(src + so)[e];
-    if ((pp & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[dp + pp - 1] = src[so + pp - 1];
 }
 
 void launch_copy_instances(hipStream_t st, double* dst, const double* src, const int* idx, int m, size_t pp, bool scatter)

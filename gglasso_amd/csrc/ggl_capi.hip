@@ -140,6 +140,16 @@ struct ggl_ctx {
     int ext_nprob = 1;                         // independent problems in the stack (ggl_ext_setup_batch), K / ext_nprob instances each
     double* snapT = nullptr;                   // per-instance snapshots of Theta (model selection), lazy
     double* snapL = nullptr;                   // ... and of L once a latent step has run
+    // ggl_finalize_L: the L a solve RETURNS is rebuilt from one eigendecomposition of the last L-step's input C where that
+    // L-step was the sign iteration (whose null space carries the iteration's residual, ~1e-13 |L|, instead of 1e-16 |L|).
+    // rank_step keeps that C by swapping W with Ckeep (no copy); ggl_snapshot_k keeps the instance's C beside its L.
+    double* Ckeep = nullptr;                   // (K,p,p) C = Theta - X - Omega of the last sign-iteration L-step, lazy
+    double* Ckeep_beta = nullptr;              // host (K): mu1_k / rho of that step
+    bool l_ns = false;                         // L is the sign iteration's (Ckeep valid); false once rebuilt / set / eigh route
+    double* snapC = nullptr;                   // (K,p,p) snapshots of C, lazy
+    double* snap_beta = nullptr;               // host (K)
+    unsigned char* snap_ns = nullptr;          // host (K): snapshot k's L is a sign-iteration L (snapC_k, snap_beta[k] valid)
+    long long finalize_calls = 0;              // eigendecompositions ggl_finalize_L ran
     double* nbrow = nullptr;                   // [K][p] row abs-sums of B' (Collatz-Wielandt weight vector)
     // the Collatz-Wielandt vector carried across iterations (k_cw_final): [cw_cur] was left behind by the last ACCEPTED
     // bound pass, the other one is what the pass in flight writes; cw_have: there is an accepted one
@@ -280,8 +290,10 @@ static int ctx_alloc(ggl_ctx* c)
     pl = std::max(pl, (size_t)theta_partial_blocks(c->p, GGL_REG_GGL, c->K, 2) * GGL_NNORM);
     c->partials_len = pl;
     HIPCHK(hipMalloc(&c->partials, pl * sizeof(double)));
-    HIPCHK(hipMalloc(&c->norms, (size_t)c->K * 8 * sizeof(double)));
-    HIPCHK(hipHostMalloc(&c->norms_h, (size_t)c->K * 8 * sizeof(double), hipHostMallocCoherent));
+    // (K,8) rows, and 2 * nprob * GGL_NNORM doubles for a batch of ext problems with ONE instance each (nprob = K)
+    const size_t nl = (size_t)c->K * std::max(8, 2 * GGL_NNORM);
+    HIPCHK(hipMalloc(&c->norms, nl * sizeof(double)));
+    HIPCHK(hipHostMalloc(&c->norms_h, nl * sizeof(double), hipHostMallocCoherent));
     HIPCHK(hipHostMalloc(&c->info_h, (size_t)c->K * sizeof(int)));
     HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
     HIPCHK(hipMemsetAsync(c->X, 0, nb, c->stream));
@@ -484,7 +496,10 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
                       c->nsT, c->nsNX, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->snapL, c->cuse, c->Lam[0],
-                      c->Lam[1], c->X1, c->cwvec[0], c->cwvec[1]};
+                      c->Lam[1], c->X1, c->cwvec[0], c->cwvec[1], c->Ckeep, c->snapC};
+    free(c->Ckeep_beta);
+    free(c->snap_beta);
+    free(c->snap_ns);
     for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize, c->inst_pk, c->rank_idx})
         if (b) (void)hipFree(b);
     if (c->rank_idx_h) (void)hipHostFree(c->rank_idx_h);
@@ -632,6 +647,7 @@ extern "C" int ggl_set_state_ex(ggl_ctx* c, const double* Omega, const double* T
     if (rc) return rc;
     if (!L) HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
     c->step_latent = (L != nullptr);          // a snapshot taken before any step keeps an uploaded L as well
+    c->l_ns = false;                          // (an uploaded L is the caller's: ggl_finalize_L leaves it alone)
     if (X) { rc = upload_stack(c, c->X, X, pr[3]); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
     // exact symmetry of the dual and latent stacks decides whether the per-element Theta-step may be used
@@ -673,6 +689,7 @@ extern "C" int ggl_state_snapshot(ggl_ctx* c, int restore)
     c->state_symmetric = c->snap_symmetric;
     c->spec_have = false;
     c->cw_have = false;
+    c->l_ns = false;
     return GGL_OK;
 }
 
@@ -1280,7 +1297,28 @@ static int finish_norms(ggl_ctx* c, int rows, double* out_norms, int group = 0)
 // L = (C - mu I)_+ with C in c->W and mu_k/rho in parameter slot 2 (pinned mirror par_h + 2K).
 // Sign Newton-Schulz with a-posteriori verification; retries at a finer resolution, then falls back to the
 // eigendecomposition, so the result always meets the eigh route's accuracy.
+static int rank_step_impl(ggl_ctx* c);
+
 static int rank_step(ggl_ctx* c)
+{
+    const long long fallbacks = c->rank_fallbacks;
+    int rc = rank_step_impl(c);
+    if (rc) return rc;
+    c->l_ns = c->rank_ns && c->rank_fallbacks == fallbacks;
+    if (c->l_ns) {
+        // keep C for ggl_finalize_L: W is scratch that every step forms anew, so the two stacks swap names (the stream was
+        // synchronised by the step's checks; a latent step neither speculates nor pre-launches, nothing in flight holds W)
+        if (!c->Ckeep) {
+            HIPCHK(hipMalloc(&c->Ckeep, c->n * sizeof(double)));
+            c->Ckeep_beta = (double*)malloc(c->K * sizeof(double));
+        }
+        std::swap(c->W, c->Ckeep);
+        memcpy(c->Ckeep_beta, c->par_h + 2 * (size_t)c->K, c->K * sizeof(double));
+    }
+    return GGL_OK;
+}
+
+static int rank_step_impl(ggl_ctx* c)
 {
     const int K = c->K;
     const double* mu_h = c->par_h + 2 * (size_t)K;
@@ -2014,7 +2052,96 @@ extern "C" int ggl_snapshot_k(ggl_ctx* c, int k)
             HIPCHK(hipMemsetAsync(c->snapL, 0, c->n * sizeof(double), c->stream));
         }
         HIPCHK(hipMemcpyAsync(c->snapL + k * pp, c->L + k * pp, nb, hipMemcpyDeviceToDevice, c->stream));
+        if (!c->snap_ns) {
+            c->snap_ns = (unsigned char*)calloc(c->K, 1);
+            c->snap_beta = (double*)calloc(c->K, sizeof(double));
+        }
+        c->snap_ns[k] = c->l_ns ? 1 : 0;
+        if (c->l_ns) {
+            // the sign iteration's L: keep its input C as well, ggl_finalize_L(which = 1) rebuilds the snapshot from it
+            if (!c->snapC) {
+                HIPCHK(hipMalloc(&c->snapC, c->n * sizeof(double)));
+                HIPCHK(hipMemsetAsync(c->snapC, 0, c->n * sizeof(double), c->stream));
+            }
+            HIPCHK(hipMemcpyAsync(c->snapC + k * pp, c->Ckeep + k * pp, nb, hipMemcpyDeviceToDevice, c->stream));
+            c->snap_beta[k] = c->Ckeep_beta[k];
+        }
     }
+    return GGL_OK;
+}
+
+// The latent component a solve returns (solver/ggl_helper.py:29-36: L = Q diag(max(d - beta, 0)) Q^T, whose null space is
+// exact to rounding -- the reference's callers apply numpy.linalg.matrix_rank to it, helper/model_selection.py:254, :638).
+// Where the L-step ran as the sign iteration, L is rebuilt here from ONE eigendecomposition of that step's input C (kept by
+// rank_step / ggl_snapshot_k): the reference's own L-step, executed once per solve instead of once per iteration.  The dual X
+// keeps the sign iteration's L in its last update (a difference of ~1e-13 |L|).
+//   which 0: the live iterate's L;  1: the snapshots' L (ggl_snapshot_k).
+//   rank_out (K ints, may be null): #{ eigenvalues of C_k above mu1_k / rho } for the instances rebuilt, -1 for the others.
+// Returns the number of instances rebuilt (0: every L already came from an eigendecomposition, nothing done), < 0 on error.
+extern "C" int ggl_finalize_L(ggl_ctx* c, int which, int* rank_out)
+{
+    ARGCHK(c, "ctx");
+    ARGCHK(which == 0 || which == 1, "which");
+    HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
+    const int K = c->K, p = c->p;
+    const size_t pp = (size_t)p * p, kp = (size_t)K * p;
+    if (rank_out) for (int k = 0; k < K; ++k) rank_out[k] = -1;
+    std::vector<unsigned char> todo(K, 0);
+    int n_todo = 0;
+    const double* beta_src = nullptr;
+    if (which == 0) {
+        if (c->l_ns) { std::fill(todo.begin(), todo.end(), 1); n_todo = K; beta_src = c->Ckeep_beta; }
+    } else if (c->snap_ns && c->snapC) {
+        for (int k = 0; k < K; ++k) if (c->snap_ns[k]) { todo[k] = 1; n_todo += 1; }
+        beta_src = c->snap_beta;
+    }
+    if (!n_todo) return 0;
+    // parameter slot 2 (mu1_k / rho) is saved and restored: the solve may go on after a snapshot was finalised
+    double* slot = c->par_h + 2 * (size_t)K;
+    std::vector<double> saved(slot, slot + K);
+    for (int k = 0; k < K; ++k) slot[k] = todo[k] ? beta_src[k] : 0.0;
+    HIPCHK(hipMemcpyAsync(c->par + 2 * (size_t)K, slot, K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    double* Csrc = which == 0 ? c->Ckeep : c->snapC;
+    double* out = which == 0 ? c->L : c->W;
+    int rc = eig_recon(c, Csrc, out, c->DvL, MAP_RANK, c->par + 2 * (size_t)K);      // (destroys Csrc)
+    if (rc) return rc;
+    std::vector<double> d(kp);
+    HIPCHK(hipMemcpyAsync(d.data(), c->DvL, kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->info_h, c->info, K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (which == 1)
+        for (int k = 0; k < K; ++k)
+            if (todo[k]) HIPCHK(hipMemcpyAsync(c->snapL + k * pp, c->W + k * pp, pp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(slot, saved.data(), K * sizeof(double));
+    HIPCHK(hipMemcpyAsync(c->par + 2 * (size_t)K, slot, K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = check_info(c, "final L");
+    if (rc) return rc;
+    for (int k = 0; k < K; ++k) {
+        if (!todo[k]) continue;
+        int r = 0;
+        for (int e = 0; e < p; ++e) r += d[(size_t)k * p + e] > beta_src[k] ? 1 : 0;
+        if (rank_out) rank_out[k] = r;
+    }
+    if (which == 0) c->l_ns = false;                  // L is an eigendecomposition's now (and Ckeep is spent)
+    else memset(c->snap_ns, 0, K);                    // (snapC is spent; a later snapshot of an instance sets its flag again)
+    if (which == 1) HIPCHK(hipMemsetAsync(c->snapC, 0, c->n * sizeof(double), c->stream));
+    c->finalize_calls += 1;
+    return n_todo;
+}
+
+/* Theta and L of instance k's snapshot (ggl_snapshot_k), either may be null */
+extern "C" int ggl_get_snapshot_k(ggl_ctx* c, int k, double* Theta, double* L)
+{
+    ARGCHK(c && k >= 0 && k < c->K, "ctx, k");
+    ARGCHK(c->snapT, "no snapshot taken (ggl_snapshot_k)");
+    ARGCHK(!L || c->snapL, "no snapshot of L (ggl_snapshot_k after a latent step)");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t pp = (size_t)c->p * c->p, nb = pp * sizeof(double), off = (size_t)k * pp;
+    if (Theta) HIPCHK(hipMemcpyAsync(Theta, c->snapT + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (L) HIPCHK(hipMemcpyAsync(L, c->snapL + off, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return GGL_OK;
 }
 

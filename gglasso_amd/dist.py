@@ -104,6 +104,10 @@ class TorchComm:
             return t.cpu().numpy()
 
 
+class CommIdError(RuntimeError):
+    """RCCL's unique id could not be created on rank 0; raised on every rank of the group by ``RcclComm.attach``."""
+
+
 class RcclComm:
     """RCCL behind the C ABI (include/ggl_hip.h, ggl_comm_* / ggl_admm_step_sharded): the library itself issues the
     two all-reduces of a K-sharded GGL iteration on the ctx stream, so an iteration is ONE C call and the host
@@ -133,17 +137,26 @@ class RcclComm:
         return torch.cuda.device(self.device)
 
     def attach(self, eng):
-        """Create this rank's communicator inside the engine's ctx (collective: every rank calls it)."""
+        """Create this rank's communicator inside the engine's ctx (collective: every rank calls it).
+        A failure to obtain the unique id on rank 0 travels with the broadcast and is raised as ``CommIdError`` on EVERY
+        rank (so a caller may fall back collectively); a failure inside ``ncclCommInitRank`` on some rank only cannot be
+        made symmetric from here -- the other ranks are inside RCCL's own rendezvous -- and such a rank should leave the
+        job (a non-zero exit makes the launcher tear the others down) rather than enter another collective."""
         import ctypes
         if self.device is None:
             self.device = getattr(eng, "device", None)
         box = [None]
         if self.rank == 0:
-            buf = ctypes.create_string_buffer(128)
-            _lib.check(_lib.load().ggl_comm_unique_id(buf))
-            box[0] = buf.raw
+            try:
+                buf = ctypes.create_string_buffer(128)
+                _lib.check(_lib.load().ggl_comm_unique_id(buf))
+                box[0] = buf.raw
+            except Exception as e:  # noqa: BLE001 -- reported to every rank below
+                box[0] = ("error", f"{type(e).__name__}: {e}")
         with self._on_device():
             self.dist.broadcast_object_list(box, src=0, group=self.group)
+        if isinstance(box[0], tuple):
+            raise CommIdError(f"rank 0 could not create the RCCL unique id ({box[0][1]})")
         eng.comm_init(self.rank, self.world, box[0])
 
     def allreduce_norms(self, arr):
@@ -225,6 +238,8 @@ def ADMM_MGL_sharded(S_local, lambda1, lambda2, reg, Omega_0, K_total, comm, The
         info, _ = _run_admm(eng, reg, K_total, p, float(lambda1), float(lambda2), bool(latent), mu1, nk, float(rho),
                             tol, rtol, 'boyd', update_rho, max_iter, verbose and comm.rank == 0, measure,
                             "Multiple", comm=comm, want_objective=False)
+        if latent and hasattr(eng, "finalize_L"):
+            eng.finalize_L()        # per instance, on this rank's slab: no exchange
         _exit_report(eng, bool(latent), 1e-5, False)
         sol = eng.state()
     finally:

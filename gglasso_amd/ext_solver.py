@@ -129,6 +129,8 @@ def ext_ADMM_MGL(S, lambda1, lambda2, reg, Omega_0, G, X0=None, X1=None, tol=1e-
                 status = 'max iterations reached'
         print(f"ADMM terminated after {iter_t+1} iterations with status: {status}.")
 
+        if latent and hasattr(eng, "finalize_L"):
+            eng.finalize_L()        # the returned L: one eigendecomposition where the L-steps were sign iterations
         # per-instance exit checks (ext_admm_solver.py:290-311)
         for a_om, a_th, a_l, min_tl, min_l in eng.exit_checks_k(bool(latent)):
             for name, dev in (("Omega", a_om), ("Theta", a_th), ("L", a_l)):
@@ -206,6 +208,9 @@ def ext_ADMM_MGL_batch(S, lambda1, lambda2, reg, G, tol=1e-5, rtol=1e-4, rho=1.,
                    'X0': {k: cut(parts[k]['X'], k) for k in range(K)},
                    'X1': {k: cut(xs['X1'][g * K + k], k) for k in range(K)}}
             results[g] = (sol, {'status': status, 'iterations': iters})
+            if latent:
+                for k in range(K):
+                    eng.snapshot_k(g * K + k)
 
         for it in range(max_iter):
             sq = eng.ext_batch_step(ng, rho, lam1f, lam2, bool(latent), mu)
@@ -227,6 +232,13 @@ def ext_ADMM_MGL_batch(S, lambda1, lambda2, reg, G, tol=1e-5, rtol=1e-4, rho=1.,
                 status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
                                                                 else 'max iterations reached')
                 collect(g, status, max_iter)
+        if latent:
+            # every problem's L_k as one eigendecomposition of its last L-step's input (HipEngine.finalize_L)
+            _, rk = eng.finalize_L(1)
+            for g in range(ng):
+                for k in range(K):
+                    if rk[g * K + k] >= 0:
+                        results[g][0]['L'][k] = np.ascontiguousarray(eng.snapshot_L_k(g * K + k)[:p[k], :p[k]])
     finally:
         eng.close()
     return results

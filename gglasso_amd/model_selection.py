@@ -115,9 +115,9 @@ def _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma,
                     lowrank[j, m] = sol['L']
             d = dev[j * nm + m] if dev is not None else None
             if latent:
-                # matrix_rank(L) of :638 at the tolerance that fits this library's L (solver.RANK_REL_TOL): from the batch's
-                # device eigenvalues, or on the host for the point-by-point walk
-                RANK[j, m] = d['rank'][0] if (d is not None and 'rank' in d) else latent_rank(sol['L'])
+                # matrix_rank(L) of :638: from the batch (the device's eigenvalue count where it rebuilt L, numpy's rule
+                # otherwise), or numpy's rule on the host for the point-by-point walk
+                RANK[j, m] = d['rank'] if (d is not None and 'rank' in d) else latent_rank(sol['L'])
             if thresholding and d is not None and 'threshold' in d:
                 # scored on the GPU for every tau of the default range; the statistics of the chosen one become the point's
                 jt = _pick_threshold(d['threshold'], N, p, method, gamma)
@@ -568,7 +568,7 @@ def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma
             BIC[g][g1, g2] = np.sum(fit + E * (np.log(Nk) + 4 * np.log(pk) * g))
         if latent:
             if (g1, g2) in dev_rank:
-                RANK[:, g1, g2] = dev_rank[(g1, g2)][:, 0]
+                RANK[:, g1, g2] = dev_rank[(g1, g2)]
             else:
                 RANK[:, g1, g2] = [latent_rank(sol['L'][k]) for k in range(K)]
         score = BIC[gamma][g1, g2] if method == 'eBIC' else AIC[g1, g2]

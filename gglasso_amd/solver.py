@@ -28,24 +28,37 @@ ENGINE_OPTIONS = {}
 
 
 # Rank of the latent component in the model-selection tables (helper/model_selection.py:256, :638 call
-# numpy.linalg.matrix_rank, i.e. #{|lambda_i| > p * eps * max|lambda|}).  That tolerance fits an L rebuilt from an
-# eigendecomposition (null space at 1e-16 |L|).  Above p = 128 the L-step is the sign iteration and the null space of its L
-# carries the iteration's residual -- measured 4e-14 .. 7e-13 |L| (tools/probe_rank_noise.py), which numpy's rule counts as
-# rank (22 instead of 6 at p = 500); the device eigensolvers add ~3e-14 |L| of their own.  Every eigenvalue the prox keeps
-# is (lambda_i(C) - mu)_+: to be missed by the cut below, an eigenvalue of C has to sit within 1e-9 |L| of the threshold.
+# numpy.linalg.matrix_rank(L), i.e. #{|lambda_i| > p * eps * max|lambda|}).  That rule fits an L rebuilt from an
+# eigendecomposition (null space at 1e-16 |L|), and every L this library RETURNS is one: below p = 128 the L-step is the LDS
+# Jacobi eigensolver, above it the per-iteration L-step is the sign iteration (null space at 4e-14 .. 7e-13 |L|, which numpy's
+# rule counts as rank: 22 for 6 at p = 500, tools/probe_rank_noise.py) and the solve's LAST L-step is redone as an
+# eigendecomposition before the solution is handed out (HipEngine.finalize_L, round 4).  So the rule is numpy's, on every
+# route; RANK_REL_TOL (rounds 1-3: a 1e-9 cut for the sign iteration's L) is kept for callers that look at an L mid-solve.
 RANK_REL_TOL = 1e-9
 
 
-def latent_rank(L, rel_tol=RANK_REL_TOL):
-    """Host counterpart of ``HipEngine.selection_rank`` for one symmetric (p,p) L."""
+def latent_rank(L, rel_tol=0.0):
+    """numpy.linalg.matrix_rank of one symmetric (p,p) L (rel_tol 0: numpy's p * eps; host counterpart of
+    ``HipEngine.selection_rank``)."""
     a = np.abs(np.linalg.eigvalsh(L))
     return int(np.count_nonzero(a > a.max() * max(rel_tol, L.shape[0] * np.finfo(np.float64).eps)))
 
 
-def _host_period(A):
+def _host_period(A, K=None, p=None):
     """(C-contiguous host array to upload, period): a numpy.broadcast_to VIEW (stride 0 along its first axis) of one (p,p)
     matrix as (K,p,p), or of one (K',p,p) stack as (G,K',p,p), is uploaded once -- period 1 resp. K' -- and replicated on
-    the device (ggl_set_S_ex / ggl_set_state_ex); anything else travels whole (period 0)."""
+    the device (ggl_set_S_ex / ggl_set_state_ex); anything else travels whole (period 0).  With K and p given the shape is
+    CHECKED against the ctx's stack -- the C side copies period * p * p (or K * p * p) doubles out of the buffer it is handed
+     -- and a single matrix, (p,p) or (1,p,p), for K > 1 instances is taken as shared (period 1)."""
+    if K is not None:
+        assert A.ndim in (2, 3, 4) and A.shape[-2:] == (p, p), \
+            f"array of shape {A.shape} does not fit a stack of {K} ({p},{p}) matrices"
+        if A.ndim == 2:
+            return as_c(A), (1 if K > 1 else 0)
+        lead = int(np.prod(A.shape[:-2]))
+        if A.ndim == 3 and A.shape[0] == 1 and K > 1:
+            return as_c(A[0]), 1
+        assert lead == K, f"array of shape {A.shape} does not fit a stack of {K} ({p},{p}) matrices"
     if A.ndim == 3 and A.shape[0] > 1 and A.strides[0] == 0:
         return as_c(A[0]), 1
     if A.ndim == 4:
@@ -76,14 +89,15 @@ class HipEngine:
         # broadcast VIEWS (what the batched grids pass for S, Omega_0, X_0) are uploaded once and replicated on the device
         # instead of being materialised on the host: _host_period
         import ctypes
-        Sh, s_period = _host_period(S)
+        assert S.ndim in (3, 4) and S.shape[-2] == S.shape[-1], f"S must be (K,p,p) or (G,K,p,p), is {S.shape}"
+        Sh, s_period = _host_period(S, self.K, self.p)
         check(self.lib.ggl_set_S_ex(self.h, ptr(Sh), s_period))
         arrs, periods = [], (ctypes.c_int * 4)(0, 0, 0, 0)
         for slot, A in enumerate((Omega_0, Theta_0, L_0, X_0)):
             if A is None:
                 arrs.append(None)
                 continue
-            Ah, periods[slot] = _host_period(np.asarray(A, dtype=np.float64))
+            Ah, periods[slot] = _host_period(np.asarray(A, dtype=np.float64), self.K, self.p)
             arrs.append(Ah)
         check(self.lib.ggl_set_state_ex(self.h, ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3]), periods))
         self._norms = np.zeros(5)
@@ -92,6 +106,8 @@ class HipEngine:
 
     def set_state(self, Omega, Theta, X, L=None):
         """Overwrite the iterate (admm_solver.py:142-150 semantics: L None zeroes it)."""
+        for A in (Omega, Theta, X, L):
+            assert A is None or np.shape(A) == (self.K, self.p, self.p), f"state arrays must be {(self.K, self.p, self.p)}"
         check(self.lib.ggl_set_state(self.h, ptr(as_c(Omega)), ptr(as_c(Theta)), ptr(None if L is None else as_c(L)),
                                      ptr(as_c(X))))
 
@@ -259,6 +275,20 @@ class HipEngine:
         out = np.zeros((self.K, 4))
         check(self.lib.ggl_selection_rank(self.h, float(rel_tol), ptr(out)))
         return out
+
+    def finalize_L(self, which=0):
+        """Rebuild the L a solve returns from one eigendecomposition of the last L-step's input where that step was the
+        sign iteration (ggl_finalize_L; which 0: live iterate, 1: snapshots).  Returns (instances rebuilt, (K,) ranks:
+        #{eig(C_k) > mu1_k/rho} for the rebuilt instances, -1 for the others)."""
+        import ctypes
+        rk = np.full(self.K, -1, dtype=np.int32)
+        n = check(self.lib.ggl_finalize_L(self.h, int(which), rk.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return int(n), rk
+
+    def snapshot_L_k(self, k):
+        L = np.empty((self.p, self.p))
+        check(self.lib.ggl_get_snapshot_k(self.h, int(k), None, ptr(L)))
+        return L
 
     def objective(self, lambda1, lambda2, reg):
         out = np.zeros(3)
@@ -580,6 +610,8 @@ def ADMM_MGL(S, lambda1, lambda2, reg, Omega_0, Theta_0=np.array([]), X_0=np.arr
         info, _ = _run_admm(eng, reg, K, p, float(lambda1), float(lambda2), bool(latent), mu1, nk, float(rho),
                             tol, rtol, stopping_criterion, update_rho, max_iter, verbose, measure, "Multiple",
                             want_objective=True)
+        if latent:
+            eng.finalize_L()        # the returned L: one eigendecomposition where the L-steps were sign iterations
         _exit_report(eng, latent, 1e-5, False)
         sol = eng.state()
     finally:
@@ -621,6 +653,8 @@ def ADMM_SGL(S, lambda1, Omega_0, Theta_0=np.array([]), X_0=np.array([]), rho=1.
         mu = as_c(np.array([mu1])) if latent else None
         info, _ = _run_admm(eng, 'SGL', 1, p, float(lambda1), 0.0, bool(latent), mu, np.ones(1), float(rho), tol,
                             rtol, stopping_criterion, update_rho, max_iter, verbose, measure, "Single")
+        if latent:
+            eng.finalize_L()
         _exit_report(eng, latent, 1e-8, True)
         st = eng.state()
     finally:

@@ -320,6 +320,20 @@ int ggl_snapshot_k(ggl_ctx *ctx, int k);
 int ggl_selection_stats(ggl_ctx *ctx, double *out);
 int ggl_threshold_scan(ggl_ctx *ctx, const double *tau, int ntau, double *out, int *n_eig);
 int ggl_selection_rank(ggl_ctx *ctx, double rel_tol, double *out);
+/* The latent component a solve RETURNS (reference: prox_rank_norm, solver/ggl_helper.py:29-36, as the last L-step of
+ * admm_solver.py:197-205 / single_admm_solver.py:172-175 leaves it: Q diag(max(d - mu1/rho, 0)) Q^T, null space exact to
+ * rounding -- the reference's callers apply numpy.linalg.matrix_rank to it, helper/model_selection.py:254, :638).
+ * Above GGL_JACOBI_MAX_P the per-iteration L-step is the sign iteration, whose L is entrywise right to ~1e-13 |L| but whose
+ * null space carries that residual.  ggl_finalize_L rebuilds L from ONE eigendecomposition of the last L-step's input
+ * C = Theta - X - Omega (kept on the device by the step itself / by ggl_snapshot_k) -- the reference's own L-step, run
+ * once per solve instead of once per iteration.  X is left as the last dual update wrote it.
+ *   which 0: the live iterate's L (call before ggl_get_state / ggl_exit_checks);  1: the L snapshots of ggl_snapshot_k
+ *   rank_out (K ints, may be NULL): #{ eigenvalues of C_k above mu1_k/rho } for every rebuilt instance, -1 otherwise
+ * Returns the number of instances rebuilt -- 0 when every L already is an eigendecomposition's (p <= GGL_JACOBI_MAX_P,
+ * GGL_OPT_RANK_EIG, a fallback in the last step, an uploaded L) and nothing was done -- or an error code < 0.
+ * ggl_get_snapshot_k: Theta and L (either may be NULL) of instance k's snapshot. */
+int ggl_finalize_L(ggl_ctx *ctx, int which, int *rank_out);
+int ggl_get_snapshot_k(ggl_ctx *ctx, int k, double *Theta, double *L);
 /* Objective pieces for measure=True (admm_solver.py:213): out = {sum_k -logdet Omega_k,
  * <Omega,S>, P_val(Theta)} (ggl_helper.py:266-270,162-176). */
 int ggl_objective(ggl_ctx *ctx, double lambda1, double lambda2, int reg, double out[3]);

@@ -140,6 +140,13 @@ class OracleEngine:
                 self._snapL = np.zeros_like(self.L)
             self._snapL[k] = self.L[k]
 
+    def finalize_L(self, which=0):
+        # every L of this engine is an eigendecomposition's (orc.rank_stack): nothing to rebuild
+        return 0, np.full(self.Th.shape[0], -1, dtype=np.int32)
+
+    def snapshot_L_k(self, k):
+        return self._snapL[k].copy()
+
     def threshold_scan(self, tau_range):
         tau_range = np.asarray(tau_range, dtype=np.float64)
         K = self.Th.shape[0]

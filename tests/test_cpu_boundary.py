@@ -516,7 +516,8 @@ def test_host_period_of_broadcast_views():
 
 
 def test_latent_rank_rule_and_threshold_choice():
-    """solver.latent_rank (the RANK tables' rule, solver.RANK_REL_TOL) and model_selection._pick_threshold (tune_threshold's
+    """solver.latent_rank (the RANK tables' rule: numpy.linalg.matrix_rank's, every returned L being an eigendecomposition's
+    since round 4; the 1e-9 cut of rounds 1-3 on request) and model_selection._pick_threshold (tune_threshold's
     choice, helper/model_selection.py:718-735, from the device table) on the host."""
     from gglasso_amd import solver, model_selection as ms
     rng = np.random.default_rng(4)
@@ -528,7 +529,8 @@ def test_latent_rank_rule_and_threshold_choice():
     L = 0.5 * (L + L.T)
     assert solver.latent_rank(L) == 7 == np.linalg.matrix_rank(L, hermitian=True)
     noisy = L + 1e-13 * (Q[:, 7:9] @ Q[:, 7:9].T)                    # a null space at 1e-13 |L|, as the sign iteration leaves it
-    assert np.linalg.matrix_rank(noisy, hermitian=True) > 7 and solver.latent_rank(noisy) == 7
+    assert np.linalg.matrix_rank(noisy, hermitian=True) > 7 and solver.latent_rank(noisy, solver.RANK_REL_TOL) == 7
+    assert solver.latent_rank(noisy) == np.linalg.matrix_rank(noisy, hermitian=True)        # default: numpy's rule
     assert solver.latent_rank(np.zeros((p, p))) == 0
     # threshold choice: scores from a table {<S,T>, log det T, nnz, lambda_min} equal the host criteria; -inf log det -> nan
     S = np.cov(rng.standard_normal((p, 4 * p)))

@@ -193,3 +193,26 @@ def test_g15_ext_admm_conforming_oracle(latent):
     ext_checks.check_g15(load_golden, orc.ext_ADMM_MGL_printing, latent)
     g = load_golden("g15_ext_admm_conforming")
     assert np.array_equal(orc.construct_trivial_G(g["S"].shape[1], g["S"].shape[0]), g["G"])
+
+
+def test_g18_latent_rank_above_the_jacobi_limit():
+    """G18 (tests/golden/make_golden_rank.py): the reference's numpy.linalg.matrix_rank(sol['L']) at p = 200 / 160
+    (helper/model_selection.py:254, :638) and the entries of Theta / L -- the oracle the GPU tests of the same fixture use."""
+    g = load_golden("g18_latent_rank_large_p")
+    S, lam = g["sgl_S"], float(g["sgl_lambda1"])
+    p = S.shape[0]
+    for mu, want in zip(g["sgl_mu1"], g["sgl_rank"]):
+        sol, info = orc.ADMM_SGL(S, lam, np.eye(p), tol=1e-10, rtol=1e-10, latent=True, mu1=float(mu))
+        assert info['status'] == 'optimal'
+        assert np.linalg.matrix_rank(sol['L']) == want
+        if mu == 0.8:
+            assert np.linalg.norm(sol['Theta'] - g["sgl_Theta"]) <= 1e-8
+            assert np.linalg.norm(sol['L'] - g["sgl_L"]) <= 1e-8
+    S2, (l1, l2), mu1 = g["mgl_S"], g["mgl_lambda"], g["mgl_mu1"]
+    K, p = S2.shape[:2]
+    for reg in ("GGL", "FGL"):
+        sol, info = orc.ADMM_MGL(S2, l1, l2, reg, np.stack([np.eye(p)] * K), tol=1e-10, rtol=1e-10, latent=True, mu1=mu1)
+        assert [np.linalg.matrix_rank(sol['L'][k]) for k in range(K)] == list(g[f"mgl_{reg}_rank"])
+        assert np.linalg.norm(sol['L'] - g[f"mgl_{reg}_L"]) <= 1e-8
+        if reg == "GGL":
+            assert np.linalg.norm(sol['Theta'] - g["mgl_GGL_Theta"]) <= 1e-8

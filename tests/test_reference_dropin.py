@@ -240,3 +240,21 @@ def test_seam3b_glasso_problem_model_selection_mgl_with_the_batched_grid(ref, ou
         if latent:
             assert np.abs(P1.solution.lowrank_ - P0.solution.lowrank_).max() <= 1e-6
             assert np.array_equal(P1.modelselect_stats['RANK'], P0.modelselect_stats['RANK'])
+
+
+def test_seam1_reference_grid_search_rank_table_above_the_jacobi_limit(ref, ours):
+    """the REFERENCE's grid_search (helper/model_selection.py:55-298) applies numpy.linalg.matrix_rank to the
+    sol['L'] our solver hands it (:254).  Driven by gglasso_amd.ADMM_MGL at p = 160 it must reproduce the RANK table the
+    reference computed with its own solver (fixture G18).  (Array work by the oracle engine here; tests/test_gpu_latent_rank.py
+    runs the same walk on the HIP engine, where the returned L is the rebuilt one.)"""
+    from conftest import load_golden
+    g = load_golden("g18_latent_rank_large_p")
+    ms = ref["ms"]
+    S, Nk = g["mgl_S"], g["grid_N"]
+    stats, ix, best = quiet(ms.grid_search, ours.ADMM_MGL, S, Nk, S.shape[1], "GGL", g["grid_l1"], l2=g["grid_l2"],
+                            method='eBIC', gamma=0.3, latent=True, mu_range=g["grid_mu_range"], ix_mu=g["grid_ix_mu"],
+                            tol=1e-10, rtol=1e-10)
+    assert np.array_equal(stats['RANK'], g["grid_RANK"])
+    assert tuple(int(v) for v in ix) == tuple(int(v) for v in g["grid_ix"])
+    assert np.allclose(stats['SP'], g["grid_SP"])
+    assert [np.linalg.matrix_rank(best['L'][k]) for k in range(S.shape[0])] == list(g["grid_best_rank"])
