@@ -1938,6 +1938,18 @@ extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[16])
     return GGL_OK;
 }
 
+// What ran last: { concurrent parts, product-kernel variant of the last matrix-function step, code of the Theta kernel the
+// process's last Theta-step launched (theta_pair.hip: theta_last_kernel), eigendecompositions ggl_finalize_L ran on this ctx }
+extern "C" int ggl_last_dispatch(ggl_ctx* c, long long out[4])
+{
+    ARGCHK(c && out, "ctx, out");
+    out[0] = c->last_parts;
+    out[1] = c->last_variant;
+    out[2] = theta_last_kernel();
+    out[3] = c->finalize_calls;
+    return GGL_OK;
+}
+
 extern "C" int ggl_rank_stats(ggl_ctx* c, long long out[4])
 {
     ARGCHK(c && out, "ctx, out");

@@ -149,6 +149,7 @@ void launch_ext_prox_od(hipStream_t st, double* out, const double* A, const doub
 
 // ---- eig_jacobi.hip ---------------------------------------------------------------------
 bool jacobi_fits(int p);
+int theta_last_kernel();   // theta_pair.hip: code of the Theta kernel the last launch ran
 // One workgroup per matrix, matrix resident in LDS (one-sided Jacobi on rows, wave-shuffle
 // reductions).  Reads the LOWER triangle of A (numpy.linalg.eigh default).
 //   D (K,p) eigenvalues (unsorted), R (K,p,p) eigenvectors in ROWS; either may be null.

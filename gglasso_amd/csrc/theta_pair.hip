@@ -1042,12 +1042,20 @@ static void launch_flat4(hipStream_t st, double* Theta, double* X, double* C, co
 // the K-column of an element over 4, 8 or 16 waves: K <= 16: 4 x 4, <= 32: 4 x 8, <= 64: 8 x 8, <= 128: 16 x 8 (16-byte
 // accesses throughout), <= 256: 16 x 16 with 8-byte accesses (two elements per lane would need 192 registers per lane, a
 // 16-wave workgroup has 128)
+// Which Theta kernel the last launch_theta_pair / launch_theta_batch of this process ran (ggl_last_dispatch; the parity tests
+// assert the dispatch of every BASELINE configuration): 0 GGL tile pairs; 100 + KMAX per-element, K-column in one thread;
+// 100 * KQ + NW per-element, K-column over NW waves of KQ values per lane (404, 408: four waves; 808 / 816 / 1616: K <= 64 /
+// 128 / 256); 2000 + tile edge: FGL Condat tiles.
+static int g_theta_kernel = -1;
+int theta_last_kernel() { return g_theta_kernel; }
+
 static void launch_flat4_any(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                              const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual,
                              double* partials, int K, int p, const int* skip, int G, const double* l1G, const double* l2G,
                              const double* gsq)
 {
 #define GGL_F4(...) launch_flat4<__VA_ARGS__>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, G, l1G, l2G, gsq)
+    g_theta_kernel = K <= 16 ? 404 : K <= 32 ? 408 : K <= 64 ? 808 : K <= 128 ? 816 : 1616;
     if (K <= 16) GGL_F4(4);
     else if (K <= 32) GGL_F4(8);
     else if (K <= 64) GGL_F4(8, 8);
@@ -1063,6 +1071,7 @@ static void launch_flat(hipStream_t st, double* Theta, double* X, double* C, con
                         const double* gsq = nullptr)
 {
     dim3 grid(flat_blocks(p), G), blk(256);
+    g_theta_kernel = 100 + KMAX;
     if (fuse_dual)
         hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
     else
@@ -1092,6 +1101,7 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
         dim3 grid(T * (T + 1) / 2, kc), blk(PT, PTY);
         const double* sq = groupsq;
         int nsq = 1;
+        g_theta_kernel = 0;
         if (!sq) {   // single rank: per-chunk sums of squares, summed on the fly by the second kernel
             if (!sqwork) return hipErrorInvalidValue;
             hipLaunchKernelGGL(k_group_partial, grid, blk, 0, st, sqwork, Omega, L, X, l1, K, p, klen);
@@ -1105,6 +1115,7 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
         return hipGetLastError();
     }
     if (K > FGL_MAX_K_TD8) return hipErrorInvalidValue;
+    g_theta_kernel = 2000 + fgl_tile(K);
     if (fgl_tile(K) == 16)
         return launch_fgl_td<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
     return launch_fgl_td<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
@@ -1129,6 +1140,7 @@ hipError_t launch_theta_batch(hipStream_t st, int reg, double* Theta, double* X,
         return hipGetLastError();
     }
     if (K > FGL_MAX_K_TD8) return hipErrorInvalidValue;
+    g_theta_kernel = 2000 + fgl_tile(K);
     if (fgl_tile(K) == 16)
         return launch_fgl_td<16>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
     return launch_fgl_td<8>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);

@@ -399,6 +399,12 @@ class HipEngine:
         check(self.lib.ggl_rank_stats(self.h, out))
         return dict(zip(("calls", "continued_calls", "continued_instances", "eigh_fallbacks"), (int(v) for v in out)))
 
+    def last_dispatch(self):
+        import ctypes
+        out = (ctypes.c_longlong * 4)()
+        check(self.lib.ggl_last_dispatch(self.h, out))
+        return dict(zip(("parts", "variant", "theta_kernel", "finalize_calls"), (int(v) for v in out)))
+
     def device_ptr(self, which):
         return self.lib.ggl_device_ptr(self.h, which)
 

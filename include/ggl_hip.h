@@ -371,6 +371,11 @@ int ggl_ns_stats(ggl_ctx *ctx, long long out[16]);
 /* L-step (sign iteration): out = { calls, calls whose first pass was continued on a compact sub-batch, instances continued in
  * total, calls that fell back to the eigendecomposition } */
 int ggl_rank_stats(ggl_ctx *ctx, long long out[4]);
+/* What ran last: out = { concurrent parts and product-kernel variant of the last matrix-function step (as in ggl_ns_stats),
+ * code of the Theta kernel of the process's last Theta-step (0 GGL tile pairs; 100+KMAX per-element kernel with the K-column
+ * in one thread; 100*KQ+NW per-element kernel with the K-column over NW waves: 404, 408, 808, 816, 1616; 2000+tile FGL
+ * Condat tiles), eigendecompositions ggl_finalize_L ran on this ctx }.  The parity tests assert the dispatch with it. */
+int ggl_last_dispatch(ggl_ctx *ctx, long long out[4]);
 
 /* ---- kernel-level test / measurement entry points (not used by the solvers) --------------------
  * ggl_dev_symm: one launch of the symmetric-product kernel on host data (kernel unit test; variant < 0 = by size).

@@ -9,6 +9,9 @@ properties (exact symmetry, positive definiteness, norm identities) for what the
   C4        FGL K=50, p=500, latent    TD=8 Condat tile, two-part sign iteration of the L-step
   C2        SGL p=1000, 20-point grid  batched lambda path, 64x64 DMA kernel over several rounds of tiles
   C5 slab   GGL K=32, p=1000           per-GPU slab of C5 at 8 GPUs: unsplit launch sequence above 2048 tile pairs
+  C5 whole  GGL K=256, p=1000          the whole stack on one GPU: Theta kernel with the K-column over 16 waves of 16
+The headline and C4 are additionally solved to convergence on both sides (the oracle's solve is observed along the way, so
+the fixed-length comparison and the converged one cost its iterations once).
 Reference loop bodies: solver/admm_solver.py:172-246, solver/single_admm_solver.py:157-214.
 """
 import contextlib
@@ -48,7 +51,8 @@ def stats(monkeypatch):
 
     def closing(self):
         if getattr(self, "h", None):
-            seen.append(self.ns_stats())
+            seen.append({**self.ns_stats(), **{"rank_" + k: v for k, v in self.rank_stats().items()},
+                         **{"dispatch_" + k: v for k, v in self.last_dispatch().items()}})
         real_close(self)
 
     monkeypatch.setattr(solver.HipEngine, "close", closing)
@@ -61,6 +65,29 @@ def _problem(reg, K, p, seed):
     return S, np.repeat(np.eye(p)[None], K, axis=0)
 
 
+def _oracle_run(S, reg, l1, l2, Om0, checkpoints, tol, latent=False, mu1=None, max_iter=1000):
+    """The oracle's ADMM_MGL (oracle/ggl_oracle.py through the test-only engine and the product's own host loop) observed
+    along ONE solve: the state after each of ``checkpoints`` iterations (tol = rtol = 1e-20 up to there, which is what a
+    fixed-length run does) and then the solve continued to tol = rtol = ``tol``.  Returns ([states], converged state,
+    status, total iterations).  The oracle's eigh is the expensive side of these tests; this way a converged full-size solve
+    costs its own iterations once."""
+    from gglasso_amd import solver
+    from oracle_engine import OracleEngine
+    K, p, _ = S.shape
+    eng = OracleEngine(S, Om0, Om0, np.zeros_like(S))
+    nk = np.ones(K)
+    rho, done, states = 1.0, 0, []
+    with oracle_threads():
+        for it in checkpoints:
+            _, rho = quiet(solver._run_admm, eng, reg, K, p, l1, l2, latent, mu1, nk, rho, 1e-20, 1e-20, 'boyd', True, it - done,
+                           False, False, "Multiple")
+            done = it
+            states.append({k: v.copy() for k, v in eng.state().items()})
+        info, rho = quiet(solver._run_admm, eng, reg, K, p, l1, l2, latent, mu1, nk, rho, tol, tol, 'boyd', True,
+                          max_iter - done, False, True, "Multiple")
+    return states, eng.state(), info['status'], done + len(info['residual'])
+
+
 def _check_state(out, ref, names, tol):
     for nm in names:
         err = float(np.abs(out[nm] - ref[nm]).max())
@@ -68,20 +95,26 @@ def _check_state(out, ref, names, tol):
 
 
 def test_headline_dispatch_ggl_K32_p500(stats):
-    """bench.py's workload: 6 iterations with the rho rule from the identity start, then 3 at fixed rho (every
-    iteration after the first speculative), both against the oracle at 1e-9."""
+    """bench.py's workload along one oracle solve: 6 iterations with the rho rule from the identity start against the oracle at
+    1e-9, the CONVERGED solve (tol = rtol = 1e-10, default Omega-step tolerance) at |Theta - oracle|_F <= 1e-8 with the oracle's
+    status and iteration count (north_star: Theta within 1e-8 Frobenius), then 3 iterations at fixed rho
+    (every iteration after the first speculative)."""
     from gglasso_amd import solver
     S, Om0 = _problem("GGL", 32, 500, 1239)
-    kw = dict(max_iter=6, tol=1e-20, rtol=1e-20)
-    with oracle_threads():
-        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
-    out, info = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
-    _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
+    (ref6,), ref, ref_status, ref_iters = _oracle_run(S, "GGL", 0.05, 0.01, Om0, [6], 1e-10)
+    out, info = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, max_iter=6, tol=1e-20, rtol=1e-20)
+    _check_state(out, ref6, ("Omega", "Theta", "X"), 1e-9)
     assert np.array_equal(out["Theta"], out["Theta"].transpose(0, 2, 1))
     assert np.array_equal(out["Omega"], out["Omega"].transpose(0, 2, 1))
     st = stats[-1]
     assert st["last_parts"] == 2 and st["last_variant"] == 17, st          # fork/join two-part chains on variant 17
     assert st["stable_calls"] == 0 and st["eigh_fallbacks"] == 0, st
+    assert st["dispatch_theta_kernel"] == 408, st                          # per-element kernel, K-column over four waves
+    out, info = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, tol=1e-10, rtol=1e-10, measure=True)
+    assert info["status"] == ref_status == "optimal"
+    assert len(info["residual"]) == ref_iters, (len(info["residual"]), ref_iters)
+    assert np.linalg.norm(out["Theta"] - ref["Theta"]) <= 1e-8
+    assert np.abs(out["Theta"] - ref["Theta"]).max() <= 1e-10
     kw = dict(max_iter=3, tol=1e-20, rtol=1e-20, update_rho=False, rho=2.0)
     with oracle_threads():
         ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
@@ -125,20 +158,33 @@ def test_c3_dispatch_ggl_K20_p200(stats):
 
 
 def test_c4_dispatch_fgl_K50_p500_latent(stats):
-    """FGL with latent variables at full size: TD=8 Condat tiles (K > 32), the L-step's sign iteration in two
-    concurrent parts with its a-posteriori check (retries and eigh fallbacks are legal, wrong results are not)."""
+    """FGL with latent variables at full size along one oracle solve: 8 iterations from the identity start
+    against the oracle at 1e-9 -- iterations 3, 4 and 6 have an instance whose eigenvalue sits within 1e-5 |C| of the threshold
+    (profiles/r3_c4_lstep_threshold_gaps.txt), so the two-tier L-step's CONTINUATION (compact sub-batch, rank_ns_plan_continue,
+    trace check) must have run -- and the converged solve (tol = rtol = 1e-9): the oracle's status and iteration count,
+    |Theta - oracle|_F <= 1e-8, and numpy.linalg.matrix_rank of every returned L_k (rebuilt by ggl_finalize_L) equal to the
+    oracle's.  TD=8 Condat tiles (K > 32), sign iteration in two concurrent parts."""
     from gglasso_amd import solver
-    S, Om0 = _problem("FGL", 50, 500, 1237)
-    mu1 = 0.5 * np.ones(50)
-    kw = dict(max_iter=2, tol=1e-20, rtol=1e-20, latent=True, mu1=mu1)
-    with oracle_threads():
-        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "FGL", Om0, **kw)
-    out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "FGL", Om0, **kw)
-    _check_state(out, ref, ("Omega", "Theta", "L", "X"), 1e-9)
+    K = 50
+    S, Om0 = _problem("FGL", K, 500, 1237)
+    mu1 = 0.5 * np.ones(K)
+    (ref8,), ref, ref_status, ref_iters = _oracle_run(S, "FGL", 0.05, 0.01, Om0, [8], 1e-9, latent=True, mu1=mu1)
+    out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "FGL", Om0, max_iter=8, tol=1e-20, rtol=1e-20, latent=True, mu1=mu1)
+    _check_state(out, ref8, ("Omega", "Theta", "L", "X"), 1e-9)
     for nm in ("Omega", "Theta", "L"):
         assert np.array_equal(out[nm], out[nm].transpose(0, 2, 1)), nm
     st = stats[-1]
-    assert st["rank_calls"] == 2 and st["last_parts"] == 2 and st["last_variant"] == 17, st
+    assert st["rank_calls"] == 8 and st["last_parts"] == 2 and st["last_variant"] == 17, st
+    assert st["rank_continued_calls"] >= 1 and st["rank_continued_instances"] >= 1, st
+    assert st["rank_eigh_fallbacks"] == 0, st
+    assert st["dispatch_theta_kernel"] == 2008 and st["dispatch_finalize_calls"] == 1, st
+    out, info = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "FGL", Om0, tol=1e-9, rtol=1e-9, latent=True, mu1=mu1, measure=True)
+    assert info["status"] == ref_status == "optimal"
+    assert len(info["residual"]) == ref_iters, (len(info["residual"]), ref_iters)
+    assert np.linalg.norm(out["Theta"] - ref["Theta"]) <= 1e-8
+    assert np.abs(out["L"] - ref["L"]).max() <= 1e-9
+    with oracle_threads():
+        assert [np.linalg.matrix_rank(out["L"][k]) for k in range(K)] == [np.linalg.matrix_rank(ref["L"][k]) for k in range(K)]
 
 
 def test_c2_dispatch_sgl_p1000_grid20():
@@ -181,6 +227,24 @@ def test_c5_slab_dispatch_ggl_K32_p1000(stats):
     st = stats[-1]
     assert st["last_parts"] == 1 and st["last_variant"] == 16, st
     assert st["spec_calls"] >= 1, st          # iteration 2 (and the chain pre-launched behind it) ran speculatively
+
+
+def test_c5_whole_ggl_K256_p1000(stats):
+    """C5 WHOLE on one GPU (solver/admm_solver.py:172-246 at K = 256, p = 1000): 2 iterations, all of
+    Omega / Theta / X against the oracle at 1e-9, on the Theta kernel that spreads the K-column over 16 waves of 16 values
+    (k_theta_ggl_flat4v<16,16>, the only one for 128 < K <= 256) and the double-buffered 64x64 DMA product kernel."""
+    from gglasso_amd import solver
+    S, Om0 = _problem("GGL", 256, 1000, 1240)
+    kw = dict(max_iter=2, tol=1e-20, rtol=1e-20)
+    with oracle_threads():
+        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
+    out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
+    _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
+    assert np.array_equal(out["Theta"], out["Theta"].transpose(0, 2, 1))
+    st = stats[-1]
+    assert st["last_parts"] == 1 and st["last_variant"] == 16, st
+    assert st["dispatch_theta_kernel"] == 1616, st
+    assert st["stable_calls"] == 0 and st["eigh_fallbacks"] == 0, st
 
 
 @pytest.mark.parametrize("K", [4, 8, 16])
