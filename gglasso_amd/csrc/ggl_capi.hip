@@ -3061,6 +3061,79 @@ extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* 
     return GGL_OK;
 }
 
+// Symmetric product on the INT8 matrix cores (gemm_i8.hip): C = A B from S int8 slices per operand, slice
+// pairs t + u <= dmax.  A, B, C: (K,p,p) host arrays, |A| <= scaleA, |B| <= scaleB entrywise (powers of two).
+// ms_out[0]: slicing both operands (two launches), ms_out[1]: one product launch (mean of iters), ms_out[2]: overflow flag.
+extern "C" int ggl_dev_symm_i8(int K, int p, int S, int dmax, const double* A, const double* B, double scaleA, double scaleB,
+                               double* C, int iters, double* ms_out)
+{
+    ARGCHK(K >= 1 && p >= 1 && iters >= 1 && A && B && C && ms_out, "arguments");
+    ARGCHK(S >= 2 && S <= 8, "2 <= S <= 8");
+    const size_t n = (size_t)K * p * p;
+    const int P = (p + 63) / 64 * 64;
+    const size_t nslice = (size_t)S * K * P * P;
+    DevBuf dA, dB, dC, dsc;
+    HIPCHK(dA.alloc(n));
+    HIPCHK(dB.alloc(n));
+    HIPCHK(dC.alloc(n));
+    HIPCHK(dsc.alloc(2 * (size_t)K));
+    int8_t *sA = nullptr, *sB = nullptr;
+    int* flag = nullptr;
+    HIPCHK(hipMalloc(&sA, nslice));
+    HIPCHK(hipMalloc(&sB, nslice));
+    HIPCHK(hipMalloc(&flag, sizeof(int)));
+    HIPCHK(hipMemset(flag, 0, sizeof(int)));
+    std::vector<double> sc(2 * (size_t)K);
+    for (int k = 0; k < K; ++k) { sc[k] = scaleA; sc[K + k] = scaleB; }
+    UP(dA.p, A, n);
+    UP(dB.p, B, n);
+    UP(dsc.p, sc.data(), sc.size());
+    hipEvent_t e0, e1, e2;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventCreate(&e2));
+    int rc = GGL_OK;
+    launch_slice_i8(nullptr, dA.p, dsc.p, sA, K, p, S, flag);       // warm-up
+    HIPCHK(hipEventRecord(e0, nullptr));
+    launch_slice_i8(nullptr, dA.p, dsc.p, sA, K, p, S, flag);
+    launch_slice_i8(nullptr, dB.p, dsc.p + K, sB, K, p, S, flag);
+    HIPCHK(hipEventRecord(e1, nullptr));
+    if (!launch_symm_i8(nullptr, sA, sB, dsc.p, dsc.p + K, dC.p, K, p, S, dmax))
+        rc = fail(GGL_E_ARG, "bad argument: (S, dmax) = (%d, %d) is not instantiated", S, dmax);
+    if (!rc) {
+        HIPCHK(hipEventRecord(e1, nullptr));
+        for (int i = 0; i < iters; ++i) launch_symm_i8(nullptr, sA, sB, dsc.p, dsc.p + K, dC.p, K, p, S, dmax);
+        HIPCHK(hipEventRecord(e2, nullptr));
+        HIPCHK(hipEventSynchronize(e2));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e1, e2));
+        ms_out[1] = ms / iters;
+        int hflag = 0;
+        HIPCHK(hipMemcpy(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost));
+        ms_out[2] = hflag;
+        HIPCHK(hipGetLastError());
+        DOWN(C, dC.p, n);
+    }
+    {
+        // slicing time, measured on its own
+        HIPCHK(hipEventRecord(e0, nullptr));
+        launch_slice_i8(nullptr, dA.p, dsc.p, sA, K, p, S, flag);
+        launch_slice_i8(nullptr, dB.p, dsc.p + K, sB, K, p, S, flag);
+        HIPCHK(hipEventRecord(e1, nullptr));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        ms_out[0] = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
+    (void)hipFree(sA);
+    (void)hipFree(sB);
+    (void)hipFree(flag);
+    return rc;
+}
+
 #ifdef GGL_DEV
 // persistent-chain probe (gemm_sym.hip): out = {ms per chain as nprod launches, ms per chain as one cooperative launch,
 // grid of the cooperative launch, max |difference| between the two chains' results (same tile code: 0 unless a workgroup

@@ -149,7 +149,11 @@ void launch_ext_prox_od(hipStream_t st, double* out, const double* A, const doub
 
 // ---- eig_jacobi.hip ---------------------------------------------------------------------
 bool jacobi_fits(int p);
-int theta_last_kernel();   // theta_pair.hip: code of the Theta kernel the last launch ran
+int theta_last_kernel();
+// gemm_i8.hip: error-free split products on the INT8 matrix cores
+void launch_slice_i8(hipStream_t st, const double* A, const double* scaleK, int8_t* out, int K, int p, int S, int* flag);
+bool launch_symm_i8(hipStream_t st, const int8_t* As, const int8_t* Bs, const double* scaleA, const double* scaleB, double* C,
+                    int K, int p, int S, int dmax);   // theta_pair.hip: code of the Theta kernel the last launch ran
 // One workgroup per matrix, matrix resident in LDS (one-sided Jacobi on rows, wave-shuffle
 // reductions).  Reads the LOWER triangle of A (numpy.linalg.eigh default).
 //   D (K,p) eigenvalues (unsorted), R (K,p,p) eigenvectors in ROWS; either may be null.

@@ -384,6 +384,10 @@ int ggl_last_dispatch(ggl_ctx *ctx, long long out[4]);
 int ggl_dev_symm(int K, int p, const double *A, const double *B, const double *E, const double *coef5K,
                  double *C, double *C2, int variant);
 int ggl_dev_symm_bench(int K, int p, int variant, int iters, double *ms_out);
+/* C = A B on the INT8 matrix cores from S signed-digit slices per operand (error-free split; gemm_i8.hip), slice pairs
+ * t + u <= dmax; |A| <= scaleA, |B| <= scaleB entrywise.  ms_out = {slicing both operands, one product launch, overflow flag}. */
+int ggl_dev_symm_i8(int K, int p, int S, int dmax, const double *A, const double *B, double scaleA, double scaleB, double *C,
+                    int iters, double *ms_out);
 /* ggl_dev_symm_bounds: C = A B on the direct-to-LDS product kernel with the bound partials of its epilogue, reduced to
  * the row sums of |C| (K,p), |C|_F^2 (K) and the spectral bound sqrt(min(|C|_inf, Collatz-Wielandt ratio, |C|_F)) (K)
  * that the Omega-step takes from B' = (W^2 + 4 beta I)^2 (kernel unit test; even p, variants 16 / 17 / 20). */
