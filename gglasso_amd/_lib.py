@@ -87,7 +87,9 @@ _SIGNATURES = {
     "ggl_profile_read": ([_vp, _dp, ctypes.POINTER(ctypes.c_longlong), _i], _i),
     "ggl_dev_symm": ([_i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _i], _i),
     "ggl_dev_symm_bench": ([_i, _i, _i, _i, _dp], _i),
+    "ggl_dev_i8_stages": ([_i], _i),
     "ggl_dev_symm_i8": ([_i, _i, _i, _i, _dp, _dp, _d, _d, _dp, _i, _dp], _i),
+    "ggl_dev_omega_i8": ([_i, _i, _dp, _dp, _dp, ctypes.POINTER(_i), _d, _dp, _i, _dp], _i),
     "ggl_dev_symm_bounds": ([_i, _i, _dp, _dp, _i, _dp, _dp, _dp, _dp], _i),
     "ggl_snapshot_k": ([_vp, _i], _i),
     "ggl_selection_stats": ([_vp, _dp], _i),

@@ -3061,6 +3061,14 @@ extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* 
     return GGL_OK;
 }
 
+// LDS stages of the int8 product kernel: 1 (default: two workgroups per CU cover each other's loads) or 2 (double buffer)
+extern "C" int ggl_dev_i8_stages(int n)
+{
+    ARGCHK(n == 1 || n == 2, "1 or 2 stages");
+    symm_i8_set_stages(n);
+    return GGL_OK;
+}
+
 // Symmetric product on the INT8 matrix cores (gemm_i8.hip): C = A B from S int8 slices per operand, slice
 // pairs t + u <= dmax.  A, B, C: (K,p,p) host arrays, |A| <= scaleA, |B| <= scaleB entrywise (powers of two).
 // ms_out[0]: slicing both operands (two launches), ms_out[1]: one product launch (mean of iters), ms_out[2]: overflow flag.
@@ -3077,6 +3085,13 @@ extern "C" int ggl_dev_symm_i8(int K, int p, int S, int dmax, const double* A, c
     HIPCHK(dB.alloc(n));
     HIPCHK(dC.alloc(n));
     HIPCHK(dsc.alloc(2 * (size_t)K));
+    DevBuf dpar;
+    HIPCHK(dpar.alloc(12 * (size_t)K));
+    {
+        std::vector<double> par(12 * (size_t)K, 0.0);
+        for (int k = 0; k < K; ++k) { par[12 * k + 1] = 1.0; par[12 * k + 8] = scaleA * scaleB; par[12 * k + 9] = par[12 * k + 10] = 1.0; }
+        UP(dpar.p, par.data(), par.size());
+    }
     int8_t *sA = nullptr, *sB = nullptr;
     int* flag = nullptr;
     HIPCHK(hipMalloc(&sA, nslice));
@@ -3098,11 +3113,11 @@ extern "C" int ggl_dev_symm_i8(int K, int p, int S, int dmax, const double* A, c
     launch_slice_i8(nullptr, dA.p, dsc.p, sA, K, p, S, flag);
     launch_slice_i8(nullptr, dB.p, dsc.p + K, sB, K, p, S, flag);
     HIPCHK(hipEventRecord(e1, nullptr));
-    if (!launch_symm_i8(nullptr, sA, sB, dsc.p, dsc.p + K, dC.p, K, p, S, dmax))
+    if (!launch_symm_i8(nullptr, sA, sB, dpar.p, dC.p, K, p, S, dmax))
         rc = fail(GGL_E_ARG, "bad argument: (S, dmax) = (%d, %d) is not instantiated", S, dmax);
     if (!rc) {
         HIPCHK(hipEventRecord(e1, nullptr));
-        for (int i = 0; i < iters; ++i) launch_symm_i8(nullptr, sA, sB, dsc.p, dsc.p + K, dC.p, K, p, S, dmax);
+        for (int i = 0; i < iters; ++i) launch_symm_i8(nullptr, sA, sB, dpar.p, dC.p, K, p, S, dmax);
         HIPCHK(hipEventRecord(e2, nullptr));
         HIPCHK(hipEventSynchronize(e2));
         float ms = 0.f;
@@ -3131,6 +3146,62 @@ extern "C" int ggl_dev_symm_i8(int K, int p, int S, int dmax, const double* A, c
     (void)hipFree(sA);
     (void)hipFree(sB);
     (void)hipFree(flag);
+    return rc;
+}
+
+// The whole Omega-step on the int8 matrix cores (gemm_i8.hip: i8_omega_plan / i8_omega_run), stand-alone: Omega = phiplus(W)
+// for a (K,p,p) host stack W, beta (K), spectral bounds cbound (K) >= lambda_max(W^2 + 4 beta I).  cfg = {s_full, s_f2, s_gf2,
+// s_ye, d_ye} (0: defaults).  ms_out = {mean milliseconds of one step (slicing of W + products), products, overflow flag,
+// algorithmic units (fp64 products the schedule stands for)}.
+extern "C" int ggl_dev_omega_i8(int K, int p, const double* W, const double* beta, const double* cbound, const int* cfg5,
+                                double tol, double* Omega, int iters, double* ms_out)
+{
+    ARGCHK(K >= 1 && p >= 1 && W && beta && cbound && Omega && iters >= 1 && ms_out, "arguments");
+    const size_t n = (size_t)K * p * p;
+    I8Omega w;
+    if (i8_omega_alloc(&w, K, p) != 0) return fail(GGL_E_HIP, "i8 workspace: allocation failed");
+    DevBuf dW, dA, dB, dY, dF, dF2, dOm;
+    int rc = GGL_OK;
+    do {
+        if (dW.alloc(n) || dA.alloc(n) || dB.alloc(n) || dY.alloc(n) || dF.alloc(n) || dF2.alloc(n) || dOm.alloc(n)) {
+            rc = fail(GGL_E_HIP, "allocation failed");
+            break;
+        }
+        if (hipMemcpy(dW.p, W, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(GGL_E_HIP, "upload"); break; }
+        I8Cfg cfg;
+        if (cfg5 && cfg5[0] > 0) { cfg.s_full = cfg5[0]; cfg.s_f2 = cfg5[1]; cfg.s_gf2 = cfg5[2]; cfg.s_ye = cfg5[3]; cfg.d_ye = cfg5[4]; }
+        I8Bufs bufs = {dW.p, dA.p, dB.p, dY.p, dF.p, dF2.p, dOm.p};
+        I8Prog prog;
+        const int np = i8_omega_plan(&w, cbound, beta, 0, K, tol, 9, cfg, bufs, &prog);
+        if (np <= 0) { rc = fail(GGL_E_ARG, "bad argument: no two-step schedule for these bounds (%d)", np); break; }
+        if (hipMemcpy(w.par, w.par_h, (size_t)I8_MAXPROD * K * 12 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(w.wscale, w.wscale_h, K * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(GGL_E_HIP, "upload of the parameter rows");
+            break;
+        }
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        bool ok = i8_omega_run(nullptr, &w, prog, dW.p);      // warm-up (and the result)
+        (void)hipEventRecord(e0, nullptr);
+        for (int i = 0; ok && i < iters; ++i) ok = i8_omega_run(nullptr, &w, prog, dW.p);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (!ok) { rc = fail(GGL_E_ARG, "bad argument: a slice configuration of the plan is not instantiated"); break; }
+        if (hipGetLastError() != hipSuccess) { rc = fail(GGL_E_HIP, "i8 Omega-step: launch failed"); break; }
+        int hflag = 0;
+        (void)hipMemcpy(&hflag, w.flag, sizeof(int), hipMemcpyDeviceToHost);
+        ms_out[0] = ms / iters;
+        ms_out[1] = np;
+        ms_out[2] = hflag;
+        ms_out[3] = prog.units;
+        if (hipMemcpy(Omega, dOm.p, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(GGL_E_HIP, "download"); break; }
+    } while (0);
+    i8_omega_free(&w);
     return rc;
 }
 

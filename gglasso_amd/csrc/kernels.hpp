@@ -151,9 +151,52 @@ void launch_ext_prox_od(hipStream_t st, double* out, const double* A, const doub
 bool jacobi_fits(int p);
 int theta_last_kernel();
 // gemm_i8.hip: error-free split products on the INT8 matrix cores
-void launch_slice_i8(hipStream_t st, const double* A, const double* scaleK, int8_t* out, int K, int p, int S, int* flag);
-bool launch_symm_i8(hipStream_t st, const int8_t* As, const int8_t* Bs, const double* scaleA, const double* scaleB, double* C,
-                    int K, int p, int S, int dmax);   // theta_pair.hip: code of the Theta kernel the last launch ran
+void launch_slice_i8(hipStream_t st, const double* A, const double* scaleK, int8_t* out, int K, int p, int S, int* flag,
+                     size_t sstride = 0);
+void symm_i8_set_stages(int n);
+bool launch_symm_i8(hipStream_t st, const int8_t* As, const int8_t* Bs, const double* par, double* C, int K, int p, int S, int dmax);
+// one product launch of k_symm_i8 (gemm_i8.hip):  acc = scale_A scale_B sum_{t+u<=dmax} 2^-(12+7(t+u)) D^A_t (D^B_u)^T,
+// out1 = cI I + cAcc acc + cE1 E1 + cE2 E2, out2 = dI I + dAcc acc + dE1 E1 + dE2 E2, each as fp64 (C) and / or int8 slices (S)
+// par[k][12] = { cI, cAcc, cE1, cE2, dI, dAcc, dE1, dE2, scale_A scale_B, 1 / scale_1, 1 / scale_2, - }
+struct I8Op {
+    const int8_t* As = nullptr;
+    const int8_t* Bs = nullptr;
+    size_t sstrideA = 0, sstrideB = 0;       // bytes between the slices of an operand
+    const double* par = nullptr;             // [K][12]
+    const double* E1 = nullptr;
+    const double* E2 = nullptr;
+    double* C1 = nullptr;
+    double* C2 = nullptr;
+    int8_t* S1 = nullptr;
+    int8_t* S2 = nullptr;
+    int nS1 = 0, nS2 = 0;
+    size_t sstride1 = 0, sstride2 = 0;
+    int* flag = nullptr;                     // raised when a digit of an output slice does not fit (a scale was too small)
+    int K = 0, p = 0, P = 0;
+};
+bool launch_symm_i8_op(hipStream_t st, const I8Op& op, int SA, int SB, int dmax);
+// the Omega-step on the int8 matrix cores (gemm_i8.hip)
+static constexpr int I8_NSLICES = 59;        // slice stacks of the workspace
+static constexpr int I8_MAXPROD = 8;
+struct I8Omega {
+    int K = 0, p = 0, P = 0;
+    size_t sl = 0;                           // bytes of one slice stack (K P P)
+    int8_t* slab = nullptr;
+    double *par = nullptr, *par_h = nullptr; // [I8_MAXPROD][K][12] device / pinned
+    double *wscale = nullptr, *wscale_h = nullptr;   // [K] scale of W
+    int* flag = nullptr;
+};
+struct I8Cfg { int s_full = 7, s_f2 = 4, s_gf2 = 3, s_ye = 5, d_ye = 4; };
+struct I8Bufs { const double* W; double *Ap, *Bp, *Y1, *F, *F2, *Om; };   // fp64 stacks (K,p,p) of the whole batch
+struct I8Prog {
+    struct Prod { I8Op op; int SA, SB, dmax; } prod[I8_MAXPROD];
+    int nprod = 0, units = 0, k0 = 0, Kp = 0, S_W = 7;
+};
+int i8_omega_alloc(I8Omega* w, int K, int p);
+void i8_omega_free(I8Omega* w);
+int i8_omega_plan(I8Omega* w, const double* cuse_h, const double* beta_h, int k0, int Kp, double tol, int degrees,
+                  const I8Cfg& cfg, const I8Bufs& bufs, I8Prog* prog);
+bool i8_omega_run(hipStream_t st, I8Omega* w, const I8Prog& prog, const double* W);   // theta_pair.hip: code of the Theta kernel the last launch ran
 // One workgroup per matrix, matrix resident in LDS (one-sided Jacobi on rows, wave-shuffle
 // reductions).  Reads the LOWER triangle of A (numpy.linalg.eigh default).
 //   D (K,p) eigenvalues (unsorted), R (K,p,p) eigenvectors in ROWS; either may be null.

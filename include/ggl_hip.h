@@ -386,8 +386,15 @@ int ggl_dev_symm(int K, int p, const double *A, const double *B, const double *E
 int ggl_dev_symm_bench(int K, int p, int variant, int iters, double *ms_out);
 /* C = A B on the INT8 matrix cores from S signed-digit slices per operand (error-free split; gemm_i8.hip), slice pairs
  * t + u <= dmax; |A| <= scaleA, |B| <= scaleB entrywise.  ms_out = {slicing both operands, one product launch, overflow flag}. */
+int ggl_dev_i8_stages(int n);   /* LDS stages of the int8 product kernel: 1 (default) or 2 */
 int ggl_dev_symm_i8(int K, int p, int S, int dmax, const double *A, const double *B, double scaleA, double scaleB, double *C,
                     int iters, double *ms_out);
+/* The whole Omega-step phiplus(W) (solver/ggl_helper.py:272-303) on the int8 matrix cores, stand-alone: W (K,p,p), beta (K),
+ * cbound (K) >= lambda_max(W^2 + 4 beta I); cfg5 = {slices of the full products, of F F, of G F^2, of Y E, diagonal cut of Y E}
+ * or NULL; tol: the schedule's stopping tolerance.  ms_out = {ms per step, product launches, overflow flag, fp64 products the
+ * schedule stands for}. */
+int ggl_dev_omega_i8(int K, int p, const double *W, const double *beta, const double *cbound, const int *cfg5, double tol,
+                     double *Omega, int iters, double *ms_out);
 /* ggl_dev_symm_bounds: C = A B on the direct-to-LDS product kernel with the bound partials of its epilogue, reduced to
  * the row sums of |C| (K,p), |C|_F^2 (K) and the spectral bound sqrt(min(|C|_inf, Collatz-Wielandt ratio, |C|_F)) (K)
  * that the Omega-step takes from B' = (W^2 + 4 beta I)^2 (kernel unit test; even p, variants 16 / 17 / 20). */

@@ -466,3 +466,73 @@ def test_rank_two_tier_continues_only_the_unresolved_instances(p):
     out, st = _rank_ex(Wat, beta, 1e-4)
     assert st["continued_calls"] == 1 and st["eigh_fallbacks"] == 1, st
     assert np.abs(out - orc.rank_stack(Wat, np.full(K, beta))).max() <= tol
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Error-free split products on the INT8 matrix cores (csrc/gemm_i8.hip; VERDICT r3 item 3 -- measured, not on the solver's path:
+# DESIGN.md section 8.7).  The kernel's arithmetic is exact integer arithmetic, so it is pinned BIT FOR BIT to a NumPy emulation.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _oz_emulate(A, B, S, dmax):
+    """sum_{t+u<=dmax} 2^-(12+7(t+u)) D^A_t (D^B_u)^T with signed-digit slices (first 6 bits, then 7 each), as the kernel."""
+    def slices(M):
+        r, out = M.copy(), []
+        for t in range(S):
+            w = 2.0 ** -(6 + 7 * t)
+            D = np.rint(r / w)
+            out.append(D)
+            r = r - D * w
+        return out
+    DA, DB = slices(A), slices(B)
+    C = np.zeros_like(A)
+    for d in range(dmax, -1, -1):
+        acc = sum(DA[t] @ DB[d - t].T for t in range(S) if 0 <= d - t < S)
+        C += acc * 2.0 ** -(12 + 7 * d)
+    return C
+
+
+@pytest.mark.parametrize("p,K,S,dmax", [(96, 3, 7, 6), (130, 2, 4, 3), (200, 9, 5, 4), (64, 1, 3, 2)])
+def test_int8_split_product_bitwise(p, K, S, dmax):
+    from gglasso_amd import _lib
+    from gglasso_amd._lib import ptr
+    lib = _lib.load()
+    rng = np.random.default_rng(p + S)
+    A, B = np.empty((K, p, p)), np.empty((K, p, p))
+    for k in range(K):
+        G = rng.standard_normal((p, p))
+        G = 0.5 * (G + G.T)
+        G /= np.linalg.norm(G, 2) * 1.0001
+        A[k] = G
+        B[k] = 0.5 * np.eye(p) + 0.3 * G - 0.2 * G @ G
+        B[k] = 0.5 * (B[k] + B[k].T)
+    C = np.zeros((K, p, p))
+    out = np.zeros(3)
+    _lib.check(lib.ggl_dev_symm_i8(K, p, S, dmax, ptr(A), ptr(B), 1.0, 1.0, ptr(C), 1, ptr(out)))
+    assert int(out[2]) == 0
+    iu = np.triu_indices(p)
+    for k in range(K):
+        assert np.array_equal(C[k][iu], _oz_emulate(A[k], B[k], S, dmax)[iu]), k
+        assert np.array_equal(C[k], C[k].T)
+    if S == 7:
+        assert max(np.abs(C[k] - A[k] @ B[k]).max() for k in range(K)) <= 1e-12
+
+
+@pytest.mark.parametrize("p,K", [(200, 3), (320, 2)])
+def test_int8_omega_step_chain_against_eigh(p, K):
+    """phiplus(W) through the 7 / 8 split products of the two-step schedules against numpy.linalg.eigh (ggl_helper.py:272-303)."""
+    import ctypes
+    from gglasso_amd import synth, _lib
+    from gglasso_amd._lib import ptr
+    lib = _lib.load()
+    S, _ = synth.make_problem("GGL", K, p, N=2 * p, seed=p)
+    W = np.ascontiguousarray(np.stack([np.eye(p) - S[k] for k in range(K)]))
+    W = 0.5 * (W + W.transpose(0, 2, 1))
+    beta = np.ones(K)
+    cb = np.array([np.linalg.eigvalsh(W[k] @ W[k] + 4 * np.eye(p))[-1] * 1.02 for k in range(K)])
+    ref, _ = orc.phiplus_stack(W, 1.0)
+    Om = np.zeros_like(W)
+    out = np.zeros(4)
+    c5 = (ctypes.c_int * 5)(7, 4, 3, 5, 4)
+    _lib.check(lib.ggl_dev_omega_i8(K, p, ptr(W), ptr(beta), ptr(cb), c5, 2e-12, ptr(Om), 1, ptr(out)))
+    assert int(out[2]) == 0 and int(out[1]) in (7, 8)
+    assert np.abs(Om - ref).max() <= 5e-10 * np.abs(ref).max()
+    assert np.array_equal(Om, Om.transpose(0, 2, 1))
