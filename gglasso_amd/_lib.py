@@ -15,7 +15,7 @@ EIG_AUTO, EIG_JACOBI, EIG_ROCSOLVER, EIG_NEWTON_SCHULZ = 0, 1, 2, 3
 CTX_STREAM_GIVEN = 1 << 16
 # ggl_ctx_set_option ids (GGL_OPT_*)
 OPTIONS = {"speculate": 1, "spec_factor": 2, "ns_mode": 3, "ns_degrees": 4, "theta_flat": 5, "rank_eig": 6, "parts": 7,
-           "parts_max_tiles": 8, "symm_variant": 9, "spin_wait": 10, "fused_bounds": 11, "pipeline": 12, "fused_start": 13, "parts_small": 14, "ns_tol": 15, "cw_warm": 16, "chain": 17, "rank_l0_coarse": 18}
+           "parts_max_tiles": 8, "symm_variant": 9, "spin_wait": 10, "fused_bounds": 11, "pipeline": 12, "fused_start": 13, "parts_small": 14, "ns_tol": 15, "cw_warm": 16, "chain": 17, "rank_l0_coarse": 18, "isolate": 19}
 
 
 def eig_flags(method=EIG_AUTO, ns_mode=0, ns_degrees=0):
@@ -92,10 +92,14 @@ _SIGNATURES = {
     "ggl_dev_omega_i8": ([_i, _i, _dp, _dp, _dp, ctypes.POINTER(_i), _d, _dp, _i, _dp], _i),
     "ggl_dev_symm_bounds": ([_i, _i, _dp, _dp, _i, _dp, _dp, _dp, _dp], _i),
     "ggl_snapshot_k": ([_vp, _i], _i),
+    "ggl_snapshot_from": ([_vp, _i, _vp, _i], _i),
     "ggl_selection_stats": ([_vp, _dp], _i),
     "ggl_threshold_scan": ([_vp, _dp, _i, _dp, ctypes.POINTER(_i)], _i),
     "ggl_selection_rank": ([_vp, _d, _dp], _i),
     "ggl_finalize_L": ([_vp, _i, ctypes.POINTER(_i)], _i),
+    "ggl_failed_instances": ([_vp, ctypes.POINTER(_i)], _i),
+    "ggl_reset_instance": ([_vp, _i], _i),
+    "ggl_ctx_create_subset": ([_vp, ctypes.POINTER(_i), _i, ctypes.POINTER(_vp)], _i),
     "ggl_get_snapshot_k": ([_vp, _i, _dp, _dp], _i),
     "ggl_dev_ns_schedule": ([_d, _i, _i, ctypes.POINTER(_i), _dp, ctypes.POINTER(_i)], _i),
     "ggl_dev_ns_schedule_tol": ([_d, _i, _d, _i, ctypes.POINTER(_i), _dp, ctypes.POINTER(_i)], _i),

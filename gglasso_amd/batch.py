@@ -18,7 +18,7 @@ from .solver import as_c, residuals_from_norms, next_rho
 
 def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max_iter=1000, tol=1e-7,
                    rtol=1e-4, update_rho=True, verbose=False, latent=False, mu1=None, lambda1_mask=None,
-                   selection_stats=False, dims=None, tau_range=None):
+                   selection_stats=False, dims=None, tau_range=None, compact=True):
     """Solve ``ADMM_SGL(S, lambda1[k], ...)`` for every k of the 1-D array ``lambda1`` at once.
 
     S: (p,p) shared by all instances, or (K,p,p) with one covariance matrix per instance (what
@@ -37,7 +37,9 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     of its slot and the caller has padded S / Omega_0 / Theta_0 with an identity block and X_0 with zeros behind it (a
     decoupled fixed point of the iteration; ``pad_blocks`` builds such stacks).  Residuals, ``dim`` and the stopping
     decision of an instance are those of its block alone, and its solution is returned un-padded.  ``lambda1_mask`` may
-    then be (K,p,p): one mask per instance (with one lambda1 per instance)."""
+    then be (K,p,p): one mask per instance (with one lambda1 per instance).
+    A point whose data are not finite (a NaN in its S) ends with ``info['status'] == 'solver error'`` and costs that point
+    only; ``compact``: once a quarter of the live slots hold finished points, the rest go on in a smaller stack."""
     S = as_c(S)
     assert S.ndim in (2, 3) and S.shape[-1] == S.shape[-2]
     p = S.shape[-1]
@@ -83,6 +85,7 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     Th0 = stack(Theta_0, Om0)
     X0 = stack(X_0, np.zeros((p, p)))
     eng = _solver.ENGINE(np.broadcast_to(S, (K, p, p)), Om0, Th0, X0)
+    engines = [eng]                  # eng: the original ctx (snapshots, statistics); cur: where the live points iterate
     try:
         if lam_pp is not None and lam_pp.ndim == 3:
             eng.set_lambda1_mask_k(lam[:, None, None] * lam_pp)        # single_admm_solver.py:114, per instance
@@ -93,50 +96,71 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
             eng.set_lambda1_mask(lam[0] * lam_pp)
         if dims is not None:
             eng.set_instance_dims(dims)
+        if hasattr(eng, "set_option"):
+            eng.set_option("isolate", 1)
         pk = np.full(K, p) if dims is None else dims
         rhos = np.full(K, float(rho))
         done = np.zeros(K, dtype=bool)
         results = [None] * K
         last = [None] * K
         dimk = (pk ** 2 + pk) / 2                                       # single_admm_solver.py:279, of the block itself
-
-        def state_of(k):
-            st = eng.state_k(k, latent)
-            return st if dims is None else {nm: np.ascontiguousarray(A[:pk[k], :pk[k]]) for nm, A in st.items()}
         keep_snapshots = selection_stats or latent
+        cur, slots = eng, np.arange(K)                                   # slots[s]: the point in slot s of cur
+        carried = np.zeros(K, dtype=np.int64)
+
+        def state_of(s):
+            k = slots[s]
+            st = cur.state_k(s, latent)
+            return st if dims is None else {nm: np.ascontiguousarray(A[:pk[k], :pk[k]]) for nm, A in st.items()}
+
+        def finish(s, status, iters):
+            k = slots[s]
+            results[k] = (state_of(s), {'status': status, 'iterations': iters, 'rho': rhos[k]})
+            if keep_snapshots:
+                eng.snapshot_k(k) if cur is eng else eng.snapshot_from(k, cur, s)
+
         for it in range(max_iter):
-            sq = eng.sgl_batch_step(rhos, lam, latent, mu)
-            fac = np.ones(K)
-            for k in range(K):
+            sq = cur.sgl_batch_step(rhos[slots], lam[slots], latent, None if mu is None else mu[slots])
+            carried[slots] += 1
+            fac = np.ones(len(slots))
+            newly = []
+            for s, k in enumerate(slots):
                 if done[k]:
                     continue
-                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[k], rhos[k], tol, rtol, dimk[k])
+                if not np.all(np.isfinite(sq[s])):
+                    # this point's data are not finite (a NaN in its S, a diverged iterate): the reference's sequential walk
+                    # (model_selection.py:619-633) would lose this point only -- so does the batch
+                    finish(s, 'solver error', it + 1)
+                    done[k] = True
+                    if hasattr(cur, "reset_instance"):
+                        cur.reset_instance(s)
+                    continue
+                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[s], rhos[k], tol, rtol, dimk[k])
                 if update_rho:
                     rn = next_rho(rhos[k], r_t, s_t)
-                    fac[k] = rhos[k] / rn
+                    fac[s] = rhos[k] / rn
                     rhos[k] = rn
                 last[k] = (r_t, s_t, e_pri, e_dual)
                 if verbose:
                     print("%4d\t%3d\t%10.4g\t%10.4g\t%10.4g\t%10.4g" % (it, k, r_t, s_t, e_pri, e_dual))
                 if (r_t <= e_pri) and (s_t <= e_dual):
                     done[k] = True
+                    newly.append(s)
             if np.any(fac != 1.0):
-                eng.scale_X_batch(fac)
-            for k in range(K):
-                if done[k] and results[k] is None:
-                    results[k] = (state_of(k), {'status': 'optimal', 'iterations': it + 1, 'rho': rhos[k]})
-                    if keep_snapshots:
-                        eng.snapshot_k(k)
+                cur.scale_X_batch(fac)
+            for s in newly:
+                finish(s, 'optimal', it + 1)
             if done.all():
                 break
-        for k in range(K):
+            cur, slots = _compact(cur, slots, done, engines, compact)
+        for s, k in enumerate(slots):
             if results[k] is None:
                 r_t, s_t, e_pri, e_dual = last[k]
                 status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
                                                                 else 'max iterations reached')
-                results[k] = (state_of(k), {'status': status, 'iterations': max_iter, 'rho': rhos[k]})
-                if keep_snapshots:
-                    eng.snapshot_k(k)
+                finish(s, status, max_iter)
+        for k in range(K):
+            results[k][1]['carried'] = int(carried[k])
         ranks = _final_L(eng, [results[k][0] for k in range(K)], 1) if latent else None
         if selection_stats:
             assert dims is None, "selection statistics are taken over whole slots"
@@ -153,8 +177,32 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                     results[k][1]['selection']['threshold'] = tab[k].copy()
                     results[k][1]['selection']['threshold_eig_problems'] = n_eig
     finally:
-        eng.close()
+        for e in engines:
+            e.close()
     return results
+
+
+# Compaction of a batch of independent problems (the reference's walk, helper/model_selection.py:208-224,
+# spends nothing on a point that has converged): once at least a quarter of the slots of the live ctx hold finished points,
+# the points still iterating move to a smaller ctx (HipEngine.subset, device to device) and the products stop paying for the
+# others.  The first step in the new ctx cannot speculate (no carried bounds) and the ctx itself costs a few allocations: the
+# move is made only when at least COMPACT_MIN_DROP slots and COMPACT_FRACTION of the live ctx can be dropped.  Every info dict
+# carries 'carried': the batch iterations the point occupied a slot for (its own 'iterations' + what it was dragged along).
+COMPACT_FRACTION = 0.25
+COMPACT_MIN_DROP = 2
+
+
+def _compact(cur, slots, done, engines, enabled, group=1):
+    if not enabled or not hasattr(cur, "subset"):
+        return cur, slots
+    alive = np.flatnonzero(~done[slots])
+    n_drop = len(slots) - len(alive)
+    if len(alive) == 0 or n_drop < COMPACT_MIN_DROP or n_drop < COMPACT_FRACTION * len(slots):
+        return cur, slots
+    idx = alive if group == 1 else (alive[:, None] * group + np.arange(group)[None, :]).reshape(-1)
+    new = cur.subset(idx)
+    engines.append(new)
+    return new, slots[alive]
 
 
 def _final_L(eng, sols, per_sol):
@@ -194,7 +242,7 @@ def pad_blocks(blocks, P, identity):
 
 def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1e-5, rtol=1e-4, update_rho=True,
                    rho=1., max_iter=1000, verbose=False, latent=False, mu1=None, selection_stats=False,
-                   tau_range=None):
+                   tau_range=None, compact=True):
     """Solve ``ADMM_MGL(S, lambda1[g], lambda2[g], reg, Omega_0, ...)`` (solver/admm_solver.py:13-313) for every
     g of the 1-D arrays ``lambda1`` / ``lambda2`` at once: the G problems are the slabs of one (G*K,p,p) stack on
     the GPU, one batched Omega-step (and L-step) over all G*K matrices and one Theta-step launch per iteration.
@@ -204,9 +252,9 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
     Every problem keeps its OWN rho, residuals, rho updates and stopping decision, exactly as if it had been solved
     on its own from ``Omega_0`` (default: identity; Theta_0 = Omega_0, X_0 = 0 as in admm_solver.py:142-150), so each
     returned (sol, info) equals the independent solve; a problem's solution is snapshotted at the iteration it
-    converges and it keeps iterating harmlessly until the batch is done.  (A solver error -- a non-finite iterate, an
-    eigensolver that does not converge -- in ANY point, finished or not, raises and ends the whole batch: the sequential walk
-    ``grid_search(..., batched=False)`` isolates the points.)
+    converges; once a quarter of the live slots hold finished problems the rest go on in a smaller stack (``compact``).  A
+    point whose data are not finite (a NaN in its S, a diverged iterate) ends with ``info['status'] == 'solver error'`` and
+    costs that point only, as in the reference's sequential walk (the ctx runs with GGL_OPT_ISOLATE).
     mu1: (K,) shared by all problems or (G,K); n_samples as in ADMM_MGL.
     Returns a list of G ``(sol, info)``; ``info`` carries 'status', 'iterations', 'rho' (+ 'selection': per-instance
     (K,4) array of <S,Theta>, log det Theta, count_nonzero(Theta), lambda_min(Theta) from the GPU when
@@ -242,50 +290,70 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
     # (G,K,p,p) broadcast VIEWS of the one problem's stacks, and of one zero matrix: uploaded once, replicated on the device
     rep = lambda A: np.broadcast_to(as_c(A), (G,) + A.shape)
     eng = _solver.ENGINE(rep(S), rep(Om0), rep(Om0), np.broadcast_to(np.zeros((p, p)), (G * K, p, p)))
+    engines = [eng]
     try:
+        if hasattr(eng, "set_option"):
+            eng.set_option("isolate", 1)
         rhos = np.full(G, float(rho))
         done = np.zeros(G, dtype=bool)
         results = [None] * G
         last = [None] * G
         dim = K * ((p ** 2 + p) / 2)
+        cur, slots = eng, np.arange(G)                                   # slots[s]: the problem in slot s of cur
+        carried = np.zeros(G, dtype=np.int64)
+        inst = lambda v: None if v is None else v.reshape(G, K)[slots].reshape(-1)
 
-        def collect(g, status, iters):
-            parts = [eng.state_k(g * K + k, True) for k in range(K)]
+        def collect(s, status, iters):
+            g = slots[s]
+            parts = [cur.state_k(s * K + k, True) for k in range(K)]
             sol = {nm: np.stack([q[nm] for q in parts]) for nm in ('Omega', 'Theta', 'L', 'X')}
             results[g] = (sol, {'status': status, 'iterations': iters, 'rho': rhos[g]})
             if selection_stats or latent:
                 for k in range(K):
-                    eng.snapshot_k(g * K + k)
+                    eng.snapshot_k(g * K + k) if cur is eng else eng.snapshot_from(g * K + k, cur, s * K + k)
 
         for it in range(max_iter):
-            sq = eng.mgl_batch_step(G, rhos, lam1, lam2, reg, latent, mu, nk)
-            fac = np.ones(G)
-            for g in range(G):
+            sq = cur.mgl_batch_step(len(slots), rhos[slots], lam1[slots], lam2[slots], reg, latent, inst(mu), nk)
+            carried[slots] += 1
+            fac = np.ones(len(slots))
+            newly = []
+            for s, g in enumerate(slots):
                 if done[g]:
                     continue
-                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[g], rhos[g], tol, rtol, dim)
+                if not np.all(np.isfinite(sq[s])):
+                    # (see ADMM_SGL_batch: a point with non-finite data costs that point only)
+                    collect(s, 'solver error', it + 1)
+                    done[g] = True
+                    if hasattr(cur, "reset_instance"):
+                        for k in range(K):
+                            cur.reset_instance(s * K + k)
+                    continue
+                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[s], rhos[g], tol, rtol, dim)
                 if update_rho:
                     rn = next_rho(rhos[g], r_t, s_t)
-                    fac[g] = rhos[g] / rn
+                    fac[s] = rhos[g] / rn
                     rhos[g] = rn
                 last[g] = (r_t, s_t, e_pri, e_dual)
                 if verbose:
                     print("%4d\t%3d\t%10.4g\t%10.4g\t%10.4g\t%10.4g" % (it, g, r_t, s_t, e_pri, e_dual))
                 if (r_t <= e_pri) and (s_t <= e_dual):
                     done[g] = True
+                    newly.append(s)
             if np.any(fac != 1.0):
-                eng.scale_X_batch(np.repeat(fac, K))
-            for g in range(G):
-                if done[g] and results[g] is None:
-                    collect(g, 'optimal', it + 1)
+                cur.scale_X_batch(np.repeat(fac, K))
+            for s in newly:
+                collect(s, 'optimal', it + 1)
             if done.all():
                 break
-        for g in range(G):
+            cur, slots = _compact(cur, slots, done, engines, compact, group=K)
+        for s, g in enumerate(slots):
             if results[g] is None:
                 r_t, s_t, e_pri, e_dual = last[g]
                 status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
                                                                 else 'max iterations reached')
-                collect(g, status, max_iter)
+                collect(s, status, max_iter)
+        for g in range(G):
+            results[g][1]['carried'] = int(carried[g])
         if latent:
             rk = _final_L(eng, [results[g][0] for g in range(G)], K)
             for g in range(G):
@@ -299,5 +367,6 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                 for g in range(G):
                     results[g][1]['threshold'] = tab[g * K:(g + 1) * K].copy()
     finally:
-        eng.close()
+        for e in engines:
+            e.close()
     return results

@@ -418,6 +418,20 @@ void launch_copy_instances(hipStream_t st, double* dst, const double* src, const
     hipLaunchKernelGGL(k_copy_instances, dim3(std::max(bx, 1), m), dim3(256), 0, st, dst, src, idx, pp, scatter ? 1 : 0);
 }
 
+// A_k = I for the K instances of a stack (ggl_reset_instance)
+__global__ __launch_bounds__(256) void k_set_identity(double* __restrict__ A, int p)
+{
+    double* a = A + (size_t)blockIdx.y * p * p;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)p * p; e += (size_t)gridDim.x * 256)
+        a[e] = (e / p == e % p) ? 1.0 : 0.0;
+}
+
+void launch_set_identity(hipStream_t st, double* A, int K, int p)
+{
+    const int bx = (int)std::min<size_t>(((size_t)p * p + 255) / 256, 512);
+    hipLaunchKernelGGL(k_set_identity, dim3(bx, K), dim3(256), 0, st, A, p);
+}
+
 void launch_dot(hipStream_t st, const double* A, const double* B, int K, int p, double* partials)
 {
     size_t pp = (size_t)p * p;

@@ -150,6 +150,12 @@ struct ggl_ctx {
     double* snap_beta = nullptr;               // host (K)
     unsigned char* snap_ns = nullptr;          // host (K): snapshot k's L is a sign-iteration L (snapC_k, snap_beta[k] valid)
     long long finalize_calls = 0;              // eigendecompositions ggl_finalize_L ran
+    // GGL_OPT_ISOLATE (batches of independent problems): an instance whose data turn non-finite (a NaN in its S, a diverged
+    // iterate) or whose eigensolver does not converge is MARKED instead of failing the call for the whole batch
+    // (helper/model_selection.py:208-224 walks the grid point by point and never loses it to one point); the host reads the
+    // marks (ggl_failed_instances), reports the point and parks its slots on the identity problem (ggl_reset_instance)
+    bool isolate = false;
+    unsigned char* failed = nullptr;           // host (K), lazy
     double* nbrow = nullptr;                   // [K][p] row abs-sums of B' (Collatz-Wielandt weight vector)
     // the Collatz-Wielandt vector carried across iterations (k_cw_final): [cw_cur] was left behind by the last ACCEPTED
     // bound pass, the other one is what the pass in flight writes; cw_have: there is an accepted one
@@ -377,6 +383,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_PARTS_SMALL: c->parts_small = (int)v; break;
         case GGL_OPT_CW_WARM: c->cw_warm = v != 0.0; break;
         case GGL_OPT_CHAIN: c->chain_mode = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
+        case GGL_OPT_ISOLATE: c->isolate = v != 0.0; break;
         case GGL_OPT_RANK_L0_COARSE:
             if (!(v >= 0.0) || v > 0.1) return fail(GGL_E_ARG, "bad argument: GGL_OPT_RANK_L0_COARSE is in [0, 0.1]");
             c->rank_l0_coarse = v;
@@ -420,6 +427,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_CW_WARM: *value = c->cw_warm; break;
         case GGL_OPT_CHAIN: *value = c->chain_mode; break;
         case GGL_OPT_RANK_L0_COARSE: *value = c->rank_l0_coarse; break;
+        case GGL_OPT_ISOLATE: *value = c->isolate; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
     }
     return GGL_OK;
@@ -498,6 +506,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
                       c->nsT, c->nsNX, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->snapL, c->cuse, c->Lam[0],
                       c->Lam[1], c->X1, c->cwvec[0], c->cwvec[1], c->Ckeep, c->snapC};
     free(c->Ckeep_beta);
+    free(c->failed);
     free(c->snap_beta);
     free(c->snap_ns);
     for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize, c->inst_pk, c->rank_idx})
@@ -812,13 +821,34 @@ static int eigvals_only(ggl_ctx* c, double* A, double* Dv)
     return GGL_OK;
 }
 
+static void mark_failed(ggl_ctx* c, int k)
+{
+    if (!c->failed) c->failed = (unsigned char*)calloc(c->K, 1);
+    c->failed[k] = 1;
+}
+
+// GGL_OPT_ISOLATE: a non-finite (or non-positive) bound of instance k marks the instance and is replaced by `repl[k]` (or
+// repl_scalar), so that the batch's schedule is planned for the healthy instances; without the option nothing is touched and
+// the planner reports the non-finite input as it always did.
+static void sanitize_bounds(ggl_ctx* c, double* b, const double* repl, double repl_scale, double repl_scalar = 1.0)
+{
+    if (!c->isolate) return;
+    for (int k = 0; k < c->K; ++k)
+        if (!std::isfinite(b[k]) || !(b[k] > 0.0)) {
+            mark_failed(c, k);
+            b[k] = repl ? repl_scale * repl[k] : repl_scalar;
+        }
+}
+
 static int check_info(ggl_ctx* c, const char* what)
 {
     const bool jac = use_jacobi(c);
     for (int k = 0; k < c->K; ++k) {
         const int v = c->info_h[k];
-        if (jac ? (v < 0) : (v != 0))
+        if (jac ? (v < 0) : (v != 0)) {
+            if (c->isolate) { mark_failed(c, k); continue; }
             return fail(GGL_E_SOLVER, "%s: eigensolver did not converge for instance %d (info=%d)", what, k, v);
+        }
     }
     return GGL_OK;
 }
@@ -1017,6 +1047,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         }
         if (spec) {
             for (int k = 0; k < K; ++k) c->cuse_h[k] = c->spec_c[k] * c->spec_factor;
+            sanitize_bounds(c, c->cuse_h, c->par_h, 4.0);
             for (int h = 0; spec && h < nh; ++h) {
                 const int k0 = k0h[h];
                 const int prc = ns_plan(c->cuse_h + k0, c->par_h + k0, Kh[h], c->coef_h + h * region,
@@ -1126,6 +1157,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             return GGL_OK;
         }
         for (int h = 0; h < nh; ++h) HIPCHK(hipStreamSynchronize(h == 0 ? c->stream : c->streamx[h - 1]));
+        sanitize_bounds(c, c->bounds_h, c->par_h, 4.0);          // (GGL_OPT_ISOLATE: lambda_min(A') = 4 beta stands in)
         // validated bounds: the next step may speculate on them
         for (int k = 0; k < K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
         c->spec_have = true;
@@ -1276,6 +1308,7 @@ static int finish_norms(ggl_ctx* c, int rows, double* out_norms, int group = 0)
             return GGL_SPEC_RETRY;
         }
         if (mine) {
+            sanitize_bounds(c, c->bounds_h, c->par_h, 4.0);
             for (int k = 0; k < c->K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
             if (c->cw_pending) { c->cw_cur ^= 1; c->cw_have = true; }
         }
@@ -1351,6 +1384,7 @@ static int rank_step_impl(ggl_ctx* c)
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
+    sanitize_bounds(c, c->bounds_h, nullptr, 0.0, 1.0);
     std::vector<double> cn(c->bounds_h, c->bounds_h + K);
     c->rank_calls += 1;
     double l0 = (c->rank_hold > 0) ? 1e-10 : c->rank_l0;
@@ -1424,6 +1458,16 @@ static int rank_step_impl(ggl_ctx* c)
             const double t = c->maxdev_h[ktr];
             return !(c->maxdev_h[k] <= check) || !(std::fabs(t - std::nearbyint(t)) <= tol);
         };
+        if (c->isolate) {
+            // an instance with non-finite data is marked and counts as resolved (its L is garbage in its own slot only; the
+            // host parks the slot on the identity problem): it must not drag the batch through the retries and the eigh fallback
+            for (int k = 0; k < K; ++k)
+                if (!std::isfinite(c->maxdev_h[k]) || !std::isfinite(c->maxdev_h[K + k])) {
+                    mark_failed(c, k);
+                    c->maxdev_h[k] = 0.0;
+                    c->maxdev_h[K + k] = 0.0;
+                }
+        }
         bool finite = true, all_ok = true;
         for (int k = 0; k < K; ++k) {
             finite = finite && std::isfinite(c->maxdev_h[k]) && std::isfinite(c->maxdev_h[K + k]);
@@ -1894,6 +1938,99 @@ extern "C" int ggl_get_state_k(ggl_ctx* c, int k, double* Omega, double* Theta, 
     return GGL_OK;
 }
 
+// GGL_OPT_ISOLATE: out[k] = 1 for every instance marked since the ctx was created (non-finite data, eigensolver failure);
+// returns how many, < 0 on error.
+extern "C" int ggl_failed_instances(ggl_ctx* c, int* out)
+{
+    ARGCHK(c, "ctx");
+    int n = 0;
+    for (int k = 0; k < c->K; ++k) {
+        const int f = (c->failed && c->failed[k]) ? 1 : 0;
+        if (out) out[k] = f;
+        n += f;
+    }
+    return n;
+}
+
+// Parks instance k on the identity problem: S_k = Omega_k = Theta_k = I, L_k = X_k = 0 -- a fixed point of every step up to
+// the penalties' shrinkage of zeros -- so that a failed point of a batch goes on harmlessly (finite data, shortest schedules)
+// while the other points finish.  Its mark (ggl_failed_instances) stays.
+extern "C" int ggl_reset_instance(ggl_ctx* c, int k)
+{
+    ARGCHK(c && k >= 0 && k < c->K, "ctx, k");
+    HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
+    const size_t pp = (size_t)c->p * c->p, off = (size_t)k * pp;
+    double* ident[] = {c->S + off, c->Om[0] + off, c->Om[1] + off, c->Theta + off};
+    double* zero[] = {c->L + off, c->X + off, c->W + off};
+    for (double* z : zero) HIPCHK(hipMemsetAsync(z, 0, pp * sizeof(double), c->stream));
+    for (double* a : ident) launch_set_identity(c->stream, a, 1, c->p);
+    HIPCHK(hipGetLastError());
+    c->spec_have = false;
+    c->cw_have = false;
+    c->l_ns = false;
+    return GGL_OK;
+}
+
+// A new ctx holding the m instances idx[0..m) of `src` (their S, Omega, Theta, L, X, masks and dimensions; the options of
+// src; nothing carried from earlier iterations): what is left of a batch of independent problems once a good part of it has
+// converged goes on in a smaller stack instead of dragging the finished points through every product.
+// Device-to-device; src is unchanged and stays valid (its snapshots are the finished points' results).
+extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ctx** out)
+{
+    ARGCHK(src && idx && out, "ctx, idx, out");
+    ARGCHK(m >= 1 && m <= src->K, "1 <= m <= K");
+    for (int i = 0; i < m; ++i) ARGCHK(idx[i] >= 0 && idx[i] < src->K, "instance index");
+    HIPCHK(hipSetDevice(src->device));
+    { int rc_ = drop_prelaunch(src); if (rc_) return rc_; }
+    ggl_ctx* c = nullptr;
+    int rc = ggl_ctx_create(src->device, m, src->p, src->flags & ~GGL_CTX_STREAM_GIVEN, nullptr, &c);
+    if (rc) return rc;
+    c->spec_enable = src->spec_enable; c->spec_factor = src->spec_factor; c->ns_force = src->ns_force;
+    c->ns_degrees = src->ns_degrees; c->theta_flat = src->theta_flat; c->rank_eig = src->rank_eig;
+    c->rank_ns = c->omega_ns && !c->rank_eig; c->ns_parts = src->ns_parts; c->parts_max_tiles = src->parts_max_tiles;
+    c->symm_variant = src->symm_variant; c->spin_wait = src->spin_wait; c->fused_bounds = src->fused_bounds;
+    c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->ns_tol = src->ns_tol;
+    c->cw_warm = src->cw_warm; c->chain_mode = src->chain_mode; c->rank_l0 = src->rank_l0; c->rank_l0_coarse = src->rank_l0_coarse;
+    c->isolate = src->isolate;
+    int* didx = nullptr;
+    hipError_t e = hipMalloc(&didx, m * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(didx, idx, m * sizeof(int), hipMemcpyHostToDevice, src->stream);
+    if (e != hipSuccess) { ggl_ctx_destroy(c); return fail(GGL_E_HIP, "subset: %s", hipGetErrorString(e)); }
+    const size_t pp = (size_t)src->p * src->p;
+    const double* from[] = {src->S, src->Om[src->cur], src->Om[src->cur ^ 1], src->Theta, src->L, src->X};
+    double* to[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X};
+    for (int i = 0; i < 6; ++i) launch_copy_instances(src->stream, to[i], from[i], didx, m, pp, false);
+    c->cur = 0;
+    c->state_symmetric = src->state_symmetric;
+    c->step_latent = src->step_latent;
+    c->nk_valid = false;
+    if (src->has_mask) {
+        e = hipMemcpyAsync(c->mask, src->mask, pp * sizeof(double), hipMemcpyDeviceToDevice, src->stream);
+        c->has_mask = true;
+    }
+    if (e == hipSuccess && src->has_maskK && src->maskK) {
+        e = hipMalloc(&c->maskK, c->n * sizeof(double));
+        if (e == hipSuccess) launch_copy_instances(src->stream, c->maskK, src->maskK, didx, m, pp, false);
+        c->has_maskK = true;
+    }
+    if (e == hipSuccess && src->has_dims && src->inst_pk) {
+        std::vector<int> all(src->K), sub(m);
+        e = hipMemcpyAsync(all.data(), src->inst_pk, src->K * sizeof(int), hipMemcpyDeviceToHost, src->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(src->stream);
+        for (int i = 0; i < m; ++i) sub[i] = all[idx[i]];
+        if (e == hipSuccess) e = hipMalloc(&c->inst_pk, m * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(c->inst_pk, sub.data(), m * sizeof(int), hipMemcpyHostToDevice);
+        c->has_dims = true;
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(src->stream);
+    (void)hipFree(didx);
+    if (e != hipSuccess) { ggl_ctx_destroy(c); return fail(GGL_E_HIP, "subset: %s", hipGetErrorString(e)); }
+    *out = c;
+    return GGL_OK;
+}
+
 extern "C" int ggl_scale_X(ggl_ctx* c, double factor)
 {
     ARGCHK(c, "ctx");
@@ -2046,41 +2183,53 @@ extern "C" int ggl_exit_checks(ggl_ctx* c, int latent, double out[5])
     return GGL_OK;
 }
 
-extern "C" int ggl_snapshot_k(ggl_ctx* c, int k)
+// Snapshot of instance ks of `src` into slot kd of `c` (c == src, kd == ks: ggl_snapshot_k).  The two-ctx form serves a batch
+// that was compacted (ggl_ctx_create_subset): a point that converges in the smaller ctx is snapshotted into the ORIGINAL
+// ctx at its original index, where the selection statistics and ggl_finalize_L run over all points at once.
+extern "C" int ggl_snapshot_from(ggl_ctx* c, int kd, ggl_ctx* src, int ks)
 {
-    ARGCHK(c, "ctx");
-    ARGCHK(k >= 0 && k < c->K, "instance index");
+    ARGCHK(c && src, "ctx");
+    ARGCHK(kd >= 0 && kd < c->K && ks >= 0 && ks < src->K, "instance index");
+    ARGCHK(c->p == src->p && c->device == src->device, "snapshot between ctxs of different dimension / device");
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
+    if (src != c) {
+        int rc_ = drop_prelaunch(src);
+        if (rc_) return rc_;
+        HIPCHK(hipStreamSynchronize(src->stream));          // the copies below run on c's stream
+    }
     const size_t pp = (size_t)c->p * c->p, nb = pp * sizeof(double);
     if (!c->snapT) {
         HIPCHK(hipMalloc(&c->snapT, c->n * sizeof(double)));
         HIPCHK(hipMemsetAsync(c->snapT, 0, c->n * sizeof(double), c->stream));
     }
-    HIPCHK(hipMemcpyAsync(c->snapT + k * pp, c->Theta + k * pp, nb, hipMemcpyDeviceToDevice, c->stream));
-    if (c->step_latent) {
+    HIPCHK(hipMemcpyAsync(c->snapT + kd * pp, src->Theta + ks * pp, nb, hipMemcpyDeviceToDevice, c->stream));
+    if (src->step_latent) {
         if (!c->snapL) {
             HIPCHK(hipMalloc(&c->snapL, c->n * sizeof(double)));
             HIPCHK(hipMemsetAsync(c->snapL, 0, c->n * sizeof(double), c->stream));
         }
-        HIPCHK(hipMemcpyAsync(c->snapL + k * pp, c->L + k * pp, nb, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->snapL + kd * pp, src->L + ks * pp, nb, hipMemcpyDeviceToDevice, c->stream));
         if (!c->snap_ns) {
             c->snap_ns = (unsigned char*)calloc(c->K, 1);
             c->snap_beta = (double*)calloc(c->K, sizeof(double));
         }
-        c->snap_ns[k] = c->l_ns ? 1 : 0;
-        if (c->l_ns) {
+        c->snap_ns[kd] = src->l_ns ? 1 : 0;
+        if (src->l_ns) {
             // the sign iteration's L: keep its input C as well, ggl_finalize_L(which = 1) rebuilds the snapshot from it
             if (!c->snapC) {
                 HIPCHK(hipMalloc(&c->snapC, c->n * sizeof(double)));
                 HIPCHK(hipMemsetAsync(c->snapC, 0, c->n * sizeof(double), c->stream));
             }
-            HIPCHK(hipMemcpyAsync(c->snapC + k * pp, c->Ckeep + k * pp, nb, hipMemcpyDeviceToDevice, c->stream));
-            c->snap_beta[k] = c->Ckeep_beta[k];
+            HIPCHK(hipMemcpyAsync(c->snapC + kd * pp, src->Ckeep + ks * pp, nb, hipMemcpyDeviceToDevice, c->stream));
+            c->snap_beta[kd] = src->Ckeep_beta[ks];
         }
     }
+    if (src != c) HIPCHK(hipStreamSynchronize(c->stream));  // src may go on (or away) right after the call
     return GGL_OK;
 }
+
+extern "C" int ggl_snapshot_k(ggl_ctx* c, int k) { return ggl_snapshot_from(c, k, c, k); }
 
 // The latent component a solve returns (solver/ggl_helper.py:29-36: L = Q diag(max(d - beta, 0)) Q^T, whose null space is
 // exact to rounding -- the reference's callers apply numpy.linalg.matrix_rank to it, helper/model_selection.py:254, :638).

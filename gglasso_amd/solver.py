@@ -252,6 +252,10 @@ class HipEngine:
     def snapshot_k(self, k):
         check(self.lib.ggl_snapshot_k(self.h, int(k)))
 
+    def snapshot_from(self, kd, src, ks):
+        """Snapshot instance ``ks`` of the engine ``src`` (a compacted batch, ``subset``) into slot ``kd`` of this one."""
+        check(self.lib.ggl_snapshot_from(self.h, int(kd), src.h, int(ks)))
+
     def selection_stats(self):
         """(K,4): <S,Theta>, log det Theta (-inf if lambda_min <= 1e-12), count_nonzero(Theta), lambda_min(Theta)
         of every instance's snapshot."""
@@ -275,6 +279,34 @@ class HipEngine:
         out = np.zeros((self.K, 4))
         check(self.lib.ggl_selection_rank(self.h, float(rel_tol), ptr(out)))
         return out
+
+    # -- batches of independent problems: fault isolation and compaction (include/ggl_hip.h, GGL_OPT_ISOLATE) ----------------
+    def failed_instances(self):
+        """(K,) 0/1: instances the library marked (non-finite data, eigensolver failure) since the ctx was created."""
+        import ctypes
+        out = np.zeros(self.K, dtype=np.int32)
+        check(self.lib.ggl_failed_instances(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return out
+
+    def reset_instance(self, k):
+        """Park instance k on the identity problem (S = Omega = Theta = I, L = X = 0)."""
+        check(self.lib.ggl_reset_instance(self.h, int(k)))
+
+    def subset(self, idx):
+        """A NEW engine holding the instances ``idx`` of this one (device to device: S, iterate, masks, dimensions, options);
+        this engine stays valid."""
+        import ctypes
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        h = _lib._vp()
+        check(self.lib.ggl_ctx_create_subset(self.h, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), int(idx.size),
+                                             ctypes.byref(h)))
+        new = object.__new__(type(self))
+        new.lib, new.h, new.K, new.p = self.lib, h, int(idx.size), self.p
+        new.device, new.stream_handle = self.device, None
+        new._norms = np.zeros(5)
+        new._norms_p = ptr(new._norms)
+        new._ptr_cache = {}
+        return new
 
     def finalize_L(self, which=0):
         """Rebuild the L a solve returns from one eigendecomposition of the last L-step's input where that step was the

@@ -117,6 +117,8 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                     * concurrent parts; 2: wherever it can run (any K >= 8, even p).  Same products, same bits
                                     * (tests/test_gpu_chain.py).  Off by default: measured SLOWER on MI355X (headline Omega
                                     * phase 0.89 vs 0.72 ms; DESIGN.md section 8.1, profiles/r3_omega_chain_*.txt)           */
+#define GGL_OPT_ISOLATE 19         /* [0] batches of independent problems: an instance whose data turn non-finite or whose eigensolver
+                                      does not converge is marked (ggl_failed_instances) instead of failing the call */
 #define GGL_OPT_RANK_L0_COARSE 18  /* [8e-5] two-tier L-step (sign iteration, p > GGL_JACOBI_MAX_P): the first pass over the whole batch
                                     * resolves eigenvalues of C down to this distance from the threshold (relative to |C - mu I|);
                                     * the instances whose residual check says that was not enough are continued, from the iterate
@@ -317,6 +319,8 @@ int ggl_ext_batch_step(ggl_ctx *ctx, double rho, const double *lambda1K, const d
  * was: the null space of an L that came out of the sign-iteration L-step (p > GGL_JACOBI_MAX_P) carries that
  * iteration's residual (~1e-12 |L|), far above numpy's tolerance but far below any eigenvalue the prox keeps. */
 int ggl_snapshot_k(ggl_ctx *ctx, int k);
+/* the same from another ctx of the same dimension (a compacted batch, ggl_ctx_create_subset): instance ks of src into slot kd */
+int ggl_snapshot_from(ggl_ctx *ctx, int kd, ggl_ctx *src, int ks);
 int ggl_selection_stats(ggl_ctx *ctx, double *out);
 int ggl_threshold_scan(ggl_ctx *ctx, const double *tau, int ntau, double *out, int *n_eig);
 int ggl_selection_rank(ggl_ctx *ctx, double rel_tol, double *out);
@@ -333,6 +337,16 @@ int ggl_selection_rank(ggl_ctx *ctx, double rel_tol, double *out);
  * GGL_OPT_RANK_EIG, a fallback in the last step, an uploaded L) and nothing was done -- or an error code < 0.
  * ggl_get_snapshot_k: Theta and L (either may be NULL) of instance k's snapshot. */
 int ggl_finalize_L(ggl_ctx *ctx, int which, int *rank_out);
+/* Fault isolation and compaction of a batch of independent problems (the reference's grid walk, helper/model_selection.py:
+ * 208-224, solves its points one by one: a point that fails costs that point, a point that has converged costs nothing more).
+ *   GGL_OPT_ISOLATE       see above; ggl_failed_instances: out[k] = 1 for every instance marked so far (out may be NULL),
+ *                         returns their number
+ *   ggl_reset_instance    parks instance k on the identity problem (S = Omega = Theta = I, L = X = 0): finite, cheapest schedules
+ *   ggl_ctx_create_subset a new ctx with the m instances idx[] of src (S, iterate, masks, dimensions, options; device to
+ *                         device), for the points still iterating once a good part of the batch is done; src stays valid */
+int ggl_failed_instances(ggl_ctx *ctx, int *out);
+int ggl_reset_instance(ggl_ctx *ctx, int k);
+int ggl_ctx_create_subset(ggl_ctx *src, const int *idx, int m, ggl_ctx **out);
 int ggl_get_snapshot_k(ggl_ctx *ctx, int k, double *Theta, double *L);
 /* Objective pieces for measure=True (admm_solver.py:213): out = {sum_k -logdet Omega_k,
  * <Omega,S>, P_val(Theta)} (ggl_helper.py:266-270,162-176). */

@@ -1,0 +1,167 @@
+"""Batches of independent problems (the grids of model selection): a point that fails costs that point, a point that has
+converged costs nothing more.  Reference: the grid walks of helper/model_selection.py:208-224 and :619-633
+solve their points one after the other -- a NaN in one point's data never reaches another point, and a finished point is
+finished.  Here the points share launches, so both properties have to be built: GGL_OPT_ISOLATE / ggl_reset_instance and
+ggl_ctx_create_subset (include/ggl_hip.h)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+@pytest.mark.parametrize("p,latent", [(40, False), (160, False), (160, True)])
+def test_sgl_batch_with_one_poisoned_point(p, latent):
+    """K = 6 single problems in one stack, S of point 2 holds a NaN: that point reports 'solver error', the other five equal
+    their independent solves (LDS-Jacobi route at p = 40, Newton-Schulz route at p = 160, with and without latent variables)."""
+    from gglasso_amd import synth, ADMM_SGL
+    from gglasso_amd.batch import ADMM_SGL_batch
+    K = 6
+    S, _ = synth.make_problem("GGL", K, p, N=2 * p, seed=77 + p)
+    bad = S.copy()
+    bad[2, 3, 5] = bad[2, 5, 3] = np.nan
+    lam = np.linspace(0.05, 0.2, K)
+    kw = dict(tol=1e-8, rtol=1e-8, max_iter=300)
+    if latent:
+        kw.update(latent=True, mu1=0.6)
+    res = ADMM_SGL_batch(bad, lam, **kw)
+    assert res[2][1]['status'] == 'solver error'
+    for k in range(K):
+        if k == 2:
+            continue
+        sol, info = quiet(ADMM_SGL, S[k], lam[k], np.eye(p), **kw)
+        assert res[k][1]['status'] == info['status'] == 'optimal', (k, res[k][1])
+        assert np.all(np.isfinite(res[k][0]['Theta']))
+        assert np.abs(res[k][0]['Theta'] - sol['Theta']).max() <= 1e-9
+        if latent:
+            assert np.abs(res[k][0]['L'] - sol['L']).max() <= 1e-9
+            assert np.linalg.matrix_rank(res[k][0]['L']) == np.linalg.matrix_rank(sol['L'])
+
+
+@pytest.mark.parametrize("reg,p", [("GGL", 150), ("FGL", 40)])
+def test_mgl_batch_step_isolates_a_poisoned_problem(reg, p):
+    """Engine level, G = 3 problems of K = 4 instances in one stack, one entry of problem 1's S is NaN.  With GGL_OPT_ISOLATE the
+    step returns (non-finite sums for problem 1, and) for problems 0 and 2 exactly the sums of the healthy batch; after
+    ggl_reset_instance on problem 1's slots every later step is finite everywhere and the healthy problems' iterates are
+    untouched.  Without the option the same step is an error for the whole batch (p > 128: the planner sees the NaN bound)."""
+    from gglasso_amd import solver, synth
+    G, K = 3, 4
+    S, _ = synth.make_problem(reg, K, p, N=2 * p, seed=5)
+    stack = np.concatenate([S] * G)
+    bad = stack.copy()
+    bad[K + 1, 0, 1] = bad[K + 1, 1, 0] = np.nan
+    eye = np.repeat(np.eye(p)[None], G * K, axis=0)
+    rho, l1, l2 = np.ones(G), np.full(G, 0.05), np.array([0.01, 0.02, 0.03])
+
+    def run(Sx, isolate, steps):
+        eng = solver.HipEngine(Sx, eye, eye, np.zeros_like(eye), options={"isolate": isolate})
+        try:
+            sums = []
+            for it in range(steps):
+                sq = eng.mgl_batch_step(G, rho, l1, l2, reg, False, None, None)
+                sums.append(sq.copy())
+                if it == 0 and isolate and not np.all(np.isfinite(sq[1])):
+                    marked = eng.failed_instances()
+                    for k in range(K):
+                        eng.reset_instance(K + k)
+            return np.array(sums), eng.state(), (marked if isolate else None)
+        finally:
+            eng.close()
+
+    good_sums, good_state, _ = run(stack, 0, 4)
+    sums, state, marked = run(bad, 1, 4)
+    assert not np.all(np.isfinite(sums[0, 1]))
+    if p > 128:
+        assert marked[K + 1] == 1 and marked[:K].sum() == 0 and marked[2 * K:].sum() == 0, marked
+    for g in (0, 2):
+        assert np.allclose(sums[:, g], good_sums[:, g], rtol=1e-9, atol=0)
+        sl = slice(g * K, (g + 1) * K)
+        for nm in ("Omega", "Theta", "X"):
+            assert np.abs(state[nm][sl] - good_state[nm][sl]).max() <= 1e-10, (g, nm)
+    assert np.all(np.isfinite(sums[1:]))                       # the parked problem iterates on the identity problem
+    if p > 128:
+        with pytest.raises(RuntimeError):
+            run(bad, 0, 1)
+
+
+def test_mgl_grid_with_a_poisoned_point_through_the_batch_driver(monkeypatch):
+    """ADMM_MGL_batch: the grid's points share S, so the fault is injected into ONE point's slab of the stack after the upload
+    (a NaN written into its S on the device); the driver must hand back G - 1 good solutions and one 'solver error'."""
+    from gglasso_amd import solver, synth, ADMM_MGL
+    from gglasso_amd.batch import ADMM_MGL_batch
+    K, p, G = 3, 140, 4
+    S, _ = synth.make_problem("GGL", K, p, N=2 * p, seed=9)
+    lam1, lam2 = np.array([0.2, 0.1, 0.07, 0.05]), np.array([0.05, 0.03, 0.02, 0.01])
+    real = solver.HipEngine
+
+    class Poisoned(real):
+        def __init__(self, Sx, *a, **kw):
+            Sx = np.array(np.broadcast_to(Sx, (G, K, p, p)))          # materialise the shared stack, poison point 2
+            Sx[2, 1, 4, 7] = Sx[2, 1, 7, 4] = np.nan
+            super().__init__(Sx, *a, **kw)
+
+    monkeypatch.setattr(solver, "ENGINE", Poisoned)
+    res = ADMM_MGL_batch(S, lam1, lam2, "GGL", tol=1e-8, rtol=1e-8, max_iter=400)
+    monkeypatch.setattr(solver, "ENGINE", real)
+    assert [r[1]['status'] for r in res] == ['optimal', 'optimal', 'solver error', 'optimal']
+    Om0 = np.repeat(np.eye(p)[None], K, axis=0)
+    for g in (0, 1, 3):
+        sol, info = quiet(ADMM_MGL, S, lam1[g], lam2[g], "GGL", Om0, tol=1e-8, rtol=1e-8, max_iter=400)
+        assert np.abs(res[g][0]['Theta'] - sol['Theta']).max() <= 1e-9, g
+
+
+@pytest.mark.parametrize("p,latent", [(60, False), (200, False), (200, True)])
+def test_sgl_batch_compaction_equals_the_uncompacted_batch(p, latent):
+    """A lambda1 path whose points need very different iteration counts, with and without compaction: same status and iteration
+    count per point, same solutions (1e-9: a step in a fresh ctx is planned from its own bounds, not from carried ones), and the
+    compacted run carries its points for far fewer batch iterations."""
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_SGL_batch
+    S, _ = synth.make_problem("GGL", 1, p, N=2 * p, seed=21)
+    lam = np.logspace(0, -2, 12)
+    kw = dict(tol=1e-7, rtol=1e-7, max_iter=500, selection_stats=True)
+    if latent:
+        kw.update(latent=True, mu1=np.linspace(0.4, 1.5, 12))
+    a = ADMM_SGL_batch(S[0], lam, compact=False, **kw)
+    b = ADMM_SGL_batch(S[0], lam, compact=True, **kw)
+    its = np.array([r[1]['iterations'] for r in a])
+    assert its.max() >= 2 * its.min() and np.array_equal(its, [r[1]['iterations'] for r in b]), its
+    for k in range(len(lam)):
+        assert a[k][1]['status'] == b[k][1]['status'] == 'optimal'
+        for nm in a[k][0]:
+            assert np.abs(a[k][0][nm] - b[k][0][nm]).max() <= 1e-9, (k, nm)
+        for nm in ('Sdot', 'logdet', 'nnz'):
+            assert np.isclose(a[k][1]['selection'][nm], b[k][1]['selection'][nm], rtol=1e-9), (k, nm)
+        if latent:
+            assert a[k][1]['selection']['rank'] == b[k][1]['selection']['rank'] == np.linalg.matrix_rank(b[k][0]['L'])
+    carried_a = sum(r[1]['carried'] for r in a)
+    carried_b = sum(r[1]['carried'] for r in b)
+    assert carried_a == len(lam) * its.max()
+    assert carried_b <= its.sum() * 1.35 and carried_b < carried_a, (carried_a, carried_b, its.sum())
+
+
+def test_mgl_batch_compaction_equals_the_uncompacted_batch():
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_MGL_batch
+    K, p = 3, 150
+    S, _ = synth.make_problem("FGL", K, p, N=2 * p, seed=23)
+    lam1 = np.logspace(-0.3, -1.7, 8)
+    lam2 = np.full(8, 0.02)
+    kw = dict(tol=1e-7, rtol=1e-7, max_iter=500, latent=True, mu1=np.array([0.8, 0.6, 0.7]), selection_stats=True)
+    a = ADMM_MGL_batch(S, lam1, lam2, "FGL", compact=False, **kw)
+    b = ADMM_MGL_batch(S, lam1, lam2, "FGL", compact=True, **kw)
+    its = np.array([r[1]['iterations'] for r in a])
+    assert np.array_equal(its, [r[1]['iterations'] for r in b]), (its, [r[1]['iterations'] for r in b])
+    for g in range(8):
+        for nm in ('Omega', 'Theta', 'L', 'X'):
+            assert np.abs(a[g][0][nm] - b[g][0][nm]).max() <= 1e-9, (g, nm)
+        assert np.array_equal(a[g][1]['rank'], b[g][1]['rank'])
+        assert np.allclose(a[g][1]['selection'], b[g][1]['selection'], rtol=1e-9)
+    assert sum(r[1]['carried'] for r in b) < sum(r[1]['carried'] for r in a)
