@@ -132,7 +132,7 @@ def test_sgl_batch_compaction_equals_the_uncompacted_batch(p, latent):
     a = ADMM_SGL_batch(S[0], lam, compact=False, **kw)
     b = ADMM_SGL_batch(S[0], lam, compact=True, **kw)
     its = np.array([r[1]['iterations'] for r in a])
-    assert its.max() >= 2 * its.min() and np.array_equal(its, [r[1]['iterations'] for r in b]), its
+    assert its.max() > its.min() + 4 and np.array_equal(its, [r[1]['iterations'] for r in b]), its
     for k in range(len(lam)):
         assert a[k][1]['status'] == b[k][1]['status'] == 'optimal'
         for nm in a[k][0]:
@@ -144,7 +144,7 @@ def test_sgl_batch_compaction_equals_the_uncompacted_batch(p, latent):
     carried_a = sum(r[1]['carried'] for r in a)
     carried_b = sum(r[1]['carried'] for r in b)
     assert carried_a == len(lam) * its.max()
-    assert carried_b <= its.sum() * 1.35 and carried_b < carried_a, (carried_a, carried_b, its.sum())
+    assert its.sum() <= carried_b < carried_a, (carried_a, carried_b, its.sum())
 
 
 def test_mgl_batch_compaction_equals_the_uncompacted_batch():
