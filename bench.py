@@ -51,6 +51,10 @@ WORKLOADS = {
     "ggl_K8_p500": ("GGL", 8, 500, False, 0.05, 0.01, 1239),
     "ggl_K4_p500": ("GGL", 4, 500, False, 0.05, 0.01, 1239),
     "ggl_K32_p1000": ("GGL", 32, 1000, False, 0.05, 0.01, 1238),   # per-GPU slab of C5 at 8 GPUs
+    # p <= 128: the one-workgroup-per-matrix LDS Jacobi eigensolver (csrc/eig_jacobi.hip), the north_star's small-p kernel
+    "ggl_K64_p100": ("GGL", 64, 100, False, 0.05, 0.01, 1241),
+    "ggl_K256_p64": ("GGL", 256, 64, False, 0.05, 0.01, 1242),
+    "ggl_K32_p128": ("GGL", 32, 128, False, 0.05, 0.01, 1243),
 }
 
 # product-kernel instances of csrc/gemm_sym.hip by the variant number ggl_ns_stats reports

@@ -105,6 +105,7 @@ _SIGNATURES = {
     "ggl_dev_ns_schedule_tol": ([_d, _i, _d, _i, ctypes.POINTER(_i), _dp, ctypes.POINTER(_i)], _i),
     "ggl_ns_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_rank_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
+    "ggl_eig_info": ([_vp, ctypes.POINTER(_i)], _i),
     "ggl_last_dispatch": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_eigh_batched": ([_i, _i, _dp, _dp, _dp, _i], _i),
     "ggl_phiplus": ([_i, _i, _dp, _dp, _dp, _dp], _i),

@@ -239,8 +239,14 @@ static bool use_jacobi(const ggl_ctx* c)
 
 static bool use_ns(int eig, int p)
 {
+    // GGL_EIG_AUTO: the matrix-function (Newton-Schulz) Omega- / L-step from p = GGL_NS_MIN_P + 1 on.  Measured in round 4
+    // (profiles/r4_jacobi_kernel_measured.txt, tools/bench_jacobi.py): the one-workgroup-per-matrix LDS Jacobi kernel takes
+    // ~2.4 us per round-robin STEP whatever K (shuffle-reduction latency + a 1024-thread barrier; ~10 sweeps of p - 1 steps:
+    // 2.5 ms at p = 100, 3.6 ms at p = 128), while the 7-8 FP64-MFMA products of the matrix-function route take 45-115 us from
+    // p = 16 to p = 128 -- 3x faster at p = 16, 20x at p = 64, 35-45x at p = 128; the two meet at p = 8 (60 us), and Jacobi wins
+    // below (22 us at p = 4).  Rounds 1-3 sent every p <= GGL_JACOBI_MAX_P to Jacobi, unmeasured.
     if (eig == GGL_EIG_NEWTON_SCHULZ) return true;
-    return eig == GGL_EIG_AUTO && !jacobi_fits(p);
+    return eig == GGL_EIG_AUTO && p > GGL_NS_MIN_P;
 }
 
 extern "C" int ggl_version(void) { return GGL_VERSION; }
@@ -2072,6 +2078,15 @@ extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[16])
     out[13] = c->last_variant;
     out[14] = c->ns_eigh_fallbacks;
     out[15] = c->pre_dropped;
+    return GGL_OK;
+}
+
+// Per-instance status word of the last eigensolver launch as the last ADMM step fetched it: the LDS Jacobi kernel reports the
+// sweeps it took (-1: not converged within its limit), rocSOLVER its info (0 = converged).
+extern "C" int ggl_eig_info(ggl_ctx* c, int* out)
+{
+    ARGCHK(c && out, "ctx, out");
+    for (int k = 0; k < c->K; ++k) out[k] = c->info_h[k];
     return GGL_OK;
 }
 

@@ -431,6 +431,13 @@ class HipEngine:
         check(self.lib.ggl_rank_stats(self.h, out))
         return dict(zip(("calls", "continued_calls", "continued_instances", "eigh_fallbacks"), (int(v) for v in out)))
 
+    def eig_info(self):
+        """(K,) sweeps of the LDS Jacobi kernel in the last step (-1: not converged), or rocSOLVER's info."""
+        import ctypes
+        out = np.zeros(self.K, dtype=np.int32)
+        check(self.lib.ggl_eig_info(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return out
+
     def last_dispatch(self):
         import ctypes
         out = (ctypes.c_longlong * 4)()

@@ -37,14 +37,16 @@ extern "C" {
 #define GGL_REG_FGL 2       /* prox_phi_fgl (ggl_helper.py:131-134) */
 
 /* eigensolver selector (ctx flags, low byte) */
-#define GGL_EIG_AUTO 0      /* p <= GGL_JACOBI_MAX_P: LDS Jacobi.  Larger p: Newton-Schulz for the Omega-step,
-                             * rocSOLVER where eigenvalues are needed (L-step, exit checks). */
+#define GGL_EIG_AUTO 0      /* p <= GGL_NS_MIN_P: LDS Jacobi for everything.  Larger p: Newton-Schulz matrix functions for the
+                             * Omega-step and the L-step; where eigenvalues themselves are needed (exit checks, KKT, objective,
+                             * selection statistics, the final L, fallbacks) LDS Jacobi up to GGL_JACOBI_MAX_P, rocSOLVER above. */
 #define GGL_EIG_JACOBI 1    /* hand-written one-workgroup-per-matrix Jacobi (p <= GGL_JACOBI_MAX_P) */
 #define GGL_EIG_ROCSOLVER 2 /* rocsolver_dsyevd_strided_batched */
 #define GGL_EIG_NEWTON_SCHULZ 3 /* Omega-step without an eigendecomposition: Omega = (W + sqrt(W^2+4 beta I))/2
                                  * by scaled Newton-Schulz products on the FP64 matrix cores (any p).
                                  * Steps that need eigenvalues themselves (L-step, exit checks) use AUTO. */
 #define GGL_JACOBI_MAX_P 128
+#define GGL_NS_MIN_P 8        /* GGL_EIG_AUTO: Omega- / L-step by Newton-Schulz matrix functions for p > this (measured crossover) */
 /* Newton-Schulz controls in the bits above the selector (ctx flags and the eig_method argument of the stateless
  * ggl_phiplus_matrix / ggl_rank_matrix): product mode 0 auto (by condition number), 1 all-symmetric products,
  * 2 stable unsymmetrised products; highest step degree 3, 5 or 9 (0 = 9).  Used by the parity tests to reach every
@@ -390,6 +392,9 @@ int ggl_rank_stats(ggl_ctx *ctx, long long out[4]);
  * in one thread; 100*KQ+NW per-element kernel with the K-column over NW waves: 404, 408, 808, 816, 1616; 2000+tile FGL
  * Condat tiles), eigendecompositions ggl_finalize_L ran on this ctx }.  The parity tests assert the dispatch with it. */
 int ggl_last_dispatch(ggl_ctx *ctx, long long out[4]);
+/* per-instance status of the last eigensolver launch a step fetched: sweeps of the LDS Jacobi kernel (-1: not converged) or
+ * rocSOLVER's info */
+int ggl_eig_info(ggl_ctx *ctx, int *out);
 
 /* ---- kernel-level test / measurement entry points (not used by the solvers) --------------------
  * ggl_dev_symm: one launch of the symmetric-product kernel on host data (kernel unit test; variant < 0 = by size).
