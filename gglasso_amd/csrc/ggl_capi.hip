@@ -173,6 +173,11 @@ struct ggl_ctx {
     bool rank_eig = false;                           // GGL_OPT_RANK_EIG: force the eigendecomposition route
     double rank_l0 = 1e-6;                           // resolution of the scaling schedule
     double rank_l0_coarse = 8e-5;                    // two-tier L-step: resolution of the first pass over the whole batch (0: one tier)
+    // deflation of the eigenvalues next to the threshold after a coarse pass (deflate.hip; GGL_OPT_RANK_DEFLATE)
+    bool rank_deflate = true;
+    double rank_l0_deflate = 2e-3;                   // resolution of the coarse pass the deflation follows
+    double *defl_G = nullptr, *defl_work = nullptr, *defl_meta = nullptr, *defl_meta_h = nullptr;   // lazy
+    long long rank_deflated_calls = 0, rank_deflated_instances = 0;
     int* rank_idx = nullptr;                         // [K] instances of the compact continuation batch (device), lazy
     int* rank_idx_h = nullptr;                       // ... pinned mirror
     long long rank_continued = 0, rank_cont_instances = 0;
@@ -390,6 +395,11 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_CW_WARM: c->cw_warm = v != 0.0; break;
         case GGL_OPT_CHAIN: c->chain_mode = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
         case GGL_OPT_ISOLATE: c->isolate = v != 0.0; break;
+        case GGL_OPT_RANK_DEFLATE: c->rank_deflate = v != 0.0; break;
+        case GGL_OPT_RANK_L0_DEFLATE:
+            if (!(v > 0.0) || v > 0.1) return fail(GGL_E_ARG, "bad argument: GGL_OPT_RANK_L0_DEFLATE is in (0, 0.1]");
+            c->rank_l0_deflate = v;
+            break;
         case GGL_OPT_RANK_L0_COARSE:
             if (!(v >= 0.0) || v > 0.1) return fail(GGL_E_ARG, "bad argument: GGL_OPT_RANK_L0_COARSE is in [0, 0.1]");
             c->rank_l0_coarse = v;
@@ -434,6 +444,8 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_CHAIN: *value = c->chain_mode; break;
         case GGL_OPT_RANK_L0_COARSE: *value = c->rank_l0_coarse; break;
         case GGL_OPT_ISOLATE: *value = c->isolate; break;
+        case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
+        case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
     }
     return GGL_OK;
@@ -510,7 +522,8 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
                       c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
                       c->nsT, c->nsNX, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->snapL, c->cuse, c->Lam[0],
-                      c->Lam[1], c->X1, c->cwvec[0], c->cwvec[1], c->Ckeep, c->snapC};
+                      c->Lam[1], c->X1, c->cwvec[0], c->cwvec[1], c->Ckeep, c->snapC, c->defl_G, c->defl_work, c->defl_meta};
+    if (c->defl_meta_h) (void)hipHostFree(c->defl_meta_h);
     free(c->Ckeep_beta);
     free(c->failed);
     free(c->snap_beta);
@@ -1403,11 +1416,16 @@ static int rank_step_impl(ggl_ctx* c)
     // the schedule for where an eigenvalue at the FINE resolution would be by now (rank_ns_image).  Same guarantee as the
     // one-tier run (eigenvalues at least rank_l0 |B| away from the threshold are resolved, the check catches the others).
     const double l_fine = l0;
-    const bool two_tier = c->rank_l0_coarse > l_fine && K >= 4;
+    // Deflation (deflate.hip): the first pass only has to resolve the eigenvalues farther than rank_l0_deflate |B| from the
+    // threshold (22 products at 1e-3 instead of 28-32); the one or two per instance that are closer are found as the range
+    // of I - X^2 and corrected exactly.  An instance whose residual has more than DEFL_Q0 - 1 directions, whose probes do not
+    // vanish or whose trace does not come out an integer goes on with the others that need it as the compact continuation.
+    const bool deflate = c->rank_deflate && c->rank_l0_deflate > l_fine && c->p <= deflate_max_p() && c->rank_hold == 0;
+    const bool two_tier = deflate || (c->rank_l0_coarse > l_fine && K >= 4);
     // resolutions of the full-batch passes, in order: [coarse (+ continuation of the instances it left),] fine, 1e-10
     double stages[3];
     int nstage = 0;
-    if (two_tier) stages[nstage++] = c->rank_l0_coarse;
+    if (two_tier) stages[nstage++] = deflate ? c->rank_l0_deflate : c->rank_l0_coarse;
     stages[nstage++] = l_fine;
     if (l_fine > 1e-10) stages[nstage++] = 1e-10;
     const size_t pp = (size_t)c->p * c->p;
@@ -1454,12 +1472,49 @@ static int rank_step_impl(ggl_ctx* c)
         // the two checks of the result (newton_schulz.hip: rank_check, rank_trace_tolerance): the entrywise residual of the
         // last step, and the distance of trace(X_last) = trace(P2) - p from an integer
         launch_trace(c->stream, c->nsYP[1], K, c->p, (double)c->p, c->maxdev + K);
+        const bool defl_stage = coarse && deflate;
+        if (defl_stage) {
+            if (!c->defl_G) {
+                // fixed Gaussian test matrix [DEFL_Q][p] (a deterministic stream: the same solve gives the same bits)
+                std::vector<double> g((size_t)DEFL_Q * c->p);
+                unsigned long long s = 0x9E3779B97F4A7C15ull;
+                auto u01 = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return ((double)(s >> 11) + 0.5) / 9007199254740992.0; };
+                for (size_t i = 0; i < g.size(); i += 2) {
+                    const double r = std::sqrt(-2.0 * std::log(u01())), a = 6.283185307179586 * u01();
+                    g[i] = r * std::cos(a);
+                    if (i + 1 < g.size()) g[i + 1] = r * std::sin(a);
+                }
+                HIPCHK(hipMalloc(&c->defl_G, g.size() * sizeof(double)));
+                HIPCHK(hipMemcpy(c->defl_G, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
+                HIPCHK(hipMalloc(&c->defl_work, 4 * (size_t)K * DEFL_Q * c->p * sizeof(double)));
+                HIPCHK(hipMalloc(&c->defl_meta, 4 * (size_t)K * sizeof(double)));
+                HIPCHK(hipHostMalloc(&c->defl_meta_h, 4 * (size_t)K * sizeof(double)));
+            }
+            const double* Xl = ((plan.steps - 1) & 1) ? c->nsYP[0] + c->n : c->nsYP[0];
+            launch_deflate(c->stream, Xl, c->W, c->par + 2 * (size_t)K, c->L, c->defl_G, c->defl_work, c->defl_meta, K, c->p, 1e-11, 1e-10);
+        }
         CopySegs dn;
         dn.add(c->maxdev_h, c->maxdev, 2 * K * sizeof(double));
+        if (defl_stage) dn.add(c->defl_meta_h, c->defl_meta, 4 * (size_t)K * sizeof(double));
         launch_copy_small(c->stream, dn);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
-        const double ttol = rank_trace_tolerance(l0, c->p);
+        if (defl_stage) {
+            // after the deflation the entrywise residual of the coarse pass says nothing (it is what was deflated); an instance
+            // is resolved when its residual had at most DEFL_Q0 - 1 directions, the probes found nothing outside them (noise
+            // is ~1e-13) and trace(X) + trace(D) is an integer.  Folded into the two numbers the generic check reads.
+            int nd = 0;
+            for (int k = 0; k < K; ++k) {
+                const double* m = c->defl_meta_h + 4 * (size_t)k;
+                const bool ok = m[0] < DEFL_Q0 && m[1] <= 1e-10 && std::isfinite(m[2]);
+                c->maxdev_h[k] = ok ? 0.0 : (std::isfinite(c->maxdev_h[k]) ? 1.0 : c->maxdev_h[k]);
+                c->maxdev_h[K + k] += m[2];
+                nd += m[0] > 0 ? 1 : 0;
+            }
+            c->rank_deflated_calls += 1;
+            c->rank_deflated_instances += nd;
+        }
+        const double ttol = defl_stage ? 1e-10 : rank_trace_tolerance(l0, c->p);
         auto unresolved = [&](int k, int ktr, double check, double tol) {
             const double t = c->maxdev_h[ktr];
             return !(c->maxdev_h[k] <= check) || !(std::fabs(t - std::nearbyint(t)) <= tol);
@@ -1998,7 +2053,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->symm_variant = src->symm_variant; c->spin_wait = src->spin_wait; c->fused_bounds = src->fused_bounds;
     c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->ns_tol = src->ns_tol;
     c->cw_warm = src->cw_warm; c->chain_mode = src->chain_mode; c->rank_l0 = src->rank_l0; c->rank_l0_coarse = src->rank_l0_coarse;
-    c->isolate = src->isolate;
+    c->isolate = src->isolate; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
     int* didx = nullptr;
     hipError_t e = hipMalloc(&didx, m * sizeof(int));
     if (e == hipSuccess) e = hipMemcpyAsync(didx, idx, m * sizeof(int), hipMemcpyHostToDevice, src->stream);
@@ -2099,6 +2154,15 @@ extern "C" int ggl_last_dispatch(ggl_ctx* c, long long out[4])
     out[1] = c->last_variant;
     out[2] = theta_last_kernel();
     out[3] = c->finalize_calls;
+    return GGL_OK;
+}
+
+// L-step calls whose first pass was followed by the deflation, and the instances that had something to deflate
+extern "C" int ggl_deflate_stats(ggl_ctx* c, long long out[2])
+{
+    ARGCHK(c && out, "ctx, out");
+    out[0] = c->rank_deflated_calls;
+    out[1] = c->rank_deflated_instances;
     return GGL_OK;
 }
 
@@ -3702,18 +3766,39 @@ extern "C" int ggl_phiplus_matrix(int K, int p, const double* beta, const double
     return eig_common(K, p, W, beta, nullptr, nullptr, out, MAP_PHIPLUS, eig_method & 0xff);
 }
 
+static int rank_matrix_impl(int K, int p, const double* beta, const double* C, double* out, int eig_method, double l0_coarse,
+                            double l0_deflate, long long* stats, int nstats);
+
+// l0_coarse >= 0: the two-tier iteration at that first-pass resolution, WITHOUT the deflation (0: one tier); < 0: the ctx
+// defaults (deflation after a first pass at GGL_OPT_RANK_L0_DEFLATE)
 extern "C" int ggl_rank_matrix_ex(int K, int p, const double* beta, const double* C, double* out, int eig_method,
                                   double l0_coarse, long long stats[6])
 {
+    return rank_matrix_impl(K, p, beta, C, out, eig_method, l0_coarse, l0_coarse >= 0.0 ? 0.0 : -1.0, stats, 6);
+}
+
+// the deflating L-step with its first-pass resolution exposed (<= 0: the default); stats[8] = the six of ggl_rank_matrix_ex +
+// { calls followed by the deflation, instances that had directions to deflate }
+extern "C" int ggl_rank_matrix_deflate(int K, int p, const double* beta, const double* C, double* out, int eig_method,
+                                       double l0_deflate, long long stats[8])
+{
+    return rank_matrix_impl(K, p, beta, C, out, eig_method, -1.0, l0_deflate > 0.0 ? l0_deflate : -1.0, stats, 8);
+}
+
+static int rank_matrix_impl(int K, int p, const double* beta, const double* C, double* out, int eig_method, double l0_coarse,
+                            double l0_deflate, long long* stats, int nstats)
+{
     ARGCHK(beta && out && C, "beta, C, out");
     ARGCHK(K >= 1 && p >= 1, "K, p");
-    if (stats) for (int i = 0; i < 6; ++i) stats[i] = 0;
+    if (stats) for (int i = 0; i < nstats; ++i) stats[i] = 0;
     if (use_ns(eig_method & 0xff, p)) {
         // the L-step of a scratch ctx: C into the work stack, beta into the mu/rho parameter slot
         ggl_ctx* c = nullptr;
         int rc = ggl_ctx_create(0, K, p, (eig_method & ~0xff) | GGL_EIG_NEWTON_SCHULZ, nullptr, &c);
         if (rc) return rc;
         if (l0_coarse >= 0.0) c->rank_l0_coarse = l0_coarse;
+        if (l0_deflate == 0.0) c->rank_deflate = false;
+        else if (l0_deflate > 0.0) c->rank_l0_deflate = l0_deflate;
         hipError_t e = hipMemcpyAsync(c->W, C, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             rc = upload_par(c, 2, beta, 0.0, 1.0);
@@ -3724,6 +3809,7 @@ extern "C" int ggl_rank_matrix_ex(int K, int p, const double* beta, const double
         if (stats) {
             stats[0] = c->rank_calls; stats[1] = c->rank_continued; stats[2] = c->rank_cont_instances;
             stats[3] = c->rank_fallbacks; stats[4] = c->rank_retries; stats[5] = c->rank_launches;
+            if (nstats >= 8) { stats[6] = c->rank_deflated_calls; stats[7] = c->rank_deflated_instances; }
         }
         ggl_ctx_destroy(c);
         if (e != hipSuccess) return fail(GGL_E_HIP, "ggl_rank_matrix: %s", hipGetErrorString(e));

@@ -151,6 +151,12 @@ void launch_ext_prox_od(hipStream_t st, double* out, const double* A, const doub
 // ---- eig_jacobi.hip ---------------------------------------------------------------------
 bool jacobi_fits(int p);
 int theta_last_kernel();
+// deflate.hip: L-step, the eigenvalues next to the threshold deflated after a coarse sign iteration
+static constexpr int DEFL_Q = 8;      // columns of the range finder: DEFL_Q0 for the basis + probes
+static constexpr int DEFL_Q0 = 6;
+void launch_deflate(hipStream_t st, const double* X, const double* C, const double* muK, double* L, const double* G, double* work,
+                    double* meta, int K, int p, double tau1, double tau2);
+int deflate_max_p();
 // gemm_i8.hip: error-free split products on the INT8 matrix cores
 void launch_slice_i8(hipStream_t st, const double* A, const double* scaleK, int8_t* out, int K, int p, int S, int* flag,
                      size_t sstride = 0);

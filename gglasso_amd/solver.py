@@ -429,7 +429,11 @@ class HipEngine:
         import ctypes
         out = (ctypes.c_longlong * 4)()
         check(self.lib.ggl_rank_stats(self.h, out))
-        return dict(zip(("calls", "continued_calls", "continued_instances", "eigh_fallbacks"), (int(v) for v in out)))
+        st = dict(zip(("calls", "continued_calls", "continued_instances", "eigh_fallbacks"), (int(v) for v in out)))
+        d = (ctypes.c_longlong * 2)()
+        check(self.lib.ggl_deflate_stats(self.h, d))
+        st["deflated_calls"], st["deflated_instances"] = int(d[0]), int(d[1])
+        return st
 
     def eig_info(self):
         """(K,) sweeps of the LDS Jacobi kernel in the last step (-1: not converged), or rocSOLVER's info."""

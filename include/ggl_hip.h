@@ -119,6 +119,9 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                     * concurrent parts; 2: wherever it can run (any K >= 8, even p).  Same products, same bits
                                     * (tests/test_gpu_chain.py).  Off by default: measured SLOWER on MI355X (headline Omega
                                     * phase 0.89 vs 0.72 ms; DESIGN.md section 8.1, profiles/r3_omega_chain_*.txt)           */
+#define GGL_OPT_RANK_DEFLATE 20    /* [1] L-step (sign iteration): after a first pass at GGL_OPT_RANK_L0_DEFLATE the eigenvalues next to the
+                                      threshold are deflated (range of I - X^2, exact small problem) instead of iterated down */
+#define GGL_OPT_RANK_L0_DEFLATE 21 /* [2e-3] resolution of that first pass */
 #define GGL_OPT_ISOLATE 19         /* [0] batches of independent problems: an instance whose data turn non-finite or whose eigensolver
                                       does not converge is marked (ggl_failed_instances) instead of failing the call */
 #define GGL_OPT_RANK_L0_COARSE 18  /* [8e-5] two-tier L-step (sign iteration, p > GGL_JACOBI_MAX_P): the first pass over the whole batch
@@ -387,6 +390,8 @@ int ggl_ns_stats(ggl_ctx *ctx, long long out[16]);
 /* L-step (sign iteration): out = { calls, calls whose first pass was continued on a compact sub-batch, instances continued in
  * total, calls that fell back to the eigendecomposition } */
 int ggl_rank_stats(ggl_ctx *ctx, long long out[4]);
+/* out = { L-step calls whose first pass was followed by the deflation, instances that had directions to deflate } */
+int ggl_deflate_stats(ggl_ctx *ctx, long long out[2]);
 /* What ran last: out = { concurrent parts and product-kernel variant of the last matrix-function step (as in ggl_ns_stats),
  * code of the Theta kernel of the process's last Theta-step (0 GGL tile pairs; 100+KMAX per-element kernel with the K-column
  * in one thread; 100*KQ+NW per-element kernel with the K-column over NW waves: 404, 408, 808, 816, 1616; 2000+tile FGL
@@ -466,6 +471,11 @@ int ggl_rank_matrix(int K, int p, const double *beta, const double *C, double *o
  * retries of the whole batch, product launches } */
 int ggl_rank_matrix_ex(int K, int p, const double *beta, const double *C, double *out, int eig_method, double l0_coarse,
                        long long stats[6]);
+/* the same with the DEFLATING L-step (a first pass at l0_deflate, <= 0: the default GGL_OPT_RANK_L0_DEFLATE, then the
+ * eigenvalues next to the threshold as the range of I - X^2; csrc/deflate.hip); ggl_rank_matrix_ex with l0_coarse >= 0 runs
+ * the two-tier iteration without it.  stats[8] = the six above + { calls followed by the deflation, instances deflated } */
+int ggl_rank_matrix_deflate(int K, int p, const double *beta, const double *C, double *out, int eig_method, double l0_deflate,
+                            long long stats[8]);
 /* prox_od_1norm(A,l), ggl_helper.py:16-27; lam_pp NULL => scalar lam. */
 int ggl_prox_od_1norm(int p, const double *A, double lam, const double *lam_pp, double *out);
 /* prox_p(X,l1,l2,reg), ggl_helper.py:190-207 (reg = GGL_REG_GGL | GGL_REG_FGL). */

@@ -536,3 +536,48 @@ def test_int8_omega_step_chain_against_eigh(p, K):
     assert int(out[2]) == 0 and int(out[1]) in (7, 8)
     assert np.abs(Om - ref).max() <= 5e-10 * np.abs(ref).max()
     assert np.array_equal(Om, Om.transpose(0, 2, 1))
+
+
+def _rank_deflate(W, beta, l0_deflate=-1.0):
+    import ctypes
+    from gglasso_amd import _lib
+    from gglasso_amd._lib import ptr
+    lib = _lib.load()
+    K, p, _ = W.shape
+    b = np.ascontiguousarray(np.broadcast_to(np.asarray(beta, dtype=np.float64), (K,)))
+    out = np.empty_like(W)
+    st = (ctypes.c_longlong * 8)()
+    _lib.check(lib.ggl_rank_matrix_deflate(K, p, ptr(b), ptr(np.ascontiguousarray(W)), ptr(out), _lib.eig_flags(3, 0, 0),
+                                           float(l0_deflate), st))
+    return out, dict(zip(("calls", "continued_calls", "continued_instances", "eigh_fallbacks", "retries", "launches",
+                          "deflated_calls", "deflated_instances"), (int(v) for v in st)))
+
+
+@pytest.mark.parametrize("p", [200, 333, 500])
+def test_rank_deflation_of_the_eigenvalues_next_to_the_threshold(p):
+    """prox_rank_norm (ggl_helper.py:29-36) with the deflating L-step (csrc/deflate.hip): after a first pass at 2e-3 the
+    eigenvalues closer than that to the threshold -- none, one, three on both sides, one at 1e-9 of the norm bound -- are
+    found as the range of I - X^2 and corrected exactly: the eigendecomposition's result at ~1e-15 with FEWER products than the
+    two-tier iteration, nothing continued.  Seven of them exceed the six columns of the basis: that instance (and only it)
+    goes on as the compact continuation."""
+    rng = np.random.default_rng(1700 + p)
+    K, beta = 10, 0.4
+    gaps = {1: [4e-4], 3: [1e-3, -3e-4, 2e-5], 4: [1e-9], 6: [-1.5e-3, 6e-7], 8: [7e-4, -2e-6]}
+    W = np.stack([_with_gaps(rng, p, beta, gaps.get(k, [])) for k in range(K)])
+    ref = orc.rank_stack(W, np.full(K, beta))
+    tol = 2e-13 * p
+    out, st = _rank_deflate(W, beta)
+    assert np.abs(out - ref).max() <= tol, np.abs(out - ref).reshape(K, -1).max(axis=1)
+    assert np.array_equal(out, out.transpose(0, 2, 1))
+    assert st["deflated_calls"] == 1 and st["deflated_instances"] >= 5, st
+    assert st["continued_calls"] == 0 and st["eigh_fallbacks"] == 0 and st["retries"] == 0, st
+    two, st2 = _rank_ex(W, beta, 8e-5)
+    assert st["launches"] < st2["launches"], (st, st2)
+    for k in range(K):
+        assert np.linalg.matrix_rank(out[k], hermitian=True, tol=1e-9) == np.linalg.matrix_rank(ref[k], hermitian=True, tol=1e-9)
+    # more directions than the basis holds: the continuation takes that instance
+    Wmany = W.copy()
+    Wmany[2] = _with_gaps(rng, p, beta, [3e-4, -2e-4, 1e-4, -5e-5, 2e-5, 6e-4, -8e-4])
+    out, st = _rank_deflate(Wmany, beta)
+    assert np.abs(out - orc.rank_stack(Wmany, np.full(K, beta))).max() <= tol
+    assert st["continued_calls"] == 1 and st["continued_instances"] == 1 and st["eigh_fallbacks"] == 0, st
