@@ -298,6 +298,8 @@ __global__ __launch_bounds__(256) void k_defl_small(const double* __restrict__ V
 __global__ __launch_bounds__(256) void k_defl_update(double* __restrict__ L, const double* __restrict__ V,
                                                      const double* __restrict__ Wm, const double* __restrict__ meta, int p)
 {
+#pragma clang fp contract(off)      // (hipcc contracts by default, also through __dmul_rn / __dadd_rn: an fma here would round
+                                    // w_i v_j + v_i w_j differently from w_j v_i + v_j w_i -- one ulp of asymmetry in L)
     const int k = blockIdx.y;
     const int r = (int)meta[k * 4 + 0];
     if (r == 0) return;
@@ -313,10 +315,10 @@ __global__ __launch_bounds__(256) void k_defl_update(double* __restrict__ L, con
 #pragma unroll
         for (int a = 0; a < DEFL_Q0; ++a) {
             if (a >= r) break;
-            const double t = __dmul_rn(wi[a], v[a * p + j]), u = __dmul_rn(vi[a], w[a * p + j]);
-            s = __dadd_rn(s, __dadd_rn(t, u));
+            const double t = wi[a] * v[a * p + j], u = vi[a] * w[a * p + j];
+            s = s + (t + u);
         }
-        Lk[(size_t)i * p + j] = __dadd_rn(Lk[(size_t)i * p + j], __dmul_rn(0.25, s));
+        Lk[(size_t)i * p + j] = Lk[(size_t)i * p + j] + 0.25 * s;
     }
 }
 
