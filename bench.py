@@ -55,6 +55,10 @@ WORKLOADS = {
     "ggl_K64_p100": ("GGL", 64, 100, False, 0.05, 0.01, 1241),
     "ggl_K256_p64": ("GGL", 256, 64, False, 0.05, 0.01, 1242),
     "ggl_K32_p128": ("GGL", 32, 128, False, 0.05, 0.01, 1243),
+    # C2 of BASELINE.json: Single GL p = 1000 over a 20-point lambda1 grid as ONE batch of 20 independent problems
+    # (gglasso_amd.batch / ggl_sgl_batch_step; lambda1 = logspace(0, -2, 20), own rho per point).  A step = one batched
+    # iteration of all 20 points; lambda1 / lambda2 of the tuple are unused.
+    "sgl_p1000_grid20": ("SGL", 20, 1000, False, 0.0, 0.0, 1235),
 }
 
 # product-kernel instances of csrc/gemm_sym.hip by the variant number ggl_ns_stats reports
@@ -116,6 +120,42 @@ def committed_profile(kernel_key):
 def quiet(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)
+
+
+def grid_cpu_baseline(S, lam, threads, eng, run, points=(0, 9, 19), iters=4):
+    """CPU oracle on a bounded sample of the lambda grid: `iters` ADMM_SGL iterations of `points` of the grid (the oracle's
+    eigh on p = 1000 takes ~1 s per iteration and point), scaled to batched iterations per second (one batched iteration =
+    all len(lam) points); and the parity of the engine's batch at those points after the same iterations."""
+    from oracle import ggl_oracle as orc
+    p = S.shape[0]
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:  # noqa: BLE001
+        limiter = contextlib.nullcontext()
+    refs = {}
+    with limiter:
+        t0 = time.perf_counter()
+        for k in points:
+            refs[k], _ = quiet(orc.ADMM_SGL, S, lam[k], np.eye(p), max_iter=iters, tol=1e-20, rtol=1e-20)
+        dt = time.perf_counter() - t0
+    per_point_iter = dt / (len(points) * iters)
+    cpu = {"value": 1.0 / (per_point_iter * len(lam)), "unit": "ADMM iters/s", "cores": threads, "kind": "port",
+           "sample": f"{iters} ADMM_SGL iterations of {len(points)} of the {len(lam)} grid points (oracle/ggl_oracle.py: "
+                     f"numpy.linalg.eigh + soft threshold) on {threads} BLAS threads, {dt:.1f} s; scaled to batched iterations "
+                     f"(all {len(lam)} points) per second"}
+    eng.profile(0)
+    eye = np.broadcast_to(np.eye(p), (len(lam), p, p))
+    eng.set_state(np.ascontiguousarray(eye), np.ascontiguousarray(eye), np.zeros((len(lam), p, p)))
+    run(iters, 1.0)
+    worst, fro = 0.0, 0.0
+    for k in points:
+        got = eng.state_k(k)
+        worst = max(worst, max(float(np.abs(got[nm] - refs[k][nm]).max()) for nm in ("Omega", "Theta", "X")))
+        fro = max(fro, float(np.linalg.norm(got["Theta"] - refs[k]["Theta"])))
+    parity = {"iters": iters, "against": f"oracle ADMM_SGL at grid points {list(points)}, identity start, rho rule on",
+              "max_abs_vs_oracle": worst, "theta_fro_vs_oracle": fro, "tolerance": "north_star: Theta within 1e-8 Frobenius"}
+    return cpu, parity
 
 
 def cpu_baseline(S, reg, lambda1, lambda2, latent, mu1, iters, threads):
@@ -216,7 +256,14 @@ def main():
         comm = RcclComm(device=local_rank) if args.comm == "capi" else TorchComm(device=f"cuda:{local_rank}")
 
     reg, K, p, latent, l1, l2, seed = WORKLOADS[args.workload]
-    S, _ = synth.make_problem(reg, K, p, N=2 * p, seed=seed)
+    is_grid = reg == "SGL"
+    if is_grid:
+        S1, _ = synth.make_problem("GGL", 1, p, N=2 * p, seed=seed)
+        S = np.broadcast_to(S1[0], (K, p, p))            # uploaded once, replicated on the device (ggl_set_S_ex)
+        lam_grid = np.logspace(0, -2, K)
+        assert not distributed, "the lambda grid runs as replicas (gglasso_amd.dist.lambda_path_sharded), not K-sharded"
+    else:
+        S, _ = synth.make_problem(reg, K, p, N=2 * p, seed=seed)
     mu1 = 0.5 * np.ones(K) if latent else None
     if distributed:
         assert reg == "GGL" and not latent, "only GGL shards across K; other workloads run as replicas"
@@ -269,6 +316,22 @@ def main():
     mu_loc = None if mu1 is None else mu1[k0:k1]
 
     def run(iters, rho):
+        if is_grid:
+            # the loop of gglasso_amd.batch.ADMM_SGL_batch without the stopping test (fixed iteration count): every point
+            # keeps its own rho (single_admm_solver.py:196-206)
+            rhos = np.full(K, float(rho)) if np.isscalar(rho) else rho
+            dimk = (p * p + p) / 2
+            for _ in range(iters):
+                sq = eng.sgl_batch_step(rhos, lam_grid, False, None)
+                fac = np.ones(K)
+                for k in range(K):
+                    r_t, s_t, _, _ = solver.residuals_from_norms(sq[k], rhos[k], 1e-20, 1e-20, dimk)
+                    rn = solver.next_rho(rhos[k], r_t, s_t)
+                    fac[k] = rhos[k] / rn
+                    rhos[k] = rn
+                if np.any(fac != 1.0):
+                    eng.scale_X_batch(fac)
+            return rhos
         info, rho = quiet(solver._run_admm, eng, reg, K, p, l1, l2, latent, mu_loc, nk, rho, 1e-20, 1e-20, 'boyd',
                           True, iters, False, False, "Multiple", comm=comm)
         return rho
@@ -337,7 +400,7 @@ def main():
     # one more region with the Omega-step iterated to fp64 resolution (GGL_OPT_NS_TOL = 0): the same record then carries
     # the rate at the accuracy of an eigendecomposition next to the rate at the default stopping tolerance
     exact = None
-    omega_is_ns = (args.eig == _lib.EIG_NEWTON_SCHULZ) or (args.eig == _lib.EIG_AUTO and p > _lib.JACOBI_MAX_P)
+    omega_is_ns = (args.eig == _lib.EIG_NEWTON_SCHULZ) or (args.eig == _lib.EIG_AUTO and p > _lib.NS_MIN_P)
     if omega_is_ns and not args.no_exact_region and effective_options["ns_tol"] > 5e-16:
         eng.set_option("ns_tol", 0.0)
         dte, na, nb, _ = one_region()
@@ -349,7 +412,9 @@ def main():
     # CPU oracle on this box's host cores (bounded sample) -- and, from the SAME oracle run, the parity of this engine
     # after the same number of iterations of the same problem (outside every timed region)
     cpu = parity = None
-    if rank == 0 and not distributed and not args.no_cpu_baseline:
+    if rank == 0 and not distributed and not args.no_cpu_baseline and is_grid:
+        cpu, parity = grid_cpu_baseline(S1[0], lam_grid, args.cpu_threads, eng, run)
+    elif rank == 0 and not distributed and not args.no_cpu_baseline:
         cpu, ref = cpu_baseline(S, reg, l1, l2, latent, mu1, args.cpu_iters, args.cpu_threads)
         eng.profile(0)
         eng.set_state(Om0, Om0, np.zeros_like(S_loc))
@@ -366,7 +431,7 @@ def main():
     eng.close()
 
     if rank == 0:
-        eig_jacobi = (args.eig == _lib.EIG_JACOBI) or (args.eig == _lib.EIG_AUTO and p <= _lib.JACOBI_MAX_P)
+        eig_jacobi = (args.eig == _lib.EIG_JACOBI) or (args.eig == _lib.EIG_AUTO and p <= _lib.NS_MIN_P)
         phases = {ph: {"ms_per_launch": ms / cnt, "launches": cnt} for ph, (ms, cnt) in prof.items() if cnt}
         if "eig_omega" in phases and ns1["launches"] > ns0["launches"]:
             # the Newton-Schulz Omega-step is timed in one event pair (speculative step: no host sync inside) or two
@@ -390,6 +455,7 @@ def main():
         kernel_name = {"eig_omega": ns_kernel + " -- Newton-Schulz product" if omega_ns else
                        ("k_jacobi" if eig_jacobi else "rocsolver_dsyevd (library, many kernels)"),
                        "theta": "k_theta_ggl" if reg == "GGL" else ("k_theta_fgl" if reg == "FGL" else "k_theta_sgl"),
+                       "allreduce_groupsq": "ncclAllReduce (p,p)+1 fp64", "allreduce_norms": "ncclAllReduce 5 fp64",
                        "recon_omega": "k_recon", "recon_L": "k_recon", "form_W": "k_form_W",
                        "dual": "k_dual_update", "eig_L": "k_jacobi" if eig_jacobi else "rocsolver_dsyevd"}.get(dom, dom)
         sec = phases[dom]["ms_per_launch"] * 1e-3
@@ -440,8 +506,10 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{reg} K={K} p={p} lambda1={l1} lambda2={l2} latent={latent}, identity start, "
-                                   f"rho0=1 update_rho, fixed iteration count",
+            "config": {"workload": (f"SGL p={p}, {K}-point lambda1 grid logspace(0,-2) as one batch of {K} independent problems, "
+                                    "identity start, rho0=1 update_rho per point, fixed iteration count" if is_grid else
+                                    f"{reg} K={K} p={p} lambda1={l1} lambda2={l2} latent={latent}, identity start, "
+                                    f"rho0=1 update_rho, fixed iteration count"),
                        "sharding": (f"K-slabs of {Kl} per GPU, collectives: " + ("RCCL behind the C ABI" if args.comm == "capi"
                                                                                   else "torch.distributed (RCCL)"))
                        if distributed else "single GPU",
@@ -481,6 +549,8 @@ def main():
             out["value_exact"] = exact
         if distributed:
             out["n_ranks_seen"] = n_ranks_seen      # ncclCommCount of the engine's communicator (capi) / the process group's size
+        if is_grid:
+            out["grid_point_iterations_per_s"] = its * K
         if parity is not None:
             out["parity"] = parity
         if cpu is not None:

@@ -23,9 +23,11 @@ def eig_flags(method=EIG_AUTO, ns_mode=0, ns_degrees=0):
     return int(method) | ((int(ns_mode) & 0x3) << 8) | ((int(ns_degrees) & 0xf) << 12)
 
 JACOBI_MAX_P = 128
+NS_MIN_P = 8          # GGL_EIG_AUTO: matrix-function Omega- / L-step for p above this (include/ggl_hip.h GGL_NS_MIN_P)
 BUF_S, BUF_OMEGA, BUF_THETA, BUF_L, BUF_X, BUF_GROUPSQ, BUF_NORMS, BUF_OMEGA_PREV = range(8)
 E_ARG, E_HIP, E_SOLVER, E_ALLOC, E_COMM = -1, -2, -3, -4, -5
-PHASES = ("form_W", "eig_omega", "recon_omega", "theta", "eig_L", "recon_L", "dual", "reduce", "eig_omega2", "bound")
+PHASES = ("form_W", "eig_omega", "recon_omega", "theta", "eig_L", "recon_L", "dual", "reduce", "eig_omega2", "bound",
+          "allreduce_groupsq", "allreduce_norms")
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _vp = ctypes.c_void_p

@@ -194,7 +194,8 @@ struct ggl_ctx {
     long long ph_cnt[GGL_NPHASE] = {};
 };
 
-#define PROF_HOT(ph) ((ph) == GGL_PH_EIG_OMEGA || (ph) == GGL_PH_EIG_OMEGA2 || (ph) == GGL_PH_EIG_L)
+#define PROF_HOT(ph) ((ph) == GGL_PH_EIG_OMEGA || (ph) == GGL_PH_EIG_OMEGA2 || (ph) == GGL_PH_EIG_L || \
+                      (ph) == GGL_PH_ALLREDUCE_GROUPSQ || (ph) == GGL_PH_ALLREDUCE_NORMS)
 #define PROF_ACTIVE(c, ph) ((c)->prof_on == 1 || ((c)->prof_on == 2 && PROF_HOT(ph)))
 #define PB(c, ph) do { if (PROF_ACTIVE(c, ph)) (void)hipEventRecord((c)->ev[ph][0], (c)->stream); } while (0)
 #define PE(c, ph) do { if (PROF_ACTIVE(c, ph)) { (void)hipEventRecord((c)->ev[ph][1], (c)->stream); (c)->ev_used[ph] = true; } } while (0)
@@ -2625,12 +2626,18 @@ static int sharded_pass(ggl_ctx* c, double rho, double lambda1, double lambda2, 
                            (1.0 / rho) * lambda1, c->K, c->p);
     launch_spec_pack(c->stream, c->spec_pending ? c->spec_flag : nullptr, c->groupsq + (size_t)c->p * c->p);
     HIPCHK(hipGetLastError());
-    if ((rc = ggl_allreduce_groupsq(c))) return rc;
+    PB(c, GGL_PH_ALLREDUCE_GROUPSQ);         // (HIP events on the ctx stream: what the collective costs THIS rank, waiting included)
+    rc = ggl_allreduce_groupsq(c);
+    PE(c, GGL_PH_ALLREDUCE_GROUPSQ);
+    if (rc) return rc;
     // latent: Theta from the reduced sums, then the L-step and the dual update on the local slab (admm_solver.py:197-208:
     // per instance, no exchange), one row of local sums; norms stay on the device
     rc = ggl_step_finish_impl(c, rho, lambda1, lambda2, GGL_REG_GGL, latent, mu1, 1 | 2, out_norms);
     if (rc) return rc;
-    if ((rc = ggl_allreduce_norms(c))) return rc;
+    PB(c, GGL_PH_ALLREDUCE_NORMS);
+    rc = ggl_allreduce_norms(c);
+    PE(c, GGL_PH_ALLREDUCE_NORMS);
+    if (rc) return rc;
     return finish_norms(c, 1, out_norms);
 }
 

@@ -374,8 +374,10 @@ int ggl_kkt_residual(ggl_ctx *ctx, double rho, double lambda1, double lambda2, i
 #define GGL_PH_REDUCE 7       /* partial-sum reduction of the norms                                */
 #define GGL_PH_EIG_OMEGA2 8   /* second part of the Newton-Schulz Omega-step (after the spectral-bound sync) */
 #define GGL_PH_BOUND 9        /* (not recorded any more: the bound kernels run inside the Omega-step chains) */
-#define GGL_NPHASE 10
-/* on: 0 off, 1 every phase, 2 only GGL_PH_EIG_OMEGA / _OMEGA2 / _EIG_L (4-6 event records per iteration) */
+#define GGL_PH_ALLREDUCE_GROUPSQ 10 /* K-sharded run: ncclAllReduce of the (p,p) + 1 group sums (ggl_admm_step_sharded)  */
+#define GGL_PH_ALLREDUCE_NORMS 11   /* K-sharded run: ncclAllReduce of the five sums                                    */
+#define GGL_NPHASE 12
+/* on: 0 off, 1 every phase, 2 only GGL_PH_EIG_OMEGA / _OMEGA2 / _EIG_L and the two all-reduces (4-10 event records per iteration) */
 int ggl_profile_enable(ggl_ctx *ctx, int on);
 int ggl_profile_read(ggl_ctx *ctx, double ms[GGL_NPHASE], long long count[GGL_NPHASE], int reset);
 /* Newton-Schulz statistics since ctx creation: Omega-step {calls, steps, calls that took the stable

@@ -66,6 +66,7 @@ def test_header_constants_match_python(lib):
     assert int(consts["GGL_REG_GGL"]) == lib.REG_GGL and int(consts["GGL_REG_FGL"]) == lib.REG_FGL
     assert int(consts["GGL_EIG_JACOBI"]) == lib.EIG_JACOBI and int(consts["GGL_EIG_ROCSOLVER"]) == lib.EIG_ROCSOLVER
     assert int(consts["GGL_JACOBI_MAX_P"]) == lib.JACOBI_MAX_P
+    assert int(consts["GGL_NS_MIN_P"]) == lib.NS_MIN_P
     assert int(consts["GGL_BUF_GROUPSQ"]) == lib.BUF_GROUPSQ
     assert int(consts["GGL_NPHASE"]) == len(lib.PHASES)
     assert int(consts["GGL_E_ARG"]) == lib.E_ARG

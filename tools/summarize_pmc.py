@@ -45,7 +45,12 @@ for sub in ("fetch", "write", "sq", "tcc"):
 # and reports FETCH_SIZE = 31.5e3 KiB).  The 8-byte-per-lane kernels (k_symm_tn, the elementwise and Theta kernels) were
 # calibrated the same way at a factor of 1: k_symm_tn with A == B reports 72.2e3 KiB for the same 64.0 MB, WRITE_SIZE
 # 64.7e3 KiB for a 64.0 MB output.
-FETCH_FACTOR = {"k_symm_dl": 2.0}
+# Round 4: the same holds for EVERY kernel that loads 16 bytes per lane -- the per-element Theta kernels since
+# round 2 (k_theta_ggl_flat4<KQ> and flat4v<8,...>; the 16 x 16-wave instance flat4v<16,...> for K > 128 uses 8-byte accesses),
+# the instance copies, the persistent chain and the int8 product kernel.  (r3_pmc_summary.json reported 224 MB per launch for
+# flat4v against 320 MB algorithmic: FETCH 188 MB was half of the truth; 2 x 94 + 125 = 313 MB.)
+FETCH_FACTOR = {"k_symm_dl": 2.0, "k_theta_ggl_flat4v<16": 1.0, "k_theta_ggl_flat4": 2.0, "k_copy_instances": 2.0,
+                "k_omega_chain": 2.0, "k_symm_i8": 2.0}
 for kname, c in out.items():
     f = c.get("FETCH_SIZE", {}).get("mean_per_launch")
     w = c.get("WRITE_SIZE", {}).get("mean_per_launch")
