@@ -6,7 +6,7 @@ L = (C - mu I)_+ = B (I + sign(B)) / 2, B = C - mu I.  The library's sign iterat
 to l0 |B|; the schedule's length is set by the eigenvalues NEXT to the threshold (22 products at l0 = 1e-3, 27 at 1e-4, 31 at
 1e-5, 36 at 1e-6).  After a COARSE pass every eigenvalue farther than l0 |B| from the threshold sits at +-1 and
 R = I - X^2 is numerically of rank r = the handful of eigenvalues within l0 |B|:
-    range finder   Y = R G, G p x q Gaussian;  V = orth(Y) (q columns; those beyond the numerical rank r dropped)
+    range finder   Y = R G, G p x q Gaussian;  Q1 = orth(Y), V = orth(R Q1) (absolute thresholds 1e-11 / 1e-10 on the remainders)
     exact small    H = V^T B V  (r x r), sign(H) by eigendecomposition
     correction     sign(B) = X + V (sign(H) - V^T X V) V^T     =>     L = B (I + X) / 2 + (B V) (sign(H) - V^T X V) V^T / 2
 p^2 q work, no product.  Guarded by the trace check (trace sign(B) must be an integer) and by a probe of the range
@@ -51,19 +51,39 @@ def sign_iterate(B, c, co):
     return X
 
 
-def deflate(B, X, q, rng, tol_rank=1e-10):
+def _orth(Y, tau):
+    """Gram-Schmidt (twice) with an ABSOLUTE acceptance threshold on the remainder of every column, as csrc/deflate.hip."""
+    V = []
+    for a in range(Y.shape[1]):
+        y = Y[:, a].copy()
+        for _ in range(2):
+            for v in V:
+                y -= (v @ y) * v
+        n = np.linalg.norm(y)
+        if n > tau:
+            V.append(y / n)
+    return np.stack(V, axis=1) if V else np.zeros((Y.shape[0], 0))
+
+
+def deflate(B, X, q, rng, tau1=1e-11, tau2=1e-10):
+    """The device algorithm (csrc/deflate.hip).  The FIRST version of this prototype took the numerical rank of Y = R G with a
+    tolerance RELATIVE to its largest column (1e-10): whenever the largest residual eigenvalue was itself small (3e-8, 5e-10)
+    that let pure noise columns into the basis -- directions that are not invariant under B -- and the 'correction' was wrong by
+    1e-2.  R's resolved part sits at ~5e-15 ABSOLUTELY (X is scaled to |X| <= 1), so the thresholds are absolute; and a
+    direction with a small residual r_i comes out of one application of R contaminated at the relative level 1e-13 / r_i, which
+    one more application (V = orth(R Q1)) removes."""
     p = len(B)
     G = rng.standard_normal((p, q + 2))
-    RG = G - X @ (X @ G)                       # R G without forming R: two tall-skinny products
-    Y, probe = RG[:, :q], RG[:, q:]
-    # orthonormalise with column pivoting by norm; columns below tol_rank * the largest are noise
-    Q, Rr = np.linalg.qr(Y)
-    d = np.abs(np.diag(Rr))
-    r = int(np.sum(d > tol_rank * max(d.max(), 1e-300))) if d.max() > 1e-13 else 0
-    V = Q[:, :r]
-    leak = np.linalg.norm(probe - V @ (V.T @ probe)) / max(np.linalg.norm(probe), 1e-300) if r else 0.0
+    R = lambda Z: Z - X @ (X @ Z)              # R Z without forming R: two tall-skinny products
+    Q1 = _orth(R(G[:, :q]), tau1)
+    V = _orth(R(Q1), tau2) if Q1.shape[1] else Q1
+    r = V.shape[1]
+    probe = R(G[:, q:])
+    for _ in range(2):
+        probe = probe - V @ (V.T @ probe)
+    leak = np.linalg.norm(probe, axis=0).max()
     if r == 0:
-        return 0.5 * sym(B @ (np.eye(p) + X)), 0, 0.0, np.trace(X)
+        return 0.5 * sym(B @ (np.eye(p) + X)), 0, leak, np.trace(X)
     BV = B @ V
     H = sym(V.T @ BV)
     w, U = np.linalg.eigh(H)
@@ -78,7 +98,7 @@ def main():
     K = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     p = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     l0c = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-3
-    q = 8
+    q = 6
     rng = np.random.default_rng(3)
     S, _ = synth.make_problem("FGL", K, p, N=2 * p, seed=1237)
     Om = np.stack([np.eye(p)] * K); Th = Om.copy(); X = np.zeros_like(S); L = np.zeros_like(S)
