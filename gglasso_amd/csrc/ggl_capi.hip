@@ -2027,6 +2027,10 @@ extern "C" int ggl_reset_instance(ggl_ctx* c, int k)
     double* zero[] = {c->L + off, c->X + off, c->W + off};
     for (double* z : zero) HIPCHK(hipMemsetAsync(z, 0, pp * sizeof(double), c->stream));
     for (double* a : ident) launch_set_identity(c->stream, a, 1, c->p);
+    // ext_ADMM_MGL state (ggl_ext_*): the copy variable Lambda = I, the second dual X1 = 0
+    for (double* lam : c->Lam)
+        if (lam) launch_set_identity(c->stream, lam + off, 1, c->p);
+    if (c->X1) HIPCHK(hipMemsetAsync(c->X1 + off, 0, pp * sizeof(double), c->stream));
     HIPCHK(hipGetLastError());
     c->spec_have = false;
     c->cw_have = false;

@@ -161,7 +161,8 @@ def ext_ADMM_MGL_batch(S, lambda1, lambda2, reg, G, tol=1e-5, rtol=1e-4, rho=1.,
     stack, one batched Omega-step (and L-step) over all ngrid*K matrices, one Theta-step, one group shrink (with a
     grid-point dimension) and one dual update per iteration.  The solver has no rho update (ext_admm_solver.py), so all
     points share rho; every point keeps its own residuals and stopping iteration and is snapshotted when it converges
-    (it keeps iterating harmlessly until the batch is done).  lambda1[g]: scalar or (K,); mu1: (K,) shared or (ngrid,K).
+    (it keeps iterating harmlessly until the batch is done); a point whose data turn non-finite ends with status
+    'solver error' and is parked, the others go on.  lambda1[g]: scalar or (K,); mu1: (K,) shared or (ngrid,K).
     Returns a list of ``(sol, info)`` as ``ext_ADMM_MGL`` (Boyd criterion), ``info`` with 'iterations' added."""
     K = len(S.keys())
     p = np.array([S[k].shape[0] for k in range(K)], dtype=int)
@@ -191,6 +192,8 @@ def ext_ADMM_MGL_batch(S, lambda1, lambda2, reg, G, tol=1e-5, rtol=1e-4, rho=1.,
     try:
         eng.ext_setup_batch(ng, p, G)
         eng.ext_set_state(rep(Om0), None)
+        if hasattr(eng, "set_option"):
+            eng.set_option("isolate", 1)        # a point with non-finite data costs that point only (batch.ADMM_MGL_batch)
         dim = ((p ** 2 + p) / 2).sum()
         rho = float(rho)
         lam1f = as_c(lam1.reshape(-1))
@@ -216,6 +219,13 @@ def ext_ADMM_MGL_batch(S, lambda1, lambda2, reg, G, tol=1e-5, rtol=1e-4, rho=1.,
             sq = eng.ext_batch_step(ng, rho, lam1f, lam2, bool(latent), mu)
             for g in range(ng):
                 if done[g]:
+                    continue
+                if not np.all(np.isfinite(sq[g])):
+                    collect(g, 'solver error', it + 1)
+                    done[g] = True
+                    if hasattr(eng, "reset_instance"):
+                        for k in range(K):
+                            eng.reset_instance(g * K + k)
                     continue
                 r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[g], rho, tol, rtol, dim)
                 last[g] = (r_t, s_t, e_pri, e_dual)

@@ -9,6 +9,8 @@ import io
 import numpy as np
 import pytest
 
+from conftest import load_golden
+
 pytestmark = pytest.mark.gpu
 
 
@@ -165,3 +167,33 @@ def test_mgl_batch_compaction_equals_the_uncompacted_batch():
         assert np.array_equal(a[g][1]['rank'], b[g][1]['rank'])
         assert np.allclose(a[g][1]['selection'], b[g][1]['selection'], rtol=1e-9)
     assert sum(r[1]['carried'] for r in b) < sum(r[1]['carried'] for r in a)
+
+
+def test_ext_grid_with_a_poisoned_point(monkeypatch):
+    """ext_ADMM_MGL_batch (the non-conforming grid of grid_search, helper/model_selection.py:208-224 with solver = ext_ADMM_MGL):
+    a NaN written into ONE grid point's slab of the padded stack -- that point reports 'solver error', the other five end
+    where their own ext_ADMM_MGL solves end."""
+    import ext_checks
+    from gglasso_amd import solver, ext_solver
+    g = load_golden("g14_ext_admm_nonconforming")
+    K, p, S, G, Om0 = ext_checks.g14_inputs(g)
+    l1s, l2s = [0.2, 0.08, 0.03], [0.1, 0.02]
+    pts = [(a, b) for b in l2s for a in l1s]
+    real = solver.HipEngine
+
+    class Poisoned(real):
+        def __init__(self, Sx, *a, **kw):
+            Sx = np.array(Sx)
+            Sx[4 * K + 1, 0, 1] = Sx[4 * K + 1, 1, 0] = np.nan          # grid point 4, instance 1
+            super().__init__(Sx, *a, **kw)
+
+    monkeypatch.setattr(solver, "ENGINE", Poisoned)
+    res = quiet(ext_solver.ext_ADMM_MGL_batch, S, [a for a, _ in pts], [b for _, b in pts], 'GGL', G, tol=1e-8, rtol=1e-8)
+    monkeypatch.setattr(solver, "ENGINE", real)
+    assert [r[1]['status'] for r in res] == ['optimal'] * 4 + ['solver error', 'optimal']
+    for i, (a, b) in enumerate(pts):
+        if i == 4:
+            continue
+        ref, rinfo = quiet(ext_solver.ext_ADMM_MGL, S, a, b, 'GGL', {k: v.copy() for k, v in Om0.items()}, G, tol=1e-8, rtol=1e-8)
+        for k in range(K):
+            assert np.abs(res[i][0]['Theta'][k] - ref['Theta'][k]).max() <= 1e-9, (i, k)
