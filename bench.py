@@ -501,6 +501,13 @@ def main():
         if default_cfg:
             # labelled as what they are: numbers of the committed rocprofv3 runs of this command, not of this run
             roof.update(committed_profile(ns_kernel.split("<")[0]))
+            if "profiled_traffic_bytes" in roof:
+                # HBM bytes per launch of the dominant kernel from the separate --pmc passes of the same command (FETCH_SIZE with
+                # the guide's gfx950 correction for 16-byte-per-lane loads + WRITE_SIZE, tools/summarize_pmc.py): counters cannot
+                # be collected inside this run, so the committed passes' figure stands here with its source beside it
+                roof["traffic"] = roof["profiled_traffic_bytes"]
+                roof["traffic_source"] = roof.get("profiled_traffic_source")
+                roof["traffic_algorithmic_bytes"] = 3 * 8.0 * (Kl / max(parts, 1)) * p * p
         out = {
             "metric": "ADMM iters/sec on (K=32,p=500) GGL at 1/2/4/8 GPUs; eigh HBM GB/s vs peak", "value": its, "unit": "ADMM iters/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

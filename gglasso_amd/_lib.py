@@ -76,6 +76,7 @@ _SIGNATURES = {
     "ggl_get_state_k": ([_vp, _i, _dp, _dp, _dp, _dp], _i),
     "ggl_exit_checks": ([_vp, _i, _dp], _i),
     "ggl_exit_checks_k": ([_vp, _i, _dp], _i),
+    "ggl_exit_checks_fast_k": ([_vp, _i, _d, _d, _dp], _i),
     "ggl_ext_setup": ([_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), _i], _i),
     "ggl_ext_set_state": ([_vp, _dp, _dp], _i),
     "ggl_ext_get_state": ([_vp, _dp, _dp], _i),

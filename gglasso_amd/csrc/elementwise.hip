@@ -418,6 +418,18 @@ void launch_copy_instances(hipStream_t st, double* dst, const double* src, const
     hipLaunchKernelGGL(k_copy_instances, dim3(std::max(bx, 1), m), dim3(256), 0, st, dst, src, idx, pp, scatter ? 1 : 0);
 }
 
+// A_k += shift * I for the K instances of a stack (the shifted definiteness tests of ggl_exit_checks_fast)
+__global__ __launch_bounds__(256) void k_add_diag(double* __restrict__ A, int p, double shift)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < p) A[(size_t)blockIdx.y * p * p + (size_t)i * p + i] += shift;
+}
+
+void launch_add_diag(hipStream_t st, double* A, int K, int p, double shift)
+{
+    hipLaunchKernelGGL(k_add_diag, dim3((p + 255) / 256, K), dim3(256), 0, st, A, p, shift);
+}
+
 // A_k = I for the K instances of a stack (ggl_reset_instance)
 __global__ __launch_bounds__(256) void k_set_identity(double* __restrict__ A, int p)
 {

@@ -131,8 +131,14 @@ def ext_ADMM_MGL(S, lambda1, lambda2, reg, Omega_0, G, X0=None, X1=None, tol=1e-
 
         if latent and hasattr(eng, "finalize_L"):
             eng.finalize_L()        # the returned L: one eigendecomposition where the L-steps were sign iterations
-        # per-instance exit checks (ext_admm_solver.py:290-311)
-        for a_om, a_th, a_l, min_tl, min_l in eng.exit_checks_k(bool(latent)):
+        # per-instance exit checks (ext_admm_solver.py:290-311): the decisions by batched Cholesky factorisations first, the
+        # eigenvalues only if some instance fails one (solver._exit_report)
+        rows = None
+        if hasattr(eng, "exit_checks_fast"):
+            f = eng.exit_checks_fast(bool(latent), 1e-5, 1e-5)
+            if f[:, 3].min() > 0 and f[:, 4].min() > 0:
+                rows = [(r[0], r[1], r[2], 1.0, 0.0) for r in f]
+        for a_om, a_th, a_l, min_tl, min_l in (rows if rows is not None else eng.exit_checks_k(bool(latent))):
             for name, dev in (("Omega", a_om), ("Theta", a_th), ("L", a_l)):
                 if dev > 1e-5:
                     warnings.warn(f"{name} variable is not symmetric, largest deviation is {dev}.")

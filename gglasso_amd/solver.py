@@ -338,6 +338,13 @@ class HipEngine:
         check(self.lib.ggl_exit_checks(self.h, int(latent), ptr(out)))
         return out
 
+    def exit_checks_fast(self, latent, shift_l, shift_tl=0.0):
+        """(K,5): the three asymmetries and the two DECISIONS of the exit checks -- Theta_k - L_k - shift_tl I positive definite,
+        L_k + shift_l I positive definite (1 / 0) -- by batched Cholesky factorisations, no eigenvalues (ggl_exit_checks_fast_k)."""
+        out = np.zeros((self.K, 5))
+        check(self.lib.ggl_exit_checks_fast_k(self.h, int(latent), float(shift_tl), float(shift_l), ptr(out)))
+        return out
+
     def exit_checks_k(self, latent):
         out = np.zeros((self.K, 5))
         check(self.lib.ggl_exit_checks_k(self.h, int(latent), ptr(out)))
@@ -603,9 +610,19 @@ def _run_admm(eng, reg, K_total, p, lambda1, lambda2, latent, mu1, nk, rho, tol,
 def _exit_report(eng, latent, psd_tol, verbose_min_ev):
     """Symmetry / definiteness checks after the loop (solver/admm_solver.py:284-301,
     solver/single_admm_solver.py:244-263)."""
+    if hasattr(eng, "exit_checks_fast"):
+        # the reference's DECISIONS first (two batched Cholesky factorisations); its eigenvalues only when a warning has to be
+        # printed: they cost as much as the whole solve (20 ms behind 25 ms of iterations at (32,500), tools/time_exit_checks.py)
+        f = eng.exit_checks_fast(latent, psd_tol)
+        a_om, a_th, a_l = f[:, 0].max(), f[:, 1].max(), f[:, 2].max()
+        for name, dev in (("Omega", a_om), ("Theta", a_th), ("L", a_l)):
+            if dev > 1e-5:
+                warnings.warn(f"{name} variable is not symmetric, largest deviation is {dev}.")
+        if f[:, 3].min() > 0 and f[:, 4].min() > 0:
+            return
     a_om, a_th, a_l, min_tl, min_l = eng.exit_checks(latent)
     for name, dev in (("Omega", a_om), ("Theta", a_th), ("L", a_l)):
-        if dev > 1e-5:
+        if dev > 1e-5 and not hasattr(eng, "exit_checks_fast"):
             warnings.warn(f"{name} variable is not symmetric, largest deviation is {dev}.")
     if min_tl <= 0:
         extra = f" (min EV is {min_tl})" if verbose_min_ev else ""

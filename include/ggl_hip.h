@@ -274,6 +274,12 @@ int ggl_exit_checks(ggl_ctx *ctx, int latent, double out[5]);
 
 /* The same five numbers per instance, out (K,5) (what the per-instance messages of solver/ext_admm_solver.py:290-311 need). */
 int ggl_exit_checks_k(ggl_ctx *ctx, int latent, double *out);
+/* The same checks as the DECISIONS the reference takes, without the eigenvalues: out[k*5..] = { the three asymmetries,
+ * 1 if Theta_k - L_k - shift_tl I is positive definite else 0, 1 if L_k + shift_l I is positive definite else 0 (1 when not
+ * latent) } -- two batched Cholesky factorisations instead of two eigendecompositions.  The reference warns when
+ * min eig(Theta - L) <= shift_tl (0 for ADMM_MGL / ADMM_SGL, 1e-5 for ext_ADMM_MGL) resp. min eig(L) < -shift_l (1e-5 / 1e-8):
+ * the instances whose flag is 0; ggl_exit_checks_k gives the eigenvalues for the message of a warning that has to be printed. */
+int ggl_exit_checks_fast_k(ggl_ctx *ctx, int latent, double shift_tl, double shift_l, double *out);
 
 /* ---- ext_ADMM_MGL: Group Graphical Lasso over instances of DIFFERENT dimension -------------------
  * solver/ext_admm_solver.py:18-323 (loop body :196-231, prox_2norm_G / prox_G_inner :394-453, stopping criterion :325-345,

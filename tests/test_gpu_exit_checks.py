@@ -160,3 +160,35 @@ def test_solvers_reach_the_definiteness_warnings(p):
     n_bad = sum(np.linalg.eigvalsh(sole["Theta"][k] - sole["L"][k]).min() <= 1e-5 for k in range(K))
     assert n_bad >= 1
     assert out.count("Theta (Theta-L resp.) may be not positive definite") == n_bad
+
+
+@pytest.mark.parametrize("p", [60, 200])
+@pytest.mark.parametrize("latent", [True, False])
+def test_exit_check_decisions_by_cholesky(p, latent):
+    """ggl_exit_checks_fast_k: the DECISIONS of admm_solver.py:294-301 (min eig(Theta - L) <= shift_tl, min eig(L) < -shift_l) from
+    two batched Cholesky factorisations must be the ones NumPy's eigenvalues give, instance by instance -- on the state with a
+    known indefinite instance each, on margins of 1e-7 either side of the shifts, and the asymmetries as before."""
+    from gglasso_amd import solver
+    K = 4
+    Om, Th, L, X = _known_state(p, K, 90 + p)
+    rng = np.random.default_rng(p)
+    # instance 3: L's smallest eigenvalue -0.9e-5 (inside the ADMM_MGL tolerance 1e-5: no warning), Theta - L's 2e-7 (> 0)
+    L[3] = _sym_with_spectrum(rng, p, np.linspace(-0.9e-5, 1.0, p))
+    Th[3] = L[3] + _sym_with_spectrum(rng, p, np.linspace(2e-7, 2.0, p))
+    if not latent:
+        L = np.zeros_like(L)
+    eng = solver.HipEngine(np.repeat(np.eye(p)[None], K, axis=0), Om, Th, X, L_0=L)
+    try:
+        want = _numpy_checks_k(Om, Th, L, latent)
+        for shift_tl, shift_l in ((0.0, 1e-5), (0.0, 1e-8), (1e-5, 1e-5), (3e-7, 0.8e-5)):
+            got = eng.exit_checks_fast(latent, shift_l, shift_tl)
+            assert np.abs(got[:, :3] - want[:, :3]).max() <= 1e-12
+            assert list(got[:, 3]) == [1.0 if want[k, 3] > shift_tl else 0.0 for k in range(K)], (shift_tl, got[:, 3], want[:, 3])
+            if latent:
+                assert list(got[:, 4]) == [1.0 if want[k, 4] > -shift_l else 0.0 for k in range(K)], (shift_l, got[:, 4], want[:, 4])
+            else:
+                assert np.all(got[:, 4] == 1.0)
+        # the eigenvalue route still answers afterwards (info / scratch left clean)
+        assert np.abs(eng.exit_checks_k(latent) - want).max() <= 1e-10
+    finally:
+        eng.close()
