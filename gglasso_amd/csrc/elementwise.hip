@@ -430,6 +430,18 @@ void launch_add_diag(hipStream_t st, double* A, int K, int p, double shift)
     hipLaunchKernelGGL(k_add_diag, dim3((p + 255) / 256, K), dim3(256), 0, st, A, p, shift);
 }
 
+// d[k][i] = A[k][i][i]
+__global__ __launch_bounds__(256) void k_get_diag(const double* __restrict__ A, int p, double* __restrict__ d)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < p) d[(size_t)blockIdx.y * p + i] = A[(size_t)blockIdx.y * p * p + (size_t)i * p + i];
+}
+
+void launch_get_diag(hipStream_t st, const double* A, int K, int p, double* d)
+{
+    hipLaunchKernelGGL(k_get_diag, dim3((p + 255) / 256, K), dim3(256), 0, st, A, p, d);
+}
+
 // A_k = I for the K instances of a stack (ggl_reset_instance)
 __global__ __launch_bounds__(256) void k_set_identity(double* __restrict__ A, int p)
 {

@@ -67,6 +67,7 @@ struct ggl_ctx {
     double* sqwork = nullptr;                     // (ggl_chunks, p, p) per-chunk sums of squares
     bool has_mask = false;
     double* partials = nullptr;
+    double* partials_own = nullptr;               // a partials buffer grown beyond the arena's (ensure_partials)
     size_t partials_len = 0;
     double *norms = nullptr, *norms_h = nullptr;  // (K,8) device / pinned
     int* info_h = nullptr;                        // pinned (K)
@@ -143,6 +144,8 @@ struct ggl_ctx {
     // ggl_finalize_L: the L a solve RETURNS is rebuilt from one eigendecomposition of the last L-step's input C where that
     // L-step was the sign iteration (whose null space carries the iteration's residual, ~1e-13 |L|, instead of 1e-16 |L|).
     // rank_step keeps that C by swapping W with Ckeep (no copy); ggl_snapshot_k keeps the instance's C beside its L.
+    void *arena_dev = nullptr, *arena_pin = nullptr, *arena_pin_coh = nullptr;   // ctx_alloc: everything allocated at creation
+    double* Ckeep_alloc = nullptr;             // what hipMalloc returned for Ckeep (Ckeep and W swap NAMES: rank_step)
     double* Ckeep = nullptr;                   // (K,p,p) C = Theta - X - Omega of the last sign-iteration L-step, lazy
     double* Ckeep_beta = nullptr;              // host (K): mu1_k / rho of that step
     bool l_ns = false;                         // L is the sign iteration's (Ckeep valid); false once rebuilt / set / eigh route
@@ -277,81 +280,80 @@ extern "C" int ggl_device_count(void)
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
+// All buffers a ctx owns from its creation come out of THREE allocations -- one device arena, one pinned arena, one
+// fine-grained (coherent) pinned arena -- carved at 256-byte boundaries: a ctx used to take ~45 hipMalloc / hipHostMalloc calls
+// and, worse, as many hipFree calls (each a device synchronisation: ggl_ctx_destroy cost 5 ms, half of a whole ADMM_MGL call at
+// (20,200); tools/time_ctx.py).  Buffers that only some uses need (snapshots, ext state, deflation work, ...) stay lazy and own.
 static int ctx_alloc(ggl_ctx* c)
 {
     const size_t nb = c->n * sizeof(double);
     const size_t kp = (size_t)c->K * c->p;
-    HIPCHK(hipMalloc(&c->S, nb));
-    HIPCHK(hipMalloc(&c->Om[0], nb));
-    HIPCHK(hipMalloc(&c->Om[1], nb));
-    HIPCHK(hipMalloc(&c->Theta, nb));
-    HIPCHK(hipMalloc(&c->L, nb));
-    HIPCHK(hipMalloc(&c->X, nb));
-    HIPCHK(hipMalloc(&c->W, nb));
-    HIPCHK(hipMalloc(&c->DvO, kp * sizeof(double)));
-    HIPCHK(hipMalloc(&c->DvL, kp * sizeof(double)));
-    HIPCHK(hipMalloc(&c->scale, 2 * kp * sizeof(double)));
-    HIPCHK(hipMalloc(&c->E, kp * sizeof(double)));
-    HIPCHK(hipMalloc(&c->info, c->K * sizeof(int)));
-    HIPCHK(hipMalloc(&c->sweeps, c->K * sizeof(int)));
-    HIPCHK(hipMalloc(&c->par, 8 * (size_t)c->K * sizeof(double)));
-    HIPCHK(hipHostMalloc(&c->par_h, 8 * (size_t)c->K * sizeof(double)));
-    HIPCHK(hipMalloc(&c->mask, (size_t)c->p * c->p * sizeof(double)));
+    struct Req { void** pp; size_t bytes; int kind; };
+    std::vector<Req> reqs;
+#define DEV(ptr, bytes) reqs.push_back({(void**)&(ptr), (size_t)(bytes), 0})
+#define PIN(ptr, bytes, kind) reqs.push_back({(void**)&(ptr), (size_t)(bytes), (kind)})
+    DEV(c->S, nb);
+    DEV(c->Om[0], nb);
+    DEV(c->Om[1], nb);
+    DEV(c->Theta, nb);
+    DEV(c->L, nb);
+    DEV(c->X, nb);
+    DEV(c->W, nb);
+    DEV(c->DvO, kp * sizeof(double));
+    DEV(c->DvL, kp * sizeof(double));
+    DEV(c->scale, 2 * kp * sizeof(double));
+    DEV(c->E, kp * sizeof(double));
+    DEV(c->info, c->K * sizeof(int));
+    DEV(c->sweeps, c->K * sizeof(int));
+    DEV(c->par, 8 * (size_t)c->K * sizeof(double));
+    PIN(c->par_h, 8 * (size_t)c->K * sizeof(double), 1);
+    DEV(c->mask, (size_t)c->p * c->p * sizeof(double));
     // (p,p) + one trailing double: the speculation flag of K-sharded runs rides on the same all-reduce
-    HIPCHK(hipMalloc(&c->groupsq, ((size_t)c->p * c->p + 8) * sizeof(double)));
-    HIPCHK(hipMemsetAsync(c->groupsq, 0, ((size_t)c->p * c->p + 8) * sizeof(double), c->stream));
-    HIPCHK(hipMalloc(&c->sqwork, (size_t)ggl_chunks(c->K, c->p) * c->p * c->p * sizeof(double)));
+    DEV(c->groupsq, ((size_t)c->p * c->p + 8) * sizeof(double));
+    DEV(c->sqwork, (size_t)ggl_chunks(c->K, c->p) * c->p * c->p * sizeof(double));
     size_t pl = (size_t)c->K * elementwise_blocks(c->p) * GGL_NNORM;
     pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_GGL, c->K) * GGL_NNORM);
     pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_FGL, c->K) * GGL_NNORM);
     pl = std::max(pl, (size_t)theta_partial_blocks(c->p, GGL_REG_GGL, c->K, 1) * GGL_NNORM);
     pl = std::max(pl, (size_t)theta_partial_blocks(c->p, GGL_REG_GGL, c->K, 2) * GGL_NNORM);
     c->partials_len = pl;
-    HIPCHK(hipMalloc(&c->partials, pl * sizeof(double)));
+    DEV(c->partials, pl * sizeof(double));
     // (K,8) rows, and 2 * nprob * GGL_NNORM doubles for a batch of ext problems with ONE instance each (nprob = K)
     const size_t nl = (size_t)c->K * std::max(8, 2 * GGL_NNORM);
-    HIPCHK(hipMalloc(&c->norms, nl * sizeof(double)));
-    HIPCHK(hipHostMalloc(&c->norms_h, nl * sizeof(double), hipHostMallocCoherent));
-    HIPCHK(hipHostMalloc(&c->info_h, (size_t)c->K * sizeof(int)));
-    HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
-    HIPCHK(hipMemsetAsync(c->X, 0, nb, c->stream));
-    HIPCHK(hipMemsetAsync(c->Om[1], 0, nb, c->stream));
+    DEV(c->norms, nl * sizeof(double));
+    PIN(c->norms_h, nl * sizeof(double), 2);
+    PIN(c->info_h, (size_t)c->K * sizeof(int), 1);
     if (c->omega_ns) {
-        for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->nsYP[i], 2 * nb));
-        HIPCHK(hipMalloc(&c->nsT, nb));
+        for (int i = 0; i < 2; ++i) { DEV(c->nsYP[i], 2 * nb); }
+        DEV(c->nsT, nb);
         const size_t cl = (size_t)NS_MAX_LAUNCHES * NS_SLOT(c->K) * sizeof(double);   // last 3 slots: start / pre tables
-        HIPCHK(hipMalloc(&c->coef, cl));
-        HIPCHK(hipHostMalloc(&c->coef_h, cl));
+        DEV(c->coef, cl);
+        PIN(c->coef_h, cl, 1);
         const size_t bl = 2 * (size_t)c->K * sizeof(double);
-        HIPCHK(hipHostMalloc(&c->bounds_h, bl, hipHostMallocCoherent));
+        PIN(c->bounds_h, bl, 2);
         const size_t nbl = 3 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);   // + Collatz-Wielandt maxima
-        HIPCHK(hipMalloc(&c->nbrow, (size_t)c->K * c->p * sizeof(double)));
-        HIPCHK(hipMalloc(&c->cwvec[0], (size_t)c->K * c->p * sizeof(double)));
-        HIPCHK(hipMalloc(&c->cwvec[1], (size_t)c->K * c->p * sizeof(double)));
-        HIPCHK(hipMalloc(&c->nbpart, nbl));
+        DEV(c->nbrow, (size_t)c->K * c->p * sizeof(double));
+        DEV(c->cwvec[0], (size_t)c->K * c->p * sizeof(double));
+        DEV(c->cwvec[1], (size_t)c->K * c->p * sizeof(double));
+        DEV(c->nbpart, nbl);
         const size_t t32 = (c->p + 31) / 32;
-        HIPCHK(hipMalloc(&c->rowpart, (size_t)c->K * t32 * c->p * sizeof(double)));
-        HIPCHK(hipMalloc(&c->fropart, (size_t)c->K * (t32 * (t32 + 1) / 2) * sizeof(double)));
-        HIPCHK(hipMalloc(&c->infpart, (size_t)c->K * bound_rows_blocks(c->p) * sizeof(double)));
-        HIPCHK(hipMalloc(&c->cwmax, c->K * sizeof(unsigned long long)));
-        HIPCHK(hipMalloc(&c->cwcnt, c->K * sizeof(unsigned)));
-        HIPCHK(hipMemsetAsync(c->cwmax, 0, c->K * sizeof(unsigned long long), c->stream));
-        HIPCHK(hipMemsetAsync(c->cwcnt, 0, c->K * sizeof(unsigned), c->stream));
-        HIPCHK(hipMalloc(&c->cuse, c->K * sizeof(double)));
-        HIPCHK(hipHostMalloc(&c->cuse_h, c->K * sizeof(double)));
+        DEV(c->rowpart, (size_t)c->K * t32 * c->p * sizeof(double));
+        DEV(c->fropart, (size_t)c->K * (t32 * (t32 + 1) / 2) * sizeof(double));
+        DEV(c->infpart, (size_t)c->K * bound_rows_blocks(c->p) * sizeof(double));
+        DEV(c->cwmax, c->K * sizeof(unsigned long long));
+        DEV(c->cwcnt, c->K * sizeof(unsigned));
+        DEV(c->cuse, c->K * sizeof(double));
+        PIN(c->cuse_h, c->K * sizeof(double), 1);
         // the words the host polls / reads right after the poll: explicitly coherent (fine-grained) pinned memory, so a
         // device store is visible to the host without a stream synchronisation whatever HIP_HOST_COHERENT says
-        HIPCHK(hipHostMalloc(&c->seq_h, sizeof(unsigned long long), hipHostMallocCoherent));
-        *c->seq_h = 0;
-        HIPCHK(hipMalloc(&c->spec_flag, ggl_ctx::MAX_PARTS * sizeof(int)));
-        HIPCHK(hipMemset(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int)));
-        HIPCHK(hipHostMalloc(&c->spec_flag_h, ggl_ctx::MAX_PARTS * sizeof(int), hipHostMallocCoherent));
-        memset(c->spec_flag_h, 0, ggl_ctx::MAX_PARTS * sizeof(int));
+        PIN(c->seq_h, sizeof(unsigned long long), 2);
+        DEV(c->spec_flag, ggl_ctx::MAX_PARTS * sizeof(int));
+        PIN(c->spec_flag_h, ggl_ctx::MAX_PARTS * sizeof(int), 2);
         c->spec_c = (double*)malloc(c->K * sizeof(double));
         c->spec_beta = (double*)malloc(c->K * sizeof(double));
         c->pre_beta = (double*)malloc(c->K * sizeof(double));
-        HIPCHK(hipMalloc(&c->maxdev, 2 * c->K * sizeof(double)));          // [K] residuals | [K] traces of the sign iterate
-        HIPCHK(hipHostMalloc(&c->maxdev_h, 2 * c->K * sizeof(double)));
+        DEV(c->maxdev, 2 * c->K * sizeof(double));          // [K] residuals | [K] traces of the sign iterate
+        PIN(c->maxdev_h, 2 * c->K * sizeof(double), 1);
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < ggl_ctx::MAX_PARTS - 1; ++i) {
             HIPCHK(hipStreamCreateWithFlags(&c->streamx[i], hipStreamNonBlocking));
@@ -359,8 +361,36 @@ static int ctx_alloc(ggl_ctx* c)
         }
         c->rank_ns = !c->rank_eig;
     }
+#undef DEV
+#undef PIN
+    size_t tot[3] = {0, 0, 0};
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    for (const Req& r : reqs) tot[r.kind] += up(std::max<size_t>(r.bytes, 8));
+    HIPCHK(hipMalloc(&c->arena_dev, std::max<size_t>(tot[0], 256)));
+    HIPCHK(hipHostMalloc(&c->arena_pin, std::max<size_t>(tot[1], 256)));
+    HIPCHK(hipHostMalloc(&c->arena_pin_coh, std::max<size_t>(tot[2], 256), hipHostMallocCoherent));
+    size_t off[3] = {0, 0, 0};
+    char* base[3] = {(char*)c->arena_dev, (char*)c->arena_pin, (char*)c->arena_pin_coh};
+    for (const Req& r : reqs) {
+        *r.pp = base[r.kind] + off[r.kind];
+        off[r.kind] += up(std::max<size_t>(r.bytes, 8));
+    }
+    // initial contents
+    HIPCHK(hipMemsetAsync(c->groupsq, 0, ((size_t)c->p * c->p + 8) * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
+    HIPCHK(hipMemsetAsync(c->X, 0, nb, c->stream));
+    HIPCHK(hipMemsetAsync(c->Om[1], 0, nb, c->stream));
+    if (c->omega_ns) {
+        HIPCHK(hipMemsetAsync(c->cwmax, 0, c->K * sizeof(unsigned long long), c->stream));
+        HIPCHK(hipMemsetAsync(c->cwcnt, 0, c->K * sizeof(unsigned), c->stream));
+        *c->seq_h = 0;
+        HIPCHK(hipMemsetAsync(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int), c->stream));
+        memset(c->spec_flag_h, 0, ggl_ctx::MAX_PARTS * sizeof(int));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     return GGL_OK;
 }
+
 
 static int drop_prelaunch(ggl_ctx* c);
 
@@ -520,10 +550,11 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
         c->comm = nullptr;
     }
     // (the rocBLAS handle is the process-wide one of blas_handle(): never destroyed here)
-    double* bufs[] = {c->S, c->Om[0], c->Om[1], c->Theta, c->L, c->X, c->W, c->DvO, c->DvL, c->scale,
-                      c->E, c->par, c->mask, c->groupsq, c->partials, c->norms, c->nsYP[0], c->nsYP[1],
-                      c->nsT, c->nsNX, c->coef, c->sqwork, c->nbpart, c->maxdev, c->nbrow, c->snapT, c->snapL, c->cuse, c->Lam[0],
-                      c->Lam[1], c->X1, c->cwvec[0], c->cwvec[1], c->Ckeep, c->snapC, c->defl_G, c->defl_work, c->defl_meta};
+    // lazily allocated buffers, each its own allocation
+    double* lazy[] = {c->partials_own, c->nsNX, c->snapT, c->snapL, c->Lam[0], c->Lam[1], c->X1, c->Ckeep_alloc, c->snapC, c->defl_G,
+                      c->defl_work, c->defl_meta, c->maskK};
+    for (double* b : lazy)
+        if (b) (void)hipFree(b);
     if (c->defl_meta_h) (void)hipHostFree(c->defl_meta_h);
     free(c->Ckeep_beta);
     free(c->failed);
@@ -532,29 +563,16 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize, c->inst_pk, c->rank_idx})
         if (b) (void)hipFree(b);
     if (c->rank_idx_h) (void)hipHostFree(c->rank_idx_h);
-    if (c->maskK) (void)hipFree(c->maskK);
     for (double* b : c->snap)
         if (b) (void)hipFree(b);
-    for (void* b : {(void*)c->rowpart, (void*)c->fropart, (void*)c->infpart, (void*)c->cwmax, (void*)c->cwcnt})
-        if (b) (void)hipFree(b);
-    if (c->spec_flag) (void)hipFree(c->spec_flag);
     if (c->chain_cnt) (void)hipFree(c->chain_cnt);
-    if (c->cuse_h) (void)hipHostFree(c->cuse_h);
-    if (c->seq_h) (void)hipHostFree(c->seq_h);
-    if (c->spec_flag_h) (void)hipHostFree(c->spec_flag_h);
     free(c->spec_c);
     free(c->spec_beta);
     free(c->pre_beta);
-    if (c->maxdev_h) (void)hipHostFree(c->maxdev_h);
-    if (c->coef_h) (void)hipHostFree(c->coef_h);
-    if (c->bounds_h) (void)hipHostFree(c->bounds_h);
-    for (double* b : bufs)
-        if (b) (void)hipFree(b);
-    if (c->info) (void)hipFree(c->info);
-    if (c->sweeps) (void)hipFree(c->sweeps);
-    if (c->par_h) (void)hipHostFree(c->par_h);
-    if (c->norms_h) (void)hipHostFree(c->norms_h);
-    if (c->info_h) (void)hipHostFree(c->info_h);
+    // everything ctx_alloc handed out: three allocations
+    if (c->arena_dev) (void)hipFree(c->arena_dev);
+    if (c->arena_pin) (void)hipHostFree(c->arena_pin);
+    if (c->arena_pin_coh) (void)hipHostFree(c->arena_pin_coh);
     for (int ph = 0; ph < GGL_NPHASE; ++ph)
         for (int e = 0; e < 2; ++e)
             if (c->ev[ph][e]) (void)hipEventDestroy(c->ev[ph][e]);
@@ -1362,7 +1380,8 @@ static int rank_step(ggl_ctx* c)
         // keep C for ggl_finalize_L: W is scratch that every step forms anew, so the two stacks swap names (the stream was
         // synchronised by the step's checks; a latent step neither speculates nor pre-launches, nothing in flight holds W)
         if (!c->Ckeep) {
-            HIPCHK(hipMalloc(&c->Ckeep, c->n * sizeof(double)));
+            HIPCHK(hipMalloc(&c->Ckeep_alloc, c->n * sizeof(double)));
+            c->Ckeep = c->Ckeep_alloc;
             c->Ckeep_beta = (double*)malloc(c->K * sizeof(double));
         }
         std::swap(c->W, c->Ckeep);
@@ -1884,10 +1903,13 @@ static int ensure_partials(ggl_ctx* c, size_t need)
 {
     if (need <= c->partials_len) return GGL_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipFree(c->partials);
+    // (the first partials buffer is part of the ctx's device arena: only a grown one is an allocation of its own)
+    if (c->partials_own) (void)hipFree(c->partials_own);
+    c->partials_own = nullptr;
     c->partials = nullptr;
     c->partials_len = 0;
-    HIPCHK(hipMalloc(&c->partials, need * sizeof(double)));
+    HIPCHK(hipMalloc(&c->partials_own, need * sizeof(double)));
+    c->partials = c->partials_own;
     c->partials_len = need;
     return GGL_OK;
 }
@@ -2503,10 +2525,25 @@ extern "C" int ggl_objective(ggl_ctx* c, double lambda1, double lambda2, int reg
     const size_t kp = (size_t)c->K * c->p;
     std::vector<double> d(kp);
     const bool from_w = c->dvo_valid;
+    bool from_chol = false;
     if (!from_w) {
+        // log det Omega_k = 2 sum_i log R_ii of the Cholesky factor (Omega = phiplus(...) is positive definite by construction):
+        // one batched potrf instead of the eigenvalues -- measure=True evaluates this EVERY iteration, and the eigenvalues cost
+        // 20 ms against a 0.8 ms iteration at (32,500) (tools/time_ctx.py).  A failed factorisation (a non-finite iterate)
+        // falls back to the eigenvalues, whose logarithms then say what went wrong.
         HIPCHK(hipMemcpyAsync(c->W, c->Om[c->cur], c->n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        int rc0 = eigvals_only(c, c->W, c->DvO);
+        std::vector<unsigned char> ok(c->K);
+        int rc0 = chol_pd_k(c, c->W, ok.data());
         if (rc0) return rc0;
+        from_chol = true;
+        for (int k = 0; k < c->K; ++k) from_chol = from_chol && ok[k];
+        if (from_chol) {
+            launch_get_diag(c->stream, c->W, c->K, c->p, c->DvO);
+        } else {
+            HIPCHK(hipMemcpyAsync(c->W, c->Om[c->cur], c->n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            rc0 = eigvals_only(c, c->W, c->DvO);
+            if (rc0) return rc0;
+        }
     }
     HIPCHK(hipMemcpyAsync(d.data(), c->DvO, kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     launch_dot(c->stream, c->Om[c->cur], c->S, c->K, c->p, c->partials);
@@ -2519,7 +2556,7 @@ extern "C" int ggl_objective(ggl_ctx* c, double lambda1, double lambda2, int reg
         const double beta = c->par_h[k];
         for (int m = 0; m < c->p; ++m) {
             const double dv = d[(size_t)k * c->p + m];
-            ld -= from_w ? std::log(0.5 * (std::sqrt(dv * dv + 4.0 * beta) + dv)) : std::log(dv);
+            ld -= from_w ? std::log(0.5 * (std::sqrt(dv * dv + 4.0 * beta) + dv)) : (from_chol ? 2.0 * std::log(dv) : std::log(dv));
         }
     }
     out[0] = ld;

@@ -59,6 +59,7 @@ void launch_count_nonzero(hipStream_t st, const double* A, int K, int p, double*
 // dst[i] = src[idx[i]] (gather) or dst[idx[i]] = src[i] (scatter) for m instances of pp doubles
 void launch_set_identity(hipStream_t st, double* A, int K, int p);
 void launch_add_diag(hipStream_t st, double* A, int K, int p, double shift);
+void launch_get_diag(hipStream_t st, const double* A, int K, int p, double* d);
 void launch_copy_instances(hipStream_t st, double* dst, const double* src, const int* idx, int m, size_t pp, bool scatter);
 // out[k] = trace(A_k) - shift, summed in a fixed order
 void launch_trace(hipStream_t st, const double* A, int K, int p, double shift, double* out);
