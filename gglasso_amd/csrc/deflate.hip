@@ -103,7 +103,7 @@ template <int MODE>
 static void launch_tall(hipStream_t st, const double* A, const double* Vin, size_t vin_stride, const double* G, size_t g_stride,
                         const double* muK, double* Vout, int K, int p, const double* meta = nullptr, int need = 0)
 {
-    const int rpb = 32;
+    const int rpb = 16;
     const size_t lds = (size_t)DEFL_Q * p * sizeof(double);
     static bool attr = false;
     if (!attr) {

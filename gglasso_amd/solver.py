@@ -742,7 +742,8 @@ def get_connected_components(S, lambda1):
 
 
 # upper edges of the size classes whose connected components share one padded stack in block_SGL (ratio ~1.5: a component
-# is padded by at most that factor; 128 is the LDS-Jacobi limit, so small components never leave that kernel)
+# is padded by at most that factor; 128 was the LDS-Jacobi limit when the edges were chosen -- since round 4 every bucket above 8
+# runs the matrix-function route, the edges only bound the padding)
 BLOCK_BUCKETS = (4, 6, 9, 13, 19, 28, 42, 63, 94, 128, 192, 288, 432, 648, 972, 1458, 2187, 3281, 4922, 7383, 11075)
 
 
