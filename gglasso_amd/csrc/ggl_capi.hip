@@ -101,6 +101,8 @@ struct ggl_ctx {
                                                // (measured at p = 500: K = 8 +7.6 % iterations/s as 4 + 4, K = 4 -2.4 % as 2 + 2)
     bool fused_start = true;                   // speculative step: first step's start matrix as 2nd output of the B' launch
     bool fused_bounds = true;                  // spectral-bound partials from the epilogue of the B' launch (GGL_OPT_FUSED_BOUNDS)
+    bool fused_cw = false;                     // k_bound_rows + k_cw_final as ONE launch (GGL_OPT_FUSED_CW): measured, no gain
+                                               // (K=4: 4654 / 4892 vs 4602 / 4774 it/s; headline -6 %): opt-in, DESIGN 9.7
     int theta_flat = 2;                        // GGL Theta-step for symmetric states: 0 tile pairs, 1 per-element kernel, 2 per-element with the K-column over four waves
     bool state_symmetric = true;               // X and L exactly symmetric (checked when the state is set)
     // speculative Omega-step: the schedule is built from the PREVIOUS iteration's spectral bounds (inflated) and the
@@ -426,6 +428,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_CW_WARM: c->cw_warm = v != 0.0; break;
         case GGL_OPT_CHAIN: c->chain_mode = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
         case GGL_OPT_ISOLATE: c->isolate = v != 0.0; break;
+        case GGL_OPT_FUSED_CW: c->fused_cw = v != 0.0; break;
         case GGL_OPT_RANK_DEFLATE: c->rank_deflate = v != 0.0; break;
         case GGL_OPT_RANK_L0_DEFLATE:
             if (!(v > 0.0) || v > 0.1) return fail(GGL_E_ARG, "bad argument: GGL_OPT_RANK_L0_DEFLATE is in (0, 0.1]");
@@ -475,6 +478,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_CHAIN: *value = c->chain_mode; break;
         case GGL_OPT_RANK_L0_COARSE: *value = c->rank_l0_coarse; break;
         case GGL_OPT_ISOLATE: *value = c->isolate; break;
+        case GGL_OPT_FUSED_CW: *value = c->fused_cw; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
@@ -1149,6 +1153,13 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             ns_prepare(sh, pre_d + NS_NCOEF * (size_t)k0, pre_d + NS_SLOT(K) + NS_NCOEF * (size_t)k0, c->W + k0 * pp, Ap, Bp, Kh[h], c->p,
                        var_parts, spec ? fused[h] : nullptr, rowp, frop);
             if (btile) {
+                if (c->fused_cw) {
+                    launch_bound_cw(sh, Bp, rowp, bT, Kh[h], c->p, c->nbrow + (size_t)k0 * c->p, frop, bT * (bT + 1) / 2,
+                                    c->cwmax + k0, c->cwcnt + k0, c->bounds_h + k0, spec ? c->cuse + k0 : nullptr,
+                                    spec ? c->spec_flag : nullptr, spec ? c->spec_flag_h : nullptr, h,
+                                    (c->cw_warm && c->cw_have) ? c->cwvec[c->cw_cur] + (size_t)k0 * c->p : nullptr,
+                                    c->cw_warm ? c->cwvec[c->cw_cur ^ 1] + (size_t)k0 * c->p : nullptr);
+                } else {
                 const int nib = bound_rows_blocks(c->p);
                 launch_bound_rows(sh, rowp, bT, Kh[h], c->p, c->nbrow + (size_t)k0 * c->p, c->infpart + (size_t)k0 * nib);
                 launch_cw_final(sh, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p, c->infpart + (size_t)k0 * nib, frop,
@@ -1156,6 +1167,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                                 spec ? c->spec_flag : nullptr, spec ? c->spec_flag_h : nullptr, h,
                                 (c->cw_warm && c->cw_have) ? c->cwvec[c->cw_cur] + (size_t)k0 * c->p : nullptr,
                                 c->cw_warm ? c->cwvec[c->cw_cur ^ 1] + (size_t)k0 * c->p : nullptr);
+                }
                 cw_written = c->cw_warm;
             } else {
                 double* nb2 = c->nbpart + 2 * (size_t)k0 * nbb;
@@ -2080,7 +2092,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->symm_variant = src->symm_variant; c->spin_wait = src->spin_wait; c->fused_bounds = src->fused_bounds;
     c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->ns_tol = src->ns_tol;
     c->cw_warm = src->cw_warm; c->chain_mode = src->chain_mode; c->rank_l0 = src->rank_l0; c->rank_l0_coarse = src->rank_l0_coarse;
-    c->isolate = src->isolate; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
+    c->isolate = src->isolate; c->fused_cw = src->fused_cw; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
     int* didx = nullptr;
     hipError_t e = hipMalloc(&didx, m * sizeof(int));
     if (e == hipSuccess) e = hipMemcpyAsync(didx, idx, m * sizeof(int), hipMemcpyHostToDevice, src->stream);

@@ -354,6 +354,10 @@ void launch_bound_final(hipStream_t st, const double* part2, const double* cwpar
 // Collatz-Wielandt pass with the final reduction done by the last workgroup of every instance
 int bound_rows_blocks(int p);
 void launch_bound_rows(hipStream_t st, const double* rowpart, int T, int K, int p, double* d, double* infpart);
+// launch_bound_rows + launch_cw_final as one launch (the speculative Omega-step's bound validation)
+void launch_bound_cw(hipStream_t st, const double* B, const double* rowpart, int T, int K, int p, double* d_out,
+                     const double* fropart, int ntile, unsigned long long* cwmax, unsigned* cnt, double* out,
+                     const double* cuse, int* flag, int* flag_host, int flag_slot, const double* dprev, double* dnext);
 void launch_cw_final(hipStream_t st, const double* B, const double* d, int K, int p, const double* infpart,
                      const double* fropart, int ntile, unsigned long long* cwmax, unsigned* cnt, double* out,
                      const double* cuse, int* flag, int* flag_host, int flag_slot, const double* dprev = nullptr,

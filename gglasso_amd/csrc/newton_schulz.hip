@@ -982,6 +982,123 @@ void launch_cw_final(hipStream_t st, const double* B, const double* d, int K, in
                        bound_rows_blocks(p), fropart, ntile, cwmax, cnt, out, cuse, flag, flag_host, flag_slot);
 }
 
+// k_bound_rows + k_cw_final as ONE launch (round 4, VERDICT r3 item 6: the K = 4 slab's iteration carried the two as 5.7 + 14.2
+// us of its 216): every workgroup adds up the row sums d_j = sum_s rowpart[k][s][j] of ITS instance itself (T * p loads out of
+// L2 -- 64 KB at p = 500 -- against a kernel boundary) and takes |B'|_inf = max_j d_j from them; RW rows per wave instead of
+// four (a slab of K = 4 has 2000 rows: 125 workgroups of 16 rows were half a workgroup per CU); the last workgroup of an
+// instance sums the Frobenius shares with all its threads (fixed order) instead of one.  Same arithmetic, same bound, same bits
+// in the Collatz-Wielandt vector as the two-kernel form.  MEASURED (interleaved A/B, bench.py --opt fused_cw=0/1): K = 4 slab
+// 4654 / 4892 it/s without against 4602 / 4774 with, K = 8 3158 / 3258 against 3178 / 3358, (20,200) 5270 / 5340 against 5384 /
+// 5267, headline 1340 / 1307 against 1214 / 1253 -- no gain where it was meant to help, a loss where the bound kernels run in
+// the shadow of the other part's products (every workgroup re-adding the row sums is work on the chain's critical path).
+// GGL_OPT_FUSED_CW, default off.
+template <int RW>
+__global__ __launch_bounds__(256) void k_bound_cw(const double* __restrict__ B, const double* __restrict__ rowpart, int T,
+                                                  double* __restrict__ d_out, const double* __restrict__ dprev,
+                                                  double* __restrict__ dnext, int p, const double* __restrict__ fropart,
+                                                  int ntile, unsigned long long* __restrict__ cwmax, unsigned* __restrict__ cnt,
+                                                  double* __restrict__ out, const double* __restrict__ cuse,
+                                                  int* __restrict__ flag, int* __restrict__ flag_host, int flag_slot)
+{
+    extern __shared__ __attribute__((aligned(16))) double dl[];          // [p] row sums | [8] scratch
+    double* sh = dl + p;
+    __shared__ int last;
+    const int k = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double mxd = 0.0;
+    for (int j = threadIdx.x; j < p; j += 256) {
+        const double* rp = rowpart + (size_t)k * T * p + j;
+        double v = 0.0;
+        for (int s2 = 0; s2 < T; ++s2) v += rp[(size_t)s2 * p];
+        dl[j] = v;
+        mxd = fmax(mxd, v);
+        if (blockIdx.x == 0 && d_out) d_out[(size_t)k * p + j] = v;
+    }
+    mxd = wave_max(mxd);
+    if (lane == 0) sh[wave] = mxd;
+    __syncthreads();
+    const double inf0 = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    __syncthreads();
+    const double scale = 1.0 / inf0;
+    const double* dg = dprev ? dprev + (size_t)k * p : nullptr;
+    const int r0 = (blockIdx.x * 4 + wave) * RW;
+    const double* w = B + (size_t)k * p * p;
+    double a[RW];
+    size_t ro[RW];
+    bool ok[RW];
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+        a[q] = 0.0;
+        ok[q] = (r0 + q) < p;
+        ro[q] = (size_t)min(r0 + q, p - 1) * p;
+    }
+    for (int j = lane; j < p; j += 64) {
+        const double dj = dg ? dg[j] : dl[j];
+#pragma unroll
+        for (int q = 0; q < RW; ++q) a[q] += fabs(w[ro[q] + j]) * dj;
+    }
+    double mx = 0.0;
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+        const double y = wave_sum(a[q]);
+        if (ok[q]) {
+            mx = fmax(mx, y / (dg ? dg[r0 + q] : dl[r0 + q]));       // a zero row gives 0/0: fmax drops the NaN
+            if (dnext && lane == 0) {
+                const double v = y * scale;                           // anything positive keeps the bound rigorous
+                dnext[(size_t)k * p + r0 + q] = (v > 0.0 && isfinite(v)) ? v : 1.0;
+            }
+        }
+    }
+    if (lane == 0) sh[wave] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+        // (agent-scope atomics carry everything the workgroups exchange: see k_cw_final)
+        const unsigned long long old =
+            __hip_atomic_fetch_max(cwmax + k, (unsigned long long)__double_as_longlong(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned arrive = 1u + (unsigned)(old >> 63);
+        last = (__hip_atomic_fetch_add(cnt + k, arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    // last workgroup of instance k: |B'|_F^2 in a fixed order (strided per-thread sums, wave sums, four waves)
+    double sq = 0.0;
+    for (int t = threadIdx.x; t < ntile; t += 256) sq += fropart[(size_t)k * ntile + t];
+    sq = wave_sum(sq);
+    __syncthreads();
+    if (lane == 0) sh[wave] = sq;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    sq = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    const double cw = __longlong_as_double((long long)__hip_atomic_exchange(cwmax + k, 0ull, __ATOMIC_RELAXED,
+                                                                            __HIP_MEMORY_SCOPE_AGENT));
+    __hip_atomic_store(cnt + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double inf = inf0;
+    const double fr = sqrt(sq);
+    if (isfinite(cw) && cw > 0.0) { const double wv = cw * (1.0 + 1e-12); inf = (wv < inf) ? wv : inf; }
+    const double b = sqrt((fr < inf) ? fr : inf);
+    out[k] = b;
+    if (flag && !(b <= cuse[k])) {
+        atomicOr(flag + flag_slot, 1);
+        flag_host[flag_slot] = 1;
+    }
+}
+
+void launch_bound_cw(hipStream_t st, const double* B, const double* rowpart, int T, int K, int p, double* d_out,
+                     const double* fropart, int ntile, unsigned long long* cwmax, unsigned* cnt, double* out,
+                     const double* cuse, int* flag, int* flag_host, int flag_slot, const double* dprev, double* dnext)
+{
+    const size_t lds = ((size_t)p + 8) * sizeof(double);
+    // rows per workgroup: 16 while that still gives every CU a few workgroups, 4 for the small slabs
+    const long wg16 = (long)((p + 15) / 16) * K;
+    if (wg16 >= 1024)
+        hipLaunchKernelGGL(k_bound_cw<4>, dim3((p + 15) / 16, K), dim3(256), lds, st, B, rowpart, T, d_out, dprev, dnext, p, fropart,
+                           ntile, cwmax, cnt, out, cuse, flag, flag_host, flag_slot);
+    else
+        hipLaunchKernelGGL(k_bound_cw<1>, dim3((p + 3) / 4, K), dim3(256), lds, st, B, rowpart, T, d_out, dprev, dnext, p, fropart,
+                           ntile, cwmax, cnt, out, cuse, flag, flag_host, flag_slot);
+}
+
 void launch_cw_bounds(hipStream_t st, const double* W, const double* rowsum, int K, int p, double* part)
 {
     hipLaunchKernelGGL(k_cw_bounds, dim3(norm_bounds_blocks(p), K), dim3(256), 0, st, W, rowsum, p, part);

@@ -122,6 +122,8 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_RANK_DEFLATE 20    /* [1] L-step (sign iteration): after a first pass at GGL_OPT_RANK_L0_DEFLATE the eigenvalues next to the
                                       threshold are deflated (range of I - X^2, exact small problem) instead of iterated down */
 #define GGL_OPT_RANK_L0_DEFLATE 21 /* [2e-3] resolution of that first pass */
+#define GGL_OPT_FUSED_CW 22        /* [0] the bound validation of a speculative Omega-step (row sums + Collatz-Wielandt pass) as ONE launch:
+                                      built in round 4 for the small slabs, measured equal there and slower at the headline */
 #define GGL_OPT_ISOLATE 19         /* [0] batches of independent problems: an instance whose data turn non-finite or whose eigensolver
                                       does not converge is marked (ggl_failed_instances) instead of failing the call */
 #define GGL_OPT_RANK_L0_COARSE 18  /* [8e-5] two-tier L-step (sign iteration, p > GGL_JACOBI_MAX_P): the first pass over the whole batch
