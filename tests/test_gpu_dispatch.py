@@ -261,3 +261,23 @@ def test_headline_slab_dispatch(stats, K):
     _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
     st = stats[-1]
     assert (st["last_parts"], st["last_variant"]) == {4: (1, 20), 8: (2, 20), 16: (1, 20)}[K], st
+
+
+def test_large_p_sgl_latent_p1500(stats):
+    """A single large matrix (ADMM_SGL, p = 1500, latent; single_admm_solver.py:157-214): the sizes the reference's own
+    benchmarks run (p = 1000 .. 5000) -- three iterations against the oracle, through the Newton-Schulz Omega-step, the
+    deflating L-step at a basis of 8 x 1500 doubles per instance and ggl_finalize_L with rocSOLVER."""
+    from gglasso_amd import solver, synth
+    p = 1500
+    S, _ = synth.make_problem("GGL", 1, p, N=2 * p, seed=1244)
+    kw = dict(max_iter=3, tol=1e-20, rtol=1e-20, latent=True, mu1=0.8)
+    with oracle_threads():
+        ref, _ = quiet(orc.ADMM_SGL, S[0], 0.05, np.eye(p), **kw)
+    out, _ = quiet(solver.ADMM_SGL, S[0], 0.05, np.eye(p), **kw)
+    for nm in ("Omega", "Theta", "L", "X"):
+        err = float(np.abs(out[nm] - ref[nm]).max())
+        assert err <= 1e-9 * max(1.0, float(np.abs(ref[nm]).max())), (nm, err)
+    with oracle_threads():
+        assert np.linalg.matrix_rank(out["L"]) == np.linalg.matrix_rank(ref["L"])
+    st = stats[-1]
+    assert st["rank_calls"] == 3 and st["rank_deflated_calls"] >= 1 and st["dispatch_finalize_calls"] == 1, st
