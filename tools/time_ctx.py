@@ -18,7 +18,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gglasso_amd import _lib, solver, synth, ADMM_MGL
 
 lib = _lib.load()
-for K, p in ((4, 500), (32, 500), (20, 200), (64, 100), (3, 50)):
+import sys as _s
+CASES = [tuple(int(v) for v in a.split(':')) for a in _s.argv[1:]] or [(4, 500), (32, 500), (20, 200), (64, 100), (3, 50)]
+for K, p in CASES:
     S, _ = synth.make_problem("GGL", K, p, N=2 * p, seed=1)
     eye = np.repeat(np.eye(p)[None], K, axis=0)
     Z = np.zeros_like(S)
