@@ -65,7 +65,8 @@ WORKLOADS = {
 VARIANT_NAMES = {0: "k_symm_tn<64,16,32,32> (register-staged)", 9: "k_symm_tn<32,32,16,16> (register-staged)",
                  40: "k_omega_chain<16,3,64> (persistent product chain, per-instance dependencies; 64x64 direct-to-LDS tiles)",
                  16: "k_symm_dl<16,2,0,64> (direct-to-LDS)", 17: "k_symm_dl<16,3,0,64> (direct-to-LDS)",
-                 20: "k_symm_dl<32,2,0,32> (direct-to-LDS, 32x32 tiles)"}
+                 20: "k_symm_dl<32,2,0,32> (direct-to-LDS, 32x32 tiles)",
+                 41: "k_omega_lds<PT> (p <= 64: the whole Omega-step in one launch, one workgroup per instance, chain resident in LDS)"}
 
 
 def phase_model(phase, reg, K, p, latent, eig_jacobi, omega_ns=False):
@@ -452,7 +453,8 @@ def main():
         # what the library dispatched in its last matrix-function step (ggl_ns_stats), not a copy of its rules
         parts, variant = ns1["last_parts"], ns1["last_variant"]
         ns_kernel = VARIANT_NAMES.get(variant, f"product-kernel variant {variant}")
-        kernel_name = {"eig_omega": ns_kernel + " -- Newton-Schulz product" if omega_ns else
+        kernel_name = {"eig_omega": ns_kernel + (" -- W, bound, schedule and all Newton-Schulz products" if variant == 41 else
+                                                 " -- Newton-Schulz product") if omega_ns else
                        ("k_jacobi" if eig_jacobi else "rocsolver_dsyevd (library, many kernels)"),
                        "theta": "k_theta_ggl" if reg == "GGL" else ("k_theta_fgl" if reg == "FGL" else "k_theta_sgl"),
                        "allreduce_groupsq": "ncclAllReduce (p,p)+1 fp64", "allreduce_norms": "ncclAllReduce 5 fp64",

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libggl_hip.so")
-SOURCES = ["elementwise.hip", "theta_pair.hip", "ext_group.hip", "eig_jacobi.hip", "recon_gemm.hip", "gemm_sym.hip", "gemm_i8.hip", "deflate.hip", "newton_schulz.hip", "ggl_capi.hip", "ggl_comm.hip", "probes_dev.hip"]
+SOURCES = ["elementwise.hip", "theta_pair.hip", "ext_group.hip", "eig_jacobi.hip", "recon_gemm.hip", "gemm_sym.hip", "gemm_i8.hip", "deflate.hip", "omega_lds.hip", "newton_schulz.hip", "ggl_capi.hip", "ggl_comm.hip", "probes_dev.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "ggl_comm.hpp", os.path.join("..", "..", "include", "ggl_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs; without it hipcc 7.2 shuttles the f64

@@ -101,6 +101,14 @@ struct ggl_ctx {
                                                // (measured at p = 500: K = 8 +7.6 % iterations/s as 4 + 4, K = 4 -2.4 % as 2 + 2)
     bool fused_start = true;                   // speculative step: first step's start matrix as 2nd output of the B' launch
     bool fused_bounds = true;                  // spectral-bound partials from the epilogue of the B' launch (GGL_OPT_FUSED_BOUNDS)
+    // small matrices: the whole Omega-step as ONE launch with the chain resident in LDS (omega_lds.hip, GGL_OPT_OMEGA_LDS)
+    bool lds_omega = true;
+    double* lds_tab = nullptr;                 // device: schedule table + the two counters behind it (lazy)
+    int lds_ntab = 0, lds_tab_deg = -1;
+    double lds_lnq = 0.0, lds_tab_tol = -1.0;
+    long long lds_calls = 0, lds_misses = 0;
+    int lds_cool = 0, lds_cool_next = 4;       // launches to sit out after an instance fell outside the kernel's range (doubles per miss)
+    bool lds_last = false;                     // the Omega-step launched last was the LDS kernel
     bool fused_cw = false;                     // k_bound_rows + k_cw_final as ONE launch (GGL_OPT_FUSED_CW): measured, no gain
                                                // (K=4: 4654 / 4892 vs 4602 / 4774 it/s; headline -6 %): opt-in, DESIGN 9.7
     int theta_flat = 2;                        // GGL Theta-step for symmetric states: 0 tile pairs, 1 per-element kernel, 2 per-element with the K-column over four waves
@@ -429,6 +437,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_CHAIN: c->chain_mode = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
         case GGL_OPT_ISOLATE: c->isolate = v != 0.0; break;
         case GGL_OPT_FUSED_CW: c->fused_cw = v != 0.0; break;
+        case GGL_OPT_OMEGA_LDS: c->lds_omega = v != 0.0; break;
         case GGL_OPT_RANK_DEFLATE: c->rank_deflate = v != 0.0; break;
         case GGL_OPT_RANK_L0_DEFLATE:
             if (!(v > 0.0) || v > 0.1) return fail(GGL_E_ARG, "bad argument: GGL_OPT_RANK_L0_DEFLATE is in (0, 0.1]");
@@ -479,6 +488,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_RANK_L0_COARSE: *value = c->rank_l0_coarse; break;
         case GGL_OPT_ISOLATE: *value = c->isolate; break;
         case GGL_OPT_FUSED_CW: *value = c->fused_cw; break;
+        case GGL_OPT_OMEGA_LDS: *value = c->lds_omega; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
@@ -555,7 +565,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     }
     // (the rocBLAS handle is the process-wide one of blas_handle(): never destroyed here)
     // lazily allocated buffers, each its own allocation
-    double* lazy[] = {c->partials_own, c->nsNX, c->snapT, c->snapL, c->Lam[0], c->Lam[1], c->X1, c->Ckeep_alloc, c->snapC, c->defl_G,
+    double* lazy[] = {c->partials_own, c->nsNX, c->lds_tab, c->snapT, c->snapL, c->Lam[0], c->Lam[1], c->X1, c->Ckeep_alloc, c->snapC, c->defl_G,
                       c->defl_work, c->defl_meta, c->maskK};
     for (double* b : lazy)
         if (b) (void)hipFree(b);
@@ -947,6 +957,33 @@ extern "C" int ggl_step_omega_spec(ggl_ctx* c, double rho, int latent, const dou
     return omega_step(c, latent, &sg, c->ns_parts < ggl_ctx::MAX_PARTS);
 }
 
+// the LDS-resident Omega-step's schedule table for the ctx's stopping tolerance / degree set (rebuilt when they change)
+static int lds_table(ggl_ctx* c)
+{
+    if (c->lds_tab && c->lds_tab_tol == c->ns_tol && c->lds_tab_deg == c->ns_degrees) return GGL_OK;
+    const size_t nt = (size_t)OMEGA_LDS_MAXTAB * OMEGA_LDS_ENT;
+    if (!c->lds_tab) {
+        HIPCHK(hipMalloc(&c->lds_tab, (nt + 2) * sizeof(double)));
+        HIPCHK(hipMemsetAsync(c->lds_tab + nt, 0, 2 * sizeof(double), c->stream));
+    }
+    std::vector<double> tab(nt, 0.0);
+    c->lds_ntab = omega_lds_build_table(c->ns_tol, c->ns_degrees, tab.data(), OMEGA_LDS_MAXTAB, &c->lds_lnq);
+    if (c->lds_ntab < 1) return fail(GGL_E_SOLVER, "LDS Omega-step: empty schedule table");
+    HIPCHK(hipStreamSynchronize(c->stream));           // (a launch still reading the old table)
+    HIPCHK(hipMemcpy(c->lds_tab, tab.data(), nt * sizeof(double), hipMemcpyHostToDevice));
+    c->lds_tab_tol = c->ns_tol;
+    c->lds_tab_deg = c->ns_degrees;
+    return GGL_OK;
+}
+
+static void lds_missed(ggl_ctx* c)
+{
+    c->lds_misses += 1;
+    c->lds_cool = c->lds_cool_next;
+    c->lds_cool_next = std::min(2 * c->lds_cool_next, 64);
+    c->lds_last = false;
+}
+
 // Omega-step with beta_k in parameter slot 0 (already on the device, or part of the pending transfer)
 static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec, bool only_spec)
 {
@@ -1015,6 +1052,62 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             HIPCHK(hipMemsetAsync(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int), c->stream));
             for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) c->spec_flag_h[h] = 0;
             c->flags_dirty = false;
+        }
+        // ---- small matrices: the whole step as ONE launch, one workgroup per instance, the chain resident in LDS ----------
+        // The kernel finds bound and schedule itself, so it needs no host round trip: where the caller can repeat a step
+        // (allow_spec) it runs like a speculative chain -- an instance outside its range (kappa > 300, non-finite data)
+        // raises validation flag 0, the Theta-step leaves the iterate alone and the step is repeated on the launch chain --
+        // elsewhere the flag is read back after a stream synchronisation.
+        c->lds_last = false;
+        if (c->lds_omega && c->p <= omega_lds_max_p() && c->ns_force == 0 && c->symm_variant < 0 && !c->chain_mode) {
+            const bool as_spec = allow_spec && c->spec_enable && !latent;
+            if (c->lds_cool > 0) {
+                if (!only_spec) c->lds_cool -= 1;
+            } else if (as_spec || !only_spec) {
+                rc = lds_table(c);
+                if (rc) return rc;
+                CopySegs sg = first;
+                sg.add(c->spec_flag, nullptr, sizeof(int));
+                sg.add(c->spec_flag + ggl_ctx::MAX_PARTS - 1, nullptr, sizeof(int));
+                c->spec_flag_h[0] = c->spec_flag_h[ggl_ctx::MAX_PARTS - 1] = 0;
+                if (c->info_dirty) sg.add(c->info, nullptr, K * sizeof(int));
+                launch_copy_small(c->stream, sg);
+                PB(c, GGL_PH_EIG_OMEGA);
+                unsigned long long* cnt = (unsigned long long*)(c->lds_tab + (size_t)OMEGA_LDS_MAXTAB * OMEGA_LDS_ENT);
+                if (!launch_omega_lds(c->stream, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->Om[nxt], c->lds_tab,
+                                      c->lds_ntab, c->lds_lnq, K, c->p, c->spec_flag, c->spec_flag_h, 0, cnt, c->bounds_h))
+                    return fail(GGL_E_HIP, "k_omega_lds: p = %d outside the kernel's range", c->p);
+                PE(c, GGL_PH_EIG_OMEGA);
+                HIPCHK(hipGetLastError());
+                c->last_parts = 1;
+                c->last_variant = 41;
+                c->lds_calls += 1;
+                c->ns_calls += 1;
+                c->ns_launches_total += 1;
+                c->lds_last = true;
+                if (c->info_dirty) { memset(c->info_h, 0, K * sizeof(int)); c->info_dirty = false; }
+                if (as_spec) {
+                    c->spec_pending = true;        // validated by the caller after its stream sync (validate_spec)
+                    c->cw_pending = false;
+                    c->dvo_valid = false;
+                    c->cur = nxt;
+                    return GGL_OK;
+                }
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (c->spec_flag_h[0] == 0) {
+                    sanitize_bounds(c, c->bounds_h, c->par_h, 4.0);
+                    for (int k = 0; k < K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
+                    c->spec_have = true;
+                    c->lds_cool_next = 4;
+                    c->dvo_valid = false;
+                    c->cur = nxt;
+                    return GGL_OK;
+                }
+                // outside the kernel's range: this step (and the next few) on the launch chain
+                lds_missed(c);
+                HIPCHK(hipMemsetAsync(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int), c->stream));
+                for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) c->spec_flag_h[h] = 0;
+            }
         }
         // ---- the whole product chain as ONE persistent launch with per-instance dependencies (k_omega_chain) ----------
         if (spec && c->chain_mode && c->fused_start && c->fused_bounds && (c->symm_variant < 0 || c->symm_variant == 17) &&
@@ -1303,6 +1396,39 @@ extern "C" int ggl_step_group_partial(ggl_ctx* c, double rho, double lambda1)
     return GGL_OK;
 }
 
+// After the stream sync that ends an iteration: a speculative Omega-step (here, or on another rank of a K-sharded run) is
+// accepted or -- GGL_SPEC_RETRY -- undone, the caller then repeats the step without speculation.
+static int validate_spec(ggl_ctx* c)
+{
+    if (c->spec_pending || c->sharded_check) {
+        // speculative Omega-step (here, or on another rank of a K-sharded run): were the assumed bounds still bounds?
+        const bool mine = c->spec_pending;
+        c->spec_pending = false;
+        c->sharded_check = false;
+        bool bad = false;
+        for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) bad = bad || (c->spec_flag_h[h] != 0);
+        if (bad) {
+            // no: the Theta-step kernels saw the flag and left the iterate alone; un-flip Omega and tell the caller
+            if (mine && c->lds_last) lds_missed(c);
+            else if (mine) c->spec_misses += 1;
+            c->flags_dirty = true;
+            c->cw_pending = false;
+            c->spec_have = false;
+            c->spec_cool = 4;
+            c->cur ^= 1;
+            return GGL_SPEC_RETRY;
+        }
+        if (mine) {
+            if (c->lds_last) { c->lds_cool_next = 4; c->spec_have = true; }
+            sanitize_bounds(c, c->bounds_h, c->par_h, 4.0);
+            for (int k = 0; k < c->K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
+            if (c->cw_pending) { c->cw_cur ^= 1; c->cw_have = true; }
+        }
+        c->cw_pending = false;
+    }
+    return GGL_OK;
+}
+
 static int finish_norms(ggl_ctx* c, int rows, double* out_norms, int group = 0)
 {
     // out_norms: 5 sums over all rows; group > 0: (rows/group, 5) -- one row of sums per `group` consecutive rows
@@ -1340,29 +1466,9 @@ static int finish_norms(ggl_ctx* c, int rows, double* out_norms, int group = 0)
                     "although the stream is idle", want, *(const volatile unsigned long long*)c->seq_h);
     c->norms_host = false;
     prof_collect(c);
-    if (c->spec_pending || c->sharded_check) {
-        // speculative Omega-step (here, or on another rank of a K-sharded run): were the assumed bounds still bounds?
-        const bool mine = c->spec_pending;
-        c->spec_pending = false;
-        c->sharded_check = false;
-        bool bad = false;
-        for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) bad = bad || (c->spec_flag_h[h] != 0);
-        if (bad) {
-            // no: the Theta-step kernels saw the flag and left the iterate alone; un-flip Omega and tell the caller
-            if (mine) c->spec_misses += 1;
-            c->flags_dirty = true;
-            c->cw_pending = false;
-            c->spec_have = false;
-            c->spec_cool = 4;
-            c->cur ^= 1;
-            return GGL_SPEC_RETRY;
-        }
-        if (mine) {
-            sanitize_bounds(c, c->bounds_h, c->par_h, 4.0);
-            for (int k = 0; k < c->K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
-            if (c->cw_pending) { c->cw_cur ^= 1; c->cw_have = true; }
-        }
-        c->cw_pending = false;
+    {
+        const int vrc = validate_spec(c);
+        if (vrc) return vrc;
     }
     int rc = check_info(c, "ADMM step");
     if (rc) return rc;
@@ -1877,34 +1983,43 @@ extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* l
     }
     CopySegs sg;
     sg.add(c->par, h, 5 * (size_t)K * sizeof(double));
-    int rc = omega_step(c, latent, &sg);
-    if (rc) return rc;
-    double* Om = c->Om[c->cur];
-    double* OmPrev = c->Om[c->cur ^ 1];
-    PB(c, GGL_PH_THETA);
     ARGCHK(!(c->has_dims && latent), "padded instances of different dimension: not with latent variables");
-    launch_theta_sgl(c->stream, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, c->par + K,
-                     c->has_maskK ? c->maskK : (c->has_mask ? c->mask : nullptr), c->par + 4 * (size_t)K, latent, c->partials,
-                     K, c->p, nullptr, c->has_dims ? c->inst_pk : nullptr, c->has_maskK ? (size_t)c->p * c->p : 0);
-    PE(c, GGL_PH_THETA);
-    HIPCHK(hipGetLastError());
-    if (latent) {
-        rc = rank_step(c);
+    int rc = GGL_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // (first attempt: the LDS-resident Omega-step may run unvalidated; when an instance falls outside its range the
+        // Theta-step has left the iterate alone and the step is repeated on the launch chain)
+        rc = attempt == 0 ? omega_step(c, latent, &sg, /*allow_spec=*/!latent) : omega_step(c, latent, nullptr, false);
         if (rc) return rc;
-        PB(c, GGL_PH_DUAL);
-        launch_dual_update(c->stream, c->X, Om, OmPrev, c->Theta, c->L, c->partials, K, c->p);
-        PE(c, GGL_PH_DUAL);
+        double* Om = c->Om[c->cur];
+        double* OmPrev = c->Om[c->cur ^ 1];
+        PB(c, GGL_PH_THETA);
+        launch_theta_sgl(c->stream, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, c->par + K,
+                         c->has_maskK ? c->maskK : (c->has_mask ? c->mask : nullptr), c->par + 4 * (size_t)K, latent, c->partials,
+                         K, c->p, c->spec_pending ? c->spec_flag : nullptr, c->has_dims ? c->inst_pk : nullptr,
+                         c->has_maskK ? (size_t)c->p * c->p : 0);
+        PE(c, GGL_PH_THETA);
+        HIPCHK(hipGetLastError());
+        if (latent) {
+            rc = rank_step(c);
+            if (rc) return rc;
+            PB(c, GGL_PH_DUAL);
+            launch_dual_update(c->stream, c->X, Om, OmPrev, c->Theta, c->L, c->partials, K, c->p);
+            PE(c, GGL_PH_DUAL);
+        }
+        PB(c, GGL_PH_REDUCE);
+        launch_reduce_partials(c->stream, c->partials, K, elementwise_blocks(c->p), GGL_NNORM, c->norms_h);
+        PE(c, GGL_PH_REDUCE);
+        HIPCHK(hipGetLastError());
+        CopySegs dn;
+        if (c->info_dirty) dn.add(c->info_h, c->info, K * sizeof(int));
+        launch_copy_small(c->stream, dn);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        prof_collect(c);
+        rc = validate_spec(c);
+        if (rc != GGL_SPEC_RETRY) break;
     }
-    PB(c, GGL_PH_REDUCE);
-    launch_reduce_partials(c->stream, c->partials, K, elementwise_blocks(c->p), GGL_NNORM, c->norms_h);
-    PE(c, GGL_PH_REDUCE);
-    HIPCHK(hipGetLastError());
-    CopySegs dn;
-    if (c->info_dirty) dn.add(c->info_h, c->info, K * sizeof(int));
-    launch_copy_small(c->stream, dn);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
-    prof_collect(c);
+    if (rc) return rc;
     rc = check_info(c, "batched SGL step");
     if (rc) return rc;
     memcpy(out_norms, c->norms_h, (size_t)K * GGL_NNORM * sizeof(double));
@@ -2092,7 +2207,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->symm_variant = src->symm_variant; c->spin_wait = src->spin_wait; c->fused_bounds = src->fused_bounds;
     c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->ns_tol = src->ns_tol;
     c->cw_warm = src->cw_warm; c->chain_mode = src->chain_mode; c->rank_l0 = src->rank_l0; c->rank_l0_coarse = src->rank_l0_coarse;
-    c->isolate = src->isolate; c->fused_cw = src->fused_cw; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
+    c->isolate = src->isolate; c->fused_cw = src->fused_cw; c->lds_omega = src->lds_omega; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
     int* didx = nullptr;
     hipError_t e = hipMalloc(&didx, m * sizeof(int));
     if (e == hipSuccess) e = hipMemcpyAsync(didx, idx, m * sizeof(int), hipMemcpyHostToDevice, src->stream);
@@ -2156,10 +2271,12 @@ extern "C" int ggl_profile_enable(ggl_ctx* c, int on)
 extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[16])
 {
     ARGCHK(c && out, "ctx, out");
+    long long lds[4] = {0, 0, 0, 0};
+    if (c->lds_calls) { int rc_ = ggl_lds_stats(c, lds); if (rc_) return rc_; }
     out[0] = c->ns_calls;
-    out[1] = c->ns_steps_total;
+    out[1] = c->ns_steps_total + (lds[3] + c->K / 2) / c->K;        // (the LDS kernel's instances run their own schedules: batch averages)
     out[2] = c->ns_stable_calls;
-    out[3] = c->ns_units_total;
+    out[3] = c->ns_units_total + (lds[2] + c->K / 2) / c->K;
     out[4] = c->ns_launches_total;
     out[5] = c->rank_calls;
     out[6] = c->rank_retries;
@@ -2172,6 +2289,25 @@ extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[16])
     out[13] = c->last_variant;
     out[14] = c->ns_eigh_fallbacks;
     out[15] = c->pre_dropped;
+    return GGL_OK;
+}
+
+// The LDS-resident Omega-step: { launches, launches an instance fell outside the kernel's range (step repeated on the launch
+// chain), products summed over all instances of all launches, Newton-Schulz steps likewise }.  Waits for the stream.
+extern "C" int ggl_lds_stats(ggl_ctx* c, long long out[4])
+{
+    ARGCHK(c && out, "ctx, out");
+    out[0] = c->lds_calls;
+    out[1] = c->lds_misses;
+    out[2] = out[3] = 0;
+    if (c->lds_tab) {
+        HIPCHK(hipSetDevice(c->device));
+        unsigned long long cnt[2] = {0, 0};
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(cnt, c->lds_tab + (size_t)OMEGA_LDS_MAXTAB * OMEGA_LDS_ENT, sizeof(cnt), hipMemcpyDeviceToHost));
+        out[2] = (long long)cnt[0];
+        out[3] = (long long)cnt[1];
+    }
     return GGL_OK;
 }
 
@@ -3550,6 +3686,61 @@ extern "C" int ggl_dev_omega_i8(int K, int p, const double* W, const double* bet
     } while (0);
     i8_omega_free(&w);
     return rc;
+}
+
+// the LDS-resident Omega-step (omega_lds.hip) stand-alone: Omega = phiplus(Theta - L - X - beta S, beta) of K instances in one
+// launch.  L may be NULL.  out = {ms per launch, fallback flag, products summed over the instances, table entries}
+extern "C" int ggl_dev_omega_lds(int K, int p, const double* Theta, const double* L, const double* X, const double* S,
+                                 const double* beta, double tol, int degrees, double* Omega, double* cbound, int iters, double* out)
+{
+    ARGCHK(K >= 1 && p >= 1 && Theta && X && S && beta && Omega && iters >= 1 && out, "arguments");
+    ARGCHK(p <= omega_lds_max_p(), "p above the LDS-resident kernel's range");
+    const size_t n = (size_t)K * p * p;
+    std::vector<double> tab((size_t)OMEGA_LDS_MAXTAB * OMEGA_LDS_ENT);
+    double lnq = 0.0;
+    const int ntab = omega_lds_build_table(tol, degrees, tab.data(), OMEGA_LDS_MAXTAB, &lnq);
+    ARGCHK(ntab >= 1, "empty schedule table");
+    DevBuf dT, dL, dX, dS, dB, dO, dTab, dC, dMisc;
+    HIPCHK(dT.alloc(n)); HIPCHK(dX.alloc(n)); HIPCHK(dS.alloc(n)); HIPCHK(dB.alloc(K)); HIPCHK(dO.alloc(n));
+    HIPCHK(dTab.alloc(tab.size())); HIPCHK(dC.alloc(K)); HIPCHK(dMisc.alloc(24));
+    if (L) { HIPCHK(dL.alloc(n)); UP(dL.p, L, n); }
+    UP(dT.p, Theta, n); UP(dX.p, X, n); UP(dS.p, S, n); UP(dB.p, beta, K); UP(dTab.p, tab.data(), tab.size());
+    HIPCHK(hipMemset(dMisc.p, 0, 24 * sizeof(double)));
+    int* flag = (int*)dMisc.p;
+    int* flag_h = flag + 2;                       // (device memory stands in for the pinned mirror here)
+    unsigned long long* units = (unsigned long long*)(dMisc.p + 20);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    bool ok = launch_omega_lds(nullptr, dT.p, L ? dL.p : nullptr, dX.p, dS.p, dB.p, dO.p, dTab.p, ntab, lnq, K, p, flag,
+                               flag_h, 0, units, dC.p);
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; ok && i < iters; ++i)
+        launch_omega_lds(nullptr, dT.p, L ? dL.p : nullptr, dX.p, dS.p, dB.p, dO.p, dTab.p, ntab, lnq, K, p, flag, flag_h, 0,
+                         nullptr, dC.p, (long long*)(dMisc.p + 4));
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!ok || hipGetLastError() != hipSuccess) return fail(GGL_E_HIP, "LDS Omega-step: launch failed");
+    int hflag = 0;
+    unsigned long long hu = 0;
+    HIPCHK(hipMemcpy(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&hu, units, sizeof(hu), hipMemcpyDeviceToHost));
+    out[0] = ms / iters; out[1] = hflag; out[2] = (double)hu; out[3] = ntab;
+    {
+        // phase stamps of instance 0 (100 MHz wall clock): out[4..12] = us since the kernel's first instruction; out[13] = its products
+        long long ts[16];
+        HIPCHK(hipMemcpy(ts, dMisc.p + 4, sizeof(ts), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 9; ++i) out[4 + i] = (double)(ts[i] - ts[0]) * 0.01;
+        out[13] = (double)ts[9];
+        out[14] = (double)(ts[14] - ts[10]) * 0.01;                                        // the A' product alone
+    }
+    DOWN(Omega, dO.p, n);
+    if (cbound) DOWN(cbound, dC.p, K);
+    return GGL_OK;
 }
 
 #ifdef GGL_DEV

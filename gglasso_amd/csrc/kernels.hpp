@@ -159,6 +159,17 @@ static constexpr int DEFL_Q0 = 6;
 void launch_deflate(hipStream_t st, const double* X, const double* C, const double* muK, double* L, const double* G, double* work,
                     double* meta, int K, int p, double tau1, double tau2);
 int deflate_max_p();
+
+// ---- the Omega-step of a small matrix as one launch, one workgroup per instance, the chain resident in LDS (omega_lds.hip) ----
+static constexpr int OMEGA_LDS_MAXSTEP = 6;      // Newton-Schulz steps of a table entry's schedule (cubic-only schedules need five)
+static constexpr int OMEGA_LDS_ENT = 8 + 6 * OMEGA_LDS_MAXSTEP;   // doubles per table entry {n, deg[6], -, coef[6][6]}
+static constexpr int OMEGA_LDS_MAXTAB = 160;     // q^-idx with q = 1.02 down to l = 300^-1/2: 145 entries
+int omega_lds_max_p();
+// units: two counters {products, steps} summed over the instances (or null); cbound (K): the bound each instance used
+int omega_lds_build_table(double tol, int degrees, double* table_h, int max_entries, double* lnq_out);
+bool launch_omega_lds(hipStream_t st, const double* Theta, const double* L, const double* X, const double* S, const double* betaK,
+                      double* Omega, const double* table, int ntab, double lnq, int K, int p, int* flag,
+                      int* flag_host, int flag_slot, unsigned long long* units, double* cbound, long long* dbg = nullptr);
 // gemm_i8.hip: error-free split products on the INT8 matrix cores
 void launch_slice_i8(hipStream_t st, const double* A, const double* scaleK, int8_t* out, int K, int p, int S, int* flag,
                      size_t sstride = 0);

@@ -442,6 +442,14 @@ class HipEngine:
         st["deflated_calls"], st["deflated_instances"] = int(d[0]), int(d[1])
         return st
 
+    def lds_stats(self):
+        """The LDS-resident Omega-step (p <= 64): launches, launches repeated on the launch chain, products and steps
+        summed over all instances."""
+        import ctypes
+        out = (ctypes.c_longlong * 4)()
+        check(self.lib.ggl_lds_stats(self.h, out))
+        return dict(zip(("calls", "misses", "products", "steps"), (int(v) for v in out)))
+
     def eig_info(self):
         """(K,) sweeps of the LDS Jacobi kernel in the last step (-1: not converged), or rocSOLVER's info."""
         import ctypes

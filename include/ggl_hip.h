@@ -124,6 +124,9 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_RANK_L0_DEFLATE 21 /* [2e-3] resolution of that first pass */
 #define GGL_OPT_FUSED_CW 22        /* [0] the bound validation of a speculative Omega-step (row sums + Collatz-Wielandt pass) as ONE launch:
                                       built in round 4 for the small slabs, measured equal there and slower at the headline */
+#define GGL_OPT_OMEGA_LDS 23       /* [1] p <= 64: the whole Omega-step as ONE launch, one workgroup per instance, the Newton-Schulz chain
+                                      resident in LDS, bound and per-instance schedule chosen on the device (omega_lds.hip); an instance
+                                      outside its range (condition number of W^2 + 4 beta I above 300) sends the step to the launch chain */
 #define GGL_OPT_ISOLATE 19         /* [0] batches of independent problems: an instance whose data turn non-finite or whose eigensolver
                                       does not converge is marked (ggl_failed_instances) instead of failing the call */
 #define GGL_OPT_RANK_L0_COARSE 18  /* [8e-5] two-tier L-step (sign iteration, p > GGL_JACOBI_MAX_P): the first pass over the whole batch
@@ -397,6 +400,9 @@ int ggl_profile_read(ggl_ctx *ctx, double ms[GGL_NPHASE], long long count[GGL_NP
  * variant (csrc/gemm_sym.hip); [14] Omega-steps that fell back to the eigendecomposition; [15] pre-launched Omega-step
  * chains (GGL_OPT_PIPELINE) that were dropped unused. */
 int ggl_ns_stats(ggl_ctx *ctx, long long out[16]);
+/* The LDS-resident Omega-step (GGL_OPT_OMEGA_LDS): out = { launches, launches repeated on the launch chain because an instance
+ * fell outside the kernel's range, products summed over all instances of all launches, Newton-Schulz steps likewise }. */
+int ggl_lds_stats(ggl_ctx *ctx, long long out[4]);
 /* L-step (sign iteration): out = { calls, calls whose first pass was continued on a compact sub-batch, instances continued in
  * total, calls that fell back to the eigendecomposition } */
 int ggl_rank_stats(ggl_ctx *ctx, long long out[4]);
@@ -429,6 +435,13 @@ int ggl_dev_symm_i8(int K, int p, int S, int dmax, const double *A, const double
  * schedule stands for}. */
 int ggl_dev_omega_i8(int K, int p, const double *W, const double *beta, const double *cbound, const int *cfg5, double tol,
                      double *Omega, int iters, double *ms_out);
+/* ggl_dev_omega_lds: the Omega-step of small matrices (p <= 64) as ONE launch, one workgroup per instance, the Newton-Schulz
+ * chain resident in LDS, bound and schedule chosen on the device (omega_lds.hip; kernel unit test and timing).
+ * Omega = phiplus(Theta - L - X - beta S, beta), L may be NULL.  cbound (K) or NULL receives the bound used.
+ * out[14] = {ms per launch, fallback flag, products summed over the instances, entries of the schedule table, [4..12] phase
+ * stamps of instance 0 in us (start, W, A', B', bound, first step, steps, W again, Omega), [13] products of instance 0}. */
+int ggl_dev_omega_lds(int K, int p, const double *Theta, const double *L, const double *X, const double *S, const double *beta,
+                      double tol, int degrees, double *Omega, double *cbound, int iters, double *out);
 /* ggl_dev_symm_bounds: C = A B on the direct-to-LDS product kernel with the bound partials of its epilogue, reduced to
  * the row sums of |C| (K,p), |C|_F^2 (K) and the spectral bound sqrt(min(|C|_inf, Collatz-Wielandt ratio, |C|_F)) (K)
  * that the Omega-step takes from B' = (W^2 + 4 beta I)^2 (kernel unit test; even p, variants 16 / 17 / 20). */
