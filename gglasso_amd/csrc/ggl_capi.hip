@@ -2056,7 +2056,7 @@ static int mgl_batch_finish(ggl_ctx* c, int G, int Kp, int reg, int latent, doub
     c->norms_host = true;
     if (!latent) {
         PB(c, GGL_PH_REDUCE);
-        launch_reduce_partials(c->stream, c->partials, G, theta_partial_blocks(c->p, reg, Kp, 2), GGL_NNORM, c->norms_h);
+        launch_reduce_partials(c->stream, c->partials, G, theta_partial_blocks(c->p, reg, Kp, 2, G), GGL_NNORM, c->norms_h);
         PE(c, GGL_PH_REDUCE);
         rows = G;
         group = 1;
@@ -2093,7 +2093,7 @@ extern "C" int ggl_mgl_batch_step(ggl_ctx* c, int G, const double* rho, const do
     if (reg == GGL_REG_FGL && Kp > fgl_max_K())
         return fail(GGL_E_ARG, "batched FGL grid: %d instances per problem exceed the %d of the Condat tile kernel", Kp,
                     fgl_max_K());
-    int rc = ensure_partials(c, (size_t)G * theta_partial_blocks(c->p, reg, Kp, 2) * GGL_NNORM);
+    int rc = ensure_partials(c, (size_t)G * theta_partial_blocks(c->p, reg, Kp, 2, G) * GGL_NNORM);
     if (rc) return rc;
     double* h = c->par_h;
     for (int g = 0; g < G; ++g) {

@@ -88,7 +88,7 @@ int pair_blocks(int p, int reg, int K);
 // flat != 0 and K <= GGL_FLAT_MAX_K (GGL only): one thread per element with its K-column in registers; valid for an
 // exactly symmetric state only.  theta_partial_blocks: norms partial rows written by launch_theta_pair.
 static constexpr int GGL_FLAT_MAX_K = 256;     // K-column over up to 16 waves of 16 instances each (theta_pair.hip, launch_flat4_any)
-int theta_partial_blocks(int p, int reg, int K, int flat);
+int theta_partial_blocks(int p, int reg, int K, int flat, int G = 1);      // G: problems in one launch (batched grid)
 // GGL/FGL Theta-step on upper-triangle K-vectors (prox_p, ggl_helper.py:190-207), mirrored.
 //   fuse_dual != 0 (non-latent): also X += Omega - Theta and norms partials [K][nblk][5].
 //   fuse_dual == 0 (latent): writes Theta and C = (Theta - X) - Omega  (admm_solver.py:198).

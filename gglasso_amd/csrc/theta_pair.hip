@@ -51,8 +51,16 @@ static constexpr int FLAT4_CHUNKS = 2;     // 64-element chunks per workgroup (h
 static constexpr int GGL_FLAT1_MAX_K = 32;   // the one-thread-per-element kernel keeps the whole K-column in ONE lane's registers
 static inline bool use_flat4(int K, int flat) { return (flat == 2 && K > FLAT4_MIN_K) || (flat != 0 && K > GGL_FLAT1_MAX_K); }
 
-int theta_partial_blocks(int p, int reg, int K, int flat)
+// Many instances of a SMALL matrix (one problem, K > 64, fewer than 256 workgroups of 128 elements): the workgroup takes 16
+// elements instead of 128 (k_theta_ggl_flat16), e.g. K = 256, p = 64: 256 workgroups instead of 32 on the chip's 256 CUs.
+static inline bool use_flat16(int K, int p, int flat, int G)
 {
+    return G == 1 && use_flat4(K, flat) && K > 64 && ((size_t)p * p + 127) / 128 < 256;
+}
+
+int theta_partial_blocks(int p, int reg, int K, int flat, int G)
+{
+    if (reg == 1 && flat && K <= GGL_FLAT_MAX_K && use_flat16(K, p, flat, G)) return (int)(((size_t)p * p + 15) / 16);
     if (reg == 1 && flat && K <= GGL_FLAT_MAX_K) return use_flat4(K, flat) ? (int)(((size_t)p * p + 64 * FLAT4_CHUNKS - 1) / (64 * FLAT4_CHUNKS)) : flat_blocks(p);
     return pair_blocks(p, reg, K);
 }
@@ -1015,6 +1023,117 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4v(double* __restrict
     }
 }
 
+// Few elements, many instances: a workgroup of 16 waves takes 16 consecutive elements (a 128-byte segment of every
+// instance) and ALL K <= 64 * KQ instances of them; lanes 0-15 / 16-31 / 32-47 / 48-63 of wave w hold the instance groups
+// 4w .. 4w+3 (KQ instances each).  The sums of squares meet by two shuffles inside the wave and one LDS round over the waves,
+// in a fixed order.  p^2 / 16 workgroups where the 128-element kernels above would launch p^2 / 128.
+template <int KQ, bool FUSE_DUAL>
+__global__ __launch_bounds__(1024) void k_theta_ggl_flat16(double* __restrict__ Theta, double* __restrict__ X,
+                                                           double* __restrict__ C, const double* __restrict__ Omega,
+                                                           const double* __restrict__ OmegaPrev,
+                                                           const double* __restrict__ L, double l1, double l2,
+                                                           double* __restrict__ partials, int K, int p,
+                                                           const int* __restrict__ skip, const double* __restrict__ gsq)
+{
+    constexpr int NW = 16;
+    __shared__ double ssh[NW][16];
+    __shared__ double scratch[GGL_NNORM * NW];
+    if (spec_failed(skip)) return;
+    const size_t pp = (size_t)p * p;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int el = lane & 15, kb = (wid * 4 + (lane >> 4)) * KQ;
+    const size_t e = (size_t)blockIdx.x * 16 + el;
+    const bool live = e < pp;
+    double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
+    double om[KQ], x[KQ], u[KQ];
+    double ss = 0.0;
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            if (kb + q < K) {
+                const size_t o = (size_t)(kb + q) * pp + e;
+                om[q] = Omega[o];
+                x[q] = X ? X[o] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            if (kb + q < K) {
+                const double l = L ? L[(size_t)(kb + q) * pp + e] : 0.0;
+                u[q] = (om[q] + l) + x[q];
+                const double sv = soft(u[q], l1);
+                ss += sv * sv;
+            }
+        }
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lane < 16) ssh[wid][lane] = ss;
+    __syncthreads();
+    if (live) {
+        double sv[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sv[w] = ssh[w][el];
+        const double tot = gsq ? gsq[e] : tree_sum<NW>(sv);
+        const double a = fmax(sqrt(tot), l2);
+        const double amul = a - l2;
+        const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
+        const bool offd = (i != j);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            if (kb + q < K) {
+                const size_t o = (size_t)(kb + q) * pp + e;
+                const double v = u[q];
+                const double th = offd ? soft(v, l1) * amul / a : v;
+                Theta[o] = th;
+                if (FUSE_DUAL) {
+                    const double xn = x[q] + (om[q] - th);
+                    X[o] = xn;
+                    const double dp = om[q] - OmegaPrev[o];
+                    acc[0] += om[q] * om[q];
+                    acc[1] += th * th;
+                    acc[2] += xn * xn;
+                    acc[3] += (om[q] - th) * (om[q] - th);
+                    acc[4] += dp * dp;
+                } else if (C) {
+                    C[o] = (th - x[q]) - om[q];
+                }
+            }
+        }
+    }
+    if (FUSE_DUAL) {
+#pragma unroll
+        for (int v = 0; v < GGL_NNORM; ++v) acc[v] = wave_sum(acc[v]);
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) scratch[wid * GGL_NNORM + v] = acc[v];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double* o = partials + (size_t)blockIdx.x * GGL_NNORM;
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) {
+                double sv[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sv[w] = scratch[w * GGL_NNORM + v];
+                o[v] = tree_sum<NW>(sv);
+            }
+        }
+    }
+}
+
+template <int KQ>
+static void launch_flat16(hipStream_t st, double* Theta, double* X, double* C, const double* Omega, const double* OmegaPrev,
+                          const double* L, double l1, double l2, int fuse_dual, double* partials, int K, int p,
+                          const int* skip, const double* gsq)
+{
+    dim3 grid((unsigned)(((size_t)p * p + 15) / 16)), blk(1024);
+    if (fuse_dual)
+        hipLaunchKernelGGL((k_theta_ggl_flat16<KQ, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, gsq);
+    else
+        hipLaunchKernelGGL((k_theta_ggl_flat16<KQ, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, gsq);
+}
+
 static inline int flat4_blocks(int p) { return (int)(((size_t)p * p + 64 * FLAT4_CHUNKS - 1) / (64 * FLAT4_CHUNKS)); }
 
 template <int KQ, int NW = 4, bool VEC_OK = true>
@@ -1045,7 +1164,8 @@ static void launch_flat4(hipStream_t st, double* Theta, double* X, double* C, co
 // Which Theta kernel the last launch_theta_pair / launch_theta_batch of this process ran (ggl_last_dispatch; the parity tests
 // assert the dispatch of every BASELINE configuration): 0 GGL tile pairs; 100 + KMAX per-element, K-column in one thread;
 // 100 * KQ + NW per-element, K-column over NW waves of KQ values per lane (404, 408: four waves; 808 / 816 / 1616: K <= 64 /
-// 128 / 256); 2000 + tile edge: FGL Condat tiles.
+// 128 / 256); 10000 + 100 * KQ + 16: the same for few elements and many instances, 16 elements per workgroup of 16 waves
+// (10216: K <= 128, 10416: K <= 256); 2000 + tile edge: FGL Condat tiles.
 static int g_theta_kernel = -1;
 int theta_last_kernel() { return g_theta_kernel; }
 
@@ -1054,6 +1174,12 @@ static void launch_flat4_any(hipStream_t st, double* Theta, double* X, double* C
                              double* partials, int K, int p, const int* skip, int G, const double* l1G, const double* l2G,
                              const double* gsq)
 {
+    if (use_flat16(K, p, 2, G)) {
+        g_theta_kernel = K <= 128 ? 10216 : 10416;
+        if (K <= 128) launch_flat16<2>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, gsq);
+        else launch_flat16<4>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, gsq);
+        return;
+    }
 #define GGL_F4(...) launch_flat4<__VA_ARGS__>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, G, l1G, l2G, gsq)
     g_theta_kernel = K <= 16 ? 404 : K <= 32 ? 408 : K <= 64 ? 808 : K <= 128 ? 816 : 1616;
     if (K <= 16) GGL_F4(4);

@@ -247,6 +247,27 @@ def test_c5_whole_ggl_K256_p1000(stats):
     assert st["stable_calls"] == 0 and st["eigh_fallbacks"] == 0, st
 
 
+@pytest.mark.parametrize("K,p,latent,code", [(256, 64, False, 10416), (100, 21, False, 10216), (130, 50, True, 10416),
+                                             (64, 64, False, 808), (256, 200, False, 1616)])
+def test_many_instances_of_a_small_matrix(stats, K, p, latent, code):
+    """GGL with K > 64 and fewer than 256 workgroups of 128 elements (BASELINE's K = 256, p = 64 among them): the Theta-step
+    takes 16 elements per workgroup (k_theta_ggl_flat16: p^2 / 16 workgroups instead of p^2 / 128 on 256 CUs), the Omega-step
+    the LDS-resident kernel.  Six iterations of all of Omega / Theta / X (/ L) against the oracle (admm_solver.py:172-246);
+    the neighbouring shapes keep their 128-element kernels."""
+    from gglasso_amd import solver
+    S, Om0 = _problem("GGL", K, p, 1250 + p)
+    kw = dict(max_iter=6, tol=1e-20, rtol=1e-20, latent=latent, mu1=(0.6 * np.ones(K) if latent else None))
+    with oracle_threads():
+        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
+    out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
+    _check_state(out, ref, ("Omega", "Theta", "X") + (("L",) if latent else ()), 1e-9)
+    assert np.array_equal(out["Theta"], out["Theta"].transpose(0, 2, 1))
+    st = stats[-1]
+    assert st["dispatch_theta_kernel"] == code, st
+    if p <= 64 and not latent:
+        assert st["last_variant"] == 41, st
+
+
 @pytest.mark.parametrize("K", [4, 8, 16])
 def test_headline_slab_dispatch(stats, K):
     """Per-GPU slabs of the headline under K-sharding at 8 / 4 / 2 GPUs (what decides strong scaling): K = 4 and K = 16
