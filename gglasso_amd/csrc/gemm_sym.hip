@@ -1608,7 +1608,7 @@ double mfma_f64_peak_tflops(hipStream_t st, double* scratch, int blocks, int ite
 }
 #endif   // GGL_DEV
 
-static constexpr int SMALL_DL_MIN_P = 130;        // the Newton-Schulz path starts above p = 128 (below: LDS Jacobi)
+static constexpr int SMALL_DL_MIN_P = 16;         // (round 4: measured ahead of the register-staged 32x32 kernel at every even p from 16 up, tools/bench_symm_small.py)
 static constexpr long SMALL_BATCH_TILES = 800;   // up to here the 32x32-tile kernel, above the 64x64 direct-to-LDS one
 
 // Product-kernel variants.  The shipped library holds the instances the solvers dispatch to:
