@@ -1,7 +1,7 @@
 // The Omega-step of a SMALL matrix as ONE launch: one workgroup per instance, every matrix of the Newton-Schulz chain resident in
 // that CU's LDS, products on the FP64 matrix cores straight out of LDS, the spectral bound and the choice of the schedule on the
-// device.  Replaces, for p <= OMEGA_LDS_MAX_P, the launch-per-product chain (8 launches of ~13 us for 0.1 ms of Omega-step at
-// p <= 128, all of it launch latency) -- and is what the north_star's "one-block-per-matrix kernel for small p" became once the
+// device.  Replaces, for p <= 64, the launch-per-product chain (a dozen launches for 0.1 ms of Omega-step at p <= 128, all of it
+// launch and tile-kernel latency) -- and is what the north_star's "one-block-per-matrix kernel for small p" became once the
 // LDS Jacobi eigensolver had been measured (2.4 us per rotation step).
 //
 // Reference: phiplus, solver/ggl_helper.py:272-303 -- Omega = Q diag((d + sqrt(d^2 + 4 beta)) / 2) Q^T = (W + (W^2 + 4 beta I)^(1/2)) / 2,
@@ -24,9 +24,10 @@ namespace ggl {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // LDS row stride (doubles) of a PT x PT matrix: ODD, so that the 16 lanes of a lane group that write a block's MIRROR image (one
-// column, 16 consecutive rows) land on 16 different bank pairs -- with an even stride those writes were 8-way conflicted and cost
-// 0.7 us of a 2.8 us product at PT = 64.  The fragment reads (two k-rows of 16 consecutive doubles per lane group) are 2-way
-// conflicted with any stride that is not 16 mod 32; they stay far below the matrix pipe's time.
+// column, 16 consecutive rows) land on 16 different bank pairs (an even stride makes those writes 8-way conflicted; measured, the
+// difference is within noise -- the epilogue's cost is its instruction count).  The fragment reads (two
+// k-rows of 16 consecutive doubles per lane group) are 2-way conflicted with any stride that is not 16 mod 32; they stay far
+// below the matrix pipe's time.
 template <int PT> struct LdsDim {
     static constexpr int LD = PT + 1, NB = PT / 16;
     static constexpr int NE = (PT / 2) * (PT + 1);          // elements of the lower triangle incl. the diagonal
