@@ -390,6 +390,7 @@ def main():
     dt = statistics.median(region_s)
     timed_iters = args.steps * len(region_s)
     prof = eng.profile_read(reset=True)
+    pipe_totals = eng.pipeline_stats() if hasattr(eng, "pipeline_stats") else None
     # untimed extra pass with every phase instrumented, for the per-phase breakdown
     eng.profile(1)
     extra_iters = min(10, args.steps)
@@ -551,6 +552,8 @@ def main():
                               "speculative_omega_steps": ns1["spec_calls"] - ns0["spec_calls"],
                               "speculation_misses": ns1["spec_misses"] - ns0["spec_misses"],
                               "prelaunched_chains_dropped": ns1["pre_dropped"] - ns0["pre_dropped"],
+                              # totals since ctx creation: whole chains launched ahead / forgotten, early first parts / continued
+                              "pipeline_totals": pipe_totals,
                               "end_of_iteration_poll_timeouts": ns1["spin_timeouts"] - ns0["spin_timeouts"]}
             if omega_ns else None,
         }

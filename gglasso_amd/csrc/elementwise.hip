@@ -191,10 +191,24 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const double* base = partials + (size_t)k * nblk * nv;
-    for (int b = threadIdx.x; b < nblk; b += 256) {
+    // four rows per trip, all their loads in flight before the first add (one workgroup walks up to ~2000 rows: with one row
+    // per trip the loop paid a global-memory latency per row, 10.5 us at the headline); the adds keep the ascending order
+    for (int b = threadIdx.x; b < nblk; b += 1024) {
+        double t[4][8];
 #pragma unroll
-        for (int v = 0; v < 8; ++v)
-            if (v < nv) acc[v] += base[(size_t)b * nv + v];
+        for (int u = 0; u < 4; ++u) {
+            const int bb = b + 256 * u;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) t[u][v] = (v < nv && bb < nblk) ? base[(size_t)bb * nv + v] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (b + 256 * u < nblk) {
+#pragma unroll
+                for (int v = 0; v < 8; ++v)
+                    if (v < nv) acc[v] += t[u][v];
+            }
+        }
     }
 #pragma unroll
     for (int v = 0; v < 8; ++v) {

@@ -119,6 +119,27 @@ struct ggl_ctx {
     bool spec_enable = true, spec_have = false, spec_pending = false;
     double *spec_c = nullptr, *spec_beta = nullptr;   // host: bounds / beta of the last validated step (K each)
     double *cuse = nullptr, *cuse_h = nullptr;        // bounds the running schedule assumes (device / pinned)
+    // The pinned plan tables (coef_h, cuse_h) exist twice and every Omega-step that writes a plan takes the other copy: the
+    // copy kernel of an EARLY phase A (below) may still be waiting in the stream when the host builds the next plan.
+    double *coef_hh[2] = {nullptr, nullptr}, *cuse_hh[2] = {nullptr, nullptr};
+    int plan_par = 0;
+    // Early phase A (GGL_OPT_PIPELINE, ggl_admm_step): the first part of the NEXT iteration's speculative chain -- parameter
+    // tables, W, A', B' (+ the first step's start): scratch only, no validation flags, nothing the repeat of a rejected step
+    // needs -- is put into the stream BEHIND this iteration's Theta-step and BEFORE the host waits for its residuals, so the
+    // device has ~0.2 ms of work queued across the host's round trip.  The rest of the chain (bound kernels, products,
+    // Omega) follows from the SAME plan once the iteration is validated and the rho rule leaves rho alone; otherwise the
+    // early part is forgotten (it wrote W and the A'/B' scratch pair only).
+    struct EarlyA {
+        bool valid = false;
+        NsPlan plans[4];
+        double* fused[4] = {nullptr, nullptr, nullptr, nullptr};
+        double* beta = nullptr;                       // (K) beta the part was built for
+    } early;
+    bool early_part = true;                           // GGL_OPT_EARLY_PART
+    bool early_caller = false;                        // set by ggl_admm_step around its Theta-step: the early part may be launched
+    bool early_request = false;                       // omega_step: launch phase A only
+    bool ratio_calm = false;                          // last validated iteration: residual ratio well inside the rho rule's band
+    long long early_launched = 0, early_used = 0;
     int *spec_flag = nullptr, *spec_flag_h = nullptr; // MAX_PARTS validation flags (device / pinned)
     long long spec_calls = 0, spec_misses = 0;
     double spec_factor = 1.02;                 // inflation of the previous bounds (GGL_SPEC_FACTOR; < 1 forces misses)
@@ -203,6 +224,11 @@ struct ggl_ctx {
     int prof_on = 0;          // 0 off, 1 every phase, 2 only the eigen/matrix-function phases (fewer event records)
     hipEvent_t ev[GGL_NPHASE][2] = {};
     bool ev_used[GGL_NPHASE] = {};
+    // an EARLY first part of the Omega-step is recorded one iteration ahead of the collection that belongs to it, and the next
+    // one goes into the stream before that collection: two event pairs, collected whenever their end has been reached
+    hipEvent_t ev_early[2][2] = {};
+    bool ev_early_used[2] = {false, false};
+    int ev_early_par = 0;
     double ph_ms[GGL_NPHASE] = {};
     long long ph_cnt[GGL_NPHASE] = {};
 };
@@ -224,6 +250,16 @@ static void prof_collect(ggl_ctx* c)   // call after a stream sync
             c->ph_cnt[ph] += 1;
         }
         c->ev_used[ph] = false;
+    }
+    for (int e = 0; e < 2; ++e) {
+        float ms = 0.f;
+        if (c->ev_early_used[e] && hipEventQuery(c->ev_early[e][1]) == hipSuccess) {
+            if (hipEventElapsedTime(&ms, c->ev_early[e][0], c->ev_early[e][1]) == hipSuccess) {
+                c->ph_ms[GGL_PH_EIG_OMEGA2] += ms;
+                c->ph_cnt[GGL_PH_EIG_OMEGA2] += 1;
+            }
+            c->ev_early_used[e] = false;
+        }
     }
 }
 
@@ -338,7 +374,8 @@ static int ctx_alloc(ggl_ctx* c)
         DEV(c->nsT, nb);
         const size_t cl = (size_t)NS_MAX_LAUNCHES * NS_SLOT(c->K) * sizeof(double);   // last 3 slots: start / pre tables
         DEV(c->coef, cl);
-        PIN(c->coef_h, cl, 1);
+        PIN(c->coef_hh[0], cl, 1);
+        PIN(c->coef_hh[1], cl, 1);
         const size_t bl = 2 * (size_t)c->K * sizeof(double);
         PIN(c->bounds_h, bl, 2);
         const size_t nbl = 3 * (size_t)c->K * norm_bounds_blocks(c->p) * sizeof(double);   // + Collatz-Wielandt maxima
@@ -353,7 +390,8 @@ static int ctx_alloc(ggl_ctx* c)
         DEV(c->cwmax, c->K * sizeof(unsigned long long));
         DEV(c->cwcnt, c->K * sizeof(unsigned));
         DEV(c->cuse, c->K * sizeof(double));
-        PIN(c->cuse_h, c->K * sizeof(double), 1);
+        PIN(c->cuse_hh[0], c->K * sizeof(double), 1);
+        PIN(c->cuse_hh[1], c->K * sizeof(double), 1);
         // the words the host polls / reads right after the poll: explicitly coherent (fine-grained) pinned memory, so a
         // device store is visible to the host without a stream synchronisation whatever HIP_HOST_COHERENT says
         PIN(c->seq_h, sizeof(unsigned long long), 2);
@@ -362,6 +400,7 @@ static int ctx_alloc(ggl_ctx* c)
         c->spec_c = (double*)malloc(c->K * sizeof(double));
         c->spec_beta = (double*)malloc(c->K * sizeof(double));
         c->pre_beta = (double*)malloc(c->K * sizeof(double));
+        c->early.beta = (double*)malloc(c->K * sizeof(double));
         DEV(c->maxdev, 2 * c->K * sizeof(double));          // [K] residuals | [K] traces of the sign iterate
         PIN(c->maxdev_h, 2 * c->K * sizeof(double), 1);
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -385,6 +424,8 @@ static int ctx_alloc(ggl_ctx* c)
         *r.pp = base[r.kind] + off[r.kind];
         off[r.kind] += up(std::max<size_t>(r.bytes, 8));
     }
+    c->coef_h = c->coef_hh[0];
+    c->cuse_h = c->cuse_hh[0];
     // initial contents
     HIPCHK(hipMemsetAsync(c->groupsq, 0, ((size_t)c->p * c->p + 8) * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
@@ -438,6 +479,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_ISOLATE: c->isolate = v != 0.0; break;
         case GGL_OPT_FUSED_CW: c->fused_cw = v != 0.0; break;
         case GGL_OPT_OMEGA_LDS: c->lds_omega = v != 0.0; break;
+        case GGL_OPT_EARLY_PART: c->early_part = v != 0.0; break;
         case GGL_OPT_RANK_DEFLATE: c->rank_deflate = v != 0.0; break;
         case GGL_OPT_RANK_L0_DEFLATE:
             if (!(v > 0.0) || v > 0.1) return fail(GGL_E_ARG, "bad argument: GGL_OPT_RANK_L0_DEFLATE is in (0, 0.1]");
@@ -489,6 +531,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_ISOLATE: *value = c->isolate; break;
         case GGL_OPT_FUSED_CW: *value = c->fused_cw; break;
         case GGL_OPT_OMEGA_LDS: *value = c->lds_omega; break;
+        case GGL_OPT_EARLY_PART: *value = c->early_part; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
@@ -583,6 +626,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     free(c->spec_c);
     free(c->spec_beta);
     free(c->pre_beta);
+    free(c->early.beta);
     // everything ctx_alloc handed out: three allocations
     if (c->arena_dev) (void)hipFree(c->arena_dev);
     if (c->arena_pin) (void)hipHostFree(c->arena_pin);
@@ -590,6 +634,9 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     for (int ph = 0; ph < GGL_NPHASE; ++ph)
         for (int e = 0; e < 2; ++e)
             if (c->ev[ph][e]) (void)hipEventDestroy(c->ev[ph][e]);
+    for (int q = 0; q < 2; ++q)
+        for (int e = 0; e < 2; ++e)
+            if (c->ev_early[q][e]) (void)hipEventDestroy(c->ev_early[q][e]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (int i = 0; i < ggl_ctx::MAX_PARTS - 1; ++i) {
         if (c->streamx[i]) (void)hipStreamDestroy(c->streamx[i]);
@@ -611,6 +658,7 @@ extern "C" int ggl_ctx_sync(ggl_ctx* c)
 // touches the state or that scratch outside ggl_admm_step waits for it and forgets it.
 static int drop_prelaunch(ggl_ctx* c)
 {
+    c->early.valid = false;          // (an early phase A wrote scratch only: nothing to undo, nothing to wait for)
     if (!c->pre_valid) return GGL_OK;
     c->pre_valid = false;
     c->pre_dropped += 1;
@@ -930,6 +978,7 @@ static constexpr int GGL_SPIN_LIMIT_MS = 2000;
 static constexpr int GGL_SPEC_RETRY = 1;     // internal: a speculative step failed validation, repeat it
 static constexpr int GGL_NOT_LAUNCHED = 2;   // internal: omega_step(only_spec) found no speculative schedule and launched nothing
 static int omega_step(ggl_ctx* c, int latent, CopySegs* pending = nullptr, bool allow_spec = false, bool only_spec = false);
+static int maybe_early(ggl_ctx* c);
 
 extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* nk)
 {
@@ -996,9 +1045,22 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
     if (pending) first = *pending;
     if (c->omega_ns) {
         const int K = c->K;
+        // early phase A (ggl_ctx::EarlyA): `want_A` launches the first part of a speculative chain only; `resume` finds that
+        // part in the stream, built for this beta, and adds the rest from the same plan
+        const bool want_A = c->early_request;
+        c->early_request = false;
+        bool resume = c->early.valid && allow_spec && !latent && !want_A && c->spec_enable;
+        for (int k = 0; resume && k < K; ++k) resume = (c->par_h[k] == c->early.beta[k]);
+        c->early.valid = false;
+        if (!resume) {
+            // a new plan goes into the OTHER copy of the pinned tables (a forgotten early part's copy kernel may not have run yet)
+            c->plan_par ^= 1;
+            c->coef_h = c->coef_hh[c->plan_par];
+            c->cuse_h = c->cuse_hh[c->plan_par];
+        }
         // phase A: A' = W^2 + 4 beta I, B' = A'^2 (both needed anyway), then the bound from B'
         double* pre = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 2) * NS_SLOT(K);
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; !resume && k < K; ++k) {
             double* o0 = pre + (size_t)k * NS_NCOEF;
             double* o1 = pre + NS_SLOT(K) + (size_t)k * NS_NCOEF;
             o0[0] = 4.0 * c->par_h[k]; o0[1] = 1.0; o0[2] = o0[3] = o0[4] = o0[5] = 0.0;
@@ -1043,6 +1105,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         bool spec = allow_spec && c->spec_enable && c->spec_have && !latent && c->spec_cool == 0;
         if (allow_spec && !only_spec && c->spec_cool > 0) c->spec_cool -= 1;      // one tick per iteration, not per attempt
         for (int k = 0; spec && k < K; ++k) spec = (c->par_h[k] == c->spec_beta[k]);
+        if (resume) spec = true;
         double* fused[ggl_ctx::MAX_PARTS] = {};      // speculative step: the first step's start as 2nd output of the B' launch
         bool cw_written = false;                     // this step's bound pass left a Collatz-Wielandt vector behind
         if (c->flags_dirty) {
@@ -1059,7 +1122,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         // raises validation flag 0, the Theta-step leaves the iterate alone and the step is repeated on the launch chain --
         // elsewhere the flag is read back after a stream synchronisation.
         c->lds_last = false;
-        if (c->lds_omega && c->p <= omega_lds_max_p() && c->ns_force == 0 && c->symm_variant < 0 && !c->chain_mode) {
+        if (c->lds_omega && c->p <= omega_lds_max_p() && c->ns_force == 0 && c->symm_variant < 0 && !c->chain_mode && !want_A && !resume) {
             const bool as_spec = allow_spec && c->spec_enable && !latent;
             if (c->lds_cool > 0) {
                 if (!only_spec) c->lds_cool -= 1;
@@ -1110,7 +1173,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             }
         }
         // ---- the whole product chain as ONE persistent launch with per-instance dependencies (k_omega_chain) ----------
-        if (spec && c->chain_mode && c->fused_start && c->fused_bounds && (c->symm_variant < 0 || c->symm_variant == 17) &&
+        if (spec && !want_A && !resume && c->chain_mode && c->fused_start && c->fused_bounds && (c->symm_variant < 0 || c->symm_variant == 17) &&
             chain_tile(K, c->p, c->chain_mode == 2) == 64) {
             if (!c->nsNX) HIPCHK(hipMalloc(&c->nsNX, 2 * c->n * sizeof(double)));
             if (!c->chain_cnt) HIPCHK(hipMalloc(&c->chain_cnt, (size_t)K * CHAIN_CNT_STRIDE * sizeof(unsigned)));
@@ -1180,7 +1243,10 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 return GGL_OK;
             }
         }
-        if (spec) {
+        if (resume) {
+            for (int h = 0; h < nh; ++h) { plans[h] = c->early.plans[h]; fused[h] = c->early.fused[h]; }
+            c->early_used += 1;
+        } else if (spec) {
             for (int k = 0; k < K; ++k) c->cuse_h[k] = c->spec_c[k] * c->spec_factor;
             sanitize_bounds(c, c->cuse_h, c->par_h, 4.0);
             for (int h = 0; spec && h < nh; ++h) {
@@ -1196,7 +1262,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             }
         }
         if (only_spec && !spec) return GGL_NOT_LAUNCHED;
-        if (nh > 1) {
+        if (nh > 1 && !resume) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
             for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
         }
@@ -1206,6 +1272,21 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         for (int h = 0; h < nh; ++h) {
             hipStream_t sh = h == 0 ? c->stream : c->streamx[h - 1];
             const int k0 = k0h[h];
+            // The host's mirrors of the validation flags are cleared when the REST of the chain is launched: the mirrors of an
+            // early part's iteration are still to be read when the part goes into the stream (the device words, cleared by
+            // the part's copy kernel, have been read by then -- the Theta-step that takes them is ahead in the stream).
+            if (!want_A) {
+                c->spec_flag_h[h] = 0;
+                if (h == 0 && nh < ggl_ctx::MAX_PARTS) c->spec_flag_h[ggl_ctx::MAX_PARTS - 1] = 0;
+            }
+            double* Ap = c->nsYP[0] + k0 * pp;
+            double* Bp = c->nsYP[0] + c->n + k0 * pp;
+            const int btile = c->fused_bounds ? symm_bounds_tile(Kh[h], c->p, var_parts) : 0;
+            const int bT = btile ? (c->p + btile - 1) / btile : 0;
+            double* rowp = btile ? c->rowpart + (size_t)k0 * bT * c->p : nullptr;
+            double* frop = btile ? c->fropart + (size_t)k0 * (bT * (bT + 1) / 2) : nullptr;
+            if (!resume) {
+            // ---- first part: parameter tables, W, A', B' (scratch only) ----
             // the pending parameter transfers are repeated on every part's stream (identical values, a few KB)
             CopySegs sg = first;
             sg.add(pre_d + NS_NCOEF * (size_t)k0, pre + NS_NCOEF * (size_t)k0, (size_t)Kh[h] * NS_NCOEF * sizeof(double));
@@ -1215,11 +1296,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             // runs, where a rank must skip and repeat the step when ANY rank's speculation failed -- also a rank that
             // did not speculate itself
             sg.add(c->spec_flag + h, nullptr, sizeof(int));
-            c->spec_flag_h[h] = 0;
-            if (h == 0 && nh < ggl_ctx::MAX_PARTS) {
-                sg.add(c->spec_flag + ggl_ctx::MAX_PARTS - 1, nullptr, sizeof(int));
-                c->spec_flag_h[ggl_ctx::MAX_PARTS - 1] = 0;
-            }
+            if (h == 0 && nh < ggl_ctx::MAX_PARTS) sg.add(c->spec_flag + ggl_ctx::MAX_PARTS - 1, nullptr, sizeof(int));
             if (spec) {
                 sg.add(start_base_d + 5 * (size_t)k0, start_base_h + 5 * (size_t)k0, (size_t)Kh[h] * 5 * sizeof(double));
                 const int nb_launch = plans[h].products - 2;
@@ -1232,19 +1309,25 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             if (h == 0) PB(c, GGL_PH_FORM_W);
             launch_form_W_sym(sh, c->W + k0 * pp, c->Theta + k0 * pp, latent ? c->L + k0 * pp : nullptr, c->X + k0 * pp,
                               c->S + k0 * pp, beta + k0, Kh[h], c->p);
-            if (h == 0) { PE(c, GGL_PH_FORM_W); PB(c, GGL_PH_EIG_OMEGA); }
-            double* Ap = c->nsYP[0] + k0 * pp;
-            double* Bp = c->nsYP[0] + c->n + k0 * pp;
+            const bool early_ev = want_A && h == 0 && c->prof_on == 2;
+            if (early_ev) {
+                c->ev_early_par ^= 1;
+                (void)hipEventRecord(c->ev_early[c->ev_early_par][0], c->stream);
+            } else if (h == 0 && !want_A) { PE(c, GGL_PH_FORM_W); PB(c, GGL_PH_EIG_OMEGA); }
             // lambda_max(A')^2 = lambda_max(B') <= min(|B'|_inf, |B'|_F, Collatz-Wielandt ratio), reduced on the
             // device; only the K_part bounds travel to the (pinned, device-visible) host array.  Where the B' launch is
             // the direct-to-LDS kernel, its epilogue leaves the row sums and Frobenius shares of B' behind (no norm pass
             // over B'), and the Collatz-Wielandt pass finishes the bound itself.
-            const int btile = c->fused_bounds ? symm_bounds_tile(Kh[h], c->p, var_parts) : 0;
-            const int bT = btile ? (c->p + btile - 1) / btile : 0;
-            double* rowp = btile ? c->rowpart + (size_t)k0 * bT * c->p : nullptr;
-            double* frop = btile ? c->fropart + (size_t)k0 * (bT * (bT + 1) / 2) : nullptr;
             ns_prepare(sh, pre_d + NS_NCOEF * (size_t)k0, pre_d + NS_SLOT(K) + NS_NCOEF * (size_t)k0, c->W + k0 * pp, Ap, Bp, Kh[h], c->p,
                        var_parts, spec ? fused[h] : nullptr, rowp, frop);
+            if (early_ev) {
+                (void)hipEventRecord(c->ev_early[c->ev_early_par][1], c->stream);
+                c->ev_early_used[c->ev_early_par] = true;
+            }
+            }
+            if (want_A) continue;
+            if (resume && h == 0) PB(c, GGL_PH_EIG_OMEGA);
+            // ---- the rest: bound of this iteration's A' (validation of the assumed one), products, Omega ----
             if (btile) {
                 if (c->fused_cw) {
                     launch_bound_cw(sh, Bp, rowp, bT, Kh[h], c->p, c->nbrow + (size_t)k0 * c->p, frop, bT * (bT + 1) / 2,
@@ -1282,6 +1365,13 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             if (h == 0 && !spec) PE(c, GGL_PH_EIG_OMEGA);
         }
         HIPCHK(hipGetLastError());
+        if (want_A) {
+            for (int h = 0; h < nh; ++h) { c->early.plans[h] = plans[h]; c->early.fused[h] = fused[h]; }
+            memcpy(c->early.beta, c->par_h, K * sizeof(double));
+            c->early.valid = true;
+            c->early_launched += 1;
+            return GGL_OK;
+        }
         if (spec) {
             for (int h = 1; h < nh; ++h) {
                 HIPCHK(hipEventRecord(c->ev_join[h - 1], c->streamx[h - 1]));
@@ -1874,6 +1964,10 @@ static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double l
         if (rows != 1) return fail(GGL_E_ARG, "deferred norms need a single row of sums (non-latent GGL/FGL)");
         return GGL_OK;
     }
+    if (!latent) {
+        const int rce = maybe_early(c);
+        if (rce) return rce;
+    }
     return finish_norms(c, rows, out_norms);
 }
 
@@ -1882,6 +1976,21 @@ extern "C" int ggl_norms_read(ggl_ctx* c, double out_norms[5])
     ARGCHK(c && out_norms, "ctx, out_norms");
     HIPCHK(hipSetDevice(c->device));
     return finish_norms(c, 1, out_norms);      // 1 = a speculative step failed validation on some rank: repeat it
+}
+
+// Early first part of the NEXT iteration's chain (ggl_ctx::EarlyA), called with this iteration's Theta-step and reduction in the
+// stream and the host about to wait for them.  Launched on a prediction -- the last iteration's residual ratio was calm, so
+// the rho rule will very likely keep rho -- and forgotten if the prediction fails (cost: ~0.2 ms of device time).
+static int maybe_early(ggl_ctx* c)
+{
+    if (!c->early_caller || !c->early_part || !c->pipeline || !c->omega_ns || !c->spec_enable || c->prof_on == 1 || c->last_step_hint || !c->ratio_calm ||
+        c->chain_mode || c->pre_valid)
+        return GGL_OK;
+    if (c->lds_omega && c->p <= omega_lds_max_p()) return GGL_OK;      // (one kernel writes Omega there: nothing to split)
+    c->early_request = true;
+    const int rc = omega_step(c, 0, nullptr, /*allow_spec=*/true, /*only_spec=*/true);
+    c->early_request = false;
+    return rc == GGL_NOT_LAUNCHED ? GGL_OK : rc;
 }
 
 // Pipelining across iterations (ggl_ctx::pipeline).  take_prelaunched: beta_k = nk/rho of the step about to run is in
@@ -1914,13 +2023,17 @@ static int maybe_prelaunch(ggl_ctx* c, double rho, const double out_norms[5])
 {
     const bool last = c->last_step_hint;
     c->last_step_hint = false;
-    if (!c->pipeline || last || !c->omega_ns || c->prof_on == 1) return GGL_OK;
+    c->ratio_calm = false;
+    if (!c->pipeline || last || !c->omega_ns || c->prof_on == 1) { c->early.valid = false; return GGL_OK; }
     const double r_t = std::sqrt(out_norms[3]), s_t = rho * std::sqrt(out_norms[4]);
-    if (r_t >= 10.0 * s_t || s_t >= 10.0 * r_t) return GGL_OK;
+    if (r_t >= 10.0 * s_t || s_t >= 10.0 * r_t) { c->early.valid = false; return GGL_OK; }
     const int cur0 = c->cur;
-    int rc = omega_step(c, 0, nullptr, /*allow_spec=*/true, /*only_spec=*/true);
+    int rc = omega_step(c, 0, nullptr, /*allow_spec=*/true, /*only_spec=*/true);      // (continues an early first part, if there is one)
     if (rc == GGL_NOT_LAUNCHED) return GGL_OK;
     if (rc) return rc;
+    // residuals well inside the band in which the rho rule keeps rho: the next iteration may put the first part of ITS
+    // successor's chain into the stream before it waits for its own residuals (maybe_early)
+    c->ratio_calm = (r_t < 4.0 * s_t && s_t < 4.0 * r_t);
     c->cur = cur0;                               // Omega_t stays the current iterate until the chain is taken over
     c->pre_spec_pending = c->spec_pending;
     c->spec_pending = false;
@@ -1952,7 +2065,9 @@ extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lamb
         rc = omega_step(c, latent, &sg, /*allow_spec=*/true);
         if (rc) return rc;
     }
+    c->early_caller = true;
     rc = ggl_step_finish_impl(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
+    c->early_caller = false;
     if (rc == GGL_SPEC_RETRY) {
         // the speculative schedule did not cover this iteration's spectrum: same step again, bounds first
         rc = omega_step(c, latent, nullptr, false);
@@ -2207,7 +2322,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->symm_variant = src->symm_variant; c->spin_wait = src->spin_wait; c->fused_bounds = src->fused_bounds;
     c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->ns_tol = src->ns_tol;
     c->cw_warm = src->cw_warm; c->chain_mode = src->chain_mode; c->rank_l0 = src->rank_l0; c->rank_l0_coarse = src->rank_l0_coarse;
-    c->isolate = src->isolate; c->fused_cw = src->fused_cw; c->lds_omega = src->lds_omega; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
+    c->isolate = src->isolate; c->fused_cw = src->fused_cw; c->lds_omega = src->lds_omega; c->early_part = src->early_part; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
     int* didx = nullptr;
     hipError_t e = hipMalloc(&didx, m * sizeof(int));
     if (e == hipSuccess) e = hipMemcpyAsync(didx, idx, m * sizeof(int), hipMemcpyHostToDevice, src->stream);
@@ -2263,6 +2378,8 @@ extern "C" int ggl_profile_enable(ggl_ctx* c, int on)
     if (on && !c->ev[0][0]) {
         for (int ph = 0; ph < GGL_NPHASE; ++ph)
             for (int e = 0; e < 2; ++e) HIPCHK(hipEventCreate(&c->ev[ph][e]));
+        for (int q = 0; q < 2; ++q)
+            for (int e = 0; e < 2; ++e) HIPCHK(hipEventCreate(&c->ev_early[q][e]));
     }
     c->prof_on = (on == 2) ? 2 : (on != 0 ? 1 : 0);
     return GGL_OK;
@@ -2308,6 +2425,18 @@ extern "C" int ggl_lds_stats(ggl_ctx* c, long long out[4])
         out[2] = (long long)cnt[0];
         out[3] = (long long)cnt[1];
     }
+    return GGL_OK;
+}
+
+// Pipelining across iterations (GGL_OPT_PIPELINE): { whole chains launched ahead of the caller's next step, of those forgotten
+// (rho changed), early first parts put into the stream before the wait for the residuals, of those continued }
+extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[4])
+{
+    ARGCHK(c && out, "ctx, out");
+    out[0] = c->pre_launched;
+    out[1] = c->pre_dropped;
+    out[2] = c->early_launched;
+    out[3] = c->early_used;
     return GGL_OK;
 }
 

@@ -450,6 +450,12 @@ class HipEngine:
         check(self.lib.ggl_lds_stats(self.h, out))
         return dict(zip(("calls", "misses", "products", "steps"), (int(v) for v in out)))
 
+    def pipeline_stats(self):
+        import ctypes
+        out = (ctypes.c_longlong * 4)()
+        check(self.lib.ggl_pipeline_stats(self.h, out))
+        return dict(zip(("prelaunched", "dropped", "early_launched", "early_used"), (int(v) for v in out)))
+
     def eig_info(self):
         """(K,) sweeps of the LDS Jacobi kernel in the last step (-1: not converged), or rocSOLVER's info."""
         import ctypes

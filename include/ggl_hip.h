@@ -127,6 +127,10 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_OMEGA_LDS 23       /* [1] p <= 64: the whole Omega-step as ONE launch, one workgroup per instance, the Newton-Schulz chain
                                       resident in LDS, bound and per-instance schedule chosen on the device (omega_lds.hip); an instance
                                       outside its range (condition number of W^2 + 4 beta I above 300) sends the step to the launch chain */
+#define GGL_OPT_EARLY_PART 24      /* [1] with GGL_OPT_PIPELINE, ggl_admm_step: the first part of the NEXT iteration's Omega-step chain (tables,
+                                      W, A', B': scratch only) goes into the stream before the host waits for this iteration's residuals,
+                                      on the prediction that the rho rule keeps rho; its schedule is built from the bounds validated one
+                                      iteration earlier, so iterates agree with GGL_OPT_EARLY_PART = 0 to the Omega-step's tolerance */
 #define GGL_OPT_ISOLATE 19         /* [0] batches of independent problems: an instance whose data turn non-finite or whose eigensolver
                                       does not converge is marked (ggl_failed_instances) instead of failing the call */
 #define GGL_OPT_RANK_L0_COARSE 18  /* [8e-5] two-tier L-step (sign iteration, p > GGL_JACOBI_MAX_P): the first pass over the whole batch
@@ -403,6 +407,11 @@ int ggl_ns_stats(ggl_ctx *ctx, long long out[16]);
 /* The LDS-resident Omega-step (GGL_OPT_OMEGA_LDS): out = { launches, launches repeated on the launch chain because an instance
  * fell outside the kernel's range, products summed over all instances of all launches, Newton-Schulz steps likewise }. */
 int ggl_lds_stats(ggl_ctx *ctx, long long out[4]);
+/* Pipelining across iterations (GGL_OPT_PIPELINE, ggl_admm_step): out = { whole Omega-step chains launched ahead of the caller's
+ * next step (after an iteration was validated, while the caller looks at its residuals), of those forgotten because rho changed,
+ * early first parts (tables, W, A', B' of the NEXT iteration's chain, put into the stream before the host waits for this
+ * iteration's residuals), of those continued }. */
+int ggl_pipeline_stats(ggl_ctx *ctx, long long out[4]);
 /* L-step (sign iteration): out = { calls, calls whose first pass was continued on a compact sub-batch, instances continued in
  * total, calls that fell back to the eigendecomposition } */
 int ggl_rank_stats(ggl_ctx *ctx, long long out[4]);

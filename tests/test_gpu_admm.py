@@ -518,20 +518,25 @@ def test_sharded_driver_rccl_behind_the_c_abi_single_rank(sol):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("early", [0, 1])
 @pytest.mark.parametrize("reg,K,p", [("GGL", 4, 160), ("GGL", 16, 200), ("FGL", 3, 150), ("GGL", 8, 400)])
-def test_pipelined_iterations_are_bitwise_the_unpipelined_ones(sol, reg, K, p, monkeypatch):
+def test_pipelined_iterations_are_bitwise_the_unpipelined_ones(sol, reg, K, p, early, monkeypatch):
     """GGL_OPT_PIPELINE: ggl_admm_step launches the next iteration's Omega-step chain before it returns.  The chain only
     touches scratch and Omega[cur^1], so the iterates must be BITWISE those of the unpipelined run -- with rho changes
-    (chains dropped), with the state read in the middle of the loop (chain dropped by ggl_get_state), and at the end."""
+    (chains dropped), with the state read in the middle of the loop (chain dropped by ggl_get_state), and at the end.
+    GGL_OPT_EARLY_PART additionally puts the first part of the chain (W, A', B') into the stream BEFORE the wait for the
+    residuals, with a schedule built from the bounds validated one iteration earlier: same iteration, the Omega-step's
+    coefficients differ in the last digits -- iterates within 1e-10 of the unpipelined ones instead of bitwise."""
     from gglasso_amd import synth, solver
     S, _ = synth.make_problem(reg, K=K, p=p, N=2 * p, seed=43)
     Om0 = np.stack([np.eye(p)] * K)
-    outs, stats = [], []
+    outs, stats, pipe_stats = [], [], []
+    n_it = 16 if not early else 40
     for pipe in (0, 1):
-        eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"pipeline": pipe})
+        eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"pipeline": pipe, "early_part": early})
         nk = np.ones(K)
         rho, mid = 1.0, None
-        for it in range(16):
+        for it in range(n_it):
             sq = eng.step(rho, 0.05, 0.01, reg, False, None, nk).copy()
             r_t, s_t, _, _ = solver.residuals_from_norms(sq, rho, 1e-20, 1e-20, 1.0)
             new = solver.next_rho(rho, r_t, s_t)
@@ -542,14 +547,24 @@ def test_pipelined_iterations_are_bitwise_the_unpipelined_ones(sol, reg, K, p, m
                 mid = eng.state()          # any entry point other than the step drops a pre-launched chain first
         outs.append((mid, eng.state(), rho))
         stats.append(eng.ns_stats())
+        pipe_stats.append(eng.pipeline_stats())
         eng.close()
     for a, b in zip(outs[0][:2], outs[1][:2]):
         for nm in ("Omega", "Theta", "X"):
-            assert np.array_equal(a[nm], b[nm]), nm
+            if early:
+                assert np.abs(a[nm] - b[nm]).max() <= 1e-10, nm
+                assert np.array_equal(b[nm], b[nm].transpose(0, 2, 1)), nm
+            else:
+                assert np.array_equal(a[nm], b[nm]), nm
     assert outs[0][2] == outs[1][2]
     assert stats[0]["pre_dropped"] == 0 and stats[1]["spec_calls"] > stats[0]["spec_calls"]
     assert stats[1]["pre_dropped"] >= 1                      # the chain behind iteration 10 was dropped by state()
-    ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, reg, Om0, max_iter=16, tol=1e-20, rtol=1e-20)
+    assert pipe_stats[0]["early_launched"] == 0
+    if early:
+        assert pipe_stats[1]["early_launched"] >= 5 and pipe_stats[1]["early_used"] >= pipe_stats[1]["early_launched"] - 3, pipe_stats[1]
+    else:
+        assert pipe_stats[1]["early_launched"] == 0
+    ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, reg, Om0, max_iter=n_it, tol=1e-20, rtol=1e-20)
     for nm in ("Omega", "Theta", "X"):
         assert np.abs(outs[1][1][nm] - ref[nm]).max() <= 1e-9, nm
 
