@@ -297,6 +297,15 @@ __global__ __launch_bounds__(256) void k_copy_small(CopySegs sg)
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < sg.words[s]; i += gridDim.x * 256) d[i] = src ? src[i] : 0u;
 }
 
+// one wave that does nothing for `us` microseconds (100 MHz wall clock): the stream-concurrency probe of ggl_capi.hip
+__global__ void k_spin_us(long long us)
+{
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < us * 100) __builtin_amdgcn_s_sleep(32);
+}
+
+void launch_spin_us(hipStream_t st, int us) { hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, st, (long long)us); }
+
 void launch_copy_small(hipStream_t st, const CopySegs& segs)
 {
     if (segs.n == 0) return;

@@ -136,6 +136,9 @@ struct ggl_ctx {
         double* beta = nullptr;                       // (K) beta the part was built for
     } early;
     bool early_part = true;                           // GGL_OPT_EARLY_PART
+    int part_priority = 0;                            // GGL_OPT_PART_PRIORITY
+    bool parts_probed = false;                        // streamx[0] has been checked to run concurrently with the main stream
+    int parts_replaced = 0;                           // candidates tried by that check (0: the stream was fine)
     bool early_caller = false;                        // set by ggl_admm_step around its Theta-step: the early part may be launched
     bool early_request = false;                       // omega_step: launch phase A only
     bool ratio_calm = false;                          // last validated iteration: residual ratio well inside the rho rule's band
@@ -480,6 +483,24 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_FUSED_CW: c->fused_cw = v != 0.0; break;
         case GGL_OPT_OMEGA_LDS: c->lds_omega = v != 0.0; break;
         case GGL_OPT_EARLY_PART: c->early_part = v != 0.0; break;
+        case GGL_OPT_PART_PRIORITY: {
+            if (v != 0.0 && v != 1.0 && v != 2.0) return fail(GGL_E_ARG, "bad argument: GGL_OPT_PART_PRIORITY is 0, 1 or 2");
+            if (!c->omega_ns || (int)v == c->part_priority) break;
+            int lo = 0, hi = 0;                       // (numerically: hi <= 0 <= lo)
+            HIPCHK(hipSetDevice(c->device));
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (int i = 0; i < ggl_ctx::MAX_PARTS - 1; ++i) {
+                HIPCHK(hipStreamSynchronize(c->streamx[i]));
+                HIPCHK(hipStreamDestroy(c->streamx[i]));
+                c->streamx[i] = nullptr;
+                if (v == 0.0) HIPCHK(hipStreamCreateWithFlags(&c->streamx[i], hipStreamNonBlocking));
+                else HIPCHK(hipStreamCreateWithPriority(&c->streamx[i], hipStreamNonBlocking, v == 1.0 ? hi : lo));
+            }
+            c->part_priority = (int)v;
+            c->parts_probed = false;
+            break;
+        }
         case GGL_OPT_RANK_DEFLATE: c->rank_deflate = v != 0.0; break;
         case GGL_OPT_RANK_L0_DEFLATE:
             if (!(v > 0.0) || v > 0.1) return fail(GGL_E_ARG, "bad argument: GGL_OPT_RANK_L0_DEFLATE is in (0, 0.1]");
@@ -532,6 +553,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_FUSED_CW: *value = c->fused_cw; break;
         case GGL_OPT_OMEGA_LDS: *value = c->lds_omega; break;
         case GGL_OPT_EARLY_PART: *value = c->early_part; break;
+        case GGL_OPT_PART_PRIORITY: *value = c->part_priority; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
         default: return fail(GGL_E_ARG, "bad argument: unknown ctx option %d", opt);
@@ -1006,6 +1028,59 @@ extern "C" int ggl_step_omega_spec(ggl_ctx* c, double rho, int latent, const dou
     return omega_step(c, latent, &sg, c->ns_parts < ggl_ctx::MAX_PARTS);
 }
 
+// HIP hands its streams a small pool of hardware queues, and two streams on the SAME queue run one after the other: the
+// concurrent parts of an Omega-step then serialise without any error (seen with RCCL in the process: every kernel of both
+// parts on one queue, K = 8 slabs 2300 instead of 3190 it/s).  Which queue a stream got cannot be asked, so it is measured,
+// once per ctx before the first two-part step: an idle wave of 150 us on the main stream and on the part stream at the same
+// time -- together they take ~150 us on different queues and ~300 us on one.  A part stream that serialises is replaced by
+// the first of up to eight fresh streams that does not (stream priorities would force another queue, but starve one part:
+// headline 1310 -> 940 / 864 it/s with a high / low priority part stream, GGL_OPT_PART_PRIORITY).
+static int probe_part_streams(ggl_ctx* c)
+{
+    if (c->parts_probed) return GGL_OK;
+    c->parts_probed = true;
+    hipEvent_t e0, e1, e2;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventCreate(&e2));
+    auto serial = [&](hipStream_t cand, bool* out) -> int {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(cand));
+        HIPCHK(hipEventRecord(e0, c->stream));
+        launch_spin_us(c->stream, 150);
+        launch_spin_us(cand, 150);
+        HIPCHK(hipEventRecord(e1, c->stream));
+        HIPCHK(hipEventRecord(e2, cand));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventSynchronize(e2));
+        float a = 0.f, b = 0.f;
+        HIPCHK(hipEventElapsedTime(&a, e0, e1));
+        HIPCHK(hipEventElapsedTime(&b, e0, e2));
+        *out = std::max(a, b) > 0.24f;
+        return GGL_OK;
+    };
+    int rc = GGL_OK;
+    bool ser = false;
+    rc = serial(c->streamx[0], &ser);
+    hipStream_t spare[8];
+    int ns = 0;
+    while (rc == GGL_OK && ser && ns < 8) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+        spare[ns++] = cand;
+        rc = serial(cand, &ser);
+        if (rc == GGL_OK && !ser) {
+            std::swap(c->streamx[0], spare[ns - 1]);      // the old part stream joins the ones to destroy
+            c->parts_replaced = ns;
+        }
+    }
+    for (int i = 0; i < ns; ++i) (void)hipStreamDestroy(spare[i]);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
+    return rc;
+}
+
 // the LDS-resident Omega-step's schedule table for the ctx's stopping tolerance / degree set (rebuilt when they change)
 static int lds_table(ggl_ctx* c)
 {
@@ -1262,6 +1337,10 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             }
         }
         if (only_spec && !spec) return GGL_NOT_LAUNCHED;
+        if (nh > 1 && !c->parts_probed) {
+            rc = probe_part_streams(c);
+            if (rc) return rc;
+        }
         if (nh > 1 && !resume) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
             for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
@@ -2429,14 +2508,16 @@ extern "C" int ggl_lds_stats(ggl_ctx* c, long long out[4])
 }
 
 // Pipelining across iterations (GGL_OPT_PIPELINE): { whole chains launched ahead of the caller's next step, of those forgotten
-// (rho changed), early first parts put into the stream before the wait for the residuals, of those continued }
-extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[4])
+// (rho changed), early first parts put into the stream before the wait for the residuals, of those continued, fresh streams the
+// concurrency probe of the part streams had to try (0: the part stream ran beside the main stream; -1: not probed yet) }
+extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[5])
 {
     ARGCHK(c && out, "ctx, out");
     out[0] = c->pre_launched;
     out[1] = c->pre_dropped;
     out[2] = c->early_launched;
     out[3] = c->early_used;
+    out[4] = c->parts_probed ? c->parts_replaced : -1;
     return GGL_OK;
 }
 

@@ -47,6 +47,7 @@ struct CopySegs {
     void add(void* d, const void* s, size_t bytes) { dst[n] = d; src[n] = s; words[n] = (unsigned)(bytes / 4); ++n; }
 };
 void launch_copy_small(hipStream_t st, const CopySegs& segs);
+void launch_spin_us(hipStream_t st, int us);      // one idle wave for `us` microseconds (stream-concurrency probe)
 // K-sharded speculation: this rank's validation flags -> one double behind the (p,p) all-reduce buffer, and back
 void launch_spec_pack(hipStream_t st, const int* flags /*4, or null*/, double* dst);
 void launch_spec_unpack(hipStream_t st, const double* src, int* flag, int* flag_host);

@@ -452,9 +452,9 @@ class HipEngine:
 
     def pipeline_stats(self):
         import ctypes
-        out = (ctypes.c_longlong * 4)()
+        out = (ctypes.c_longlong * 5)()
         check(self.lib.ggl_pipeline_stats(self.h, out))
-        return dict(zip(("prelaunched", "dropped", "early_launched", "early_used"), (int(v) for v in out)))
+        return dict(zip(("prelaunched", "dropped", "early_launched", "early_used", "part_streams_tried"), (int(v) for v in out)))
 
     def eig_info(self):
         """(K,) sweeps of the LDS Jacobi kernel in the last step (-1: not converged), or rocSOLVER's info."""

@@ -131,6 +131,9 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                       W, A', B': scratch only) goes into the stream before the host waits for this iteration's residuals,
                                       on the prediction that the rho rule keeps rho; its schedule is built from the bounds validated one
                                       iteration earlier, so iterates agree with GGL_OPT_EARLY_PART = 0 to the Omega-step's tolerance */
+#define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
+                                      2 = with the lowest stream priority (streams of another priority never share a hardware queue with
+                                      the ctx's main stream) */
 #define GGL_OPT_ISOLATE 19         /* [0] batches of independent problems: an instance whose data turn non-finite or whose eigensolver
                                       does not converge is marked (ggl_failed_instances) instead of failing the call */
 #define GGL_OPT_RANK_L0_COARSE 18  /* [8e-5] two-tier L-step (sign iteration, p > GGL_JACOBI_MAX_P): the first pass over the whole batch
@@ -410,8 +413,10 @@ int ggl_lds_stats(ggl_ctx *ctx, long long out[4]);
 /* Pipelining across iterations (GGL_OPT_PIPELINE, ggl_admm_step): out = { whole Omega-step chains launched ahead of the caller's
  * next step (after an iteration was validated, while the caller looks at its residuals), of those forgotten because rho changed,
  * early first parts (tables, W, A', B' of the NEXT iteration's chain, put into the stream before the host waits for this
- * iteration's residuals), of those continued }. */
-int ggl_pipeline_stats(ggl_ctx *ctx, long long out[4]);
+ * iteration's residuals), of those continued, fresh streams the concurrency probe had to try before the first two-part
+ * Omega-step until one ran BESIDE the ctx's main stream (HIP streams share a small pool of hardware queues, and two streams on
+ * one queue serialise; 0: the part stream was fine, -1: not probed yet) }. */
+int ggl_pipeline_stats(ggl_ctx *ctx, long long out[5]);
 /* L-step (sign iteration): out = { calls, calls whose first pass was continued on a compact sub-batch, instances continued in
  * total, calls that fell back to the eigendecomposition } */
 int ggl_rank_stats(ggl_ctx *ctx, long long out[4]);

@@ -52,7 +52,8 @@ def stats(monkeypatch):
     def closing(self):
         if getattr(self, "h", None):
             seen.append({**self.ns_stats(), **{"rank_" + k: v for k, v in self.rank_stats().items()},
-                         **{"dispatch_" + k: v for k, v in self.last_dispatch().items()}})
+                         **{"dispatch_" + k: v for k, v in self.last_dispatch().items()},
+                         **{"pipe_" + k: v for k, v in self.pipeline_stats().items()}})
         real_close(self)
 
     monkeypatch.setattr(solver.HipEngine, "close", closing)
@@ -282,6 +283,9 @@ def test_headline_slab_dispatch(stats, K):
     _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
     st = stats[-1]
     assert (st["last_parts"], st["last_variant"]) == {4: (1, 20), 8: (2, 20), 16: (1, 20)}[K], st
+    # two concurrent parts: the part stream was checked to run BESIDE the main stream before the first such step (two HIP
+    # streams on one hardware queue serialise silently; -1 = never probed, n > 0 = n fresh streams tried until one did)
+    assert (st["pipe_part_streams_tried"] >= 0) == (K == 8), st
 
 
 def test_large_p_sgl_latent_p1500(stats):
