@@ -13,7 +13,7 @@ it keeps iterating harmlessly until the whole batch is done.
 import numpy as np
 
 from . import solver as _solver
-from .solver import as_c, residuals_from_norms, next_rho
+from .solver import as_c
 
 
 def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max_iter=1000, tol=1e-7,
@@ -102,7 +102,7 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
         rhos = np.full(K, float(rho))
         done = np.zeros(K, dtype=bool)
         results = [None] * K
-        last = [None] * K
+        last = np.zeros((K, 4))                                         # r_t, s_t, e_pri, e_dual of every point's last iteration
         dimk = (pk ** 2 + pk) / 2                                       # single_admm_solver.py:279, of the block itself
         keep_snapshots = selection_stats or latent
         cur, slots = eng, np.arange(K)                                   # slots[s]: the point in slot s of cur
@@ -122,37 +122,20 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
         for it in range(max_iter):
             sq = cur.sgl_batch_step(rhos[slots], lam[slots], latent, None if mu is None else mu[slots])
             carried[slots] += 1
-            fac = np.ones(len(slots))
-            newly = []
-            for s, k in enumerate(slots):
-                if done[k]:
-                    continue
-                if not np.all(np.isfinite(sq[s])):
-                    # this point's data are not finite (a NaN in its S, a diverged iterate): the reference's sequential walk
-                    # (model_selection.py:619-633) would lose this point only -- so does the batch
-                    finish(s, 'solver error', it + 1)
-                    done[k] = True
-                    if hasattr(cur, "reset_instance"):
-                        cur.reset_instance(s)
-                    continue
-                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[s], rhos[k], tol, rtol, dimk[k])
-                if update_rho:
-                    rn = next_rho(rhos[k], r_t, s_t)
-                    fac[s] = rhos[k] / rn
-                    rhos[k] = rn
-                last[k] = (r_t, s_t, e_pri, e_dual)
-                if verbose:
-                    print("%4d\t%3d\t%10.4g\t%10.4g\t%10.4g\t%10.4g" % (it, k, r_t, s_t, e_pri, e_dual))
-                if (r_t <= e_pri) and (s_t <= e_dual):
-                    done[k] = True
-                    newly.append(s)
+            bad, newly, fac = _decide(sq, slots, rhos, done, last, dimk[slots], tol, rtol, update_rho, it, verbose)
+            for s in bad:
+                # this point's data are not finite (a NaN in its S, a diverged iterate): the reference's sequential walk
+                # (model_selection.py:619-633) would lose this point only -- so does the batch
+                finish(s, 'solver error', it + 1)
+                if hasattr(cur, "reset_instance"):
+                    cur.reset_instance(int(s))
             if np.any(fac != 1.0):
                 cur.scale_X_batch(fac)
             for s in newly:
                 finish(s, 'optimal', it + 1)
             if done.all():
                 break
-            cur, slots = _compact(cur, slots, done, engines, compact)
+            cur, slots = _compact(cur, slots, done, engines, compact, p=p, it=it)
         for s, k in enumerate(slots):
             if results[k] is None:
                 r_t, s_t, e_pri, e_dual = last[k]
@@ -182,6 +165,40 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     return results
 
 
+def _decide(sq, ids, rhos, done, last, dims, tol, rtol, update_rho, it, verbose):
+    """One iteration's host decisions for ALL points of a batch at once -- the reference's per-problem arithmetic
+    (ADMM_stopping_criterion, solver/admm_solver.py:316-331; residual balancing, :227-233; what ``residuals_from_norms`` /
+    ``next_rho`` do for one problem), element-wise in float64 in the same order of operations, so every decision is the one
+    the per-point loop took.  A Python loop over the points costs ~12 us per point and iteration: for a 100-point grid of
+    p = 64 problems that was 1.2 ms of host time per 0.1 ms of device time.
+
+    sq: (len(ids), 5) squared norms of the slots; ids[s]: the point in slot s.  Updates rhos / done / last (rows
+    r_t, s_t, e_pri, e_dual) in place; returns (slots with non-finite sums, slots that converged now, X scaling factors)."""
+    sq = np.asarray(sq, dtype=np.float64).reshape(len(ids), -1)
+    live = ~done[ids]
+    finite = np.all(np.isfinite(sq), axis=1)
+    bad = np.flatnonzero(live & ~finite)
+    ok = live & finite
+    n_om, n_thl, n_x, n_r, n_s = np.sqrt(np.where(ok[:, None], sq[:, :5], 0.0)).T
+    rho = rhos[ids]
+    r_t, s_t = n_r, rho * n_s
+    e_pri = dims * tol + rtol * np.maximum(n_om, n_thl)
+    e_dual = dims * tol + rtol * rho * n_x
+    fac = np.ones(len(ids))
+    if update_rho:
+        rn = np.where(r_t >= 10 * s_t, 2 * rho, np.where(s_t >= 10 * r_t, 0.5 * rho, 1. * rho))
+        fac[ok] = (rho / rn)[ok]
+        rhos[ids[ok]] = rn[ok]
+    last[ids[ok]] = np.stack([r_t, s_t, e_pri, e_dual], axis=1)[ok]
+    if verbose:
+        for s in np.flatnonzero(ok):
+            print("%4d\t%3d\t%10.4g\t%10.4g\t%10.4g\t%10.4g" % (it, ids[s], r_t[s], s_t[s], e_pri[s], e_dual[s]))
+    newly = np.flatnonzero(ok & (r_t <= e_pri) & (s_t <= e_dual))
+    done[ids[bad]] = True
+    done[ids[newly]] = True
+    return bad, newly, fac
+
+
 # Compaction of a batch of independent problems (VERDICT r3 item 7; the reference's walk, helper/model_selection.py:208-224,
 # spends nothing on a point that has converged): once at least a quarter of the slots of the live ctx hold finished points,
 # the points still iterating move to a smaller ctx (HipEngine.subset, device to device) and the products stop paying for the
@@ -190,14 +207,26 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
 # carries 'carried': the batch iterations the point occupied a slot for (its own 'iterations' + what it was dragged along).
 COMPACT_FRACTION = 0.25
 COMPACT_MIN_DROP = 2
+# ... and only when the iterations it saves outweigh what the move costs.  A deterministic model, not a clock (the decision
+# changes the last digits of the result -- the first step in the new ctx plans its schedule afresh -- and must not depend on
+# the machine's mood): a slot of dimension p costs ~2.1e-13 * p^3 s of device time per iteration where the iteration is
+# product-bound (p = 1000: 0.21 ms per slot, tools/bench_grid.py) and nothing below the launch-bound floor, the move ~8 ms
+# (a ctx, its copies, its destruction, one step without speculation; at p = 500 a move that the model priced at 4 ms still
+# lost: 33.5 vs 30.0 ms), and a batch that has run `it` iterations is taken to
+# need as many again (at least 10).  Measured before the model (tools/bench_grid.py): compaction made a 20-point p = 50 grid
+# 3 times and a 100-point p = 64 grid 4 times SLOWER (39.9 vs 13.4 ms, 60.2 vs 14.9 ms) while it takes 13 % off p = 1000.
+COMPACT_SLOT_S_PER_P3 = 2.1e-13
+COMPACT_COST_S = 8e-3
 
 
-def _compact(cur, slots, done, engines, enabled, group=1):
+def _compact(cur, slots, done, engines, enabled, group=1, p=None, it=0):
     if not enabled or not hasattr(cur, "subset"):
         return cur, slots
     alive = np.flatnonzero(~done[slots])
     n_drop = len(slots) - len(alive)
     if len(alive) == 0 or n_drop < COMPACT_MIN_DROP or n_drop < COMPACT_FRACTION * len(slots):
+        return cur, slots
+    if p is not None and n_drop * group * COMPACT_SLOT_S_PER_P3 * float(p) ** 3 * max(it + 1, 10) < COMPACT_COST_S:
         return cur, slots
     idx = alive if group == 1 else (alive[:, None] * group + np.arange(group)[None, :]).reshape(-1)
     new = cur.subset(idx)
@@ -297,7 +326,7 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
         rhos = np.full(G, float(rho))
         done = np.zeros(G, dtype=bool)
         results = [None] * G
-        last = [None] * G
+        last = np.zeros((G, 4))
         dim = K * ((p ** 2 + p) / 2)
         cur, slots = eng, np.arange(G)                                   # slots[s]: the problem in slot s of cur
         carried = np.zeros(G, dtype=np.int64)
@@ -315,37 +344,20 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
         for it in range(max_iter):
             sq = cur.mgl_batch_step(len(slots), rhos[slots], lam1[slots], lam2[slots], reg, latent, inst(mu), nk)
             carried[slots] += 1
-            fac = np.ones(len(slots))
-            newly = []
-            for s, g in enumerate(slots):
-                if done[g]:
-                    continue
-                if not np.all(np.isfinite(sq[s])):
-                    # (see ADMM_SGL_batch: a point with non-finite data costs that point only)
-                    collect(s, 'solver error', it + 1)
-                    done[g] = True
-                    if hasattr(cur, "reset_instance"):
-                        for k in range(K):
-                            cur.reset_instance(s * K + k)
-                    continue
-                r_t, s_t, e_pri, e_dual = residuals_from_norms(sq[s], rhos[g], tol, rtol, dim)
-                if update_rho:
-                    rn = next_rho(rhos[g], r_t, s_t)
-                    fac[s] = rhos[g] / rn
-                    rhos[g] = rn
-                last[g] = (r_t, s_t, e_pri, e_dual)
-                if verbose:
-                    print("%4d\t%3d\t%10.4g\t%10.4g\t%10.4g\t%10.4g" % (it, g, r_t, s_t, e_pri, e_dual))
-                if (r_t <= e_pri) and (s_t <= e_dual):
-                    done[g] = True
-                    newly.append(s)
+            bad, newly, fac = _decide(sq, slots, rhos, done, last, dim, tol, rtol, update_rho, it, verbose)
+            for s in bad:
+                # (see ADMM_SGL_batch: a point with non-finite data costs that point only)
+                collect(s, 'solver error', it + 1)
+                if hasattr(cur, "reset_instance"):
+                    for k in range(K):
+                        cur.reset_instance(int(s) * K + k)
             if np.any(fac != 1.0):
                 cur.scale_X_batch(np.repeat(fac, K))
             for s in newly:
                 collect(s, 'optimal', it + 1)
             if done.all():
                 break
-            cur, slots = _compact(cur, slots, done, engines, compact, group=K)
+            cur, slots = _compact(cur, slots, done, engines, compact, group=K, p=p, it=it)
         for s, g in enumerate(slots):
             if results[g] is None:
                 r_t, s_t, e_pri, e_dual = last[g]

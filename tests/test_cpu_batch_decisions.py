@@ -1,0 +1,86 @@
+"""Host logic of the batch drivers (no GPU): ``batch._decide`` takes one iteration's stopping / rho decisions for all points
+of a batch at once and must take, bit for bit, the decisions of the reference's per-problem arithmetic
+(ADMM_stopping_criterion, solver/admm_solver.py:316-331; residual balancing :227-233 -- ``solver.residuals_from_norms`` /
+``solver.next_rho``)."""
+import numpy as np
+
+from gglasso_amd import batch, solver
+
+
+def _loop(sq, ids, rhos, done, last, dims, tol, rtol, update_rho):
+    bad, newly, fac = [], [], np.ones(len(ids))
+    for s, k in enumerate(ids):
+        if done[k]:
+            continue
+        if not np.all(np.isfinite(sq[s])):
+            bad.append(s)
+            done[k] = True
+            continue
+        r_t, s_t, e_pri, e_dual = solver.residuals_from_norms(sq[s], rhos[k], tol, rtol, dims[s])
+        if update_rho:
+            rn = solver.next_rho(rhos[k], r_t, s_t)
+            fac[s] = rhos[k] / rn
+            rhos[k] = rn
+        last[k] = (r_t, s_t, e_pri, e_dual)
+        if (r_t <= e_pri) and (s_t <= e_dual):
+            done[k] = True
+            newly.append(s)
+    return np.array(bad, dtype=np.int64), np.array(newly, dtype=np.int64), fac
+
+
+def test_vectorised_decisions_are_the_per_point_ones():
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        n_all = int(rng.integers(1, 40))
+        ids = np.sort(rng.choice(n_all, size=int(rng.integers(1, n_all + 1)), replace=False))
+        sq = rng.uniform(0, 1, (len(ids), 5)) ** rng.integers(1, 12)            # residuals from O(1) down to ~1e-12
+        sq[:, :3] *= rng.uniform(1, 1e4, (len(ids), 1))
+        # the boundaries of the rho rule and of the stopping test, exactly
+        if len(ids) > 2:
+            sq[0, 3] = 100.0 * sq[0, 4]
+            sq[1, 4] = 100.0 * sq[1, 3]
+        if trial % 5 == 0:
+            sq[rng.integers(len(ids)), rng.integers(5)] = [np.nan, np.inf, -np.inf][trial % 3]
+        rhos0 = 2.0 ** rng.integers(-4, 5, n_all).astype(float)
+        done0 = rng.uniform(size=n_all) < 0.2
+        dims = (rng.integers(2, 60, len(ids)) ** 2).astype(float)
+        tol, rtol = 10.0 ** -rng.integers(3, 9), 10.0 ** -rng.integers(2, 8)
+        for update_rho in (True, False):
+            a = dict(rhos=rhos0.copy(), done=done0.copy(), last=np.zeros((n_all, 4)))
+            b = dict(rhos=rhos0.copy(), done=done0.copy(), last=np.zeros((n_all, 4)))
+            ra = batch._decide(sq, ids, a["rhos"], a["done"], a["last"], dims, tol, rtol, update_rho, 0, False)
+            rb = _loop(sq, ids, b["rhos"], b["done"], b["last"], dims, tol, rtol, update_rho)
+            for x, y in zip(ra, rb):
+                assert np.array_equal(np.asarray(x), np.asarray(y))
+            for key in ("rhos", "done", "last"):
+                assert np.array_equal(a[key], b[key]), key
+
+
+def test_scalar_dimension_as_in_the_multiple_graph_batch():
+    sq = np.array([[4.0, 9.0, 1.0, 1e-12, 1e-14], [4.0, 9.0, 1.0, 1.0, 1e-4]])
+    ids = np.arange(2)
+    rhos, done, last = np.ones(2), np.zeros(2, dtype=bool), np.zeros((2, 4))
+    bad, newly, fac = batch._decide(sq, ids, rhos, done, last, 50.0, 1e-7, 1e-5, True, 0, False)
+    assert len(bad) == 0 and list(newly) == [0] and list(done) == [True, False]
+    assert list(rhos) == [2.0, 2.0] and list(fac) == [0.5, 0.5]      # r_t >= 10 s_t for both
+
+
+def test_compaction_cost_model():
+    """batch._compact moves the live points to a smaller ctx only where the saved iterations outweigh the move (a model in p,
+    the dropped slots and the iterations so far -- never a clock: the decision shows in the last digits of the result)."""
+    class Eng:
+        def subset(self, idx):
+            return ("subset", tuple(int(i) for i in idx))
+
+    def moved(p, n, n_done, it, group=1):
+        done = np.zeros(n, dtype=bool)
+        done[:n_done] = True
+        cur, slots = batch._compact(Eng(), np.arange(n), done, [], True, group=group, p=p, it=it)
+        return not isinstance(cur, Eng)
+
+    assert moved(1000, 20, 5, 3)                    # C2 of SURVEY section 8: compacts after a few iterations
+    assert not moved(64, 100, 60, 50)               # a hundred small problems: never
+    assert not moved(50, 20, 10, 80)
+    assert not moved(500, 20, 5, 3) and not moved(500, 20, 10, 18) and moved(500, 20, 10, 40)
+    assert moved(500, 12, 6, 10, group=6) and not moved(500, 12, 6, 10, group=1)
+    assert not moved(1000, 20, 1, 3) and not moved(1000, 20, 4, 3)      # the old rules stay: >= 2 slots and a quarter of the ctx

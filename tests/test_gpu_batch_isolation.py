@@ -120,12 +120,14 @@ def test_mgl_grid_with_a_poisoned_point_through_the_batch_driver(monkeypatch):
 
 
 @pytest.mark.parametrize("p,latent", [(60, False), (200, False), (200, True)])
-def test_sgl_batch_compaction_equals_the_uncompacted_batch(p, latent):
+def test_sgl_batch_compaction_equals_the_uncompacted_batch(p, latent, monkeypatch):
     """A lambda1 path whose points need very different iteration counts, with and without compaction: same status and iteration
     count per point, same solutions (1e-9: a step in a fresh ctx is planned from its own bounds, not from carried ones), and the
-    compacted run carries its points for far fewer batch iterations."""
-    from gglasso_amd import synth
+    compacted run carries its points for far fewer batch iterations.  (The cost model that keeps small problems from being
+    compacted at all -- batch.COMPACT_COST_S -- is switched off: this is the mechanism's test.)"""
+    from gglasso_amd import batch, synth
     from gglasso_amd.batch import ADMM_SGL_batch
+    monkeypatch.setattr(batch, "COMPACT_COST_S", 0.0)
     S, _ = synth.make_problem("GGL", 1, p, N=2 * p, seed=21)
     lam = np.logspace(0, -2, 12)
     kw = dict(tol=1e-7, rtol=1e-7, max_iter=500, selection_stats=True)
@@ -149,9 +151,10 @@ def test_sgl_batch_compaction_equals_the_uncompacted_batch(p, latent):
     assert its.sum() <= carried_b < carried_a, (carried_a, carried_b, its.sum())
 
 
-def test_mgl_batch_compaction_equals_the_uncompacted_batch():
-    from gglasso_amd import synth
+def test_mgl_batch_compaction_equals_the_uncompacted_batch(monkeypatch):
+    from gglasso_amd import batch, synth
     from gglasso_amd.batch import ADMM_MGL_batch
+    monkeypatch.setattr(batch, "COMPACT_COST_S", 0.0)
     K, p = 3, 150
     S, _ = synth.make_problem("FGL", K, p, N=2 * p, seed=23)
     lam1 = np.logspace(-0.3, -1.7, 8)
@@ -167,6 +170,22 @@ def test_mgl_batch_compaction_equals_the_uncompacted_batch():
         assert np.array_equal(a[g][1]['rank'], b[g][1]['rank'])
         assert np.allclose(a[g][1]['selection'], b[g][1]['selection'], rtol=1e-9)
     assert sum(r[1]['carried'] for r in b) < sum(r[1]['carried'] for r in a)
+
+
+def test_small_problems_are_not_compacted():
+    """The move to a smaller ctx costs ~8 ms; an iteration of a 12-point p = 60 batch costs 0.1 ms.  By default (the cost model
+    of batch._compact) such a batch stays where it is: every point is carried to the end, and the results are the
+    uncompacted ones bit for bit."""
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_SGL_batch
+    S, _ = synth.make_problem("GGL", 1, 60, N=120, seed=21)
+    lam = np.logspace(0, -2, 12)
+    kw = dict(tol=1e-7, rtol=1e-7, max_iter=500)
+    a = ADMM_SGL_batch(S[0], lam, compact=False, **kw)
+    b = ADMM_SGL_batch(S[0], lam, compact=True, **kw)
+    assert [r[1]['carried'] for r in a] == [r[1]['carried'] for r in b]
+    for k in range(len(lam)):
+        assert np.array_equal(a[k][0]['Theta'], b[k][0]['Theta'])
 
 
 def test_ext_grid_with_a_poisoned_point(monkeypatch):
