@@ -365,6 +365,7 @@ static int ctx_alloc(ggl_ctx* c)
     pl = std::max(pl, (size_t)pair_blocks(c->p, GGL_REG_FGL, c->K) * GGL_NNORM);
     pl = std::max(pl, (size_t)theta_partial_blocks(c->p, GGL_REG_GGL, c->K, 1) * GGL_NNORM);
     pl = std::max(pl, (size_t)theta_partial_blocks(c->p, GGL_REG_GGL, c->K, 2) * GGL_NNORM);
+    pl = std::max(pl, (size_t)theta_partial_blocks(c->p, GGL_REG_FGL, c->K, 2) * GGL_NNORM);
     c->partials_len = pl;
     DEV(c->partials, pl * sizeof(double));
     // (K,8) rows, and 2 * nprob * GGL_NNORM doubles for a batch of ext problems with ONE instance each (nprob = K)

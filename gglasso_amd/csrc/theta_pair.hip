@@ -12,6 +12,7 @@
 // FGL (ggl_helper.py:131-134): the K-vector of each pair sits in an LDS column ([k][thread], bank
 // = thread, conflict free however the threads' scan positions diverge) and Condat's scan
 // (fgl_helper.py:11-68) runs on it in place, one pair per thread.
+#include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -58,8 +59,10 @@ static inline bool use_flat16(int K, int p, int flat, int G)
     return G == 1 && use_flat4(K, flat) && K > 64 && ((size_t)p * p + 127) / 128 < 256;
 }
 
+static inline int fgl_flat_nt(int K);
 int theta_partial_blocks(int p, int reg, int K, int flat, int G)
 {
+    if (reg == 2 && flat && K <= FGL_MAX_K_TD8) return (int)(((size_t)p * p + fgl_flat_nt(K) - 1) / fgl_flat_nt(K));
     if (reg == 1 && flat && K <= GGL_FLAT_MAX_K && use_flat16(K, p, flat, G)) return (int)(((size_t)p * p + 15) / 16);
     if (reg == 1 && flat && K <= GGL_FLAT_MAX_K) return use_flat4(K, flat) ? (int)(((size_t)p * p + 64 * FLAT4_CHUNKS - 1) / (64 * FLAT4_CHUNKS)) : flat_blocks(p);
     return pair_blocks(p, reg, K);
@@ -645,6 +648,161 @@ __global__ __launch_bounds__(TD * TD) void k_theta_fgl(double* __restrict__ Thet
     }
 }
 
+// FGL per ELEMENT (exactly symmetric state, like the GGL per-element kernels): a workgroup takes NT consecutive elements of the
+// flattened (p,p) index, every thread the K-column of its own element -- (i,j) and (j,i) are both computed, each from its own
+// (bitwise equal) inputs, so the output is bitwise symmetric without a mirror pass.  Twice the scans of the tile-pair kernel
+// above (cheap since round 3's uniform scan), but every global access is a full row of the wave (512 contiguous bytes per
+// instance) where the 8 x 8 tiles read 64-byte row segments and wrote the mirror tile column-wise through LDS: the memory
+// side was 202 of the tile kernel's 263 us at (50,500).
+// Reference: prox_phi_fgl = prox_1norm(prox_tv(v, l2), l1) on the K-vector of every off-diagonal element
+// (solver/ggl_helper.py:73-82, fgl_helper.py:11-68), the diagonal passes through (ggl_helper.py:191-208).
+template <int NT, bool FUSE_DUAL>
+__global__ __launch_bounds__(NT) void k_theta_fgl_flat(double* __restrict__ Theta, double* __restrict__ X,
+                                                       double* __restrict__ C, const double* __restrict__ Omega,
+                                                       const double* __restrict__ OmegaPrev,
+                                                       const double* __restrict__ L, double l1, double l2,
+                                                       double* __restrict__ partials, int K, int p,
+                                                       const int* __restrict__ skip, const double* __restrict__ l1G,
+                                                       const double* __restrict__ l2G)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // [K][NT] then scratch
+    if (spec_failed(skip)) return;
+    {
+        const size_t goff = (size_t)blockIdx.y * K * p * p;
+        Theta += goff; Omega += goff;
+        if (X) X += goff;
+        if (C) C += goff;
+        if (OmegaPrev) OmegaPrev += goff;
+        if (L) L += goff;
+        if (l1G) { l1 = l1G[(size_t)blockIdx.y * K]; l2 = l2G[(size_t)blockIdx.y * K]; }
+        if (partials) partials += (size_t)blockIdx.y * gridDim.x * GGL_NNORM;
+    }
+    const size_t pp = (size_t)p * p;
+    const int tid = threadIdx.x;
+    const size_t e = (size_t)blockIdx.x * NT + tid;
+    const bool live = e < pp;
+    double* ycol = lds + tid;
+    double* scratch = lds + (size_t)K * NT;
+    double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
+    // The K-columns fill the LDS (K = 50: six waves per CU), so nothing but a thread's own loads hides the memory latency:
+    // the loads of N instances of all three stacks are issued before the first is used (8 in flight: 0.33 ms at (50,500),
+    // 16: 0.20 ms, 32: 0.25 ms), and the odd instances at the end go in batches of 8 / 4 / 2 / 1, not one by one.
+    auto load = [&](int k, auto nconst) {
+        constexpr int N = decltype(nconst)::value;
+        double v[N], l[N], x[N];
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const size_t o = (size_t)(k + q) * pp + e;
+            v[q] = Omega[o];
+            l[q] = L ? L[o] : 0.0;
+            x[q] = X ? X[o] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            double u = v[q];
+            if (L) u += l[q];
+            if (X) u += x[q];
+            ycol[(k + q) * NT] = u;
+        }
+    };
+    auto store = [&](int k, auto nconst) {
+        constexpr int N = decltype(nconst)::value;
+        double om[N], x[N], op[N];
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const size_t o = (size_t)(k + q) * pp + e;
+            if (FUSE_DUAL || C) { om[q] = Omega[o]; x[q] = X[o]; }
+            if (FUSE_DUAL) op[q] = OmegaPrev[o];
+        }
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const size_t o = (size_t)(k + q) * pp + e;
+            const double th = ycol[(k + q) * NT];
+            Theta[o] = th;
+            if (FUSE_DUAL) {
+                const double xn = x[q] + (om[q] - th);
+                X[o] = xn;
+                const double dp = om[q] - op[q];
+                acc[0] += om[q] * om[q];
+                acc[1] += th * th;
+                acc[2] += xn * xn;
+                acc[3] += (om[q] - th) * (om[q] - th);
+                acc[4] += dp * dp;
+            } else if (C) {
+                C[o] = (th - x[q]) - om[q];
+            }
+        }
+    };
+    using I16 = std::integral_constant<int, 16>;
+    using I8 = std::integral_constant<int, 8>;
+    using I4 = std::integral_constant<int, 4>;
+    using I2 = std::integral_constant<int, 2>;
+    using I1 = std::integral_constant<int, 1>;
+    if (live) {
+        int k = 0;
+        for (; k + 16 <= K; k += 16) load(k, I16{});
+        if (k + 8 <= K) { load(k, I8{}); k += 8; }
+        if (k + 4 <= K) { load(k, I4{}); k += 4; }
+        if (k + 2 <= K) { load(k, I2{}); k += 2; }
+        if (k < K) load(k, I1{});
+        const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
+        if (i != j) condat_scan(ycol, NT, K, l2, [l1](double v) { return soft(v, l1); });     // prox_phi_fgl: prox_1norm(prox_tv(v))
+        // (every thread reads back its own column only: no barrier)
+        k = 0;
+        for (; k + 16 <= K; k += 16) store(k, I16{});
+        if (k + 8 <= K) { store(k, I8{}); k += 8; }
+        if (k + 4 <= K) { store(k, I4{}); k += 4; }
+        if (k + 2 <= K) { store(k, I2{}); k += 2; }
+        if (k < K) store(k, I1{});
+    }
+    if (FUSE_DUAL) {
+        constexpr int NW = (NT + 63) / 64;
+#pragma unroll
+        for (int v = 0; v < GGL_NNORM; ++v) acc[v] = wave_sum(acc[v]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) scratch[(tid >> 6) * GGL_NNORM + v] = acc[v];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double* o = partials + (size_t)blockIdx.x * GGL_NNORM;
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) {
+                double s = 0.0;
+                for (int w = 0; w < NW; ++w) s += scratch[w * GGL_NNORM + v];
+                o[v] = s;
+            }
+        }
+    }
+}
+
+// elements per workgroup of the per-element FGL kernel: 128 while the K-columns of 128 elements fit the LDS, else 64
+static inline int fgl_flat_nt(int K) { return ((size_t)K * 128 * 8 + 1024 <= (size_t)150 * 1024) ? 128 : 64; }
+
+template <int NT>
+static hipError_t launch_fgl_flat(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
+                                  const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual,
+                                  double* partials, int K, int p, const int* skip, int G, const double* l1G, const double* l2G)
+{
+    const size_t lds = ((size_t)K * NT + GGL_NNORM * 4) * sizeof(double);
+    dim3 grid((unsigned)(((size_t)p * p + NT - 1) / NT), G), blk(NT);
+    hipError_t e;
+    if (fuse_dual) {
+        e = hipFuncSetAttribute((const void*)k_theta_fgl_flat<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_theta_fgl_flat<NT, true>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
+    } else {
+        e = hipFuncSetAttribute((const void*)k_theta_fgl_flat<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_theta_fgl_flat<NT, false>), grid, blk, lds, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G);
+    }
+    return hipGetLastError();
+}
+
+static hipError_t launch_fgl_flat_any(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
+                                      const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual,
+                                      double* partials, int K, int p, const int* skip, int G, const double* l1G, const double* l2G);
+
 template <int TD>
 static hipError_t launch_fgl_td(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                                 const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual,
@@ -1164,7 +1322,7 @@ static void launch_flat4(hipStream_t st, double* Theta, double* X, double* C, co
 // Which Theta kernel the last launch_theta_pair / launch_theta_batch of this process ran (ggl_last_dispatch; the parity tests
 // assert the dispatch of every BASELINE configuration): 0 GGL tile pairs; 100 + KMAX per-element, K-column in one thread;
 // 100 * KQ + NW per-element, K-column over NW waves of KQ values per lane (404, 408: four waves; 808 / 816 / 1616: K <= 64 /
-// 128 / 256); 10000 + 100 * KQ + 16: the same for few elements and many instances, 16 elements per workgroup of 16 waves
+// 128 / 256); 3000 + elements per workgroup: FGL per element (3128 / 3064); 10000 + 100 * KQ + 16: the same for few elements and many instances, 16 elements per workgroup of 16 waves
 // (10216: K <= 128, 10416: K <= 256); 2000 + tile edge: FGL Condat tiles.
 static int g_theta_kernel = -1;
 int theta_last_kernel() { return g_theta_kernel; }
@@ -1241,10 +1399,22 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
         return hipGetLastError();
     }
     if (K > FGL_MAX_K_TD8) return hipErrorInvalidValue;
+    if (flat) return launch_fgl_flat_any(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr);
     g_theta_kernel = 2000 + fgl_tile(K);
     if (fgl_tile(K) == 16)
         return launch_fgl_td<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
     return launch_fgl_td<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip);
+}
+
+// 3000 + elements per workgroup: the per-element FGL kernel (ggl_last_dispatch)
+static hipError_t launch_fgl_flat_any(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
+                                      const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual,
+                                      double* partials, int K, int p, const int* skip, int G, const double* l1G, const double* l2G)
+{
+    const int nt = fgl_flat_nt(K);
+    g_theta_kernel = 3000 + nt;
+    if (nt == 128) return launch_fgl_flat<128>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, G, l1G, l2G);
+    return launch_fgl_flat<64>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, G, l1G, l2G);
 }
 
 // Theta-step of G independent problems of K instances each in one launch (stacks (G*K,p,p); thresholds of problem g at
@@ -1266,10 +1436,8 @@ hipError_t launch_theta_batch(hipStream_t st, int reg, double* Theta, double* X,
         return hipGetLastError();
     }
     if (K > FGL_MAX_K_TD8) return hipErrorInvalidValue;
-    g_theta_kernel = 2000 + fgl_tile(K);
-    if (fgl_tile(K) == 16)
-        return launch_fgl_td<16>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
-    return launch_fgl_td<8>(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
+    // (the batched grids start from exactly symmetric points: always the per-element kernel; theta_partial_blocks(.., 2, G))
+    return launch_fgl_flat_any(st, Theta, X, C, Omega, OmegaPrev, L, 0.0, 0.0, fuse_dual, partials, K, p, skip, G, l1G, l2G);
 }
 
 hipError_t launch_prox_p(hipStream_t st, int reg, double* out, const double* V, double l1, double l2, int K, int p,
