@@ -50,6 +50,7 @@ struct ggl_ctx {
     size_t n = 0;   // K*p*p
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    size_t arena_tot[3] = {0, 0, 0};                 // sizes of the three arenas (reuse across ctxs: pool_take_arenas)
     rocblas_handle blas = nullptr;
     double *S = nullptr, *Om[2] = {nullptr, nullptr}, *Theta = nullptr, *L = nullptr, *X = nullptr, *W = nullptr;
     int cur = 0;              // Om[cur] is Omega_t, Om[cur^1] is Omega_{t-1}
@@ -327,6 +328,99 @@ extern "C" int ggl_device_count(void)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Reuse across ctxs: a solve of a small problem spent more time creating and destroying its ctx than iterating (K = 20,
+// p = 50: create 0.53 ms, destroy 1.74 ms -- three frees that each wait for the device and unmap, four stream
+// destructions -- against 2.0 ms for 30 iterations; tools/time_ctx.py).  Destroyed ctxs therefore leave their three arenas
+// (up to POOL_MAX_BYTES of device memory, two sets) and their streams behind for the next ctx on the same device whose
+// arenas have exactly the same sizes -- the usual case: a grid walked point by point, a compaction, repeated solves.  A
+// reused arena is cleared completely (a fresh one is not guaranteed to be, but in practice is: the same state either way).
+// Whatever is still pooled when the process ends is left to the driver.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t POOL_MAX_BYTES = (size_t)256 << 20;
+constexpr int POOL_SETS = 2, POOL_STREAMS = 8;
+struct ArenaSet { bool used = false; int device = 0; size_t tot[3] = {0, 0, 0}; void* ptr[3] = {nullptr, nullptr, nullptr}; unsigned long long age = 0; };
+struct PoolStream { hipStream_t s = nullptr; int device = 0; };
+std::mutex g_pool_mu;
+ArenaSet g_arenas[POOL_SETS];
+PoolStream g_streams[POOL_STREAMS];
+int g_nstreams = 0;
+unsigned long long g_pool_clock = 0;
+
+bool pool_take_arenas(int device, const size_t tot[3], void* out[3])
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (ArenaSet& a : g_arenas)
+        if (a.used && a.device == device && a.tot[0] == tot[0] && a.tot[1] == tot[1] && a.tot[2] == tot[2]) {
+            for (int i = 0; i < 3; ++i) out[i] = a.ptr[i];
+            a.used = false;
+            return true;
+        }
+    return false;
+}
+
+// returns false when the set was not taken (the caller frees it)
+bool pool_put_arenas(int device, const size_t tot[3], void* const ptr[3])
+{
+    if (tot[0] > POOL_MAX_BYTES) return false;
+    ArenaSet victim;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        ArenaSet* slot = nullptr;
+        for (ArenaSet& a : g_arenas)
+            if (!a.used) { slot = &a; break; }
+        if (!slot) {
+            slot = &g_arenas[0];
+            for (ArenaSet& a : g_arenas)
+                if (a.age < slot->age) slot = &a;
+            victim = *slot;
+        }
+        slot->used = true;
+        slot->device = device;
+        slot->age = ++g_pool_clock;
+        for (int i = 0; i < 3; ++i) { slot->tot[i] = tot[i]; slot->ptr[i] = ptr[i]; }
+    }
+    if (victim.used) {
+        (void)hipSetDevice(victim.device);
+        (void)hipFree(victim.ptr[0]);
+        (void)hipHostFree(victim.ptr[1]);
+        (void)hipHostFree(victim.ptr[2]);
+        (void)hipSetDevice(device);
+    }
+    return true;
+}
+
+hipError_t pool_stream_create(int device, hipStream_t* out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (int i = 0; i < g_nstreams; ++i)
+            if (g_streams[i].device == device) {
+                *out = g_streams[i].s;
+                g_streams[i] = g_streams[--g_nstreams];
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void pool_stream_release(int device, hipStream_t s, bool poolable)
+{
+    if (!s) return;
+    if (poolable) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_nstreams < POOL_STREAMS) {
+            g_streams[g_nstreams].s = s;
+            g_streams[g_nstreams].device = device;
+            ++g_nstreams;
+            return;
+        }
+    }
+    (void)hipStreamDestroy(s);
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
 // All buffers a ctx owns from its creation come out of THREE allocations -- one device arena, one pinned arena, one
@@ -409,7 +503,7 @@ static int ctx_alloc(ggl_ctx* c)
         PIN(c->maxdev_h, 2 * c->K * sizeof(double), 1);
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < ggl_ctx::MAX_PARTS - 1; ++i) {
-            HIPCHK(hipStreamCreateWithFlags(&c->streamx[i], hipStreamNonBlocking));
+            HIPCHK(pool_stream_create(c->device, &c->streamx[i]));
             HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
         }
         c->rank_ns = !c->rank_eig;
@@ -419,9 +513,20 @@ static int ctx_alloc(ggl_ctx* c)
     size_t tot[3] = {0, 0, 0};
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     for (const Req& r : reqs) tot[r.kind] += up(std::max<size_t>(r.bytes, 8));
-    HIPCHK(hipMalloc(&c->arena_dev, std::max<size_t>(tot[0], 256)));
-    HIPCHK(hipHostMalloc(&c->arena_pin, std::max<size_t>(tot[1], 256)));
-    HIPCHK(hipHostMalloc(&c->arena_pin_coh, std::max<size_t>(tot[2], 256), hipHostMallocCoherent));
+    for (int i = 0; i < 3; ++i) c->arena_tot[i] = std::max<size_t>(tot[i], 256);
+    void* reused[3];
+    if (pool_take_arenas(c->device, c->arena_tot, reused)) {
+        c->arena_dev = reused[0];
+        c->arena_pin = reused[1];
+        c->arena_pin_coh = reused[2];
+        HIPCHK(hipMemsetAsync(c->arena_dev, 0, c->arena_tot[0], c->stream));
+        memset(c->arena_pin, 0, c->arena_tot[1]);
+        memset(c->arena_pin_coh, 0, c->arena_tot[2]);
+    } else {
+        HIPCHK(hipMalloc(&c->arena_dev, c->arena_tot[0]));
+        HIPCHK(hipHostMalloc(&c->arena_pin, c->arena_tot[1]));
+        HIPCHK(hipHostMalloc(&c->arena_pin_coh, c->arena_tot[2], hipHostMallocCoherent));
+    }
     size_t off[3] = {0, 0, 0};
     char* base[3] = {(char*)c->arena_dev, (char*)c->arena_pin, (char*)c->arena_pin_coh};
     for (const Req& r : reqs) {
@@ -607,7 +712,7 @@ extern "C" int ggl_ctx_create(int device, int K, int p, int flags, void* stream,
         // stream, e.g. torch's default stream); without the bit a NULL handle means "create one"
         c->stream = (hipStream_t)stream;
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        hipError_t e = pool_stream_create(c->device, &c->stream);
         if (e != hipSuccess) { delete c; return fail(GGL_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
@@ -651,9 +756,14 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     free(c->pre_beta);
     free(c->early.beta);
     // everything ctx_alloc handed out: three allocations
-    if (c->arena_dev) (void)hipFree(c->arena_dev);
-    if (c->arena_pin) (void)hipHostFree(c->arena_pin);
-    if (c->arena_pin_coh) (void)hipHostFree(c->arena_pin_coh);
+    {
+        void* ptr[3] = {c->arena_dev, c->arena_pin, c->arena_pin_coh};
+        if (!(c->arena_dev && c->arena_pin && c->arena_pin_coh && pool_put_arenas(c->device, c->arena_tot, ptr))) {
+            if (c->arena_dev) (void)hipFree(c->arena_dev);
+            if (c->arena_pin) (void)hipHostFree(c->arena_pin);
+            if (c->arena_pin_coh) (void)hipHostFree(c->arena_pin_coh);
+        }
+    }
     for (int ph = 0; ph < GGL_NPHASE; ++ph)
         for (int e = 0; e < 2; ++e)
             if (c->ev[ph][e]) (void)hipEventDestroy(c->ev[ph][e]);
@@ -662,10 +772,10 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
             if (c->ev_early[q][e]) (void)hipEventDestroy(c->ev_early[q][e]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (int i = 0; i < ggl_ctx::MAX_PARTS - 1; ++i) {
-        if (c->streamx[i]) (void)hipStreamDestroy(c->streamx[i]);
+        if (c->streamx[i]) { (void)hipStreamSynchronize(c->streamx[i]); pool_stream_release(c->device, c->streamx[i], c->part_priority == 0); }
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream && c->stream) pool_stream_release(c->device, c->stream, true);
     delete c;
     return GGL_OK;
 }
