@@ -24,77 +24,58 @@
 namespace ggl {
 
 // ---------------------------------------------------------------------------------------------
-// tall-skinny products with a symmetric (K,p,p) stack: Vout[k][q][i] = sum_j A[k][i][j] Vin[k][q][j]
+// tall-skinny products with a SYMMETRIC (K,p,p) stack: Vout[k][q][i] = sum_j A[k][i][j] Vin[k][q][j]
 //   MODE 0: A Vin;   MODE 1: G - A Vin (G [q][p] shared);   MODE 2: A Vin - mu_k Vin
-// vectors are stored [K][DEFL_Q][p] (every column contiguous).  One wave per row, the DEFL_Q columns of Vin in LDS.
+// vectors are stored [K][DEFL_Q][p] (every column contiguous), the DEFL_Q columns of Vin in LDS.
+// A is symmetric, so the sum runs down COLUMN i: a lane owns one output index, a workgroup 64 of them, its four waves every
+// fourth row j (each row segment a full 512-byte wave row, eight rows of loads in flight), Vin[q][j] is an LDS broadcast and
+// no value crosses lanes until the four waves' partial sums meet in LDS, in a fixed order.  (The first version walked the
+// ROWS, one wave per four rows, and reduced 32 sums per step across the wave with shuffles: 50 us per pass at K = 50,
+// p = 500, 2 TB/s -- the shuffles, not the memory.)
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void k_defl_tall(const double* __restrict__ A, const double* __restrict__ Vin, size_t vin_stride,
                                                    const double* __restrict__ G, size_t g_stride, const double* __restrict__ muK,
-                                                   double* __restrict__ Vout, int p, int rows_per_block,
-                                                   const double* __restrict__ meta, int need)
+                                                   double* __restrict__ Vout, int p, const double* __restrict__ meta, int need)
 {
     // need: 0 always; 1 only instances with accepted columns (meta[k][0] > 0)
-    extern __shared__ __attribute__((aligned(16))) double vs[];          // [DEFL_Q][p]
+    extern __shared__ __attribute__((aligned(16))) double vs[];          // [DEFL_Q][p], then [4][DEFL_Q][64] partial sums
     const int k = blockIdx.y;
     if (need == 1 && meta[k * 4 + 0] == 0.0) return;
     const double* vin = Vin + (size_t)k * vin_stride;
     for (int e = threadIdx.x; e < DEFL_Q * p; e += 256) vs[e] = vin[e];
     __syncthreads();
+    double* red = vs + (size_t)DEFL_Q * p;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const double* Ak = A + (size_t)k * p * p;
-    double* vout = Vout + (size_t)k * DEFL_Q * p;
-    const int r0 = blockIdx.x * rows_per_block;
-    constexpr int RW = 4;                               // rows a wave works on at once: RW independent load streams, every
-    for (int rr = wave * RW; rr < rows_per_block; rr += 4 * RW) {      // column value read from LDS once for RW rows
-        double acc[RW][DEFL_Q];
+    const int i = blockIdx.x * 64 + lane;
+    const double* col = A + (size_t)k * p * p + min(i, p - 1);
+    double acc[DEFL_Q];
 #pragma unroll
-        for (int x = 0; x < RW; ++x)
+    for (int q = 0; q < DEFL_Q; ++q) acc[q] = 0.0;
+    constexpr int U = 8;
+    for (int j = wave; j < p; j += 4 * U) {
+        double a[U];
 #pragma unroll
-            for (int q = 0; q < DEFL_Q; ++q) acc[x][q] = 0.0;
-        const double* a[RW];
+        for (int u = 0; u < U; ++u) a[u] = (j + 4 * u < p) ? col[(size_t)(j + 4 * u) * p] : 0.0;
 #pragma unroll
-        for (int x = 0; x < RW; ++x) a[x] = Ak + (size_t)min(r0 + rr + x, p - 1) * p;
-        if ((p & 1) == 0) {
-            // even p: every row starts 16-byte aligned -- two columns per lane and load (8-byte accesses run at 0.5-0.7x
-            // the 16-byte rate on this chip)
-            for (int j = 2 * lane; j < p; j += 128) {
-                double2 av[RW];
+        for (int u = 0; u < U; ++u) {
+            const int jj = min(j + 4 * u, p - 1);
 #pragma unroll
-                for (int x = 0; x < RW; ++x) av[x] = *reinterpret_cast<const double2*>(a[x] + j);
-#pragma unroll
-                for (int q = 0; q < DEFL_Q; ++q) {
-                    const double2 v = *reinterpret_cast<const double2*>(vs + q * p + j);
-#pragma unroll
-                    for (int x = 0; x < RW; ++x) acc[x][q] = fma(av[x].y, v.y, fma(av[x].x, v.x, acc[x][q]));
-                }
-            }
-        } else {
-            for (int j = lane; j < p; j += 64) {
-                double av[RW];
-#pragma unroll
-                for (int x = 0; x < RW; ++x) av[x] = a[x][j];
-#pragma unroll
-                for (int q = 0; q < DEFL_Q; ++q) {
-                    const double v = vs[q * p + j];
-#pragma unroll
-                    for (int x = 0; x < RW; ++x) acc[x][q] = fma(av[x], v, acc[x][q]);
-                }
-            }
+            for (int q = 0; q < DEFL_Q; ++q) acc[q] = fma(a[u], vs[q * p + jj], acc[q]);
         }
+    }
 #pragma unroll
-        for (int x = 0; x < RW; ++x) {
+    for (int q = 0; q < DEFL_Q; ++q) red[(wave * DEFL_Q + q) * 64 + lane] = acc[q];
+    __syncthreads();
+    if (i < p) {
 #pragma unroll
-            for (int q = 0; q < DEFL_Q; ++q) acc[x][q] = wave_sum(acc[x][q]);
-            const int row = r0 + rr + x;
-            if (row < p && lane < DEFL_Q) {
-                double v = 0.0;
-#pragma unroll
-                for (int q = 0; q < DEFL_Q; ++q) if (lane == q) v = acc[x][q];
-                if (MODE == 1) v = G[(size_t)k * g_stride + lane * p + row] - v;
-                if (MODE == 2) v -= muK[k] * vs[lane * p + row];
-                vout[(size_t)lane * p + row] = v;
-            }
+        for (int h = 0; h < DEFL_Q / 4; ++h) {
+            const int q = wave + 4 * h;
+            double v = (red[(0 * DEFL_Q + q) * 64 + lane] + red[(1 * DEFL_Q + q) * 64 + lane]) +
+                       (red[(2 * DEFL_Q + q) * 64 + lane] + red[(3 * DEFL_Q + q) * 64 + lane]);
+            if (MODE == 1) v = G[(size_t)k * g_stride + (size_t)q * p + i] - v;
+            if (MODE == 2) v -= muK[k] * vs[q * p + i];
+            Vout[(size_t)k * DEFL_Q * p + (size_t)q * p + i] = v;
         }
     }
 }
@@ -103,15 +84,15 @@ template <int MODE>
 static void launch_tall(hipStream_t st, const double* A, const double* Vin, size_t vin_stride, const double* G, size_t g_stride,
                         const double* muK, double* Vout, int K, int p, const double* meta = nullptr, int need = 0)
 {
-    const int rpb = 16;
-    const size_t lds = (size_t)DEFL_Q * p * sizeof(double);
+    static_assert(DEFL_Q % 4 == 0, "the columns are dealt over the four waves on the way out");
+    const size_t lds = ((size_t)DEFL_Q * p + 4 * DEFL_Q * 64) * sizeof(double);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)k_defl_tall<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         attr = true;
     }
-    hipLaunchKernelGGL(k_defl_tall<MODE>, dim3((p + rpb - 1) / rpb, K), dim3(256), lds, st, A, Vin, vin_stride, G, g_stride, muK, Vout,
-                       p, rpb, meta, need);
+    hipLaunchKernelGGL(k_defl_tall<MODE>, dim3((p + 63) / 64, K), dim3(256), lds, st, A, Vin, vin_stride, G, g_stride, muK, Vout,
+                       p, meta, need);
 }
 
 // block-wide sums of NV values per thread (256 threads); results in every thread.  scratch: 4 * NV doubles.
@@ -365,6 +346,6 @@ void launch_deflate(hipStream_t st, const double* X, const double* C, const doub
     hipLaunchKernelGGL(k_defl_update, dim3(p, K), dim3(256), 0, st, L, BV /*V*/, Wm, meta, p);
 }
 
-int deflate_max_p() { return (int)((160 * 1024 - 256 - 64) / (DEFL_Q * sizeof(double))); }
+int deflate_max_p() { return (int)((160 * 1024 - 256 - 64 - 4 * DEFL_Q * 64 * sizeof(double)) / (DEFL_Q * sizeof(double))); }
 
 }  // namespace ggl
