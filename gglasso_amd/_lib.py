@@ -90,9 +90,6 @@ _SIGNATURES = {
     "ggl_profile_read": ([_vp, _dp, ctypes.POINTER(ctypes.c_longlong), _i], _i),
     "ggl_dev_symm": ([_i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _i], _i),
     "ggl_dev_symm_bench": ([_i, _i, _i, _i, _dp], _i),
-    "ggl_dev_i8_stages": ([_i], _i),
-    "ggl_dev_symm_i8": ([_i, _i, _i, _i, _dp, _dp, _d, _d, _dp, _i, _dp], _i),
-    "ggl_dev_omega_i8": ([_i, _i, _dp, _dp, _dp, ctypes.POINTER(_i), _d, _dp, _i, _dp], _i),
     "ggl_lds_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_pipeline_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_dev_omega_lds": ([_i, _i, _dp, _dp, _dp, _dp, _dp, _d, _i, _dp, _dp, _i, _dp], _i),
@@ -130,6 +127,9 @@ _SIGNATURES = {
 
 # libggl_hip_dev.so only (-DGGL_DEV)
 _DEV_SIGNATURES = {
+    "ggl_dev_i8_stages": ([_i], _i),
+    "ggl_dev_symm_i8": ([_i, _i, _i, _i, _dp, _dp, _d, _d, _dp, _i, _dp], _i),
+    "ggl_dev_omega_i8": ([_i, _i, _dp, _dp, _dp, ctypes.POINTER(_i), _d, _dp, _i, _dp], _i),
     "ggl_dev_mfma_f64_peak": ([_dp], _i),
     "ggl_dev_symm_timeline": ([_i, _i, ctypes.POINTER(ctypes.c_longlong), _i, ctypes.POINTER(_i)], _i),
     "ggl_dev_chain_probe": ([_i, _i, _i, _i, _i, _i, _dp], _i),

@@ -122,17 +122,21 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
         for it in range(max_iter):
             sq = cur.sgl_batch_step(rhos[slots], lam[slots], latent, None if mu is None else mu[slots])
             carried[slots] += 1
-            bad, newly, fac = _decide(sq, slots, rhos, done, last, dimk[slots], tol, rtol, update_rho, it, verbose)
+            bad, newly, fac = _decide(sq, slots, rhos, done, last, dimk[slots], tol, rtol, update_rho, it, verbose,
+                                      marked=_marked(cur, 1))
+            if np.any(fac != 1.0):
+                cur.scale_X_batch(fac)          # (a failed point's factor is 1; single_admm_solver.py:205 comes before the break)
+            # the converged points before the failed ones are parked: collecting them reads what the ctx knows about the last
+            # L-step of the WHOLE batch, which parking a point must not disturb
+            for s in newly:
+                finish(s, 'optimal', it + 1)
             for s in bad:
-                # this point's data are not finite (a NaN in its S, a diverged iterate): the reference's sequential walk
-                # (model_selection.py:619-633) would lose this point only -- so does the batch
+                # this point's data are not finite (a NaN in its S, a diverged iterate) or the library marked it (an
+                # eigensolver that did not converge): the reference's sequential walk (model_selection.py:619-633) would
+                # lose this point only -- so does the batch
                 finish(s, 'solver error', it + 1)
                 if hasattr(cur, "reset_instance"):
                     cur.reset_instance(int(s))
-            if np.any(fac != 1.0):
-                cur.scale_X_batch(fac)
-            for s in newly:
-                finish(s, 'optimal', it + 1)
             if done.all():
                 break
             cur, slots = _compact(cur, slots, done, engines, compact, p=p, it=it)
@@ -145,9 +149,11 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
         for k in range(K):
             results[k][1]['carried'] = int(carried[k])
         ranks = _final_L(eng, [results[k][0] for k in range(K)], 1) if latent else None
+        _late_failures(eng, results, 1)
         if selection_stats:
             assert dims is None, "selection statistics are taken over whole slots"
             st = eng.selection_stats()
+            _late_failures(eng, results, 1)
             for k in range(K):
                 results[k][1]['selection'] = {'Sdot': st[k, 0], 'logdet': st[k, 1], 'nnz': st[k, 2],
                                               'lambda_min': st[k, 3]}
@@ -165,18 +171,42 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     return results
 
 
-def _decide(sq, ids, rhos, done, last, dims, tol, rtol, update_rho, it, verbose):
+def _marked(eng, group):
+    """(slots,) bool: problems with an instance the library has marked (GGL_OPT_ISOLATE: non-finite bounds, an eigensolver that
+    did not converge, a failed eigendecomposition fallback of the L-step).  With isolation on such an instance no longer
+    fails the call, and its numbers may well be finite -- the host has to ask."""
+    if not hasattr(eng, "failed_instances"):
+        return None
+    f = np.asarray(eng.failed_instances()) != 0
+    return f.reshape(-1, group).any(axis=1)
+
+
+def _late_failures(eng, results, group):
+    """Marks set on the ORIGINAL ctx after the iterations (the eigendecompositions of ggl_finalize_L and of the selection
+    statistics run there over the snapshots of all points): such a point is reported as failed, not as 'optimal'."""
+    m = _marked(eng, group)
+    if m is None:
+        return
+    for g in np.flatnonzero(m):
+        if results[g] is not None and results[g][1]['status'] != 'solver error':
+            results[g][1]['status'] = 'solver error'
+
+
+def _decide(sq, ids, rhos, done, last, dims, tol, rtol, update_rho, it, verbose, marked=None):
     """One iteration's host decisions for ALL points of a batch at once -- the reference's per-problem arithmetic
     (ADMM_stopping_criterion, solver/admm_solver.py:316-331; residual balancing, :227-233; what ``residuals_from_norms`` /
     ``next_rho`` do for one problem), element-wise in float64 in the same order of operations, so every decision is the one
     the per-point loop took.  A Python loop over the points costs ~12 us per point and iteration: for a 100-point grid of
     p = 64 problems that was 1.2 ms of host time per 0.1 ms of device time.
 
-    sq: (len(ids), 5) squared norms of the slots; ids[s]: the point in slot s.  Updates rhos / done / last (rows
+    sq: (len(ids), 5) squared norms of the slots; ids[s]: the point in slot s; marked: (len(ids),) bool, slots the library
+    has marked as failed (they end like slots with non-finite sums).  Updates rhos / done / last (rows
     r_t, s_t, e_pri, e_dual) in place; returns (slots with non-finite sums, slots that converged now, X scaling factors)."""
     sq = np.asarray(sq, dtype=np.float64).reshape(len(ids), -1)
     live = ~done[ids]
     finite = np.all(np.isfinite(sq), axis=1)
+    if marked is not None:
+        finite &= ~np.asarray(marked, dtype=bool)         # (a marked point is treated like one with non-finite sums)
     bad = np.flatnonzero(live & ~finite)
     ok = live & finite
     n_om, n_thl, n_x, n_r, n_s = np.sqrt(np.where(ok[:, None], sq[:, :5], 0.0)).T
@@ -344,17 +374,18 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
         for it in range(max_iter):
             sq = cur.mgl_batch_step(len(slots), rhos[slots], lam1[slots], lam2[slots], reg, latent, inst(mu), nk)
             carried[slots] += 1
-            bad, newly, fac = _decide(sq, slots, rhos, done, last, dim, tol, rtol, update_rho, it, verbose)
+            bad, newly, fac = _decide(sq, slots, rhos, done, last, dim, tol, rtol, update_rho, it, verbose,
+                                      marked=_marked(cur, K))
+            if np.any(fac != 1.0):
+                cur.scale_X_batch(np.repeat(fac, K))
+            for s in newly:                      # (before the failed ones are parked: see ADMM_SGL_batch)
+                collect(s, 'optimal', it + 1)
             for s in bad:
-                # (see ADMM_SGL_batch: a point with non-finite data costs that point only)
+                # (see ADMM_SGL_batch: a point with non-finite data or a mark costs that point only)
                 collect(s, 'solver error', it + 1)
                 if hasattr(cur, "reset_instance"):
                     for k in range(K):
                         cur.reset_instance(int(s) * K + k)
-            if np.any(fac != 1.0):
-                cur.scale_X_batch(np.repeat(fac, K))
-            for s in newly:
-                collect(s, 'optimal', it + 1)
             if done.all():
                 break
             cur, slots = _compact(cur, slots, done, engines, compact, group=K, p=p, it=it)
@@ -378,6 +409,7 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                 tab, _ = eng.threshold_scan(tau_range)
                 for g in range(G):
                     results[g][1]['threshold'] = tab[g * K:(g + 1) * K].copy()
+        _late_failures(eng, results, K)
     finally:
         for e in engines:
             e.close()

@@ -86,11 +86,8 @@ static void launch_tall(hipStream_t st, const double* A, const double* Vin, size
 {
     static_assert(DEFL_Q % 4 == 0, "the columns are dealt over the four waves on the way out");
     const size_t lds = ((size_t)DEFL_Q * p + 4 * DEFL_Q * 64) * sizeof(double);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_defl_tall<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        attr = true;
-    }
+    // per launch, not once per process: the attribute belongs to the CURRENT device's copy of the kernel
+    (void)hipFuncSetAttribute((const void*)k_defl_tall<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     hipLaunchKernelGGL(k_defl_tall<MODE>, dim3((p + 63) / 64, K), dim3(256), lds, st, A, Vin, vin_stride, G, g_stride, muK, Vout,
                        p, meta, need);
 }
@@ -328,11 +325,7 @@ void launch_deflate(hipStream_t st, const double* X, const double* C, const doub
     double *Y = work, *BV = work + vs, *XV = work + 2 * vs, *Wm = work + 3 * vs;
     const size_t vst = (size_t)DEFL_Q * p;
     const size_t lds = ((size_t)DEFL_Q * p + 4 * DEFL_Q) * sizeof(double);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_defl_basis, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        attr = true;
-    }
+    (void)hipFuncSetAttribute((const void*)k_defl_basis, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     launch_tall<0>(st, X, G, 0, nullptr, 0, nullptr, XV, K, p);                    // X G      (scratch: XV)
     launch_tall<1>(st, X, XV, vst, G, 0, nullptr, Y, K, p);                        // Y = R G = G - X (X G)
     hipLaunchKernelGGL(k_defl_basis, dim3(K), dim3(256), lds, st, Y, meta, p, tau1, G);        // Q1, r1 (+ G's probe columns)

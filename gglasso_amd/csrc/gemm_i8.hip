@@ -17,9 +17,11 @@
 // lanes of a fragment read (rows r .. r+15, same chunk) cover all 64 banks.
 // Tile 64 x 64, 4 waves of 32 x 32 (2 x 2 MFMA blocks), k-step 64, two LDS stages of 2 * S * 4 KiB (112 KiB at S = 7: one
 // workgroup per CU; every wave holds 2 S A-fragments + 2 S B-fragments and 4 * (DMAX + 1) accumulators in registers).
+// Measured and rejected: built into libggl_hip_dev.so only (-DGGL_DEV), like the other rejected variants.
 #include "common.hpp"
 #include "kernels.hpp"
 
+#ifdef GGL_DEV
 namespace ggl {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -565,3 +567,4 @@ bool i8_omega_run(hipStream_t st, I8Omega* w, const I8Prog& prog, const double* 
 }
 
 }  // namespace ggl
+#endif  // GGL_DEV

@@ -546,8 +546,10 @@ static int ctx_alloc(ggl_ctx* c)
         *c->seq_h = 0;
         HIPCHK(hipMemsetAsync(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int), c->stream));
         memset(c->spec_flag_h, 0, ggl_ctx::MAX_PARTS * sizeof(int));
-        HIPCHK(hipStreamSynchronize(c->stream));
     }
+    // whatever route the ctx takes: its first user may write these buffers from ANOTHER stream (ggl_ctx_create_subset copies
+    // on the source's stream), and a memset still queued here would land on top of that
+    HIPCHK(hipStreamSynchronize(c->stream));
     return GGL_OK;
 }
 
@@ -730,6 +732,10 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (!c) return GGL_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);      // also valid for the NULL (legacy default) stream
+    // the part streams too, BEFORE anything is freed or handed to the pool: an early first part (maybe_early) with several
+    // parts returns without joining them, so they may still be writing W / the Newton-Schulz scratch
+    for (int i = 0; i < ggl_ctx::MAX_PARTS - 1; ++i)
+        if (c->streamx[i]) (void)hipStreamSynchronize(c->streamx[i]);
     if (c->comm) {
         if (const RcclApi* api = rccl_api(nullptr)) (void)api->CommDestroy(c->comm);
         c->comm = nullptr;
@@ -1325,7 +1331,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 unsigned long long* cnt = (unsigned long long*)(c->lds_tab + (size_t)OMEGA_LDS_MAXTAB * OMEGA_LDS_ENT);
                 if (!launch_omega_lds(c->stream, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->Om[nxt], c->lds_tab,
                                       c->lds_ntab, c->lds_lnq, K, c->p, c->spec_flag, c->spec_flag_h, 0, cnt, c->bounds_h))
-                    return fail(GGL_E_HIP, "k_omega_lds: p = %d outside the kernel's range", c->p);
+                    return fail(GGL_E_HIP, "k_omega_lds: p = %d outside the kernel's range, or the LDS attribute was refused", c->p);
                 PE(c, GGL_PH_EIG_OMEGA);
                 HIPCHK(hipGetLastError());
                 c->last_parts = 1;
@@ -2488,7 +2494,8 @@ extern "C" int ggl_reset_instance(ggl_ctx* c, int k)
     HIPCHK(hipGetLastError());
     c->spec_have = false;
     c->cw_have = false;
-    c->l_ns = false;
+    // (l_ns stays: it says where the OTHER instances' L came from -- a point that converges in the iteration another one
+    // fails in is still snapshotted with its C and rebuilt by ggl_finalize_L)
     return GGL_OK;
 }
 
@@ -2525,6 +2532,17 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->state_symmetric = src->state_symmetric;
     c->step_latent = src->step_latent;
     c->nk_valid = false;
+    if (src->l_ns && src->Ckeep && src->Ckeep_beta) {
+        // the kept input of the last (sign-iteration) L-step moves along: a point collected from the new ctx before its
+        // first L-step there (max_iter right after a compaction) is still rebuilt by ggl_finalize_L
+        e = hipMalloc(&c->Ckeep_alloc, c->n * sizeof(double));
+        if (e != hipSuccess) { (void)hipFree(didx); ggl_ctx_destroy(c); return fail(GGL_E_HIP, "subset: %s", hipGetErrorString(e)); }
+        c->Ckeep = c->Ckeep_alloc;
+        c->Ckeep_beta = (double*)malloc(m * sizeof(double));
+        for (int i = 0; i < m; ++i) c->Ckeep_beta[i] = src->Ckeep_beta[idx[i]];
+        launch_copy_instances(src->stream, c->Ckeep, src->Ckeep, didx, m, pp, false);
+        c->l_ns = true;
+    }
     if (src->has_mask) {
         e = hipMemcpyAsync(c->mask, src->mask, pp * sizeof(double), hipMemcpyDeviceToDevice, src->stream);
         c->has_mask = true;
@@ -3868,6 +3886,7 @@ extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* 
 }
 
 // LDS stages of the int8 product kernel: 1 (default: two workgroups per CU cover each other's loads) or 2 (double buffer)
+#ifdef GGL_DEV
 extern "C" int ggl_dev_i8_stages(int n)
 {
     ARGCHK(n == 1 || n == 2, "1 or 2 stages");
@@ -4010,6 +4029,7 @@ extern "C" int ggl_dev_omega_i8(int K, int p, const double* W, const double* bet
     i8_omega_free(&w);
     return rc;
 }
+#endif  // GGL_DEV (the int8 route: measured, rejected -- DESIGN 9.4)
 
 // the LDS-resident Omega-step (omega_lds.hip) stand-alone: Omega = phiplus(Theta - L - X - beta S, beta) of K instances in one
 // launch.  L may be NULL.  out = {ms per launch, fallback flag, products summed over the instances, table entries}

@@ -397,11 +397,9 @@ bool launch_omega_lds(hipStream_t st, const double* Theta, const double* L, cons
 #define GGL_OL(PT)                                                                                                              \
     do {                                                                                                                        \
         const size_t lds = ((size_t)4 * PT * LdsDim<PT>::LD + PT + 8 + 512) * sizeof(double);                                          \
-        static bool attr = false;                                                                                               \
-        if (!attr) {                                                                                                            \
-            (void)hipFuncSetAttribute((const void*)k_omega_lds<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
-            attr = true;                                                                                                        \
-        }                                                                                                                       \
+        /* per launch: the attribute belongs to the current device's copy of the kernel */                            \
+        if (hipFuncSetAttribute((const void*)k_omega_lds<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return false;                                                                                                        \
         hipLaunchKernelGGL(k_omega_lds<PT>, dim3(K), dim3(256), lds, st, Theta, L, X, S, betaK, Omega, table, ntab, lnq, p, \
                            flag, flag_host, flag_slot, units, cbound, dbg);                                                          \
     } while (0)

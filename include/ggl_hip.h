@@ -438,17 +438,6 @@ int ggl_eig_info(ggl_ctx *ctx, int *out);
 int ggl_dev_symm(int K, int p, const double *A, const double *B, const double *E, const double *coef5K,
                  double *C, double *C2, int variant);
 int ggl_dev_symm_bench(int K, int p, int variant, int iters, double *ms_out);
-/* C = A B on the INT8 matrix cores from S signed-digit slices per operand (error-free split; gemm_i8.hip), slice pairs
- * t + u <= dmax; |A| <= scaleA, |B| <= scaleB entrywise.  ms_out = {slicing both operands, one product launch, overflow flag}. */
-int ggl_dev_i8_stages(int n);   /* LDS stages of the int8 product kernel: 1 (default) or 2 */
-int ggl_dev_symm_i8(int K, int p, int S, int dmax, const double *A, const double *B, double scaleA, double scaleB, double *C,
-                    int iters, double *ms_out);
-/* The whole Omega-step phiplus(W) (solver/ggl_helper.py:272-303) on the int8 matrix cores, stand-alone: W (K,p,p), beta (K),
- * cbound (K) >= lambda_max(W^2 + 4 beta I); cfg5 = {slices of the full products, of F F, of G F^2, of Y E, diagonal cut of Y E}
- * or NULL; tol: the schedule's stopping tolerance.  ms_out = {ms per step, product launches, overflow flag, fp64 products the
- * schedule stands for}. */
-int ggl_dev_omega_i8(int K, int p, const double *W, const double *beta, const double *cbound, const int *cfg5, double tol,
-                     double *Omega, int iters, double *ms_out);
 /* ggl_dev_omega_lds: the Omega-step of small matrices (p <= 64) as ONE launch, one workgroup per instance, the Newton-Schulz
  * chain resident in LDS, bound and schedule chosen on the device (omega_lds.hip; kernel unit test and timing).
  * Omega = phiplus(Theta - L - X - beta S, beta), L may be NULL.  cbound (K) or NULL receives the bound used.
@@ -473,6 +462,17 @@ int ggl_dev_ns_schedule(double l, int degrees, int max_steps, int *deg_out, doub
 int ggl_dev_ns_schedule_tol(double l, int degrees, double tol, int max_steps, int *deg_out, double *coef_out,
                             int *units_out);
 #ifdef GGL_DEV
+/* C = A B on the INT8 matrix cores from S signed-digit slices per operand (error-free split; gemm_i8.hip), slice pairs
+ * t + u <= dmax; |A| <= scaleA, |B| <= scaleB entrywise.  ms_out = {slicing both operands, one product launch, overflow flag}. */
+int ggl_dev_i8_stages(int n);   /* LDS stages of the int8 product kernel: 1 (default) or 2 */
+int ggl_dev_symm_i8(int K, int p, int S, int dmax, const double *A, const double *B, double scaleA, double scaleB, double *C,
+                    int iters, double *ms_out);
+/* The whole Omega-step phiplus(W) (solver/ggl_helper.py:272-303) on the int8 matrix cores, stand-alone: W (K,p,p), beta (K),
+ * cbound (K) >= lambda_max(W^2 + 4 beta I); cfg5 = {slices of the full products, of F F, of G F^2, of Y E, diagonal cut of Y E}
+ * or NULL; tol: the schedule's stopping tolerance.  ms_out = {ms per step, product launches, overflow flag, fp64 products the
+ * schedule stands for}. */
+int ggl_dev_omega_i8(int K, int p, const double *W, const double *beta, const double *cbound, const int *cfg5, double tol,
+                     double *Omega, int iters, double *ms_out);
 /* libggl_hip_dev.so only (python -m gglasso_amd.build --dev): measured FP64 matrix-core ceiling of this GPU in TFLOP/s
  * (MFMA-only probe kernel); per-workgroup timestamps {start, loop begin, loop end, end, XCC id} of one launch of the
  * 64x64 kernel */

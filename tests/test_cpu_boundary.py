@@ -56,7 +56,8 @@ def test_shipped_library_reads_no_environment_and_has_no_dev_kernels(lib):
     syms = subprocess.run(["nm", "-D", "--undefined-only", lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "getenv" not in syms
     blob = open(lib.LIB_PATH, "rb").read()
-    for needle in (b"k_mfma_f64_peak", b"k_mfma_valu_mix", b"GGL_SPEC_FACTOR", b"GGL_NS_MODE"):
+    for needle in (b"k_mfma_f64_peak", b"k_mfma_valu_mix", b"GGL_SPEC_FACTOR", b"GGL_NS_MODE", b"k_symm_i8", b"k_slice_i8",
+                   b"ggl_dev_symm_i8", b"ggl_dev_omega_i8"):
         assert needle not in blob, needle
 
 

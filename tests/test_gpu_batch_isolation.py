@@ -216,3 +216,57 @@ def test_ext_grid_with_a_poisoned_point(monkeypatch):
         ref, rinfo = quiet(ext_solver.ext_ADMM_MGL, S, a, b, 'GGL', {k: v.copy() for k, v in Om0.items()}, G, tol=1e-8, rtol=1e-8)
         for k in range(K):
             assert np.abs(res[i][0]['Theta'][k] - ref['Theta'][k]).max() <= 1e-9, (i, k)
+
+
+def test_kept_L_step_input_survives_parking_and_compaction():
+    """whether the last L-step was the sign iteration (and its kept input C) is state of the whole ctx.  Parking a
+    failed instance (ggl_reset_instance) must not make the OTHER instances' snapshots lose it, and a compacted ctx
+    (ggl_ctx_create_subset) must carry it, so that a point collected before the new ctx's first L-step is still rebuilt by
+    ggl_finalize_L (rank from the eigendecomposition, >= 0) instead of keeping the iteration's L."""
+    from gglasso_amd import solver, synth
+    K, p = 4, 150
+    S, _ = synth.make_problem("GGL", K, p, N=2 * p, seed=3)
+    eye = np.repeat(np.eye(p)[None], K, axis=0)
+    eng = solver.HipEngine(S, eye, eye, np.zeros_like(eye), options={"isolate": 1})
+    sub = None
+    try:
+        rho, lam, mu = np.ones(K), np.full(K, 0.1), np.full(K, 0.5)
+        for _ in range(6):
+            eng.sgl_batch_step(rho, lam, True, mu)
+        eng.reset_instance(1)
+        eng.snapshot_k(0)
+        sub = eng.subset(np.array([2, 3]))
+        eng.snapshot_from(3, sub, 1)                      # before any step in the new ctx
+        n, rk = eng.finalize_L(1)
+        assert n == 2 and rk[0] >= 0 and rk[3] >= 0 and rk[1] == -1 and rk[2] == -1
+        for k in (0, 3):
+            L = eng.snapshot_L_k(k)
+            assert np.linalg.matrix_rank(L) == rk[k]
+    finally:
+        if sub is not None:
+            sub.close()
+        eng.close()
+
+
+def test_marked_instance_with_finite_sums_is_reported(monkeypatch):
+    """with GGL_OPT_ISOLATE a non-converged eigensolver marks the instance and the call goes on; the sums of that
+    point can be finite.  The batch drivers ask the library (ggl_failed_instances) after every step: a marked point ends as
+    'solver error', never as 'optimal'."""
+    from gglasso_amd import solver, synth
+    from gglasso_amd.batch import ADMM_SGL_batch
+    K, p = 4, 30
+    S, _ = synth.make_problem("GGL", K, p, N=2 * p, seed=9)
+    real = solver.HipEngine.failed_instances
+    calls = {"n": 0}
+
+    def fake(self):
+        calls["n"] += 1
+        out = real(self)
+        if calls["n"] >= 3 and self.K == K:
+            out[1] = 1                                   # as if instance 1's eigensolver had not converged in step 3
+        return out
+
+    monkeypatch.setattr(solver.HipEngine, "failed_instances", fake)
+    res = ADMM_SGL_batch(S, np.full(K, 0.1), tol=1e-8, rtol=1e-8, max_iter=200, compact=False)
+    assert res[1][1]['status'] == 'solver error' and res[1][1]['iterations'] == 3
+    assert all(res[k][1]['status'] == 'optimal' for k in (0, 2, 3))

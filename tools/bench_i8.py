@@ -19,7 +19,7 @@ import proto_ozaki as oz
 def main():
     p = int(sys.argv[1]) if len(sys.argv) > 1 else 500
     Ks = [int(v) for v in sys.argv[2:]] or [4, 16, 32]
-    lib = _lib.load()
+    lib = _lib.load_dev()
     rng = np.random.default_rng(5)
     print(f"p = {p}: product launch, microseconds (HIP events, mean of 20); 'eq TF/s' = K p^3 / time: what an FP64 product "
           f"kernel would have to run at to match (FP64 matrix peak 78.6)")

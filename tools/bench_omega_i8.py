@@ -33,7 +33,7 @@ def iterate_W(p, Kgen, iters, seed=1239):
 def main():
     p = int(sys.argv[1]) if len(sys.argv) > 1 else 500
     Ks = [int(v) for v in sys.argv[2:]] or [4, 16, 32]
-    lib = _lib.load()
+    lib = _lib.load_dev()
     Kgen = 4
     Wg = iterate_W(p, Kgen, 8)
     ref, _ = orc.phiplus_stack(Wg, 1.0)

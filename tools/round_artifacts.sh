@@ -8,6 +8,16 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
+# both libraries from THIS tree first: a stale development library once overwrote three evidence files with tracebacks
+# 
+python -m gglasso_amd.build --dev || { echo "build failed"; exit 1; }
+# keep <file> <command...>: run the command, keep its output only if it exited 0 and holds no traceback
+FAILED=""
+keep() {
+  local out=$1; shift
+  if "$@" > $out.tmp 2>&1 && ! grep -q "Traceback" $out.tmp; then mv $out.tmp $out
+  else echo "FAILED: $* (output left in $out.failed)"; mv $out.tmp $out.failed; FAILED="$FAILED $(basename $out)"; fi
+}
 ( time python -m pytest tests -m gpu -x -q --durations=10 ) > $O/pytest_gpu.txt 2>&1
 tail -4 $O/pytest_gpu.txt
 bash tools/profile_round.sh $TAG > $O/profile.log 2>&1
@@ -31,15 +41,15 @@ python tools/bench_grid.py 2>&1 | grep "^{" > $O/workload_sgl_grid_p1000_L20.jso
 python tools/bench_mgl_grid.py 2>&1 | grep "^{" > $O/workload_mgl_grid_8x1_K4_p500.json
 python tools/bench_mgl_grid.py --reg FGL --K 6 --p 300 --l1 4 --l2 3 2>&1 | grep "^{" > $O/workload_mgl_grid_4x3_fgl_K6_p300.json
 K=32 TOL=1e-10 python tools/parity_headline.py ns_tol=2e-12,0 > $O/parity_headline.txt 2>&1
-python tools/bench_chain.py > $O/omega_chain.txt 2>&1
-python tools/bench_tile_variants.py > $O/tile_variants.txt 2>&1
-python tools/bench_small_batches.py > $O/small_batches_product_kernel.txt 2>&1
+keep $O/omega_chain.txt python tools/bench_chain.py
+keep $O/tile_variants.txt python tools/bench_tile_variants.py
+keep $O/small_batches_product_kernel.txt python tools/bench_small_batches.py
 # (round 4: everything a doc cites comes out of this script -- VERDICT r3 weak #10)
-python tools/bench_jacobi.py > $O/jacobi_kernel_measured.txt 2>&1
+keep $O/jacobi_kernel_measured.txt python tools/bench_jacobi.py
 bash tools/small_p_artifacts.sh $TAG > $O/small_p_artifacts.log 2>&1
-python tools/bench_i8.py 500 4 16 32 > $O/i8_product_kernel.txt 2>&1
-python tools/bench_omega_i8.py 500 4 16 32 > $O/i8_omega_step_chain.txt 2>&1
-python tools/stress_solve.py > $O/stress_solve.txt 2>&1
+keep $O/i8_product_kernel.txt python tools/bench_i8.py 500 4 16 32
+keep $O/i8_omega_step_chain.txt python tools/bench_omega_i8.py 500 4 16 32
+keep $O/stress_solve.txt python tools/stress_solve.py
 REG=FGL LATENT=1 K=50 SEED=1237 TOL=1e-9 python tools/parity_headline.py >> $O/parity_headline.txt 2>&1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/c4 -o bench -- python3 $R/bench.py --workload fgl_K50_p500_latent --steps 20 --warmup 5 --regions 2 --no-cpu-baseline > $O/c4_prof.log 2>&1 )
 python - <<PY > $O/c4_kernel_stats.txt 2>&1
@@ -51,3 +61,4 @@ PY
 head -c 700 $O/bench_final.json
 rm -rf $R/gpurun_out/prof_$TAG/*/*.db 2>/dev/null
 find $R/gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete
+[ -z "$FAILED" ] || { echo "round_artifacts: sub-tools failed:$FAILED"; exit 1; }
