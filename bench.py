@@ -458,7 +458,7 @@ def main():
                                                  " -- Newton-Schulz product") if omega_ns else
                        ("k_jacobi" if eig_jacobi else "rocsolver_dsyevd (library, many kernels)"),
                        "theta": "k_theta_ggl" if reg == "GGL" else ("k_theta_fgl" if reg == "FGL" else "k_theta_sgl"),
-                       "allreduce_groupsq": "ncclAllReduce (p,p)+1 fp64", "allreduce_norms": "ncclAllReduce 5 fp64",
+                       "allreduce_groupsq": "ncclAllReduce p(p+1)/2+1 fp64 (packed upper triangle + flag)", "allreduce_norms": "ncclAllReduce 5 fp64",
                        "recon_omega": "k_recon", "recon_L": "k_recon", "form_W": "k_form_W",
                        "dual": "k_dual_update", "eig_L": "k_jacobi" if eig_jacobi else "rocsolver_dsyevd"}.get(dom, dom)
         sec = phases[dom]["ms_per_launch"] * 1e-3

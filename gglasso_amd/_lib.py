@@ -33,6 +33,8 @@ _dp = ctypes.POINTER(ctypes.c_double)
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _d = ctypes.c_double
+_ubp = ctypes.POINTER(ctypes.c_ubyte)
+_ip = ctypes.POINTER(ctypes.c_int)
 
 _SIGNATURES = {
     "ggl_version": ([], _i),
@@ -73,6 +75,9 @@ _SIGNATURES = {
     "ggl_sgl_batch_step": ([_vp, _dp, _dp, _i, _dp, _dp], _i),
     "ggl_mgl_batch_step": ([_vp, _i, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp], _i),
     "ggl_scale_X_batch": ([_vp, _dp], _i),
+    "ggl_batch_decide": ([_i, _dp, _ubp, _ubp, _dp, _dp, _d, _d, _i, _dp, _dp, _ip], _i),
+    "ggl_sgl_batch_run": ([_vp, _i, _dp, _dp, _i, _dp, _dp, _d, _d, _i, _ubp, _dp, _ip], _i),
+    "ggl_mgl_batch_run": ([_vp, _i, _i, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _d, _d, _i, _ubp, _dp, _ip], _i),
     "ggl_get_state_k": ([_vp, _i, _dp, _dp, _dp, _dp], _i),
     "ggl_exit_checks": ([_vp, _i, _dp], _i),
     "ggl_exit_checks_k": ([_vp, _i, _dp], _i),

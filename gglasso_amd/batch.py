@@ -119,27 +119,37 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
             if keep_snapshots:
                 eng.snapshot_k(k) if cur is eng else eng.snapshot_from(k, cur, s)
 
-        for it in range(max_iter):
-            sq = cur.sgl_batch_step(rhos[slots], lam[slots], latent, None if mu is None else mu[slots])
-            carried[slots] += 1
-            bad, newly, fac = _decide(sq, slots, rhos, done, last, dimk[slots], tol, rtol, update_rho, it, verbose,
-                                      marked=_marked(cur, 1))
-            if np.any(fac != 1.0):
-                cur.scale_X_batch(fac)          # (a failed point's factor is 1; single_admm_solver.py:205 comes before the break)
+        it = 0                                                           # batch iterations run so far
+        while it < max_iter:
+            if hasattr(cur, "sgl_batch_run") and not verbose:
+                # iterations until some point converges or fails, decisions and X rescale in C (ggl_sgl_batch_run)
+                bad, newly, n = _run_in_c(lambda rho_s: cur.sgl_batch_run(
+                    max_iter - it, rho_s, lam[slots], latent, None if mu is None else mu[slots], dimk[slots], tol, rtol,
+                    update_rho, done[slots]), slots, rhos, done, last)
+                carried[slots] += n
+                it += n
+            else:
+                sq = cur.sgl_batch_step(rhos[slots], lam[slots], latent, None if mu is None else mu[slots])
+                carried[slots] += 1
+                bad, newly, fac = _decide(sq, slots, rhos, done, last, dimk[slots], tol, rtol, update_rho, it, verbose,
+                                          marked=_marked(cur, 1))
+                if np.any(fac != 1.0):
+                    cur.scale_X_batch(fac)      # (a failed point's factor is 1; single_admm_solver.py:205 comes before the break)
+                it += 1
             # the converged points before the failed ones are parked: collecting them reads what the ctx knows about the last
             # L-step of the WHOLE batch, which parking a point must not disturb
             for s in newly:
-                finish(s, 'optimal', it + 1)
+                finish(s, 'optimal', it)
             for s in bad:
                 # this point's data are not finite (a NaN in its S, a diverged iterate) or the library marked it (an
                 # eigensolver that did not converge): the reference's sequential walk (model_selection.py:619-633) would
                 # lose this point only -- so does the batch
-                finish(s, 'solver error', it + 1)
+                finish(s, 'solver error', it)
                 if hasattr(cur, "reset_instance"):
                     cur.reset_instance(int(s))
             if done.all():
                 break
-            cur, slots = _compact(cur, slots, done, engines, compact, p=p, it=it)
+            cur, slots = _compact(cur, slots, done, engines, compact, p=p, it=it - 1)
         for s, k in enumerate(slots):
             if results[k] is None:
                 r_t, s_t, e_pri, e_dual = last[k]
@@ -169,6 +179,23 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
         for e in engines:
             e.close()
     return results
+
+
+def _run_in_c(run, slots, rhos, done, last):
+    """One call of HipEngine.sgl_batch_run / mgl_batch_run on the live ctx (``run(rho_s)``: the call, with the slots' rhos as a
+    contiguous array it updates in place) folded back into the per-point bookkeeping of the drivers: rhos, last (rows
+    r_t, s_t, e_pri, e_dual), done.  Returns (slots that failed, slots that converged, iterations run)."""
+    rho_s = np.ascontiguousarray(rhos[slots], dtype=np.float64)
+    n, last_s, status = run(rho_s)
+    live = ~done[slots]
+    rhos[slots[live]] = rho_s[live]
+    upd = live & (status != 2)
+    last[slots[upd]] = last_s[upd]
+    bad = np.flatnonzero(live & (status == 2))
+    newly = np.flatnonzero(live & (status == 1))
+    done[slots[bad]] = True
+    done[slots[newly]] = True
+    return bad, newly, n
 
 
 def _marked(eng, group):
@@ -371,24 +398,33 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                 for k in range(K):
                     eng.snapshot_k(g * K + k) if cur is eng else eng.snapshot_from(g * K + k, cur, s * K + k)
 
-        for it in range(max_iter):
-            sq = cur.mgl_batch_step(len(slots), rhos[slots], lam1[slots], lam2[slots], reg, latent, inst(mu), nk)
-            carried[slots] += 1
-            bad, newly, fac = _decide(sq, slots, rhos, done, last, dim, tol, rtol, update_rho, it, verbose,
-                                      marked=_marked(cur, K))
-            if np.any(fac != 1.0):
-                cur.scale_X_batch(np.repeat(fac, K))
+        it = 0
+        while it < max_iter:
+            if hasattr(cur, "mgl_batch_run") and not verbose:
+                bad, newly, n = _run_in_c(lambda rho_s: cur.mgl_batch_run(
+                    len(slots), max_iter - it, rho_s, lam1[slots], lam2[slots], reg, latent, inst(mu), nk,
+                    np.full(len(slots), float(dim)), tol, rtol, update_rho, done[slots]), slots, rhos, done, last)
+                carried[slots] += n
+                it += n
+            else:
+                sq = cur.mgl_batch_step(len(slots), rhos[slots], lam1[slots], lam2[slots], reg, latent, inst(mu), nk)
+                carried[slots] += 1
+                bad, newly, fac = _decide(sq, slots, rhos, done, last, dim, tol, rtol, update_rho, it, verbose,
+                                          marked=_marked(cur, K))
+                if np.any(fac != 1.0):
+                    cur.scale_X_batch(np.repeat(fac, K))
+                it += 1
             for s in newly:                      # (before the failed ones are parked: see ADMM_SGL_batch)
-                collect(s, 'optimal', it + 1)
+                collect(s, 'optimal', it)
             for s in bad:
                 # (see ADMM_SGL_batch: a point with non-finite data or a mark costs that point only)
-                collect(s, 'solver error', it + 1)
+                collect(s, 'solver error', it)
                 if hasattr(cur, "reset_instance"):
                     for k in range(K):
                         cur.reset_instance(int(s) * K + k)
             if done.all():
                 break
-            cur, slots = _compact(cur, slots, done, engines, compact, group=K, p=p, it=it)
+            cur, slots = _compact(cur, slots, done, engines, compact, group=K, p=p, it=it - 1)
         for s, g in enumerate(slots):
             if results[g] is None:
                 r_t, s_t, e_pri, e_dual = last[g]

@@ -60,4 +60,11 @@ __device__ __forceinline__ bool spec_failed(const int* __restrict__ skip)
     return skip != nullptr && (skip[0] | skip[1] | skip[2] | skip[3]) != 0;
 }
 
+// (tri_index / tri_len: kernels.hpp)
+// the reduced flag behind the packed sums: > 0 when some rank's speculative schedule did not cover its spectrum
+__device__ __forceinline__ bool gsq_rejected(const double* __restrict__ gsq, int p)
+{
+    return gsq != nullptr && gsq[tri_len(p)] > 0.5;
+}
+
 }  // namespace ggl

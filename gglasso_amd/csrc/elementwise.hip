@@ -262,32 +262,6 @@ void launch_scale_batch(hipStream_t st, double* X, const double* fK, int K, int 
     hipLaunchKernelGGL(k_scale_batch, dim3(elementwise_blocks(p), K), dim3(EW_THREADS), 0, st, X, fK, pp);
 }
 
-// K-sharded speculation: the validation flags of this rank travel with the (p,p) all-reduce of the GGL Theta-step
-// as one extra double (pack), and come back as the number of ranks that missed (unpack: > 0 => every rank skips
-// its Theta-step and repeats the iteration).
-__global__ void k_spec_pack(const int* __restrict__ flags, double* __restrict__ dst)
-{
-    dst[0] = (flags != nullptr && (flags[0] | flags[1] | flags[2] | flags[3]) != 0) ? 1.0 : 0.0;
-}
-
-__global__ void k_spec_unpack(const double* __restrict__ src, int* __restrict__ flag, int* __restrict__ flag_host)
-{
-    if (src[0] > 0.5) {
-        *flag = 1;
-        *flag_host = 1;
-    }
-}
-
-void launch_spec_pack(hipStream_t st, const int* flags, double* dst)
-{
-    hipLaunchKernelGGL(k_spec_pack, dim3(1), dim3(1), 0, st, flags, dst);
-}
-
-void launch_spec_unpack(hipStream_t st, const double* src, int* flag, int* flag_host)
-{
-    hipLaunchKernelGGL(k_spec_unpack, dim3(1), dim3(1), 0, st, src, flag, flag_host);
-}
-
 __global__ __launch_bounds__(256) void k_copy_small(CopySegs sg)
 {
     const int s = blockIdx.y;
@@ -305,6 +279,28 @@ __global__ void k_spin_us(long long us)
 }
 
 void launch_spin_us(hipStream_t st, int us) { hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, st, (long long)us); }
+
+// the same by ONE workgroup, which then publishes a sequence number in (coherent) pinned memory: the host waits for the
+// copies by polling that word instead of a stream synchronisation (finish_norms of a K-sharded step)
+__global__ __launch_bounds__(256) void k_copy_small_seq(CopySegs sg, unsigned long long* seq, unsigned long long seq_val)
+{
+    for (int s = 0; s < sg.n; ++s) {
+        unsigned* d = (unsigned*)sg.dst[s];
+        const unsigned* src = (const unsigned*)sg.src[s];
+        for (unsigned i = threadIdx.x; i < sg.words[s]; i += 256) d[i] = src ? src[i] : 0u;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        *(volatile unsigned long long*)seq = seq_val;
+    }
+}
+
+void launch_copy_small_seq(hipStream_t st, const CopySegs& segs, unsigned long long* seq, unsigned long long seq_val)
+{
+    hipLaunchKernelGGL(k_copy_small_seq, dim3(1), dim3(256), 0, st, segs, seq, seq_val);
+}
 
 void launch_copy_small(hipStream_t st, const CopySegs& segs)
 {

@@ -72,6 +72,7 @@ struct ggl_ctx {
     size_t partials_len = 0;
     double *norms = nullptr, *norms_h = nullptr;  // (K,8) device / pinned
     int* info_h = nullptr;                        // pinned (K)
+    double* gflag_h = nullptr;                    // pinned: the all-reduced speculation flag of a K-sharded step
     bool nk_valid = false;
     // Newton-Schulz Omega-step (newton_schulz.hip)
     bool omega_ns = false;
@@ -467,6 +468,7 @@ static int ctx_alloc(ggl_ctx* c)
     DEV(c->norms, nl * sizeof(double));
     PIN(c->norms_h, nl * sizeof(double), 2);
     PIN(c->info_h, (size_t)c->K * sizeof(int), 1);
+    PIN(c->gflag_h, sizeof(double), 2);
     if (c->omega_ns) {
         for (int i = 0; i < 2; ++i) { DEV(c->nsYP[i], 2 * nb); }
         DEV(c->nsT, nb);
@@ -1675,9 +1677,8 @@ extern "C" int ggl_step_group_partial(ggl_ctx* c, double rho, double lambda1)
     ARGCHK(rho > 0, "rho must be positive");
     HIPCHK(hipSetDevice(c->device));
     // u = soft(Omega + L + X, l1/rho) (admm_solver.py:190-191): L only takes part in the latent model (it is zero otherwise)
-    launch_group_sums_full(c->stream, c->groupsq, c->sqwork, c->Om[c->cur], c->step_latent ? c->L : nullptr, c->X,
-                           (1.0 / rho) * lambda1, c->K, c->p);
-    launch_spec_pack(c->stream, c->spec_pending ? c->spec_flag : nullptr, c->groupsq + (size_t)c->p * c->p);
+    launch_group_sums_packed(c->stream, c->groupsq, c->sqwork, c->Om[c->cur], c->step_latent ? c->L : nullptr, c->X,
+                             (1.0 / rho) * lambda1, c->K, c->p, c->spec_pending ? c->spec_flag : nullptr);
     HIPCHK(hipGetLastError());
     return GGL_OK;
 }
@@ -1688,11 +1689,12 @@ static int validate_spec(ggl_ctx* c)
 {
     if (c->spec_pending || c->sharded_check) {
         // speculative Omega-step (here, or on another rank of a K-sharded run): were the assumed bounds still bounds?
-        const bool mine = c->spec_pending;
+        const bool mine = c->spec_pending, sharded = c->sharded_check;
         c->spec_pending = false;
         c->sharded_check = false;
         bool bad = false;
         for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) bad = bad || (c->spec_flag_h[h] != 0);
+        if (sharded) bad = bad || (*c->gflag_h > 0.5);        // some rank (possibly this one) missed: all repeat
         if (bad) {
             // no: the Theta-step kernels saw the flag and left the iterate alone; un-flip Omega and tell the caller
             if (mine && c->lds_last) lds_missed(c);
@@ -1723,11 +1725,22 @@ static int finish_norms(ggl_ctx* c, int rows, double* out_norms, int group = 0)
     CopySegs dn;
     if (!c->norms_host) dn.add(c->norms_h, c->norms, (size_t)rows * GGL_NNORM * sizeof(double));
     if (c->info_dirty) dn.add(c->info_h, c->info, c->K * sizeof(int));
-    launch_copy_small(c->stream, dn);
+    if (c->sharded_check) dn.add(c->gflag_h, c->groupsq + ggl::tri_len(c->p), sizeof(double));   // the all-reduced speculation flag
+    // a few words to fetch (the all-reduced sums and flag of a K-sharded step) and a host that may poll: the copy publishes
+    // the sequence number itself, behind its copies
+    size_t dn_words = 0;
+    for (int i = 0; i < dn.n; ++i) dn_words += dn.words[i];
+    const bool dn_seq = dn.n > 0 && dn_words <= 4096 && c->seq_h && c->spin_wait && !c->prof_on;
+    if (dn_seq) {
+        c->seq_wait = ++c->seq_next;
+        launch_copy_small_seq(c->stream, dn, c->seq_h, c->seq_wait);
+    } else {
+        launch_copy_small(c->stream, dn);
+    }
     HIPCHK(hipGetLastError());
     bool waited = false;
     const unsigned long long want = c->seq_wait;
-    if (want != 0 && dn.n == 0) {
+    if (want != 0 && (dn.n == 0 || dn_seq)) {
         // everything this step produced for the host is in (coherent) pinned memory and the reduction publishes a
         // sequence number after it: poll that word (the stream is in order, so all earlier work is complete as well).
         // Bounded: after GGL_SPIN_LIMIT_MS the wait falls back to a stream synchronisation, and a sequence number that
@@ -1747,7 +1760,7 @@ static int finish_norms(ggl_ctx* c, int rows, double* out_norms, int group = 0)
     }
     c->seq_wait = 0;
     if (!waited || c->prof_on) HIPCHK(hipStreamSynchronize(c->stream));
-    if (want != 0 && dn.n == 0 && !waited && *(const volatile unsigned long long*)c->seq_h != want)
+    if (want != 0 && (dn.n == 0 || dn_seq) && !waited && *(const volatile unsigned long long*)c->seq_h != want)
         return fail(GGL_E_HIP, "end of iteration: the norm reduction did not publish sequence number %llu (found %llu) "
                     "although the stream is idle", want, *(const volatile unsigned long long*)c->seq_h);
     c->norms_host = false;
@@ -2113,12 +2126,9 @@ static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double l
             return fail(GGL_E_ARG, "FGL Theta-step: K = %d exceeds the %d instances whose K-vectors fit the LDS scan buffer "
                         "of one workgroup (solver/fgl_helper.py:11-68 is a serial scan along K)", c->K, fgl_max_K());
         PB(c, GGL_PH_THETA);
-        if (groupsq_ready && c->omega_ns) {
-            // K-sharded: the reduced flag decides for every rank, whether it speculated itself or not
-            launch_spec_unpack(c->stream, c->groupsq + (size_t)c->p * c->p, c->spec_flag + ggl_ctx::MAX_PARTS - 1,
-                               c->spec_flag_h + ggl_ctx::MAX_PARTS - 1);
-            c->sharded_check = true;
-        }
+        // K-sharded: the reduced flag (behind the packed sums) decides for every rank, whether it speculated itself or not --
+        // the Theta kernels read it there, the host gets it with the norms (finish_norms)
+        if (groupsq_ready && c->omega_ns) c->sharded_check = true;
         // the flat GGL kernel computes every (i,j) from its own inputs: only for an exactly symmetric state
         const int flat = (c->theta_flat && c->state_symmetric) ? c->theta_flat : 0;
         HIPCHK(launch_theta_pair(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, l1, l2,
@@ -2275,6 +2285,9 @@ extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lamb
 }
 
 // ---- K independent single problems with their own rho / lambda1 (batched lambda path) ----------
+static int sgl_batch_step_impl(ggl_ctx* c, const double* rho, const double* lambda1, int latent, const double* mu1,
+                               double* out_norms);
+
 extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* lambda1, int latent, const double* mu1,
                                   double* out_norms)
 {
@@ -2282,6 +2295,12 @@ extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* l
     ARGCHK(!latent || mu1, "latent needs mu1");
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
+    return sgl_batch_step_impl(c, rho, lambda1, latent, mu1, out_norms);
+}
+
+static int sgl_batch_step_impl(ggl_ctx* c, const double* rho, const double* lambda1, int latent, const double* mu1,
+                               double* out_norms)
+{
     const int K = c->K;
     for (int k = 0; k < K; ++k) ARGCHK(rho[k] > 0, "rho must be positive");
     double* h = c->par_h;
@@ -2387,6 +2406,9 @@ static int mgl_batch_finish(ggl_ctx* c, int G, int Kp, int reg, int latent, doub
     return finish_norms(c, rows, out_norms, group);
 }
 
+static int mgl_batch_step_impl(ggl_ctx* c, int G, const double* rho, const double* lambda1, const double* lambda2,
+                               int reg, int latent, const double* mu1, const double* nk, double* out_norms);
+
 extern "C" int ggl_mgl_batch_step(ggl_ctx* c, int G, const double* rho, const double* lambda1, const double* lambda2,
                                   int reg, int latent, const double* mu1, const double* nk, double* out_norms)
 {
@@ -2397,6 +2419,12 @@ extern "C" int ggl_mgl_batch_step(ggl_ctx* c, int G, const double* rho, const do
     ARGCHK(c->state_symmetric, "the batched Theta-step needs exactly symmetric dual / latent start points");
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
+    return mgl_batch_step_impl(c, G, rho, lambda1, lambda2, reg, latent, mu1, nk, out_norms);
+}
+
+static int mgl_batch_step_impl(ggl_ctx* c, int G, const double* rho, const double* lambda1, const double* lambda2,
+                               int reg, int latent, const double* mu1, const double* nk, double* out_norms)
+{
     const int K = c->K, Kp = K / G;
     if (reg == GGL_REG_GGL && Kp > GGL_FLAT_MAX_K)
         return fail(GGL_E_ARG, "batched GGL grid: %d instances per problem exceed the %d of the per-element Theta kernel", Kp,
@@ -2444,6 +2472,149 @@ extern "C" int ggl_scale_X_batch(ggl_ctx* c, const double* factor)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));   // the pinned slot is reused by the next call
     return GGL_OK;
+}
+
+// ---- n iterations of a batch per call: the host side of the grid walks in C ------------------------------------------------
+// One iteration's decisions for all points of a batch: ADMM_stopping_criterion (solver/admm_solver.py:316-331,
+// single_admm_solver.py:277-291) and the residual-balancing rule (:227-233 / :196-206), per point, in the reference's order
+// of operations -- bit for bit what gglasso_amd.batch._decide computes with NumPy (tests/test_cpu_batch_decisions.py runs the
+// two against each other).  Host only.
+//   sq (n,5) squared norms {|Omega|, |Theta - L|, |X|, |Omega - Theta + L|, |Omega - Omega_prev|};  live (n) 0/1;  marked (n) 0/1 or
+//   NULL (points the library marked: they end like points with non-finite sums);  rho (n) in/out;  dims (n);
+//   last (n,4) = {r_t, s_t, e_pri, e_dual}, rows of the live finite points are rewritten;  fac (n) out: rho / rho_new (1 for
+//   the others);  status (n) out: 0 goes on (or not live), 1 converged in this iteration, 2 failed (non-finite sums / marked).
+// Returns the number of points with status != 0.
+extern "C" int ggl_batch_decide(int n, const double* sq, const unsigned char* live, const unsigned char* marked, double* rho,
+                                const double* dims, double tol, double rtol, int update_rho, double* last, double* fac,
+                                int* status)
+{
+    ARGCHK(n >= 0 && sq && live && rho && dims && last && fac && status, "batch_decide: arguments");
+    int events = 0;
+    for (int i = 0; i < n; ++i) {
+        fac[i] = 1.0;
+        status[i] = 0;
+        if (!live[i]) continue;
+        const double* q = sq + (size_t)i * GGL_NNORM;
+        bool finite = !(marked && marked[i]);
+        for (int j = 0; j < GGL_NNORM; ++j) finite = finite && std::isfinite(q[j]);
+        if (!finite) { status[i] = 2; events += 1; continue; }
+        const double n_om = std::sqrt(q[0]), n_thl = std::sqrt(q[1]), n_x = std::sqrt(q[2]), n_r = std::sqrt(q[3]),
+                     n_s = std::sqrt(q[4]);
+        const double r = rho[i];
+        const double r_t = n_r, s_t = r * n_s;
+        const double e_pri = dims[i] * tol + rtol * std::fmax(n_om, n_thl);
+        const double e_dual = dims[i] * tol + (rtol * r) * n_x;
+        if (update_rho) {
+            const double rn = (r_t >= 10 * s_t) ? 2 * r : ((s_t >= 10 * r_t) ? 0.5 * r : 1. * r);
+            fac[i] = r / rn;
+            rho[i] = rn;
+        }
+        double* l = last + (size_t)i * 4;
+        l[0] = r_t; l[1] = s_t; l[2] = e_pri; l[3] = e_dual;
+        if (r_t <= e_pri && s_t <= e_dual) { status[i] = 1; events += 1; }
+    }
+    return events;
+}
+
+// X_k <- fac_g X_k for the instances of every point (group instances per point), queued on the stream without a host wait:
+// the pinned slot is rewritten only after the NEXT iteration's synchronisation.
+static int batch_rescale(ggl_ctx* c, const double* fac, int n, int group)
+{
+    bool any = false;
+    for (int g = 0; g < n; ++g) any = any || fac[g] != 1.0;
+    if (!any) return GGL_OK;
+    double* h = c->par_h + 5 * (size_t)c->K;
+    for (int g = 0; g < n; ++g)
+        for (int k = 0; k < group; ++k) h[(size_t)g * group + k] = fac[g];
+    CopySegs sg;
+    sg.add(c->par + 5 * (size_t)c->K, h, c->K * sizeof(double));
+    launch_copy_small(c->stream, sg);
+    launch_scale_batch(c->stream, c->X, c->par + 5 * (size_t)c->K, c->K, c->p);
+    HIPCHK(hipGetLastError());
+    return GGL_OK;
+}
+
+static void batch_marks(ggl_ctx* c, int n, int group, unsigned char* marked)
+{
+    for (int g = 0; g < n; ++g) {
+        marked[g] = 0;
+        if (!c->failed) continue;
+        for (int k = 0; k < group; ++k) marked[g] |= c->failed[(size_t)g * group + k] ? 1 : 0;
+    }
+}
+
+// Up to n_iters iterations of ggl_sgl_batch_step with everything the host loop of gglasso_amd.batch.ADMM_SGL_batch does between
+// two of them -- per-point stopping test, rho rule, X rescale (single_admm_solver.py:186-214; the grid walk it serves:
+// helper/model_selection.py:619-633) -- done here, per iteration a loop over the K points instead of a Python round trip
+// (~100 us where the device needs 50 us at p <= 64).  Returns after the first iteration in which any live point converges
+// or fails (the caller snapshots / parks / compacts and calls again) or after n_iters; the return value is the number of
+// iterations run (>= 1), < 0 on error.
+//   rho (K) in/out;  done (K) 0/1: points that are finished (dragged along, no decisions);  dims (K): (p_k^2 + p_k) / 2;
+//   last (K,4), status (K): as ggl_batch_decide, of the LAST iteration run.
+extern "C" int ggl_sgl_batch_run(ggl_ctx* c, int n_iters, double* rho, const double* lambda1, int latent, const double* mu1,
+                                 const double* dims, double tol, double rtol, int update_rho, const unsigned char* done,
+                                 double* last, int* status)
+{
+    ARGCHK(c && rho && lambda1 && dims && done && last && status, "ctx, rho, lambda1, dims, done, last, status");
+    ARGCHK(n_iters >= 1, "n_iters >= 1");
+    ARGCHK(!latent || mu1, "latent needs mu1");
+    HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
+    const int K = c->K;
+    std::vector<double> sq((size_t)K * GGL_NNORM), fac(K);
+    std::vector<unsigned char> live(K), marked(K);
+    for (int k = 0; k < K; ++k) live[k] = done[k] ? 0 : 1;
+    for (int it = 0; it < n_iters; ++it) {
+        int rc = sgl_batch_step_impl(c, rho, lambda1, latent, mu1, sq.data());
+        if (rc) return rc;
+        batch_marks(c, K, 1, marked.data());
+        const int events = ggl_batch_decide(K, sq.data(), live.data(), marked.data(), rho, dims, tol, rtol, update_rho, last,
+                                            fac.data(), status);
+        if (events < 0) return events;
+        rc = batch_rescale(c, fac.data(), K, 1);
+        if (rc) return rc;
+        if (events > 0 || it == n_iters - 1) {
+            HIPCHK(hipStreamSynchronize(c->stream));       // (the caller reads the state / rewrites the pinned slots next)
+            return it + 1;
+        }
+    }
+    return n_iters;
+}
+
+// The same for G multiple-graph problems in one stack (ggl_mgl_batch_step; admm_solver.py:215-237, the grid walk
+// helper/model_selection.py:208-224).  rho, lambda1, lambda2, dims, done, status: (G); last (G,4).
+extern "C" int ggl_mgl_batch_run(ggl_ctx* c, int G, int n_iters, double* rho, const double* lambda1, const double* lambda2,
+                                 int reg, int latent, const double* mu1, const double* nk, const double* dims, double tol,
+                                 double rtol, int update_rho, const unsigned char* done, double* last, int* status)
+{
+    ARGCHK(c && rho && lambda1 && lambda2 && dims && done && last && status, "ctx, rho, lambda1, lambda2, dims, done, last, status");
+    ARGCHK(n_iters >= 1, "n_iters >= 1");
+    ARGCHK(reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
+    ARGCHK(G >= 1 && c->K % G == 0, "the ctx holds G problems of K/G instances each");
+    ARGCHK(!latent || mu1, "latent needs mu1");
+    ARGCHK(c->state_symmetric, "the batched Theta-step needs exactly symmetric dual / latent start points");
+    HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
+    const int Kp = c->K / G;
+    std::vector<double> sq((size_t)G * GGL_NNORM), fac(G);
+    std::vector<unsigned char> live(G), marked(G);
+    for (int g = 0; g < G; ++g) live[g] = done[g] ? 0 : 1;
+    for (int it = 0; it < n_iters; ++it) {
+        int rc = mgl_batch_step_impl(c, G, rho, lambda1, lambda2, reg, latent, mu1, nk, sq.data());
+        if (rc > 0) return fail(GGL_E_SOLVER, "batched MGL step: speculative step rejected twice");
+        if (rc) return rc;
+        batch_marks(c, G, Kp, marked.data());
+        const int events = ggl_batch_decide(G, sq.data(), live.data(), marked.data(), rho, dims, tol, rtol, update_rho, last,
+                                            fac.data(), status);
+        if (events < 0) return events;
+        rc = batch_rescale(c, fac.data(), G, Kp);
+        if (rc) return rc;
+        if (events > 0 || it == n_iters - 1) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            return it + 1;
+        }
+    }
+    return n_iters;
 }
 
 extern "C" int ggl_get_state_k(ggl_ctx* c, int k, double* Omega, double* Theta, double* L, double* X)
@@ -3185,7 +3356,8 @@ extern "C" int ggl_allreduce_groupsq(ggl_ctx* c)
 {
     ARGCHK(c && c->comm, "ctx with a communicator (ggl_comm_init)");
     const RcclApi* api = rccl_api(nullptr);
-    NCCLCHK(api, api->AllReduce(c->groupsq, c->groupsq, (size_t)c->p * c->p + 1, RcclApi::Float64, RcclApi::Sum, c->comm, c->stream));
+    // the packed upper triangle + the flag: 8 (p (p + 1) / 2 + 1) bytes on the wire
+    NCCLCHK(api, api->AllReduce(c->groupsq, c->groupsq, ggl::tri_len(c->p) + 1, RcclApi::Float64, RcclApi::Sum, c->comm, c->stream));
     return GGL_OK;
 }
 
@@ -3209,9 +3381,10 @@ static int sharded_pass(ggl_ctx* c, double rho, double lambda1, double lambda2, 
         rc = omega_step(c, latent, &sg, speculate && !latent && c->ns_parts < ggl_ctx::MAX_PARTS);
         if (rc) return rc;
     }
-    launch_group_sums_full(c->stream, c->groupsq, c->sqwork, c->Om[c->cur], latent ? c->L : nullptr, c->X,
-                           (1.0 / rho) * lambda1, c->K, c->p);
-    launch_spec_pack(c->stream, c->spec_pending ? c->spec_flag : nullptr, c->groupsq + (size_t)c->p * c->p);
+    // this rank's packed sums with its validation flag behind them: one launch (the flag used to be a kernel of its own
+    // before the collective and another one after it)
+    launch_group_sums_packed(c->stream, c->groupsq, c->sqwork, c->Om[c->cur], latent ? c->L : nullptr, c->X,
+                             (1.0 / rho) * lambda1, c->K, c->p, c->spec_pending ? c->spec_flag : nullptr);
     HIPCHK(hipGetLastError());
     PB(c, GGL_PH_ALLREDUCE_GROUPSQ);         // (HIP events on the ctx stream: what the collective costs THIS rank, waiting included)
     rc = ggl_allreduce_groupsq(c);

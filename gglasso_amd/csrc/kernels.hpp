@@ -47,10 +47,8 @@ struct CopySegs {
     void add(void* d, const void* s, size_t bytes) { dst[n] = d; src[n] = s; words[n] = (unsigned)(bytes / 4); ++n; }
 };
 void launch_copy_small(hipStream_t st, const CopySegs& segs);
+void launch_copy_small_seq(hipStream_t st, const CopySegs& segs, unsigned long long* seq, unsigned long long seq_val);
 void launch_spin_us(hipStream_t st, int us);      // one idle wave for `us` microseconds (stream-concurrency probe)
-// K-sharded speculation: this rank's validation flags -> one double behind the (p,p) all-reduce buffer, and back
-void launch_spec_pack(hipStream_t st, const int* flags /*4, or null*/, double* dst);
-void launch_spec_unpack(hipStream_t st, const double* src, int* flag, int* flag_host);
 // X[k] *= fK[k]
 void launch_scale_batch(hipStream_t st, double* X, const double* fK, int K, int p);
 // out[k] = max_{i,j} |A[k,i,j] - A[k,j,i]|
@@ -93,7 +91,8 @@ int theta_partial_blocks(int p, int reg, int K, int flat, int G = 1);      // G:
 // GGL/FGL Theta-step on upper-triangle K-vectors (prox_p, ggl_helper.py:190-207), mirrored.
 //   fuse_dual != 0 (non-latent): also X += Omega - Theta and norms partials [K][nblk][5].
 //   fuse_dual == 0 (latent): writes Theta and C = (Theta - X) - Omega  (admm_solver.py:198).
-// groupsq != null (GGL only): use this FULL symmetric (p,p) array as sum_k u^2 instead of computing it (K-sharded).
+// groupsq != null (GGL only): use this PACKED upper triangle (+ trailing flag: a set flag makes the kernel leave the iterate
+// alone) as sum_k u^2 instead of computing it (K-sharded).
 // Returns hipErrorInvalidValue if K is beyond what the FGL kernel's LDS scan buffer holds.
 // sqwork: ggl_chunks(K,p)*p*p doubles of scratch for the GGL sums of squares (unused when groupsq is given).
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C,
@@ -113,11 +112,22 @@ int ggl_chunks(int K, int p);
 void launch_group_partial(hipStream_t st, double* sq, const double* Omega, const double* L,
                           const double* X, double l1, int K, int p);
 // out(p,p) = sum_c sq[c], mirrored into the FULL symmetric matrix (diagonal 0)
-void launch_sum_chunks(hipStream_t st, double* out, const double* sq, int nsq, int p);
-// GROUPSQ of a K-sharded run: the full symmetric (p,p) matrix of this rank's sum_k soft(Omega+L+X, l1)^2 (per-element
-// kernel for K <= GGL_FLAT_MAX_K, tile pairs + launch_sum_chunks beyond; sqwork: ggl_chunks(K,p)*p*p doubles)
-void launch_group_sums_full(hipStream_t st, double* out, double* sqwork, const double* Omega, const double* L,
-                            const double* X, double l1, int K, int p);
+void launch_sum_chunks(hipStream_t st, double* out, const double* sq, int nsq, int p, const int* flags);
+// GROUPSQ of a K-sharded run (theta_pair.hip, ggl_capi.hip): the sums of squares sum_k u^2 are symmetric, so what the ranks
+// exchange is the PACKED upper triangle, row-major with the diagonal -- p (p + 1) / 2 doubles -- followed by one double for
+// the speculation flag.  Element (i,j) in either order:
+__host__ __device__ __forceinline__ size_t tri_index(int i, int j, int p)
+{
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    return (size_t)a * p - ((size_t)a * (a - 1)) / 2 + (size_t)(b - a);
+}
+__host__ __device__ __forceinline__ size_t tri_len(int p) { return (size_t)p * (p + 1) / 2; }
+// GROUPSQ of a K-sharded run: the PACKED upper triangle (tri_index, common.hpp) of this rank's sum_k soft(Omega+L+X, l1)^2
+// followed by this rank's speculation flag (flags: the validation flags of the step's parts, or null): tri_len(p) + 1
+// doubles, one launch (per-element kernel for K <= GGL_FLAT_MAX_K, tile pairs + launch_sum_chunks beyond; sqwork:
+// ggl_chunks(K,p)*p*p doubles)
+void launch_group_sums_packed(hipStream_t st, double* out, double* sqwork, const double* Omega, const double* L,
+                              const double* X, double l1, int K, int p, const int* flags);
 // stateless prox_p: out = prox_p(V)   (V symmetric stack; upper triangle decides)
 hipError_t launch_prox_p(hipStream_t st, int reg, double* out, const double* V, double l1, double l2,
                          int K, int p, double* sqwork);

@@ -141,33 +141,36 @@ __global__ __launch_bounds__(256) void k_group_partial(double* __restrict__ sq, 
         if (ok[q]) sq[(size_t)blockIdx.y * pp + off[q]] = ss[q];
 }
 
-// out = the FULL symmetric (p,p) matrix of sum_c sq[c][i][j] (sq holds the strict upper triangle; diagonal 0): what the
-// ranks of a K-sharded run all-reduce, whichever Theta kernel each of them runs afterwards
+// out = the PACKED upper triangle (tri_index, common.hpp) of sum_c sq[c][i][j] (sq holds the strict upper triangle; diagonal
+// 0) followed by the speculation flag of this rank: what the ranks of a K-sharded run all-reduce -- p (p + 1) / 2 + 1
+// doubles, half the full matrix -- whichever Theta kernel each of them runs afterwards
 __global__ __launch_bounds__(256) void k_sum_chunks(double* __restrict__ out, const double* __restrict__ sq, int nsq,
-                                                    int p)
+                                                    int p, const int* __restrict__ flags)
 {
     const size_t pp = (size_t)p * p;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[tri_len(p)] = spec_failed(flags) ? 1.0 : 0.0;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < pp; e += (size_t)gridDim.x * 256) {
         const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
+        if (i > j) continue;
         double s = 0.0;
-        if (i != j) {
-            const size_t src = (i < j) ? e : (size_t)j * p + i;
-            for (int c = 0; c < nsq; ++c) s += sq[(size_t)c * pp + src];
-        }
-        out[e] = s;
+        if (i != j)
+            for (int c = 0; c < nsq; ++c) s += sq[(size_t)c * pp + e];
+        out[tri_index(i, j, p)] = s;
     }
 }
 
-// the same matrix from one thread per element (K <= GGL_FLAT_MAX_K): sum_k soft(Omega + L + X, l1)^2 of the element's own
-// K-column, no tile pairs, no chunk buffer
+// the same vector from one thread per element of the upper triangle (K <= GGL_FLAT_MAX_K): sum_k soft(Omega + L + X, l1)^2 of
+// the element's own K-column, no tile pairs, no chunk buffer; the lower triangle is neither read nor written (half the pass)
 __global__ __launch_bounds__(256) void k_group_partial_flat(double* __restrict__ out, const double* __restrict__ Omega,
                                                             const double* __restrict__ L, const double* __restrict__ X,
-                                                            double l1, int K, int p)
+                                                            double l1, int K, int p, const int* __restrict__ flags)
 {
     const size_t pp = (size_t)p * p;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e == 0) out[tri_len(p)] = spec_failed(flags) ? 1.0 : 0.0;
     if (e >= pp) return;
     const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
+    if (i > j) return;
     double ss = 0.0;
     if (i != j) {
 #pragma unroll 4
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void k_group_partial_flat(double* __restrict__
             ss += u * u;
         }
     }
-    out[e] = ss;
+    out[tri_index(i, j, p)] = ss;
 }
 
 template <bool FUSE_DUAL>
@@ -190,11 +193,13 @@ __global__ __launch_bounds__(256) void k_theta_ggl(double* __restrict__ Theta, d
                                                    const double* __restrict__ L, double l1, double l2,
                                                    const double* __restrict__ sq, int nsq,
                                                    double* __restrict__ partials, int K, int p, int klen,
-                                                   const int* __restrict__ skip)
+                                                   const int* __restrict__ skip, int packed)
 {
+    // packed: sq is the all-reduced GROUPSQ of a K-sharded run (packed upper triangle + flag, common.hpp), nsq = 1
     __shared__ double tile[2][PT][PT + 1];
     __shared__ double scratch[GGL_NNORM * 4];
     if (spec_failed(skip)) return;
+    if (packed && gsq_rejected(sq, p)) return;
     const int T = (p + PT - 1) / PT;
     int I, J;
     decode_pair(blockIdx.x, T, I, J);
@@ -216,8 +221,11 @@ __global__ __launch_bounds__(256) void k_theta_ggl(double* __restrict__ Theta, d
         lo_ok[q] = (J0 + r < p) && (I0 + tx < p) && (!diag || r > tx);   // element (J0+r, I0+tx)
         lo_off[q] = (size_t)(J0 + r) * p + (I0 + tx);
         double ss = 0.0;
-        if (pr_ok[q])
-            for (int c = 0; c < nsq; ++c) ss += sq[(size_t)c * pp + up_off[q]];
+        if (pr_ok[q]) {
+            if (packed) ss = sq[tri_index(I0 + r, J0 + tx, p)];
+            else
+                for (int c = 0; c < nsq; ++c) ss += sq[(size_t)c * pp + up_off[q]];
+        }
         const double a = fmax(sqrt(ss), l2);
         amul[q] = a - l2;
         adiv[q] = a;
@@ -313,24 +321,25 @@ void launch_group_partial(hipStream_t st, double* sq, const double* Omega, const
                        l1, K, p, ggl_chunk_len(K, p));
 }
 
-void launch_sum_chunks(hipStream_t st, double* out, const double* sq, int nsq, int p)
+void launch_sum_chunks(hipStream_t st, double* out, const double* sq, int nsq, int p, const int* flags)
 {
     const size_t pp = (size_t)p * p;
     int blocks = (int)((pp + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_sum_chunks, dim3(blocks), dim3(256), 0, st, out, sq, nsq, p);
+    hipLaunchKernelGGL(k_sum_chunks, dim3(blocks), dim3(256), 0, st, out, sq, nsq, p, flags);
 }
 
-// GROUPSQ of a K-sharded run: the full symmetric (p,p) matrix of this rank's sum_k u^2
-void launch_group_sums_full(hipStream_t st, double* out, double* sqwork, const double* Omega, const double* L,
-                            const double* X, double l1, int K, int p)
+// GROUPSQ of a K-sharded run: the packed upper triangle of this rank's sum_k u^2 + this rank's speculation flag (flags: the
+// validation flags of the step's parts, or null) -- ONE launch, tri_len(p) + 1 doubles
+void launch_group_sums_packed(hipStream_t st, double* out, double* sqwork, const double* Omega, const double* L,
+                              const double* X, double l1, int K, int p, const int* flags)
 {
     if (K <= GGL_FLAT_MAX_K) {
-        hipLaunchKernelGGL(k_group_partial_flat, dim3(flat_blocks(p)), dim3(256), 0, st, out, Omega, L, X, l1, K, p);
+        hipLaunchKernelGGL(k_group_partial_flat, dim3(flat_blocks(p)), dim3(256), 0, st, out, Omega, L, X, l1, K, p, flags);
         return;
     }
     launch_group_partial(st, sqwork, Omega, L, X, l1, K, p);
-    launch_sum_chunks(st, out, sqwork, ggl_chunks(K, p), p);
+    launch_sum_chunks(st, out, sqwork, ggl_chunks(K, p), p, flags);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -855,6 +864,7 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
     // gsq != null (K-sharded run): the full (p,p) matrix of sum_k u^2 over ALL ranks' instances replaces the local sum
     __shared__ double scratch[GGL_NNORM * 4];
     if (spec_failed(skip)) return;
+    if (gsq_rejected(gsq, p)) return;      // (K-sharded run: the all-reduced flag behind the packed sums)
     const size_t pp = (size_t)p * p;
     {   // grid-point dimension of a batch of independent problems (see k_theta_fgl)
         const size_t goff = (size_t)blockIdx.y * K * pp;
@@ -881,7 +891,7 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
         }
         double ss = 0.0;
         if (gsq) {
-            ss = gsq[e];
+            ss = gsq[tri_index(i, j, p)];
         } else {
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
@@ -964,6 +974,7 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4(double* __restrict_
     __shared__ double ssh[NW][64];
     __shared__ double scratch[GGL_NNORM * NW];
     if (spec_failed(skip)) return;
+    if (gsq_rejected(gsq, p)) return;      // (K-sharded run: the all-reduced flag behind the packed sums)
     const size_t pp = (size_t)p * p;
     {   // grid-point dimension of a batch of independent problems (see k_theta_fgl)
         const size_t goff = (size_t)blockIdx.y * K * pp;
@@ -1009,10 +1020,10 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4(double* __restrict_
             double sv[NW];
 #pragma unroll
             for (int w = 0; w < NW; ++w) sv[w] = ssh[w][lane];
-            const double tot = gsq ? gsq[e] : tree_sum<NW>(sv);
+            const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
+            const double tot = gsq ? gsq[tri_index(i, j, p)] : tree_sum<NW>(sv);
             const double a = fmax(sqrt(tot), l2);
             const double amul = a - l2;
-            const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
             const bool offd = (i != j);
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
@@ -1074,6 +1085,7 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4v(double* __restrict
     __shared__ double2 ssh[NW][64];
     __shared__ double scratch[GGL_NNORM * NW];
     if (spec_failed(skip)) return;
+    if (gsq_rejected(gsq, p)) return;      // (K-sharded run: the all-reduced flag behind the packed sums)
     const size_t pp = (size_t)p * p;
     {
         const size_t goff = (size_t)blockIdx.y * K * pp;
@@ -1118,8 +1130,11 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4v(double* __restrict
     __syncthreads();
     if (live) {
         double2 tot;
-        if (gsq) tot = ld2(gsq + e);
-        else {
+        if (gsq) {
+            const int gi = (int)(e / p), gj = (int)(e - (size_t)gi * p);
+            tot.x = gsq[tri_index(gi, gj, p)];
+            tot.y = gsq[tri_index(gi, gj + 1, p)];
+        } else {
             double sx[NW], sy[NW];
 #pragma unroll
             for (int w = 0; w < NW; ++w) { sx[w] = ssh[w][lane].x; sy[w] = ssh[w][lane].y; }
@@ -1197,6 +1212,7 @@ __global__ __launch_bounds__(1024) void k_theta_ggl_flat16(double* __restrict__ 
     __shared__ double ssh[NW][16];
     __shared__ double scratch[GGL_NNORM * NW];
     if (spec_failed(skip)) return;
+    if (gsq_rejected(gsq, p)) return;      // (K-sharded run: the all-reduced flag behind the packed sums)
     const size_t pp = (size_t)p * p;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int el = lane & 15, kb = (wid * 4 + (lane >> 4)) * KQ;
@@ -1232,10 +1248,10 @@ __global__ __launch_bounds__(1024) void k_theta_ggl_flat16(double* __restrict__ 
         double sv[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) sv[w] = ssh[w][el];
-        const double tot = gsq ? gsq[e] : tree_sum<NW>(sv);
+        const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
+        const double tot = gsq ? gsq[tri_index(i, j, p)] : tree_sum<NW>(sv);
         const double a = fmax(sqrt(tot), l2);
         const double amul = a - l2;
-        const int i = (int)(e / p), j = (int)(e - (size_t)i * p);
         const bool offd = (i != j);
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
@@ -1392,10 +1408,11 @@ hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, 
             sq = sqwork;
             nsq = kc;
         }
+        const int packed = groupsq ? 1 : 0;
         if (fuse_dual)
-            hipLaunchKernelGGL(k_theta_ggl<true>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, sq, nsq, partials, K, p, klen, skip);
+            hipLaunchKernelGGL(k_theta_ggl<true>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, sq, nsq, partials, K, p, klen, skip, packed);
         else
-            hipLaunchKernelGGL(k_theta_ggl<false>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, sq, nsq, partials, K, p, klen, skip);
+            hipLaunchKernelGGL(k_theta_ggl<false>, grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, sq, nsq, partials, K, p, klen, skip, packed);
         return hipGetLastError();
     }
     if (K > FGL_MAX_K_TD8) return hipErrorInvalidValue;

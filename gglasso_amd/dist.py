@@ -4,7 +4,8 @@ What shards and what does not:
   * Omega-step / L-step (eigendecompositions): independent per instance k -> contiguous K-slabs.
   * GGL Theta-step: the group norm |u[:,i,j]|_2 runs over ALL K (solver/ggl_helper.py:38-43), so a
     K-sharded run needs one exchange per iteration: every rank soft-thresholds its slab, accumulates
-    sum_k u^2 into a (p,p) buffer, the buffers are all-reduced (8*p*p bytes; 2 MB at p=500), and every
+    sum_k u^2 into the packed upper triangle of a (p,p) buffer, the buffers are all-reduced (4*p*(p+1)+8 bytes; 1 MB at
+    p=500), and every
     rank scales its own slab.  This is the only data-path collective.
   * stopping test: the five squared norms are all-reduced (40 bytes) before the host takes the sqrt.
   * FGL Theta-step: Condat's scan is sequential along K (solver/fgl_helper.py:24-66) -> no K-sharding;
@@ -171,9 +172,10 @@ class RcclComm:
 
 
 def _hip_groupsq_tensor(self, torch, device):
-    # (p,p) sums + the trailing speculation flag (include/ggl_hip.h, ggl_step_omega_spec): one flat vector
+    # the packed upper triangle of the (p,p) sums + the trailing speculation flag (include/ggl_hip.h, GGL_BUF_GROUPSQ):
+    # one flat vector of p (p + 1) / 2 + 1 doubles
     ptr = self.device_ptr(_lib.BUF_GROUPSQ)
-    return torch.as_tensor(_DeviceView(ptr, (self.p * self.p + 1,)), device=device)
+    return torch.as_tensor(_DeviceView(ptr, (self.p * (self.p + 1) // 2 + 1,)), device=device)
 
 
 def _hip_norms_tensor(self, torch, device):

@@ -227,6 +227,34 @@ class HipEngine:
     def scale_X_batch(self, factors):
         check(self.lib.ggl_scale_X_batch(self.h, ptr(as_c(factors))))
 
+    def sgl_batch_run(self, n_iters, rho, lambda1, latent, mu1, dims, tol, rtol, update_rho, done):
+        """Up to ``n_iters`` iterations of ``sgl_batch_step`` with the per-point stopping test, rho rule and X rescale taken in
+        C (ggl_sgl_batch_run); stops after the first iteration in which a live point converges or fails.  ``rho`` (K,) float64
+        is updated IN PLACE.  Returns (iterations run, last (K,4), status (K,) int32: 0 goes on, 1 converged, 2 failed)."""
+        assert rho.dtype == np.float64 and rho.flags.c_contiguous and rho.shape == (self.K,)
+        last = np.zeros((self.K, 4))
+        status = np.zeros(self.K, dtype=np.int32)
+        dn = np.ascontiguousarray(done, dtype=np.uint8)
+        n = check(self.lib.ggl_sgl_batch_run(self.h, int(n_iters), ptr(rho), ptr(as_c(lambda1)), int(latent),
+                                             ptr(None if mu1 is None else as_c(mu1)), ptr(as_c(dims)), float(tol), float(rtol),
+                                             int(bool(update_rho)), dn.ctypes.data_as(_lib._ubp), ptr(last),
+                                             status.ctypes.data_as(_lib._ip)))
+        return int(n), last, status
+
+    def mgl_batch_run(self, G, n_iters, rho, lambda1, lambda2, reg, latent, mu1, nk, dims, tol, rtol, update_rho, done):
+        """The same for G multiple-graph problems in one stack (ggl_mgl_batch_run); ``rho`` (G,) is updated in place."""
+        G = int(G)
+        assert rho.dtype == np.float64 and rho.flags.c_contiguous and rho.shape == (G,)
+        last = np.zeros((G, 4))
+        status = np.zeros(G, dtype=np.int32)
+        dn = np.ascontiguousarray(done, dtype=np.uint8)
+        n = check(self.lib.ggl_mgl_batch_run(self.h, G, int(n_iters), ptr(rho), ptr(as_c(lambda1)), ptr(as_c(lambda2)),
+                                             _REG[reg], int(latent), ptr(None if mu1 is None else as_c(mu1)),
+                                             ptr(None if nk is None else as_c(nk)), ptr(as_c(dims)), float(tol), float(rtol),
+                                             int(bool(update_rho)), dn.ctypes.data_as(_lib._ubp), ptr(last),
+                                             status.ctypes.data_as(_lib._ip)))
+        return int(n), last, status
+
     # -- G independent multiple-graph problems in one stack (batched lambda1 x lambda2 grid) -------------------
     def mgl_batch_step(self, G, rho, lambda1, lambda2, reg, latent, mu1, nk):
         """One ADMM_MGL iteration of all G problems (problem g = instances g*K/G ..); returns the (G,5) sums."""

@@ -64,7 +64,8 @@ extern "C" {
 #define GGL_BUF_THETA 2
 #define GGL_BUF_L 3
 #define GGL_BUF_X 4
-#define GGL_BUF_GROUPSQ 5   /* (p,p) partial sum_k u^2 of the GGL Theta-step (K-sharded runs) + 1 flag double */
+#define GGL_BUF_GROUPSQ 5   /* partial sum_k u^2 of the GGL Theta-step (K-sharded runs): PACKED upper triangle, row-major with the
+                             * diagonal, element (i,j), i <= j, at i p - i (i - 1) / 2 + (j - i): p (p + 1) / 2 doubles, + 1 flag double */
 #define GGL_BUF_NORMS 6     /* (K,5) per-instance squared norms of the stopping test */
 #define GGL_BUF_OMEGA_PREV 7
 
@@ -197,14 +198,14 @@ int ggl_hint_last_step(ggl_ctx *ctx);
 /* The same iteration split at the one point where a K-sharded GGL run has to exchange data
  * (sum_k u^2 couples the shards, ggl_helper.py:38-43):
  *   ggl_step_omega          Omega-step on the local K-slab
- *   ggl_step_group_partial  u = soft(Omega+L+X, l1/rho); GROUPSQ(p,p) = sum_{local k} u^2  (GGL only)
+ *   ggl_step_group_partial  u = soft(Omega+L+X, l1/rho); GROUPSQ = packed upper triangle of sum_{local k} u^2  (GGL only)
  *   -- caller all-reduces GGL_BUF_GROUPSQ over ranks (RCCL) --
  *   ggl_step_finish         Theta from the reduced GROUPSQ, L-step, X update, local norms       */
 int ggl_step_omega(ggl_ctx *ctx, double rho, int latent, const double *nk);
 int ggl_step_group_partial(ggl_ctx *ctx, double rho, double lambda1);
 /* ggl_step_omega that may run speculatively (schedule from the previous iteration's bounds, no host sync).  The
- * validation flag of this rank is appended to GROUPSQ as element p*p by ggl_step_group_partial, so the caller's
- * all-reduce must cover p*p+1 doubles; ggl_step_finish reads the reduced flag back and, if ANY rank missed, leaves
+ * validation flag of this rank is appended to GROUPSQ as element p(p+1)/2 by ggl_step_group_partial, so the caller's
+ * all-reduce must cover p(p+1)/2 + 1 doubles; ggl_step_finish reads the reduced flag back and, if ANY rank missed, leaves
  * the iterate alone; ggl_norms_read (or ggl_step_finish without deferred norms) then returns 1 on every rank:
  * repeat the iteration with ggl_step_omega. */
 int ggl_step_omega_spec(ggl_ctx *ctx, double rho, int latent, const double *nk);
@@ -222,8 +223,8 @@ int ggl_norms_read(ggl_ctx *ctx, double out_norms[5]);
  *                       (MPI_Bcast, a file, torch.distributed's store -- gglasso_amd/dist.py uses broadcast_object_list)
  *   ggl_comm_init       ncclCommInitRank for this ctx's device; the collectives run on the ctx stream
  *   ggl_admm_step_sharded  the whole iteration of admm_solver.py:179-224 on this rank's slab with its two exchanges:
- *                       Omega-step (speculative) | local sum_k u^2 -> ncclAllReduce of GROUPSQ (p*p + 1 doubles: the
- *                       validation flag rides along) | Theta-step, dual update, five local sums -> ncclAllReduce (5
+ *                       Omega-step (speculative) | local sum_k u^2 -> ncclAllReduce of GROUPSQ (p(p+1)/2 + 1 doubles: the
+ *                       packed upper triangle, the validation flag rides along) | Theta-step, dual update, five local sums -> ncclAllReduce (5
  *                       doubles) | one host synchronisation.  out_norms are the GLOBAL sums: every rank takes the same
  *                       rho / stopping decision.  A rejected speculative step is repeated inside the call on all ranks.
  *   ggl_allreduce_groupsq / ggl_allreduce_norms  the two collectives alone, for callers that use the split entry points. */
@@ -272,6 +273,28 @@ int ggl_get_state_k(ggl_ctx *ctx, int k, double *Omega, double *Theta, double *L
  * GGL: K/G <= 32; state exactly symmetric. */
 int ggl_mgl_batch_step(ggl_ctx *ctx, int G, const double *rho, const double *lambda1, const double *lambda2,
                        int reg, int latent, const double *mu1, const double *nk, double *out_norms);
+
+/* ---- n iterations of a batch per call (round 5): the HOST LOOP of the grid walks in C -----------------------------------
+ * The reference's grid walks (helper/model_selection.py:208-224, :619-633) run, per point and iteration, the stopping test
+ * (ADMM_stopping_criterion, solver/admm_solver.py:316-331 / single_admm_solver.py:277-291), the residual-balancing rho rule
+ * and the dual rescale (admm_solver.py:227-237 / single_admm_solver.py:196-206).  gglasso_amd.batch did that in NumPy between
+ * two C calls (~100 us per batch iteration where the device needs 50 us at p <= 64).
+ * ggl_batch_decide (host only, no GPU): one iteration's decisions for n points, bit for bit gglasso_amd.batch._decide --
+ *   sq (n,5) squared norms; live (n) 0/1; marked (n) 0/1 or NULL (ggl_failed_instances); rho (n) in/out; dims (n);
+ *   last (n,4) {r_t, s_t, e_pri, e_dual} (rows of live finite points rewritten); fac (n) out = rho / rho_new;
+ *   status (n) out: 0 goes on, 1 converged now, 2 failed (non-finite sums or marked).  Returns #{status != 0}.
+ * ggl_sgl_batch_run / ggl_mgl_batch_run: up to n_iters iterations of ggl_sgl_batch_step / ggl_mgl_batch_step with those
+ *   decisions and the X rescale in between; return after the first iteration in which a live point converges or fails (the
+ *   caller snapshots, parks, compacts: gglasso_amd/batch.py) or after n_iters.  Return value: iterations run, < 0 on error.
+ *   done (n) 0/1: finished points (dragged along, no decisions).  last / status: of the last iteration run. */
+int ggl_batch_decide(int n, const double *sq, const unsigned char *live, const unsigned char *marked, double *rho,
+                     const double *dims, double tol, double rtol, int update_rho, double *last, double *fac, int *status);
+int ggl_sgl_batch_run(ggl_ctx *ctx, int n_iters, double *rho, const double *lambda1, int latent, const double *mu1,
+                      const double *dims, double tol, double rtol, int update_rho, const unsigned char *done,
+                      double *last, int *status);
+int ggl_mgl_batch_run(ggl_ctx *ctx, int G, int n_iters, double *rho, const double *lambda1, const double *lambda2,
+                      int reg, int latent, const double *mu1, const double *nk, const double *dims, double tol, double rtol,
+                      int update_rho, const unsigned char *done, double *last, int *status);
 
 /* host only: out = {largest K/G of the batched GGL grid (per-element Theta kernel), largest K of the FGL Theta-step (the
  * K-vectors of a tile of pairs live in LDS)}; callers choose between the batched grid and the sequential walk with it */
@@ -392,7 +415,7 @@ int ggl_kkt_residual(ggl_ctx *ctx, double rho, double lambda1, double lambda2, i
 #define GGL_PH_REDUCE 7       /* partial-sum reduction of the norms                                */
 #define GGL_PH_EIG_OMEGA2 8   /* second part of the Newton-Schulz Omega-step (after the spectral-bound sync) */
 #define GGL_PH_BOUND 9        /* (not recorded any more: the bound kernels run inside the Omega-step chains) */
-#define GGL_PH_ALLREDUCE_GROUPSQ 10 /* K-sharded run: ncclAllReduce of the (p,p) + 1 group sums (ggl_admm_step_sharded)  */
+#define GGL_PH_ALLREDUCE_GROUPSQ 10 /* K-sharded run: ncclAllReduce of the p(p+1)/2 + 1 packed group sums (ggl_admm_step_sharded)  */
 #define GGL_PH_ALLREDUCE_NORMS 11   /* K-sharded run: ncclAllReduce of the five sums                                    */
 #define GGL_NPHASE 12
 /* on: 0 off, 1 every phase, 2 only GGL_PH_EIG_OMEGA / _OMEGA2 / _EIG_L and the two all-reduces (4-10 event records per iteration) */

@@ -84,3 +84,44 @@ def test_compaction_cost_model():
     assert not moved(500, 20, 5, 3) and not moved(500, 20, 10, 18) and moved(500, 20, 10, 40)
     assert moved(500, 12, 6, 10, group=6) and not moved(500, 12, 6, 10, group=1)
     assert not moved(1000, 20, 1, 3) and not moved(1000, 20, 4, 3)      # the old rules stay: >= 2 slots and a quarter of the ctx
+
+
+def test_c_decisions_are_the_numpy_ones():
+    """ggl_batch_decide -- what ggl_sgl_batch_run / ggl_mgl_batch_run take between two iterations without returning to Python --
+    against ``batch._decide`` bit for bit: rhos, factors, the stored residuals, which points converged and which failed,
+    including the rule's boundaries, non-finite sums and points the library marked (host only: no GPU needed)."""
+    import ctypes
+    from gglasso_amd import _lib
+    lib = _lib.load()
+    ptr = _lib.ptr
+    rng = np.random.default_rng(1)
+    for trial in range(300):
+        n = int(rng.integers(1, 40))
+        ids = np.arange(n)
+        sq = rng.uniform(0, 1, (n, 5)) ** rng.integers(1, 12)
+        sq[:, :3] *= rng.uniform(1, 1e4, (n, 1))
+        if n > 2:
+            sq[0, 3] = 100.0 * sq[0, 4]
+            sq[1, 4] = 100.0 * sq[1, 3]
+        if trial % 5 == 0:
+            sq[rng.integers(n), rng.integers(5)] = [np.nan, np.inf, -np.inf][trial % 3]
+        rhos0 = 2.0 ** rng.integers(-4, 5, n).astype(float)
+        done0 = rng.uniform(size=n) < 0.2
+        marked = rng.uniform(size=n) < (0.1 if trial % 3 == 0 else 0.0)
+        dims = (rng.integers(2, 60, n) ** 2).astype(float)
+        tol, rtol = 10.0 ** -rng.integers(3, 9), 10.0 ** -rng.integers(2, 8)
+        for update_rho in (True, False):
+            a = dict(rhos=rhos0.copy(), done=done0.copy(), last=np.zeros((n, 4)))
+            bad, newly, fac = batch._decide(sq, ids, a["rhos"], a["done"], a["last"], dims, tol, rtol, update_rho, 0, False,
+                                            marked=marked)
+            rho_c, last_c, fac_c = rhos0.copy(), np.zeros((n, 4)), np.zeros(n)
+            status = np.zeros(n, dtype=np.int32)
+            live = np.ascontiguousarray(~done0, dtype=np.uint8)
+            mk = np.ascontiguousarray(marked, dtype=np.uint8)
+            ev = lib.ggl_batch_decide(n, ptr(np.ascontiguousarray(sq)), live.ctypes.data_as(_lib._ubp),
+                                      mk.ctypes.data_as(_lib._ubp), ptr(rho_c), ptr(dims), float(tol), float(rtol),
+                                      int(update_rho), ptr(last_c), ptr(fac_c), status.ctypes.data_as(_lib._ip))
+            assert ev == len(bad) + len(newly)
+            assert np.array_equal(np.flatnonzero(status == 2), bad) and np.array_equal(np.flatnonzero(status == 1), newly)
+            assert np.array_equal(rho_c, a["rhos"]) and np.array_equal(fac_c, fac)
+            assert np.array_equal(last_c, a["last"])

@@ -267,6 +267,8 @@ def test_marked_instance_with_finite_sums_is_reported(monkeypatch):
         return out
 
     monkeypatch.setattr(solver.HipEngine, "failed_instances", fake)
-    res = ADMM_SGL_batch(S, np.full(K, 0.1), tol=1e-8, rtol=1e-8, max_iter=200, compact=False)
+    # (verbose: the driver's Python loop, which asks through HipEngine.failed_instances -- the C loop of ggl_sgl_batch_run reads
+    # the ctx's marks directly and hands them to the same decision function, tests/test_cpu_batch_decisions.py)
+    res = quiet(ADMM_SGL_batch, S, np.full(K, 0.1), tol=1e-8, rtol=1e-8, max_iter=200, compact=False, verbose=True)
     assert res[1][1]['status'] == 'solver error' and res[1][1]['iterations'] == 3
     assert all(res[k][1]['status'] == 'optimal' for k in (0, 2, 3))

@@ -14,7 +14,8 @@ Only the r eigenvalues above beta matter (r <= 6 of 500 on this problem), and C 
 Reported per ADMM iteration (max over the instances): r, the gap structure around beta, passes over C needed for
 max|L~ - L| <= 1e-10 cold (random start) and warm (previous V), plain and filtered, and what the residual bound says.
 
-    python tools/proto_subspace.py [K] [p] [iters] [b] [mu1]
+    python tools/proto_subspace.py [K] [p] [iters] [b] [mu1]        (C4's problem)
+    python tools/proto_subspace.py --sgl                            (a genuinely low-rank latent problem: fixture G18's data)
 """
 import os
 import sys
@@ -120,5 +121,48 @@ def main():
         rho = rn
 
 
+def main_sgl():
+    """The same measurement on a problem whose latent component IS of low rank: fixture G18's data (the marginal of a Gaussian
+    with 5 hidden variables, p = 200, generated by the real reference; ADMM_SGL, lambda1 = 0.03, latent), three mu1."""
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                             "g18_latent_rank_large_p.npz"))
+    S = g["sgl_S"]
+    p = S.shape[0]
+    rng = np.random.default_rng(1)
+    b = 16
+    for mu1 in (1.5, 0.8, 0.4):
+        Om = np.eye(p); Th = Om.copy(); X = np.zeros_like(S); L = np.zeros_like(S); rho = 1.0; lam = 0.03
+        Vw = {md: rng.standard_normal((p, b)) for md in ("plain", 4, 8)}
+        print(f"ADMM_SGL p={p} latent (G18 data), mu1={mu1}, block b={b}: (cold, warm) passes over C for max|L~ - L| <= 1e-10")
+        for it in range(40):
+            W = Th - L - X - S / rho
+            Omp = Om
+            Om = orc.phiplus_stack(W[None], 1 / rho)[0][0]
+            Th = orc.prox_od_1norm(Om + L + X, lam / rho)
+            C = Th - X - Om
+            beta = mu1 / rho
+            Lref = orc.rank_stack(C[None], beta)[0]
+            ev = np.linalg.eigvalsh(C)[::-1]
+            r = int((ev > beta).sum())
+            out = {}
+            for md in ("plain", 4, 8):
+                cold = solve(C, beta, Lref, rng.standard_normal((p, b)), md, sigma=-ev[-1], lo=ev[-1])
+                warm = solve(C, beta, Lref, Vw[md], md, sigma=-ev[-1], lo=ev[-1])
+                Vw[md] = warm[1]
+                out[md] = (cold[0], warm[0], warm[2], warm[3])
+            if it < 10 or it % 5 == 0:
+                print(f"it {it:2d} rho {rho:4.2f} r {r} lam_max {ev[0]:.3f} lam_min {ev[-1]:.3f} gap above "
+                      f"{(ev[r - 1] - beta) if r else np.nan:.1e} below {beta - ev[r]:.1e} beta-lam_b+1 {beta - ev[b]:.1e} | "
+                      f"plain {out['plain'][:2]} cheb4 {out[4][:2]} cheb8 {out[8][:2]} err {out[8][2]:.1e} bound {out[8][3]:.1e}",
+                      flush=True)
+            L = Lref
+            X = X + Om - Th + L
+            n_r = np.linalg.norm(Om - Th + L)
+            n_s = rho * np.linalg.norm(Om - Omp)
+            rn = 2 * rho if n_r >= 10 * n_s else (0.5 * rho if n_s >= 10 * n_r else rho)
+            X = (rho / rn) * X
+            rho = rn
+
+
 if __name__ == "__main__":
-    main()
+    main_sgl() if "--sgl" in sys.argv else main()
