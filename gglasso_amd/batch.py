@@ -119,16 +119,18 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
             if keep_snapshots:
                 eng.snapshot_k(k) if cur is eng else eng.snapshot_from(k, cur, s)
 
-        it = 0                                                           # batch iterations run so far
-        while it < max_iter:
-            if hasattr(cur, "sgl_batch_run") and not verbose:
-                # iterations until some point converges or fails, decisions and X rescale in C (ggl_sgl_batch_run)
-                bad, newly, n = _run_in_c(lambda rho_s: cur.sgl_batch_run(
-                    max_iter - it, rho_s, lam[slots], latent, None if mu is None else mu[slots], dimk[slots], tol, rtol,
-                    update_rho, done[slots]), slots, rhos, done, last)
-                carried[slots] += n
-                it += n
-            else:
+        if hasattr(eng, "batch_run") and not verbose:
+            # the whole loop in C (ggl_sgl_batch_run): decisions, X rescale, device snapshots of the points that finish,
+            # parking of the ones that fail; Python is back in the picture only to compact the batch
+            snaps, status, iters = _loop_in_c(eng, engines, K, 1, p, rhos, last, carried, dimk, tol, rtol, update_rho, max_iter,
+                                              compact, latent,
+                                              lambda sl: dict(lambda1=lam[sl], latent=latent, mu1=None if mu is None else mu[sl]))
+            for k in range(K):
+                sol = {nm: np.ascontiguousarray(A[k, :pk[k], :pk[k]]) for nm, A in snaps.items()}
+                results[k] = (sol, {'status': status[k], 'iterations': int(iters[k]), 'rho': rhos[k]})
+        else:
+            it = 0                                                           # batch iterations run so far
+            while it < max_iter:
                 sq = cur.sgl_batch_step(rhos[slots], lam[slots], latent, None if mu is None else mu[slots])
                 carried[slots] += 1
                 bad, newly, fac = _decide(sq, slots, rhos, done, last, dimk[slots], tol, rtol, update_rho, it, verbose,
@@ -136,26 +138,23 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                 if np.any(fac != 1.0):
                     cur.scale_X_batch(fac)      # (a failed point's factor is 1; single_admm_solver.py:205 comes before the break)
                 it += 1
-            # the converged points before the failed ones are parked: collecting them reads what the ctx knows about the last
-            # L-step of the WHOLE batch, which parking a point must not disturb
-            for s in newly:
-                finish(s, 'optimal', it)
-            for s in bad:
-                # this point's data are not finite (a NaN in its S, a diverged iterate) or the library marked it (an
-                # eigensolver that did not converge): the reference's sequential walk (model_selection.py:619-633) would
-                # lose this point only -- so does the batch
-                finish(s, 'solver error', it)
-                if hasattr(cur, "reset_instance"):
-                    cur.reset_instance(int(s))
-            if done.all():
-                break
-            cur, slots = _compact(cur, slots, done, engines, compact, p=p, it=it - 1)
-        for s, k in enumerate(slots):
-            if results[k] is None:
-                r_t, s_t, e_pri, e_dual = last[k]
-                status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
-                                                                else 'max iterations reached')
-                finish(s, status, max_iter)
+                # the converged points before the failed ones are parked: collecting them reads what the ctx knows about the
+                # last L-step of the WHOLE batch, which parking a point must not disturb
+                for s in newly:
+                    finish(s, 'optimal', it)
+                for s in bad:
+                    # this point's data are not finite (a NaN in its S, a diverged iterate) or the library marked it (an
+                    # eigensolver that did not converge): the reference's sequential walk (model_selection.py:619-633) would
+                    # lose this point only -- so does the batch
+                    finish(s, 'solver error', it)
+                    if hasattr(cur, "reset_instance"):
+                        cur.reset_instance(int(s))
+                if done.all():
+                    break
+                cur, slots = _compact(cur, slots, done, engines, compact, p=p, it=it - 1)
+            for s, k in enumerate(slots):
+                if results[k] is None:
+                    finish(s, _leftover_status(last[k]), max_iter)
         for k in range(K):
             results[k][1]['carried'] = int(carried[k])
         ranks = _final_L(eng, [results[k][0] for k in range(K)], 1) if latent else None
@@ -181,21 +180,54 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
     return results
 
 
-def _run_in_c(run, slots, rhos, done, last):
-    """One call of HipEngine.sgl_batch_run / mgl_batch_run on the live ctx (``run(rho_s)``: the call, with the slots' rhos as a
-    contiguous array it updates in place) folded back into the per-point bookkeeping of the drivers: rhos, last (rows
-    r_t, s_t, e_pri, e_dual), done.  Returns (slots that failed, slots that converged, iterations run)."""
-    rho_s = np.ascontiguousarray(rhos[slots], dtype=np.float64)
-    n, last_s, status = run(rho_s)
-    live = ~done[slots]
-    rhos[slots[live]] = rho_s[live]
-    upd = live & (status != 2)
-    last[slots[upd]] = last_s[upd]
-    bad = np.flatnonzero(live & (status == 2))
-    newly = np.flatnonzero(live & (status == 1))
-    done[slots[bad]] = True
-    done[slots[newly]] = True
-    return bad, newly, n
+def _leftover_status(row):
+    r_t, s_t, e_pri, e_dual = row
+    return 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual else 'max iterations reached')
+
+
+def _loop_in_c(eng, engines, n, group, p, rhos, last, carried, dims, tol, rtol, update_rho, max_iter, compact, latent, args_of):
+    """The iteration loop of a batch with the host side in C (HipEngine.batch_run -> ggl_sgl_batch_run / ggl_mgl_batch_run):
+    n points of ``group`` instances each; rhos (n,), last (n,4), carried (n,) are updated in place; ``args_of(slots)``: the
+    keyword arguments of ``batch_run`` that describe the points in the slots of the live ctx.  Every point's solution is
+    snapshotted on the device at the iteration it finishes (in the ORIGINAL ctx ``eng`` at its original index, also out of a
+    compacted ctx) and all of them come back with one download per stack.  Returns ({'Omega','Theta','X'[,'L']} stacks of
+    eng, status strings (n), iteration counts (n))."""
+    status = np.zeros(n, dtype=np.int32)
+    fin_iter = np.zeros(n, dtype=np.int32)
+    cur, slots = eng, np.arange(n)
+    inst = lambda sl: (sl[:, None] * group + np.arange(group)[None, :]).reshape(-1)     # instance slots of point slots
+    dims = np.broadcast_to(np.asarray(dims, dtype=np.float64), (n,))
+    it = 0
+    while it < max_iter:
+        ns = len(slots)
+        # when to come back for a compaction: once enough slots of the live ctx hold finished points -- and never where the
+        # cost model (_compact) cannot be met within max_iter
+        stop_after = 0
+        if compact and hasattr(cur, "subset") and \
+                ns * group * COMPACT_SLOT_S_PER_P3 * float(p) ** 3 * max(max_iter, 10) >= COMPACT_COST_S:
+            stop_after = max(COMPACT_MIN_DROP, int(np.ceil(COMPACT_FRACTION * ns)))
+        rho_s, last_s = np.ascontiguousarray(rhos[slots]), np.ascontiguousarray(last[slots])
+        st_s, fi_s = np.ascontiguousarray(status[slots]), np.ascontiguousarray(fin_iter[slots])
+        done_before = int(np.count_nonzero(st_s))
+        if stop_after:
+            stop_after = max(stop_after, done_before + 1)
+        k = cur.batch_run(max_iter - it, rho_s, last_s, st_s, fi_s, it, dims[slots], tol, rtol, update_rho,
+                          snap=(eng, inst(slots)), stop_after=stop_after, **args_of(slots))
+        rhos[slots], last[slots], status[slots], fin_iter[slots] = rho_s, last_s, st_s, fi_s
+        carried[slots] += k
+        it += k
+        done = status != 0
+        if done.all():
+            break
+        cur, slots = _compact(cur, slots, done, engines, compact, group=group, p=p, it=it - 1)
+    for s, g in enumerate(slots):
+        if status[g] == 0:                      # ran into max_iter: what it holds now is its solution
+            for q in range(group):
+                eng.snapshot_state_from(g * group + q, cur, s * group + q)
+    names = {1: 'optimal', 2: 'solver error'}
+    out_status = [names[int(status[g])] if status[g] else _leftover_status(last[g]) for g in range(n)]
+    iters = np.where(status != 0, fin_iter, max_iter)
+    return eng.snapshots(latent), out_status, iters
 
 
 def _marked(eng, group):
@@ -398,15 +430,18 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                 for k in range(K):
                     eng.snapshot_k(g * K + k) if cur is eng else eng.snapshot_from(g * K + k, cur, s * K + k)
 
-        it = 0
-        while it < max_iter:
-            if hasattr(cur, "mgl_batch_run") and not verbose:
-                bad, newly, n = _run_in_c(lambda rho_s: cur.mgl_batch_run(
-                    len(slots), max_iter - it, rho_s, lam1[slots], lam2[slots], reg, latent, inst(mu), nk,
-                    np.full(len(slots), float(dim)), tol, rtol, update_rho, done[slots]), slots, rhos, done, last)
-                carried[slots] += n
-                it += n
-            else:
+        if hasattr(eng, "batch_run") and not verbose:
+            snaps, status, iters = _loop_in_c(eng, engines, G, K, p, rhos, last, carried, float(dim), tol, rtol, update_rho,
+                                              max_iter, compact, True,
+                                              lambda sl: dict(lambda1=lam1[sl], lambda2=lam2[sl], reg=reg, latent=latent,
+                                                              mu1=None if mu is None else mu.reshape(G, K)[sl].reshape(-1),
+                                                              nk=nk, G=len(sl)))
+            for g in range(G):
+                sol = {nm: snaps[nm][g * K:(g + 1) * K].copy() for nm in ('Omega', 'Theta', 'L', 'X')}
+                results[g] = (sol, {'status': status[g], 'iterations': int(iters[g]), 'rho': rhos[g]})
+        else:
+            it = 0
+            while it < max_iter:
                 sq = cur.mgl_batch_step(len(slots), rhos[slots], lam1[slots], lam2[slots], reg, latent, inst(mu), nk)
                 carried[slots] += 1
                 bad, newly, fac = _decide(sq, slots, rhos, done, last, dim, tol, rtol, update_rho, it, verbose,
@@ -414,23 +449,20 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                 if np.any(fac != 1.0):
                     cur.scale_X_batch(np.repeat(fac, K))
                 it += 1
-            for s in newly:                      # (before the failed ones are parked: see ADMM_SGL_batch)
-                collect(s, 'optimal', it)
-            for s in bad:
-                # (see ADMM_SGL_batch: a point with non-finite data or a mark costs that point only)
-                collect(s, 'solver error', it)
-                if hasattr(cur, "reset_instance"):
-                    for k in range(K):
-                        cur.reset_instance(int(s) * K + k)
-            if done.all():
-                break
-            cur, slots = _compact(cur, slots, done, engines, compact, group=K, p=p, it=it - 1)
-        for s, g in enumerate(slots):
-            if results[g] is None:
-                r_t, s_t, e_pri, e_dual = last[g]
-                status = 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual
-                                                                else 'max iterations reached')
-                collect(s, status, max_iter)
+                for s in newly:                      # (before the failed ones are parked: see ADMM_SGL_batch)
+                    collect(s, 'optimal', it)
+                for s in bad:
+                    # (see ADMM_SGL_batch: a point with non-finite data or a mark costs that point only)
+                    collect(s, 'solver error', it)
+                    if hasattr(cur, "reset_instance"):
+                        for k in range(K):
+                            cur.reset_instance(int(s) * K + k)
+                if done.all():
+                    break
+                cur, slots = _compact(cur, slots, done, engines, compact, group=K, p=p, it=it - 1)
+            for s, g in enumerate(slots):
+                if results[g] is None:
+                    collect(s, _leftover_status(last[g]), max_iter)
         for g in range(G):
             results[g][1]['carried'] = int(carried[g])
         if latent:

@@ -105,6 +105,7 @@ struct ggl_ctx {
     bool fused_bounds = true;                  // spectral-bound partials from the epilogue of the B' launch (GGL_OPT_FUSED_BOUNDS)
     // small matrices: the whole Omega-step as ONE launch with the chain resident in LDS (omega_lds.hip, GGL_OPT_OMEGA_LDS)
     bool lds_omega = true;
+    int lds_waves = 0;                          // waves per workgroup of k_omega_lds: 0 by size, 4, 8 (GGL_OPT_OMEGA_LDS = 4 / 8)
     double* lds_tab = nullptr;                 // device: schedule table + the two counters behind it (lazy)
     int lds_ntab = 0, lds_tab_deg = -1;
     double lds_lnq = 0.0, lds_tab_tol = -1.0;
@@ -115,6 +116,12 @@ struct ggl_ctx {
                                                // (K=4: 4654 / 4892 vs 4602 / 4774 it/s; headline -6 %): opt-in, DESIGN 9.7
     int theta_flat = 2;                        // GGL Theta-step for symmetric states: 0 tile pairs, 1 per-element kernel, 2 per-element with the K-column over four waves
     bool state_symmetric = true;               // X and L exactly symmetric (checked when the state is set)
+    bool S_symmetric = false;                  // S exactly symmetric (checked by ggl_set_S)
+    // W of the next Omega-step written by this iteration's Theta kernel (GGL_OPT_FUSED_W, launch_theta_pair's WNext): valid for
+    // the early first part that follows in the same ggl_admm_step, built for wf_beta
+    bool fused_w = true, wf_ready = false;
+    double* wf_beta = nullptr;                 // host (K)
+    long long wf_written = 0, wf_used = 0;
     // speculative Omega-step: the schedule is built from the PREVIOUS iteration's spectral bounds (inflated) and the
     // products are launched without waiting for this iteration's bounds; a device-side check sets spec_flag when a
     // bound was exceeded, the state-changing kernels of the step then do nothing and the host repeats the step
@@ -186,6 +193,8 @@ struct ggl_ctx {
     double* Ckeep_beta = nullptr;              // host (K): mu1_k / rho of that step
     bool l_ns = false;                         // L is the sign iteration's (Ckeep valid); false once rebuilt / set / eigh route
     double* snapC = nullptr;                   // (K,p,p) snapshots of C, lazy
+    double* snapOm = nullptr;                  // (K,p,p) snapshots of Omega and X (ggl_snapshot_state_from), lazy
+    double* snapX = nullptr;
     double* snap_beta = nullptr;               // host (K)
     unsigned char* snap_ns = nullptr;          // host (K): snapshot k's L is a sign-iteration L (snapC_k, snap_beta[k] valid)
     long long finalize_calls = 0;              // eigendecompositions ggl_finalize_L ran
@@ -501,6 +510,7 @@ static int ctx_alloc(ggl_ctx* c)
         c->spec_beta = (double*)malloc(c->K * sizeof(double));
         c->pre_beta = (double*)malloc(c->K * sizeof(double));
         c->early.beta = (double*)malloc(c->K * sizeof(double));
+        c->wf_beta = (double*)malloc(c->K * sizeof(double));
         DEV(c->maxdev, 2 * c->K * sizeof(double));          // [K] residuals | [K] traces of the sign iterate
         PIN(c->maxdev_h, 2 * c->K * sizeof(double), 1);
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -591,8 +601,9 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_CHAIN: c->chain_mode = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
         case GGL_OPT_ISOLATE: c->isolate = v != 0.0; break;
         case GGL_OPT_FUSED_CW: c->fused_cw = v != 0.0; break;
-        case GGL_OPT_OMEGA_LDS: c->lds_omega = v != 0.0; break;
+        case GGL_OPT_OMEGA_LDS: c->lds_omega = v != 0.0; c->lds_waves = (v == 4.0 || v == 8.0) ? (int)v : 0; break;
         case GGL_OPT_EARLY_PART: c->early_part = v != 0.0; break;
+        case GGL_OPT_FUSED_W: c->fused_w = v != 0.0; break;
         case GGL_OPT_PART_PRIORITY: {
             if (v != 0.0 && v != 1.0 && v != 2.0) return fail(GGL_E_ARG, "bad argument: GGL_OPT_PART_PRIORITY is 0, 1 or 2");
             if (!c->omega_ns || (int)v == c->part_priority) break;
@@ -661,8 +672,9 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_RANK_L0_COARSE: *value = c->rank_l0_coarse; break;
         case GGL_OPT_ISOLATE: *value = c->isolate; break;
         case GGL_OPT_FUSED_CW: *value = c->fused_cw; break;
-        case GGL_OPT_OMEGA_LDS: *value = c->lds_omega; break;
+        case GGL_OPT_OMEGA_LDS: *value = c->lds_omega ? (c->lds_waves ? c->lds_waves : 1) : 0; break;
         case GGL_OPT_EARLY_PART: *value = c->early_part; break;
+        case GGL_OPT_FUSED_W: *value = c->fused_w; break;
         case GGL_OPT_PART_PRIORITY: *value = c->part_priority; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
@@ -744,7 +756,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     }
     // (the rocBLAS handle is the process-wide one of blas_handle(): never destroyed here)
     // lazily allocated buffers, each its own allocation
-    double* lazy[] = {c->partials_own, c->nsNX, c->lds_tab, c->snapT, c->snapL, c->Lam[0], c->Lam[1], c->X1, c->Ckeep_alloc, c->snapC, c->defl_G,
+    double* lazy[] = {c->partials_own, c->nsNX, c->lds_tab, c->snapT, c->snapL, c->Lam[0], c->Lam[1], c->X1, c->Ckeep_alloc, c->snapC, c->snapOm, c->snapX, c->defl_G,
                       c->defl_work, c->defl_meta, c->maskK};
     for (double* b : lazy)
         if (b) (void)hipFree(b);
@@ -763,6 +775,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     free(c->spec_beta);
     free(c->pre_beta);
     free(c->early.beta);
+    free(c->wf_beta);
     // everything ctx_alloc handed out: three allocations
     {
         void* ptr[3] = {c->arena_dev, c->arena_pin, c->arena_pin_coh};
@@ -855,6 +868,7 @@ static int upload_stack(ggl_ctx* c, double* dst, const double* src, int period)
     return GGL_OK;
 }
 
+static int host_reduce(ggl_ctx* c, int rows, int nv, double* out /*nv*/, bool take_max);
 extern "C" int ggl_set_S_ex(ggl_ctx* c, const double* S, int period)
 {
     ARGCHK(c && S, "ctx, S");
@@ -865,6 +879,14 @@ extern "C" int ggl_set_S_ex(ggl_ctx* c, const double* S, int period)
     int rc = upload_stack(c, c->S, S, period);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
+    // exact symmetry of S decides whether a Theta kernel may form the next W per element (GGL_OPT_FUSED_W)
+    launch_asym_max(c->stream, c->S, c->K, c->p, c->norms);
+    HIPCHK(hipGetLastError());
+    double asym = 1.0;
+    rc = host_reduce(c, c->K, 1, &asym, true);
+    if (rc) return rc;
+    c->S_symmetric = (asym == 0.0);
+    c->wf_ready = false;
     return GGL_OK;
 }
 
@@ -1120,6 +1142,7 @@ static constexpr int GGL_SPEC_RETRY = 1;     // internal: a speculative step fai
 static constexpr int GGL_NOT_LAUNCHED = 2;   // internal: omega_step(only_spec) found no speculative schedule and launched nothing
 static int omega_step(ggl_ctx* c, int latent, CopySegs* pending = nullptr, bool allow_spec = false, bool only_spec = false);
 static int maybe_early(ggl_ctx* c);
+static bool early_wanted(const ggl_ctx* c);
 
 extern "C" int ggl_step_omega(ggl_ctx* c, double rho, int latent, const double* nk)
 {
@@ -1243,6 +1266,10 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         // part in the stream, built for this beta, and adds the rest from the same plan
         const bool want_A = c->early_request;
         c->early_request = false;
+        // W already in place?  (written by the Theta kernel that precedes this early first part in the stream, for this beta)
+        bool w_ready = c->wf_ready && want_A && !latent;
+        for (int k = 0; w_ready && k < K; ++k) w_ready = (c->par_h[k] == c->wf_beta[k]);
+        c->wf_ready = false;
         bool resume = c->early.valid && allow_spec && !latent && !want_A && c->spec_enable;
         for (int k = 0; resume && k < K; ++k) resume = (c->par_h[k] == c->early.beta[k]);
         c->early.valid = false;
@@ -1332,7 +1359,8 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 PB(c, GGL_PH_EIG_OMEGA);
                 unsigned long long* cnt = (unsigned long long*)(c->lds_tab + (size_t)OMEGA_LDS_MAXTAB * OMEGA_LDS_ENT);
                 if (!launch_omega_lds(c->stream, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->Om[nxt], c->lds_tab,
-                                      c->lds_ntab, c->lds_lnq, K, c->p, c->spec_flag, c->spec_flag_h, 0, cnt, c->bounds_h))
+                                      c->lds_ntab, c->lds_lnq, K, c->p, c->spec_flag, c->spec_flag_h, 0, cnt, c->bounds_h, nullptr,
+                                      c->lds_waves))
                     return fail(GGL_E_HIP, "k_omega_lds: p = %d outside the kernel's range, or the LDS attribute was refused", c->p);
                 PE(c, GGL_PH_EIG_OMEGA);
                 HIPCHK(hipGetLastError());
@@ -1505,8 +1533,10 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             }
             launch_copy_small(sh, sg);
             if (h == 0) PB(c, GGL_PH_FORM_W);
-            launch_form_W_sym(sh, c->W + k0 * pp, c->Theta + k0 * pp, latent ? c->L + k0 * pp : nullptr, c->X + k0 * pp,
-                              c->S + k0 * pp, beta + k0, Kh[h], c->p);
+            if (!w_ready)
+                launch_form_W_sym(sh, c->W + k0 * pp, c->Theta + k0 * pp, latent ? c->L + k0 * pp : nullptr, c->X + k0 * pp,
+                                  c->S + k0 * pp, beta + k0, Kh[h], c->p);
+            else if (h == 0) c->wf_used += 1;
             const bool early_ev = want_A && h == 0 && c->prof_on == 2;
             if (early_ev) {
                 c->ev_early_par ^= 1;
@@ -2131,9 +2161,19 @@ static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double l
         if (groupsq_ready && c->omega_ns) c->sharded_check = true;
         // the flat GGL kernel computes every (i,j) from its own inputs: only for an exactly symmetric state
         const int flat = (c->theta_flat && c->state_symmetric) ? c->theta_flat : 0;
+        // the early first part of the next chain will follow (same conditions as maybe_early): let the kernel write that
+        // chain's W = Theta - X - beta S itself -- beta is this iteration's, which is what the early part assumes
+        WNext wn;
+        int wn_done = 0;
+        if (c->fused_w && !latent && !groupsq_ready && reg == GGL_REG_GGL && flat && c->S_symmetric && early_wanted(c)) {
+            wn.S = c->S;
+            wn.beta = c->par;
+        }
         HIPCHK(launch_theta_pair(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, l1, l2,
                                  groupsq_ready ? c->groupsq : nullptr, c->sqwork, latent ? 0 : 1, c->partials, c->K,
-                                 c->p, flat, (c->spec_pending || c->sharded_check) ? c->spec_flag : nullptr));
+                                 c->p, flat, (c->spec_pending || c->sharded_check) ? c->spec_flag : nullptr, wn, &wn_done));
+        c->wf_ready = wn_done != 0;
+        if (c->wf_ready) { memcpy(c->wf_beta, c->par_h, c->K * sizeof(double)); c->wf_written += 1; }
         PE(c, GGL_PH_THETA);
         if (!latent) {
             PB(c, GGL_PH_REDUCE);
@@ -2187,12 +2227,18 @@ extern "C" int ggl_norms_read(ggl_ctx* c, double out_norms[5])
 // Early first part of the NEXT iteration's chain (ggl_ctx::EarlyA), called with this iteration's Theta-step and reduction in the
 // stream and the host about to wait for them.  Launched on a prediction -- the last iteration's residual ratio was calm, so
 // the rho rule will very likely keep rho -- and forgotten if the prediction fails (cost: ~0.2 ms of device time).
-static int maybe_early(ggl_ctx* c)
+static bool early_wanted(const ggl_ctx* c)
 {
     if (!c->early_caller || !c->early_part || !c->pipeline || !c->omega_ns || !c->spec_enable || c->prof_on == 1 || c->last_step_hint || !c->ratio_calm ||
         c->chain_mode || c->pre_valid)
-        return GGL_OK;
-    if (c->lds_omega && c->p <= omega_lds_max_p()) return GGL_OK;      // (one kernel writes Omega there: nothing to split)
+        return false;
+    if (c->lds_omega && c->p <= omega_lds_max_p()) return false;       // (one kernel writes Omega there: nothing to split)
+    return true;
+}
+
+static int maybe_early(ggl_ctx* c)
+{
+    if (!early_wanted(c)) return GGL_OK;
     c->early_request = true;
     const int rc = omega_step(c, 0, nullptr, /*allow_spec=*/true, /*only_spec=*/true);
     c->early_request = false;
@@ -2546,73 +2592,116 @@ static void batch_marks(ggl_ctx* c, int n, int group, unsigned char* marked)
 // Up to n_iters iterations of ggl_sgl_batch_step with everything the host loop of gglasso_amd.batch.ADMM_SGL_batch does between
 // two of them -- per-point stopping test, rho rule, X rescale (single_admm_solver.py:186-214; the grid walk it serves:
 // helper/model_selection.py:619-633) -- done here, per iteration a loop over the K points instead of a Python round trip
-// (~100 us where the device needs 50 us at p <= 64).  Returns after the first iteration in which any live point converges
-// or fails (the caller snapshots / parks / compacts and calls again) or after n_iters; the return value is the number of
-// iterations run (>= 1), < 0 on error.
-//   rho (K) in/out;  done (K) 0/1: points that are finished (dragged along, no decisions);  dims (K): (p_k^2 + p_k) / 2;
-//   last (K,4), status (K): as ggl_batch_decide, of the LAST iteration run.
-extern "C" int ggl_sgl_batch_run(ggl_ctx* c, int n_iters, double* rho, const double* lambda1, int latent, const double* mu1,
-                                 const double* dims, double tol, double rtol, int update_rho, const unsigned char* done,
-                                 double* last, int* status)
+// (~100 us where the device needs 50 us at p <= 64).
+//   rho (K) in/out;  dims (K): (p_k^2 + p_k) / 2;  status (K) in/out: 0 live, 1 converged, 2 failed -- points that are not 0
+//   on entry are finished (dragged along, no decisions);  last (K,4) in/out: {r_t, s_t, e_pri, e_dual} of the last
+//   iteration a point was live in;  fin_iter (K) in/out: for a point that finishes during this call, it_base + the
+//   iteration of this call it finished in (1-based).
+//   snap_ctx == NULL: returns after the first iteration in which a live point converges or fails (the caller collects it).
+//   snap_ctx != NULL (may be ctx itself; snap_index (K): the slot in snap_ctx of every slot of ctx): a point that finishes
+//   is snapshotted there on the device (ggl_snapshot_state_from: Omega, Theta, L, X at that iteration, after the X rescale
+//   -- single_admm_solver.py:205 comes before the break), a failed one is then parked on the identity problem
+//   (ggl_reset_instance), and the loop goes on; it returns when every point is finished, when at least stop_after points
+//   are (stop_after > 0: the caller may want to compact the batch) or after n_iters.
+// Returns the number of iterations run (>= 1), < 0 on error.
+struct BatchRun {
+    int n, group;                  // points, instances per point
+    double* rho; const double* dims; double tol, rtol; int update_rho;
+    double* last; int* status; int* fin_iter; int it_base;
+    ggl_ctx* snap_ctx; const int* snap_index; int stop_after;
+};
+
+// after one iteration's step (sums in sq): decisions, rescale, snapshots; *stop = the call should return now
+static int batch_after_step(ggl_ctx* c, const BatchRun& b, const double* sq, int it, bool last_iter, bool* stop)
 {
-    ARGCHK(c && rho && lambda1 && dims && done && last && status, "ctx, rho, lambda1, dims, done, last, status");
+    std::vector<double> fac(b.n);
+    std::vector<unsigned char> live(b.n), marked(b.n);
+    std::vector<int> ev(b.n);
+    for (int g = 0; g < b.n; ++g) live[g] = b.status[g] == 0 ? 1 : 0;
+    batch_marks(c, b.n, b.group, marked.data());
+    const int events = ggl_batch_decide(b.n, sq, live.data(), marked.data(), b.rho, b.dims, b.tol, b.rtol, b.update_rho, b.last,
+                                        fac.data(), ev.data());
+    if (events < 0) return events;
+    int rc = batch_rescale(c, fac.data(), b.n, b.group);
+    if (rc) return rc;
+    int finished = 0;
+    for (int g = 0; g < b.n; ++g) {
+        if (ev[g] != 0) {
+            b.status[g] = ev[g];
+            b.fin_iter[g] = b.it_base + it + 1;
+            if (b.snap_ctx) {
+                for (int k = 0; k < b.group; ++k) {
+                    const int s = g * b.group + k;
+                    rc = ggl_snapshot_state_from(b.snap_ctx, b.snap_index[s], c, s);
+                    if (rc) return rc;
+                }
+                if (ev[g] == 2)
+                    for (int k = 0; k < b.group; ++k) {
+                        rc = ggl_reset_instance(c, g * b.group + k);
+                        if (rc) return rc;
+                    }
+            }
+        }
+        finished += b.status[g] != 0 ? 1 : 0;
+    }
+    *stop = last_iter || finished == b.n || (events > 0 && (!b.snap_ctx || (b.stop_after > 0 && finished >= b.stop_after)));
+    if (*stop) HIPCHK(hipStreamSynchronize(c->stream));       // (the caller reads the state / rewrites the pinned slots next)
+    return GGL_OK;
+}
+
+extern "C" int ggl_sgl_batch_run(ggl_ctx* c, int n_iters, double* rho, const double* lambda1, int latent, const double* mu1,
+                                 const double* dims, double tol, double rtol, int update_rho, double* last, int* status,
+                                 int* fin_iter, int it_base, ggl_ctx* snap_ctx, const int* snap_index, int stop_after)
+{
+    ARGCHK(c && rho && lambda1 && dims && last && status && fin_iter, "ctx, rho, lambda1, dims, last, status, fin_iter");
     ARGCHK(n_iters >= 1, "n_iters >= 1");
     ARGCHK(!latent || mu1, "latent needs mu1");
+    ARGCHK(!snap_ctx || snap_index, "snapshots need the destination slots");
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
     const int K = c->K;
-    std::vector<double> sq((size_t)K * GGL_NNORM), fac(K);
-    std::vector<unsigned char> live(K), marked(K);
-    for (int k = 0; k < K; ++k) live[k] = done[k] ? 0 : 1;
+    const BatchRun b = {K, 1, rho, dims, tol, rtol, update_rho, last, status, fin_iter, it_base, snap_ctx, snap_index, stop_after};
+    std::vector<double> sq((size_t)K * GGL_NNORM);
     for (int it = 0; it < n_iters; ++it) {
         int rc = sgl_batch_step_impl(c, rho, lambda1, latent, mu1, sq.data());
         if (rc) return rc;
-        batch_marks(c, K, 1, marked.data());
-        const int events = ggl_batch_decide(K, sq.data(), live.data(), marked.data(), rho, dims, tol, rtol, update_rho, last,
-                                            fac.data(), status);
-        if (events < 0) return events;
-        rc = batch_rescale(c, fac.data(), K, 1);
+        bool stop = false;
+        rc = batch_after_step(c, b, sq.data(), it, it == n_iters - 1, &stop);
         if (rc) return rc;
-        if (events > 0 || it == n_iters - 1) {
-            HIPCHK(hipStreamSynchronize(c->stream));       // (the caller reads the state / rewrites the pinned slots next)
-            return it + 1;
-        }
+        if (stop) return it + 1;
     }
     return n_iters;
 }
 
 // The same for G multiple-graph problems in one stack (ggl_mgl_batch_step; admm_solver.py:215-237, the grid walk
-// helper/model_selection.py:208-224).  rho, lambda1, lambda2, dims, done, status: (G); last (G,4).
+// helper/model_selection.py:208-224).  rho, lambda1, lambda2, dims, status, fin_iter: (G); last (G,4); snap_index: (K)
+// per INSTANCE slot.
 extern "C" int ggl_mgl_batch_run(ggl_ctx* c, int G, int n_iters, double* rho, const double* lambda1, const double* lambda2,
                                  int reg, int latent, const double* mu1, const double* nk, const double* dims, double tol,
-                                 double rtol, int update_rho, const unsigned char* done, double* last, int* status)
+                                 double rtol, int update_rho, double* last, int* status, int* fin_iter, int it_base,
+                                 ggl_ctx* snap_ctx, const int* snap_index, int stop_after)
 {
-    ARGCHK(c && rho && lambda1 && lambda2 && dims && done && last && status, "ctx, rho, lambda1, lambda2, dims, done, last, status");
+    ARGCHK(c && rho && lambda1 && lambda2 && dims && last && status && fin_iter,
+           "ctx, rho, lambda1, lambda2, dims, last, status, fin_iter");
     ARGCHK(n_iters >= 1, "n_iters >= 1");
     ARGCHK(reg == GGL_REG_GGL || reg == GGL_REG_FGL, "reg");
     ARGCHK(G >= 1 && c->K % G == 0, "the ctx holds G problems of K/G instances each");
     ARGCHK(!latent || mu1, "latent needs mu1");
+    ARGCHK(!snap_ctx || snap_index, "snapshots need the destination slots");
     ARGCHK(c->state_symmetric, "the batched Theta-step needs exactly symmetric dual / latent start points");
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
-    const int Kp = c->K / G;
-    std::vector<double> sq((size_t)G * GGL_NNORM), fac(G);
-    std::vector<unsigned char> live(G), marked(G);
-    for (int g = 0; g < G; ++g) live[g] = done[g] ? 0 : 1;
+    const BatchRun b = {G, c->K / G, rho, dims, tol, rtol, update_rho, last, status, fin_iter, it_base, snap_ctx, snap_index,
+                        stop_after};
+    std::vector<double> sq((size_t)G * GGL_NNORM);
     for (int it = 0; it < n_iters; ++it) {
         int rc = mgl_batch_step_impl(c, G, rho, lambda1, lambda2, reg, latent, mu1, nk, sq.data());
         if (rc > 0) return fail(GGL_E_SOLVER, "batched MGL step: speculative step rejected twice");
         if (rc) return rc;
-        batch_marks(c, G, Kp, marked.data());
-        const int events = ggl_batch_decide(G, sq.data(), live.data(), marked.data(), rho, dims, tol, rtol, update_rho, last,
-                                            fac.data(), status);
-        if (events < 0) return events;
-        rc = batch_rescale(c, fac.data(), G, Kp);
+        bool stop = false;
+        rc = batch_after_step(c, b, sq.data(), it, it == n_iters - 1, &stop);
         if (rc) return rc;
-        if (events > 0 || it == n_iters - 1) {
-            HIPCHK(hipStreamSynchronize(c->stream));
-            return it + 1;
-        }
+        if (stop) return it + 1;
     }
     return n_iters;
 }
@@ -2690,7 +2779,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->symm_variant = src->symm_variant; c->spin_wait = src->spin_wait; c->fused_bounds = src->fused_bounds;
     c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->ns_tol = src->ns_tol;
     c->cw_warm = src->cw_warm; c->chain_mode = src->chain_mode; c->rank_l0 = src->rank_l0; c->rank_l0_coarse = src->rank_l0_coarse;
-    c->isolate = src->isolate; c->fused_cw = src->fused_cw; c->lds_omega = src->lds_omega; c->early_part = src->early_part; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
+    c->isolate = src->isolate; c->fused_cw = src->fused_cw; c->lds_omega = src->lds_omega; c->lds_waves = src->lds_waves; c->early_part = src->early_part; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
     int* didx = nullptr;
     hipError_t e = hipMalloc(&didx, m * sizeof(int));
     if (e == hipSuccess) e = hipMemcpyAsync(didx, idx, m * sizeof(int), hipMemcpyHostToDevice, src->stream);
@@ -2701,6 +2790,8 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     for (int i = 0; i < 6; ++i) launch_copy_instances(src->stream, to[i], from[i], didx, m, pp, false);
     c->cur = 0;
     c->state_symmetric = src->state_symmetric;
+    c->S_symmetric = src->S_symmetric;
+    c->fused_w = src->fused_w;
     c->step_latent = src->step_latent;
     c->nk_valid = false;
     if (src->l_ns && src->Ckeep && src->Ckeep_beta) {
@@ -2810,7 +2901,7 @@ extern "C" int ggl_lds_stats(ggl_ctx* c, long long out[4])
 // Pipelining across iterations (GGL_OPT_PIPELINE): { whole chains launched ahead of the caller's next step, of those forgotten
 // (rho changed), early first parts put into the stream before the wait for the residuals, of those continued, fresh streams the
 // concurrency probe of the part streams had to try (0: the part stream ran beside the main stream; -1: not probed yet) }
-extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[5])
+extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[7])
 {
     ARGCHK(c && out, "ctx, out");
     out[0] = c->pre_launched;
@@ -2818,6 +2909,8 @@ extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[5])
     out[2] = c->early_launched;
     out[3] = c->early_used;
     out[4] = c->parts_probed ? c->parts_replaced : -1;
+    out[5] = c->wf_written;
+    out[6] = c->wf_used;
     return GGL_OK;
 }
 
@@ -3053,6 +3146,49 @@ extern "C" int ggl_snapshot_from(ggl_ctx* c, int kd, ggl_ctx* src, int ks)
 }
 
 extern "C" int ggl_snapshot_k(ggl_ctx* c, int k) { return ggl_snapshot_from(c, k, c, k); }
+
+// ggl_snapshot_from plus Omega and X of the instance: the WHOLE solution of a point of a batch stays on the device at the
+// iteration it finished, and the batch driver fetches all points' solutions at the end with ONE download per stack
+// (ggl_get_snapshots) instead of three or four small ones per point (~40 us each: 4 ms of a 9 ms 100-point grid).
+extern "C" int ggl_snapshot_state_from(ggl_ctx* c, int kd, ggl_ctx* src, int ks)
+{
+    ARGCHK(c && src, "ctx");
+    ARGCHK(kd >= 0 && kd < c->K && ks >= 0 && ks < src->K, "instance index");
+    ARGCHK(c->p == src->p && c->device == src->device, "snapshot between ctxs of different dimension / device");
+    HIPCHK(hipSetDevice(c->device));
+    for (double** b : {&c->snapOm, &c->snapX}) {
+        if (!*b) {
+            HIPCHK(hipMalloc(b, c->n * sizeof(double)));
+            HIPCHK(hipMemsetAsync(*b, 0, c->n * sizeof(double), c->stream));
+        }
+    }
+    const size_t pp = (size_t)c->p * c->p, nb = pp * sizeof(double);
+    if (src != c) {
+        int rc_ = drop_prelaunch(src);
+        if (rc_) return rc_;
+        HIPCHK(hipStreamSynchronize(src->stream));          // the copies below run on c's stream
+    }
+    HIPCHK(hipMemcpyAsync(c->snapOm + kd * pp, src->Om[src->cur] + ks * pp, nb, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->snapX + kd * pp, src->X + ks * pp, nb, hipMemcpyDeviceToDevice, c->stream));
+    return ggl_snapshot_from(c, kd, src, ks);
+}
+
+/* whole snapshot stacks (K,p,p), any may be null: Omega, Theta, L, X as ggl_snapshot_state_from left them */
+extern "C" int ggl_get_snapshots(ggl_ctx* c, double* Omega, double* Theta, double* L, double* X)
+{
+    ARGCHK(c, "ctx");
+    ARGCHK(!Theta || c->snapT, "no snapshot taken");
+    ARGCHK((!Omega && !X) || (c->snapOm && c->snapX), "no state snapshot taken (ggl_snapshot_state_from)");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nb = c->n * sizeof(double);
+    if (Omega) HIPCHK(hipMemcpyAsync(Omega, c->snapOm, nb, hipMemcpyDeviceToHost, c->stream));
+    if (Theta) HIPCHK(hipMemcpyAsync(Theta, c->snapT, nb, hipMemcpyDeviceToHost, c->stream));
+    if (L && c->snapL) HIPCHK(hipMemcpyAsync(L, c->snapL, nb, hipMemcpyDeviceToHost, c->stream));
+    else if (L) memset(L, 0, nb);          // no latent step ever ran: L is what the solvers return then, zeros (admm_solver.py:150)
+    if (X) HIPCHK(hipMemcpyAsync(X, c->snapX, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GGL_OK;
+}
 
 // The latent component a solve returns (solver/ggl_helper.py:29-36: L = Q diag(max(d - beta, 0)) Q^T, whose null space is
 // exact to rounding -- the reference's callers apply numpy.linalg.matrix_rank to it, helper/model_selection.py:254, :638).
@@ -4211,6 +4347,9 @@ extern "C" int ggl_dev_omega_lds(int K, int p, const double* Theta, const double
 {
     ARGCHK(K >= 1 && p >= 1 && Theta && X && S && beta && Omega && iters >= 1 && out, "arguments");
     ARGCHK(p <= omega_lds_max_p(), "p above the LDS-resident kernel's range");
+    const int waves = degrees / 1000;             // degrees + 1000 * waves: 4 or 8 waves per workgroup (0: by size)
+    degrees %= 1000;
+    ARGCHK(waves == 0 || waves == 4 || waves == 8, "waves per workgroup: 4 or 8");
     const size_t n = (size_t)K * p * p;
     std::vector<double> tab((size_t)OMEGA_LDS_MAXTAB * OMEGA_LDS_ENT);
     double lnq = 0.0;
@@ -4229,11 +4368,11 @@ extern "C" int ggl_dev_omega_lds(int K, int p, const double* Theta, const double
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     bool ok = launch_omega_lds(nullptr, dT.p, L ? dL.p : nullptr, dX.p, dS.p, dB.p, dO.p, dTab.p, ntab, lnq, K, p, flag,
-                               flag_h, 0, units, dC.p);
+                               flag_h, 0, units, dC.p, nullptr, waves);
     (void)hipEventRecord(e0, nullptr);
     for (int i = 0; ok && i < iters; ++i)
         launch_omega_lds(nullptr, dT.p, L ? dL.p : nullptr, dX.p, dS.p, dB.p, dO.p, dTab.p, ntab, lnq, K, p, flag, flag_h, 0,
-                         nullptr, dC.p, (long long*)(dMisc.p + 4));
+                         nullptr, dC.p, (long long*)(dMisc.p + 4), waves);
     (void)hipEventRecord(e1, nullptr);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;

@@ -95,10 +95,16 @@ int theta_partial_blocks(int p, int reg, int K, int flat, int G = 1);      // G:
 // alone) as sum_k u^2 instead of computing it (K-sharded).
 // Returns hipErrorInvalidValue if K is beyond what the FGL kernel's LDS scan buffer holds.
 // sqwork: ggl_chunks(K,p)*p*p doubles of scratch for the GGL sums of squares (unused when groupsq is given).
+// wn (fuse_dual, GGL, per-element kernels only): S and beta_k of the NEXT Omega-step -- the kernel then also writes
+// C = (Theta_new - X_new) - beta_k S, that step's W (admm_solver.py:180; k_form_W_sym's arithmetic per element, which equals
+// its "lower triangle, mirrored" for a bitwise symmetric state and S), saving the k_form_W_sym pass and launch;
+// *wn_done = 1 when the launched kernel wrote it.
+struct WNext { const double* S = nullptr; const double* beta = nullptr; };
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C,
                              const double* Omega, const double* OmegaPrev, const double* L,
                              double l1, double l2, const double* groupsq, double* sqwork, int fuse_dual,
-                             double* partials, int K, int p, int flat = 0, const int* skip = nullptr);
+                             double* partials, int K, int p, int flat = 0, const int* skip = nullptr, WNext wn = WNext(),
+                             int* wn_done = nullptr);
 // largest K the FGL Theta-step kernel serves (K-vectors of an 8x8 tile pair in one workgroup's LDS)
 int fgl_max_K();
 // G independent problems of K instances each in one launch: stacks (G*K,p,p), thresholds of problem g at l1G[g*K] /
@@ -180,7 +186,8 @@ int omega_lds_max_p();
 int omega_lds_build_table(double tol, int degrees, double* table_h, int max_entries, double* lnq_out);
 bool launch_omega_lds(hipStream_t st, const double* Theta, const double* L, const double* X, const double* S, const double* betaK,
                       double* Omega, const double* table, int ntab, double lnq, int K, int p, int* flag,
-                      int* flag_host, int flag_slot, unsigned long long* units, double* cbound, long long* dbg = nullptr);
+                      int* flag_host, int flag_slot, unsigned long long* units, double* cbound, long long* dbg = nullptr,
+                      int waves = 0);
 // gemm_i8.hip: error-free split products on the INT8 matrix cores
 void launch_slice_i8(hipStream_t st, const double* A, const double* scaleK, int8_t* out, int K, int p, int S, int* flag,
                      size_t sstride = 0);

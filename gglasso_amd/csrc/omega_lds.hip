@@ -31,7 +31,6 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 template <int PT> struct LdsDim {
     static constexpr int LD = PT + 1, NB = PT / 16;
     static constexpr int NE = (PT / 2) * (PT + 1);          // elements of the lower triangle incl. the diagonal
-    static constexpr int NIT = (NE + 255) / 256;            // ... per thread
 };
 
 // element e of the lower triangle, rows folded in pairs (row r with row PT-1-r: PT+1 elements per pair, row-contiguous)
@@ -44,19 +43,23 @@ __device__ __forceinline__ void tri_index(int e, int& i, int& j)
 }
 
 // out = cI I + cA (A B) + cE E for commuting symmetric A, B (and symmetric E) in LDS, all zero beyond p; only the upper 16 x 16
-// blocks are computed (dealt over the four waves) and mirrored.  A wave works through its blocks one after the other and
-// spreads the epilogue of block s (accumulator reads, affine combination, the stores of the block and of its mirror image)
-// over the first k-steps of block s+1: a wave64 vector instruction takes 4 cycles and there are ~150 of them per block, which
-// next to a 1.6 us matrix phase cost 1.1 us when they ran after it; under the matrix instructions of the next block (64 cycles
-// each, 56 of them free for the vector unit) only the last block's epilogue is exposed.
+// blocks are computed (dealt over the NW waves: block w, w + NW, ...) and mirrored.  A wave works through its blocks one
+// after the other and spreads the epilogue of block s (accumulator reads, affine combination, the stores of the block and of
+// its mirror image) over the first k-steps of block s+1: a wave64 vector instruction takes 4 cycles and there are ~150 of
+// them per block, which next to a 1.6 us matrix phase cost 1.1 us when they ran after it; under the matrix instructions of
+// the next block (64 cycles each, 56 of them free for the vector unit) only the last block's epilogue is exposed.
+// NW = 8 (round 5): TWO waves per SIMD -- ten blocks at PT = 64 are 2/2/1/1/1/1/1/1, i.e. the same three blocks on the busiest
+// SIMD as with four waves (3/3/2/2), but what a lone wave exposes (the last block's epilogue, the first fragments' LDS
+// latency, the barrier) now runs under the other wave's matrix instructions; a wave without a block in a slot issues nothing
+// there (with four waves it multiplied a dummy block, which two waves per SIMD would pay for).
 // ALIAS: out is one of the operands -- every value is kept in registers until all waves have finished reading.
-template <int PT, bool ALIAS>
+template <int PT, bool ALIAS, int NW>
 __device__ __forceinline__ void lds_symm(const double* A, const double* B, double* out, double cI, double cA, const double* E,
                                          double cE, int p, long long* ts = nullptr)
 {
     if (ts && threadIdx.x == 0) ts[0] = (long long)wall_clock64();
     constexpr int LD = LdsDim<PT>::LD, NB = LdsDim<PT>::NB, NPAIR = NB * (NB + 1) / 2;
-    constexpr int MAXB = (NPAIR + 3) / 4;
+    constexpr int MAXB = (NPAIR + NW - 1) / NW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fk = lane >> 4;
     constexpr int KS = PT / 4, NT = MAXB * KS, D = 4, RING = 8;      // fragments are read D k-steps ahead: the LDS latency is
@@ -70,7 +73,7 @@ __device__ __forceinline__ void lds_symm(const double* A, const double* B, doubl
     int Ib[MAXB], Jb[MAXB];
 #pragma unroll
     for (int s = 0; s < MAXB; ++s) {
-        int pr = wave + 4 * s, I = -1, J = 0;
+        int pr = wave + NW * s, I = -1, J = 0;
         if (pr < NPAIR) {
             I = 0;
             while (pr >= NB - I) { pr -= NB - I; ++I; }
@@ -78,7 +81,8 @@ __device__ __forceinline__ void lds_symm(const double* A, const double* B, doubl
         }
         Ib[s] = I; Jb[s] = J;
         ap[s] = A + fk * LD + 16 * max(I, 0) + fr;       // a(i, k) = A[k][i] (symmetric): lanes of a k-row read contiguously
-        bp[s] = B + fk * LD + 16 * J + fr;               // (an idle slot multiplies block (0,0) into an accumulator nobody reads)
+        bp[s] = B + fk * LD + 16 * J + fr;
+        if (ALIAS) krmax[s] = -1;
     }
     // register r of the finished block (C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg)
     auto epilogue = [&](int sdone, int r) {
@@ -91,32 +95,46 @@ __device__ __forceinline__ void lds_symm(const double* A, const double* B, doubl
         }
     };
     double af[RING], bf[RING];
+    // (a wave's idle slots are its LAST ones: Ib[s] < 0 implies Ib[s+1] < 0; the conditions below are wave-uniform)
 #pragma unroll
-    for (int t = 0; t < D && t < NT; ++t) { af[t] = ap[t / KS][(t % KS) * 4 * LD]; bf[t] = bp[t / KS][(t % KS) * 4 * LD]; }
+    for (int t = 0; t < D && t < NT; ++t)
+        if (Ib[t / KS] >= 0) { af[t] = ap[t / KS][(t % KS) * 4 * LD]; bf[t] = bp[t / KS][(t % KS) * 4 * LD]; }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int s = t / KS, kq = t % KS;
-        if (t + D < NT) {
-            af[(t + D) % RING] = ap[(t + D) / KS][((t + D) % KS) * 4 * LD];
-            bf[(t + D) % RING] = bp[(t + D) / KS][((t + D) % KS) * 4 * LD];
-        }
-        if (kq == 0) acc = (v4d){0.0, 0.0, 0.0, 0.0};
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t % RING], bf[t % RING], acc, 0, 0, 0);
-        if (s > 0 && kq < 4) epilogue(s - 1, kq);
-        if (kq == KS - 1) {
-            const int I = Ib[s], J = Jb[s];
-            pacc = acc;
-            pij = (16 * max(I, 0) + fk) * LD + 16 * J + fr;
-            pji = (16 * J + fr) * LD + 16 * max(I, 0) + fk;
-            // diagonal blocks: the registers with row <= col are stored (and mirrored), one of them holds the diagonal element
-            const int dr = fr - fk;
-            prmax = (I < 0) ? -1 : ((I != J) ? 3 : (dr >= 0 ? (dr >> 2) : -1));
-            prd = (I == J && dr >= 0 && (dr & 3) == 0 && 16 * I + fr < p) ? (dr >> 2) : -1;
-            if (ALIAS) { kij[s] = pij; kji[s] = pji; krmax[s] = prmax; }
+        if (Ib[s] >= 0) {
+            if (t + D < NT && Ib[(t + D) / KS] >= 0) {
+                af[(t + D) % RING] = ap[(t + D) / KS][((t + D) % KS) * 4 * LD];
+                bf[(t + D) % RING] = bp[(t + D) / KS][((t + D) % KS) * 4 * LD];
+            }
+            if (kq == 0) acc = (v4d){0.0, 0.0, 0.0, 0.0};
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t % RING], bf[t % RING], acc, 0, 0, 0);
+            if (s > 0 && kq < 4) epilogue(s - 1, kq);
+            if (kq == KS - 1) {
+                const int I = Ib[s], J = Jb[s];
+                pacc = acc;
+                pij = (16 * I + fk) * LD + 16 * J + fr;
+                pji = (16 * J + fr) * LD + 16 * I + fk;
+                // diagonal blocks: the registers with row <= col are stored (and mirrored), one of them holds the diagonal element
+                const int dr = fr - fk;
+                prmax = (I != J) ? 3 : (dr >= 0 ? (dr >> 2) : -1);
+                prd = (I == J && dr >= 0 && (dr & 3) == 0 && 16 * I + fr < p) ? (dr >> 2) : -1;
+                if (ALIAS) { kij[s] = pij; kji[s] = pji; krmax[s] = prmax; }
+            }
         }
     }
+    // the last block this wave computed (slot MAXB - 1, or an earlier one when its last slots are idle)
+    {
+        int slast = -1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) epilogue(MAXB - 1, r);
+        for (int s = 0; s < MAXB; ++s) if (Ib[s] >= 0) slast = s;
+#pragma unroll
+        for (int s = 0; s < MAXB; ++s)
+            if (s == slast) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) epilogue(s, r);
+            }
+    }
     if (ALIAS) {
         __syncthreads();
 #pragma unroll
@@ -130,8 +148,8 @@ __device__ __forceinline__ void lds_symm(const double* A, const double* B, doubl
 }
 
 // table entry: { n, deg[OMEGA_LDS_MAXSTEP], (pad to 8), coef[OMEGA_LDS_MAXSTEP][6] = {t0..t4, l_after} } = OMEGA_LDS_ENT doubles
-template <int PT>
-__global__ __launch_bounds__(256) void k_omega_lds(const double* __restrict__ Theta, const double* __restrict__ Lm,
+template <int PT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_omega_lds(const double* __restrict__ Theta, const double* __restrict__ Lm,
                                                    const double* __restrict__ X, const double* __restrict__ S,
                                                    const double* __restrict__ betaK, double* __restrict__ Omega,
                                                    const double* __restrict__ table, int ntab,
@@ -139,7 +157,7 @@ __global__ __launch_bounds__(256) void k_omega_lds(const double* __restrict__ Th
                                                    int flag_slot, unsigned long long* __restrict__ units,
                                                    double* __restrict__ cbound, long long* __restrict__ dbg)
 {
-    constexpr int LD = LdsDim<PT>::LD, NE = LdsDim<PT>::NE, NIT = LdsDim<PT>::NIT;
+    constexpr int LD = LdsDim<PT>::LD, NE = LdsDim<PT>::NE, NTH = 64 * NW, NIT = (NE + NTH - 1) / NTH;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* b0 = lds;
     double* b1 = b0 + PT * LD;
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(256) void k_omega_lds(const double* __restrict__ Th
     double* b3 = b2 + PT * LD;
     double* vec = b3 + PT * LD;              // [PT] row sums
     double* sh = vec + PT;                   // [8]
-    double* part = sh + 8;                   // [2][256] partial column sums
+    double* part = sh + 8;                   // [2][NTH] partial column sums
     const int k = blockIdx.x, tid = threadIdx.x;
 #define GGL_TS(i) do { if (dbg && k == 0 && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
     GGL_TS(0);
@@ -162,8 +180,8 @@ __global__ __launch_bounds__(256) void k_omega_lds(const double* __restrict__ Th
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int i, j;
-            tri_index<PT>(tid + 256 * it, i, j);
-            const bool in = (tid + 256 * it) < NE && i < p;
+            tri_index<PT>(tid + NTH * it, i, j);
+            const bool in = (tid + NTH * it) < NE && i < p;
             const size_t o = off + (size_t)i * p + j;
             th[it] = in ? Theta[o] : 0.0;
             ll[it] = (in && Lm) ? Lm[o] : 0.0;
@@ -173,37 +191,37 @@ __global__ __launch_bounds__(256) void k_omega_lds(const double* __restrict__ Th
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int i, j;
-            tri_index<PT>(tid + 256 * it, i, j);
+            tri_index<PT>(tid + NTH * it, i, j);
             double t = th[it];
             if (Lm) t -= ll[it];
             wreg[it] = (t - xx[it]) - beta * ss[it];
-            if (tid + 256 * it < NE) { b0[i * LD + j] = wreg[it]; b0[j * LD + i] = wreg[it]; }
+            if (tid + NTH * it < NE) { b0[i * LD + j] = wreg[it]; b0[j * LD + i] = wreg[it]; }
         }
     }
     __syncthreads();
     GGL_TS(1);
     // A' = W W + 4 beta I -> b1;  B' = A' A' -> b2
-    lds_symm<PT, false>(b0, b0, b1, 4.0 * beta, 1.0, nullptr, 0.0, p, (dbg && k == 0) ? dbg + 10 : nullptr);
+    lds_symm<PT, false, NW>(b0, b0, b1, 4.0 * beta, 1.0, nullptr, 0.0, p, (dbg && k == 0) ? dbg + 10 : nullptr);
     GGL_TS(2);
-    lds_symm<PT, false>(b1, b1, b2, 0.0, 1.0, nullptr, 0.0, p);
+    lds_symm<PT, false, NW>(b1, b1, b2, 0.0, 1.0, nullptr, 0.0, p);
     GGL_TS(3);
     // the bound: row sums d, |B'|_inf, |B'|_F^2, Collatz-Wielandt ratio max_i (|B'| d)_i / d_i.  B' is symmetric: a thread walks
     // down a COLUMN (lanes on consecutive columns: conflict-free), NQ threads per column; the PT column totals are finished by
     // the first PT threads, which all sit in wave 0 (PT <= 64), so each block-wide reduction is one shuffle chain.
     double fro, inf;
     {
-        constexpr int NQ = 256 / PT;
+        constexpr int NQ = 256 / PT;          // (not NTH / PT: the order of these sums must not depend on the number of waves)
         const int col = tid % PT, q = tid / PT;
         double s1 = 0.0, s2 = 0.0;
         if (q < NQ)
             for (int j = q; j < PT; j += NQ) { const double x = b2[j * LD + col]; s1 += fabs(x); s2 += x * x; }
         part[tid] = s1;
-        part[256 + tid] = s2;
+        part[NTH + tid] = s2;
         __syncthreads();
         if (tid < 64) {
             double d = 0.0, f = 0.0;
             if (tid < PT)
-                for (int qq = 0; qq < NQ; ++qq) { d += part[qq * PT + tid]; f += part[256 + qq * PT + tid]; }
+                for (int qq = 0; qq < NQ; ++qq) { d += part[qq * PT + tid]; f += part[NTH + qq * PT + tid]; }
             if (tid < PT) vec[tid] = d;
             const double dm = wave_max(d), fs = wave_sum(f);
             if (tid == 0) { sh[0] = dm; sh[1] = fs; }
@@ -256,20 +274,20 @@ __global__ __launch_bounds__(256) void k_omega_lds(const double* __restrict__ Th
         // T1 into B''s buffer
         if (d0 == 9) {
             // U = t2 I + (t3/c) A' + (t4/c^2) B' -> f0 (elementwise), T1 = t0 I + (t1/c) A' + (U B') / c^2 -> f1
-            for (int e = tid; e < PT * PT; e += 256) {
+            for (int e = tid; e < PT * PT; e += NTH) {
                 const int i = e / PT, j = e - i * PT, o = i * LD + j;
                 double u = (t[3] / c) * Ap[o] + (t[4] / (c * c)) * Bp[o];
                 if (i == j && i < p) u += t[2];
                 f0[o] = u;
             }
             __syncthreads();
-            lds_symm<PT, false>(f0, Bp, f1, t[0], 1.0 / (c * c), Ap, t[1] / c, p);
+            lds_symm<PT, false, NW>(f0, Bp, f1, t[0], 1.0 / (c * c), Ap, t[1] / c, p);
             nprod += 1;
             Z = f1;                                       // T1
             f1 = Bp;                                      // B' is dead
         } else {
             const double c2 = (d0 == 5) ? t[2] / (c * c) : 0.0;
-            for (int e = tid; e < PT * PT; e += 256) {
+            for (int e = tid; e < PT * PT; e += NTH) {
                 const int i = e / PT, j = e - i * PT, o = i * LD + j;
                 double x = (t[1] / c) * Ap[o] + c2 * Bp[o];
                 if (i == j && i < p) x += t[0];
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(256) void k_omega_lds(const double* __restrict__ Th
             Z = Bp;                                       // T1 in place of B'
         }
         // Y1 = (A'/c) T1 -> f0
-        lds_symm<PT, false>(Ap, Z, f0, 0.0, 1.0 / c, nullptr, 0.0, p);
+        lds_symm<PT, false, NW>(Ap, Z, f0, 0.0, 1.0 / c, nullptr, 0.0, p);
         nprod += 1;
         Y = f0;
         f0 = Ap;                                          // A' is dead: free buffers f0, f1 (deg 9) or f0 and b3
@@ -292,41 +310,41 @@ __global__ __launch_bounds__(256) void k_omega_lds(const double* __restrict__ Th
         const bool last = (it == n - 1);
         double* T;
         if (d == 3) {
-            lds_symm<PT, false>(Z, Y, f0, t[0], t[1], nullptr, 0.0, p);          // T = t0 I + t1 (Z Y)
+            lds_symm<PT, false, NW>(Z, Y, f0, t[0], t[1], nullptr, 0.0, p);          // T = t0 I + t1 (Z Y)
             nprod += 1;
             T = f0;
         } else if (d == 5) {
-            lds_symm<PT, false>(Z, Y, f0, 0.0, 1.0, nullptr, 0.0, p);            // M = Z Y
-            lds_symm<PT, false>(f0, f0, f1, t[0], t[2], f0, t[1], p);            // T = t0 I + t2 M M + t1 M
+            lds_symm<PT, false, NW>(Z, Y, f0, 0.0, 1.0, nullptr, 0.0, p);            // M = Z Y
+            lds_symm<PT, false, NW>(f0, f0, f1, t[0], t[2], f0, t[1], p);            // T = t0 I + t2 M M + t1 M
             nprod += 2;
             T = f1;
             double* sw = f0; f0 = f1; f1 = sw;            // T lives in (new) f0; M's buffer is free as f1
         } else {
             const double a = t[3] / (2.0 * t[4]), dl = t[2] / t[4] - a * a, e = t[1] - t[4] * dl * a;
-            lds_symm<PT, false>(Z, Y, f0, 0.0, 1.0, nullptr, 0.0, p);            // M = Z Y -> f0
-            lds_symm<PT, false>(f0, f0, f1, 0.0, 1.0, f0, a, p);                 // Q = M M + a M -> f1
+            lds_symm<PT, false, NW>(Z, Y, f0, 0.0, 1.0, nullptr, 0.0, p);            // M = Z Y -> f0
+            lds_symm<PT, false, NW>(f0, f0, f1, 0.0, 1.0, f0, a, p);                 // Q = M M + a M -> f1
             // T = t0 I + t4 (Q Q + dl Q) + e M -> in place of Q (reads finish before the writes)
             {
                 // out = f I + t4 (Q Q) + [t4 dl Q + e M]: two E terms -- fold the second into a pre-pass on M's buffer
-                for (int q = tid; q < PT * PT; q += 256) {
+                for (int q = tid; q < PT * PT; q += NTH) {
                     const int i = q / PT, j = q - i * PT, o = i * LD + j;
                     f0[o] = e * f0[o] + t[4] * dl * f1[o];
                 }
                 __syncthreads();
-                lds_symm<PT, true>(f1, f1, f1, t[0], t[4], f0, 1.0, p);
+                lds_symm<PT, true, NW>(f1, f1, f1, t[0], t[4], f0, 1.0, p);
             }
             nprod += 3;
             T = f1;
             double* sw = f0; f0 = f1; f1 = sw;            // T in f0, the other buffer free as f1
         }
         if (last) {
-            lds_symm<PT, false>(Y, T, f1, 0.0, 1.0, nullptr, 0.0, p);            // Y_last = Y T -> f1
+            lds_symm<PT, false, NW>(Y, T, f1, 0.0, 1.0, nullptr, 0.0, p);            // Y_last = Y T -> f1
             nprod += 1;
             Y = f1;
         } else {
             // Ynew = Y T -> f1;  Znew = T Z -> old Y's buffer
-            lds_symm<PT, false>(Y, T, f1, 0.0, 1.0, nullptr, 0.0, p);
-            lds_symm<PT, false>(T, Z, Y, 0.0, 1.0, nullptr, 0.0, p);
+            lds_symm<PT, false, NW>(Y, T, f1, 0.0, 1.0, nullptr, 0.0, p);
+            lds_symm<PT, false, NW>(T, Z, Y, 0.0, 1.0, nullptr, 0.0, p);
             nprod += 2;
             double* oldY = Y;
             double* oldZ = Z;
@@ -342,8 +360,8 @@ __global__ __launch_bounds__(256) void k_omega_lds(const double* __restrict__ Th
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         int i, j;
-        tri_index<PT>(tid + 256 * it, i, j);
-        if (tid + 256 * it < NE) {
+        tri_index<PT>(tid + NTH * it, i, j);
+        if (tid + NTH * it < NE) {
             const double om = 0.5 * wreg[it] + (0.5 * sc) * Y[i * LD + j];
             wb[i * LD + j] = om;
             wb[j * LD + i] = om;
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(256) void k_omega_lds(const double* __restrict__ Th
     }
     __syncthreads();
     GGL_TS(7);
-    for (int e = tid; e < PT * PT; e += 256) {
+    for (int e = tid; e < PT * PT; e += NTH) {
         const int i = e / PT, j = e - i * PT;
         if (i < p && j < p) Omega[off + (size_t)i * p + j] = wb[i * LD + j];
     }
@@ -392,21 +410,23 @@ int omega_lds_build_table(double tol, int degrees, double* table_h, int max_entr
 
 bool launch_omega_lds(hipStream_t st, const double* Theta, const double* L, const double* X, const double* S, const double* betaK,
                       double* Omega, const double* table, int ntab, double lnq, int K, int p, int* flag,
-                      int* flag_host, int flag_slot, unsigned long long* units, double* cbound, long long* dbg)
+                      int* flag_host, int flag_slot, unsigned long long* units, double* cbound, long long* dbg, int waves)
 {
-#define GGL_OL(PT)                                                                                                              \
+    // waves: 4 or 8 per workgroup, 0 = by size (two waves per SIMD from PT = 48 on, where a wave has more than one block)
+#define GGL_OL(PT, NW)                                                                                                          \
     do {                                                                                                                        \
-        const size_t lds = ((size_t)4 * PT * LdsDim<PT>::LD + PT + 8 + 512) * sizeof(double);                                          \
+        const size_t lds = ((size_t)4 * PT * LdsDim<PT>::LD + PT + 8 + 2 * 64 * NW) * sizeof(double);                               \
         /* per launch: the attribute belongs to the current device's copy of the kernel */                            \
-        if (hipFuncSetAttribute((const void*)k_omega_lds<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        if (hipFuncSetAttribute((const void*)k_omega_lds<PT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return false;                                                                                                        \
-        hipLaunchKernelGGL(k_omega_lds<PT>, dim3(K), dim3(256), lds, st, Theta, L, X, S, betaK, Omega, table, ntab, lnq, p, \
+        hipLaunchKernelGGL((k_omega_lds<PT, NW>), dim3(K), dim3(64 * NW), lds, st, Theta, L, X, S, betaK, Omega, table, ntab, lnq, p, \
                            flag, flag_host, flag_slot, units, cbound, dbg);                                                          \
     } while (0)
-    if (p <= 16) GGL_OL(16);
-    else if (p <= 32) GGL_OL(32);
-    else if (p <= 48) GGL_OL(48);
-    else if (p <= 64) GGL_OL(64);
+    const bool w8 = waves == 8 || (waves == 0 && p > 32);
+    if (p <= 16) GGL_OL(16, 4);
+    else if (p <= 32) GGL_OL(32, 4);
+    else if (p <= 48) { if (w8) GGL_OL(48, 8); else GGL_OL(48, 4); }
+    else if (p <= 64) { if (w8) GGL_OL(64, 8); else GGL_OL(64, 4); }
     else return false;
 #undef GGL_OL
     return true;

@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
                                                         const double* __restrict__ L, double l1, double l2,
                                                         double* __restrict__ partials, int K, int p,
                                                         const int* __restrict__ skip, const double* __restrict__ l1G,
-                                                        const double* __restrict__ l2G, const double* __restrict__ gsq)
+                                                        const double* __restrict__ l2G, const double* __restrict__ gsq, WNext wn)
 {
     // gsq != null (K-sharded run): the full (p,p) matrix of sum_k u^2 over ALL ranks' instances replaces the local sum
     __shared__ double scratch[GGL_NNORM * 4];
@@ -915,6 +915,7 @@ __global__ __launch_bounds__(256) void k_theta_ggl_flat(double* __restrict__ The
                 if (FUSE_DUAL) {
                     const double xn = x[k] + (om[k] - th);
                     X[o] = xn;
+                    if (wn.S) C[o] = (th - xn) - wn.beta[k] * wn.S[o];      // W of the NEXT Omega-step (k_form_W_sym's arithmetic)
                     const double dp = om[k] - OmegaPrev[o];
                     acc[0] += om[k] * om[k];
                     acc[1] += th * th;
@@ -969,7 +970,7 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4(double* __restrict_
                                                          const double* __restrict__ L, double l1, double l2,
                                                          double* __restrict__ partials, int K, int p,
                                                          const int* __restrict__ skip, const double* __restrict__ l1G,
-                                                         const double* __restrict__ l2G, const double* __restrict__ gsq)
+                                                         const double* __restrict__ l2G, const double* __restrict__ gsq, WNext wn)
 {
     __shared__ double ssh[NW][64];
     __shared__ double scratch[GGL_NNORM * NW];
@@ -1035,6 +1036,7 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4(double* __restrict_
                     if (FUSE_DUAL) {
                         const double xn = x[q] + (om[q] - th);
                         X[o] = xn;
+                        if (wn.S) C[o] = (th - xn) - wn.beta[kb + q] * wn.S[o];
                         const double dp = om[q] - OmegaPrev[o];
                         acc[0] += om[q] * om[q];
                         acc[1] += th * th;
@@ -1079,7 +1081,7 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4v(double* __restrict
                                                           const double* __restrict__ L, double l1, double l2,
                                                           double* __restrict__ partials, int K, int p,
                                                           const int* __restrict__ skip, const double* __restrict__ l1G,
-                                                          const double* __restrict__ l2G, const double* __restrict__ gsq)
+                                                          const double* __restrict__ l2G, const double* __restrict__ gsq, WNext wn)
 {
     static_assert(FLAT4_CHUNKS == 2, "128 elements per workgroup");
     __shared__ double2 ssh[NW][64];
@@ -1159,6 +1161,14 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4v(double* __restrict
                     xn.x = x[q].x + (om[q].x - th.x);
                     xn.y = x[q].y + (om[q].y - th.y);
                     *reinterpret_cast<double2*>(X + o) = xn;
+                    if (wn.S) {
+                        const double2 sv = ld2(wn.S + o);
+                        const double bk = wn.beta[kb + q];
+                        double2 wv;
+                        wv.x = (th.x - xn.x) - bk * sv.x;
+                        wv.y = (th.y - xn.y) - bk * sv.y;
+                        *reinterpret_cast<double2*>(C + o) = wv;
+                    }
                     const double2 op = ld2(OmegaPrev + o);
                     const double d0 = om[q].x - op.x, d1 = om[q].y - op.y;
                     acc[0] += om[q].x * om[q].x + om[q].y * om[q].y;
@@ -1206,7 +1216,7 @@ __global__ __launch_bounds__(1024) void k_theta_ggl_flat16(double* __restrict__ 
                                                            const double* __restrict__ OmegaPrev,
                                                            const double* __restrict__ L, double l1, double l2,
                                                            double* __restrict__ partials, int K, int p,
-                                                           const int* __restrict__ skip, const double* __restrict__ gsq)
+                                                           const int* __restrict__ skip, const double* __restrict__ gsq, WNext wn)
 {
     constexpr int NW = 16;
     __shared__ double ssh[NW][16];
@@ -1263,6 +1273,7 @@ __global__ __launch_bounds__(1024) void k_theta_ggl_flat16(double* __restrict__ 
                 if (FUSE_DUAL) {
                     const double xn = x[q] + (om[q] - th);
                     X[o] = xn;
+                    if (wn.S) C[o] = (th - xn) - wn.beta[kb + q] * wn.S[o];
                     const double dp = om[q] - OmegaPrev[o];
                     acc[0] += om[q] * om[q];
                     acc[1] += th * th;
@@ -1299,13 +1310,13 @@ __global__ __launch_bounds__(1024) void k_theta_ggl_flat16(double* __restrict__ 
 template <int KQ>
 static void launch_flat16(hipStream_t st, double* Theta, double* X, double* C, const double* Omega, const double* OmegaPrev,
                           const double* L, double l1, double l2, int fuse_dual, double* partials, int K, int p,
-                          const int* skip, const double* gsq)
+                          const int* skip, const double* gsq, WNext wn = WNext())
 {
     dim3 grid((unsigned)(((size_t)p * p + 15) / 16)), blk(1024);
     if (fuse_dual)
-        hipLaunchKernelGGL((k_theta_ggl_flat16<KQ, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, gsq);
+        hipLaunchKernelGGL((k_theta_ggl_flat16<KQ, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, gsq, wn);
     else
-        hipLaunchKernelGGL((k_theta_ggl_flat16<KQ, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, gsq);
+        hipLaunchKernelGGL((k_theta_ggl_flat16<KQ, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, gsq, wn);
 }
 
 static inline int flat4_blocks(int p) { return (int)(((size_t)p * p + 64 * FLAT4_CHUNKS - 1) / (64 * FLAT4_CHUNKS)); }
@@ -1314,22 +1325,22 @@ template <int KQ, int NW = 4, bool VEC_OK = true>
 static void launch_flat4(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                          const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual, double* partials,
                          int K, int p, const int* skip, int G = 1, const double* l1G = nullptr, const double* l2G = nullptr,
-                         const double* gsq = nullptr)
+                         const double* gsq = nullptr, WNext wn = WNext())
 {
     dim3 grid(flat4_blocks(p), G), blk(NW * 64);
     if constexpr (VEC_OK) {
         if ((p & 1) == 0) {          // p^2 even: two consecutive elements per lane, 16-byte accesses
             if (fuse_dual)
-                hipLaunchKernelGGL((k_theta_ggl_flat4v<KQ, true, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+                hipLaunchKernelGGL((k_theta_ggl_flat4v<KQ, true, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq, wn);
             else
-                hipLaunchKernelGGL((k_theta_ggl_flat4v<KQ, false, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+                hipLaunchKernelGGL((k_theta_ggl_flat4v<KQ, false, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq, wn);
             return;
         }
     }
     if (fuse_dual)
-        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, true, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, true, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq, wn);
     else
-        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, false, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+        hipLaunchKernelGGL((k_theta_ggl_flat4<KQ, false, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq, wn);
 }
 
 // the K-column of an element over 4, 8 or 16 waves: K <= 16: 4 x 4, <= 32: 4 x 8, <= 64: 8 x 8, <= 128: 16 x 8 (16-byte
@@ -1346,15 +1357,15 @@ int theta_last_kernel() { return g_theta_kernel; }
 static void launch_flat4_any(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                              const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual,
                              double* partials, int K, int p, const int* skip, int G, const double* l1G, const double* l2G,
-                             const double* gsq)
+                             const double* gsq, WNext wn = WNext())
 {
     if (use_flat16(K, p, 2, G)) {
         g_theta_kernel = K <= 128 ? 10216 : 10416;
-        if (K <= 128) launch_flat16<2>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, gsq);
-        else launch_flat16<4>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, gsq);
+        if (K <= 128) launch_flat16<2>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, gsq, wn);
+        else launch_flat16<4>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, gsq, wn);
         return;
     }
-#define GGL_F4(...) launch_flat4<__VA_ARGS__>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, G, l1G, l2G, gsq)
+#define GGL_F4(...) launch_flat4<__VA_ARGS__>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, G, l1G, l2G, gsq, wn)
     g_theta_kernel = K <= 16 ? 404 : K <= 32 ? 408 : K <= 64 ? 808 : K <= 128 ? 816 : 1616;
     if (K <= 16) GGL_F4(4);
     else if (K <= 32) GGL_F4(8);
@@ -1368,31 +1379,37 @@ template <int KMAX>
 static void launch_flat(hipStream_t st, double* Theta, double* X, double* C, const double* Omega,
                         const double* OmegaPrev, const double* L, double l1, double l2, int fuse_dual, double* partials,
                         int K, int p, const int* skip, int G = 1, const double* l1G = nullptr, const double* l2G = nullptr,
-                        const double* gsq = nullptr)
+                        const double* gsq = nullptr, WNext wn = WNext())
 {
     dim3 grid(flat_blocks(p), G), blk(256);
     g_theta_kernel = 100 + KMAX;
     if (fuse_dual)
-        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, true>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq, wn);
     else
-        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq);
+        hipLaunchKernelGGL((k_theta_ggl_flat<KMAX, false>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq, wn);
 }
 
 hipError_t launch_theta_pair(hipStream_t st, int reg, double* Theta, double* X, double* C, const double* Omega,
                              const double* OmegaPrev, const double* L, double l1, double l2,
                              const double* groupsq, double* sqwork, int fuse_dual, double* partials, int K, int p,
-                             int flat, const int* skip)
+                             int flat, const int* skip, WNext wn, int* wn_done)
 {
+    // wn (S, beta given; fuse_dual): the per-element GGL kernels also write C = (Theta - X_new) - beta_k S, the W of the NEXT
+    // Omega-step (admm_solver.py:180), from the values they hold anyway; *wn_done = 1 when the kernel launched did so
+    if (wn_done) *wn_done = 0;
+    if (!fuse_dual || reg != 1) wn = WNext();
     // per-element kernels (exactly symmetric state): the group sums are the element's own K-column, or -- K-sharded run --
     // the all-reduced FULL matrix `groupsq` (launch_group_sums_full on every rank)
     if (reg == 1 && K <= GGL_FLAT_MAX_K && use_flat4(K, flat)) {
-        launch_flat4_any(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
+        launch_flat4_any(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq, wn);
+        if (wn_done && wn.S) *wn_done = 1;
         return hipGetLastError();
     }
     if (reg == 1 && flat && K <= GGL_FLAT1_MAX_K) {
-        if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
-        else if (K <= 16) launch_flat<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
-        else launch_flat<32>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq);
+        if (K <= 8) launch_flat<8>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq, wn);
+        else if (K <= 16) launch_flat<16>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq, wn);
+        else launch_flat<32>(st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, fuse_dual, partials, K, p, skip, 1, nullptr, nullptr, groupsq, wn);
+        if (wn_done && wn.S) *wn_done = 1;
         return hipGetLastError();
     }
     if (reg == 1) {

@@ -227,33 +227,53 @@ class HipEngine:
     def scale_X_batch(self, factors):
         check(self.lib.ggl_scale_X_batch(self.h, ptr(as_c(factors))))
 
-    def sgl_batch_run(self, n_iters, rho, lambda1, latent, mu1, dims, tol, rtol, update_rho, done):
-        """Up to ``n_iters`` iterations of ``sgl_batch_step`` with the per-point stopping test, rho rule and X rescale taken in
-        C (ggl_sgl_batch_run); stops after the first iteration in which a live point converges or fails.  ``rho`` (K,) float64
-        is updated IN PLACE.  Returns (iterations run, last (K,4), status (K,) int32: 0 goes on, 1 converged, 2 failed)."""
-        assert rho.dtype == np.float64 and rho.flags.c_contiguous and rho.shape == (self.K,)
-        last = np.zeros((self.K, 4))
-        status = np.zeros(self.K, dtype=np.int32)
-        dn = np.ascontiguousarray(done, dtype=np.uint8)
-        n = check(self.lib.ggl_sgl_batch_run(self.h, int(n_iters), ptr(rho), ptr(as_c(lambda1)), int(latent),
-                                             ptr(None if mu1 is None else as_c(mu1)), ptr(as_c(dims)), float(tol), float(rtol),
-                                             int(bool(update_rho)), dn.ctypes.data_as(_lib._ubp), ptr(last),
-                                             status.ctypes.data_as(_lib._ip)))
-        return int(n), last, status
+    def batch_run(self, n_iters, rho, last, status, fin_iter, it_base, dims, tol, rtol, update_rho, snap=None, stop_after=0,
+                  *, lambda1, lambda2=None, reg=None, latent=False, mu1=None, nk=None, G=None):
+        """Up to ``n_iters`` batch iterations in ONE C call (ggl_sgl_batch_run; ggl_mgl_batch_run when ``G`` problems of K/G
+        instances are given): per-point stopping test, rho rule and X rescale taken in C, bit for bit ``batch._decide``.
+        rho (n,) float64, last (n,4) float64, status (n,) int32 (0 live, 1 converged, 2 failed), fin_iter (n,) int32 are
+        updated IN PLACE.  snap = (engine, slots int32 per instance slot): finishing points are snapshotted there on the
+        device, failed ones parked, and the loop goes on until all are finished, ``stop_after`` are (> 0), or n_iters;
+        None: returns after the first iteration with an event.  Returns the iterations run."""
+        ip = _lib._ip
+        n = self.K if G is None else int(G)
+        for a, dt, shp in ((rho, np.float64, (n,)), (last, np.float64, (n, 4)), (status, np.int32, (n,)),
+                           (fin_iter, np.int32, (n,))):
+            assert a.dtype == dt and a.flags.c_contiguous and a.shape == shp, (a.dtype, a.shape, shp)
+        sh, si = (None, None)
+        if snap is not None:
+            sh = snap[0].h
+            si = np.ascontiguousarray(snap[1], dtype=np.int32)
+            assert si.shape == (self.K,)
+        sip = None if si is None else si.ctypes.data_as(ip)
+        mu = ptr(None if mu1 is None else as_c(mu1))
+        if G is None:
+            rc = self.lib.ggl_sgl_batch_run(self.h, int(n_iters), ptr(rho), ptr(as_c(lambda1)), int(latent), mu,
+                                            ptr(as_c(dims)), float(tol), float(rtol), int(bool(update_rho)), ptr(last),
+                                            status.ctypes.data_as(ip), fin_iter.ctypes.data_as(ip), int(it_base), sh, sip,
+                                            int(stop_after))
+        else:
+            rc = self.lib.ggl_mgl_batch_run(self.h, n, int(n_iters), ptr(rho), ptr(as_c(lambda1)), ptr(as_c(lambda2)),
+                                            _REG[reg], int(latent), mu, ptr(None if nk is None else as_c(nk)),
+                                            ptr(as_c(dims)), float(tol), float(rtol), int(bool(update_rho)), ptr(last),
+                                            status.ctypes.data_as(ip), fin_iter.ctypes.data_as(ip), int(it_base), sh, sip,
+                                            int(stop_after))
+        return int(check(rc))
 
-    def mgl_batch_run(self, G, n_iters, rho, lambda1, lambda2, reg, latent, mu1, nk, dims, tol, rtol, update_rho, done):
-        """The same for G multiple-graph problems in one stack (ggl_mgl_batch_run); ``rho`` (G,) is updated in place."""
-        G = int(G)
-        assert rho.dtype == np.float64 and rho.flags.c_contiguous and rho.shape == (G,)
-        last = np.zeros((G, 4))
-        status = np.zeros(G, dtype=np.int32)
-        dn = np.ascontiguousarray(done, dtype=np.uint8)
-        n = check(self.lib.ggl_mgl_batch_run(self.h, G, int(n_iters), ptr(rho), ptr(as_c(lambda1)), ptr(as_c(lambda2)),
-                                             _REG[reg], int(latent), ptr(None if mu1 is None else as_c(mu1)),
-                                             ptr(None if nk is None else as_c(nk)), ptr(as_c(dims)), float(tol), float(rtol),
-                                             int(bool(update_rho)), dn.ctypes.data_as(_lib._ubp), ptr(last),
-                                             status.ctypes.data_as(_lib._ip)))
-        return int(n), last, status
+    def snapshot_state_from(self, kd, src, ks):
+        """Omega, Theta, L, X of instance ``ks`` of the engine ``src`` (may be this one) into slot ``kd``'s device snapshot."""
+        check(self.lib.ggl_snapshot_state_from(self.h, int(kd), src.h, int(ks)))
+
+    def snapshots(self, latent=False):
+        """{'Omega','Theta','X'[,'L']}: the (K,p,p) snapshot stacks, one download each."""
+        shape = (self.K, self.p, self.p)
+        Om, Th, X = np.empty(shape), np.empty(shape), np.empty(shape)
+        L = np.empty(shape) if latent else None
+        check(self.lib.ggl_get_snapshots(self.h, ptr(Om), ptr(Th), ptr(L), ptr(X)))
+        out = {'Omega': Om, 'Theta': Th, 'X': X}
+        if latent:
+            out['L'] = L
+        return out
 
     # -- G independent multiple-graph problems in one stack (batched lambda1 x lambda2 grid) -------------------
     def mgl_batch_step(self, G, rho, lambda1, lambda2, reg, latent, mu1, nk):
@@ -480,9 +500,10 @@ class HipEngine:
 
     def pipeline_stats(self):
         import ctypes
-        out = (ctypes.c_longlong * 5)()
+        out = (ctypes.c_longlong * 7)()
         check(self.lib.ggl_pipeline_stats(self.h, out))
-        return dict(zip(("prelaunched", "dropped", "early_launched", "early_used", "part_streams_tried"), (int(v) for v in out)))
+        return dict(zip(("prelaunched", "dropped", "early_launched", "early_used", "part_streams_tried", "w_fused", "w_fused_used"),
+                        (int(v) for v in out)))
 
     def eig_info(self):
         """(K,) sweeps of the LDS Jacobi kernel in the last step (-1: not converged), or rocSOLVER's info."""

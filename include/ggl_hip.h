@@ -127,11 +127,15 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                       built in round 4 for the small slabs, measured equal there and slower at the headline */
 #define GGL_OPT_OMEGA_LDS 23       /* [1] p <= 64: the whole Omega-step as ONE launch, one workgroup per instance, the Newton-Schulz chain
                                       resident in LDS, bound and per-instance schedule chosen on the device (omega_lds.hip); an instance
-                                      outside its range (condition number of W^2 + 4 beta I above 300) sends the step to the launch chain */
+                                      outside its range (condition number of W^2 + 4 beta I above 300) sends the step to the launch chain.
+                                      1: waves per workgroup by size (8, i.e. two per SIMD, for 32 < p <= 64; round 5), 4 / 8: that many */
 #define GGL_OPT_EARLY_PART 24      /* [1] with GGL_OPT_PIPELINE, ggl_admm_step: the first part of the NEXT iteration's Omega-step chain (tables,
                                       W, A', B': scratch only) goes into the stream before the host waits for this iteration's residuals,
                                       on the prediction that the rho rule keeps rho; its schedule is built from the bounds validated one
                                       iteration earlier, so iterates agree with GGL_OPT_EARLY_PART = 0 to the Omega-step's tolerance */
+#define GGL_OPT_FUSED_W 26         /* [1] with GGL_OPT_EARLY_PART, GGL, exactly symmetric state and S: the Theta kernel that precedes an early
+                                      first part also writes that part's W = Theta - X - beta S (admm_solver.py:180) from the values it
+                                      holds -- one pass over three stacks and one launch per part less (round 5) */
 #define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
                                       2 = with the lowest stream priority (streams of another priority never share a hardware queue with
                                       the ctx's main stream) */
@@ -284,17 +288,26 @@ int ggl_mgl_batch_step(ggl_ctx *ctx, int G, const double *rho, const double *lam
  *   last (n,4) {r_t, s_t, e_pri, e_dual} (rows of live finite points rewritten); fac (n) out = rho / rho_new;
  *   status (n) out: 0 goes on, 1 converged now, 2 failed (non-finite sums or marked).  Returns #{status != 0}.
  * ggl_sgl_batch_run / ggl_mgl_batch_run: up to n_iters iterations of ggl_sgl_batch_step / ggl_mgl_batch_step with those
- *   decisions and the X rescale in between; return after the first iteration in which a live point converges or fails (the
- *   caller snapshots, parks, compacts: gglasso_amd/batch.py) or after n_iters.  Return value: iterations run, < 0 on error.
- *   done (n) 0/1: finished points (dragged along, no decisions).  last / status: of the last iteration run. */
+ *   decisions and the X rescale in between.  status (n) in/out: 0 live, 1 converged, 2 failed (points that are not 0 on
+ *   entry are dragged along without decisions); last (n,4) in/out; fin_iter (n) in/out: it_base + the iteration of this call
+ *   a point finished in (1-based).  snap_ctx NULL: return after the first iteration in which a live point converges or
+ *   fails.  snap_ctx given (ctx itself, or the ORIGINAL ctx of a compacted batch; snap_index: destination slot of every
+ *   instance slot): a finishing point's whole solution is snapshotted there on the device (ggl_snapshot_state_from), a
+ *   failed point is then parked (ggl_reset_instance), and the loop goes on until every point is finished, at least
+ *   stop_after points are (> 0: the caller may compact), or n_iters.  Return value: iterations run, < 0 on error.
+ * ggl_snapshot_state_from: ggl_snapshot_from + Omega and X; ggl_get_snapshots: the snapshot stacks (K,p,p), any NULL --
+ *   ONE download per stack at the end of a batch instead of three or four small ones per point. */
 int ggl_batch_decide(int n, const double *sq, const unsigned char *live, const unsigned char *marked, double *rho,
                      const double *dims, double tol, double rtol, int update_rho, double *last, double *fac, int *status);
 int ggl_sgl_batch_run(ggl_ctx *ctx, int n_iters, double *rho, const double *lambda1, int latent, const double *mu1,
-                      const double *dims, double tol, double rtol, int update_rho, const unsigned char *done,
-                      double *last, int *status);
+                      const double *dims, double tol, double rtol, int update_rho, double *last, int *status,
+                      int *fin_iter, int it_base, ggl_ctx *snap_ctx, const int *snap_index, int stop_after);
 int ggl_mgl_batch_run(ggl_ctx *ctx, int G, int n_iters, double *rho, const double *lambda1, const double *lambda2,
                       int reg, int latent, const double *mu1, const double *nk, const double *dims, double tol, double rtol,
-                      int update_rho, const unsigned char *done, double *last, int *status);
+                      int update_rho, double *last, int *status, int *fin_iter, int it_base, ggl_ctx *snap_ctx,
+                      const int *snap_index, int stop_after);
+int ggl_snapshot_state_from(ggl_ctx *ctx, int k_dst, ggl_ctx *src, int k_src);
+int ggl_get_snapshots(ggl_ctx *ctx, double *Omega, double *Theta, double *L, double *X);
 
 /* host only: out = {largest K/G of the batched GGL grid (per-element Theta kernel), largest K of the FGL Theta-step (the
  * K-vectors of a tile of pairs live in LDS)}; callers choose between the batched grid and the sequential walk with it */
@@ -438,8 +451,9 @@ int ggl_lds_stats(ggl_ctx *ctx, long long out[4]);
  * early first parts (tables, W, A', B' of the NEXT iteration's chain, put into the stream before the host waits for this
  * iteration's residuals), of those continued, fresh streams the concurrency probe had to try before the first two-part
  * Omega-step until one ran BESIDE the ctx's main stream (HIP streams share a small pool of hardware queues, and two streams on
- * one queue serialise; 0: the part stream was fine, -1: not probed yet) }. */
-int ggl_pipeline_stats(ggl_ctx *ctx, long long out[5]);
+ * one queue serialise; 0: the part stream was fine, -1: not probed yet), Theta-steps that also wrote the next Omega-step's W
+ * (GGL_OPT_FUSED_W), of those used by the early first part that followed }. */
+int ggl_pipeline_stats(ggl_ctx *ctx, long long out[7]);
 /* L-step (sign iteration): out = { calls, calls whose first pass was continued on a compact sub-batch, instances continued in
  * total, calls that fell back to the eigendecomposition } */
 int ggl_rank_stats(ggl_ctx *ctx, long long out[4]);
@@ -465,7 +479,8 @@ int ggl_dev_symm_bench(int K, int p, int variant, int iters, double *ms_out);
  * chain resident in LDS, bound and schedule chosen on the device (omega_lds.hip; kernel unit test and timing).
  * Omega = phiplus(Theta - L - X - beta S, beta), L may be NULL.  cbound (K) or NULL receives the bound used.
  * out[14] = {ms per launch, fallback flag, products summed over the instances, entries of the schedule table, [4..12] phase
- * stamps of instance 0 in us (start, W, A', B', bound, first step, steps, W again, Omega), [13] products of instance 0}. */
+ * stamps of instance 0 in us (start, W, A', B', bound, first step, steps, W again, Omega), [13] products of instance 0}.
+ * degrees + 1000 * w: w = 4 or 8 waves per workgroup (0: by size, as the solver runs it). */
 int ggl_dev_omega_lds(int K, int p, const double *Theta, const double *L, const double *X, const double *S, const double *beta,
                       double tol, int degrees, double *Omega, double *cbound, int iters, double *out);
 /* ggl_dev_symm_bounds: C = A B on the direct-to-LDS product kernel with the bound partials of its epilogue, reduced to

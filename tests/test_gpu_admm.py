@@ -532,8 +532,10 @@ def test_pipelined_iterations_are_bitwise_the_unpipelined_ones(sol, reg, K, p, e
     Om0 = np.stack([np.eye(p)] * K)
     outs, stats, pipe_stats = [], [], []
     n_it = 16 if not early else 40
-    for pipe in (0, 1):
-        eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"pipeline": pipe, "early_part": early})
+    # (third run, early part only: GGL_OPT_FUSED_W off -- the W of an early first part comes from k_form_W_sym instead of the
+    # Theta kernel that precedes it: the same arithmetic per element, the same iterates)
+    for pipe, fused_w in ((0, 1), (1, 1)) + (((1, 0),) if early else ()):
+        eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"pipeline": pipe, "early_part": early, "fused_w": fused_w})
         nk = np.ones(K)
         rho, mid = 1.0, None
         for it in range(n_it):
@@ -562,6 +564,12 @@ def test_pipelined_iterations_are_bitwise_the_unpipelined_ones(sol, reg, K, p, e
     assert pipe_stats[0]["early_launched"] == 0
     if early:
         assert pipe_stats[1]["early_launched"] >= 5 and pipe_stats[1]["early_used"] >= pipe_stats[1]["early_launched"] - 3, pipe_stats[1]
+        if reg == "GGL":
+            assert pipe_stats[1]["w_fused_used"] >= pipe_stats[1]["early_launched"] - 1, pipe_stats[1]
+        assert pipe_stats[2]["w_fused"] == 0 and pipe_stats[2]["early_launched"] == pipe_stats[1]["early_launched"]
+        for a, b in zip(outs[1][:2], outs[2][:2]):
+            for nm in ("Omega", "Theta", "X"):
+                assert np.abs(a[nm] - b[nm]).max() <= 1e-13, nm
     else:
         assert pipe_stats[1]["early_launched"] == 0
     ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, reg, Om0, max_iter=n_it, tol=1e-20, rtol=1e-20)

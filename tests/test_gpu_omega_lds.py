@@ -51,13 +51,18 @@ def test_kernel_against_eigh(p, latent):
     W = Theta - (L if latent else 0.0) - X - beta[:, None, None] * S
     ref, _ = orc.phiplus_stack(W, beta)
     lam = np.array([np.linalg.eigvalsh(W[k] @ W[k] + 4 * beta[k] * np.eye(p))[-1] for k in range(K)])
-    for tol, bar in ((2e-12, 1e-11), (1e-10, 5e-10)):
-        Om, cb, out = _dev_omega(*[np.ascontiguousarray(a) for a in dirty[:3]], beta,
-                                 L=np.ascontiguousarray(dirty[3]) if latent else None, tol=tol)
-        assert out[1] == 0
-        assert np.abs(Om - ref).max() <= bar * max(1.0, np.abs(ref).max()), (p, tol)
-        assert np.array_equal(Om, Om.transpose(0, 2, 1))
-        assert np.all(cb >= lam * (1 - 1e-12)) and np.all(cb <= 4.0 * lam + 1e-300)      # a bound, and not a wild one
+    first = {}
+    # waves per workgroup: 0 = what the solver runs (two per SIMD above p = 32, round 5), 4 and 8 explicitly -- the blocks
+    # are dealt differently, every block's arithmetic is the same: bit-identical results
+    for waves in (0, 4, 8):
+        for tol, bar in ((2e-12, 1e-11), (1e-10, 5e-10)):
+            Om, cb, out = _dev_omega(*[np.ascontiguousarray(a) for a in dirty[:3]], beta,
+                                     L=np.ascontiguousarray(dirty[3]) if latent else None, tol=tol, degrees=9 + 1000 * waves)
+            assert out[1] == 0
+            assert np.abs(Om - ref).max() <= bar * max(1.0, np.abs(ref).max()), (p, tol, waves)
+            assert np.array_equal(Om, Om.transpose(0, 2, 1))
+            assert np.all(cb >= lam * (1 - 1e-12)) and np.all(cb <= 4.0 * lam + 1e-300)      # a bound, and not a wild one
+            assert np.array_equal(first.setdefault(tol, Om), Om), (p, tol, waves)
 
 
 @pytest.mark.parametrize("degrees", [3, 5, 9])

@@ -38,17 +38,17 @@ def main():
             beta = np.full(K, 1.0 / rho)
             W = Th - X - beta[:, None, None] * S
             ref, _ = orc.phiplus_stack(W, 1.0 / rho)
-            for tol in (2e-12, 1e-10):
+            for tol, waves in ((2e-12, 4), (2e-12, 8), (1e-10, 4), (1e-10, 8)):
                 Om = np.zeros_like(W)
                 cb = np.zeros(K)
                 out = np.zeros(18)
-                _lib.check(lib.ggl_dev_omega_lds(K, p, ptr(Th), None, ptr(X), ptr(S), ptr(beta), tol, 9, ptr(Om), ptr(cb), 20, ptr(out)))
+                _lib.check(lib.ggl_dev_omega_lds(K, p, ptr(Th), None, ptr(X), ptr(S), ptr(beta), tol, 9 + 1000 * waves, ptr(Om), ptr(cb), 20, ptr(out)))
                 lam = np.linalg.eigvalsh(W[0] @ W[0] + 4 * beta[0] * np.eye(p))[-1]
                 err = np.abs(Om - ref).max() / np.abs(ref).max()
                 sym = np.abs(Om - Om.transpose(0, 2, 1)).max()
-                print(f"K={K:5d} p={p:3d} iterate {it} rho={rho}: tol {tol:7.0e}  {out[0] * 1e3:7.1f} us  flag {int(out[1])}  products/instance "
+                print(f"K={K:5d} p={p:3d} iterate {it} rho={rho}: tol {tol:7.0e} waves {waves}  {out[0] * 1e3:7.1f} us  flag {int(out[1])}  products/instance "
                       f"{out[2] / K:4.1f}  rel err {err:8.2e}  asym {sym:.1e}  bound/lambda_max {cb[0] / lam:6.3f}  kappa {cb[0] / (4 * beta[0]):6.1f}")
-                if tol == 2e-12:
+                if tol == 2e-12 and p > 32:
                     print("      instance 0 (us): form W %.2f | A' %.2f | B' %.2f | bound %.2f | first step %.2f | steps %.2f | (gap %.2f) W again %.2f | Omega %.2f | products %d"
                           % (out[5], out[6] - out[5], out[7] - out[6], out[8] - out[7], out[9] - out[8], out[10] - out[9], 0.0, out[11] - out[10], out[12] - out[11], out[13]))
 
