@@ -184,7 +184,7 @@ void launch_dual_update(hipStream_t st, double* X, const double* Omega, const do
 // per-thread sums, wave shuffles, four wave results added in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partials, int nblk, int nv,
                                                          double* __restrict__ out, unsigned long long* seq,
-                                                         unsigned long long seq_val)
+                                                         unsigned long long seq_val, unsigned* __restrict__ arrive)
 {
     __shared__ double sh[4][8];
     const int k = blockIdx.x;
@@ -221,20 +221,34 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
     if (threadIdx.x < nv) out[(size_t)k * nv + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
     // single-row reductions into pinned host memory: publish a sequence number AFTER the sums, so that the host can
     // wait for this kernel by polling one word instead of a stream synchronisation
-    if (seq != nullptr && blockIdx.x == 0) {
+    if (seq != nullptr && gridDim.x == 1) {
         __syncthreads();
         if (threadIdx.x == 0) {
             __threadfence_system();
             *(volatile unsigned long long*)seq = seq_val;
         }
+    } else if (seq != nullptr) {
+        // several rows (a batch of independent problems): every workgroup makes its row visible, then counts itself in; the
+        // last one to arrive publishes the sequence number and leaves the counter at zero for the next launch
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            const unsigned prev = atomicAdd(arrive, 1u);
+            if (prev == gridDim.x - 1) {
+                *arrive = 0u;
+                __threadfence_system();
+                *(volatile unsigned long long*)seq = seq_val;
+            }
+        }
     }
 }
 
 void launch_reduce_partials(hipStream_t st, const double* partials, int K, int nblk, int nv, double* out,
-                            unsigned long long* seq, unsigned long long seq_val)
+                            unsigned long long* seq, unsigned long long seq_val, unsigned* arrive)
 {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(256), 0, st, partials, nblk, nv, out, K == 1 ? seq : nullptr,
-                       seq_val);
+    // seq with K > 1 rows needs the arrival counter (device memory, zero between launches)
+    hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(256), 0, st, partials, nblk, nv, out,
+                       (K == 1 || arrive) ? seq : nullptr, seq_val, arrive);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -73,6 +73,7 @@ struct ggl_ctx {
     double *norms = nullptr, *norms_h = nullptr;  // (K,8) device / pinned
     int* info_h = nullptr;                        // pinned (K)
     double* gflag_h = nullptr;                    // pinned: the all-reduced speculation flag of a K-sharded step
+    unsigned* arrive = nullptr;                   // device: arrival counter of a multi-row norm reduction that publishes seq
     bool nk_valid = false;
     // Newton-Schulz Omega-step (newton_schulz.hip)
     bool omega_ns = false;
@@ -478,6 +479,7 @@ static int ctx_alloc(ggl_ctx* c)
     PIN(c->norms_h, nl * sizeof(double), 2);
     PIN(c->info_h, (size_t)c->K * sizeof(int), 1);
     PIN(c->gflag_h, sizeof(double), 2);
+    DEV(c->arrive, 256);
     if (c->omega_ns) {
         for (int i = 0; i < 2; ++i) { DEV(c->nsYP[i], 2 * nb); }
         DEV(c->nsT, nb);
@@ -549,6 +551,7 @@ static int ctx_alloc(ggl_ctx* c)
     c->cuse_h = c->cuse_hh[0];
     // initial contents
     HIPCHK(hipMemsetAsync(c->groupsq, 0, ((size_t)c->p * c->p + 8) * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->arrive, 0, 256, c->stream));
     HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
     HIPCHK(hipMemsetAsync(c->X, 0, nb, c->stream));
     HIPCHK(hipMemsetAsync(c->Om[1], 0, nb, c->stream));
@@ -2383,23 +2386,18 @@ static int sgl_batch_step_impl(ggl_ctx* c, const double* rho, const double* lamb
             PE(c, GGL_PH_DUAL);
         }
         PB(c, GGL_PH_REDUCE);
-        launch_reduce_partials(c->stream, c->partials, K, elementwise_blocks(c->p), GGL_NNORM, c->norms_h);
+        // the K rows of sums go to pinned memory, the last workgroup publishes a sequence number: the host polls that word
+        // instead of synchronising the stream (~10 us of a 70-us batch iteration at p <= 64)
+        if (c->seq_h && c->spin_wait) c->seq_wait = ++c->seq_next;
+        launch_reduce_partials(c->stream, c->partials, K, elementwise_blocks(c->p), GGL_NNORM, c->norms_h,
+                               c->seq_wait ? c->seq_h : nullptr, c->seq_wait, c->arrive);
         PE(c, GGL_PH_REDUCE);
         HIPCHK(hipGetLastError());
-        CopySegs dn;
-        if (c->info_dirty) dn.add(c->info_h, c->info, K * sizeof(int));
-        launch_copy_small(c->stream, dn);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
-        prof_collect(c);
-        rc = validate_spec(c);
+        c->norms_host = true;
+        rc = finish_norms(c, K, out_norms, 1);          // (waits, validates a speculative step, checks the eigensolver's status)
         if (rc != GGL_SPEC_RETRY) break;
     }
-    if (rc) return rc;
-    rc = check_info(c, "batched SGL step");
-    if (rc) return rc;
-    memcpy(out_norms, c->norms_h, (size_t)K * GGL_NNORM * sizeof(double));
-    return GGL_OK;
+    return rc;
 }
 
 static int ensure_partials(ggl_ctx* c, size_t need)
@@ -2432,7 +2430,9 @@ static int mgl_batch_finish(ggl_ctx* c, int G, int Kp, int reg, int latent, doub
     c->norms_host = true;
     if (!latent) {
         PB(c, GGL_PH_REDUCE);
-        launch_reduce_partials(c->stream, c->partials, G, theta_partial_blocks(c->p, reg, Kp, 2, G), GGL_NNORM, c->norms_h);
+        if (c->seq_h && c->spin_wait) c->seq_wait = ++c->seq_next;
+        launch_reduce_partials(c->stream, c->partials, G, theta_partial_blocks(c->p, reg, Kp, 2, G), GGL_NNORM, c->norms_h,
+                               c->seq_wait ? c->seq_h : nullptr, c->seq_wait, c->arrive);
         PE(c, GGL_PH_REDUCE);
         rows = G;
         group = 1;
@@ -2443,7 +2443,9 @@ static int mgl_batch_finish(ggl_ctx* c, int G, int Kp, int reg, int latent, doub
         launch_dual_update(c->stream, c->X, Om, OmPrev, c->Theta, c->L, c->partials, K, c->p);
         PE(c, GGL_PH_DUAL);
         PB(c, GGL_PH_REDUCE);
-        launch_reduce_partials(c->stream, c->partials, K, elementwise_blocks(c->p), GGL_NNORM, c->norms_h);
+        if (c->seq_h && c->spin_wait) c->seq_wait = ++c->seq_next;
+        launch_reduce_partials(c->stream, c->partials, K, elementwise_blocks(c->p), GGL_NNORM, c->norms_h,
+                               c->seq_wait ? c->seq_h : nullptr, c->seq_wait, c->arrive);
         PE(c, GGL_PH_REDUCE);
         rows = K;
         group = Kp;
@@ -3535,7 +3537,9 @@ static int sharded_pass(ggl_ctx* c, double rho, double lambda1, double lambda2, 
     PE(c, GGL_PH_ALLREDUCE_NORMS);
     if (rc) return rc;
     // (no early first part of the next chain here, as ggl_admm_step queues one: measured behind the two collectives it is
-    // neutral to slightly negative -- K = 4 / 8 / 16 slabs 4182 / 2855 / 1978 it/s with it, 4224 / 3070 / 2009 without)
+    // neutral to negative -- round 4, with its own form_W pass: K = 4 / 8 / 16 slabs 4182 / 2855 / 1978 it/s with it, 4224 /
+    // 3070 / 2009 without; round 5, with the W written by the Theta kernel (GGL_OPT_FUSED_W): 4397 / 2877 / 2003 with,
+    // 4352 / 3035 / 1990 without)
     return finish_norms(c, 1, out_norms);
 }
 

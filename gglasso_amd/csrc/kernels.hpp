@@ -31,9 +31,10 @@ void launch_theta_sgl(hipStream_t st, double* Theta, double* X, double* C, const
 void launch_dual_update(hipStream_t st, double* X, const double* Omega, const double* OmegaPrev,
                         const double* Theta, const double* L, double* partials, int K, int p);
 // out[k][v] = sum_b partials[k][b][v]   (fixed order => deterministic)
-// seq (optional, K == 1 only): pinned word that receives seq_val after the sums have been written
+// seq (optional): pinned word that receives seq_val after the sums have been written; with K > 1 rows it needs `arrive`,
+// one device word that is zero between launches (the last workgroup to arrive publishes)
 void launch_reduce_partials(hipStream_t st, const double* partials, int K, int nblk, int nv, double* out,
-                            unsigned long long* seq = nullptr, unsigned long long seq_val = 0);
+                            unsigned long long* seq = nullptr, unsigned long long seq_val = 0, unsigned* arrive = nullptr);
 void launch_scale(hipStream_t st, double* X, double f, size_t n);
 // Small transfers between pinned host memory (device-visible) and HBM as an ordinary kernel in the stream:
 // a hipMemcpyAsync of a few KB costs ~15 us of queue idle time around its blit (measured, rocprofv3), this

@@ -96,6 +96,9 @@ __device__ __forceinline__ void lds_symm(const double* A, const double* B, doubl
     };
     double af[RING], bf[RING];
     // (a wave's idle slots are its LAST ones: Ib[s] < 0 implies Ib[s+1] < 0; the conditions below are wave-uniform)
+    // (Skipping the k-steps entirely beyond p -- zeros times zeros; p = 50 in a 64-tile would run 13 of 16 -- was measured: a
+    // guard per step on the loads and the matrix instruction costs every size ~30 %, K = 256, p = 64: 40.1 -> 51.6 us, for the
+    // 10 % it saves at p = 50.  Not kept: the steps stay unconditional inside a block.)
 #pragma unroll
     for (int t = 0; t < D && t < NT; ++t)
         if (Ib[t / KS] >= 0) { af[t] = ap[t / KS][(t % KS) * 4 * LD]; bf[t] = bp[t / KS][(t % KS) * 4 * LD]; }

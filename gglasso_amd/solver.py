@@ -29,11 +29,12 @@ ENGINE_OPTIONS = {}
 
 # Rank of the latent component in the model-selection tables (helper/model_selection.py:256, :638 call
 # numpy.linalg.matrix_rank(L), i.e. #{|lambda_i| > p * eps * max|lambda|}).  That rule fits an L rebuilt from an
-# eigendecomposition (null space at 1e-16 |L|), and every L this library RETURNS is one: below p = 128 the L-step is the LDS
-# Jacobi eigensolver, above it the per-iteration L-step is the sign iteration (null space at 4e-14 .. 7e-13 |L|, which numpy's
-# rule counts as rank: 22 for 6 at p = 500, tools/probe_rank_noise.py) and the solve's LAST L-step is redone as an
-# eigendecomposition before the solution is handed out (HipEngine.finalize_L, round 4).  So the rule is numpy's, on every
-# route; RANK_REL_TOL (rounds 1-3: a 1e-9 cut for the sign iteration's L) is kept for callers that look at an L mid-solve.
+# eigendecomposition (null space at 1e-16 |L|), and every L this library RETURNS is one: up to p = 8 (GGL_NS_MIN_P; rounds
+# 1-3: 128) the L-step is the LDS Jacobi eigensolver, above it the per-iteration L-step is the sign iteration (null space at
+# 4e-14 .. 7e-13 |L|, which numpy's rule counts as rank: 22 for 6 on a p = 500 SGL problem, tools/probe_rank_noise.py) and the
+# solve's LAST L-step is redone as an eigendecomposition before the solution is handed out (HipEngine.finalize_L, round 4).  So
+# the rule is numpy's, on every route; RANK_REL_TOL (rounds 1-3: a 1e-9 cut for the sign iteration's L) is kept for callers
+# that look at an L mid-solve.
 RANK_REL_TOL = 1e-9
 
 

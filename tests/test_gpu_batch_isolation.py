@@ -272,3 +272,69 @@ def test_marked_instance_with_finite_sums_is_reported(monkeypatch):
     res = quiet(ADMM_SGL_batch, S, np.full(K, 0.1), tol=1e-8, rtol=1e-8, max_iter=200, compact=False, verbose=True)
     assert res[1][1]['status'] == 'solver error' and res[1][1]['iterations'] == 3
     assert all(res[k][1]['status'] == 'optimal' for k in (0, 2, 3))
+
+
+@pytest.mark.parametrize("p,latent", [(40, False), (150, True)])
+def test_sgl_batch_c_loop_is_the_python_loop(p, latent):
+    """The batch's host loop in C (ggl_sgl_batch_run: per-point stopping test, rho rule, X rescale, device snapshots, one
+    download per stack) against the drivers' Python loop (verbose=True; the reference's arithmetic in NumPy, one download per
+    point): the same kernels in the same order under the same decisions -- statuses, iteration counts, rhos and every
+    solution array bit for bit (single_admm_solver.py:186-214; the walk: helper/model_selection.py:619-633)."""
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_SGL_batch
+    K = 7
+    S, _ = synth.make_problem("GGL", K, p, N=2 * p, seed=11 + p)
+    lam = np.logspace(-0.5, -1.5, K)
+    kw = dict(tol=1e-7, rtol=1e-6, max_iter=60, compact=False)
+    if latent:
+        kw.update(latent=True, mu1=0.7)
+    a = ADMM_SGL_batch(S, lam, **kw)
+    b = quiet(ADMM_SGL_batch, S, lam, verbose=True, **kw)
+    assert {i['status'] for _, i in a} <= {'optimal', 'max iterations reached', 'primal optimal', 'dual optimal'}
+    for (sa, ia), (sb, ib) in zip(a, b):
+        assert (ia['status'], ia['iterations'], ia['rho'], ia['carried']) == (ib['status'], ib['iterations'], ib['rho'], ib['carried'])
+        assert sa.keys() == sb.keys()
+        for nm in sa:
+            assert np.array_equal(sa[nm], sb[nm]), nm
+
+
+def test_mgl_batch_c_loop_is_the_python_loop():
+    """The same for G multiple-graph problems in one stack (ggl_mgl_batch_run; admm_solver.py:215-237, the grid walk
+    helper/model_selection.py:208-224), with compaction on both sides."""
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_MGL_batch
+    K, p = 3, 60
+    S, _ = synth.make_problem("GGL", K, p, N=2 * p, seed=5)
+    l1 = np.array([0.2, 0.1, 0.05, 0.2, 0.1, 0.05])
+    l2 = np.array([0.05, 0.05, 0.05, 0.01, 0.01, 0.01])
+    kw = dict(tol=1e-7, rtol=1e-6, max_iter=80)
+    a = ADMM_MGL_batch(S, l1, l2, "GGL", **kw)
+    b = quiet(ADMM_MGL_batch, S, l1, l2, "GGL", verbose=True, **kw)
+    for (sa, ia), (sb, ib) in zip(a, b):
+        assert (ia['status'], ia['iterations'], ia['rho']) == (ib['status'], ib['iterations'], ib['rho'])
+        for nm in ('Omega', 'Theta', 'L', 'X'):
+            assert np.array_equal(sa[nm], sb[nm]), nm
+
+
+def test_batch_run_without_snapshots_returns_at_the_first_event():
+    """ggl_sgl_batch_run with snap_ctx = NULL: the call comes back after the first iteration in which a live point converges
+    (status 1, fin_iter = it_base + that iteration), rho / last updated in place; the caller collects and calls again."""
+    from gglasso_amd import solver, synth
+    K, p = 5, 30
+    S, _ = synth.make_problem("GGL", K, p, N=2 * p, seed=2)
+    eye = np.repeat(np.eye(p)[None], K, axis=0)
+    eng = solver.HipEngine(S, eye, eye, np.zeros_like(eye))
+    try:
+        rho, last = np.ones(K), np.zeros((K, 4))
+        status, fin = np.zeros(K, dtype=np.int32), np.zeros(K, dtype=np.int32)
+        lam = np.array([0.5, 0.3, 0.2, 0.1, 0.05])
+        dims = np.full(K, (p * p + p) / 2)
+        n = eng.batch_run(500, rho, last, status, fin, 100, dims, 1e-7, 1e-5, True, lambda1=lam)
+        assert 1 <= n < 500 and np.count_nonzero(status == 1) >= 1 and np.all(status != 2)
+        done = status == 1
+        assert np.all(fin[done] == 100 + n) and np.all(fin[~done] == 0)
+        assert np.all(last[done, 0] <= last[done, 2]) and np.all(last[done, 1] <= last[done, 3])
+        n2 = eng.batch_run(500, rho, last, status, fin, 100 + n, dims, 1e-7, 1e-5, True, lambda1=lam)
+        assert n2 >= 1 and np.all(fin[done] == 100 + n)          # finished points are dragged along, untouched
+    finally:
+        eng.close()

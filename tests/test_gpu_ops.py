@@ -479,7 +479,10 @@ def _dev_lib():
     import os
     if not os.path.exists(_lib.DEV_LIB_PATH):
         pytest.skip("libggl_hip_dev.so not built (python -m gglasso_amd.build --dev)")
-    return _lib.load_dev()
+    try:
+        return _lib.load_dev()
+    except AttributeError as e:             # a development library older than the header: rebuild it
+        pytest.skip(f"libggl_hip_dev.so is stale ({e}): python -m gglasso_amd.build --dev")
 
 
 def _oz_emulate(A, B, S, dmax):

@@ -61,4 +61,21 @@ PY
 head -c 700 $O/bench_final.json
 rm -rf $R/gpurun_out/prof_$TAG/*/*.db 2>/dev/null
 find $R/gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete
+# (round 5) the batch drivers' loop in C, the K-sharded slabs incl. K = 16, the fused-W A/B, timelines by kernel
+{
+  for a in "--p 50 --points 20" "--p 64 --points 100"; do python tools/bench_grid.py $a --no-sequential 2>&1 | grep "^{"; done
+  python tools/time_batch.py --p 1000 --points 20 2>&1 | grep -v amdgpu.ids
+  python tools/time_batch.py --p 64 --points 100 2>&1 | grep -v amdgpu.ids
+  python tools/time_batch.py --p 50 --points 20 2>&1 | grep -v amdgpu.ids
+} > $O/grids.txt 2>&1
+GGL_BENCH_FORCE_DIST=1 python bench.py --workload ggl_K16_p500 --steps 30 --warmup 8 --regions 5 --no-cpu-baseline --comm capi 2>&1 | grep "^{" > $O/workload_ggl_K16_p500_sharded_1rank_rccl_capi.json
+{
+  echo "bench.py [--workload w] --opt fused_w=1|0 (GGL_OPT_FUSED_W), interleaved in one box: it/s"
+  for rep in 1 2; do for w in ggl_K32_p500 ggl_K8_p500 ggl_K4_p500 ggl_K20_p200; do for fw in 1 0; do
+    python bench.py --workload $w --steps 30 --warmup 8 --regions 5 --no-cpu-baseline --no-exact-region --opt fused_w=$fw 2>/dev/null | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w fused_w=$fw', round(d['value'],1), 'it/s', round(d['ms_per_step'],4), 'ms', (d.get('newton_schulz') or {}).get('pipeline_totals'))"
+  done; done; done
+} > $O/fused_w_ab.txt 2>&1
+bash tools/trace_iteration.sh ggl_K4_p500 > $O/timeline_K4.txt 2>&1
+bash tools/trace_iteration.sh ggl_K32_p500 > $O/timeline_headline_by_kernel.txt 2>&1
+rm -rf $R/gpurun_out/trace_*/*.db $R/gpurun_out/trace_*/*/*.db 2>/dev/null
 [ -z "$FAILED" ] || { echo "round_artifacts: sub-tools failed:$FAILED"; exit 1; }
