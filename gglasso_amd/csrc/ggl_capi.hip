@@ -74,6 +74,12 @@ struct ggl_ctx {
     int* info_h = nullptr;                        // pinned (K)
     double* gflag_h = nullptr;                    // pinned: the all-reduced speculation flag of a K-sharded step
     unsigned* arrive = nullptr;                   // device: arrival counter of a multi-row norm reduction that publishes seq
+    // K independent single problems at p <= 64 (ggl_sgl_batch_step): the LDS-resident Omega-step goes on with the Theta-step
+    // (omega_lds.hip, LdsSgl) -- sgl_req: what the caller asks omega_step for; sgl_done: the fused form was launched
+    const LdsSgl* sgl_req = nullptr;
+    bool sgl_done = false;
+    int* sgl_fail_h = nullptr;                    // pinned (K): instances the fused kernel could not serve
+    long long sgl_fused_calls = 0, sgl_fallback_instances = 0;
     bool nk_valid = false;
     // Newton-Schulz Omega-step (newton_schulz.hip)
     bool omega_ns = false;
@@ -479,6 +485,7 @@ static int ctx_alloc(ggl_ctx* c)
     PIN(c->norms_h, nl * sizeof(double), 2);
     PIN(c->info_h, (size_t)c->K * sizeof(int), 1);
     PIN(c->gflag_h, sizeof(double), 2);
+    PIN(c->sgl_fail_h, (size_t)c->K * sizeof(int), 2);
     DEV(c->arrive, 256);
     if (c->omega_ns) {
         for (int i = 0; i < 2; ++i) { DEV(c->nsYP[i], 2 * nb); }
@@ -1346,6 +1353,9 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         // raises validation flag 0, the Theta-step leaves the iterate alone and the step is repeated on the launch chain --
         // elsewhere the flag is read back after a stream synchronisation.
         c->lds_last = false;
+        const LdsSgl* sgl_req = c->sgl_req;         // (consumed here, whichever route the step takes)
+        c->sgl_req = nullptr;
+        c->sgl_done = false;
         if (c->lds_omega && c->p <= omega_lds_max_p() && c->ns_force == 0 && c->symm_variant < 0 && !c->chain_mode && !want_A && !resume) {
             const bool as_spec = allow_spec && c->spec_enable && !latent;
             if (c->lds_cool > 0) {
@@ -1353,19 +1363,39 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             } else if (as_spec || !only_spec) {
                 rc = lds_table(c);
                 if (rc) return rc;
+                // K independent single problems: the same workgroup goes on with the Theta-step and the stopping-test sums
+                LdsSgl sgl;
+                const bool fused = sgl_req && as_spec && c->seq_h && c->spin_wait && !c->prof_on;
+                // ... and takes its three parameters per instance (beta, lambda1 / rho, 1 / rho) straight from the pinned
+                // mirror the caller has just filled: no parameter copy in front of it, the iteration is ONE launch (the
+                // device flag stays zero in this form -- a miss clears it itself, sgl_fused_finish)
+                const bool no_copy = fused && !c->info_dirty && pending != nullptr;
                 CopySegs sg = first;
                 sg.add(c->spec_flag, nullptr, sizeof(int));
                 sg.add(c->spec_flag + ggl_ctx::MAX_PARTS - 1, nullptr, sizeof(int));
                 c->spec_flag_h[0] = c->spec_flag_h[ggl_ctx::MAX_PARTS - 1] = 0;
                 if (c->info_dirty) sg.add(c->info, nullptr, K * sizeof(int));
-                launch_copy_small(c->stream, sg);
+                if (!no_copy) launch_copy_small(c->stream, sg);
                 PB(c, GGL_PH_EIG_OMEGA);
                 unsigned long long* cnt = (unsigned long long*)(c->lds_tab + (size_t)OMEGA_LDS_MAXTAB * OMEGA_LDS_ENT);
+                if (fused) {
+                    sgl = *sgl_req;
+                    sgl.Theta = c->Theta; sgl.X = c->X; sgl.OmegaPrev = c->Om[c->cur];
+                    sgl.norms = c->norms_h; sgl.fail = c->sgl_fail_h;
+                    sgl.seq = c->seq_h; sgl.seq_val = c->seq_wait = ++c->seq_next; sgl.arrive = c->arrive;
+                    memset(c->sgl_fail_h, 0, K * sizeof(int));
+                    if (no_copy) {
+                        beta = c->par_h;
+                        sgl.l1K = c->par_h + K;
+                        sgl.invrhoK = c->par_h + 4 * (size_t)K;
+                    }
+                }
                 if (!launch_omega_lds(c->stream, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->Om[nxt], c->lds_tab,
                                       c->lds_ntab, c->lds_lnq, K, c->p, c->spec_flag, c->spec_flag_h, 0, cnt, c->bounds_h, nullptr,
-                                      c->lds_waves))
+                                      c->lds_waves, fused ? &sgl : nullptr))
                     return fail(GGL_E_HIP, "k_omega_lds: p = %d outside the kernel's range, or the LDS attribute was refused", c->p);
                 PE(c, GGL_PH_EIG_OMEGA);
+                c->sgl_done = fused;
                 HIPCHK(hipGetLastError());
                 c->last_parts = 1;
                 c->last_variant = 41;
@@ -1375,7 +1405,9 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 c->lds_last = true;
                 if (c->info_dirty) { memset(c->info_h, 0, K * sizeof(int)); c->info_dirty = false; }
                 if (as_spec) {
-                    c->spec_pending = true;        // validated by the caller after its stream sync (validate_spec)
+                    // validated by the caller after its stream sync (validate_spec) -- the fused SGL form is not speculative in
+                    // that sense: an instance outside the range is redone ALONE by the caller (sgl_fused_finish)
+                    c->spec_pending = !fused;
                     c->cw_pending = false;
                     c->dvo_valid = false;
                     c->cur = nxt;
@@ -2336,6 +2368,7 @@ extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lamb
 // ---- K independent single problems with their own rho / lambda1 (batched lambda path) ----------
 static int sgl_batch_step_impl(ggl_ctx* c, const double* rho, const double* lambda1, int latent, const double* mu1,
                                double* out_norms);
+static int sgl_fused_finish(ggl_ctx* c, const double* rho, const double* lambda1, double* out_norms);
 
 extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* lambda1, int latent, const double* mu1,
                                   double* out_norms)
@@ -2345,6 +2378,93 @@ extern "C" int ggl_sgl_batch_step(ggl_ctx* c, const double* rho, const double* l
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
     return sgl_batch_step_impl(c, rho, lambda1, latent, mu1, out_norms);
+}
+
+// After the fused launch of a batch of single problems (k_omega_lds<.., SGL>): wait for the sequence number its last workgroup
+// publishes; the rows of sums are in pinned memory.  Instances the kernel could not serve (condition number of W^2 + 4 beta I
+// above 300, non-finite data: their iterate is untouched) are redone ALONE on the launch chain -- a compact ctx of just those
+// instances (ggl_ctx_create_subset) runs the ordinary step and its Omega, Theta, X and sums are scattered back -- and the
+// kernel sits out the next few steps as after any miss.
+static int sgl_fused_finish(ggl_ctx* c, const double* rho, const double* lambda1, double* out_norms)
+{
+    const int K = c->K;
+    c->sgl_done = false;
+    c->sgl_fused_calls += 1;
+    c->norms_host = true;
+    double* rows = c->norms_h;
+    {
+        // (finish_norms' wait, without its validation of a speculative step: nothing here is speculative)
+        const unsigned long long want = c->seq_wait;
+        const volatile unsigned long long* sq = c->seq_h;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool waited = false;
+        for (unsigned spin = 1;; ++spin) {
+            if (*sq == want) { waited = true; break; }
+            __builtin_ia32_pause();
+            if ((spin & 0xfff) == 0 &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(GGL_SPIN_LIMIT_MS)) {
+                c->spin_timeouts += 1;
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        c->seq_wait = 0;
+        if (!waited) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (*sq != want) return fail(GGL_E_HIP, "fused SGL step: sequence number %llu not published (found %llu)", want, (unsigned long long)*sq);
+        }
+    }
+    c->norms_host = false;
+    memcpy(out_norms, rows, (size_t)K * GGL_NNORM * sizeof(double));
+    if (c->spec_flag_h[0] == 0) {
+        // every instance served: the bounds the kernel used are validated ones (what validate_spec keeps for the launch chain)
+        c->lds_cool_next = 4;
+        c->spec_have = true;
+        sanitize_bounds(c, c->bounds_h, c->par_h, 4.0);
+        for (int k = 0; k < K; ++k) { c->spec_c[k] = c->bounds_h[k]; c->spec_beta[k] = c->par_h[k]; }
+        return GGL_OK;
+    }
+    // ---- some instances fell outside the kernel's range ----
+    lds_missed(c);
+    c->spec_have = false;
+    HIPCHK(hipMemsetAsync(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int), c->stream));
+    for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) c->spec_flag_h[h] = 0;
+    std::vector<int> idx;
+    for (int k = 0; k < K; ++k) if (c->sgl_fail_h[k]) idx.push_back(k);
+    const int m = (int)idx.size();
+    if (m == 0) return fail(GGL_E_SOLVER, "fused SGL step: the flag is raised but no instance is marked");
+    c->sgl_fallback_instances += m;
+    // the compact ctx takes Omega_t as its current iterate: the fused launch has flipped `cur` already
+    c->cur ^= 1;
+    ggl_ctx* sub = nullptr;
+    int rc = ggl_ctx_create_subset(c, idx.data(), m, &sub);
+    c->cur ^= 1;
+    if (rc) return rc;
+    sub->lds_omega = false;
+    std::vector<double> r(m), l(m), on((size_t)m * GGL_NNORM);
+    for (int i = 0; i < m; ++i) { r[i] = rho[idx[i]]; l[i] = lambda1[idx[i]]; }
+    rc = sgl_batch_step_impl(sub, r.data(), l.data(), 0, nullptr, on.data());
+    int* didx = nullptr;
+    if (!rc && hipMalloc(&didx, m * sizeof(int)) != hipSuccess) rc = fail(GGL_E_HIP, "fused SGL step: allocation failed");
+    if (!rc) {
+        const size_t pp = (size_t)c->p * c->p;
+        hipError_t e = hipMemcpyAsync(didx, idx.data(), m * sizeof(int), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            launch_copy_instances(c->stream, c->Om[c->cur], sub->Om[sub->cur], didx, m, pp, true);
+            launch_copy_instances(c->stream, c->Theta, sub->Theta, didx, m, pp, true);
+            launch_copy_instances(c->stream, c->X, sub->X, didx, m, pp, true);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(GGL_E_HIP, "fused SGL step: %s", hipGetErrorString(e));
+        for (int i = 0; i < m && !rc; ++i) {
+            memcpy(out_norms + (size_t)idx[i] * GGL_NNORM, on.data() + (size_t)i * GGL_NNORM, GGL_NNORM * sizeof(double));
+            if (sub->failed && sub->failed[i]) mark_failed(c, idx[i]);
+        }
+    }
+    if (didx) (void)hipFree(didx);
+    (void)ggl_ctx_destroy(sub);
+    return rc;
 }
 
 static int sgl_batch_step_impl(ggl_ctx* c, const double* rho, const double* lambda1, int latent, const double* mu1,
@@ -2367,8 +2487,20 @@ static int sgl_batch_step_impl(ggl_ctx* c, const double* rho, const double* lamb
     for (int attempt = 0; attempt < 2; ++attempt) {
         // (first attempt: the LDS-resident Omega-step may run unvalidated; when an instance falls outside its range the
         // Theta-step has left the iterate alone and the step is repeated on the launch chain)
+        LdsSgl req;
+        if (attempt == 0 && !latent) {
+            // p <= 64: ask for the fused form -- Omega-step, Theta-step, dual update and sums in ONE launch (omega_lds.hip)
+            req.l1K = c->par + K;
+            req.mask = c->has_maskK ? c->maskK : (c->has_mask ? c->mask : nullptr);
+            req.mask_stride = c->has_maskK ? (size_t)c->p * c->p : 0;
+            req.invrhoK = c->par + 4 * (size_t)K;
+            req.pk = c->has_dims ? c->inst_pk : nullptr;
+            c->sgl_req = &req;
+        }
         rc = attempt == 0 ? omega_step(c, latent, &sg, /*allow_spec=*/!latent) : omega_step(c, latent, nullptr, false);
+        c->sgl_req = nullptr;
         if (rc) return rc;
+        if (c->sgl_done) return sgl_fused_finish(c, rho, lambda1, out_norms);
         double* Om = c->Om[c->cur];
         double* OmPrev = c->Om[c->cur ^ 1];
         PB(c, GGL_PH_THETA);

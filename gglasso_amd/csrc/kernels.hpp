@@ -185,10 +185,21 @@ static constexpr int OMEGA_LDS_MAXTAB = 160;     // q^-idx with q = 1.02 down to
 int omega_lds_max_p();
 // units: two counters {products, steps} summed over the instances (or null); cbound (K): the bound each instance used
 int omega_lds_build_table(double tol, int degrees, double* table_h, int max_entries, double* lnq_out);
+// SGL form (sgl != null, L == null): the workgroup goes on with the instance's Theta-step, dual update and stopping-test sums
+// (k_theta_sgl's arithmetic) -- Theta / X are the stacks it READS for W and WRITES afterwards (sg.Theta, sg.X: the same stacks),
+// OmegaPrev the previous iterate, l1K (K) lambda1 / rho or mask (+ mask_stride: 0 shared, p*p per instance) with invrhoK (K),
+// pk (K, or null) the instances' own dimensions; norms (K,5) and fail (K ints, zeroed by the caller) in pinned memory; seq /
+// seq_val / arrive as launch_reduce_partials.
+struct LdsSgl {
+    double* Theta = nullptr; double* X = nullptr; const double* OmegaPrev = nullptr;
+    const double* l1K = nullptr; const double* mask = nullptr; size_t mask_stride = 0; const double* invrhoK = nullptr;
+    const int* pk = nullptr; double* norms = nullptr; int* fail = nullptr;
+    unsigned long long* seq = nullptr; unsigned long long seq_val = 0; unsigned* arrive = nullptr;
+};
 bool launch_omega_lds(hipStream_t st, const double* Theta, const double* L, const double* X, const double* S, const double* betaK,
                       double* Omega, const double* table, int ntab, double lnq, int K, int p, int* flag,
                       int* flag_host, int flag_slot, unsigned long long* units, double* cbound, long long* dbg = nullptr,
-                      int waves = 0);
+                      int waves = 0, const LdsSgl* sgl = nullptr);
 // gemm_i8.hip: error-free split products on the INT8 matrix cores
 void launch_slice_i8(hipStream_t st, const double* A, const double* scaleK, int8_t* out, int K, int p, int S, int* flag,
                      size_t sstride = 0);

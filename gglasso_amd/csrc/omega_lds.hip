@@ -150,15 +150,34 @@ __device__ __forceinline__ void lds_symm(const double* A, const double* B, doubl
     if (ts && threadIdx.x == 0) ts[4] = (long long)wall_clock64();
 }
 
+// thread 0 of a workgroup of the SGL form: this instance's row (or its failure mark) is written -- make it visible to the host,
+// count the workgroup in, and as the last one publish the sequence number (cf. k_reduce_partials)
+__device__ __forceinline__ void lds_sgl_arrive(const LdsSgl& sg)
+{
+    __threadfence_system();
+    const unsigned prev = atomicAdd(sg.arrive, 1u);
+    if (prev == gridDim.x - 1) {
+        *sg.arrive = 0u;
+        __threadfence_system();
+        if (sg.seq) *(volatile unsigned long long*)sg.seq = sg.seq_val;
+    }
+}
+
 // table entry: { n, deg[OMEGA_LDS_MAXSTEP], (pad to 8), coef[OMEGA_LDS_MAXSTEP][6] = {t0..t4, l_after} } = OMEGA_LDS_ENT doubles
-template <int PT, int NW>
+// SGL (round 5): K INDEPENDENT single problems (single_admm_solver.py:157-214) -- the workgroup that holds an instance's Omega
+// in LDS goes straight on with that instance's Theta-step, dual update and the five sums of the stopping test
+// (prox_od_1norm, solver/ggl_helper.py:16-27; single_admm_solver.py:169, :178, :277-291; k_theta_sgl's arithmetic), writes the
+// row of sums to pinned memory and, as the last workgroup to arrive, the sequence number the host polls: a batch iteration is
+// this ONE kernel behind its parameter copy instead of four dependent launches.  An instance outside the kernel's range marks
+// itself (sg.fail) and leaves its iterate alone -- the caller redoes exactly those instances on the launch chain.
+template <int PT, int NW, bool SGL>
 __global__ __launch_bounds__(64 * NW) void k_omega_lds(const double* __restrict__ Theta, const double* __restrict__ Lm,
                                                    const double* __restrict__ X, const double* __restrict__ S,
                                                    const double* __restrict__ betaK, double* __restrict__ Omega,
                                                    const double* __restrict__ table, int ntab,
                                                    double lnq, int p, int* __restrict__ flag, int* __restrict__ flag_host,
                                                    int flag_slot, unsigned long long* __restrict__ units,
-                                                   double* __restrict__ cbound, long long* __restrict__ dbg)
+                                                   double* __restrict__ cbound, long long* __restrict__ dbg, LdsSgl sg)
 {
     constexpr int LD = LdsDim<PT>::LD, NE = LdsDim<PT>::NE, NTH = 64 * NW, NIT = (NE + NTH - 1) / NTH;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -177,6 +196,10 @@ __global__ __launch_bounds__(64 * NW) void k_omega_lds(const double* __restrict_
     // W = ((Theta - L) - X) - beta S from the LOWER triangle, mirrored (what numpy.linalg.eigh reads; k_form_W_sym's arithmetic).
     // Every thread owns NIT elements of the triangle: all their loads are issued before the first is used (row-contiguous, no
     // upper-triangle traffic), and the values stay in registers until the final Omega = (W + sqrt(c) Y) / 2.
+    // (SGL form: Theta and X are also WRITTEN by this kernel, through sg -- they are read through sg as well, never through
+    // the __restrict__ parameters)
+    const double* Thr = SGL ? sg.Theta : Theta;
+    const double* Xr = SGL ? sg.X : X;
     double wreg[NIT];
     {
         double th[NIT], xx[NIT], ss[NIT], ll[NIT];
@@ -186,9 +209,9 @@ __global__ __launch_bounds__(64 * NW) void k_omega_lds(const double* __restrict_
             tri_index<PT>(tid + NTH * it, i, j);
             const bool in = (tid + NTH * it) < NE && i < p;
             const size_t o = off + (size_t)i * p + j;
-            th[it] = in ? Theta[o] : 0.0;
+            th[it] = in ? Thr[o] : 0.0;
             ll[it] = (in && Lm) ? Lm[o] : 0.0;
-            xx[it] = in ? X[o] : 0.0;
+            xx[it] = in ? Xr[o] : 0.0;
             ss[it] = in ? S[o] : 0.0;
         }
 #pragma unroll
@@ -262,7 +285,11 @@ __global__ __launch_bounds__(64 * NW) void k_omega_lds(const double* __restrict_
     const double* ent = table + (size_t)min(idx, ntab - 1) * OMEGA_LDS_ENT;
     const int n = bad ? 0 : (int)ent[0];
     if (n < 1 || n > OMEGA_LDS_MAXSTEP) {
-        if (tid == 0) { atomicOr(flag + flag_slot, 1); flag_host[flag_slot] = 1; }
+        if (tid == 0) {
+            atomicOr(flag + flag_slot, 1);
+            flag_host[flag_slot] = 1;
+            if (SGL) { sg.fail[k] = 1; lds_sgl_arrive(sg); }
+        }
         return;
     }
     if (tid == 0 && cbound) cbound[k] = c;
@@ -372,9 +399,51 @@ __global__ __launch_bounds__(64 * NW) void k_omega_lds(const double* __restrict_
     }
     __syncthreads();
     GGL_TS(7);
-    for (int e = tid; e < PT * PT; e += NTH) {
-        const int i = e / PT, j = e - i * PT;
-        if (i < p && j < p) Omega[off + (size_t)i * p + j] = wb[i * LD + j];
+    if (!SGL) {
+        for (int e = tid; e < PT * PT; e += NTH) {
+            const int i = e / PT, j = e - i * PT;
+            if (i < p && j < p) Omega[off + (size_t)i * p + j] = wb[i * LD + j];
+        }
+    } else {
+        // Theta = prox_od_1norm(Omega + X, lambda1 / rho), X += Omega - Theta, the five sums over the instance's own block
+        // (in place: every element is read and written by its own thread only, and the reads for W are long done)
+        double* ThW = sg.Theta;
+        double* XW = sg.X;
+        const int pin = sg.pk ? sg.pk[k] : p;
+        const double* mask = sg.mask ? sg.mask + (size_t)k * sg.mask_stride : nullptr;
+        const double lk = mask ? 0.0 : sg.l1K[k];
+        const double inv_rho = mask ? sg.invrhoK[k] : 0.0;
+        double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
+        for (int e = tid; e < PT * PT; e += NTH) {
+            const int i = e / PT, j = e - i * PT;
+            if (i < p && j < p) {
+                const size_t o = (size_t)i * p + j;
+                const double om = wb[i * LD + j];
+                const double x = XW[off + o];
+                const double v = om + x;                                   // (k_theta_sgl: (om + l) + x with l = 0)
+                const double thr = mask ? inv_rho * mask[o] : lk;
+                const double th = (i == j) ? v : soft(v, thr);
+                const double xn = (x + om) - th;                           // single_admm_solver.py:178
+                const double dp = om - sg.OmegaPrev[off + o];
+                Omega[off + o] = om;
+                ThW[off + o] = th;
+                XW[off + o] = xn;
+                if (i < pin && j < pin) {
+                    acc[0] += om * om;
+                    acc[1] += th * th;
+                    acc[2] += xn * xn;
+                    acc[3] += (om - th) * (om - th);
+                    acc[4] += dp * dp;
+                }
+            }
+        }
+        __syncthreads();                                 // (part[] is free again: the bound is long done)
+        block_sum<GGL_NNORM>(acc, part);
+        if (tid == 0) {
+#pragma unroll
+            for (int v = 0; v < GGL_NNORM; ++v) sg.norms[(size_t)k * GGL_NNORM + v] = acc[v];
+            lds_sgl_arrive(sg);
+        }
     }
     GGL_TS(8);
     if (dbg && k == 0 && tid == 0) dbg[9] = nprod;
@@ -413,17 +482,26 @@ int omega_lds_build_table(double tol, int degrees, double* table_h, int max_entr
 
 bool launch_omega_lds(hipStream_t st, const double* Theta, const double* L, const double* X, const double* S, const double* betaK,
                       double* Omega, const double* table, int ntab, double lnq, int K, int p, int* flag,
-                      int* flag_host, int flag_slot, unsigned long long* units, double* cbound, long long* dbg, int waves)
+                      int* flag_host, int flag_slot, unsigned long long* units, double* cbound, long long* dbg, int waves,
+                      const LdsSgl* sgl)
 {
+    const LdsSgl sg = sgl ? *sgl : LdsSgl();
     // waves: 4 or 8 per workgroup, 0 = by size (two waves per SIMD from PT = 48 on, where a wave has more than one block)
 #define GGL_OL(PT, NW)                                                                                                          \
     do {                                                                                                                        \
         const size_t lds = ((size_t)4 * PT * LdsDim<PT>::LD + PT + 8 + 2 * 64 * NW) * sizeof(double);                               \
         /* per launch: the attribute belongs to the current device's copy of the kernel */                            \
-        if (hipFuncSetAttribute((const void*)k_omega_lds<PT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-            return false;                                                                                                        \
-        hipLaunchKernelGGL((k_omega_lds<PT, NW>), dim3(K), dim3(64 * NW), lds, st, Theta, L, X, S, betaK, Omega, table, ntab, lnq, p, \
-                           flag, flag_host, flag_slot, units, cbound, dbg);                                                          \
+        if (sgl) {                                                                                                              \
+            if (hipFuncSetAttribute((const void*)k_omega_lds<PT, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+                return false;                                                                                                    \
+            hipLaunchKernelGGL((k_omega_lds<PT, NW, true>), dim3(K), dim3(64 * NW), lds, st, Theta, L, X, S, betaK, Omega, table, ntab, lnq, p, \
+                               flag, flag_host, flag_slot, units, cbound, dbg, sg);                                                  \
+        } else {                                                                                                                 \
+            if (hipFuncSetAttribute((const void*)k_omega_lds<PT, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+                return false;                                                                                                    \
+            hipLaunchKernelGGL((k_omega_lds<PT, NW, false>), dim3(K), dim3(64 * NW), lds, st, Theta, L, X, S, betaK, Omega, table, ntab, lnq, p, \
+                               flag, flag_host, flag_slot, units, cbound, dbg, sg);                                                  \
+        }                                                                                                                        \
     } while (0)
     const bool w8 = waves == 8 || (waves == 0 && p > 32);
     if (p <= 16) GGL_OL(16, 4);

@@ -187,8 +187,10 @@ def test_an_instance_outside_the_range_repeats_the_step_on_the_launch_chain(engi
 
 
 def test_batched_sgl_path_unvalidated_launch_and_repeat(engines):
-    """ggl_sgl_batch_step: the kernel runs unvalidated, the Theta kernel takes the flag; one badly scaled point of the batch
-    sends the WHOLE batch's step to the launch chain and changes nothing for the others."""
+    """ggl_sgl_batch_step at p <= 64 (round 5): ONE launch per iteration -- the workgroup that holds an instance's Omega in LDS
+    goes on with its Theta-step, dual update and stopping-test sums (k_omega_lds<.., SGL>).  A badly scaled point of the
+    batch marks itself and leaves its iterate alone; it is redone ALONE on the launch chain (a compact ctx of the marked
+    instances, scattered back), the others' step stands, and the kernel sits out the next steps as after any miss."""
     from gglasso_amd import batch, solver
     p = 30
     S, _ = _ggl(1, p, 11)
