@@ -2706,10 +2706,8 @@ static int batch_rescale(ggl_ctx* c, const double* fac, int n, int group)
     double* h = c->par_h + 5 * (size_t)c->K;
     for (int g = 0; g < n; ++g)
         for (int k = 0; k < group; ++k) h[(size_t)g * group + k] = fac[g];
-    CopySegs sg;
-    sg.add(c->par + 5 * (size_t)c->K, h, c->K * sizeof(double));
-    launch_copy_small(c->stream, sg);
-    launch_scale_batch(c->stream, c->X, c->par + 5 * (size_t)c->K, c->K, c->p);
+    // (the kernel reads its K factors from the pinned slot itself: one launch, no copy in front of it)
+    launch_scale_batch(c->stream, c->X, h, c->K, c->p);
     HIPCHK(hipGetLastError());
     return GGL_OK;
 }
