@@ -217,6 +217,11 @@ struct ggl_ctx {
     double* cwvec[2] = {nullptr, nullptr};
     int cw_cur = 0;
     bool cw_have = false, cw_warm = true, cw_pending = false, pre_cw_pending = false;
+    // the same for the L-step's norm bound (round 5, GGL_OPT_RANK_CW): |C|_2^2 = lambda_max(C C) <= the Collatz-Wielandt ratio of
+    // |C C| for a vector carried across ADMM iterations (lazy buffers, one pair)
+    double* cwvecL[2] = {nullptr, nullptr};
+    int cwL_cur = 0;
+    bool cwL_have = false, rank_cw = false;      // (measured at C4: no gain, see include/ggl_hip.h -- off)
     // bound partials written by the epilogue of the B' product launch (no norm pass over B'): row sums per tile column,
     // Frobenius shares per tile, block maxima of the row sums; merge cells of the Collatz-Wielandt kernel
     double *rowpart = nullptr, *fropart = nullptr, *infpart = nullptr;
@@ -614,6 +619,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_OMEGA_LDS: c->lds_omega = v != 0.0; c->lds_waves = (v == 4.0 || v == 8.0) ? (int)v : 0; break;
         case GGL_OPT_EARLY_PART: c->early_part = v != 0.0; break;
         case GGL_OPT_FUSED_W: c->fused_w = v != 0.0; break;
+        case GGL_OPT_RANK_CW: c->rank_cw = v != 0.0; break;
         case GGL_OPT_PART_PRIORITY: {
             if (v != 0.0 && v != 1.0 && v != 2.0) return fail(GGL_E_ARG, "bad argument: GGL_OPT_PART_PRIORITY is 0, 1 or 2");
             if (!c->omega_ns || (int)v == c->part_priority) break;
@@ -649,6 +655,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
     }
     c->spec_have = false;      // a schedule built under other settings is not reused
     c->cw_have = false;
+    c->cwL_have = false;
     return GGL_OK;
 }
 
@@ -685,6 +692,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_OMEGA_LDS: *value = c->lds_omega ? (c->lds_waves ? c->lds_waves : 1) : 0; break;
         case GGL_OPT_EARLY_PART: *value = c->early_part; break;
         case GGL_OPT_FUSED_W: *value = c->fused_w; break;
+        case GGL_OPT_RANK_CW: *value = c->rank_cw; break;
         case GGL_OPT_PART_PRIORITY: *value = c->part_priority; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
@@ -766,7 +774,7 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     }
     // (the rocBLAS handle is the process-wide one of blas_handle(): never destroyed here)
     // lazily allocated buffers, each its own allocation
-    double* lazy[] = {c->partials_own, c->nsNX, c->lds_tab, c->snapT, c->snapL, c->Lam[0], c->Lam[1], c->X1, c->Ckeep_alloc, c->snapC, c->snapOm, c->snapX, c->defl_G,
+    double* lazy[] = {c->partials_own, c->nsNX, c->lds_tab, c->snapT, c->snapL, c->Lam[0], c->Lam[1], c->X1, c->Ckeep_alloc, c->snapC, c->snapOm, c->snapX, c->cwvecL[0], c->cwvecL[1], c->defl_G,
                       c->defl_work, c->defl_meta, c->maskK};
     for (double* b : lazy)
         if (b) (void)hipFree(b);
@@ -884,6 +892,7 @@ extern "C" int ggl_set_S_ex(ggl_ctx* c, const double* S, int period)
     ARGCHK(c && S, "ctx, S");
     c->spec_have = false;
     c->cw_have = false;
+    c->cwL_have = false;
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
     int rc = upload_stack(c, c->S, S, period);
@@ -918,7 +927,8 @@ extern "C" int ggl_set_state_ex(ggl_ctx* c, const double* Omega, const double* T
     ARGCHK(c, "ctx");
     const int pr[4] = {periods ? periods[0] : 0, periods ? periods[1] : 0, periods ? periods[2] : 0, periods ? periods[3] : 0};
     c->spec_have = false;      // bounds of another iterate say nothing about this one
-    c->cw_have = false;        // (any positive vector would do, but every solve shall start the same way)
+    c->cw_have = false;
+    c->cwL_have = false;        // (any positive vector would do, but every solve shall start the same way)
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
     const size_t nb = c->n * sizeof(double);
@@ -971,6 +981,7 @@ extern "C" int ggl_state_snapshot(ggl_ctx* c, int restore)
     c->state_symmetric = c->snap_symmetric;
     c->spec_have = false;
     c->cw_have = false;
+    c->cwL_have = false;
     c->l_ns = false;
     return GGL_OK;
 }
@@ -1895,7 +1906,21 @@ static int rank_step_impl(ggl_ctx* c)
         launch_symm(c->stream, c->W, c->W, c->nsT, nullptr, nullptr, c->coef, K, c->p, c->symm_variant, nullptr, c->rowpart,
                     c->fropart);
         launch_bound_rows(c->stream, c->rowpart, bT, K, c->p, c->nbrow, c->infpart);
-        launch_bound_sqrt_inf_fro(c->stream, c->infpart, bound_rows_blocks(c->p), c->fropart, bT * (bT + 1) / 2, K, c->bounds_h);
+        if (c->rank_cw) {
+            // one pass over P for the Collatz-Wielandt ratio max_i (|P| v)_i / v_i >= rho(|P|) >= |C|_2^2, v carried across ADMM
+            // iterations (any positive v keeps it a bound; the kernel leaves |P| v / |P|_inf for the next call): the row-sum
+            // bound is ~2.4x the spectral radius on an ADMM run's C, this one settles near 1.1x -- and every factor 2.6 of
+            // slack is a cubic step of the sign iteration (the Omega-step's bound of B' has done this since round 2)
+            if (!c->cwvecL[0])
+                for (double*& b : c->cwvecL) HIPCHK(hipMalloc(&b, (size_t)K * c->p * sizeof(double)));
+            launch_cw_final(c->stream, c->nsT, c->nbrow, K, c->p, c->infpart, c->fropart, bT * (bT + 1) / 2, c->cwmax, c->cwcnt,
+                            c->bounds_h, nullptr, nullptr, nullptr, 0, c->cwL_have ? c->cwvecL[c->cwL_cur] : nullptr,
+                            c->cwvecL[c->cwL_cur ^ 1]);
+            c->cwL_cur ^= 1;
+            c->cwL_have = true;
+        } else {
+            launch_bound_sqrt_inf_fro(c->stream, c->infpart, bound_rows_blocks(c->p), c->fropart, bT * (bT + 1) / 2, K, c->bounds_h);
+        }
         c->rank_units += 1.0;
         have_P = true;
     } else {
@@ -2886,6 +2911,7 @@ extern "C" int ggl_reset_instance(ggl_ctx* c, int k)
     HIPCHK(hipGetLastError());
     c->spec_have = false;
     c->cw_have = false;
+    c->cwL_have = false;
     // (l_ns stays: it says where the OTHER instances' L came from -- a point that converges in the iteration another one
     // fails in is still snapshotted with its C and rebuilt by ggl_finalize_L)
     return GGL_OK;
@@ -2924,6 +2950,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->state_symmetric = src->state_symmetric;
     c->S_symmetric = src->S_symmetric;
     c->fused_w = src->fused_w;
+    c->rank_cw = src->rank_cw;
     c->step_latent = src->step_latent;
     c->nk_valid = false;
     if (src->l_ns && src->Ckeep && src->Ckeep_beta) {

@@ -136,6 +136,12 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_FUSED_W 26         /* [1] with GGL_OPT_EARLY_PART, GGL, exactly symmetric state and S: the Theta kernel that precedes an early
                                       first part also writes that part's W = Theta - X - beta S (admm_solver.py:180) from the values it
                                       holds -- one pass over three stacks and one launch per part less (round 5) */
+#define GGL_OPT_RANK_CW 27         /* [0] L-step (sign iteration): the norm bound |C|_2 from a Collatz-Wielandt pass over C C with a vector
+                                      carried across ADMM iterations (as the Omega-step's bound) instead of sqrt(min(|C C|_inf, |C C|_F)).
+                                      Built and measured in round 5 (FGL K=50, p=500, latent): the schedule is a step function of the
+                                      resolution -- 22.0 products with either bound at GGL_OPT_RANK_L0_DEFLATE = 2e-3, 21.4 / 20.8 at
+                                      4e-3 where 3-4x as many instances need the continuation -- and the pass costs 25 us: 211 it/s
+                                      without, 202 with.  Off. */
 #define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
                                       2 = with the lowest stream priority (streams of another priority never share a hardware queue with
                                       the ctx's main stream) */
