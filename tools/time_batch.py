@@ -25,6 +25,10 @@ def timed(name, fn):
         return r
     return w
 E = solver.HipEngine
+from gglasso_amd import _lib as _L
+_lib = _L.load()
+for nm in ("ggl_ctx_create", "ggl_set_S_ex", "ggl_set_state_ex", "ggl_ctx_set_option", "ggl_ctx_destroy"):
+    setattr(_lib, nm, timed("C:" + nm, getattr(_lib, nm)))
 for nm in ("batch_run", "subset", "snapshots", "snapshot_state_from", "close", "__init__", "finalize_L", "selection_stats"):
     setattr(E, nm, timed(nm, getattr(E, nm)))
 batch.ADMM_SGL_batch(S, lam[:2], Omega_0=eye, X_0=eye, max_iter=3)
