@@ -167,12 +167,6 @@ def load():
     if "torch" not in sys.modules and os.environ.get("GGL_TORCH_FIRST", "1") != "0":
         try:
             import torch  # noqa: F401
-            # importing torch leaves ~10^6 long-lived objects behind; every full collection of Python's cyclic GC walks them
-            # (20-30 ms), and a batch driver that returns a few hundred arrays triggers one per call -- measured as "22 ms in
-            # HipEngine.__init__" of every 100-point grid after the first (tools/time_batch.py).  Objects that exist now are
-            # module-level state of the import: park them in the permanent generation (gc.freeze, the documented use)
-            import gc
-            gc.freeze()
         except Exception:  # noqa: BLE001  (torch absent or broken: the single-GPU path does not need it)
             pass
     _lib = _bind(ctypes.CDLL(LIB_PATH), _SIGNATURES)

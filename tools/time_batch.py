@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Where a batched grid's wall time goes (dev tool): the C loop (HipEngine.batch_run), compactions (subset), the final download
+"""(Note: this tool's wrappers keep engines alive past their close(), so from the second repetition on every ctx creates
+fresh streams -- ~6 ms each, "__init__ 22 ms" -- which plain repeated calls do not: tools/time_init2.py.)
+Where a batched grid's wall time goes (dev tool): the C loop (HipEngine.batch_run), compactions (subset), the final download
 of the snapshot stacks, the rest.   tools/time_batch.py [--p 1000] [--points 20] [--compact 0|1]"""
 import argparse, os, sys, time
 import numpy as np
