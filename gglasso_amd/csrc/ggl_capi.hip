@@ -98,6 +98,10 @@ struct ggl_ctx {
     static constexpr int MAX_PARTS = 4;
     hipStream_t streamx[MAX_PARTS - 1] = {};   // extra streams: the parts of the batch run their
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS - 1] = {};   // Newton-Schulz launch sequences concurrently
+    // GGL_OPT_BOUND_SIDE: the bound kernels that validate a speculative step's assumed bound run on a side stream beside the
+    // chain's first products (per part: fork after B', join before the first launch that overwrites B')
+    int bound_side = 0;                        // 0 off, 1 on, 2 by regime (two concurrent parts of a large batch)
+    hipEvent_t ev_bfork[MAX_PARTS] = {}, ev_bjoin[MAX_PARTS] = {};
     // Pipelining across iterations: right after an iteration has been validated, ggl_admm_step launches the NEXT iteration's
     // (speculative) Omega-step chain for the same beta before it returns, so the GPU works through the host's round trip
     // (norms -> rho rule -> next call).  The chain only writes scratch and Omega[cur^1]; it is consumed by the next call if
@@ -620,6 +624,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_EARLY_PART: c->early_part = v != 0.0; break;
         case GGL_OPT_FUSED_W: c->fused_w = v != 0.0; break;
         case GGL_OPT_RANK_CW: c->rank_cw = v != 0.0; break;
+        case GGL_OPT_BOUND_SIDE: c->bound_side = (int)v; break;
         case GGL_OPT_PART_PRIORITY: {
             if (v != 0.0 && v != 1.0 && v != 2.0) return fail(GGL_E_ARG, "bad argument: GGL_OPT_PART_PRIORITY is 0, 1 or 2");
             if (!c->omega_ns || (int)v == c->part_priority) break;
@@ -693,6 +698,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_EARLY_PART: *value = c->early_part; break;
         case GGL_OPT_FUSED_W: *value = c->fused_w; break;
         case GGL_OPT_RANK_CW: *value = c->rank_cw; break;
+        case GGL_OPT_BOUND_SIDE: *value = c->bound_side; break;
         case GGL_OPT_PART_PRIORITY: *value = c->part_priority; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
@@ -810,6 +816,10 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
         for (int e = 0; e < 2; ++e)
             if (c->ev_early[q][e]) (void)hipEventDestroy(c->ev_early[q][e]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < ggl_ctx::MAX_PARTS; ++i) {
+        if (c->ev_bfork[i]) (void)hipEventDestroy(c->ev_bfork[i]);
+        if (c->ev_bjoin[i]) (void)hipEventDestroy(c->ev_bjoin[i]);
+    }
     for (int i = 0; i < ggl_ctx::MAX_PARTS - 1; ++i) {
         if (c->streamx[i]) { (void)hipStreamSynchronize(c->streamx[i]); pool_stream_release(c->device, c->streamx[i], c->part_priority == 0); }
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -1602,6 +1612,29 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             if (want_A) continue;
             if (resume && h == 0) PB(c, GGL_PH_EIG_OMEGA);
             // ---- the rest: bound of this iteration's A' (validation of the assumed one), products, Omega ----
+            // speculative chain of a small launch sequence: the two bound kernels only VALIDATE (the schedule was built from
+            // the previous iteration's bound), so they need not sit in the chain's dependent sequence -- side stream, beside
+            // the first products, joined before B' is overwritten (ns_run) -- where the chip has room (one or two parts of few
+            // tiles; at the headline both parts are bound by throughput and round 3 measured this slower)
+            hipStream_t sb = sh;
+            hipEvent_t bfree = nullptr;
+            const int side_slot = nh + h - 1;                      // part streams 0 .. nh-2 are taken by the parts
+            // measured (profiles/r5_bound_side.txt): three interleaved pairs per workload in one box -- headline (two parts of
+            // 16) +3.0 / +1.5 / +2.2 %; K = 16 and K = 4 within noise; K = 8 (two parts of 4) -1.5 %, C3 -5.5 %, (64,100) -5 %,
+            // (32,128) -4.6 %: a cross-stream wait costs more than the small launches hide -- and six more headline pairs in a
+            // second box: -2.4 / +0.8 / -1.6 % with 50-step regions, -0.1 / +0.8 / +3.1 % with the driver's 20-step regions.
+            // Nine pairs, +0.8 % on average with a run-to-run scatter of +-2 %: not a result.  Off by default.
+            const bool side_on = c->bound_side == 1 || (c->bound_side == 2 && nh > 1 && K >= 16);
+            if (side_on && spec && btile && !c->fused_cw && side_slot < ggl_ctx::MAX_PARTS - 1 && c->streamx[side_slot]) {
+                if (!c->ev_bfork[h]) {
+                    HIPCHK(hipEventCreateWithFlags(&c->ev_bfork[h], hipEventDisableTiming));
+                    HIPCHK(hipEventCreateWithFlags(&c->ev_bjoin[h], hipEventDisableTiming));
+                }
+                sb = c->streamx[side_slot];
+                HIPCHK(hipEventRecord(c->ev_bfork[h], sh));
+                HIPCHK(hipStreamWaitEvent(sb, c->ev_bfork[h], 0));
+                bfree = c->ev_bjoin[h];
+            }
             if (btile) {
                 if (c->fused_cw) {
                     launch_bound_cw(sh, Bp, rowp, bT, Kh[h], c->p, c->nbrow + (size_t)k0 * c->p, frop, bT * (bT + 1) / 2,
@@ -1611,8 +1644,8 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                                     c->cw_warm ? c->cwvec[c->cw_cur ^ 1] + (size_t)k0 * c->p : nullptr);
                 } else {
                 const int nib = bound_rows_blocks(c->p);
-                launch_bound_rows(sh, rowp, bT, Kh[h], c->p, c->nbrow + (size_t)k0 * c->p, c->infpart + (size_t)k0 * nib);
-                launch_cw_final(sh, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p, c->infpart + (size_t)k0 * nib, frop,
+                launch_bound_rows(sb, rowp, bT, Kh[h], c->p, c->nbrow + (size_t)k0 * c->p, c->infpart + (size_t)k0 * nib);
+                launch_cw_final(sb, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p, c->infpart + (size_t)k0 * nib, frop,
                                 bT * (bT + 1) / 2, c->cwmax + k0, c->cwcnt + k0, c->bounds_h + k0, spec ? c->cuse + k0 : nullptr,
                                 spec ? c->spec_flag : nullptr, spec ? c->spec_flag_h : nullptr, h,
                                 (c->cw_warm && c->cw_have) ? c->cwvec[c->cw_cur] + (size_t)k0 * c->p : nullptr,
@@ -1627,10 +1660,11 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 launch_bound_final(sh, nb2, nbc, nbb, Kh[h], c->bounds_h + k0, 0, spec ? c->cuse + k0 : nullptr,
                                    spec ? c->spec_flag + h : nullptr, spec ? c->spec_flag_h + h : nullptr);
             }
+            if (bfree) HIPCHK(hipEventRecord(bfree, sb));
             if (spec) {
                 ns_run(sh, plans[h], c->coef + h * region, start_base_d + 5 * k0, c->W + k0 * pp, c->nsYP[0] + k0 * pp,
                        c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kh[h], c->p,
-                       var_parts, nh > 1 ? c->n : 0, fused[h] != nullptr);
+                       var_parts, nh > 1 ? c->n : 0, fused[h] != nullptr, bfree);
                 c->ns_launches_total += plans[h].products;
                 const double frac = (double)Kh[h] / K;
                 c->ns_units_frac += frac * plans[h].units;
@@ -2951,6 +2985,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->S_symmetric = src->S_symmetric;
     c->fused_w = src->fused_w;
     c->rank_cw = src->rank_cw;
+    c->bound_side = src->bound_side;
     c->step_latent = src->step_latent;
     c->nk_valid = false;
     if (src->l_ns && src->Ckeep && src->Ckeep_beta) {

@@ -369,7 +369,7 @@ void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, cons
                 int K, int p, int variant, double* start2 = nullptr, double* rowpart = nullptr, double* fropart = nullptr);
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
             double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride = 0,
-            bool fused_start = false);
+            bool fused_start = false, hipEvent_t bprime_free = nullptr);
 // the same launches as a product list for k_omega_chain; NX: an extra [Y|Z] pair (A', B' survive); 0 = not a pure chain
 int ns_chain_ops(const NsPlan& plan, const double* pre0_d, const double* pre1_d, const double* coef_d, const double* W,
                  double* AB, double* YP, double* NX, double* Tb, double* out, int K, int p, size_t pstride, double* start2,

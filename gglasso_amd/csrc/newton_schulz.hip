@@ -15,6 +15,7 @@
 #include <vector>
 #include <unordered_map>
 
+#include <functional>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -611,8 +612,18 @@ double* ns_fused_start(const NsPlan& plan, const double* start_hk, double* YP, d
 // exactly, which is what makes the coupled iteration insensitive to rounding (the symmetrised form
 // amplifies commutator errors by ~sqrt(kappa)/4 per step).
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,
-            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride, bool fused_start)
+            double* AB, double* YP, double* Tb, double* out, int K, int p, int variant, size_t pstride, bool fused_start,
+            hipEvent_t bprime_free)
 {
+    // bprime_free (speculative steps with GGL_OPT_BOUND_SIDE): the bound kernels that validate the assumed bound read B'
+    // (AB + n1) on a SIDE stream while this chain's first products run; the event is waited for before the first launch
+    // that overwrites B', or at the end
+    bool bwaited = bprime_free == nullptr;
+    const double* bprime = AB + (pstride ? pstride : (size_t)K * p * p);
+    auto before_write = [&](const double* o1, const double* o2) {
+        if (!bwaited && (o1 == bprime || o2 == bprime)) { (void)hipStreamWaitEvent(st, bprime_free, 0); bwaited = true; }
+    };
+    struct AtExit { std::function<void()> f; ~AtExit() { f(); } } at_exit{[&]() { before_write(bprime, nullptr); }};
     // fused_start: the first step's elementwise start (ns_fused_start) was written by ns_prepare's B' launch
     // pstride: distance (doubles) between the two stacks of a [Y|Z] pair; 0 = contiguous (K*p*p).  A sub-batch
     // of a larger ctx (two-stream execution) passes the full-stack stride.
@@ -653,6 +664,7 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
             // M = Z Y into the output stack (scratch until the last launch), Q and Q + d I into the other pair,
             // T = f I + t4 Q (Q + d I) + e M
             launch_symm(st, cur + n1, cur, out, nullptr, nullptr, coef_d + cs * g++, K, p, variant);
+            before_write(nxt, nxt + n1);
             launch_symm(st, out, out, nxt, nxt + n1, out, coef_d + cs * g++, K, p, variant);
             launch_symm(st, nxt, nxt + n1, Tb, nullptr, out, coef_d + cs * g++, K, p, variant);
         } else {
@@ -662,9 +674,11 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
         if (it == n - 1) {
             launch_symm(st, cur, Tb, out, nullptr, W, coef_d + cs * g++, K, p, variant);
         } else if (plan.stable) {
+            before_write(nxt + n1, nullptr);
             launch_gemm_right(st, cur, Tb, nxt, coef_d + cs * g++, 2 * K, K, p, 0);   // needs a contiguous pair
             std::swap(cur, nxt);
         } else {
+            before_write(nxt, nxt + n1);
             launch_symm_pair(st, cur, Tb, nxt, Tb, cur + n1, nxt + n1, coef_d + cs * g++, K, p, variant);
             std::swap(cur, nxt);
         }

@@ -142,6 +142,11 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                       resolution -- 22.0 products with either bound at GGL_OPT_RANK_L0_DEFLATE = 2e-3, 21.4 / 20.8 at
                                       4e-3 where 3-4x as many instances need the continuation -- and the pass costs 25 us: 211 it/s
                                       without, 202 with.  Off. */
+#define GGL_OPT_BOUND_SIDE 28      /* [0] speculative Omega-step: the two kernels that validate the assumed bound run on a side stream beside the
+                                      chain's first products, joined before B' is overwritten (round 5).  0 off, 1 on, 2 only for two
+                                      concurrent parts of a large batch.  Bitwise the in-chain order; measured: the small launch-bound
+                                      sequences lose 2-5 % to the cross-stream waits, the headline gains 0.8 % over nine A/B pairs
+                                      whose scatter is +-2 % (profiles/r5_bound_side.txt): off */
 #define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
                                       2 = with the lowest stream priority (streams of another priority never share a hardware queue with
                                       the ctx's main stream) */

@@ -711,3 +711,36 @@ def test_shared_start_arrays_are_replicated_on_the_device():
         finally:
             e1.close()
             e2.close()
+
+
+@pytest.mark.parametrize("K,p", [(4, 300), (8, 400), (20, 200)])
+def test_bound_validation_on_a_side_stream_is_bitwise(sol, K, p):
+    """GGL_OPT_BOUND_SIDE: the kernels that validate a speculative Omega-step's assumed bound run on a side stream beside the
+    chain's first products and are joined before B' is overwritten -- the same kernels on the same data, so the iterates
+    are bitwise those of the in-chain order (one part, two concurrent parts at K = 8, a three-step schedule at (20,200));
+    with spec_factor 0.9 every speculative step is REJECTED by those kernels and repeated: the flag must arrive in time."""
+    from gglasso_amd import synth, solver
+    S, _ = synth.make_problem("GGL", K=K, p=p, N=2 * p, seed=7)
+    Om0 = np.stack([np.eye(p)] * K)
+    nk = np.ones(K)
+    for extra in ({}, {"spec_factor": 0.9}):
+        outs = []
+        for side in (0, 1):          # (the default, 2, is one of the two depending on the regime)
+            eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"bound_side": side, **extra})
+            rho = 1.0
+            for it in range(14):
+                sq = eng.step(rho, 0.05, 0.01, "GGL", False, None, nk).copy()
+                r_t, s_t, _, _ = solver.residuals_from_norms(sq, rho, 1e-20, 1e-20, 1.0)
+                new = solver.next_rho(rho, r_t, s_t)
+                if new != rho:
+                    eng.scale_X(rho / new)
+                rho = new
+            outs.append((eng.state(), eng.ns_stats()))
+            eng.close()
+        for nm in ("Omega", "Theta", "X"):
+            assert np.array_equal(outs[0][0][nm], outs[1][0][nm]), (nm, extra)
+        assert outs[0][1]["spec_misses"] == outs[1][1]["spec_misses"]
+        if extra:
+            assert outs[1][1]["spec_misses"] >= 2
+        else:
+            assert outs[1][1]["spec_calls"] >= 8
