@@ -78,6 +78,8 @@ struct ggl_ctx {
     // (omega_lds.hip, LdsSgl) -- sgl_req: what the caller asks omega_step for; sgl_done: the fused form was launched
     const LdsSgl* sgl_req = nullptr;
     bool sgl_done = false;
+    bool pending_beta_only = false;               // the caller's pending parameter transfer holds beta (slot 0) and nothing else
+    bool par0_stale = false;                      // the device copy of beta was skipped (the LDS kernel read the pinned mirror)
     int* sgl_fail_h = nullptr;                    // pinned (K): instances the fused kernel could not serve
     long long sgl_fused_calls = 0, sgl_fallback_instances = 0;
     bool nk_valid = false;
@@ -1291,6 +1293,10 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
     c->step_latent = latent;
     CopySegs first;
     if (pending) first = *pending;
+    // a step whose LDS kernel read beta from the pinned mirror never uploaded it: whoever reads the DEVICE copy next (every
+    // other route below does, through `first`) gets it now
+    else if (c->par0_stale) first.add(c->par, c->par_h, (size_t)c->K * sizeof(double));
+    c->par0_stale = false;
     if (c->omega_ns) {
         const int K = c->K;
         // early phase A (ggl_ctx::EarlyA): `want_A` launches the first part of a speculative chain only; `resume` finds that
@@ -1390,7 +1396,9 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 // ... and takes its three parameters per instance (beta, lambda1 / rho, 1 / rho) straight from the pinned
                 // mirror the caller has just filled: no parameter copy in front of it, the iteration is ONE launch (the
                 // device flag stays zero in this form -- a miss clears it itself, sgl_fused_finish)
-                const bool no_copy = fused && !c->info_dirty && pending != nullptr;
+                // The plain form does the same when the pending transfer is nothing but beta (ggl_admm_step): the validation
+                // flags it used to zero with that copy ARE zero unless a step was rejected (flags_dirty, handled above).
+                const bool no_copy = !c->info_dirty && ((fused && pending != nullptr) || (!sgl_req && (pending == nullptr || c->pending_beta_only)));
                 CopySegs sg = first;
                 sg.add(c->spec_flag, nullptr, sizeof(int));
                 sg.add(c->spec_flag + ggl_ctx::MAX_PARTS - 1, nullptr, sizeof(int));
@@ -1406,11 +1414,11 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                     sgl.seq = c->seq_h; sgl.seq_val = c->seq_wait = ++c->seq_next; sgl.arrive = c->arrive;
                     memset(c->sgl_fail_h, 0, K * sizeof(int));
                     if (no_copy) {
-                        beta = c->par_h;
                         sgl.l1K = c->par_h + K;
                         sgl.invrhoK = c->par_h + 4 * (size_t)K;
                     }
                 }
+                if (no_copy && first.n > 0) { beta = c->par_h; c->par0_stale = true; }
                 if (!launch_omega_lds(c->stream, c->Theta, latent ? c->L : nullptr, c->X, c->S, beta, c->Om[nxt], c->lds_tab,
                                       c->lds_ntab, c->lds_lnq, K, c->p, c->spec_flag, c->spec_flag_h, 0, cnt, c->bounds_h, nullptr,
                                       c->lds_waves, fused ? &sgl : nullptr))
@@ -1445,6 +1453,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                     return GGL_OK;
                 }
                 // outside the kernel's range: this step (and the next few) on the launch chain
+                c->par0_stale = false;                 // (whose parameter copy carries `first`)
                 lds_missed(c);
                 HIPCHK(hipMemsetAsync(c->spec_flag, 0, ggl_ctx::MAX_PARTS * sizeof(int), c->stream));
                 for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) c->spec_flag_h[h] = 0;
@@ -2408,7 +2417,9 @@ extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lamb
     int rc = upload_par(c, 0, nk, 1.0, rho, &sg);   // beta_k = nk/rho    (admm_solver.py:180,184)
     if (rc) return rc;
     if (!take_prelaunched(c, latent)) {
+        c->pending_beta_only = true;
         rc = omega_step(c, latent, &sg, /*allow_spec=*/true);
+        c->pending_beta_only = false;
         if (rc) return rc;
     }
     c->early_caller = true;
