@@ -10,14 +10,9 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:60]))
 rows.sort()
-# an iteration starts at the first k_form_W launch after the previous iteration's norm reduction
-starts, armed = [], True
-for i, r in enumerate(rows):
-    if "form_W" in r[2] and armed:
-        starts.append(i)
-        armed = False
-    elif "reduce_partials" in r[2]:
-        armed = True
+# an iteration ends with its norm reduction: the next launch starts the following one (k_form_W is no marker any more: with
+# GGL_OPT_FUSED_W the Theta kernel writes W and steady-state iterations have no such launch)
+starts = [i + 1 for i, r in enumerate(rows) if "reduce_partials" in r[2] and i + 1 < len(rows)]
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 its = list(zip(starts[skip:-1], starts[skip + 1:]))
 tot = busy = 0.0
