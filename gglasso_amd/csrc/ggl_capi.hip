@@ -79,6 +79,8 @@ struct ggl_ctx {
     const LdsSgl* sgl_req = nullptr;
     bool sgl_done = false;
     bool pending_beta_only = false;               // the caller's pending parameter transfer holds beta (slot 0) and nothing else
+    bool pending_pinned_ok = false;               // ... or more, and every kernel that reads it this step can take the pinned mirror
+    bool lds_pinned = true;                       // GGL_OPT_LDS_PINNED: the LDS kernels read their parameters from the pinned mirror
     bool par0_stale = false;                      // the device copy of beta was skipped (the LDS kernel read the pinned mirror)
     int* sgl_fail_h = nullptr;                    // pinned (K): instances the fused kernel could not serve
     long long sgl_fused_calls = 0, sgl_fallback_instances = 0;
@@ -627,6 +629,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_FUSED_W: c->fused_w = v != 0.0; break;
         case GGL_OPT_RANK_CW: c->rank_cw = v != 0.0; break;
         case GGL_OPT_BOUND_SIDE: c->bound_side = (int)v; break;
+        case GGL_OPT_LDS_PINNED: c->lds_pinned = v != 0.0; break;
         case GGL_OPT_PART_PRIORITY: {
             if (v != 0.0 && v != 1.0 && v != 2.0) return fail(GGL_E_ARG, "bad argument: GGL_OPT_PART_PRIORITY is 0, 1 or 2");
             if (!c->omega_ns || (int)v == c->part_priority) break;
@@ -701,6 +704,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_FUSED_W: *value = c->fused_w; break;
         case GGL_OPT_RANK_CW: *value = c->rank_cw; break;
         case GGL_OPT_BOUND_SIDE: *value = c->bound_side; break;
+        case GGL_OPT_LDS_PINNED: *value = c->lds_pinned; break;
         case GGL_OPT_PART_PRIORITY: *value = c->part_priority; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
@@ -1293,9 +1297,9 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
     c->step_latent = latent;
     CopySegs first;
     if (pending) first = *pending;
-    // a step whose LDS kernel read beta from the pinned mirror never uploaded it: whoever reads the DEVICE copy next (every
-    // other route below does, through `first`) gets it now
-    else if (c->par0_stale) first.add(c->par, c->par_h, (size_t)c->K * sizeof(double));
+    // a step whose kernels read their parameters from the pinned mirror never uploaded them: whoever reads the DEVICE copy
+    // next (every other route below does, through `first`) gets it now
+    else if (c->par0_stale) first.add(c->par, c->par_h, 8 * (size_t)c->K * sizeof(double));      // (all eight slots: a few KB)
     c->par0_stale = false;
     if (c->omega_ns) {
         const int K = c->K;
@@ -1398,7 +1402,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 // device flag stays zero in this form -- a miss clears it itself, sgl_fused_finish)
                 // The plain form does the same when the pending transfer is nothing but beta (ggl_admm_step): the validation
                 // flags it used to zero with that copy ARE zero unless a step was rejected (flags_dirty, handled above).
-                const bool no_copy = !c->info_dirty && ((fused && pending != nullptr) || (!sgl_req && (pending == nullptr || c->pending_beta_only)));
+                const bool no_copy = c->lds_pinned && !c->info_dirty && ((fused && pending != nullptr) || (!sgl_req && (pending == nullptr || c->pending_beta_only || c->pending_pinned_ok)));
                 CopySegs sg = first;
                 sg.add(c->spec_flag, nullptr, sizeof(int));
                 sg.add(c->spec_flag + ggl_ctx::MAX_PARTS - 1, nullptr, sizeof(int));
@@ -2624,9 +2628,12 @@ static int mgl_batch_finish(ggl_ctx* c, int G, int Kp, int reg, int latent, doub
     double* Om = c->Om[c->cur];
     double* OmPrev = c->Om[c->cur ^ 1];
     const int* skip = c->spec_pending ? c->spec_flag : nullptr;
+    // (par0_stale: this step's LDS kernel read its beta from the pinned mirror and the parameter copy was skipped -- the
+    // Theta kernel takes its two thresholds per problem from there as well)
+    const double* parb = c->par0_stale ? c->par_h : c->par;
     PB(c, GGL_PH_THETA);
-    HIPCHK(launch_theta_batch(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, c->par + K,
-                              c->par + 6 * (size_t)K, latent ? 0 : 1, c->partials, G, Kp, c->p, skip));
+    HIPCHK(launch_theta_batch(c->stream, reg, c->Theta, c->X, c->W, Om, OmPrev, latent ? c->L : nullptr, parb + K,
+                              parb + 6 * (size_t)K, latent ? 0 : 1, c->partials, G, Kp, c->p, skip));
     PE(c, GGL_PH_THETA);
     int rows, group;
     c->norms_host = true;
@@ -2699,7 +2706,9 @@ static int mgl_batch_step_impl(ggl_ctx* c, int G, const double* rho, const doubl
     CopySegs sg;
     sg.add(c->par, h, 3 * (size_t)K * sizeof(double));
     sg.add(c->par + 6 * (size_t)K, h + 6 * (size_t)K, (size_t)K * sizeof(double));
+    c->pending_pinned_ok = !latent;
     rc = omega_step(c, latent, &sg, /*allow_spec=*/true);
+    c->pending_pinned_ok = false;
     if (rc) return rc;
     rc = mgl_batch_finish(c, G, Kp, reg, latent, out_norms);
     if (rc != GGL_SPEC_RETRY) return rc;
@@ -2997,6 +3006,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->fused_w = src->fused_w;
     c->rank_cw = src->rank_cw;
     c->bound_side = src->bound_side;
+    c->lds_pinned = src->lds_pinned;
     c->step_latent = src->step_latent;
     c->nk_valid = false;
     if (src->l_ns && src->Ckeep && src->Ckeep_beta) {

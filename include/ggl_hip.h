@@ -147,6 +147,8 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                       concurrent parts of a large batch.  Bitwise the in-chain order; measured: the small launch-bound
                                       sequences lose 2-5 % to the cross-stream waits, the headline gains 0.8 % over nine A/B pairs
                                       whose scatter is +-2 % (profiles/r5_bound_side.txt): off */
+#define GGL_OPT_LDS_PINNED 29      /* [1] p <= 64: the LDS-resident kernels (and the Theta kernel of a batched grid behind them) read their per-step
+                                      parameters from the pinned host mirror instead of waiting for a copy kernel in front of them */
 #define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
                                       2 = with the lowest stream priority (streams of another priority never share a hardware queue with
                                       the ctx's main stream) */

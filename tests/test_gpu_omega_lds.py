@@ -211,3 +211,45 @@ def test_batched_sgl_path_unvalidated_launch_and_repeat(engines):
     assert np.abs(resk[2][0]["Theta"] - one["Theta"]).max() <= 1e-8
     bad, _ = quiet(solver.ADMM_SGL, Sk[1], 0.1, np.eye(p), tol=1e-9, rtol=1e-9, max_iter=300)
     assert np.abs(resk[1][0]["Theta"] - bad["Theta"]).max() <= 1e-8 * max(1.0, np.abs(bad["Theta"]).max())
+
+
+def test_random_small_batches_of_single_problems_against_the_oracle():
+    """The one-launch iteration of a batch of single problems (k_omega_lds<.., SGL>: Omega-step, prox_od_1norm, dual update and
+    stopping-test sums by the workgroup that holds the instance; single_admm_solver.py:157-214) on random p <= 64, K, lambda1,
+    with a shared mask, per-instance masks, padded instances of different dimension (block_SGL's batches) and a badly scaled
+    point (redone alone on the launch chain): Theta and the exit status of every point against the oracle's ADMM_SGL.
+    tools/fuzz_sgl_batch.py is the long form."""
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_SGL_batch, pad_blocks
+    rng = np.random.default_rng(3)
+    kw = dict(tol=1e-8, rtol=1e-7, max_iter=400)
+    for case, kind in enumerate(["plain", "mask", "maskK", "dims", "scaled", "plain", "dims", "scaled"]):
+        p, K = int(rng.integers(3, 65)), int(rng.integers(2, 9))
+        S, _ = synth.make_problem("GGL", K, p, N=2 * p + 5, seed=100 + case)
+        lam = np.exp(rng.uniform(np.log(0.03), np.log(0.5), K))
+        ref_S, ref_mask, args = [S[k] for k in range(K)], [None] * K, dict(kw)
+        if kind == "mask":
+            M = rng.uniform(0.2, 2.0, (p, p))
+            M = 0.5 * (M + M.T)
+            lam = np.full(K, lam[0])
+            args["lambda1_mask"], ref_mask = M, [M] * K
+        elif kind == "maskK":
+            M = rng.uniform(0.2, 2.0, (K, p, p))
+            M = 0.5 * (M + M.transpose(0, 2, 1))
+            args["lambda1_mask"], ref_mask = M, [M[k] for k in range(K)]
+        elif kind == "dims":
+            dims = rng.integers(2, p + 1, K)
+            ref_S = [S[k][:dims[k], :dims[k]] for k in range(K)]
+            S = pad_blocks(ref_S, p, True)
+            args.update(dims=dims, Omega_0=pad_blocks([np.eye(d) for d in dims], p, True), X_0=np.zeros((K, p, p)))
+        elif kind == "scaled":
+            S = S.copy()
+            S[1] *= 70.0
+            ref_S = [S[k] for k in range(K)]
+        res = quiet(ADMM_SGL_batch, S, lam, **args)
+        for k in range(K):
+            q = ref_S[k].shape[0]
+            ref, rinfo = quiet(orc.ADMM_SGL, ref_S[k], float(lam[k]), np.eye(q),
+                               lambda1_mask=None if ref_mask[k] is None else ref_mask[k][:q, :q], **kw)
+            assert res[k][1]["status"] == rinfo["status"], (kind, p, K, k)
+            assert np.abs(res[k][0]["Theta"] - ref["Theta"]).max() <= 1e-8 * max(1.0, np.abs(ref["Theta"]).max()), (kind, p, K, k)
