@@ -75,6 +75,8 @@ GGL_BENCH_FORCE_DIST=1 python bench.py --workload ggl_K16_p500 --steps 30 --warm
     python bench.py --workload $w --steps 30 --warmup 8 --regions 5 --no-cpu-baseline --no-exact-region --opt fused_w=$fw 2>/dev/null | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w fused_w=$fw', round(d['value'],1), 'it/s', round(d['ms_per_step'],4), 'ms', (d.get('newton_schulz') or {}).get('pipeline_totals'))"
   done; done; done
 } > $O/fused_w_ab.txt 2>&1
+keep $O/fuzz_sgl_batch.txt python tools/fuzz_sgl_batch.py 60 1
+bash tools/r5_s.sh > $O/lds_pinned_ab.txt 2>&1
 bash tools/trace_iteration.sh ggl_K4_p500 > $O/timeline_K4.txt 2>&1
 bash tools/trace_iteration.sh ggl_K32_p500 > $O/timeline_headline_by_kernel.txt 2>&1
 rm -rf $R/gpurun_out/trace_*/*.db $R/gpurun_out/trace_*/*/*.db 2>/dev/null
