@@ -285,6 +285,46 @@ __global__ __launch_bounds__(256) void k_copy_small(CopySegs sg)
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < sg.words[s]; i += gridDim.x * 256) d[i] = src ? src[i] : 0u;
 }
 
+// Join of concurrent launch sequences WITHOUT a cross-queue event (GGL_OPT_JOIN_FLAG).  An event wait between two hardware
+// queues costs ~25 us of idle time on the waiting queue after the event has fired (tools/event_timeline.py: the last product
+// of the second part done at 649 us, the Theta kernel behind the wait done at 740 us, the kernel itself 57 us).  Instead the
+// part's stream ends with k_set_flag (an agent-scope store of the join's sequence number, performed at the memory side: the
+// kernel before it has completed, end-of-kernel release included), and the main stream carries k_wait_flags -- ONE wave that
+// polls the words and exits -- in front of the kernel that needs the parts' results: the dependency becomes an ordinary
+// in-queue one.  A wave that waits longer than the time-out (the two streams share a hardware queue after all, or the other
+// part died) raises the step's validation flag: the kernels behind it leave the iterate alone and the host repeats the step
+// on the synchronising route.
+__global__ void k_set_flag(unsigned long long* f, unsigned long long v)
+{
+    __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void k_wait_flags(const unsigned long long* f, int n, unsigned long long v, int* skip, int* skip_host, int slot,
+                             long long timeout_ticks)
+{
+    if ((int)threadIdx.x >= n) return;
+    const long long t0 = (long long)wall_clock64();
+    while (__hip_atomic_load(f + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((long long)wall_clock64() - t0 > timeout_ticks) {
+            atomicOr(skip + slot, 1);
+            skip_host[slot] = 1;
+            break;
+        }
+    }
+}
+
+void launch_set_flag(hipStream_t st, unsigned long long* f, unsigned long long v)
+{
+    hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, st, f, v);
+}
+
+void launch_wait_flags(hipStream_t st, const unsigned long long* f, int n, unsigned long long v, int* skip, int* skip_host,
+                       int slot, double timeout_ms)
+{
+    hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, st, f, n, v, skip, skip_host, slot, (long long)(timeout_ms * 1e5));
+}
+
 // one wave that does nothing for `us` microseconds (100 MHz wall clock): the stream-concurrency probe of ggl_capi.hip
 __global__ void k_spin_us(long long us)
 {

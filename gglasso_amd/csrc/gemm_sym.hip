@@ -1709,9 +1709,19 @@ int symm_auto_variant(int nprod, int p)
 }
 
 // Two independent products in one launch: C = coef[k]-affine(A*B) for k < K and C1 = coef[K+k]-scaled(A1*B1).
+// Launch hook of the event timeline (ggl_trace_*, ggl_capi.hip): called after every product launch with its stream.
+static void (*g_symm_hook)(hipStream_t, int, void*) = nullptr;
+static void* g_symm_hook_arg = nullptr;
+void symm_set_launch_hook(void (*fn)(hipStream_t, int, void*), void* arg) { g_symm_hook = fn; g_symm_hook_arg = arg; }
+struct SymmHookAtExit {
+    hipStream_t st; int kind;
+    ~SymmHookAtExit() { if (g_symm_hook) g_symm_hook(st, kind, g_symm_hook_arg); }
+};
+
 void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
                       double* C1, const double* coef2K, int K, int p, int variant)
 {
+    SymmHookAtExit hook{st, 1};
     if (variant < 0) variant = symm_auto_variant(2 * K, p);
     if (variant >= 41 && variant <= 50) variant = 20;       // k_symm_sk takes single products only
     switch (variant) {
@@ -1748,6 +1758,7 @@ int symm_bounds_tile(int K, int p, int variant)
 void launch_symm(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                  const double* coef, int K, int p, int variant, double* maxdev, double* rowpart, double* fropart)
 {
+    SymmHookAtExit hook{st, 0};
     if (variant < 0) variant = symm_auto_variant(K, p);
 #define GGL_TN(BM, BK, WM, WN, LM) \
     launch_cfg<BM, BK, WM, WN, LM>(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev)

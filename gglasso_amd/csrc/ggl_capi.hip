@@ -74,6 +74,18 @@ struct ggl_ctx {
     int* info_h = nullptr;                        // pinned (K)
     double* gflag_h = nullptr;                    // pinned: the all-reduced speculation flag of a K-sharded step
     unsigned* arrive = nullptr;                   // device: arrival counter of a multi-row norm reduction that publishes seq
+    // event timeline of iterations without a profiler (ggl_trace_start / ggl_trace_read): an event behind every launch of the
+    // step on its stream, host marks beside them
+    struct Trace {
+        bool on = false;
+        int cap = 0, n = 0, nhost = 0;
+        hipEvent_t base = nullptr;
+        std::vector<hipEvent_t> ev;
+        std::vector<int> tag, lane;              // lane: 0 main stream, 1.. part / side streams
+        std::vector<double> host_us;             // host marks: microseconds since the base event completed
+        std::vector<int> host_tag;
+        std::chrono::steady_clock::time_point t0;
+    } trace;
     // K independent single problems at p <= 64 (ggl_sgl_batch_step): the LDS-resident Omega-step goes on with the Theta-step
     // (omega_lds.hip, LdsSgl) -- sgl_req: what the caller asks omega_step for; sgl_done: the fused form was launched
     const LdsSgl* sgl_req = nullptr;
@@ -105,6 +117,11 @@ struct ggl_ctx {
     // GGL_OPT_BOUND_SIDE: the bound kernels that validate a speculative step's assumed bound run on a side stream beside the
     // chain's first products (per part: fork after B', join before the first launch that overwrites B')
     int bound_side = 0;                        // 0 off, 1 on, 2 by regime (two concurrent parts of a large batch)
+    // GGL_OPT_JOIN_FLAG: the parts of a speculative chain are joined through flag words in device memory (k_set_flag /
+    // k_wait_flags) instead of a cross-queue event wait
+    bool join_flag = true;
+    unsigned long long* join_words = nullptr;   // device [MAX_PARTS]
+    unsigned long long join_seq = 0;
     hipEvent_t ev_bfork[MAX_PARTS] = {}, ev_bjoin[MAX_PARTS] = {};
     // Pipelining across iterations: right after an iteration has been validated, ggl_admm_step launches the NEXT iteration's
     // (speculative) Omega-step chain for the same beta before it returns, so the GPU works through the host's round trip
@@ -500,6 +517,7 @@ static int ctx_alloc(ggl_ctx* c)
     PIN(c->gflag_h, sizeof(double), 2);
     PIN(c->sgl_fail_h, (size_t)c->K * sizeof(int), 2);
     DEV(c->arrive, 256);
+    DEV(c->join_words, 256);
     if (c->omega_ns) {
         for (int i = 0; i < 2; ++i) { DEV(c->nsYP[i], 2 * nb); }
         DEV(c->nsT, nb);
@@ -572,6 +590,7 @@ static int ctx_alloc(ggl_ctx* c)
     // initial contents
     HIPCHK(hipMemsetAsync(c->groupsq, 0, ((size_t)c->p * c->p + 8) * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->arrive, 0, 256, c->stream));
+    HIPCHK(hipMemsetAsync(c->join_words, 0, 256, c->stream));
     HIPCHK(hipMemsetAsync(c->L, 0, nb, c->stream));
     HIPCHK(hipMemsetAsync(c->X, 0, nb, c->stream));
     HIPCHK(hipMemsetAsync(c->Om[1], 0, nb, c->stream));
@@ -630,6 +649,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_RANK_CW: c->rank_cw = v != 0.0; break;
         case GGL_OPT_BOUND_SIDE: c->bound_side = (int)v; break;
         case GGL_OPT_LDS_PINNED: c->lds_pinned = v != 0.0; break;
+        case GGL_OPT_JOIN_FLAG: c->join_flag = v != 0.0; break;
         case GGL_OPT_PART_PRIORITY: {
             if (v != 0.0 && v != 1.0 && v != 2.0) return fail(GGL_E_ARG, "bad argument: GGL_OPT_PART_PRIORITY is 0, 1 or 2");
             if (!c->omega_ns || (int)v == c->part_priority) break;
@@ -705,6 +725,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_RANK_CW: *value = c->rank_cw; break;
         case GGL_OPT_BOUND_SIDE: *value = c->bound_side; break;
         case GGL_OPT_LDS_PINNED: *value = c->lds_pinned; break;
+        case GGL_OPT_JOIN_FLAG: *value = c->join_flag; break;
         case GGL_OPT_PART_PRIORITY: *value = c->part_priority; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
@@ -822,6 +843,9 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
         for (int e = 0; e < 2; ++e)
             if (c->ev_early[q][e]) (void)hipEventDestroy(c->ev_early[q][e]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->trace.on) symm_set_launch_hook(nullptr, nullptr);
+    for (hipEvent_t e : c->trace.ev) if (e) (void)hipEventDestroy(e);
+    if (c->trace.base) (void)hipEventDestroy(c->trace.base);
     for (int i = 0; i < ggl_ctx::MAX_PARTS; ++i) {
         if (c->ev_bfork[i]) (void)hipEventDestroy(c->ev_bfork[i]);
         if (c->ev_bjoin[i]) (void)hipEventDestroy(c->ev_bjoin[i]);
@@ -1287,6 +1311,36 @@ static void lds_missed(ggl_ctx* c)
     c->lds_last = false;
 }
 
+// ---- event timeline ------------------------------------------------------------------------------------------------------
+// tags: 1 parameter copy, 2 form_W, 3 bound_rows, 4 cw_final, 10 product, 11 pair of products, 20 Theta, 21 norm reduction,
+// 22 group sums (K-sharded), 23 all-reduce; host marks: 100 step entered, 101 Theta + reduction queued, 102 early part
+// queued, 103 residuals seen, 104 rest of the next chain queued (step returns)
+static int trace_lane(const ggl_ctx* c, hipStream_t st)
+{
+    if (st == c->stream) return 0;
+    for (int i = 0; i < ggl_ctx::MAX_PARTS - 1; ++i)
+        if (st == c->streamx[i]) return i + 1;
+    return -1;
+}
+static void trace_mark(ggl_ctx* c, hipStream_t st, int tag)
+{
+    ggl_ctx::Trace& t = c->trace;
+    if (!t.on || t.n >= t.cap) return;
+    if (hipEventRecord(t.ev[t.n], st) != hipSuccess) return;
+    t.tag[t.n] = tag;
+    t.lane[t.n] = trace_lane(c, st);
+    t.n += 1;
+}
+static void trace_host(ggl_ctx* c, int tag)
+{
+    ggl_ctx::Trace& t = c->trace;
+    if (!t.on || t.nhost >= t.cap) return;
+    t.host_us[t.nhost] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t.t0).count();
+    t.host_tag[t.nhost] = tag;
+    t.nhost += 1;
+}
+static void trace_symm_hook(hipStream_t st, int kind, void* arg) { trace_mark((ggl_ctx*)arg, st, 10 + kind); }
+
 // Omega-step with beta_k in parameter slot 0 (already on the device, or part of the pending transfer)
 static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec, bool only_spec)
 {
@@ -1601,11 +1655,13 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 if (h == 0 && c->info_dirty) sg.add(c->info, nullptr, K * sizeof(int));
             }
             launch_copy_small(sh, sg);
+            trace_mark(c, sh, 1);
             if (h == 0) PB(c, GGL_PH_FORM_W);
-            if (!w_ready)
+            if (!w_ready) {
                 launch_form_W_sym(sh, c->W + k0 * pp, c->Theta + k0 * pp, latent ? c->L + k0 * pp : nullptr, c->X + k0 * pp,
                                   c->S + k0 * pp, beta + k0, Kh[h], c->p);
-            else if (h == 0) c->wf_used += 1;
+                trace_mark(c, sh, 2);
+            } else if (h == 0) c->wf_used += 1;
             const bool early_ev = want_A && h == 0 && c->prof_on == 2;
             if (early_ev) {
                 c->ev_early_par ^= 1;
@@ -1658,11 +1714,13 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 } else {
                 const int nib = bound_rows_blocks(c->p);
                 launch_bound_rows(sb, rowp, bT, Kh[h], c->p, c->nbrow + (size_t)k0 * c->p, c->infpart + (size_t)k0 * nib);
+                trace_mark(c, sb, 3);
                 launch_cw_final(sb, Bp, c->nbrow + (size_t)k0 * c->p, Kh[h], c->p, c->infpart + (size_t)k0 * nib, frop,
                                 bT * (bT + 1) / 2, c->cwmax + k0, c->cwcnt + k0, c->bounds_h + k0, spec ? c->cuse + k0 : nullptr,
                                 spec ? c->spec_flag : nullptr, spec ? c->spec_flag_h : nullptr, h,
                                 (c->cw_warm && c->cw_have) ? c->cwvec[c->cw_cur] + (size_t)k0 * c->p : nullptr,
                                 c->cw_warm ? c->cwvec[c->cw_cur ^ 1] + (size_t)k0 * c->p : nullptr);
+                trace_mark(c, sb, 4);
                 }
                 cw_written = c->cw_warm;
             } else {
@@ -1694,9 +1752,17 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             return GGL_OK;
         }
         if (spec) {
-            for (int h = 1; h < nh; ++h) {
-                HIPCHK(hipEventRecord(c->ev_join[h - 1], c->streamx[h - 1]));
-                HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
+            if (nh > 1 && c->join_flag) {
+                // (see k_wait_flags: the waiting queue idles ~25 us behind a cross-queue event that has fired)
+                c->join_seq += 1;
+                for (int h = 1; h < nh; ++h) launch_set_flag(c->streamx[h - 1], c->join_words + h, c->join_seq);
+                launch_wait_flags(c->stream, c->join_words + 1, nh - 1, c->join_seq, c->spec_flag, c->spec_flag_h, 0, 200.0);
+                HIPCHK(hipGetLastError());
+            } else {
+                for (int h = 1; h < nh; ++h) {
+                    HIPCHK(hipEventRecord(c->ev_join[h - 1], c->streamx[h - 1]));
+                    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
+                }
             }
             PE(c, GGL_PH_EIG_OMEGA);
             c->ns_units_total = (long long)(c->ns_units_frac + 0.5);
@@ -2281,12 +2347,15 @@ static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double l
                                  c->p, flat, (c->spec_pending || c->sharded_check) ? c->spec_flag : nullptr, wn, &wn_done));
         c->wf_ready = wn_done != 0;
         if (c->wf_ready) { memcpy(c->wf_beta, c->par_h, c->K * sizeof(double)); c->wf_written += 1; }
+        trace_mark(c, c->stream, 20);
         PE(c, GGL_PH_THETA);
         if (!latent) {
             PB(c, GGL_PH_REDUCE);
             if (!defer_norms && c->seq_h && c->spin_wait) c->seq_wait = ++c->seq_next;
             launch_reduce_partials(c->stream, c->partials, 1, theta_partial_blocks(c->p, reg, c->K, flat), GGL_NNORM,
                                    norms_dst, c->seq_wait ? c->seq_h : nullptr, c->seq_wait);
+            trace_mark(c, c->stream, 21);
+            trace_host(c, 101);
             PE(c, GGL_PH_REDUCE);
             rows = 1;
         }
@@ -2349,6 +2418,7 @@ static int maybe_early(ggl_ctx* c)
     c->early_request = true;
     const int rc = omega_step(c, 0, nullptr, /*allow_spec=*/true, /*only_spec=*/true);
     c->early_request = false;
+    trace_host(c, 102);
     return rc == GGL_NOT_LAUNCHED ? GGL_OK : rc;
 }
 
@@ -2417,6 +2487,7 @@ extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lamb
     ARGCHK(c, "ctx");
     ARGCHK(rho > 0, "rho must be positive");
     HIPCHK(hipSetDevice(c->device));
+    trace_host(c, 100);
     CopySegs sg;
     int rc = upload_par(c, 0, nk, 1.0, rho, &sg);   // beta_k = nk/rho    (admm_solver.py:180,184)
     if (rc) return rc;
@@ -2436,7 +2507,10 @@ extern "C" int ggl_admm_step(ggl_ctx* c, double rho, double lambda1, double lamb
         rc = ggl_step_finish_impl(c, rho, lambda1, lambda2, reg, latent, mu1, 0, out_norms);
     }
     if (rc != GGL_OK || latent) return rc;
-    return maybe_prelaunch(c, rho, out_norms);
+    trace_host(c, 103);
+    rc = maybe_prelaunch(c, rho, out_norms);
+    trace_host(c, 104);
+    return rc;
 }
 
 // ---- K independent single problems with their own rho / lambda1 (batched lambda path) ----------
@@ -3007,6 +3081,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->rank_cw = src->rank_cw;
     c->bound_side = src->bound_side;
     c->lds_pinned = src->lds_pinned;
+    c->join_flag = src->join_flag;
     c->step_latent = src->step_latent;
     c->nk_valid = false;
     if (src->l_ns && src->Ckeep && src->Ckeep_beta) {
@@ -3131,6 +3206,60 @@ extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[7])
 
 // Per-instance status word of the last eigensolver launch as the last ADMM step fetched it: the LDS Jacobi kernel reports the
 // sweeps it took (-1: not converged within its limit), rocSOLVER its info (0 = converged).
+// Event timeline without a profiler.  ggl_trace_start: from now on every launch of ggl_admm_step's iteration is followed by an
+// event on its stream (up to max_events; product launches through the hook of gemm_sym.hip) and the host notes when it
+// entered the step, queued the Theta-step, queued the early part, saw the residuals and returned.  ggl_trace_read stops the
+// recording, waits for the device and returns rows {kind 0 device / 1 host, lane (0 main stream, 1.. part streams), tag,
+// microseconds since the start}: device rows give the COMPLETION time of the launch they follow.  Returns the rows written.
+extern "C" int ggl_trace_start(ggl_ctx* c, int max_events)
+{
+    ARGCHK(c && max_events >= 16 && max_events <= (1 << 16), "ctx, 16 <= max_events <= 65536");
+    HIPCHK(hipSetDevice(c->device));
+    DROP_PRE(c);
+    ggl_ctx::Trace& t = c->trace;
+    for (hipEvent_t e : t.ev) (void)hipEventDestroy(e);
+    if (t.base) (void)hipEventDestroy(t.base);
+    t.ev.assign(max_events, nullptr);
+    for (hipEvent_t& e : t.ev) HIPCHK(hipEventCreate(&e));
+    t.tag.assign(max_events, 0); t.lane.assign(max_events, 0);
+    t.host_us.assign(max_events, 0.0); t.host_tag.assign(max_events, 0);
+    t.cap = max_events; t.n = 0; t.nhost = 0;
+    HIPCHK(hipEventCreate(&t.base));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipEventRecord(t.base, c->stream));
+    HIPCHK(hipEventSynchronize(t.base));
+    t.t0 = std::chrono::steady_clock::now();
+    symm_set_launch_hook(trace_symm_hook, c);
+    t.on = true;
+    return GGL_OK;
+}
+
+extern "C" int ggl_trace_read(ggl_ctx* c, double* out /*(cap,4)*/, int cap)
+{
+    ARGCHK(c && out && cap >= 1, "ctx, out, cap");
+    ggl_ctx::Trace& t = c->trace;
+    t.on = false;
+    symm_set_launch_hook(nullptr, nullptr);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    int n = 0;
+    for (int i = 0; i < t.n && n < cap; ++i, ++n) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.base, t.ev[i]) != hipSuccess) ms = -1.f;
+        double* o = out + 4 * (size_t)n;
+        o[0] = 0.0; o[1] = t.lane[i]; o[2] = t.tag[i]; o[3] = 1e3 * (double)ms;
+    }
+    for (int i = 0; i < t.nhost && n < cap; ++i, ++n) {
+        double* o = out + 4 * (size_t)n;
+        o[0] = 1.0; o[1] = -1.0; o[2] = t.host_tag[i]; o[3] = t.host_us[i];
+    }
+    for (hipEvent_t e : t.ev) (void)hipEventDestroy(e);
+    t.ev.clear();
+    if (t.base) { (void)hipEventDestroy(t.base); t.base = nullptr; }
+    t.n = t.nhost = 0;
+    return n;
+}
+
 extern "C" int ggl_eig_info(ggl_ctx* c, int* out)
 {
     ARGCHK(c && out, "ctx, out");

@@ -49,7 +49,11 @@ struct CopySegs {
 };
 void launch_copy_small(hipStream_t st, const CopySegs& segs);
 void launch_copy_small_seq(hipStream_t st, const CopySegs& segs, unsigned long long* seq, unsigned long long seq_val);
-void launch_spin_us(hipStream_t st, int us);      // one idle wave for `us` microseconds (stream-concurrency probe)
+void launch_spin_us(hipStream_t st, int us);
+// join of concurrent launch sequences through memory instead of a cross-queue event (elementwise.hip)
+void launch_set_flag(hipStream_t st, unsigned long long* f, unsigned long long v);
+void launch_wait_flags(hipStream_t st, const unsigned long long* f, int n, unsigned long long v, int* skip, int* skip_host,
+                       int slot, double timeout_ms);      // one idle wave for `us` microseconds (stream-concurrency probe)
 // X[k] *= fK[k]
 void launch_scale_batch(hipStream_t st, double* X, const double* fK, int K, int p);
 // out[k] = max_{i,j} |A[k,i,j] - A[k,j,i]|
@@ -323,6 +327,8 @@ double mfma_valu_mix_tflops(hipStream_t st, double* scratch, int blocks, int ite
 void launch_gemm_right(hipStream_t st, const double* A, const double* T, double* C, const double* scal,
                        int nbatch, int K, int p, int variant);
 
+// event timeline (ggl_trace_*): fn(stream, kind 0 single / 1 pair, arg) after every product launch; null switches it off
+void symm_set_launch_hook(void (*fn)(hipStream_t, int, void*), void* arg);
 // two independent symmetric products in one launch; coef2K: [2K][NS_NCOEF] (second half for the second product)
 void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* C, const double* A1, const double* B1,
                       double* C1, const double* coef2K, int K, int p, int variant);

@@ -149,6 +149,9 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                       whose scatter is +-2 % (profiles/r5_bound_side.txt): off */
 #define GGL_OPT_LDS_PINNED 29      /* [1] p <= 64: the LDS-resident kernels (and the Theta kernel of a batched grid behind them) read their per-step
                                       parameters from the pinned host mirror instead of waiting for a copy kernel in front of them */
+#define GGL_OPT_JOIN_FLAG 30       /* [1] concurrent parts of a speculative Omega-step are joined through flag words in device memory (a one-wave
+                                      kernel on the main stream polls what the parts' streams set behind their last launch) instead of a
+                                      cross-queue event wait, which idles the waiting queue ~25 us after the event has fired */
 #define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
                                       2 = with the lowest stream priority (streams of another priority never share a hardware queue with
                                       the ctx's main stream) */
@@ -477,6 +480,14 @@ int ggl_deflate_stats(ggl_ctx *ctx, long long out[2]);
  * in one thread; 100*KQ+NW per-element kernel with the K-column over NW waves: 404, 408, 808, 816, 1616; 2000+tile FGL
  * Condat tiles), eigendecompositions ggl_finalize_L ran on this ctx }.  The parity tests assert the dispatch with it. */
 int ggl_last_dispatch(ggl_ctx *ctx, long long out[4]);
+/* Event timeline of ggl_admm_step's iterations without a profiler (round 5; tools/event_timeline.py): after ggl_trace_start every
+ * launch of the iteration is followed by an event on its stream and the host notes its own marks; ggl_trace_read stops the
+ * recording and returns rows {kind 0 device / 1 host, lane (0 main stream, 1.. part streams; -1 host), tag, microseconds since the
+ * start}.  Device rows give the COMPLETION time of the launch they follow.  Device tags: 1 parameter copy, 2 form_W, 3 bound_rows,
+ * 4 cw_final, 10 product, 11 pair of products, 20 Theta-step, 21 norm reduction; host tags: 100 step entered, 101 Theta-step and
+ * reduction queued, 102 early first part queued, 103 residuals seen, 104 rest of the next chain queued (the step returns). */
+int ggl_trace_start(ggl_ctx *ctx, int max_events);
+int ggl_trace_read(ggl_ctx *ctx, double *out, int cap);
 /* per-instance status of the last eigensolver launch a step fetched: sweeps of the LDS Jacobi kernel (-1: not converged) or
  * rocSOLVER's info */
 int ggl_eig_info(ggl_ctx *ctx, int *out);

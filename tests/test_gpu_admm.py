@@ -725,8 +725,10 @@ def test_bound_validation_on_a_side_stream_is_bitwise(sol, K, p):
     nk = np.ones(K)
     for extra in ({}, {"spec_factor": 0.9}):
         outs = []
-        for side in (0, 1):          # (the default, 2, is one of the two depending on the regime)
-            eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"bound_side": side, **extra})
+        # (side, join_flag): the validation kernels in the chain / on a side stream; the parts joined through flag words in
+        # device memory (GGL_OPT_JOIN_FLAG, the default) / through a cross-queue event -- all four orders of the same kernels
+        for side, jf in ((0, 1), (1, 1), (0, 0), (1, 0)):
+            eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"bound_side": side, "join_flag": jf, **extra})
             rho = 1.0
             for it in range(14):
                 sq = eng.step(rho, 0.05, 0.01, "GGL", False, None, nk).copy()
@@ -737,9 +739,10 @@ def test_bound_validation_on_a_side_stream_is_bitwise(sol, K, p):
                 rho = new
             outs.append((eng.state(), eng.ns_stats()))
             eng.close()
-        for nm in ("Omega", "Theta", "X"):
-            assert np.array_equal(outs[0][0][nm], outs[1][0][nm]), (nm, extra)
-        assert outs[0][1]["spec_misses"] == outs[1][1]["spec_misses"]
+        for o in outs[1:]:
+            for nm in ("Omega", "Theta", "X"):
+                assert np.array_equal(outs[0][0][nm], o[0][nm]), (nm, extra)
+            assert outs[0][1]["spec_misses"] == o[1]["spec_misses"]
         if extra:
             assert outs[1][1]["spec_misses"] >= 2
         else:
