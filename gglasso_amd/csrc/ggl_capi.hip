@@ -120,6 +120,7 @@ struct ggl_ctx {
     // GGL_OPT_JOIN_FLAG: the parts of a speculative chain are joined through flag words in device memory (k_set_flag /
     // k_wait_flags) instead of a cross-queue event wait
     bool join_flag = true;
+    bool parts_serial = false;                 // probe_part_streams found no part stream that runs beside the main one
     unsigned long long* join_words = nullptr;   // device [MAX_PARTS]
     unsigned long long join_seq = 0;
     hipEvent_t ev_bfork[MAX_PARTS] = {}, ev_bjoin[MAX_PARTS] = {};
@@ -1277,6 +1278,7 @@ static int probe_part_streams(ggl_ctx* c)
             c->parts_replaced = ns;
         }
     }
+    c->parts_serial = ser;
     for (int i = 0; i < ns; ++i) (void)hipStreamDestroy(spare[i]);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -1752,7 +1754,9 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             return GGL_OK;
         }
         if (spec) {
-            if (nh > 1 && c->join_flag) {
+            // (parts that share a hardware queue keep the event join: a polling wave in front of the kernel it waits for would
+            // sit out its time limit -- the host queues the set before the wait, so this is belt and braces)
+            if (nh > 1 && c->join_flag && !c->parts_serial) {
                 // (see k_wait_flags: the waiting queue idles ~25 us behind a cross-queue event that has fired)
                 c->join_seq += 1;
                 for (int h = 1; h < nh; ++h) launch_set_flag(c->streamx[h - 1], c->join_words + h, c->join_seq);
@@ -2462,7 +2466,11 @@ static int maybe_prelaunch(ggl_ctx* c, double rho, const double out_norms[5])
     if (rc) return rc;
     // residuals well inside the band in which the rho rule keeps rho: the next iteration may put the first part of ITS
     // successor's chain into the stream before it waits for its own residuals (maybe_early)
-    c->ratio_calm = (r_t < 4.0 * s_t && s_t < 4.0 * r_t);
+    // (the rule acts at a ratio of 10 and the ratio moves by a few per cent per iteration: inside a factor 8 the prediction
+    // "rho stays" fails about once per rho change, and a failed prediction costs one forgotten early part.  Round 4 used a
+    // factor 4, which tools/event_timeline.py showed to switch the early part OFF for good once a solve's residual ratio
+    // settles between 4 and 10 -- C3 from iteration ~40 on.)
+    c->ratio_calm = (r_t < 8.0 * s_t && s_t < 8.0 * r_t);
     c->cur = cur0;                               // Omega_t stays the current iterate until the chain is taken over
     c->pre_spec_pending = c->spec_pending;
     c->spec_pending = false;

@@ -923,6 +923,8 @@ __global__ __launch_bounds__(256) void k_cw_final(const double* __restrict__ B, 
 {
     // 16 rows per workgroup, 4 per wave, all four streamed together (independent loads in flight)
     __shared__ double sh[4];
+    __shared__ double shfro[256];
+    __shared__ int shlast;
     const int k = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * 16 + wave * 4;
@@ -960,24 +962,42 @@ __global__ __launch_bounds__(256) void k_cw_final(const double* __restrict__ B, 
     }
     if (lane == 0) sh[wave] = mx;
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    mx = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
     // Everything the workgroups exchange travels in agent-scope atomics (performed at the memory side, coherent across
     // the XCDs' L2s) -- no cache write-back / invalidate fences: a __threadfence() per workgroup writes back the whole XCD
     // L2, which the product kernels of the other part keep dirtying (measured: +150 us per iteration).  One atomic max
     // and one arrival per workgroup (thousands of atomics on sixteen addresses serialise: measured 74 us for one per
     // row).  The arrival depends on the RETURNED value of the max, so it cannot be performed before it.
-    const unsigned long long old =
-        __hip_atomic_fetch_max(cwmax + k, (unsigned long long)__double_as_longlong(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned arrive = 1u + (unsigned)(old >> 63);                   // old is a non-negative double: + 0
-    if (__hip_atomic_fetch_add(cnt + k, arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
-    // last workgroup of instance k: every block maximum has been merged
-    const double cw = __longlong_as_double((long long)__hip_atomic_exchange(cwmax + k, 0ull, __ATOMIC_RELAXED,
-                                                                            __HIP_MEMORY_SCOPE_AGENT));
-    __hip_atomic_store(cnt + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    double inf = 0.0, sq = 0.0;
+    if (threadIdx.x == 0) {
+        mx = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+        const unsigned long long old = __hip_atomic_fetch_max(cwmax + k, (unsigned long long)__double_as_longlong(mx),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned arrive = 1u + (unsigned)(old >> 63);               // old is a non-negative double: + 0
+        shlast = __hip_atomic_fetch_add(cnt + k, arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!shlast) return;
+    // last workgroup of instance k: every block maximum has been merged.  The Frobenius shares are fetched by all threads
+    // at once and added by one in tile order (round 5: the event timeline showed this kernel at 12.6 us on (20, 200) and
+    // 18.8 us on a K = 4 slab of p = 500 -- T (T + 1) / 2 = 36 dependent loads by one thread were most of the second figure).
+    double cw = 0.0;
+    if (threadIdx.x == 0) {
+        cw = __longlong_as_double((long long)__hip_atomic_exchange(cwmax + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __hip_atomic_store(cnt + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    double sq = 0.0;
+    for (int t0 = 0; t0 < ntile; t0 += 256) {
+        const int t = t0 + (int)threadIdx.x;
+        shfro[threadIdx.x] = (t < ntile) ? fropart[(size_t)k * ntile + t] : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int m = min(256, ntile - t0);
+            for (int q = 0; q < m; ++q) sq += shfro[q];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    double inf = 0.0;
     for (int b2 = 0; b2 < ninf; ++b2) inf = fmax(inf, infpart[(size_t)k * ninf + b2]);
-    for (int t = 0; t < ntile; ++t) sq += fropart[(size_t)k * ntile + t];
     const double fr = sqrt(sq);
     if (isfinite(cw) && cw > 0.0) { const double wv = cw * (1.0 + 1e-12); inf = (wv < inf) ? wv : inf; }
     const double b = sqrt((fr < inf) ? fr : inf);
