@@ -366,8 +366,10 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
                                              const double* __restrict__ E, const double* __restrict__ coef, int K,
                                              int p, const double* __restrict__ A1, const double* __restrict__ B1,
                                              double* __restrict__ C1, int K1, double* __restrict__ maxdev,
-                                             double* __restrict__ rowpart, double* __restrict__ fropart, int k, int b)
+                                             double* __restrict__ rowpart, double* __restrict__ fropart, int k, int b,
+                                             double* smem)
 {
+    // smem: the caller's NSTG * 2 * BK * BM doubles of LDS ([buf][A|B][BK][BM]; later the mirror tile)
     // rowpart / fropart != null: the launch also leaves what a spectral bound of C needs, with no pass over C --
     // rowpart[k][s][i] = sum over the columns of tile-column s of |C[i][.]| (summed over s: the row sums of |C|) and
     // fropart[k][tile] = the tile's share of |C|_F^2 (mirror included), every slot written by exactly one workgroup
@@ -383,7 +385,6 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
     static_assert(BM == 64 || BM == 32, "tile edge");
     static_assert(IPW >= 1, "k-slab too shallow for this tile");
     static_assert(NSTG * 2 * SLAB >= BM * BM, "the mirror tile reuses the slab storage");
-    __shared__ __attribute__((aligned(16))) double smem[NSTG * 2 * SLAB];   // [buf][A|B][BK][64]; later the mirror tile
     const int T = (p + BM - 1) / BM;
     const int blockTile = b;
     const bool second = k >= K;
@@ -741,18 +742,129 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
     }
 }
 
+// The bound validation of a speculative Omega-step as extra workgroups of a product launch (CwRider, kernels.hpp): workgroup
+// idx of the rider takes rows 16 bx .. 16 bx + 15 of instance k.  Arithmetic and order are those of k_bound_rows (row sums in
+// tile-column order, their maximum) and k_cw_final (lane-strided products, wave sums, memory-side atomic max and arrival, the
+// Frobenius shares added in tile order by the last workgroup of the instance) -- the bound and the vector left for the next
+// iteration are the same bits.  Every workgroup adds the row sums of its instance itself (T p loads out of L2; the only thing
+// it needs of them is their maximum, the scale of the next vector): hidden work on CUs the product leaves idle.
+__device__ __forceinline__ void cw_rider_body(const CwRider& r, int idx, double* sh)
+{
+    const int k = idx / r.nbx, bx = idx - k * r.nbx;
+    if (k >= r.K) return;
+    const int p = r.p;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double mxd = 0.0;
+    for (int j = threadIdx.x; j < p; j += 256) {
+        const double* rp = r.rowpart + (size_t)k * r.T * p + j;
+        double v = 0.0;
+        for (int s2 = 0; s2 < r.T; ++s2) v += rp[(size_t)s2 * p];
+        mxd = fmax(mxd, v);
+        if (bx == 0 && r.d_out) r.d_out[(size_t)k * p + j] = v;
+    }
+    mxd = wave_max(mxd);
+    if (lane == 0) sh[wave] = mxd;
+    __syncthreads();
+    const double inf0 = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    __syncthreads();
+    const double scale = 1.0 / inf0;
+    const double* dk = r.dprev + (size_t)k * p;
+    const int r0 = bx * 16 + wave * 4;
+    const double* w = r.B + (size_t)k * p * p;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    size_t ro[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ok[q] = (r0 + q) < p;
+        ro[q] = (size_t)min(r0 + q, p - 1) * p;
+    }
+    for (int j = lane; j < p; j += 64) {
+        const double dj = dk[j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] += fabs(w[ro[q] + j]) * dj;
+    }
+    double mx = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double y = wave_sum(a[q]);
+        if (ok[q]) {
+            mx = fmax(mx, y / dk[r0 + q]);
+            if (r.dnext && lane == 0) {
+                const double v = y * scale;
+                r.dnext[(size_t)k * p + r0 + q] = (v > 0.0 && isfinite(v)) ? v : 1.0;
+            }
+        }
+    }
+    if (lane == 0) sh[wave] = mx;
+    __syncthreads();
+    int* last = reinterpret_cast<int*>(sh + 4);
+    if (threadIdx.x == 0) {
+        mx = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+        const unsigned long long old = __hip_atomic_fetch_max(r.cwmax + k, (unsigned long long)__double_as_longlong(mx),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned arrive = 1u + (unsigned)(old >> 63);
+        *last = __hip_atomic_fetch_add(r.cnt + k, arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)r.nbx - 1;
+    }
+    __syncthreads();
+    if (!*last) return;
+    double cw = 0.0;
+    if (threadIdx.x == 0) {
+        cw = __longlong_as_double((long long)__hip_atomic_exchange(r.cwmax + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __hip_atomic_store(r.cnt + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    double sq = 0.0;
+    double* shfro = sh + 8;
+    for (int t0 = 0; t0 < r.ntile; t0 += 256) {
+        const int t = t0 + (int)threadIdx.x;
+        __syncthreads();
+        shfro[threadIdx.x] = (t < r.ntile) ? r.fropart[(size_t)k * r.ntile + t] : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int m = min(256, r.ntile - t0);
+            for (int q = 0; q < m; ++q) sq += shfro[q];
+        }
+    }
+    if (threadIdx.x != 0) return;
+    double inf = inf0;
+    const double fr = sqrt(sq);
+    if (isfinite(cw) && cw > 0.0) { const double wv = cw * (1.0 + 1e-12); inf = (wv < inf) ? wv : inf; }
+    const double b = sqrt((fr < inf) ? fr : inf);
+    r.out[k] = b;
+    if (r.flag && !(b <= r.cuse[k])) {
+        atomicOr(r.flag + r.flag_slot, 1);
+        r.flag_host[r.flag_slot] = 1;
+    }
+}
+
+// a rider nobody took (symm_flush_rider)
+__global__ __launch_bounds__(256) void k_cw_rider(const CwRider rider)
+{
+    __shared__ __attribute__((aligned(16))) double sh[8 + 256];
+    cw_rider_body(rider, (int)blockIdx.x, sh);
+}
+
 template <int BK, int NSTG, int ABL = 0, int BM = 64, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ A, const double* __restrict__ B,
                                                  double* __restrict__ C, double* __restrict__ C2,
                                                  const double* __restrict__ E, const double* __restrict__ coef, int K,
                                                  int p, const double* __restrict__ A1, const double* __restrict__ B1,
                                                  double* __restrict__ C1, int K1, double* __restrict__ maxdev,
-                                                 double* __restrict__ rowpart, double* __restrict__ fropart)
+                                                 double* __restrict__ rowpart, double* __restrict__ fropart, const CwRider rider)
 {
+    __shared__ __attribute__((aligned(16))) double smem[NSTG * 2 * BK * BM];
     const int T = (p + BM - 1) / BM;
+    if constexpr (NW == 4) {
+        // workgroups behind the product's own: the bound validation of the previous launch's output (CwRider)
+        const int base = xcd_grid(T * (T + 1) / 2, K + K1);
+        if ((int)blockIdx.x >= base) {
+            cw_rider_body(rider, (int)blockIdx.x - base, smem);
+            return;
+        }
+    }
     int k, b;
     if (!decode_block_xcd(T * (T + 1) / 2, K + K1, k, b)) return;
-    symm_dl_tile<BK, NSTG, ABL, BM, NW>(A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, k, b);
+    symm_dl_tile<BK, NSTG, ABL, BM, NW>(A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, k, b, smem);
 }
 
 #ifdef GGL_DEV
@@ -1106,6 +1218,7 @@ __global__ __launch_bounds__(256) void k_symm_sk(const double* __restrict__ A, c
 template <int BK, int NSTG, int BM, int AUX>
 __global__ __launch_bounds__(256) void k_omega_chain(const ChainProg P, unsigned* __restrict__ state)
 {
+    __shared__ __attribute__((aligned(16))) double smem[NSTG * 2 * BK * BM];
     __shared__ int sh_job[3];
     __shared__ unsigned char sh_step[CHAIN_MAX_INST];         // per instance of this XCD: the product last seen ready
     unsigned xcc;
@@ -1176,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_omega_chain(const ChainProg P, unsigned
         int kk = jk;
         if (o.pair && jb >= P.ntiles) { kk = P.K + jk; jb -= P.ntiles; }
         symm_dl_tile<BK, NSTG, 0, BM, 4, AUX>(o.A, o.B, o.C, o.C2, o.E, o.coef, P.K, P.p, o.A1, o.B1, o.C1, o.pair ? P.K : 0,
-                                               nullptr, o.rowpart, o.fropart, kk, jb);
+                                               nullptr, o.rowpart, o.fropart, kk, jb, smem);
         // this tile's stores are in the XCD's L2 before the arrival is counted; the barrier also frees the LDS image
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1281,6 +1394,7 @@ template <int BK, int NSTG, int BM>
 __global__ __launch_bounds__(256) void k_symm_chain_probe(double* X0, double* X1, const double* coef, int K, int p,
                                                           int nprod, unsigned* bar, unsigned* err, int two_level)
 {
+    __shared__ __attribute__((aligned(16))) double smem[NSTG * 2 * BK * BM];
     const int T = (p + BM - 1) / BM, ntiles = T * (T + 1) / 2;
     const int total = xcd_grid(ntiles, K);
     unsigned xcd = blockIdx.x % NXCD;
@@ -1298,7 +1412,7 @@ __global__ __launch_bounds__(256) void k_symm_chain_probe(double* X0, double* X1
             int k, b;
             if (decode_block_xcd(ntiles, K, k, b, L))
                 symm_dl_tile<BK, NSTG, 0, BM, 4>(src, src, dst, nullptr, nullptr, coef, K, p, nullptr, nullptr, nullptr, 0,
-                                                 nullptr, nullptr, nullptr, k, b);
+                                                 nullptr, nullptr, nullptr, k, b, smem);
             __syncthreads();                                         // the slab storage is reused by the next tile
         }
         if (j + 1 < nprod) {
@@ -1335,14 +1449,28 @@ int launch_chain_probe(hipStream_t st, double* X0, double* X1, const double* coe
 }
 #endif
 
+static thread_local CwRider g_rider;          // pending (K > 0): see symm_set_rider
+void symm_set_rider(const CwRider& r) { g_rider = r; }
+void symm_flush_rider(hipStream_t st)
+{
+    if (g_rider.K <= 0) return;
+    hipLaunchKernelGGL(k_cw_rider, dim3(g_rider.K * g_rider.nbx), dim3(256), 0, st, g_rider);
+    g_rider = CwRider{};
+}
+
 static void launch_dl(hipStream_t st, const double* A, const double* B, double* C, double* C2, const double* E,
                       const double* coef, int K, int p, const double* A1, const double* B1, double* C1, int K1,
                       double* maxdev, int dl_cfg = 0, double* rowpart = nullptr, double* fropart = nullptr)
 {
-#define GGL_DL(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart)
+    // (the eight-wave development variants do not carry riders: the rider stays pending)
+    const bool eight = dl_cfg == 6 || dl_cfg == 7;
+    const CwRider rider = (g_rider.K > 0 && !eight) ? g_rider : CwRider{};
+    if (rider.K > 0) g_rider = CwRider{};
+    const int nride = rider.K * rider.nbx;
+#define GGL_DL(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, rider)
     if (dl_cfg == 4 || (dl_cfg >= 8 && dl_cfg <= 13) || (dl_cfg >= 18 && dl_cfg <= 21)) {
         const int T32 = (p + 31) / 32;
-        const dim3 grid(xcd_grid(T32 * (T32 + 1) / 2, K + K1));
+        const dim3 grid(xcd_grid(T32 * (T32 + 1) / 2, K + K1) + nride);
         // 32x32 tiles, k-slab 32, double buffer: 32 KiB of LDS, five workgroups per CU.  Measured (MI355X, p = 500, us per
         // launch at K = 2 / 4 / 8 / 16): 15.9 / 21.8 / 35.0 / 58.6, against 16.3 / 26.4 / 40.2 / 70.3 with four slabs in
         // flight (64 KiB, two workgroups per CU: residency, not prefetch depth, is what the small batches lack)
@@ -1364,13 +1492,13 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
         return;
     }
     const int T = (p + 63) / 64;
-    const dim3 grid(xcd_grid(T * (T + 1) / 2, K + K1));
+    const dim3 grid(xcd_grid(T * (T + 1) / 2, K + K1) + nride);
 #ifdef GGL_DEV
     if (dl_cfg == 6 || dl_cfg == 7) {
         // eight waves per workgroup (two per SIMD) for batches that leave one workgroup per CU.  Measured (MI355X, p = 500):
         // K = 4: 27.0 / 26.3 us vs 26.6 us for the 32x32 kernel; K = 8: 43.9 / 49.3 vs 40.4; K = 16: 68.6 / 74.9 vs 63.9 --
         // no gain anywhere, so the shipped library does not carry them
-#define GGL_DL8(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(512), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart)
+#define GGL_DL8(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(512), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, rider)
         if (dl_cfg == 6) GGL_DL8(16, 4, 0, 64, 8);
         else GGL_DL8(32, 3, 0, 64, 8);
 #undef GGL_DL8

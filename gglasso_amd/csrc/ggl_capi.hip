@@ -120,6 +120,8 @@ struct ggl_ctx {
     // GGL_OPT_JOIN_FLAG: the parts of a speculative chain are joined through flag words in device memory (k_set_flag /
     // k_wait_flags) instead of a cross-queue event wait
     bool join_flag = true;
+    int cw_rider = 1;                          // GGL_OPT_CW_RIDER: 0 two kernels, 1 rides in the next product launch, 2 the rider's own launch
+    long long cw_rides = 0;
     bool parts_serial = false;                 // probe_part_streams found no part stream that runs beside the main one
     unsigned long long* join_words = nullptr;   // device [MAX_PARTS]
     unsigned long long join_seq = 0;
@@ -651,6 +653,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_BOUND_SIDE: c->bound_side = (int)v; break;
         case GGL_OPT_LDS_PINNED: c->lds_pinned = v != 0.0; break;
         case GGL_OPT_JOIN_FLAG: c->join_flag = v != 0.0; break;
+        case GGL_OPT_CW_RIDER: c->cw_rider = (int)v; break;
         case GGL_OPT_PART_PRIORITY: {
             if (v != 0.0 && v != 1.0 && v != 2.0) return fail(GGL_E_ARG, "bad argument: GGL_OPT_PART_PRIORITY is 0, 1 or 2");
             if (!c->omega_ns || (int)v == c->part_priority) break;
@@ -727,6 +730,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_BOUND_SIDE: *value = c->bound_side; break;
         case GGL_OPT_LDS_PINNED: *value = c->lds_pinned; break;
         case GGL_OPT_JOIN_FLAG: *value = c->join_flag; break;
+        case GGL_OPT_CW_RIDER: *value = c->cw_rider; break;
         case GGL_OPT_PART_PRIORITY: *value = c->part_priority; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
@@ -1706,7 +1710,23 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 HIPCHK(hipStreamWaitEvent(sb, c->ev_bfork[h], 0));
                 bfree = c->ev_bjoin[h];
             }
-            if (btile) {
+            // GGL_OPT_CW_RIDER: the validation rides in the first product launch of ns_run (CwRider, kernels.hpp) -- needs the
+            // Collatz-Wielandt vector of the previous iteration
+            const bool ride = c->cw_rider && spec && btile && !c->fused_cw && sb == sh && c->cw_warm && c->cw_have;
+            if (ride) {
+                CwRider r;
+                r.B = Bp; r.rowpart = rowp; r.fropart = frop;
+                r.dprev = c->cwvec[c->cw_cur] + (size_t)k0 * c->p;
+                r.dnext = c->cwvec[c->cw_cur ^ 1] + (size_t)k0 * c->p;
+                r.d_out = c->nbrow + (size_t)k0 * c->p;
+                r.cwmax = c->cwmax + k0; r.cnt = c->cwcnt + k0; r.out = c->bounds_h + k0; r.cuse = c->cuse + k0;
+                r.flag = c->spec_flag; r.flag_host = c->spec_flag_h; r.flag_slot = h;
+                r.T = bT; r.ntile = bT * (bT + 1) / 2; r.p = c->p; r.K = Kh[h]; r.nbx = (c->p + 15) / 16;
+                symm_set_rider(r);
+                if (c->cw_rider == 2) symm_flush_rider(sh);
+                c->cw_rides += 1;
+                cw_written = true;
+            } else if (btile) {
                 if (c->fused_cw) {
                     launch_bound_cw(sh, Bp, rowp, bT, Kh[h], c->p, c->nbrow + (size_t)k0 * c->p, frop, bT * (bT + 1) / 2,
                                     c->cwmax + k0, c->cwcnt + k0, c->bounds_h + k0, spec ? c->cuse + k0 : nullptr,
@@ -1738,6 +1758,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 ns_run(sh, plans[h], c->coef + h * region, start_base_d + 5 * k0, c->W + k0 * pp, c->nsYP[0] + k0 * pp,
                        c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kh[h], c->p,
                        var_parts, nh > 1 ? c->n : 0, fused[h] != nullptr, bfree);
+                symm_flush_rider(sh);                     // (a chain without a direct-to-LDS product launch: its own launch)
                 c->ns_launches_total += plans[h].products;
                 const double frac = (double)Kh[h] / K;
                 c->ns_units_frac += frac * plans[h].units;
@@ -3090,6 +3111,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->bound_side = src->bound_side;
     c->lds_pinned = src->lds_pinned;
     c->join_flag = src->join_flag;
+    c->cw_rider = src->cw_rider;
     c->step_latent = src->step_latent;
     c->nk_valid = false;
     if (src->l_ns && src->Ckeep && src->Ckeep_beta) {
@@ -3199,7 +3221,7 @@ extern "C" int ggl_lds_stats(ggl_ctx* c, long long out[4])
 // Pipelining across iterations (GGL_OPT_PIPELINE): { whole chains launched ahead of the caller's next step, of those forgotten
 // (rho changed), early first parts put into the stream before the wait for the residuals, of those continued, fresh streams the
 // concurrency probe of the part streams had to try (0: the part stream ran beside the main stream; -1: not probed yet) }
-extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[7])
+extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[8])
 {
     ARGCHK(c && out, "ctx, out");
     out[0] = c->pre_launched;
@@ -3209,6 +3231,7 @@ extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[7])
     out[4] = c->parts_probed ? c->parts_replaced : -1;
     out[5] = c->wf_written;
     out[6] = c->wf_used;
+    out[7] = c->cw_rides;
     return GGL_OK;
 }
 

@@ -327,6 +327,32 @@ double mfma_valu_mix_tflops(hipStream_t st, double* scratch, int blocks, int ite
 void launch_gemm_right(hipStream_t st, const double* A, const double* T, double* C, const double* scal,
                        int nbatch, int K, int p, int variant);
 
+
+// The speculative Omega-step's bound validation (launch_bound_rows + launch_cw_final) riding in the NEXT product launch: the
+// launches of a small sequence leave most CUs idle (K = 4, p = 500: 144 workgroups on 256 CUs) and the schedule does not
+// depend on the validation, so the validating workgroups are appended to the grid of the first product after B' instead of
+// sitting between B' and that product as two dependent launches (event timeline, round 5: 8.5 + 18.8 us of a K = 4 slab's
+// 220 us, 6.5 + 12.6 of (20,200)'s 192).  Same arithmetic in the same order as the two kernels: same bound, same vector.
+// Needs the Collatz-Wielandt vector of the previous iteration (dprev); the cold first step keeps the two launches.
+struct CwRider {
+    const double* B = nullptr;            // B' [K][p][p]
+    const double* rowpart = nullptr;      // [K][T][p] row-sum partials of the B' launch
+    const double* fropart = nullptr;      // [K][ntile]
+    const double* dprev = nullptr;        // [K][p]
+    double* dnext = nullptr;              // [K][p] (optional)
+    double* d_out = nullptr;              // [K][p] row sums (optional)
+    unsigned long long* cwmax = nullptr;  // [K], zero on entry, left zero
+    unsigned* cnt = nullptr;              // [K], zero on entry, left zero
+    double* out = nullptr;                // [K] bounds (pinned host)
+    const double* cuse = nullptr;         // [K] the bound the running schedule assumes
+    int* flag = nullptr;
+    int* flag_host = nullptr;
+    int flag_slot = 0;
+    int T = 0, ntile = 0, p = 0, K = 0;   // K = 0: no rider
+    int nbx = 0;                          // workgroups per instance, 16 rows each
+};
+void symm_set_rider(const CwRider& r);    // taken by the next launch_symm of this host thread that runs the direct-to-LDS kernel
+void symm_flush_rider(hipStream_t st);    // a rider nobody took gets a launch of its own
 // event timeline (ggl_trace_*): fn(stream, kind 0 single / 1 pair, arg) after every product launch; null switches it off
 void symm_set_launch_hook(void (*fn)(hipStream_t, int, void*), void* arg);
 // two independent symmetric products in one launch; coef2K: [2K][NS_NCOEF] (second half for the second product)

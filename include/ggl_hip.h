@@ -152,6 +152,11 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_JOIN_FLAG 30       /* [1] concurrent parts of a speculative Omega-step are joined through flag words in device memory (a one-wave
                                       kernel on the main stream polls what the parts' streams set behind their last launch) instead of a
                                       cross-queue event wait, which idles the waiting queue ~25 us after the event has fired */
+#define GGL_OPT_CW_RIDER 31        /* [1] speculative Omega-step: the validation of the assumed spectral bound (row sums, Collatz-Wielandt ratio,
+                                      Frobenius norm of B' = A'^2) runs as extra workgroups of the first product launch after B' instead of two
+                                      dependent launches in front of it (the schedule does not wait for it; small launch sequences leave most
+                                      CUs idle).  Same arithmetic, same bound.  2: the rider as a launch of its own (what a chain without such a
+                                      product launch gets; for tests). */
 #define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
                                       2 = with the lowest stream priority (streams of another priority never share a hardware queue with
                                       the ctx's main stream) */
@@ -468,8 +473,9 @@ int ggl_lds_stats(ggl_ctx *ctx, long long out[4]);
  * iteration's residuals), of those continued, fresh streams the concurrency probe had to try before the first two-part
  * Omega-step until one ran BESIDE the ctx's main stream (HIP streams share a small pool of hardware queues, and two streams on
  * one queue serialise; 0: the part stream was fine, -1: not probed yet), Theta-steps that also wrote the next Omega-step's W
- * (GGL_OPT_FUSED_W), of those used by the early first part that followed }. */
-int ggl_pipeline_stats(ggl_ctx *ctx, long long out[7]);
+ * (GGL_OPT_FUSED_W), of those used by the early first part that followed, bound validations that rode in a product launch
+ * (GGL_OPT_CW_RIDER; counted per part) }. */
+int ggl_pipeline_stats(ggl_ctx *ctx, long long out[8]);
 /* L-step (sign iteration): out = { calls, calls whose first pass was continued on a compact sub-batch, instances continued in
  * total, calls that fell back to the eigendecomposition } */
 int ggl_rank_stats(ggl_ctx *ctx, long long out[4]);

@@ -727,8 +727,12 @@ def test_bound_validation_on_a_side_stream_is_bitwise(sol, K, p):
         outs = []
         # (side, join_flag): the validation kernels in the chain / on a side stream; the parts joined through flag words in
         # device memory (GGL_OPT_JOIN_FLAG, the default) / through a cross-queue event -- all four orders of the same kernels
-        for side, jf in ((0, 1), (1, 1), (0, 0), (1, 0)):
-            eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"bound_side": side, "join_flag": jf, **extra})
+        # rider: the validation as extra workgroups of the first product launch behind B' (GGL_OPT_CW_RIDER, the default; same
+        # arithmetic in the same order) / as the two kernels / (2) as the launch of its own a rider gets that no product takes
+        rides = []
+        for side, jf, rider in ((0, 1, 0), (1, 1, 0), (0, 0, 0), (1, 0, 0), (0, 1, 1), (0, 0, 1), (0, 1, 2)):
+            eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S),
+                                   options={"bound_side": side, "join_flag": jf, "cw_rider": rider, **extra})
             rho = 1.0
             for it in range(14):
                 sq = eng.step(rho, 0.05, 0.01, "GGL", False, None, nk).copy()
@@ -738,11 +742,14 @@ def test_bound_validation_on_a_side_stream_is_bitwise(sol, K, p):
                     eng.scale_X(rho / new)
                 rho = new
             outs.append((eng.state(), eng.ns_stats()))
+            rides.append(eng.pipeline_stats()["bound_rides"])
             eng.close()
         for o in outs[1:]:
             for nm in ("Omega", "Theta", "X"):
                 assert np.array_equal(outs[0][0][nm], o[0][nm]), (nm, extra)
-            assert outs[0][1]["spec_misses"] == o[1]["spec_misses"]
+        misses = [o[1]["spec_misses"] for o in outs]
+        assert len(set(misses)) == 1, (misses, rides, extra)
+        assert rides[:4] == [0, 0, 0, 0] and min(rides[4:]) >= (2 if extra else 6), rides       # (a rejected step leaves no vector to ride on)
         if extra:
             assert outs[1][1]["spec_misses"] >= 2
         else:
