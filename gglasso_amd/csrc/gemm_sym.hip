@@ -850,7 +850,8 @@ __global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ 
                                                  const double* __restrict__ E, const double* __restrict__ coef, int K,
                                                  int p, const double* __restrict__ A1, const double* __restrict__ B1,
                                                  double* __restrict__ C1, int K1, double* __restrict__ maxdev,
-                                                 double* __restrict__ rowpart, double* __restrict__ fropart, const CwRider rider)
+                                                 double* __restrict__ rowpart, double* __restrict__ fropart, const CwRider rider,
+                                                 const CopySegs cps)
 {
     __shared__ __attribute__((aligned(16))) double smem[NSTG * 2 * BK * BM];
     const int T = (p + BM - 1) / BM;
@@ -858,7 +859,29 @@ __global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ 
         // workgroups behind the product's own: the bound validation of the previous launch's output (CwRider)
         const int base = xcd_grid(T * (T + 1) / 2, K + K1);
         if ((int)blockIdx.x >= base) {
-            cw_rider_body(rider, (int)blockIdx.x - base, smem);
+            const int idx = (int)blockIdx.x - base, ncw = rider.K * rider.nbx;
+            if (idx < ncw) cw_rider_body(rider, idx, smem);
+            else {
+                // (k_copy_small: words from the pinned tables, or zeros; 1024 words per workgroup, so that no thread waits for
+                // more than four reads over PCIe one after the other -- one workgroup per segment took 45 us for the 30 KB of a
+                // K = 64 schedule)
+                int blk = idx - ncw;
+                for (int sgi = 0; sgi < cps.n; ++sgi) {
+                    const int nb = (int)((cps.words[sgi] + 1023u) / 1024u);
+                    if (blk < nb) {
+                        unsigned* d = (unsigned*)cps.dst[sgi];
+                        const unsigned* src = (const unsigned*)cps.src[sgi];
+                        const unsigned i0 = (unsigned)blk * 1024u + threadIdx.x;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned i = i0 + 256u * e;
+                            if (i < cps.words[sgi]) d[i] = src ? src[i] : 0u;
+                        }
+                        break;
+                    }
+                    blk -= nb;
+                }
+            }
             return;
         }
     }
@@ -1450,9 +1473,15 @@ int launch_chain_probe(hipStream_t st, double* X0, double* X1, const double* coe
 #endif
 
 static thread_local CwRider g_rider;          // pending (K > 0): see symm_set_rider
+static thread_local CopySegs g_copy_rider;    // pending (n > 0): see symm_set_copy_rider
 void symm_set_rider(const CwRider& r) { g_rider = r; }
+void symm_set_copy_rider(const CopySegs& sg) { g_copy_rider = sg; }
 void symm_flush_rider(hipStream_t st)
 {
+    if (g_copy_rider.n > 0) {
+        launch_copy_small(st, g_copy_rider);
+        g_copy_rider = CopySegs{};
+    }
     if (g_rider.K <= 0) return;
     hipLaunchKernelGGL(k_cw_rider, dim3(g_rider.K * g_rider.nbx), dim3(256), 0, st, g_rider);
     g_rider = CwRider{};
@@ -1466,8 +1495,12 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
     const bool eight = dl_cfg == 6 || dl_cfg == 7;
     const CwRider rider = (g_rider.K > 0 && !eight) ? g_rider : CwRider{};
     if (rider.K > 0) g_rider = CwRider{};
-    const int nride = rider.K * rider.nbx;
-#define GGL_DL(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, rider)
+    const CopySegs cps = (g_copy_rider.n > 0 && !eight) ? g_copy_rider : CopySegs{};
+    if (cps.n > 0) g_copy_rider = CopySegs{};
+    int ncopy = 0;
+    for (int i = 0; i < cps.n; ++i) ncopy += (int)((cps.words[i] + 1023u) / 1024u);
+    const int nride = rider.K * rider.nbx + ncopy;
+#define GGL_DL(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, rider, cps)
     if (dl_cfg == 4 || (dl_cfg >= 8 && dl_cfg <= 13) || (dl_cfg >= 18 && dl_cfg <= 21)) {
         const int T32 = (p + 31) / 32;
         const dim3 grid(xcd_grid(T32 * (T32 + 1) / 2, K + K1) + nride);
@@ -1498,7 +1531,7 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
         // eight waves per workgroup (two per SIMD) for batches that leave one workgroup per CU.  Measured (MI355X, p = 500):
         // K = 4: 27.0 / 26.3 us vs 26.6 us for the 32x32 kernel; K = 8: 43.9 / 49.3 vs 40.4; K = 16: 68.6 / 74.9 vs 63.9 --
         // no gain anywhere, so the shipped library does not carry them
-#define GGL_DL8(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(512), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, rider)
+#define GGL_DL8(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(512), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, rider, cps)
         if (dl_cfg == 6) GGL_DL8(16, 4, 0, 64, 8);
         else GGL_DL8(32, 3, 0, 64, 8);
 #undef GGL_DL8

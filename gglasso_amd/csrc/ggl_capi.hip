@@ -120,6 +120,9 @@ struct ggl_ctx {
     // GGL_OPT_JOIN_FLAG: the parts of a speculative chain are joined through flag words in device memory (k_set_flag /
     // k_wait_flags) instead of a cross-queue event wait
     bool join_flag = true;
+    int copy_rider = 1;                        // GGL_OPT_COPY_RIDER: 0 off, 1 single launch sequences only, 2 always
+    long long copy_rides = 0;
+    std::vector<double> pre0_beta;             // [K] the beta the DEVICE's coefficient rows of A' were last written for (NaN: none)
     int cw_rider = 1;                          // GGL_OPT_CW_RIDER: 0 two kernels, 1 rides in the next product launch, 2 the rider's own launch
     long long cw_rides = 0;
     bool parts_serial = false;                 // probe_part_streams found no part stream that runs beside the main one
@@ -554,6 +557,7 @@ static int ctx_alloc(ggl_ctx* c)
         c->pre_beta = (double*)malloc(c->K * sizeof(double));
         c->early.beta = (double*)malloc(c->K * sizeof(double));
         c->wf_beta = (double*)malloc(c->K * sizeof(double));
+        c->pre0_beta.assign(c->K, std::nan(""));
         DEV(c->maxdev, 2 * c->K * sizeof(double));          // [K] residuals | [K] traces of the sign iterate
         PIN(c->maxdev_h, 2 * c->K * sizeof(double), 1);
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -654,6 +658,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_LDS_PINNED: c->lds_pinned = v != 0.0; break;
         case GGL_OPT_JOIN_FLAG: c->join_flag = v != 0.0; break;
         case GGL_OPT_CW_RIDER: c->cw_rider = (int)v; break;
+        case GGL_OPT_COPY_RIDER: c->copy_rider = (int)v; break;
         case GGL_OPT_PART_PRIORITY: {
             if (v != 0.0 && v != 1.0 && v != 2.0) return fail(GGL_E_ARG, "bad argument: GGL_OPT_PART_PRIORITY is 0, 1 or 2");
             if (!c->omega_ns || (int)v == c->part_priority) break;
@@ -731,6 +736,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_LDS_PINNED: *value = c->lds_pinned; break;
         case GGL_OPT_JOIN_FLAG: *value = c->join_flag; break;
         case GGL_OPT_CW_RIDER: *value = c->cw_rider; break;
+        case GGL_OPT_COPY_RIDER: *value = c->copy_rider; break;
         case GGL_OPT_PART_PRIORITY: *value = c->part_priority; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
@@ -1355,6 +1361,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
     const double* beta = c->par;
     const int nxt = c->cur ^ 1;
     c->step_latent = latent;
+    if (latent && !c->pre0_beta.empty()) std::fill(c->pre0_beta.begin(), c->pre0_beta.end(), std::nan(""));   // (the L-step's tables share the buffer)
     CopySegs first;
     if (pending) first = *pending;
     // a step whose kernels read their parameters from the pinned mirror never uploaded them: whoever reads the DEVICE copy
@@ -1643,8 +1650,22 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             if (!resume) {
             // ---- first part: parameter tables, W, A', B' (scratch only) ----
             // the pending parameter transfers are repeated on every part's stream (identical values, a few KB)
+            // GGL_OPT_COPY_RIDER: nothing pending and the device's coefficient rows of A' = W^2 + 4 beta I already those of this
+            // beta (they only change with rho): no launch of its own reads the rest before B', so the tables ride in the A'
+            // launch (symm_set_copy_rider) -- one dependent launch less between the norm reduction and A'
+            // MEASURED (profiles/r5_copy_rider_ab.txt, three interleaved pairs per workload in one box): single launch sequences
+            // K = 4 slab +4 %, (20,200) +4 %, K = 16 +1.4 %, (64,100) +4 %, (32,128) +5 %; TWO concurrent parts lose -- headline
+            // -2.3 %, K = 8 slab -5 %, three of three pairs each (both A' launches end ~7 us earlier in the event timeline and
+            // the iteration is no shorter: the parts are bound by what they share, not by their first launch) -- so: 1 = only
+            // where the chain is one sequence.
+            bool ride_copy = (c->copy_rider == 2 || (c->copy_rider == 1 && nh == 1)) && first.n == 0 && !latent && btile != 0 &&
+                             !c->chain_mode && c->prof_on != 1;
+            for (int k = k0; ride_copy && k < k0 + Kh[h]; ++k) ride_copy = (c->pre0_beta[k] == c->par_h[k]);
             CopySegs sg = first;
-            sg.add(pre_d + NS_NCOEF * (size_t)k0, pre + NS_NCOEF * (size_t)k0, (size_t)Kh[h] * NS_NCOEF * sizeof(double));
+            if (!ride_copy) {
+                sg.add(pre_d + NS_NCOEF * (size_t)k0, pre + NS_NCOEF * (size_t)k0, (size_t)Kh[h] * NS_NCOEF * sizeof(double));
+                for (int k = k0; k < k0 + Kh[h]; ++k) c->pre0_beta[k] = c->par_h[k];
+            }
             sg.add(pre_d + NS_SLOT(K) + NS_NCOEF * (size_t)k0, pre + NS_SLOT(K) + NS_NCOEF * (size_t)k0,
                    (size_t)Kh[h] * NS_NCOEF * sizeof(double));
             // validation flags of this step: this part's slot, and (part 0) the slot of the all-reduced flag of K-sharded
@@ -1660,8 +1681,13 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 sg.add(c->cuse + k0, c->cuse_h + k0, (size_t)Kh[h] * sizeof(double));
                 if (h == 0 && c->info_dirty) sg.add(c->info, nullptr, K * sizeof(int));
             }
-            launch_copy_small(sh, sg);
-            trace_mark(c, sh, 1);
+            if (ride_copy) {
+                symm_set_copy_rider(sg);
+                c->copy_rides += 1;
+            } else {
+                launch_copy_small(sh, sg);
+                trace_mark(c, sh, 1);
+            }
             if (h == 0) PB(c, GGL_PH_FORM_W);
             if (!w_ready) {
                 launch_form_W_sym(sh, c->W + k0 * pp, c->Theta + k0 * pp, latent ? c->L + k0 * pp : nullptr, c->X + k0 * pp,
@@ -1679,6 +1705,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             // over B'), and the Collatz-Wielandt pass finishes the bound itself.
             ns_prepare(sh, pre_d + NS_NCOEF * (size_t)k0, pre_d + NS_SLOT(K) + NS_NCOEF * (size_t)k0, c->W + k0 * pp, Ap, Bp, Kh[h], c->p,
                        var_parts, spec ? fused[h] : nullptr, rowp, frop);
+            symm_flush_rider(sh);
             if (early_ev) {
                 (void)hipEventRecord(c->ev_early[c->ev_early_par][1], c->stream);
                 c->ev_early_used[c->ev_early_par] = true;
@@ -3112,6 +3139,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->lds_pinned = src->lds_pinned;
     c->join_flag = src->join_flag;
     c->cw_rider = src->cw_rider;
+    c->copy_rider = src->copy_rider;
     c->step_latent = src->step_latent;
     c->nk_valid = false;
     if (src->l_ns && src->Ckeep && src->Ckeep_beta) {
@@ -3221,7 +3249,7 @@ extern "C" int ggl_lds_stats(ggl_ctx* c, long long out[4])
 // Pipelining across iterations (GGL_OPT_PIPELINE): { whole chains launched ahead of the caller's next step, of those forgotten
 // (rho changed), early first parts put into the stream before the wait for the residuals, of those continued, fresh streams the
 // concurrency probe of the part streams had to try (0: the part stream ran beside the main stream; -1: not probed yet) }
-extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[8])
+extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[9])
 {
     ARGCHK(c && out, "ctx, out");
     out[0] = c->pre_launched;
@@ -3232,6 +3260,7 @@ extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[8])
     out[5] = c->wf_written;
     out[6] = c->wf_used;
     out[7] = c->cw_rides;
+    out[8] = c->copy_rides;
     return GGL_OK;
 }
 

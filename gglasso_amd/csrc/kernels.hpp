@@ -351,8 +351,11 @@ struct CwRider {
     int T = 0, ntile = 0, p = 0, K = 0;   // K = 0: no rider
     int nbx = 0;                          // workgroups per instance, 16 rows each
 };
+// The same for the small host-to-device transfers in front of a chain (launch_copy_small): one extra workgroup per segment of
+// the NEXT direct-to-LDS product launch, for tables that launch itself does not read.
+void symm_set_copy_rider(const CopySegs& sg);
 void symm_set_rider(const CwRider& r);    // taken by the next launch_symm of this host thread that runs the direct-to-LDS kernel
-void symm_flush_rider(hipStream_t st);    // a rider nobody took gets a launch of its own
+void symm_flush_rider(hipStream_t st);    // riders nobody took get launches of their own
 // event timeline (ggl_trace_*): fn(stream, kind 0 single / 1 pair, arg) after every product launch; null switches it off
 void symm_set_launch_hook(void (*fn)(hipStream_t, int, void*), void* arg);
 // two independent symmetric products in one launch; coef2K: [2K][NS_NCOEF] (second half for the second product)

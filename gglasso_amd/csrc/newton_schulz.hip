@@ -589,6 +589,7 @@ void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, cons
     // start2 != null (the bound is already known): the B' launch also writes start2 = dI I + dC B' + dE A' -- the
     // first step's U (degree nine) or Z1 (quintic) -- with {dI, dC, dE} in pre1_d
     launch_symm(st, W, W, Ap, nullptr, nullptr, pre0_d, K, p, variant);
+    symm_flush_rider(st);         // (tables riding in the A' launch: a launch of another kernel family did not take them)
     launch_symm(st, Ap, Ap, Bp, start2, start2 ? Ap : nullptr, pre1_d, K, p, variant, nullptr, rowpart, fropart);
 }
 

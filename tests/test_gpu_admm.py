@@ -730,9 +730,13 @@ def test_bound_validation_on_a_side_stream_is_bitwise(sol, K, p):
         # rider: the validation as extra workgroups of the first product launch behind B' (GGL_OPT_CW_RIDER, the default; same
         # arithmetic in the same order) / as the two kernels / (2) as the launch of its own a rider gets that no product takes
         rides = []
-        for side, jf, rider in ((0, 1, 0), (1, 1, 0), (0, 0, 0), (1, 0, 0), (0, 1, 1), (0, 0, 1), (0, 1, 2)):
+        # copy rider (GGL_OPT_COPY_RIDER, the default): the chain's table transfers as extra workgroups of the A' launch / as
+        # the copy kernel in front of it
+        copies = []
+        for side, jf, rider, cpr in ((0, 1, 0, 0), (1, 1, 0, 0), (0, 0, 0, 0), (1, 0, 0, 0), (0, 1, 1, 0), (0, 0, 1, 0), (0, 1, 2, 0),
+                                     (0, 1, 1, 2), (0, 1, 0, 2)):
             eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S),
-                                   options={"bound_side": side, "join_flag": jf, "cw_rider": rider, **extra})
+                                   options={"bound_side": side, "join_flag": jf, "cw_rider": rider, "copy_rider": cpr, **extra})
             rho = 1.0
             for it in range(14):
                 sq = eng.step(rho, 0.05, 0.01, "GGL", False, None, nk).copy()
@@ -743,13 +747,15 @@ def test_bound_validation_on_a_side_stream_is_bitwise(sol, K, p):
                 rho = new
             outs.append((eng.state(), eng.ns_stats()))
             rides.append(eng.pipeline_stats()["bound_rides"])
+            copies.append(eng.pipeline_stats()["copy_rides"])
             eng.close()
         for o in outs[1:]:
             for nm in ("Omega", "Theta", "X"):
                 assert np.array_equal(outs[0][0][nm], o[0][nm]), (nm, extra)
         misses = [o[1]["spec_misses"] for o in outs]
         assert len(set(misses)) == 1, (misses, rides, extra)
-        assert rides[:4] == [0, 0, 0, 0] and min(rides[4:]) >= (2 if extra else 6), rides       # (a rejected step leaves no vector to ride on)
+        assert rides[:4] == [0, 0, 0, 0] and rides[8] == 0 and min(rides[4:8]) >= (2 if extra else 6), rides   # (a rejected step leaves no vector to ride on)
+        assert copies[:7] == [0] * 7 and min(copies[7:]) >= (1 if extra else 6), copies
         if extra:
             assert outs[1][1]["spec_misses"] >= 2
         else:
