@@ -837,6 +837,53 @@ __device__ __forceinline__ void cw_rider_body(const CwRider& r, int idx, double*
     }
 }
 
+// the norm reduction as a rider (RedRider): k_reduce_partials' single row -- four rows per trip, strided per-thread sums in
+// ascending order, wave sums, the four waves added in a fixed order -- then the sums and, behind them, the sequence number as
+// system-scope stores (posted writes to the host arrive in order; no cache write-back fence inside a product launch)
+__device__ __forceinline__ void red_rider_body(const RedRider& r, double* smem)
+{
+    double (*sh)[8] = reinterpret_cast<double (*)[8]>(smem);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nblk = r.nblk, nv = r.nv;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double* base = r.partials;
+    // (two rows per trip where k_reduce_partials takes four -- the same rows per thread in the same ascending order, hence the
+    // same sums -- so that this branch stays inside the product kernel's 81 registers: with four the 32x32 kernel went to 108
+    // and from five to four workgroups per CU)
+    for (int b = threadIdx.x; b < nblk; b += 512) {
+        double t[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int bb = b + 256 * u;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) t[u][v] = (v < nv && bb < nblk) ? base[(size_t)bb * nv + v] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (b + 256 * u < nblk) {
+#pragma unroll
+                for (int v = 0; v < 8; ++v)
+                    if (v < nv) acc[v] += t[u][v];
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        if (v < nv) {
+            const double s = wave_sum(acc[v]);
+            if (lane == 0) sh[wid][v] = s;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+        const double s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+        __hip_atomic_store(r.out + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(r.seq, r.seq_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // a rider nobody took (symm_flush_rider)
 __global__ __launch_bounds__(256) void k_cw_rider(const CwRider rider)
 {
@@ -851,15 +898,26 @@ __global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ 
                                                  int p, const double* __restrict__ A1, const double* __restrict__ B1,
                                                  double* __restrict__ C1, int K1, double* __restrict__ maxdev,
                                                  double* __restrict__ rowpart, double* __restrict__ fropart, const CwRider rider,
-                                                 const CopySegs cps)
+                                                 const CopySegs cps, const RedRider red)
 {
     __shared__ __attribute__((aligned(16))) double smem[NSTG * 2 * BK * BM];
     const int T = (p + BM - 1) / BM;
+    int bid = (int)blockIdx.x;
     if constexpr (NW == 4) {
-        // workgroups behind the product's own: the bound validation of the previous launch's output (CwRider)
+        // The norm reduction the host is waiting for rides in FRONT of the product's workgroups (dispatched first: behind them
+        // its result reached the host ~10 us after the Theta kernel had ended, in front ~5); NXCD slots, one of them working,
+        // so that the tiles keep their XCDs.
+        if (red.nblk > 0) {
+            if (bid < NXCD) {
+                if (bid == 0) red_rider_body(red, smem);
+                return;
+            }
+            bid -= NXCD;
+        }
+        // workgroups behind the product's own: the bound validation of the previous launch's output (CwRider), table transfers
         const int base = xcd_grid(T * (T + 1) / 2, K + K1);
-        if ((int)blockIdx.x >= base) {
-            const int idx = (int)blockIdx.x - base, ncw = rider.K * rider.nbx;
+        if (bid >= base) {
+            const int idx = bid - base, ncw = rider.K * rider.nbx;
             if (idx < ncw) cw_rider_body(rider, idx, smem);
             else {
                 // (k_copy_small: words from the pinned tables, or zeros; 1024 words per workgroup, so that no thread waits for
@@ -886,7 +944,7 @@ __global__ __launch_bounds__(NW * 64) void k_symm_dl(const double* __restrict__ 
         }
     }
     int k, b;
-    if (!decode_block_xcd(T * (T + 1) / 2, K + K1, k, b)) return;
+    if (!decode_block_xcd(T * (T + 1) / 2, K + K1, k, b, bid)) return;
     symm_dl_tile<BK, NSTG, ABL, BM, NW>(A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, k, b, smem);
 }
 
@@ -1474,10 +1532,17 @@ int launch_chain_probe(hipStream_t st, double* X0, double* X1, const double* coe
 
 static thread_local CwRider g_rider;          // pending (K > 0): see symm_set_rider
 static thread_local CopySegs g_copy_rider;    // pending (n > 0): see symm_set_copy_rider
+static thread_local RedRider g_red_rider;     // pending (nblk > 0): see symm_set_reduce_rider
+void symm_set_reduce_rider(const RedRider& r) { g_red_rider = r; }
 void symm_set_rider(const CwRider& r) { g_rider = r; }
 void symm_set_copy_rider(const CopySegs& sg) { g_copy_rider = sg; }
 void symm_flush_rider(hipStream_t st)
 {
+    if (g_red_rider.nblk > 0) {
+        launch_reduce_partials(st, g_red_rider.partials, 1, g_red_rider.nblk, g_red_rider.nv, g_red_rider.out, g_red_rider.seq,
+                               g_red_rider.seq_val);
+        g_red_rider = RedRider{};
+    }
     if (g_copy_rider.n > 0) {
         launch_copy_small(st, g_copy_rider);
         g_copy_rider = CopySegs{};
@@ -1497,10 +1562,12 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
     if (rider.K > 0) g_rider = CwRider{};
     const CopySegs cps = (g_copy_rider.n > 0 && !eight) ? g_copy_rider : CopySegs{};
     if (cps.n > 0) g_copy_rider = CopySegs{};
-    int ncopy = 0;
+    const RedRider red = (g_red_rider.nblk > 0 && !eight) ? g_red_rider : RedRider{};
+    if (red.nblk > 0) g_red_rider = RedRider{};
+    int ncopy = red.nblk > 0 ? NXCD : 0;          // (in front of the tiles, see k_symm_dl)
     for (int i = 0; i < cps.n; ++i) ncopy += (int)((cps.words[i] + 1023u) / 1024u);
     const int nride = rider.K * rider.nbx + ncopy;
-#define GGL_DL(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, rider, cps)
+#define GGL_DL(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(256), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, rider, cps, red)
     if (dl_cfg == 4 || (dl_cfg >= 8 && dl_cfg <= 13) || (dl_cfg >= 18 && dl_cfg <= 21)) {
         const int T32 = (p + 31) / 32;
         const dim3 grid(xcd_grid(T32 * (T32 + 1) / 2, K + K1) + nride);
@@ -1531,7 +1598,7 @@ static void launch_dl(hipStream_t st, const double* A, const double* B, double* 
         // eight waves per workgroup (two per SIMD) for batches that leave one workgroup per CU.  Measured (MI355X, p = 500):
         // K = 4: 27.0 / 26.3 us vs 26.6 us for the 32x32 kernel; K = 8: 43.9 / 49.3 vs 40.4; K = 16: 68.6 / 74.9 vs 63.9 --
         // no gain anywhere, so the shipped library does not carry them
-#define GGL_DL8(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(512), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, rider, cps)
+#define GGL_DL8(...) hipLaunchKernelGGL((k_symm_dl<__VA_ARGS__>), grid, dim3(512), 0, st, A, B, C, C2, E, coef, K, p, A1, B1, C1, K1, maxdev, rowpart, fropart, rider, cps, red)
         if (dl_cfg == 6) GGL_DL8(16, 4, 0, 64, 8);
         else GGL_DL8(32, 3, 0, 64, 8);
 #undef GGL_DL8

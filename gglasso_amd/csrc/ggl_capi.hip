@@ -120,6 +120,9 @@ struct ggl_ctx {
     // GGL_OPT_JOIN_FLAG: the parts of a speculative chain are joined through flag words in device memory (k_set_flag /
     // k_wait_flags) instead of a cross-queue event wait
     bool join_flag = true;
+    int red_rider = 2;                         // GGL_OPT_REDUCE_RIDER: 0 off, 1 single launch sequences only, 2 always
+    long long red_rides = 0;
+    RedRider red_pending;                      // a Theta-step's norm reduction waiting for the early part's A' launch
     int copy_rider = 1;                        // GGL_OPT_COPY_RIDER: 0 off, 1 single launch sequences only, 2 always
     long long copy_rides = 0;
     std::vector<double> pre0_beta;             // [K] the beta the DEVICE's coefficient rows of A' were last written for (NaN: none)
@@ -659,6 +662,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_JOIN_FLAG: c->join_flag = v != 0.0; break;
         case GGL_OPT_CW_RIDER: c->cw_rider = (int)v; break;
         case GGL_OPT_COPY_RIDER: c->copy_rider = (int)v; break;
+        case GGL_OPT_REDUCE_RIDER: c->red_rider = (int)v; break;
         case GGL_OPT_PART_PRIORITY: {
             if (v != 0.0 && v != 1.0 && v != 2.0) return fail(GGL_E_ARG, "bad argument: GGL_OPT_PART_PRIORITY is 0, 1 or 2");
             if (!c->omega_ns || (int)v == c->part_priority) break;
@@ -737,6 +741,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_JOIN_FLAG: *value = c->join_flag; break;
         case GGL_OPT_CW_RIDER: *value = c->cw_rider; break;
         case GGL_OPT_COPY_RIDER: *value = c->copy_rider; break;
+        case GGL_OPT_REDUCE_RIDER: *value = c->red_rider; break;
         case GGL_OPT_PART_PRIORITY: *value = c->part_priority; break;
         case GGL_OPT_RANK_DEFLATE: *value = c->rank_deflate; break;
         case GGL_OPT_RANK_L0_DEFLATE: *value = c->rank_l0_deflate; break;
@@ -1681,6 +1686,18 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 sg.add(c->cuse + k0, c->cuse_h + k0, (size_t)Kh[h] * sizeof(double));
                 if (h == 0 && c->info_dirty) sg.add(c->info, nullptr, K * sizeof(int));
             }
+            if (h == 0 && c->red_pending.nblk > 0) {
+                // (with anything else in front of A' the reduction goes first, as its own launch)
+                if (w_ready && (c->red_rider == 2 || nh == 1)) {
+                    symm_set_reduce_rider(c->red_pending);
+                    c->red_rides += 1;
+                } else {
+                    launch_reduce_partials(sh, c->red_pending.partials, 1, c->red_pending.nblk, c->red_pending.nv, c->red_pending.out,
+                                           c->red_pending.seq, c->red_pending.seq_val);
+                    trace_mark(c, sh, 21);
+                }
+                c->red_pending = RedRider{};
+            }
             if (ride_copy) {
                 symm_set_copy_rider(sg);
                 c->copy_rides += 1;
@@ -2404,9 +2421,25 @@ static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double l
         if (!latent) {
             PB(c, GGL_PH_REDUCE);
             if (!defer_norms && c->seq_h && c->spin_wait) c->seq_wait = ++c->seq_next;
-            launch_reduce_partials(c->stream, c->partials, 1, theta_partial_blocks(c->p, reg, c->K, flat), GGL_NNORM,
-                                   norms_dst, c->seq_wait ? c->seq_h : nullptr, c->seq_wait);
-            trace_mark(c, c->stream, 21);
+            // GGL_OPT_REDUCE_RIDER: the early first part of the next chain follows and its first launch is A' (W written by the
+            // Theta kernel above): the reduction rides in that launch (RedRider) -- maybe_early below hands it over, and
+            // launches it after all if no A' came
+            c->red_pending = RedRider{};
+            // MEASURED (profiles/r5_reduce_rider_ab.txt, three interleaved rounds per workload, always / off): K = 4 slab +3.9 %,
+            // K = 8 +1.8 %, (20,200) +2.5 %, K = 16 +1.7 %, headline +0.6 %, (64,100) +3 %, (32,128) +2.8 %.
+            if ((c->red_rider == 2 || (c->red_rider == 1 && c->last_parts == 1)) && wn_done && c->seq_wait && !defer_norms &&
+                c->prof_on != 1) {
+                c->red_pending.partials = c->partials;
+                c->red_pending.nblk = theta_partial_blocks(c->p, reg, c->K, flat);
+                c->red_pending.nv = GGL_NNORM;
+                c->red_pending.out = norms_dst;
+                c->red_pending.seq = c->seq_h;
+                c->red_pending.seq_val = c->seq_wait;
+            } else {
+                launch_reduce_partials(c->stream, c->partials, 1, theta_partial_blocks(c->p, reg, c->K, flat), GGL_NNORM,
+                                       norms_dst, c->seq_wait ? c->seq_h : nullptr, c->seq_wait);
+                trace_mark(c, c->stream, 21);
+            }
             trace_host(c, 101);
             PE(c, GGL_PH_REDUCE);
             rows = 1;
@@ -2440,6 +2473,13 @@ static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double l
     }
     if (!latent) {
         const int rce = maybe_early(c);
+        if (c->red_pending.nblk > 0) {
+            // no early part after all (or an error on the way): the reduction as its own launch
+            launch_reduce_partials(c->stream, c->red_pending.partials, 1, c->red_pending.nblk, c->red_pending.nv, c->red_pending.out,
+                                   c->red_pending.seq, c->red_pending.seq_val);
+            trace_mark(c, c->stream, 21);
+            c->red_pending = RedRider{};
+        }
         if (rce) return rce;
     }
     return finish_norms(c, rows, out_norms);
@@ -3140,6 +3180,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->join_flag = src->join_flag;
     c->cw_rider = src->cw_rider;
     c->copy_rider = src->copy_rider;
+    c->red_rider = src->red_rider;
     c->step_latent = src->step_latent;
     c->nk_valid = false;
     if (src->l_ns && src->Ckeep && src->Ckeep_beta) {
@@ -3249,7 +3290,7 @@ extern "C" int ggl_lds_stats(ggl_ctx* c, long long out[4])
 // Pipelining across iterations (GGL_OPT_PIPELINE): { whole chains launched ahead of the caller's next step, of those forgotten
 // (rho changed), early first parts put into the stream before the wait for the residuals, of those continued, fresh streams the
 // concurrency probe of the part streams had to try (0: the part stream ran beside the main stream; -1: not probed yet) }
-extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[9])
+extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[10])
 {
     ARGCHK(c && out, "ctx, out");
     out[0] = c->pre_launched;
@@ -3261,6 +3302,7 @@ extern "C" int ggl_pipeline_stats(ggl_ctx* c, long long out[9])
     out[6] = c->wf_used;
     out[7] = c->cw_rides;
     out[8] = c->copy_rides;
+    out[9] = c->red_rides;
     return GGL_OK;
 }
 

@@ -354,6 +354,17 @@ struct CwRider {
 // The same for the small host-to-device transfers in front of a chain (launch_copy_small): one extra workgroup per segment of
 // the NEXT direct-to-LDS product launch, for tables that launch itself does not read.
 void symm_set_copy_rider(const CopySegs& sg);
+// ... and for the single-row norm reduction behind a Theta-step (launch_reduce_partials with a sequence word) when the NEXT
+// chain's A' launch follows it in the stream anyway: out[v] = sum_b partials[b][v] in k_reduce_partials' order, then the
+// sequence number, by ONE extra workgroup (the first of the riders) of that launch.
+struct RedRider {
+    const double* partials = nullptr;
+    double* out = nullptr;                 // pinned host
+    unsigned long long* seq = nullptr;     // pinned host
+    unsigned long long seq_val = 0;
+    int nblk = 0, nv = 0;                  // nblk = 0: no rider
+};
+void symm_set_reduce_rider(const RedRider& r);
 void symm_set_rider(const CwRider& r);    // taken by the next launch_symm of this host thread that runs the direct-to-LDS kernel
 void symm_flush_rider(hipStream_t st);    // riders nobody took get launches of their own
 // event timeline (ggl_trace_*): fn(stream, kind 0 single / 1 pair, arg) after every product launch; null switches it off

@@ -501,10 +501,10 @@ class HipEngine:
 
     def pipeline_stats(self):
         import ctypes
-        out = (ctypes.c_longlong * 9)()
+        out = (ctypes.c_longlong * 10)()
         check(self.lib.ggl_pipeline_stats(self.h, out))
         return dict(zip(("prelaunched", "dropped", "early_launched", "early_used", "part_streams_tried", "w_fused", "w_fused_used",
-                         "bound_rides", "copy_rides"),
+                         "bound_rides", "copy_rides", "reduce_rides"),
                         (int(v) for v in out)))
 
     def eig_info(self):

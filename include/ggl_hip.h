@@ -161,6 +161,9 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                       flag zeroing) ride in the A' = W^2 + 4 beta I launch as extra workgroups when nothing else is pending and the
                                       device's coefficient rows of A' are already those of this beta: one dependent launch less per iteration.  1 = where the
                                       chain is ONE launch sequence (two concurrent parts measured slower with it), 2 = always, 0 = never */
+#define GGL_OPT_REDUCE_RIDER 33    /* [2] the norm reduction behind a Theta-step rides in the A' launch of the next chain's early first part (one extra
+                                      workgroup; same sums in the same order) when that launch follows it in the stream anyway: one dependent
+                                      launch less per iteration.  1 = single launch sequences, 2 = always, 0 = never */
 #define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
                                       2 = with the lowest stream priority (streams of another priority never share a hardware queue with
                                       the ctx's main stream) */
@@ -478,8 +481,9 @@ int ggl_lds_stats(ggl_ctx *ctx, long long out[4]);
  * Omega-step until one ran BESIDE the ctx's main stream (HIP streams share a small pool of hardware queues, and two streams on
  * one queue serialise; 0: the part stream was fine, -1: not probed yet), Theta-steps that also wrote the next Omega-step's W
  * (GGL_OPT_FUSED_W), of those used by the early first part that followed, bound validations that rode in a product launch
- * (GGL_OPT_CW_RIDER; counted per part), table transfers that rode in an A' launch (GGL_OPT_COPY_RIDER; per part) }. */
-int ggl_pipeline_stats(ggl_ctx *ctx, long long out[9]);
+ * (GGL_OPT_CW_RIDER; counted per part), table transfers that rode in an A' launch (GGL_OPT_COPY_RIDER; per part), norm
+ * reductions that did (GGL_OPT_REDUCE_RIDER) }. */
+int ggl_pipeline_stats(ggl_ctx *ctx, long long out[10]);
 /* L-step (sign iteration): out = { calls, calls whose first pass was continued on a compact sub-batch, instances continued in
  * total, calls that fell back to the eigendecomposition } */
 int ggl_rank_stats(ggl_ctx *ctx, long long out[4]);

@@ -534,8 +534,12 @@ def test_pipelined_iterations_are_bitwise_the_unpipelined_ones(sol, reg, K, p, e
     n_it = 16 if not early else 40
     # (third run, early part only: GGL_OPT_FUSED_W off -- the W of an early first part comes from k_form_W_sym instead of the
     # Theta kernel that precedes it: the same arithmetic per element, the same iterates)
-    for pipe, fused_w in ((0, 1), (1, 1)) + (((1, 0),) if early else ()):
-        eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S), options={"pipeline": pipe, "early_part": early, "fused_w": fused_w})
+    # (fourth run, early part only: the riders off -- bound validation, table transfers and norm reduction as launches of their
+    # own instead of extra workgroups of a product launch: the same arithmetic in the same order, bitwise the second run)
+    no_riders = {"cw_rider": 0, "copy_rider": 0, "reduce_rider": 0}
+    for pipe, fused_w, extra in ((0, 1, {}), (1, 1, {})) + (((1, 0, {}), (1, 1, no_riders)) if early else ()):
+        eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S),
+                               options={"pipeline": pipe, "early_part": early, "fused_w": fused_w, **extra})
         nk = np.ones(K)
         rho, mid = 1.0, None
         for it in range(n_it):
@@ -570,6 +574,16 @@ def test_pipelined_iterations_are_bitwise_the_unpipelined_ones(sol, reg, K, p, e
         for a, b in zip(outs[1][:2], outs[2][:2]):
             for nm in ("Omega", "Theta", "X"):
                 assert np.abs(a[nm] - b[nm]).max() <= 1e-13, nm
+        for a, b in zip(outs[1][:2], outs[3][:2]):
+            for nm in ("Omega", "Theta", "X"):
+                assert np.array_equal(a[nm], b[nm]), nm
+        assert stats[1]["spec_misses"] == stats[3]["spec_misses"]
+        assert pipe_stats[3]["bound_rides"] == pipe_stats[3]["copy_rides"] == pipe_stats[3]["reduce_rides"] == 0
+        assert pipe_stats[1]["bound_rides"] >= 5, pipe_stats[1]
+        if reg == "GGL":
+            assert pipe_stats[1]["reduce_rides"] >= 5, pipe_stats[1]
+            if (K, p) != (8, 400):                                # (one launch sequence: the tables ride as well)
+                assert pipe_stats[1]["copy_rides"] >= 5, pipe_stats[1]
     else:
         assert pipe_stats[1]["early_launched"] == 0
     ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, reg, Om0, max_iter=n_it, tol=1e-20, rtol=1e-20)
@@ -735,8 +749,11 @@ def test_bound_validation_on_a_side_stream_is_bitwise(sol, K, p):
         copies = []
         for side, jf, rider, cpr in ((0, 1, 0, 0), (1, 1, 0, 0), (0, 0, 0, 0), (1, 0, 0, 0), (0, 1, 1, 0), (0, 0, 1, 0), (0, 1, 2, 0),
                                      (0, 1, 1, 2), (0, 1, 0, 2)):
+            # (the reduce rider -- GGL_OPT_REDUCE_RIDER, the norm reduction in the next chain's A' launch -- goes with the copy
+            # rider here; test_pipelined_iterations_are_bitwise_the_unpipelined_ones has the early parts it needs)
             eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S),
-                                   options={"bound_side": side, "join_flag": jf, "cw_rider": rider, "copy_rider": cpr, **extra})
+                                   options={"bound_side": side, "join_flag": jf, "cw_rider": rider, "copy_rider": cpr,
+                                            "reduce_rider": cpr, **extra})
             rho = 1.0
             for it in range(14):
                 sq = eng.step(rho, 0.05, 0.01, "GGL", False, None, nk).copy()

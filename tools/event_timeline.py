@@ -67,9 +67,14 @@ def main():
     print(f"{name} {opts or ''}: {wall * 1e6:.1f} us per iteration while tracing (host clock, {n_trace + 2} iterations); "
           f"{len(dev)} device events, {len(host)} host marks")
     red = dev[dev[:, 2] == 21][:, 3]          # completion of the norm reductions: an iteration's device work ends there
+    what = "norm reduction"
+    if len(red) < 3:
+        # GGL_OPT_REDUCE_RIDER: the reduction rides in the next A' launch and has no completion event of its own
+        red = dev[dev[:, 2] == 20][:, 3]
+        what = "Theta kernel (the norm reduction rides in the next launch)"
     for it in range(1, min(n_trace + 1, len(red))):
         a, b = red[it - 1], red[it]
-        print(f"\n--- iteration {it}: from the end of the previous norm reduction (t = 0) to the end of this one ({b - a:.1f} us) ---")
+        print(f"\n--- iteration {it}: from the end of the previous {what} (t = 0) to the end of this one ({b - a:.1f} us) ---")
         ev = [r for r in rows if a - 1e-9 < r[3] <= b + 40 and not (r[0] == 0 and r[3] <= a)]
         ev.sort(key=lambda r: r[3])
         last_end = {}
@@ -88,7 +93,7 @@ def main():
     prod = dev[(dev[:, 2] == 10) | (dev[:, 2] == 11)]
     if len(th) > 2 and len(red) > 2:
         per = np.diff(red)
-        print(f"\nsteady state: {per.mean():.1f} us between norm reductions (min {per.min():.1f}, max {per.max():.1f})")
+        print(f"\nsteady state: {per.mean():.1f} us between the ends of two iterations' {what} (min {per.min():.1f}, max {per.max():.1f})")
         gaps = []
         for t_th in th[1:]:
             before = prod[prod[:, 3] < t_th][:, 3]
