@@ -12,7 +12,14 @@ with open(sys.argv[1]) as f:
 rows.sort()
 # an iteration ends with its norm reduction: the next launch starts the following one (k_form_W is no marker any more: with
 # GGL_OPT_FUSED_W the Theta kernel writes W and steady-state iterations have no such launch)
-starts = [i + 1 for i, r in enumerate(rows) if "reduce_partials" in r[2] and i + 1 < len(rows)]
+# ... and with GGL_OPT_REDUCE_RIDER the reduction rides in the next A' launch: the marker is the Theta kernel, plus the
+# reduction where one follows it)
+starts = []
+for i, r in enumerate(rows):
+    if "k_theta" in r[2]:
+        j = i + 2 if (i + 1 < len(rows) and "reduce_partials" in rows[i + 1][2]) else i + 1
+        if j < len(rows):
+            starts.append(j)
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 its = list(zip(starts[skip:-1], starts[skip + 1:]))
 tot = busy = 0.0

@@ -17,7 +17,11 @@ def short(n):
     return n[:58]
 # two iterations shortly before the end of the second timed region; an iteration ends with its norm reduction (k_form_W is
 # no marker any more: with GGL_OPT_FUSED_W the Theta kernel writes W and steady-state iterations have no such launch)
-idx = [i + 1 for i, r in enumerate(rows) if "k_reduce_partials" in r["Kernel_Name"]]
+# ... and with GGL_OPT_REDUCE_RIDER the reduction rides in the next A' launch: the Theta kernel, plus a reduction that follows it)
+idx = []
+for i, r in enumerate(rows):
+    if "k_theta" in r["Kernel_Name"]:
+        idx.append(i + 2 if (i + 1 < len(rows) and "k_reduce_partials" in rows[i + 1]["Kernel_Name"]) else i + 1)
 a, b = idx[-12], idx[-10]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
