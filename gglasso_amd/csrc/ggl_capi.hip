@@ -484,6 +484,19 @@ void pool_stream_release(int device, hipStream_t s, bool poolable)
 // fine-grained (coherent) pinned arena -- carved at 256-byte boundaries: a ctx used to take ~45 hipMalloc / hipHostMalloc calls
 // and, worse, as many hipFree calls (each a device synchronisation: ggl_ctx_destroy cost 5 ms, half of a whole ADMM_MGL call at
 // (20,200); tools/time_ctx.py).  Buffers that only some uses need (snapshots, ext state, deflation work, ...) stay lazy and own.
+// Lazily allocated device buffers of a ctx start from zeros as its arenas do (0xFF bytes under GGL_DEBUG_POISON=1, see ctx_alloc)
+static int poison_fill()
+{
+    static const int fill = [] { const char* e = getenv("GGL_DEBUG_POISON"); return (e && e[0] == '1') ? 0xFF : 0; }();
+    return fill;
+}
+template <class T> static hipError_t malloc_filled(T** p, size_t bytes, hipStream_t st)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(*p, poison_fill(), bytes, st);
+}
+
 static int ctx_alloc(ggl_ctx* c)
 {
     const size_t nb = c->n * sizeof(double);
@@ -582,13 +595,20 @@ static int ctx_alloc(ggl_ctx* c)
         c->arena_dev = reused[0];
         c->arena_pin = reused[1];
         c->arena_pin_coh = reused[2];
-        HIPCHK(hipMemsetAsync(c->arena_dev, 0, c->arena_tot[0], c->stream));
-        memset(c->arena_pin, 0, c->arena_tot[1]);
-        memset(c->arena_pin_coh, 0, c->arena_tot[2]);
     } else {
         HIPCHK(hipMalloc(&c->arena_dev, c->arena_tot[0]));
         HIPCHK(hipHostMalloc(&c->arena_pin, c->arena_tot[1]));
         HIPCHK(hipHostMalloc(&c->arena_pin_coh, c->arena_tot[2], hipHostMallocCoherent));
+    }
+    // Every arena starts from zeros, fresh or reused: hipMalloc hands back whatever an earlier allocation of the process left
+    // there (a test of the full GPU suite failed once in eight runs and never alone -- behind the 20 GB ctxs of the C5 tests).
+    // GGL_DEBUG_POISON=1 (environment, read here) fills them with 0xFF bytes instead -- NaN doubles, -1 ints -- so that a
+    // buffer which is read before it is written shows up at once instead of once in a while.
+    {
+        const int fill = poison_fill();
+        HIPCHK(hipMemsetAsync(c->arena_dev, fill, c->arena_tot[0], c->stream));
+        memset(c->arena_pin, fill, c->arena_tot[1]);
+        memset(c->arena_pin_coh, fill, c->arena_tot[2]);
     }
     size_t off[3] = {0, 0, 0};
     char* base[3] = {(char*)c->arena_dev, (char*)c->arena_pin, (char*)c->arena_pin_coh};
@@ -1028,7 +1048,7 @@ extern "C" int ggl_state_snapshot(ggl_ctx* c, int restore)
     double* cur[4] = {c->Om[c->cur], c->Theta, c->L, c->X};
     if (!restore) {
         for (int i = 0; i < 4; ++i) {
-            if (!c->snap[i]) HIPCHK(hipMalloc(&c->snap[i], nb));
+            if (!c->snap[i]) HIPCHK(malloc_filled(&c->snap[i], nb, c->stream));
             HIPCHK(hipMemcpyAsync(c->snap[i], cur[i], nb, hipMemcpyDeviceToDevice, c->stream));
         }
         c->snap_symmetric = c->state_symmetric;
@@ -1077,7 +1097,7 @@ extern "C" int ggl_set_lambda1_mask_k(ggl_ctx* c, const double* lam)
     HIPCHK(hipSetDevice(c->device));
     c->has_maskK = (lam != nullptr);
     if (lam) {
-        if (!c->maskK) HIPCHK(hipMalloc(&c->maskK, c->n * sizeof(double)));
+        if (!c->maskK) HIPCHK(malloc_filled(&c->maskK, c->n * sizeof(double), c->stream));
         HIPCHK(hipMemcpyAsync(c->maskK, lam, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
@@ -1091,7 +1111,7 @@ extern "C" int ggl_set_instance_dims(ggl_ctx* c, const int* pk)
     c->has_dims = (pk != nullptr);
     if (pk) {
         for (int k = 0; k < c->K; ++k) ARGCHK(pk[k] >= 1 && pk[k] <= c->p, "1 <= p_k <= p (the padded dimension of the ctx)");
-        if (!c->inst_pk) HIPCHK(hipMalloc(&c->inst_pk, c->K * sizeof(int)));
+        if (!c->inst_pk) HIPCHK(malloc_filled(&c->inst_pk, c->K * sizeof(int), c->stream));
         HIPCHK(hipMemcpyAsync(c->inst_pk, pk, c->K * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
@@ -1542,7 +1562,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         // ---- the whole product chain as ONE persistent launch with per-instance dependencies (k_omega_chain) ----------
         if (spec && !want_A && !resume && c->chain_mode && c->fused_start && c->fused_bounds && (c->symm_variant < 0 || c->symm_variant == 17) &&
             chain_tile(K, c->p, c->chain_mode == 2) == 64) {
-            if (!c->nsNX) HIPCHK(hipMalloc(&c->nsNX, 2 * c->n * sizeof(double)));
+            if (!c->nsNX) HIPCHK(malloc_filled(&c->nsNX, 2 * c->n * sizeof(double), c->stream));
             if (!c->chain_cnt) HIPCHK(hipMalloc(&c->chain_cnt, (size_t)K * CHAIN_CNT_STRIDE * sizeof(unsigned)));
             for (int k = 0; k < K; ++k) c->cuse_h[k] = c->spec_c[k] * c->spec_factor;
             NsPlan& pl = plans[0];
@@ -2059,7 +2079,7 @@ static int rank_step(ggl_ctx* c)
         // keep C for ggl_finalize_L: W is scratch that every step forms anew, so the two stacks swap names (the stream was
         // synchronised by the step's checks; a latent step neither speculates nor pre-launches, nothing in flight holds W)
         if (!c->Ckeep) {
-            HIPCHK(hipMalloc(&c->Ckeep_alloc, c->n * sizeof(double)));
+            HIPCHK(malloc_filled(&c->Ckeep_alloc, c->n * sizeof(double), c->stream));
             c->Ckeep = c->Ckeep_alloc;
             c->Ckeep_beta = (double*)malloc(c->K * sizeof(double));
         }
@@ -2098,7 +2118,7 @@ static int rank_step_impl(ggl_ctx* c)
             // bound is ~2.4x the spectral radius on an ADMM run's C, this one settles near 1.1x -- and every factor 2.6 of
             // slack is a cubic step of the sign iteration (the Omega-step's bound of B' has done this since round 2)
             if (!c->cwvecL[0])
-                for (double*& b : c->cwvecL) HIPCHK(hipMalloc(&b, (size_t)K * c->p * sizeof(double)));
+                for (double*& b : c->cwvecL) HIPCHK(malloc_filled(&b, (size_t)K * c->p * sizeof(double), c->stream));
             launch_cw_final(c->stream, c->nsT, c->nbrow, K, c->p, c->infpart, c->fropart, bT * (bT + 1) / 2, c->cwmax, c->cwcnt,
                             c->bounds_h, nullptr, nullptr, nullptr, 0, c->cwL_have ? c->cwvecL[c->cwL_cur] : nullptr,
                             c->cwvecL[c->cwL_cur ^ 1]);
@@ -2199,8 +2219,8 @@ static int rank_step_impl(ggl_ctx* c)
                 }
                 HIPCHK(hipMalloc(&c->defl_G, g.size() * sizeof(double)));
                 HIPCHK(hipMemcpy(c->defl_G, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
-                HIPCHK(hipMalloc(&c->defl_work, 4 * (size_t)K * DEFL_Q * c->p * sizeof(double)));
-                HIPCHK(hipMalloc(&c->defl_meta, 4 * (size_t)K * sizeof(double)));
+                HIPCHK(malloc_filled(&c->defl_work, 4 * (size_t)K * DEFL_Q * c->p * sizeof(double), c->stream));
+                HIPCHK(malloc_filled(&c->defl_meta, 4 * (size_t)K * sizeof(double), c->stream));
                 HIPCHK(hipHostMalloc(&c->defl_meta_h, 4 * (size_t)K * sizeof(double)));
             }
             const double* Xl = ((plan.steps - 1) & 1) ? c->nsYP[0] + c->n : c->nsYP[0];
@@ -2261,7 +2281,7 @@ static int rank_step_impl(ggl_ctx* c)
             const double lp = rank_ns_image(l0, c->ns_degrees, l_fine) * (1.0 - 1e-9);
             if (2 * m > K || !(lp > 0.0) || !(lp < 0.999)) continue;   // too many for a compact batch: the whole batch at l_fine
             if (!c->rank_idx) {
-                HIPCHK(hipMalloc(&c->rank_idx, K * sizeof(int)));
+                HIPCHK(malloc_filled(&c->rank_idx, K * sizeof(int), c->stream));
                 HIPCHK(hipHostMalloc(&c->rank_idx_h, K * sizeof(int)));
             }
             std::vector<double> mu2(m);
@@ -2789,7 +2809,7 @@ static int ensure_partials(ggl_ctx* c, size_t need)
     c->partials_own = nullptr;
     c->partials = nullptr;
     c->partials_len = 0;
-    HIPCHK(hipMalloc(&c->partials_own, need * sizeof(double)));
+    HIPCHK(malloc_filled(&c->partials_own, need * sizeof(double), c->stream));
     c->partials = c->partials_own;
     c->partials_len = need;
     return GGL_OK;
@@ -4083,8 +4103,8 @@ static int ext_setup_impl(ggl_ctx* c, int nprob, const int* pk_all, const int* G
     HIPCHK(hipMemcpyAsync(c->ext_gsize, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     const size_t nb = c->n * sizeof(double);
     if (!c->X1) {
-        for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->Lam[i], nb));
-        HIPCHK(hipMalloc(&c->X1, nb));
+        for (int i = 0; i < 2; ++i) HIPCHK(malloc_filled(&c->Lam[i], nb, c->stream));
+        HIPCHK(malloc_filled(&c->X1, nb, c->stream));
         // the ext kernels write GGL_NNORM sums per (instance, chunk) twice per iteration
         int rcp = ensure_partials(c, 2 * (size_t)Ktot * ext_blocks(p) * GGL_NNORM);
         if (rcp) return rcp;

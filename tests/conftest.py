@@ -13,6 +13,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # GGL_TEST_OPTIONS="name=value,...": ctx options every engine of the session starts with (gglasso_amd._lib.OPTIONS) -- for
+    # running the whole suite with a feature switched off when a failure has to be pinned on it
+    extra = os.environ.get("GGL_TEST_OPTIONS", "")
+    if extra:
+        from gglasso_amd import solver
+        for item in extra.split(","):
+            name, value = item.split("=")
+            solver.ENGINE_OPTIONS[name.strip()] = float(value)
 
 
 def load_golden(name):
