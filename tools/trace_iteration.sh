@@ -22,7 +22,7 @@ idx = []
 for i, r in enumerate(rows):
     if "k_theta" in r["Kernel_Name"]:
         idx.append(i + 2 if (i + 1 < len(rows) and "k_reduce_partials" in rows[i + 1]["Kernel_Name"]) else i + 1)
-a, b = idx[-12], idx[-10]
+a, b = idx[-16], idx[-14]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
 print(f"two consecutive iterations of $W${TRACE_TAG:-} (us from the first kernel's start; gap = idle time of the device before the kernel)")
