@@ -110,6 +110,8 @@ _SIGNATURES = {
     "ggl_selection_rank": ([_vp, _d, _dp], _i),
     "ggl_finalize_L": ([_vp, _i, ctypes.POINTER(_i)], _i),
     "ggl_failed_instances": ([_vp, ctypes.POINTER(_i)], _i),
+    "ggl_failed_reason": ([_vp, _i, _dp], _i),
+    "ggl_debug_poison": ([_i], _i),
     "ggl_reset_instance": ([_vp, _i], _i),
     "ggl_ctx_create_subset": ([_vp, ctypes.POINTER(_i), _i, ctypes.POINTER(_vp)], _i),
     "ggl_get_snapshot_k": ([_vp, _i, _dp, _dp], _i),

@@ -122,12 +122,15 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
         if hasattr(eng, "batch_run") and not verbose:
             # the whole loop in C (ggl_sgl_batch_run): decisions, X rescale, device snapshots of the points that finish,
             # parking of the ones that fail; Python is back in the picture only to compact the batch
-            snaps, status, iters = _loop_in_c(eng, engines, K, 1, p, rhos, last, carried, dimk, tol, rtol, update_rho, max_iter,
-                                              compact, latent,
-                                              lambda sl: dict(lambda1=lam[sl], latent=latent, mu1=None if mu is None else mu[sl]))
+            snaps, status, iters, why = _loop_in_c(eng, engines, K, 1, p, rhos, last, carried, dimk, tol, rtol, update_rho,
+                                                   max_iter, compact, latent,
+                                                   lambda sl: dict(lambda1=lam[sl], latent=latent,
+                                                                   mu1=None if mu is None else mu[sl]))
             for k in range(K):
                 sol = {nm: np.ascontiguousarray(A[k, :pk[k], :pk[k]]) for nm, A in snaps.items()}
                 results[k] = (sol, {'status': status[k], 'iterations': int(iters[k]), 'rho': rhos[k]})
+                if k in why:
+                    results[k][1]['error'] = why[k]
         else:
             it = 0                                                           # batch iterations run so far
             while it < max_iter:
@@ -147,6 +150,7 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                     # eigensolver that did not converge): the reference's sequential walk (model_selection.py:619-633) would
                     # lose this point only -- so does the batch
                     finish(s, 'solver error', it)
+                    results[slots[s]][1]['error'] = _why(cur, int(s), 1)
                     if hasattr(cur, "reset_instance"):
                         cur.reset_instance(int(s))
                 if done.all():
@@ -174,6 +178,7 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                 for k in range(K):
                     results[k][1]['selection']['threshold'] = tab[k].copy()
                     results[k][1]['selection']['threshold_eig_problems'] = n_eig
+        _warn_failures(results)
     finally:
         for e in engines:
             e.close()
@@ -194,6 +199,7 @@ def _loop_in_c(eng, engines, n, group, p, rhos, last, carried, dims, tol, rtol, 
     eng, status strings (n), iteration counts (n))."""
     status = np.zeros(n, dtype=np.int32)
     fin_iter = np.zeros(n, dtype=np.int32)
+    reasons = {}
     cur, slots = eng, np.arange(n)
     inst = lambda sl: (sl[:, None] * group + np.arange(group)[None, :]).reshape(-1)     # instance slots of point slots
     dims = np.broadcast_to(np.asarray(dims, dtype=np.float64), (n,))
@@ -213,6 +219,8 @@ def _loop_in_c(eng, engines, n, group, p, rhos, last, carried, dims, tol, rtol, 
             stop_after = max(stop_after, done_before + 1)
         k = cur.batch_run(max_iter - it, rho_s, last_s, st_s, fi_s, it, dims[slots], tol, rtol, update_rho,
                           snap=(eng, inst(slots)), stop_after=stop_after, **args_of(slots))
+        for s in np.flatnonzero((st_s == 2) & (status[slots] != 2)):
+            reasons[int(slots[s])] = _why(cur, int(s) * group, group)          # (asked of the ctx that marked it)
         rhos[slots], last[slots], status[slots], fin_iter[slots] = rho_s, last_s, st_s, fi_s
         carried[slots] += k
         it += k
@@ -227,7 +235,7 @@ def _loop_in_c(eng, engines, n, group, p, rhos, last, carried, dims, tol, rtol, 
     names = {1: 'optimal', 2: 'solver error'}
     out_status = [names[int(status[g])] if status[g] else _leftover_status(last[g]) for g in range(n)]
     iters = np.where(status != 0, fin_iter, max_iter)
-    return eng.snapshots(latent), out_status, iters
+    return eng.snapshots(latent), out_status, iters, reasons
 
 
 def _marked(eng, group):
@@ -240,6 +248,27 @@ def _marked(eng, group):
     return f.reshape(-1, group).any(axis=1)
 
 
+def _why(ctx, first, group):
+    """Text for a 'solver error' point whose instances are first .. first + group - 1 of ctx: the library's reason for the
+    first marked one, or that the point's own sums stopped being finite."""
+    if hasattr(ctx, "failed_reason"):
+        for q in range(group):
+            r = ctx.failed_reason(first + q)
+            if r:
+                return r
+    return "its residual sums are not finite (NaN / Inf in its data or a diverged iterate)"
+
+
+def _warn_failures(results):
+    """One warning per point that ends as 'solver error' (the reference warns about numerical trouble and goes on,
+    solver/admm_solver.py:284-301): the point's index and what went wrong."""
+    import warnings
+    for g, res in enumerate(results):
+        if res is not None and res[1].get('status') == 'solver error':
+            warnings.warn(f"batch point {g}: solver error -- {res[1].get('error', 'marked by the library')}; "
+                          f"the other points are not affected", RuntimeWarning, stacklevel=3)
+
+
 def _late_failures(eng, results, group):
     """Marks set on the ORIGINAL ctx after the iterations (the eigendecompositions of ggl_finalize_L and of the selection
     statistics run there over the snapshots of all points): such a point is reported as failed, not as 'optimal'."""
@@ -249,6 +278,7 @@ def _late_failures(eng, results, group):
     for g in np.flatnonzero(m):
         if results[g] is not None and results[g][1]['status'] != 'solver error':
             results[g][1]['status'] = 'solver error'
+            results[g][1]['error'] = _why(eng, int(g) * group, group)
 
 
 def _decide(sq, ids, rhos, done, last, dims, tol, rtol, update_rho, it, verbose, marked=None):
@@ -431,7 +461,7 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                     eng.snapshot_k(g * K + k) if cur is eng else eng.snapshot_from(g * K + k, cur, s * K + k)
 
         if hasattr(eng, "batch_run") and not verbose:
-            snaps, status, iters = _loop_in_c(eng, engines, G, K, p, rhos, last, carried, float(dim), tol, rtol, update_rho,
+            snaps, status, iters, why = _loop_in_c(eng, engines, G, K, p, rhos, last, carried, float(dim), tol, rtol, update_rho,
                                               max_iter, compact, True,
                                               lambda sl: dict(lambda1=lam1[sl], lambda2=lam2[sl], reg=reg, latent=latent,
                                                               mu1=None if mu is None else mu.reshape(G, K)[sl].reshape(-1),
@@ -439,6 +469,8 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
             for g in range(G):
                 sol = {nm: snaps[nm][g * K:(g + 1) * K].copy() for nm in ('Omega', 'Theta', 'L', 'X')}
                 results[g] = (sol, {'status': status[g], 'iterations': int(iters[g]), 'rho': rhos[g]})
+                if g in why:
+                    results[g][1]['error'] = why[g]
         else:
             it = 0
             while it < max_iter:
@@ -454,6 +486,7 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                 for s in bad:
                     # (see ADMM_SGL_batch: a point with non-finite data or a mark costs that point only)
                     collect(s, 'solver error', it)
+                    results[slots[s]][1]['error'] = _why(cur, int(s) * K, K)
                     if hasattr(cur, "reset_instance"):
                         for k in range(K):
                             cur.reset_instance(int(s) * K + k)
@@ -478,6 +511,7 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                 for g in range(G):
                     results[g][1]['threshold'] = tab[g * K:(g + 1) * K].copy()
         _late_failures(eng, results, K)
+        _warn_failures(results)
     finally:
         for e in engines:
             e.close()

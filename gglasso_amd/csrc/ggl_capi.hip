@@ -246,6 +246,8 @@ struct ggl_ctx {
     // marks (ggl_failed_instances), reports the point and parks its slots on the identity problem (ggl_reset_instance)
     bool isolate = false;
     unsigned char* failed = nullptr;           // host (K), lazy
+    int* fail_why = nullptr;                   // host (K): why the instance was marked first (mark_failed), with
+    double* fail_value = nullptr;              // host (K): the offending value
     double* nbrow = nullptr;                   // [K][p] row abs-sums of B' (Collatz-Wielandt weight vector)
     // the Collatz-Wielandt vector carried across iterations (k_cw_final): [cw_cur] was left behind by the last ACCEPTED
     // bound pass, the other one is what the pass in flight writes; cw_have: there is an accepted one
@@ -484,11 +486,13 @@ void pool_stream_release(int device, hipStream_t s, bool poolable)
 // fine-grained (coherent) pinned arena -- carved at 256-byte boundaries: a ctx used to take ~45 hipMalloc / hipHostMalloc calls
 // and, worse, as many hipFree calls (each a device synchronisation: ggl_ctx_destroy cost 5 ms, half of a whole ADMM_MGL call at
 // (20,200); tools/time_ctx.py).  Buffers that only some uses need (snapshots, ext state, deflation work, ...) stay lazy and own.
-// Lazily allocated device buffers of a ctx start from zeros as its arenas do (0xFF bytes under GGL_DEBUG_POISON=1, see ctx_alloc)
-static int poison_fill()
+// Lazily allocated device buffers of a ctx start from zeros as its arenas do (0xFF bytes after ggl_debug_poison(1), see ctx_alloc)
+static int g_poison = 0;
+static int poison_fill() { return g_poison ? 0xFF : 0; }
+extern "C" int ggl_debug_poison(int on)
 {
-    static const int fill = [] { const char* e = getenv("GGL_DEBUG_POISON"); return (e && e[0] == '1') ? 0xFF : 0; }();
-    return fill;
+    g_poison = on ? 1 : 0;
+    return GGL_OK;
 }
 template <class T> static hipError_t malloc_filled(T** p, size_t bytes, hipStream_t st)
 {
@@ -602,8 +606,9 @@ static int ctx_alloc(ggl_ctx* c)
     }
     // Every arena starts from zeros, fresh or reused: hipMalloc hands back whatever an earlier allocation of the process left
     // there (a test of the full GPU suite failed once in eight runs and never alone -- behind the 20 GB ctxs of the C5 tests).
-    // GGL_DEBUG_POISON=1 (environment, read here) fills them with 0xFF bytes instead -- NaN doubles, -1 ints -- so that a
-    // buffer which is read before it is written shows up at once instead of once in a while.
+    // ggl_debug_poison(1) (process-wide; the tests call it when GGL_DEBUG_POISON=1 is in THEIR environment -- the library reads
+    // none) fills them with 0xFF bytes instead -- NaN doubles, -1 ints -- so that a buffer which is read before it is written
+    // shows up at once instead of once in a while.
     {
         const int fill = poison_fill();
         HIPCHK(hipMemsetAsync(c->arena_dev, fill, c->arena_tot[0], c->stream));
@@ -853,6 +858,8 @@ extern "C" int ggl_ctx_destroy(ggl_ctx* c)
     if (c->defl_meta_h) (void)hipHostFree(c->defl_meta_h);
     free(c->Ckeep_beta);
     free(c->failed);
+    free(c->fail_why);
+    free(c->fail_value);
     free(c->snap_beta);
     free(c->snap_ns);
     for (int* b : {c->ext_pk, c->ext_Gt, c->ext_gsize, c->inst_pk, c->rank_idx})
@@ -1184,9 +1191,17 @@ static int eigvals_only(ggl_ctx* c, double* A, double* Dv)
     return GGL_OK;
 }
 
-static void mark_failed(ggl_ctx* c, int k)
+// why: 1 a spectral / norm bound that is not finite or not positive (value = the bound), 2 an eigensolver that did not converge
+// (value = its info), 3 a non-finite residual or trace of the L-step's sign iteration (value = it), 4 marked in a subset ctx
+// (fused batch iteration) -- kept for ggl_failed_reason: the FIRST mark of an instance stays
+static void mark_failed(ggl_ctx* c, int k, int why = 0, double value = 0.0)
 {
-    if (!c->failed) c->failed = (unsigned char*)calloc(c->K, 1);
+    if (!c->failed) {
+        c->failed = (unsigned char*)calloc(c->K, 1);
+        c->fail_why = (int*)calloc(c->K, sizeof(int));
+        c->fail_value = (double*)calloc(c->K, sizeof(double));
+    }
+    if (!c->failed[k]) { c->fail_why[k] = why; c->fail_value[k] = value; }
     c->failed[k] = 1;
 }
 
@@ -1198,7 +1213,7 @@ static void sanitize_bounds(ggl_ctx* c, double* b, const double* repl, double re
     if (!c->isolate) return;
     for (int k = 0; k < c->K; ++k)
         if (!std::isfinite(b[k]) || !(b[k] > 0.0)) {
-            mark_failed(c, k);
+            mark_failed(c, k, 1, b[k]);
             b[k] = repl ? repl_scale * repl[k] : repl_scalar;
         }
 }
@@ -1209,7 +1224,7 @@ static int check_info(ggl_ctx* c, const char* what)
     for (int k = 0; k < c->K; ++k) {
         const int v = c->info_h[k];
         if (jac ? (v < 0) : (v != 0)) {
-            if (c->isolate) { mark_failed(c, k); continue; }
+            if (c->isolate) { mark_failed(c, k, 2, (double)v); continue; }
             return fail(GGL_E_SOLVER, "%s: eigensolver did not converge for instance %d (info=%d)", what, k, v);
         }
     }
@@ -2257,7 +2272,7 @@ static int rank_step_impl(ggl_ctx* c)
             // host parks the slot on the identity problem): it must not drag the batch through the retries and the eigh fallback
             for (int k = 0; k < K; ++k)
                 if (!std::isfinite(c->maxdev_h[k]) || !std::isfinite(c->maxdev_h[K + k])) {
-                    mark_failed(c, k);
+                    mark_failed(c, k, 3, !std::isfinite(c->maxdev_h[k]) ? c->maxdev_h[k] : c->maxdev_h[K + k]);
                     c->maxdev_h[k] = 0.0;
                     c->maxdev_h[K + k] = 0.0;
                 }
@@ -2727,7 +2742,7 @@ static int sgl_fused_finish(ggl_ctx* c, const double* rho, const double* lambda1
         if (e != hipSuccess) rc = fail(GGL_E_HIP, "fused SGL step: %s", hipGetErrorString(e));
         for (int i = 0; i < m && !rc; ++i) {
             memcpy(out_norms + (size_t)idx[i] * GGL_NNORM, on.data() + (size_t)i * GGL_NNORM, GGL_NNORM * sizeof(double));
-            if (sub->failed && sub->failed[i]) mark_failed(c, idx[i]);
+            if (sub->failed && sub->failed[i]) mark_failed(c, idx[i], sub->fail_why ? sub->fail_why[i] : 4, sub->fail_value ? sub->fail_value[i] : 0.0);
         }
     }
     if (didx) (void)hipFree(didx);
@@ -3127,6 +3142,15 @@ extern "C" int ggl_get_state_k(ggl_ctx* c, int k, double* Omega, double* Theta, 
 
 // GGL_OPT_ISOLATE: out[k] = 1 for every instance marked since the ctx was created (non-finite data, eigensolver failure);
 // returns how many, < 0 on error.
+extern "C" int ggl_failed_reason(ggl_ctx* c, int k, double out[2])
+{
+    ARGCHK(c && out && k >= 0 && k < c->K, "ctx, out, k");
+    const bool f = c->failed && c->failed[k];
+    out[0] = f ? (double)c->fail_why[k] : 0.0;
+    out[1] = f ? c->fail_value[k] : 0.0;
+    return GGL_OK;
+}
+
 extern "C" int ggl_failed_instances(ggl_ctx* c, int* out)
 {
     ARGCHK(c, "ctx");

@@ -337,6 +337,17 @@ class HipEngine:
         check(self.lib.ggl_failed_instances(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
         return out
 
+    _FAIL_WHY = {1: "a spectral / norm bound that is not finite or not positive", 2: "an eigensolver that did not converge",
+                 3: "a non-finite residual in the L-step's sign iteration", 4: "marked inside a fused batch iteration"}
+
+    def failed_reason(self, k):
+        """Why the library marked instance k (ggl_failed_reason), as text, or None if it did not."""
+        out = np.zeros(2)
+        check(self.lib.ggl_failed_reason(self.h, int(k), ptr(out)))
+        if out[0] == 0:
+            return None
+        return f"{self._FAIL_WHY.get(int(out[0]), 'marked')} (value {out[1]!r})"
+
     def reset_instance(self, k):
         """Park instance k on the identity problem (S = Omega = Theta = I, L = X = 0)."""
         check(self.lib.ggl_reset_instance(self.h, int(k)))

@@ -433,7 +433,17 @@ int ggl_finalize_L(ggl_ctx *ctx, int which, int *rank_out);
  *   ggl_reset_instance    parks instance k on the identity problem (S = Omega = Theta = I, L = X = 0): finite, cheapest schedules
  *   ggl_ctx_create_subset a new ctx with the m instances idx[] of src (S, iterate, masks, dimensions, options; device to
  *                         device), for the points still iterating once a good part of the batch is done; src stays valid */
+/* Debugging aid, process-wide: after ggl_debug_poison(1) every ctx created fills its device and pinned buffers with 0xFF bytes
+ * (NaN doubles, -1 ints) instead of zeros before it initialises what it documents as initialised -- a read of memory the library
+ * never wrote then fails at once instead of depending on what an earlier allocation left behind.  tests/conftest.py switches it
+ * on for a whole session when GGL_DEBUG_POISON=1 is set in the environment of the TEST process. */
+int ggl_debug_poison(int on);
 int ggl_failed_instances(ggl_ctx *ctx, int *out);
+/* Why instance k was marked (the first mark stays): out[0] = 1 a spectral or norm bound that was not finite or not positive,
+ * 2 an eigensolver that did not converge, 3 a non-finite residual or trace in the L-step's sign iteration, 4 marked inside a
+ * fused batch iteration, 0 not marked; out[1] = the offending value (the bound, the solver's info, the residual).  What the
+ * batch drivers put into the warning that goes with a 'solver error' point. */
+int ggl_failed_reason(ggl_ctx *ctx, int k, double out[2]);
 int ggl_reset_instance(ggl_ctx *ctx, int k);
 int ggl_ctx_create_subset(ggl_ctx *src, const int *idx, int m, ggl_ctx **out);
 int ggl_get_snapshot_k(ggl_ctx *ctx, int k, double *Theta, double *L);

@@ -15,6 +15,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # GGL_TEST_OPTIONS="name=value,...": ctx options every engine of the session starts with (gglasso_amd._lib.OPTIONS) -- for
     # running the whole suite with a feature switched off when a failure has to be pinned on it
+    # GGL_DEBUG_POISON=1: every ctx of the session starts from 0xFF-filled buffers instead of zeros (ggl_debug_poison)
+    if os.environ.get("GGL_DEBUG_POISON", "") == "1":
+        from gglasso_amd import _lib
+        _lib.load().ggl_debug_poison(1)
     extra = os.environ.get("GGL_TEST_OPTIONS", "")
     if extra:
         from gglasso_amd import solver

@@ -33,8 +33,13 @@ def test_sgl_batch_with_one_poisoned_point(p, latent):
     kw = dict(tol=1e-8, rtol=1e-8, max_iter=300)
     if latent:
         kw.update(latent=True, mu1=0.6)
-    res = ADMM_SGL_batch(bad, lam, **kw)
+    with pytest.warns(RuntimeWarning, match="batch point 2: solver error") as rec:
+        res = ADMM_SGL_batch(bad, lam, **kw)
     assert res[2][1]['status'] == 'solver error'
+    # the point comes with the reason (ggl_failed_reason, or its own non-finite sums), and it is the only one warned about
+    assert isinstance(res[2][1].get('error'), str) and len(res[2][1]['error']) > 10, res[2][1]
+    assert len([w for w in rec if "solver error" in str(w.message)]) == 1
+    assert all('error' not in res[k][1] for k in range(K) if k != 2)
     for k in range(K):
         if k == 2:
             continue

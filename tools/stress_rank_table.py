@@ -11,6 +11,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gglasso_amd import solver, synth, model_selection as ms  # noqa: E402
 
+if os.environ.get("GGL_DEBUG_POISON", "") == "1":
+    from gglasso_amd import _lib
+    _lib.load().ggl_debug_poison(1)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 S, _ = synth.make_problem("GGL", 1, p, seed=3)
