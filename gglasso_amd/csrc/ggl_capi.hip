@@ -140,6 +140,7 @@ struct ggl_ctx {
     bool last_step_hint = false;               // ggl_hint_last_step: the next ggl_admm_step is the caller's last one
     double* pre_beta = nullptr;                // host: beta the pre-launched chain was built for (K)
     long long pre_launched = 0, pre_dropped = 0;
+    int parts_order = 0;                       // GGL_OPT_PARTS_ORDER
     int parts_bias = 0;                        // GGL_OPT_PARTS_BIAS: two concurrent parts take K/2 + bias and K/2 - bias instances
     int parts_small = 8;                       // smallest K (< 16, p >= 384) that is split into two concurrent parts; 0 = never
                                                // (measured at p = 500: K = 8 +7.6 % iterations/s as 4 + 4, K = 4 -2.4 % as 2 + 2)
@@ -676,6 +677,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_FUSED_START: c->fused_start = v != 0.0; break;
         case GGL_OPT_PARTS_SMALL: c->parts_small = (int)v; break;
         case GGL_OPT_PARTS_BIAS: c->parts_bias = (int)v; break;
+        case GGL_OPT_PARTS_ORDER: c->parts_order = (int)v; break;
         case GGL_OPT_CW_WARM: c->cw_warm = v != 0.0; break;
         case GGL_OPT_CHAIN: c->chain_mode = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
         case GGL_OPT_ISOLATE: c->isolate = v != 0.0; break;
@@ -754,6 +756,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_FUSED_START: *value = c->fused_start; break;
         case GGL_OPT_PARTS_SMALL: *value = c->parts_small; break;
         case GGL_OPT_PARTS_BIAS: *value = c->parts_bias; break;
+        case GGL_OPT_PARTS_ORDER: *value = c->parts_order; break;
         case GGL_OPT_NS_TOL: *value = c->ns_tol; break;
         case GGL_OPT_CW_WARM: *value = c->cw_warm; break;
         case GGL_OPT_CHAIN: *value = c->chain_mode; break;
@@ -1675,7 +1678,10 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         // (The parts' launches are issued part after part.  Issuing them round-robin, so that the parts start together
         // instead of ~100 us apart, was measured 3 % SLOWER at (32,500): the stagger is what keeps the parts' prologues
         // and epilogues from coinciding.)
-        for (int h = 0; h < nh; ++h) {
+        for (int hh = 0; hh < nh; ++hh) {
+            // GGL_OPT_PARTS_ORDER: the part on the main stream is queued LAST, so that it is the one that ends last and the
+            // Theta kernel behind it finds the other part's flag set already
+            const int h = (c->parts_order && nh == 2 && c->prof_on == 0) ? nh - 1 - hh : hh;
             hipStream_t sh = h == 0 ? c->stream : c->streamx[h - 1];
             const int k0 = k0h[h];
             // The host's mirrors of the validation flags are cleared when the REST of the chain is launched: the mirrors of an
@@ -3207,7 +3213,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->ns_degrees = src->ns_degrees; c->theta_flat = src->theta_flat; c->rank_eig = src->rank_eig;
     c->rank_ns = c->omega_ns && !c->rank_eig; c->ns_parts = src->ns_parts; c->parts_max_tiles = src->parts_max_tiles;
     c->symm_variant = src->symm_variant; c->spin_wait = src->spin_wait; c->fused_bounds = src->fused_bounds;
-    c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->parts_bias = src->parts_bias; c->ns_tol = src->ns_tol;
+    c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->parts_bias = src->parts_bias; c->parts_order = src->parts_order; c->ns_tol = src->ns_tol;
     c->cw_warm = src->cw_warm; c->chain_mode = src->chain_mode; c->rank_l0 = src->rank_l0; c->rank_l0_coarse = src->rank_l0_coarse;
     c->isolate = src->isolate; c->fused_cw = src->fused_cw; c->lds_omega = src->lds_omega; c->lds_waves = src->lds_waves; c->early_part = src->early_part; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
     int* didx = nullptr;

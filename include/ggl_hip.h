@@ -166,6 +166,7 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                       launch less per iteration.  1 = single launch sequences, 2 = always, 0 = never */
 #define GGL_OPT_PARTS_BIAS 34      /* [0] two concurrent parts of an Omega-step take K/2 + bias and K/2 - bias instances (the second part starts and
                                       ends ~40 us after the first) */
+#define GGL_OPT_PARTS_ORDER 35     /* [0] two concurrent parts: 1 = the part on the ctx's main stream is queued after the other one */
 #define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
                                       2 = with the lowest stream priority (streams of another priority never share a hardware queue with
                                       the ctx's main stream) */
