@@ -4696,6 +4696,48 @@ extern "C" int ggl_dev_symm_bench(int K, int p, int variant, int iters, double* 
     return GGL_OK;
 }
 
+#ifdef GGL_DEV
+// What does a change of kernel between dependent launches cost?  mode 0: `iters` products; 1: `iters` x (product, then a
+// one-thread kernel that stores a word); 2: `iters` of the one-thread kernel; 3: `iters` x (product, elementwise scale by 1 of
+// the output: an LDS-free kernel over the same data).  ms per repetition (tools/kernel_switch_cost.py).
+extern "C" int ggl_dev_switch_bench(int K, int p, int variant, int iters, int mode, double* ms_out)
+{
+    ARGCHK(K >= 1 && p >= 1 && iters >= 1 && ms_out && mode >= 0 && mode <= 3, "arguments");
+    const size_t n = (size_t)K * p * p;
+    std::vector<double> h(n, 0.25), coef((size_t)K * NS_NCOEF, 0.0);
+    for (int k = 0; k < K; ++k) coef[(size_t)k * NS_NCOEF + 1] = 1.0 / p;
+    DevBuf dA, dB, dC, dcoef, dflag;
+    HIPCHK(dA.alloc(n));
+    HIPCHK(dB.alloc(n));
+    HIPCHK(dC.alloc(n));
+    HIPCHK(dcoef.alloc(coef.size()));
+    HIPCHK(dflag.alloc(8));
+    UP(dA.p, h.data(), n);
+    UP(dB.p, h.data(), n);
+    UP(dcoef.p, coef.data(), coef.size());
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    auto rep = [&](int i) {
+        if (mode != 2) launch_symm(nullptr, dA.p, dB.p, dC.p, nullptr, nullptr, dcoef.p, K, p, variant);
+        if (mode == 1 || mode == 2) launch_set_flag(nullptr, (unsigned long long*)dflag.p, (unsigned long long)i);
+        if (mode == 3) launch_scale(nullptr, dC.p, 1.0, n);
+    };
+    for (int i = 0; i < 3; ++i) rep(i);
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) rep(i);
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    *ms_out = ms / iters;
+    return GGL_OK;
+}
+#endif
+
 // LDS stages of the int8 product kernel: 1 (default: two workgroups per CU cover each other's loads) or 2 (double buffer)
 #ifdef GGL_DEV
 extern "C" int ggl_dev_i8_stages(int n)
