@@ -574,6 +574,10 @@ int ggl_dev_mfma_lds_probe(double *out6);
 /* k_omega_chain on a synthetic chain of nprod dependent products X <- I - 1.5 X^2: out = {ms as nprod launches, ms as one
  * persistent launch, persistent workgroups, max |difference| of the results, completion flag, done counters [K]} */
 int ggl_dev_chain_run(int K, int p, int nprod, int iters, double *out);
+/* What a change of kernel between dependent launches costs (tools/kernel_switch_cost.py): mode 0 `iters` product launches, 1 each
+ * followed by a one-thread kernel, 2 the one-thread kernel alone, 3 each followed by an elementwise kernel over its output;
+ * ms per repetition. */
+int ggl_dev_switch_bench(int K, int p, int variant, int iters, int mode, double *ms_out);
 int ggl_dev_symm_timeline(int K, int p, long long *out, int max_blocks, int *nblocks_out);
 /* persistent-chain probe: nprod dependent products X <- X X of a K-batch as nprod launches (out[0], ms) and as ONE cooperative
  * launch with grid-wide barriers between the products (out[1], ms); out[2] grid of the latter, out[3] max |difference| of
