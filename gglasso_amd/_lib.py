@@ -15,7 +15,7 @@ EIG_AUTO, EIG_JACOBI, EIG_ROCSOLVER, EIG_NEWTON_SCHULZ = 0, 1, 2, 3
 CTX_STREAM_GIVEN = 1 << 16
 # ggl_ctx_set_option ids (GGL_OPT_*)
 OPTIONS = {"speculate": 1, "spec_factor": 2, "ns_mode": 3, "ns_degrees": 4, "theta_flat": 5, "rank_eig": 6, "parts": 7,
-           "parts_max_tiles": 8, "symm_variant": 9, "spin_wait": 10, "fused_bounds": 11, "pipeline": 12, "fused_start": 13, "parts_small": 14, "ns_tol": 15, "cw_warm": 16, "chain": 17, "rank_l0_coarse": 18, "isolate": 19, "rank_deflate": 20, "rank_l0_deflate": 21, "fused_cw": 22, "omega_lds": 23, "early_part": 24, "part_priority": 25, "fused_w": 26, "rank_cw": 27, "bound_side": 28, "lds_pinned": 29, "join_flag": 30, "cw_rider": 31, "copy_rider": 32, "reduce_rider": 33, "parts_bias": 34, "parts_order": 35}
+           "parts_max_tiles": 8, "symm_variant": 9, "spin_wait": 10, "fused_bounds": 11, "pipeline": 12, "fused_start": 13, "parts_small": 14, "ns_tol": 15, "cw_warm": 16, "chain": 17, "rank_l0_coarse": 18, "isolate": 19, "rank_deflate": 20, "rank_l0_deflate": 21, "fused_cw": 22, "omega_lds": 23, "early_part": 24, "part_priority": 25, "fused_w": 26, "rank_cw": 27, "bound_side": 28, "lds_pinned": 29, "join_flag": 30, "cw_rider": 31, "copy_rider": 32, "reduce_rider": 33, "parts_bias": 34, "parts_order": 35, "download_threads": 36}
 
 
 def eig_flags(method=EIG_AUTO, ns_mode=0, ns_degrees=0):

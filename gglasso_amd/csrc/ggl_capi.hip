@@ -12,6 +12,7 @@
 #include <cstring>
 #include <numeric>
 #include <atomic>
+#include <thread>
 #include <mutex>
 #include <chrono>
 #include <vector>
@@ -140,6 +141,7 @@ struct ggl_ctx {
     bool last_step_hint = false;               // ggl_hint_last_step: the next ggl_admm_step is the caller's last one
     double* pre_beta = nullptr;                // host: beta the pre-launched chain was built for (K)
     long long pre_launched = 0, pre_dropped = 0;
+    int download_threads = 8;                  // GGL_OPT_DOWNLOAD_THREADS: host threads that touch a download's destination pages first
     int parts_order = 0;                       // GGL_OPT_PARTS_ORDER
     int parts_bias = 0;                        // GGL_OPT_PARTS_BIAS: two concurrent parts take K/2 + bias and K/2 - bias instances
     int parts_small = 8;                       // smallest K (< 16, p >= 384) that is split into two concurrent parts; 0 = never
@@ -678,6 +680,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_PARTS_SMALL: c->parts_small = (int)v; break;
         case GGL_OPT_PARTS_BIAS: c->parts_bias = (int)v; break;
         case GGL_OPT_PARTS_ORDER: c->parts_order = (int)v; break;
+        case GGL_OPT_DOWNLOAD_THREADS: c->download_threads = std::min(std::max((int)v, 1), 64); break;
         case GGL_OPT_CW_WARM: c->cw_warm = v != 0.0; break;
         case GGL_OPT_CHAIN: c->chain_mode = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
         case GGL_OPT_ISOLATE: c->isolate = v != 0.0; break;
@@ -757,6 +760,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_PARTS_SMALL: *value = c->parts_small; break;
         case GGL_OPT_PARTS_BIAS: *value = c->parts_bias; break;
         case GGL_OPT_PARTS_ORDER: *value = c->parts_order; break;
+        case GGL_OPT_DOWNLOAD_THREADS: *value = c->download_threads; break;
         case GGL_OPT_NS_TOL: *value = c->ns_tol; break;
         case GGL_OPT_CW_WARM: *value = c->cw_warm; break;
         case GGL_OPT_CHAIN: *value = c->chain_mode; break;
@@ -1075,18 +1079,54 @@ extern "C" int ggl_state_snapshot(ggl_ctx* c, int restore)
     return GGL_OK;
 }
 
+// Whole stacks to the caller's (pageable) arrays.  MEASURED (tools/time_download.py, profiles/r5_download.txt): into arrays whose
+// pages exist the copy runs at 55 GB/s (256 MB of a headline solve: 4.6 ms); into the FRESH arrays a solve returns it runs at
+// 10 GB/s (26 ms) -- the time goes into the first touch of the destination's pages (a fault and a zeroed page per 4 KB, all in
+// the one thread that copies out of the runtime's staging buffer), not into the transfer; more copy threads on more streams
+// change nothing (tried: 2 threads +-10 %, 3-4 slower).  So the pages are touched first, by several host threads at once (one
+// byte per page of memory that is about to be overwritten anyway), then ONE copy per stack: 25 -> 20 ms at the headline, 63 ->
+// 46 ms for 640 MB, 40 -> 29 ms for C4's 400 MB (four threads do what sixteen do; what is left is the caller's allocator).
+struct Xfer { void* dst; const void* src; size_t bytes; };
+static int download_stacks(ggl_ctx* c, const std::vector<Xfer>& xs)
+{
+    size_t total = 0;
+    for (const Xfer& x : xs) total += x.bytes;
+    const int nthr = std::min(c->download_threads, (int)std::max(1u, std::thread::hardware_concurrency()));
+    if (total >= ((size_t)32 << 20) && nthr > 1) {
+        const size_t block = (size_t)2 << 20, page = 4096;
+        // (MADV_HUGEPAGE on the destination first, on a box with transparent huge pages on request: no difference, measured)
+        std::vector<Xfer> work;
+        for (const Xfer& x : xs)
+            for (size_t o = 0; o < x.bytes; o += block) work.push_back({(char*)x.dst + o, nullptr, std::min(block, x.bytes - o)});
+        std::atomic<int> next{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; ++t)
+            th.emplace_back([&]() {
+                for (int i = next++; i < (int)work.size(); i = next++) {
+                    volatile char* d = (volatile char*)work[i].dst;
+                    for (size_t o = 0; o < work[i].bytes; o += page) d[o] = 0;
+                    d[work[i].bytes - 1] = 0;
+                }
+            });
+        for (std::thread& t : th) t.join();
+    }
+    for (const Xfer& x : xs) HIPCHK(hipMemcpyAsync(x.dst, x.src, x.bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GGL_OK;
+}
+
 extern "C" int ggl_get_state(ggl_ctx* c, double* Omega, double* Theta, double* L, double* X)
 {
     ARGCHK(c, "ctx");
     HIPCHK(hipSetDevice(c->device));
     DROP_PRE(c);
     const size_t nb = c->n * sizeof(double);
-    if (Omega) HIPCHK(hipMemcpyAsync(Omega, c->Om[c->cur], nb, hipMemcpyDeviceToHost, c->stream));
-    if (Theta) HIPCHK(hipMemcpyAsync(Theta, c->Theta, nb, hipMemcpyDeviceToHost, c->stream));
-    if (L) HIPCHK(hipMemcpyAsync(L, c->L, nb, hipMemcpyDeviceToHost, c->stream));
-    if (X) HIPCHK(hipMemcpyAsync(X, c->X, nb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return GGL_OK;
+    std::vector<Xfer> xs;
+    if (Omega) xs.push_back({Omega, c->Om[c->cur], nb});
+    if (Theta) xs.push_back({Theta, c->Theta, nb});
+    if (L) xs.push_back({L, c->L, nb});
+    if (X) xs.push_back({X, c->X, nb});
+    return download_stacks(c, xs);
 }
 
 extern "C" int ggl_set_lambda1_mask(ggl_ctx* c, const double* lam)
@@ -3213,7 +3253,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->ns_degrees = src->ns_degrees; c->theta_flat = src->theta_flat; c->rank_eig = src->rank_eig;
     c->rank_ns = c->omega_ns && !c->rank_eig; c->ns_parts = src->ns_parts; c->parts_max_tiles = src->parts_max_tiles;
     c->symm_variant = src->symm_variant; c->spin_wait = src->spin_wait; c->fused_bounds = src->fused_bounds;
-    c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->parts_bias = src->parts_bias; c->parts_order = src->parts_order; c->ns_tol = src->ns_tol;
+    c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->parts_bias = src->parts_bias; c->parts_order = src->parts_order; c->download_threads = src->download_threads; c->ns_tol = src->ns_tol;
     c->cw_warm = src->cw_warm; c->chain_mode = src->chain_mode; c->rank_l0 = src->rank_l0; c->rank_l0_coarse = src->rank_l0_coarse;
     c->isolate = src->isolate; c->fused_cw = src->fused_cw; c->lds_omega = src->lds_omega; c->lds_waves = src->lds_waves; c->early_part = src->early_part; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
     int* didx = nullptr;
@@ -3681,13 +3721,13 @@ extern "C" int ggl_get_snapshots(ggl_ctx* c, double* Omega, double* Theta, doubl
     ARGCHK((!Omega && !X) || (c->snapOm && c->snapX), "no state snapshot taken (ggl_snapshot_state_from)");
     HIPCHK(hipSetDevice(c->device));
     const size_t nb = c->n * sizeof(double);
-    if (Omega) HIPCHK(hipMemcpyAsync(Omega, c->snapOm, nb, hipMemcpyDeviceToHost, c->stream));
-    if (Theta) HIPCHK(hipMemcpyAsync(Theta, c->snapT, nb, hipMemcpyDeviceToHost, c->stream));
-    if (L && c->snapL) HIPCHK(hipMemcpyAsync(L, c->snapL, nb, hipMemcpyDeviceToHost, c->stream));
+    std::vector<Xfer> xs;
+    if (Omega) xs.push_back({Omega, c->snapOm, nb});
+    if (Theta) xs.push_back({Theta, c->snapT, nb});
+    if (L && c->snapL) xs.push_back({L, c->snapL, nb});
     else if (L) memset(L, 0, nb);          // no latent step ever ran: L is what the solvers return then, zeros (admm_solver.py:150)
-    if (X) HIPCHK(hipMemcpyAsync(X, c->snapX, nb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return GGL_OK;
+    if (X) xs.push_back({X, c->snapX, nb});
+    return download_stacks(c, xs);
 }
 
 // The latent component a solve returns (solver/ggl_helper.py:29-36: L = Q diag(max(d - beta, 0)) Q^T, whose null space is

@@ -167,6 +167,9 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_PARTS_BIAS 34      /* [0] two concurrent parts of an Omega-step take K/2 + bias and K/2 - bias instances (the second part starts and
                                       ends ~40 us after the first) */
 #define GGL_OPT_PARTS_ORDER 35     /* [0] two concurrent parts: 1 = the part on the ctx's main stream is queued after the other one */
+#define GGL_OPT_DOWNLOAD_THREADS 36 /* [8] ggl_get_state / ggl_get_snapshots of more than 32 MB: host threads that touch the pages of the caller's
+                                      (typically freshly allocated) arrays before the copy -- the first touch, not the transfer, is what a
+                                      download into new memory waits for; 1 = none */
 #define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
                                       2 = with the lowest stream priority (streams of another priority never share a hardware queue with
                                       the ctx's main stream) */
