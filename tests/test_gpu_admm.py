@@ -777,3 +777,26 @@ def test_bound_validation_on_a_side_stream_is_bitwise(sol, K, p):
             assert outs[1][1]["spec_misses"] >= 2
         else:
             assert outs[1][1]["spec_calls"] >= 8
+
+
+def test_download_touches_fresh_pages_first_and_returns_the_same_bytes(sol):
+    """GGL_OPT_DOWNLOAD_THREADS: a whole-state download of more than 32 MB touches the pages of the caller's arrays from several
+    host threads before the copy (tools/time_download.py) -- the arrays must come back with the same bytes as with one thread,
+    into fresh arrays and into arrays that hold other data."""
+    from gglasso_amd import synth, solver
+    K, p = 6, 600                                  # 4 stacks of 17 MB
+    S, _ = synth.make_problem("GGL", K=K, p=p, N=2 * p, seed=11)
+    Om0 = np.stack([np.eye(p)] * K)
+    eng = solver.HipEngine(S, Om0, Om0, np.zeros_like(S))
+    try:
+        for _ in range(3):
+            eng.step(1.0, 0.05, 0.01, "GGL", False, None, np.ones(K))
+        eng.set_option("download_threads", 1)
+        one = eng.state()
+        eng.set_option("download_threads", 8)
+        many = eng.state()
+        for nm in one:
+            assert np.array_equal(one[nm], many[nm]), nm
+        assert np.abs(many["Theta"]).max() > 0 and np.isfinite(many["Omega"]).all()
+    finally:
+        eng.close()
