@@ -125,3 +125,26 @@ def test_c_decisions_are_the_numpy_ones():
             assert np.array_equal(np.flatnonzero(status == 2), bad) and np.array_equal(np.flatnonzero(status == 1), newly)
             assert np.array_equal(rho_c, a["rhos"]) and np.array_equal(fac_c, fac)
             assert np.array_equal(last_c, a["last"])
+
+
+def test_failed_points_say_why():
+    """A point that ends as 'solver error' carries the reason -- the library's for the first marked instance of the point
+    (HipEngine.failed_reason / ggl_failed_reason), or that its own sums stopped being finite -- and gets ONE warning."""
+    import warnings
+    from gglasso_amd import batch
+
+    class Ctx:
+        def failed_reason(self, k):
+            return {5: "an eigensolver that did not converge (value 3.0)"}.get(k)
+
+    assert batch._why(Ctx(), 4, 2) == "an eigensolver that did not converge (value 3.0)"       # instances 4, 5 of the point
+    assert "not finite" in batch._why(Ctx(), 0, 2)                                              # nothing marked: the sums
+    assert "not finite" in batch._why(object(), 0, 1)                                           # an engine without marks
+    results = [({}, {'status': 'optimal'}), ({}, {'status': 'solver error', 'error': 'X'}), None,
+               ({}, {'status': 'solver error'})]
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        batch._warn_failures(results)
+    msgs = [str(w.message) for w in rec]
+    assert len(msgs) == 2 and msgs[0].startswith("batch point 1: solver error -- X") and "batch point 3" in msgs[1]
+    assert all(issubclass(w.category, RuntimeWarning) for w in rec)
