@@ -115,6 +115,7 @@ _SIGNATURES = {
     "ggl_reset_instance": ([_vp, _i], _i),
     "ggl_ctx_create_subset": ([_vp, ctypes.POINTER(_i), _i, ctypes.POINTER(_vp)], _i),
     "ggl_get_snapshot_k": ([_vp, _i, _dp, _dp], _i),
+    "ggl_get_snapshot_state_k": ([_vp, _i, _dp, _dp], _i),
     "ggl_dev_ns_schedule": ([_d, _i, _i, ctypes.POINTER(_i), _dp, ctypes.POINTER(_i)], _i),
     "ggl_dev_ns_schedule_tol": ([_d, _i, _d, _i, ctypes.POINTER(_i), _dp, ctypes.POINTER(_i)], _i),
     "ggl_ns_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),

@@ -18,14 +18,17 @@ from .solver import as_c
 
 def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max_iter=1000, tol=1e-7,
                    rtol=1e-4, update_rho=True, verbose=False, latent=False, mu1=None, lambda1_mask=None,
-                   selection_stats=False, dims=None, tau_range=None, compact=True):
+                   selection_stats=False, dims=None, tau_range=None, compact=True, fetch=None, select=None):
     """Solve ``ADMM_SGL(S, lambda1[k], ...)`` for every k of the 1-D array ``lambda1`` at once.
 
     S: (p,p) shared by all instances, or (K,p,p) with one covariance matrix per instance (what
     ``block_SGL`` needs for equally sized blocks).  Omega_0 / Theta_0 / X_0: (p,p) shared start or (K,p,p) per instance (default identity /
     Omega_0 / zeros, as in single_admm_solver.py:129-137).  mu1: scalar or (K,) when ``latent``.
     Returns a list of K ``(sol, info)`` pairs with the reference's keys; ``info`` additionally carries
-    ``'iterations'`` and the final ``'rho'``.  ``selection_stats``: also keep a device snapshot of every instance's
+    ``'iterations'`` and the final ``'rho'``.  ``fetch`` (names, e.g. ``('Theta', 'L')``; needs the C loop): download only these
+    stacks -- a grid walk looks at Theta (and L) of every point and returns the whole solution of ONE (the download of a
+    20-point grid at p = 1000 is 480 MB otherwise); ``select(results)`` is then called before the device state goes away and
+    returns ``(k, target)``: point k's missing stacks are fetched into the dict ``target`` (and into its own sol).  ``selection_stats``: also keep a device snapshot of every instance's
     solution's Theta and attach ``info['selection'] = {'Sdot','logdet','nnz','lambda_min'}`` computed on the GPU
     (what the AIC / eBIC tables of model selection are made of); with ``latent`` also ``'rank'``:
     numpy.linalg.matrix_rank of the instance's L (an int; every returned L is rebuilt from one eigendecomposition of
@@ -125,7 +128,7 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
             snaps, status, iters, why = _loop_in_c(eng, engines, K, 1, p, rhos, last, carried, dimk, tol, rtol, update_rho,
                                                    max_iter, compact, latent,
                                                    lambda sl: dict(lambda1=lam[sl], latent=latent,
-                                                                   mu1=None if mu is None else mu[sl]))
+                                                                   mu1=None if mu is None else mu[sl]), fetch=fetch)
             for k in range(K):
                 sol = {nm: np.ascontiguousarray(A[k, :pk[k], :pk[k]]) for nm, A in snaps.items()}
                 results[k] = (sol, {'status': status[k], 'iterations': int(iters[k]), 'rho': rhos[k]})
@@ -178,6 +181,15 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                 for k in range(K):
                     results[k][1]['selection']['threshold'] = tab[k].copy()
                     results[k][1]['selection']['threshold_eig_problems'] = n_eig
+        if select is not None:
+            k_sel, target = select(results)
+            if fetch is not None and k_sel is not None and hasattr(eng, "snapshot_state_k"):
+                Om_k, X_k = eng.snapshot_state_k(int(k_sel))
+                q = int(pk[k_sel])
+                for d in (results[int(k_sel)][0], target):
+                    if d is not None:
+                        d.setdefault('Omega', np.ascontiguousarray(Om_k[:q, :q]))
+                        d.setdefault('X', np.ascontiguousarray(X_k[:q, :q]))
         _warn_failures(results)
     finally:
         for e in engines:
@@ -190,7 +202,8 @@ def _leftover_status(row):
     return 'primal optimal' if r_t <= e_pri else ('dual optimal' if s_t <= e_dual else 'max iterations reached')
 
 
-def _loop_in_c(eng, engines, n, group, p, rhos, last, carried, dims, tol, rtol, update_rho, max_iter, compact, latent, args_of):
+def _loop_in_c(eng, engines, n, group, p, rhos, last, carried, dims, tol, rtol, update_rho, max_iter, compact, latent, args_of,
+               fetch=None):
     """The iteration loop of a batch with the host side in C (HipEngine.batch_run -> ggl_sgl_batch_run / ggl_mgl_batch_run):
     n points of ``group`` instances each; rhos (n,), last (n,4), carried (n,) are updated in place; ``args_of(slots)``: the
     keyword arguments of ``batch_run`` that describe the points in the slots of the live ctx.  Every point's solution is
@@ -235,7 +248,7 @@ def _loop_in_c(eng, engines, n, group, p, rhos, last, carried, dims, tol, rtol, 
     names = {1: 'optimal', 2: 'solver error'}
     out_status = [names[int(status[g])] if status[g] else _leftover_status(last[g]) for g in range(n)]
     iters = np.where(status != 0, fin_iter, max_iter)
-    return eng.snapshots(latent), out_status, iters, reasons
+    return (eng.snapshots(latent) if fetch is None else eng.snapshots(latent, names=fetch)), out_status, iters, reasons
 
 
 def _marked(eng, group):
@@ -390,7 +403,7 @@ def pad_blocks(blocks, P, identity):
 
 def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1e-5, rtol=1e-4, update_rho=True,
                    rho=1., max_iter=1000, verbose=False, latent=False, mu1=None, selection_stats=False,
-                   tau_range=None, compact=True):
+                   tau_range=None, compact=True, fetch=None, select=None):
     """Solve ``ADMM_MGL(S, lambda1[g], lambda2[g], reg, Omega_0, ...)`` (solver/admm_solver.py:13-313) for every
     g of the 1-D arrays ``lambda1`` / ``lambda2`` at once: the G problems are the slabs of one (G*K,p,p) stack on
     the GPU, one batched Omega-step (and L-step) over all G*K matrices and one Theta-step launch per iteration.
@@ -465,9 +478,9 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                                               max_iter, compact, True,
                                               lambda sl: dict(lambda1=lam1[sl], lambda2=lam2[sl], reg=reg, latent=latent,
                                                               mu1=None if mu is None else mu.reshape(G, K)[sl].reshape(-1),
-                                                              nk=nk, G=len(sl)))
+                                                              nk=nk, G=len(sl)), fetch=fetch)
             for g in range(G):
-                sol = {nm: snaps[nm][g * K:(g + 1) * K].copy() for nm in ('Omega', 'Theta', 'L', 'X')}
+                sol = {nm: snaps[nm][g * K:(g + 1) * K].copy() for nm in ('Omega', 'Theta', 'L', 'X') if nm in snaps}
                 results[g] = (sol, {'status': status[g], 'iterations': int(iters[g]), 'rho': rhos[g]})
                 if g in why:
                     results[g][1]['error'] = why[g]
@@ -511,6 +524,16 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                 for g in range(G):
                     results[g][1]['threshold'] = tab[g * K:(g + 1) * K].copy()
         _late_failures(eng, results, K)
+        if select is not None:
+            # (fetch / select as in ADMM_SGL_batch: the whole solution of the ONE point the caller selects)
+            g_sel, target = select(results)
+            if fetch is not None and g_sel is not None and hasattr(eng, "snapshot_state_k"):
+                parts = [eng.snapshot_state_k(int(g_sel) * K + k) for k in range(K)]
+                Om_g, X_g = np.stack([q[0] for q in parts]), np.stack([q[1] for q in parts])
+                for d in (results[int(g_sel)][0], target):
+                    if d is not None:
+                        d.setdefault('Omega', Om_g)
+                        d.setdefault('X', X_g)
         _warn_failures(results)
     finally:
         for e in engines:

@@ -3805,6 +3805,19 @@ extern "C" int ggl_get_snapshot_k(ggl_ctx* c, int k, double* Theta, double* L)
     return GGL_OK;
 }
 
+/* Omega and X of instance k's snapshot (ggl_snapshot_state_from), either may be null */
+extern "C" int ggl_get_snapshot_state_k(ggl_ctx* c, int k, double* Omega, double* X)
+{
+    ARGCHK(c && k >= 0 && k < c->K, "ctx, k");
+    ARGCHK(c->snapOm && c->snapX, "no state snapshot taken (ggl_snapshot_state_from)");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t pp = (size_t)c->p * c->p, nb = pp * sizeof(double), off = (size_t)k * pp;
+    if (Omega) HIPCHK(hipMemcpyAsync(Omega, c->snapOm + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (X) HIPCHK(hipMemcpyAsync(X, c->snapX + off, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GGL_OK;
+}
+
 extern "C" int ggl_selection_stats(ggl_ctx* c, double* out)
 {
     ARGCHK(c && out, "ctx, out");

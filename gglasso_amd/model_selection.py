@@ -79,19 +79,21 @@ def ebic(S, Theta, N, gamma=0.5):
     return sum(ebic_single(S[k], Theta[k], Nk[k], gamma) for k in range(S.shape[0]))
 
 
-def _solve_grid(S, lam, mu, latent, tol, rtol, max_iter, tau_range=None):
+def _solve_grid(S, lam, mu, latent, tol, rtol, max_iter, tau_range=None, fetch=None, select=None):
     """All (lambda1[, mu1]) instances as ONE batch from the reference's start (Omega_0 = X_0 = identity,
     model_selection.py:595-596).  S: (p,p) shared, or (n,p,p) one covariance matrix per instance.  ``tau_range``: also
     score every instance's estimate thresholded at every tau on the GPU (tune_threshold, :707-737)."""
     eye = np.eye(S.shape[-1])
+    # fetch / select: a grid walk reads Theta (and L) of every point; only the point it selects is returned whole, so only
+    # that point's Omega and X are downloaded (ADMM_SGL_batch)
     res = ADMM_SGL_batch(S, lam, Omega_0=eye, X_0=eye, tol=tol, rtol=rtol, latent=latent, mu1=mu, max_iter=max_iter,
-                         selection_stats=True, tau_range=tau_range)
+                         selection_stats=True, tau_range=tau_range, fetch=fetch, select=select)
     # per instance: the solution, and <S,Theta>, log det Theta, non-zero count computed on the GPU
     return [s for s, _ in res], [info['selection'] for _, info in res]
 
 
 def _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma, gammas, store_all, lambda1_mask,
-                 thresholding=False):
+                 thresholding=False, return_index=False):
     """AIC / eBIC / sparsity / rank tables, best point and stored estimates of one (lambda1, mu1) grid
     (model_selection.py:583-690); sols[j*M+m] solves (lambda_range[j], mu_range[m]).  thresholding: every point's
     Theta is replaced by its best thresholded version (tune_threshold, :641-650) before the criteria are taken."""
@@ -105,7 +107,7 @@ def _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma,
     TAU = np.zeros((nl, nm)) if thresholding else None
     estimates = np.zeros((nl, nm, p, p)) if store_all else None
     lowrank = np.zeros((nl, nm, p, p)) if store_all else None
-    best_sol, curr_min = dict(), np.inf
+    best_sol, curr_min, best_k = dict(), np.inf, None
     for j in range(nl):
         for m in range(nm):
             sol = sols[j * nm + m]
@@ -148,6 +150,7 @@ def _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma,
             if score < curr_min:
                 curr_min = score
                 best_sol = dict(sol)
+                best_k = j * nm + m
     AIC[AIC == -np.inf] = np.nan
     for g in gammas:
         BIC[g][BIC[g] == -np.inf] = np.nan
@@ -155,6 +158,8 @@ def _grid_tables(S, N, sols, dev, lambda_range, mu_range, latent, method, gamma,
     ix = np.unravel_index(np.nanargmin(table), table.shape)
     stats = {'BIC': BIC, 'AIC': AIC, 'SP': SP, 'RANK': RANK, 'LAMBDA': LAMB, 'MU': MU, 'TAU': TAU,
              'BEST': {'lambda1': LAMB[ix], 'mu1': MU[ix]}, 'GAMMA': gammas}
+    if return_index:
+        return best_sol, estimates, lowrank, stats, best_k
     return best_sol, estimates, lowrank, stats
 
 
@@ -184,8 +189,19 @@ def single_grid_search(S, lambda_range, N, method='eBIC', gamma=0.3, latent=Fals
 
     # instance j*nm + m solves (lambda_range[j], mu_range[m])
     if lambda1_mask is None:
-        sols, dev = _solve_grid(S, np.repeat(lambda_range, nm), np.tile(mu_range, nl) if latent else None, latent, tol,
-                                rtol, max_iter, default_tau_range() if thresholding else None)
+        # the tables are taken while the batch's device state is still there (``select``): Theta (and L) of all points come
+        # down, Omega and X of the selected one only -- what the reference returns as best_sol (:652-660)
+        out = {}
+
+        def select(results):
+            tabs = _grid_tables(S, N, [sol for sol, _ in results], [info['selection'] for _, info in results], lambda_range,
+                                mu_range, latent, method, gamma, gammas, store_all, None, thresholding, return_index=True)
+            out['tables'] = tabs[:4]
+            return tabs[4], tabs[0]
+
+        _solve_grid(S, np.repeat(lambda_range, nm), np.tile(mu_range, nl) if latent else None, latent, tol, rtol, max_iter,
+                    default_tau_range() if thresholding else None, fetch=('Theta', 'L'), select=select)
+        return out['tables']
     else:
         sols, dev = [], None
         Om0 = np.eye(p)
@@ -274,7 +290,8 @@ def K_single_grid(S, lambda_range, N, method='eBIC', gamma=0.3, latent=False, mu
         S_inst = np.repeat(S[list(ks)], per_k, axis=0)
         lam = np.tile(np.repeat(lambda_range, nm), len(ks))
         mu = np.tile(np.tile(mu_range, nl), len(ks)) if latent else None
-        s_, d_ = _solve_grid(S_inst, lam, mu, latent, tol, rtol, max_iter, default_tau_range() if thresholding else None)
+        s_, d_ = _solve_grid(S_inst, lam, mu, latent, tol, rtol, max_iter, default_tau_range() if thresholding else None,
+                             fetch=('Theta', 'L'))            # (K_single_grid uses Theta and L of the points, nothing else)
         sols += s_
         dev += d_
 
@@ -482,8 +499,24 @@ def grid_search(solver, S, N, p, reg, l1, l2=None, w2=None, method='eBIC', gamma
             lam1 = np.array([L1[order[i]] for i in idx])
             lam2 = np.array([L2[order[i]] for i in idx])
             mu = np.stack([mu_range[ix_mu[:, order[i][1]]] for i in idx]) if latent else None
+            # without thresholding the walk below reads Theta and L of the points and returns the whole solution of the best one
+            # only: Theta and L of all points come down, Omega and X of each batch's best (the overall best is one of them)
+            sel = None
+            if not thresholding:
+                pS_, Nk_ = S.shape[1], np.asarray(N, dtype=np.float64) * np.ones(K)
+
+                def sel(results):
+                    best, best_g = np.inf, None
+                    for g, (_, info) in enumerate(results):
+                        d = info['selection']
+                        fit, E = Nk_ * d[:, 0] - Nk_ * d[:, 1], (d[:, 2] - pS_) / 2
+                        sc = np.sum(fit + E * (np.log(Nk_) + 4 * np.log(pS_) * gamma)) if method == 'eBIC' else np.sum(fit + E)
+                        if sc < best:
+                            best, best_g = sc, g
+                    return best_g, None
             res = ADMM_MGL_batch(S, lam1, lam2, reg, tol=tol, rtol=rtol, latent=latent, mu1=mu, selection_stats=True,
-                                 tau_range=default_tau_range() if thresholding else None)
+                                 tau_range=default_tau_range() if thresholding else None,
+                                 fetch=None if thresholding else ('Theta', 'L'), select=sel)
             local += [(i, r) for i, r in zip(idx, res)]
         if group is not None:
             gathered = [None] * dist.get_world_size(group)

@@ -265,16 +265,20 @@ class HipEngine:
         """Omega, Theta, L, X of instance ``ks`` of the engine ``src`` (may be this one) into slot ``kd``'s device snapshot."""
         check(self.lib.ggl_snapshot_state_from(self.h, int(kd), src.h, int(ks)))
 
-    def snapshots(self, latent=False):
-        """{'Omega','Theta','X'[,'L']}: the (K,p,p) snapshot stacks, one download each."""
+    def snapshots(self, latent=False, names=None):
+        """{'Omega','Theta','X'[,'L']}: the (K,p,p) snapshot stacks, one download each; ``names``: only these."""
         shape = (self.K, self.p, self.p)
-        Om, Th, X = np.empty(shape), np.empty(shape), np.empty(shape)
-        L = np.empty(shape) if latent else None
-        check(self.lib.ggl_get_snapshots(self.h, ptr(Om), ptr(Th), ptr(L), ptr(X)))
-        out = {'Omega': Om, 'Theta': Th, 'X': X}
-        if latent:
-            out['L'] = L
-        return out
+        want = [nm for nm in ('Omega', 'Theta', 'X') + (('L',) if latent else ()) if names is None or nm in names]
+        arr = {nm: np.empty(shape) for nm in want}
+        check(self.lib.ggl_get_snapshots(self.h, ptr(arr.get('Omega')), ptr(arr.get('Theta')), ptr(arr.get('L')),
+                                         ptr(arr.get('X'))))
+        return arr
+
+    def snapshot_state_k(self, k):
+        """(Omega, X) of instance k's snapshot."""
+        Om, X = np.empty((self.p, self.p)), np.empty((self.p, self.p))
+        check(self.lib.ggl_get_snapshot_state_k(self.h, int(k), ptr(Om), ptr(X)))
+        return Om, X
 
     # -- G independent multiple-graph problems in one stack (batched lambda1 x lambda2 grid) -------------------
     def mgl_batch_step(self, G, rho, lambda1, lambda2, reg, latent, mu1, nk):

@@ -451,6 +451,10 @@ int ggl_failed_reason(ggl_ctx *ctx, int k, double out[2]);
 int ggl_reset_instance(ggl_ctx *ctx, int k);
 int ggl_ctx_create_subset(ggl_ctx *src, const int *idx, int m, ggl_ctx **out);
 int ggl_get_snapshot_k(ggl_ctx *ctx, int k, double *Theta, double *L);
+/* Omega and X of instance k's snapshot (ggl_snapshot_state_from), either may be NULL: what a grid walk fetches for the ONE point it
+ * selects after it has taken Theta (and L) of all points with ggl_get_snapshots(NULL, Theta, L, NULL) -- the reference's
+ * single_grid_search returns the whole sol of the best point only (helper/model_selection.py:652-660). */
+int ggl_get_snapshot_state_k(ggl_ctx *ctx, int k, double *Omega, double *X);
 /* Objective pieces for measure=True (admm_solver.py:213): out = {sum_k -logdet Omega_k,
  * <Omega,S>, P_val(Theta)} (ggl_helper.py:266-270,162-176). */
 int ggl_objective(ggl_ctx *ctx, double lambda1, double lambda2, int reg, double out[3]);

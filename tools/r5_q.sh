@@ -1,4 +1,9 @@
-cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do
-  timeout 900 python -m pytest tests/test_gpu_dispatch.py tests/test_gpu_exit_checks.py tests/test_gpu_ext.py tests/test_gpu_latent_rank.py tests/test_gpu_omega_lds.py tests/test_gpu_ops.py tests/test_gpu_selection.py -q -m gpu -W always 2>&1 | grep -E "passed|failed|solver error|AssertionError|array\(" | head -12
-done
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r5
+python tools/bench_grid.py 2>&1 | grep "^{" > gpurun_out/r5/workload_sgl_grid_p1000_L20.json
+python tools/bench_mgl_grid.py 2>&1 | grep "^{" > gpurun_out/r5/workload_mgl_grid_8x1_K4_p500.json
+python tools/bench_mgl_grid.py --reg FGL --K 6 --p 300 --l1 4 --l2 3 2>&1 | grep "^{" > gpurun_out/r5/workload_mgl_grid_4x3_fgl_K6_p300.json
+python - <<'PY'
+import json
+for f in ("workload_sgl_grid_p1000_L20","workload_mgl_grid_8x1_K4_p500","workload_mgl_grid_4x3_fgl_K6_p300"):
+    d=json.load(open("gpurun_out/r5/"+f+".json")); print(f, {k: round(v,4) for k,v in d.items() if isinstance(v,float)})
+PY
