@@ -55,6 +55,11 @@ WORKLOADS = {
     "ggl_K64_p100": ("GGL", 64, 100, False, 0.05, 0.01, 1241),
     "ggl_K256_p64": ("GGL", 256, 64, False, 0.05, 0.01, 1242),
     "ggl_K32_p128": ("GGL", 32, 128, False, 0.05, 0.01, 1243),
+    # odd p next to its even neighbour (the direct-to-LDS product kernel needs 16-byte rows)
+    "ggl_K32_p501": ("GGL", 32, 501, False, 0.05, 0.01, 1239),
+    "ggl_K32_p502": ("GGL", 32, 502, False, 0.05, 0.01, 1239),
+    "ggl_K20_p201": ("GGL", 20, 201, False, 0.05, 0.01, 1236),
+    "ggl_K20_p202": ("GGL", 20, 202, False, 0.05, 0.01, 1236),
     # C2 of BASELINE.json: Single GL p = 1000 over a 20-point lambda1 grid as ONE batch of 20 independent problems
     # (gglasso_amd.batch / ggl_sgl_batch_step; lambda1 = logspace(0, -2, 20), own rho per point).  A step = one batched
     # iteration of all 20 points; lambda1 / lambda2 of the tuple are unused.

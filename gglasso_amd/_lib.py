@@ -149,6 +149,7 @@ _DEV_SIGNATURES = {
     "ggl_dev_mfma_lds_probe": ([_dp], _i),
     "ggl_dev_chain_run": ([_i, _i, _i, _i, _dp], _i),
     "ggl_dev_switch_bench": ([_i, _i, _i, _i, _i, _dp], _i),
+    "ggl_dev_vendor_bench": ([_i, _i, _i, _i, _dp], _i),
 }
 
 EXPORTS = tuple(_SIGNATURES)

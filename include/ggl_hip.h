@@ -439,8 +439,9 @@ int ggl_finalize_L(ggl_ctx *ctx, int which, int *rank_out);
  *                         device), for the points still iterating once a good part of the batch is done; src stays valid */
 /* Debugging aid, process-wide: after ggl_debug_poison(1) every ctx created fills its device and pinned buffers with 0xFF bytes
  * (NaN doubles, -1 ints) instead of zeros before it initialises what it documents as initialised -- a read of memory the library
- * never wrote then fails at once instead of depending on what an earlier allocation left behind.  tests/conftest.py switches it
- * on for a whole session when GGL_DEBUG_POISON=1 is set in the environment of the TEST process. */
+ * never wrote then fails at once instead of depending on what an earlier allocation left behind.  2..255: that byte instead
+ * (0x7F: 1.4e306, 0x47: 1.5e35 -- finite garbage, which a max / min reduction or a comparison keeps where it drops a NaN).
+ * tests/conftest.py switches it on for a whole session when GGL_DEBUG_POISON=<n> is set in the environment of the TEST process. */
 int ggl_debug_poison(int on);
 int ggl_failed_instances(ggl_ctx *ctx, int *out);
 /* Why instance k was marked (the first mark stays): out[0] = 1 a spectral or norm bound that was not finite or not positive,
@@ -585,6 +586,10 @@ int ggl_dev_chain_run(int K, int p, int nprod, int iters, double *out);
  * followed by a one-thread kernel, 2 the one-thread kernel alone, 3 each followed by an elementwise kernel over its output;
  * ms per repetition. */
 int ggl_dev_switch_bench(int K, int p, int variant, int iters, int mode, double *ms_out);
+/* A measured ceiling for the product kernel: the vendor's FP64 GEMM at the same shapes (tools/bench_vendor.py).  mode 0
+ * rocblas_dgemm_strided_batched (N,N), 1 (T,N), 2 rocblas_dsyrk_strided_batched (one triangle), 3 rocblas_dsyrkx_strided_batched
+ * (one triangle of A B^T: the library's form of a symmetric product), 4 the product kernel itself.  ms per call. */
+int ggl_dev_vendor_bench(int K, int p, int mode, int iters, double *ms_out);
 int ggl_dev_symm_timeline(int K, int p, long long *out, int max_blocks, int *nblocks_out);
 /* persistent-chain probe: nprod dependent products X <- X X of a K-batch as nprod launches (out[0], ms) and as ONE cooperative
  * launch with grid-wide barriers between the products (out[1], ms); out[2] grid of the latter, out[3] max |difference| of

@@ -16,9 +16,11 @@ def pytest_configure(config):
     # GGL_TEST_OPTIONS="name=value,...": ctx options every engine of the session starts with (gglasso_amd._lib.OPTIONS) -- for
     # running the whole suite with a feature switched off when a failure has to be pinned on it
     # GGL_DEBUG_POISON=1: every ctx of the session starts from 0xFF-filled buffers instead of zeros (ggl_debug_poison)
-    if os.environ.get("GGL_DEBUG_POISON", "") == "1":
+    # (GGL_DEBUG_POISON=127 / 71: 0x7F / 0x47 bytes -- FINITE garbage, 1.4e306 / 1.5e35, which a max reduction keeps where it
+    # drops a NaN)
+    if os.environ.get("GGL_DEBUG_POISON", "") not in ("", "0"):
         from gglasso_amd import _lib
-        _lib.load().ggl_debug_poison(1)
+        _lib.load().ggl_debug_poison(int(os.environ["GGL_DEBUG_POISON"]))
     extra = os.environ.get("GGL_TEST_OPTIONS", "")
     if extra:
         from gglasso_amd import solver
