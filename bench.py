@@ -435,6 +435,7 @@ def main():
                   "tolerance": "north_star: Theta within 1e-8 Frobenius of the reference"}
     n_ranks_seen = eng.comm_count() if (distributed and args.comm == "capi") else (world if distributed else 1)
     rank_totals = eng.rank_stats() if latent else None
+    group_totals = eng.group_stats() if hasattr(eng, "group_stats") else None
     eng.close()
 
     if rank == 0:
@@ -559,7 +560,15 @@ def main():
                               "prelaunched_chains_dropped": ns1["pre_dropped"] - ns0["pre_dropped"],
                               # totals since ctx creation: whole chains launched ahead / forgotten, early first parts / continued
                               "pipeline_totals": pipe_totals,
-                              "end_of_iteration_poll_timeouts": ns1["spin_timeouts"] - ns0["spin_timeouts"]}
+                              "end_of_iteration_poll_timeouts": ns1["spin_timeouts"] - ns0["spin_timeouts"],
+                              # GGL_OPT_GROUP_SCHED (totals since ctx creation): Omega-steps that ran as contiguous groups with
+                              # their own schedules, the split and the product units (A', B' included) of the last such step,
+                              # mean units per group slot over the grouped steps
+                              "group_schedules": (lambda g: {"grouped_steps": g["steps"], "last_groups": g["len"],
+                                                             "last_products_per_group": g["units"],
+                                                             "mean_products_per_group": [round(u / max(1, g["steps"]), 3)
+                                                                                         for u in g["units_sum"][:max(len(g["len"]), 1)]]})
+                              (group_totals) if group_totals else None}
             if omega_ns else None,
         }
         if exact is not None:

@@ -15,7 +15,7 @@ EIG_AUTO, EIG_JACOBI, EIG_ROCSOLVER, EIG_NEWTON_SCHULZ = 0, 1, 2, 3
 CTX_STREAM_GIVEN = 1 << 16
 # ggl_ctx_set_option ids (GGL_OPT_*)
 OPTIONS = {"speculate": 1, "spec_factor": 2, "ns_mode": 3, "ns_degrees": 4, "theta_flat": 5, "rank_eig": 6, "parts": 7,
-           "parts_max_tiles": 8, "symm_variant": 9, "spin_wait": 10, "fused_bounds": 11, "pipeline": 12, "fused_start": 13, "parts_small": 14, "ns_tol": 15, "cw_warm": 16, "chain": 17, "rank_l0_coarse": 18, "isolate": 19, "rank_deflate": 20, "rank_l0_deflate": 21, "fused_cw": 22, "omega_lds": 23, "early_part": 24, "part_priority": 25, "fused_w": 26, "rank_cw": 27, "bound_side": 28, "lds_pinned": 29, "join_flag": 30, "cw_rider": 31, "copy_rider": 32, "reduce_rider": 33, "parts_bias": 34, "parts_order": 35, "download_threads": 36}
+           "parts_max_tiles": 8, "symm_variant": 9, "spin_wait": 10, "fused_bounds": 11, "pipeline": 12, "fused_start": 13, "parts_small": 14, "ns_tol": 15, "cw_warm": 16, "chain": 17, "rank_l0_coarse": 18, "isolate": 19, "rank_deflate": 20, "rank_l0_deflate": 21, "fused_cw": 22, "omega_lds": 23, "early_part": 24, "part_priority": 25, "fused_w": 26, "rank_cw": 27, "bound_side": 28, "lds_pinned": 29, "join_flag": 30, "cw_rider": 31, "copy_rider": 32, "reduce_rider": 33, "parts_bias": 34, "parts_order": 35, "download_threads": 36, "group_sched": 37}
 
 
 def eig_flags(method=EIG_AUTO, ns_mode=0, ns_degrees=0):
@@ -98,6 +98,8 @@ _SIGNATURES = {
     "ggl_dev_symm": ([_i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _i], _i),
     "ggl_dev_symm_bench": ([_i, _i, _i, _i, _dp], _i),
     "ggl_lds_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
+    "ggl_group_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong), _dp], _i),
+    "ggl_spectral_bounds": ([_vp, _dp, _dp], _i),
     "ggl_pipeline_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_trace_start": ([_vp, _i], _i),
     "ggl_trace_read": ([_vp, _dp, _i], _i),
@@ -112,12 +114,15 @@ _SIGNATURES = {
     "ggl_failed_instances": ([_vp, ctypes.POINTER(_i)], _i),
     "ggl_failed_reason": ([_vp, _i, _dp], _i),
     "ggl_debug_poison": ([_i], _i),
+    "ggl_set_odd_dl": ([_i], _i),
     "ggl_reset_instance": ([_vp, _i], _i),
     "ggl_ctx_create_subset": ([_vp, ctypes.POINTER(_i), _i, ctypes.POINTER(_vp)], _i),
     "ggl_get_snapshot_k": ([_vp, _i, _dp, _dp], _i),
     "ggl_get_snapshot_state_k": ([_vp, _i, _dp, _dp], _i),
     "ggl_dev_ns_schedule": ([_d, _i, _i, ctypes.POINTER(_i), _dp, ctypes.POINTER(_i)], _i),
     "ggl_dev_ns_schedule_tol": ([_d, _i, _d, _i, ctypes.POINTER(_i), _dp, ctypes.POINTER(_i)], _i),
+    "ggl_dev_group_partition": ([ctypes.POINTER(_i), _i, _i, _i, ctypes.POINTER(_i)], _i),
+    "ggl_dev_ns_units": ([_d, _i, _d], _i),
     "ggl_ns_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_rank_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_deflate_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
@@ -152,6 +157,7 @@ _DEV_SIGNATURES = {
     "ggl_dev_vendor_bench": ([_i, _i, _i, _i, _dp], _i),
 }
 
+ABI_VERSION = 300      # include/ggl_hip.h GGL_VERSION: argument layouts and buffer formats this binding was written against
 EXPORTS = tuple(_SIGNATURES)
 _lib = None
 
@@ -176,7 +182,12 @@ def load():
             import torch  # noqa: F401
         except Exception:  # noqa: BLE001  (torch absent or broken: the single-GPU path does not need it)
             pass
-    _lib = _bind(ctypes.CDLL(LIB_PATH), _SIGNATURES)
+    lib = _bind(ctypes.CDLL(LIB_PATH), _SIGNATURES)
+    v = lib.ggl_version()
+    if v // 100 != ABI_VERSION // 100:
+        raise RuntimeError(f"{LIB_PATH} speaks ABI version {v}, this binding {ABI_VERSION} (include/ggl_hip.h GGL_VERSION): "
+                           "rebuild it with `python -m gglasso_amd.build --force`")
+    _lib = lib
     return _lib
 
 

@@ -164,7 +164,10 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                     finish(s, _leftover_status(last[k]), max_iter)
         for k in range(K):
             results[k][1]['carried'] = int(carried[k])
-        ranks = _final_L(eng, [results[k][0] for k in range(K)], 1) if latent else None
+        ranks = None
+        if latent:
+            ranks, inconsistent = _final_L(eng, [results[k][0] for k in range(K)], 1)
+            _mark_inconsistent(results, inconsistent)
         _late_failures(eng, results, 1)
         if selection_stats:
             assert dims is None, "selection statistics are taken over whole slots"
@@ -181,15 +184,31 @@ def ADMM_SGL_batch(S, lambda1, Omega_0=None, Theta_0=None, X_0=None, rho=1., max
                 for k in range(K):
                     results[k][1]['selection']['threshold'] = tab[k].copy()
                     results[k][1]['selection']['threshold_eig_problems'] = n_eig
+        # a point that ended as 'solver error' has no statistics: NaN in every table built from them (never the selected
+        # point, never a rank of 0 that reads like a result) -- the reference's walk has no such point, it only warns
+        for k in range(K):
+            info = results[k][1]
+            if info['status'] == 'solver error' and 'selection' in info:
+                info['selection'] = {nm: (np.full_like(np.asarray(v, dtype=np.float64), np.nan) if nm == 'threshold' else
+                                          (v if nm == 'threshold_eig_problems' else float('nan')))
+                                     for nm, v in info['selection'].items()}
+                info['selection']['failed'] = True
         if select is not None:
             k_sel, target = select(results)
-            if fetch is not None and k_sel is not None and hasattr(eng, "snapshot_state_k"):
-                Om_k, X_k = eng.snapshot_state_k(int(k_sel))
-                q = int(pk[k_sel])
-                for d in (results[int(k_sel)][0], target):
-                    if d is not None:
-                        d.setdefault('Omega', np.ascontiguousarray(Om_k[:q, :q]))
-                        d.setdefault('X', np.ascontiguousarray(X_k[:q, :q]))
+            if k_sel is not None:
+                own = results[int(k_sel)][0]
+                if ('Omega' not in own or 'X' not in own) and fetch is not None and hasattr(eng, "snapshot_state_k"):
+                    # (the C loop kept every finished point's state on the device and `fetch` left Omega / X there; the
+                    # Python loop -- verbose=True, engines without batch_run -- downloaded them when the point finished and
+                    # never took a state snapshot: ADVICE r5)
+                    Om_k, X_k = eng.snapshot_state_k(int(k_sel))
+                    q = int(pk[k_sel])
+                    own.setdefault('Omega', np.ascontiguousarray(Om_k[:q, :q]))
+                    own.setdefault('X', np.ascontiguousarray(X_k[:q, :q]))
+                if target is not None:
+                    for nm in ('Omega', 'X'):
+                        if nm in own:
+                            target.setdefault(nm, own[nm])
         _warn_failures(results)
     finally:
         for e in engines:
@@ -280,6 +299,15 @@ def _warn_failures(results):
         if res is not None and res[1].get('status') == 'solver error':
             warnings.warn(f"batch point {g}: solver error -- {res[1].get('error', 'marked by the library')}; "
                           f"the other points are not affected", RuntimeWarning, stacklevel=3)
+
+
+def _mark_inconsistent(results, points):
+    """Points whose rebuilt latent component is not the one their last iteration computed (_final_L): 'solver error'."""
+    for g in points:
+        if results[g] is not None and results[g][1]['status'] != 'solver error':
+            results[g][1]['status'] = 'solver error'
+            results[g][1]['error'] = ("the latent component rebuilt from the kept input of the last L-step differs from the "
+                                      "iteration's own (an internal inconsistency: please report it)")
 
 
 def _late_failures(eng, results, group):
@@ -374,19 +402,35 @@ def _final_L(eng, sols, per_sol):
     instance, numpy's rule on the (eigendecomposition's) L otherwise."""
     n_rebuilt, rk = eng.finalize_L(1)
     rk = np.array(rk, dtype=np.int64)
+    bad = []
     for g, sol in enumerate(sols):
         for k in range(per_sol):
             i = g * per_sol + k
+            single = per_sol == 1 and sol['L'].ndim == 2
+            L_it = sol['L'] if single else sol['L'][k]             # the L of the iteration the point finished in
             if rk[i] >= 0:
                 L = eng.snapshot_L_k(i)
                 q = sol['L'].shape[-1]                 # (instances of a padded batch are returned un-padded)
-                if per_sol == 1 and sol['L'].ndim == 2:
-                    sol['L'] = np.ascontiguousarray(L[:q, :q])
+                L = np.ascontiguousarray(L[:q, :q])
+                # the rebuilt L IS the iteration's L up to the sign iteration's residual (~1e-13 |L|): anything else means the
+                # kept input of that L-step is not what the step saw (round 5's intermittent RANK table [[0,0,63],[0,0,108]]
+                # was of this kind) -- the point is reported, never returned as if it were a result
+                nrm = float(np.abs(L_it).max())
+                if not (np.all(np.isfinite(L)) and float(np.abs(L - L_it).max()) <= 1e-6 * max(nrm, 1e-300) + 1e-12):
+                    bad.append(g)
+                    continue
+                if single:
+                    sol['L'] = L
                 else:
-                    sol['L'][k] = L[:q, :q]
+                    sol['L'][k] = L
             else:
-                rk[i] = _solver.latent_rank(sol['L'] if (per_sol == 1 and sol['L'].ndim == 2) else sol['L'][k])
-    return rk
+                try:
+                    rk[i] = _solver.latent_rank(L_it)
+                except np.linalg.LinAlgError:          # (a NaN in L: the point is a failed one)
+                    bad.append(g)
+    for g in bad:
+        rk[g * per_sol:(g + 1) * per_sol] = -1
+    return rk, sorted(set(bad))
 
 
 def pad_blocks(blocks, P, identity):
@@ -512,9 +556,10 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
         for g in range(G):
             results[g][1]['carried'] = int(carried[g])
         if latent:
-            rk = _final_L(eng, [results[g][0] for g in range(G)], K)
+            rk, inconsistent = _final_L(eng, [results[g][0] for g in range(G)], K)
+            _mark_inconsistent(results, inconsistent)
             for g in range(G):
-                results[g][1]['rank'] = rk[g * K:(g + 1) * K].copy()
+                results[g][1]['rank'] = rk[g * K:(g + 1) * K].astype(np.float64)
         if selection_stats:
             st = eng.selection_stats()
             for g in range(G):
@@ -524,16 +569,25 @@ def ADMM_MGL_batch(S, lambda1, lambda2, reg, Omega_0=None, n_samples=None, tol=1
                 for g in range(G):
                     results[g][1]['threshold'] = tab[g * K:(g + 1) * K].copy()
         _late_failures(eng, results, K)
+        for g in range(G):                      # (see ADMM_SGL_batch: a failed point has no statistics)
+            info = results[g][1]
+            if info['status'] == 'solver error':
+                for nm in ('selection', 'threshold', 'rank'):
+                    if nm in info:
+                        info[nm] = np.full(np.shape(info[nm]), np.nan)
         if select is not None:
             # (fetch / select as in ADMM_SGL_batch: the whole solution of the ONE point the caller selects)
             g_sel, target = select(results)
-            if fetch is not None and g_sel is not None and hasattr(eng, "snapshot_state_k"):
-                parts = [eng.snapshot_state_k(int(g_sel) * K + k) for k in range(K)]
-                Om_g, X_g = np.stack([q[0] for q in parts]), np.stack([q[1] for q in parts])
-                for d in (results[int(g_sel)][0], target):
-                    if d is not None:
-                        d.setdefault('Omega', Om_g)
-                        d.setdefault('X', X_g)
+            if g_sel is not None:
+                own = results[int(g_sel)][0]
+                if ('Omega' not in own or 'X' not in own) and fetch is not None and hasattr(eng, "snapshot_state_k"):
+                    parts = [eng.snapshot_state_k(int(g_sel) * K + k) for k in range(K)]
+                    own.setdefault('Omega', np.stack([q[0] for q in parts]))
+                    own.setdefault('X', np.stack([q[1] for q in parts]))
+                if target is not None:
+                    for nm in ('Omega', 'X'):
+                        if nm in own:
+                            target.setdefault(nm, own[nm])
         _warn_failures(results)
     finally:
         for e in engines:

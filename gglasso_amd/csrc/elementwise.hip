@@ -222,6 +222,8 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
     // single-row reductions into pinned host memory: publish a sequence number AFTER the sums, so that the host can
     // wait for this kernel by polling one word instead of a stream synchronisation
     if (seq != nullptr && gridDim.x == 1) {
+        // (the row carries the sequence number itself, behind the sums: the host's second check, finish_norms)
+        if (threadIdx.x == nv) out[nv] = (double)seq_val;
         __syncthreads();
         if (threadIdx.x == 0) {
             __threadfence_system();
@@ -489,6 +491,29 @@ void launch_copy_instances(hipStream_t st, double* dst, const double* src, const
 {
     const int bx = (int)std::min<size_t>((pp / 2 + 255) / 256, 256);
     hipLaunchKernelGGL(k_copy_instances, dim3(std::max(bx, 1), m), dim3(256), 0, st, dst, src, idx, pp, scatter ? 1 : 0);
+}
+
+// One contiguous block of doubles copied / filled by an ordinary kernel in the stream: what the snapshots of a batch use instead
+// of hipMemcpyAsync / hipMemsetAsync, whose device-to-device copies and fills are the runtime's (blit kernels or SDMA, ordered
+// against each other by the runtime's own signals) -- a kernel behind a kernel in one stream is ordered by the queue itself.
+__global__ __launch_bounds__(256) void k_copy_block(double* __restrict__ dst, const double* __restrict__ src, size_t n)
+{
+    const size_t step = (size_t)gridDim.x * 256;
+    if (((reinterpret_cast<size_t>(dst) | reinterpret_cast<size_t>(src)) & 15) == 0) {
+        const size_t n2 = n / 2;
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n2; e += step)
+            reinterpret_cast<double2*>(dst)[e] = src ? reinterpret_cast<const double2*>(src)[e] : double2{0.0, 0.0};
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src ? src[n - 1] : 0.0;
+        return;
+    }
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += step) dst[e] = src ? src[e] : 0.0;
+}
+
+void launch_copy_block(hipStream_t st, double* dst, const double* src, size_t n)
+{
+    if (n == 0) return;
+    const int bx = (int)std::min<size_t>((n / 2 + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_copy_block, dim3(std::max(bx, 1)), dim3(256), 0, st, dst, src, n);
 }
 
 // A_k += shift * I for the K instances of a stack (the shifted definiteness tests of ggl_exit_checks_fast)

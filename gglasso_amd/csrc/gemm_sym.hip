@@ -412,7 +412,10 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
     // instruction beside an MFMA takes matrix-pipe issue slots (tools/probe_mfma_mix.py: 2 integer VALU per MFMA cost 11 % of
     // the FP64 MFMA rate, 8 cost 17 %), and recomputing min / mul / 64-bit adds per instruction was ~25 of them per slab.
     // Only the last, partial slab (rows beyond the matrix clamped to its last row) goes the long way.
-    const unsigned pu = (unsigned)p, pm1 = (unsigned)(p - 1), pm2 = (unsigned)(p - 2);
+    // (pm2: the last column PAIR a lane may start at -- p - 2 for even p; for odd p the pair (p - 1, p), whose second half is
+    // the first element of the next row: in the stack for every row but the last row of the last instance, where it is the 8
+    // bytes behind the stack -- every stack that can be an operand is allocated with that slack, stack_bytes())
+    const unsigned pu = (unsigned)p, pm1 = (unsigned)(p - 1), pm2 = (unsigned)(p - 1) & ~1u;
     const int lrow = lane / LPR;
     const unsigned cpos = (unsigned)((lane % LPR) * 2) ^ (unsigned)(16 * (lrow & 1));
     const unsigned ca = min((unsigned)I0 + cpos, pm2), cb = min((unsigned)J0 + cpos, pm2);
@@ -607,7 +610,7 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
             // columns c2, c2 + 1 of row `row` sit at (c2 ^ row), (c2 ^ row) ^ 1: one aligned pair, swapped for odd rows
             double2 t = ld2(smem + row * BM + ((c2 ^ row) & ~1));
             if (row & 1) { const double h = t.x; t.x = t.y; t.y = h; }
-            if (gi < p && gj < p) {
+            if (gi < p && gj + 1 < p) {
                 double2 e = {0.0, 0.0};
                 if (Ek) e = lde2(Ek + (size_t)gi * p + gj);
                 double2 v;
@@ -623,6 +626,18 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
                 }
                 if (rowpart) {          // the bound partials (and then the mirror) read the FINAL values from the tile
                     if (row & 1) { const double h = v.x; v.x = v.y; v.y = h; }
+                    *reinterpret_cast<double2*>(smem + row * BM + ((c2 ^ row) & ~1)) = v;
+                }
+            } else if (gi < p && gj < p) {
+                // odd p: the last column is the first half of a pair whose second half lies outside the matrix
+                const double e0 = Ek ? ld_pol<AUX>(Ek + (size_t)gi * p + gj) : 0.0;
+                const double v0 = t.x + cE * e0;
+                dev = fmax(dev, fabs(v0));
+                Ck[(size_t)gi * p + gj] = v0;
+                if (C2k) C2k[(size_t)gi * p + gj] = c2val(dC, v0, dE, e0);
+                if (rowpart) {
+                    double2 v = {v0, 0.0};
+                    if (row & 1) { v.x = 0.0; v.y = v0; }
                     *reinterpret_cast<double2*>(smem + row * BM + ((c2 ^ row) & ~1)) = v;
                 }
             } else if (rowpart) {
@@ -722,7 +737,7 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
         };
         for (int e2 = tid; e2 < BM * BM / 2; e2 += NT) {
             const int a = e2 / (BM / 2), c2 = (e2 % (BM / 2)) * 2;      // out[J0+a][I0+c2 .. +1] = tile[c2 .. +1][a]
-            if (J0 + a < p && I0 + c2 < p) {
+            if (J0 + a < p && I0 + c2 + 1 < p) {
                 double2 v;
                 v.x = smem[c2 * BM + (a ^ c2)];
                 v.y = smem[(c2 + 1) * BM + (a ^ (c2 + 1))];
@@ -737,6 +752,15 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
                     w.y = c2val(dC, v.y, dE, e.y);
                     *reinterpret_cast<double2*>(C2k + (size_t)(J0 + a) * p + I0 + c2) = w;
                 }
+            } else if (J0 + a < p && I0 + c2 < p) {
+                // (never taken: I < J, so the rows I0 .. I0 + BM - 1 of an off-diagonal tile all lie inside the matrix and an
+                // odd last column can only belong to tile column J; kept so that the pair test above stands on its own)
+                double v0 = smem[c2 * BM + (a ^ c2)];
+                const bool need_e = Ek && (!rowpart || (C2k && dE != 0.0));
+                const double e0 = need_e ? ld_pol<AUX>(Ek + (size_t)(J0 + a) * p + I0 + c2) : 0.0;
+                if (!rowpart) v0 += cE * e0;
+                Ck[(size_t)(J0 + a) * p + I0 + c2] = v0;
+                if (C2k) C2k[(size_t)(J0 + a) * p + I0 + c2] = c2val(dC, v0, dE, e0);
             }
         }
     }
@@ -839,7 +863,11 @@ __device__ __forceinline__ void cw_rider_body(const CwRider& r, int idx, double*
 
 // the norm reduction as a rider (RedRider): k_reduce_partials' single row -- four rows per trip, strided per-thread sums in
 // ascending order, wave sums, the four waves added in a fixed order -- then the sums and, behind them, the sequence number as
-// system-scope stores (posted writes to the host arrive in order; no cache write-back fence inside a product launch)
+// system-scope stores.  No release FENCE here: inside a product launch it would write back an XCD's L2 (the tiles' output).
+// What orders the two instead: the sums are system-scope (write-through, uncached) stores of ONE wave, `s_waitcnt vmcnt(0)`
+// returns when they have been acknowledged, the barrier puts thread 0's store of the sequence number behind that -- and the
+// row carries the sequence number a second time, in the same store instruction as the sums (slot nv), which the host checks
+// after the poll (finish_norms): a sequence number that overtook its sums would be seen without its stamp.
 __device__ __forceinline__ void red_rider_body(const RedRider& r, double* smem)
 {
     double (*sh)[8] = reinterpret_cast<double (*)[8]>(smem);
@@ -875,8 +903,9 @@ __device__ __forceinline__ void red_rider_body(const RedRider& r, double* smem)
         }
     }
     __syncthreads();
-    if ((int)threadIdx.x < nv) {
-        const double s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if ((int)threadIdx.x <= nv) {
+        const double s = (int)threadIdx.x == nv ? (double)r.seq_val
+                                                : (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
         __hip_atomic_store(r.out + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1930,6 +1959,24 @@ void symm_release_workspace(hipStream_t) {}
 // p = 200, K = 20: 11.8 / 16.4 (register-staged 32x32: 14.7).  Four times the workgroups and five of them resident per CU
 // fill the chip where the 64x64 tiles leave it waiting; from ~1000 tile pairs on the 64x64 tiles' halved L2 -> LDS
 // traffic wins.  Odd p: the register-staged kernels 9 / 0.
+// Odd p on the direct-to-LDS kernel (round 6).  Its DMA moves 16 bytes per lane, and for odd p every other row of a stack starts
+// on an 8-byte boundary only: rounds 1-5 sent every odd p to the register-staged kernel, 25-37 % slower per product.  The
+// hardware takes dword-aligned addresses for global_load_lds_dwordx4 and for 16-byte global loads / stores (the queues run in
+// unaligned-access mode), so what odd p needs is (i) the last column as the first half of a pair whose second half lies
+// outside the matrix (symm_dl_tile: clamp, epilogue) and (ii) 8 bytes of slack behind every stack that can be an operand.
+// g_odd_dl = false restores the old dispatch (GGL_OPT_ODD_DL, for A/B runs and tests).
+static bool g_odd_dl = true;
+void symm_set_odd_dl(bool on) { g_odd_dl = on; }
+bool symm_dl_serves(int p) { return p >= 2 && ((p & 1) == 0 || g_odd_dl); }
+
+// the kernel a variant really runs for this p: a direct-to-LDS variant that the dimension does not allow falls to the
+// register-staged kernel of the same tile (what ggl_ns_stats reports: the dispatch tests assert the kernel, not the request)
+int symm_effective_variant(int variant, int p)
+{
+    if (variant >= 16 && variant <= 39 && !symm_dl_serves(p)) return (variant == 20 || variant >= 24) ? 9 : 0;
+    return variant;
+}
+
 int symm_auto_variant(int nprod, int p)
 {
     const long T64 = (p + 63) / 64;
@@ -1954,7 +2001,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
     if (variant >= 41 && variant <= 50) variant = 20;       // k_symm_sk takes single products only
     switch (variant) {
         case 16: case 17: case 18: case 19: case 20: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
-            if ((p & 1) == 0 && p >= 2) {
+            if (symm_dl_serves(p)) {
                 launch_dl(st, A, B, C, nullptr, nullptr, coef2K, K, p, A1, B1, C1, K, nullptr, variant - 16);
                 break;
             }
@@ -1977,7 +2024,7 @@ void launch_symm_pair(hipStream_t st, const double* A, const double* B, double* 
 int symm_bounds_tile(int K, int p, int variant)
 {
     if (variant < 0) variant = symm_auto_variant(K, p);
-    if ((p & 1) != 0 || p < 2) return 0;
+    if (!symm_dl_serves(p)) return 0;
     if (variant == 20 || (variant >= 24 && variant <= 29) || (variant >= 34 && variant <= 37) || (variant >= 41 && variant <= 50)) return 32;
     if ((variant >= 16 && variant <= 19) || variant == 22 || variant == 23 || (variant >= 30 && variant <= 33) || variant == 38 || variant == 39) return 64;
     return 0;
@@ -1998,7 +2045,7 @@ void launch_symm(hipStream_t st, const double* A, const double* B, double* C, do
 #endif
     switch (variant) {
         case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
-            if ((p & 1) == 0 && p >= 2) {
+            if (symm_dl_serves(p)) {
                 launch_dl(st, A, B, C, C2, E, coef, K, p, nullptr, nullptr, nullptr, 0, maxdev, variant - 16, rowpart, fropart);
                 break;
             }

@@ -144,6 +144,13 @@ struct ggl_ctx {
     int download_threads = 8;                  // GGL_OPT_DOWNLOAD_THREADS: host threads that touch a download's destination pages first
     int parts_order = 0;                       // GGL_OPT_PARTS_ORDER
     int parts_bias = 0;                        // GGL_OPT_PARTS_BIAS: two concurrent parts take K/2 + bias and K/2 - bias instances
+    // GGL_OPT_GROUP_SCHED: a batch whose instances need different product counts (a grid of independent problems) runs as up
+    // to three contiguous groups with their own schedules (ns_group_partition, newton_schulz.hip) where the size rule would
+    // run it as one launch sequence
+    int group_sched = 1;
+    long long group_steps = 0;                 // Omega-steps that ran as such groups
+    int last_groups = 1, last_group_len[MAX_PARTS] = {}, last_group_units[MAX_PARTS] = {};
+    double group_units_sum[MAX_PARTS] = {};    // per group slot: product units summed over the grouped steps
     int parts_small = 8;                       // smallest K (< 16, p >= 384) that is split into two concurrent parts; 0 = never
                                                // (measured at p = 500: K = 8 +7.6 % iterations/s as 4 + 4, K = 4 -2.4 % as 2 + 2)
     bool fused_start = true;                   // speculative step: first step's start matrix as 2nd output of the B' launch
@@ -188,6 +195,7 @@ struct ggl_ctx {
         NsPlan plans[4];
         double* fused[4] = {nullptr, nullptr, nullptr, nullptr};
         double* beta = nullptr;                       // (K) beta the part was built for
+        int nh = 0, Kh[4] = {}, k0h[4] = {};          // the split the part was launched with (the rest must use the same)
     } early;
     bool early_part = true;                           // GGL_OPT_EARLY_PART
     int part_priority = 0;                            // GGL_OPT_PART_PRIORITY
@@ -202,6 +210,7 @@ struct ggl_ctx {
     double spec_factor = 1.02;                 // inflation of the previous bounds (GGL_SPEC_FACTOR; < 1 forces misses)
     unsigned long long* seq_h = nullptr;       // pinned: sequence number published by the last kernel of a step
     unsigned long long seq_next = 0, seq_wait = 0;   // seq_wait != 0: finish_norms may poll instead of synchronising
+    unsigned long long stamp_want = 0;         // a single-row reduction carries its sequence number in slot GGL_NNORM of its row as well
     bool spin_wait = true;
     long long spin_timeouts = 0;               // polls that hit GGL_SPIN_LIMIT_MS and fell back to a stream sync
     bool sharded_check = false;                // this step's Theta kernels ran under the all-reduced validation flag
@@ -492,6 +501,15 @@ void pool_stream_release(int device, hipStream_t s, bool poolable)
 // Lazily allocated device buffers of a ctx start from zeros as its arenas do (0xFF bytes after ggl_debug_poison(1), see ctx_alloc)
 static int g_poison = 0;
 static int poison_fill() { return g_poison; }
+// process-wide: odd p on the direct-to-LDS product kernel (default 1) or on the register-staged one as in rounds 1-5 (0) -- for
+// A/B runs and the parity test of the two routes; returns the previous setting
+extern "C" int ggl_set_odd_dl(int on)
+{
+    const int was = symm_dl_serves(3) ? 1 : 0;
+    symm_set_odd_dl(on != 0);
+    return was;
+}
+
 extern "C" int ggl_debug_poison(int on)
 {
     // 0: zeros (default); 1: 0xFF bytes (NaN doubles, -1 ints); 2..255: that byte -- 0x7F gives 1.4e306 doubles and 0x47
@@ -506,6 +524,8 @@ template <class T> static hipError_t malloc_filled(T** p, size_t bytes, hipStrea
     return hipMemsetAsync(*p, poison_fill(), bytes, st);
 }
 
+static constexpr size_t STACK_SLACK = 64;      // bytes behind every stack that can be a product operand (odd p, see ctx_alloc)
+
 static int ctx_alloc(ggl_ctx* c)
 {
     const size_t nb = c->n * sizeof(double);
@@ -514,13 +534,15 @@ static int ctx_alloc(ggl_ctx* c)
     std::vector<Req> reqs;
 #define DEV(ptr, bytes) reqs.push_back({(void**)&(ptr), (size_t)(bytes), 0})
 #define PIN(ptr, bytes, kind) reqs.push_back({(void**)&(ptr), (size_t)(bytes), (kind)})
-    DEV(c->S, nb);
-    DEV(c->Om[0], nb);
-    DEV(c->Om[1], nb);
-    DEV(c->Theta, nb);
-    DEV(c->L, nb);
-    DEV(c->X, nb);
-    DEV(c->W, nb);
+    // (+ STACK_SLACK: for odd p the product kernel's DMA reads the last element of a stack as the first half of a 16-byte
+    // pair, gemm_sym.hip symm_dl_serves -- every buffer that can be a product operand has a few bytes behind it)
+    DEV(c->S, nb + STACK_SLACK);
+    DEV(c->Om[0], nb + STACK_SLACK);
+    DEV(c->Om[1], nb + STACK_SLACK);
+    DEV(c->Theta, nb + STACK_SLACK);
+    DEV(c->L, nb + STACK_SLACK);
+    DEV(c->X, nb + STACK_SLACK);
+    DEV(c->W, nb + STACK_SLACK);
     DEV(c->DvO, kp * sizeof(double));
     DEV(c->DvL, kp * sizeof(double));
     DEV(c->scale, 2 * kp * sizeof(double));
@@ -551,8 +573,8 @@ static int ctx_alloc(ggl_ctx* c)
     DEV(c->arrive, 256);
     DEV(c->join_words, 256);
     if (c->omega_ns) {
-        for (int i = 0; i < 2; ++i) { DEV(c->nsYP[i], 2 * nb); }
-        DEV(c->nsT, nb);
+        for (int i = 0; i < 2; ++i) { DEV(c->nsYP[i], 2 * nb + STACK_SLACK); }
+        DEV(c->nsT, nb + STACK_SLACK);
         const size_t cl = (size_t)NS_MAX_LAUNCHES * NS_SLOT(c->K) * sizeof(double);   // last 3 slots: start / pre tables
         DEV(c->coef, cl);
         PIN(c->coef_hh[0], cl, 1);
@@ -680,6 +702,11 @@ static int set_option(ggl_ctx* c, int opt, double v)
         case GGL_OPT_PIPELINE: c->pipeline = v != 0.0; break;
         case GGL_OPT_FUSED_START: c->fused_start = v != 0.0; break;
         case GGL_OPT_PARTS_SMALL: c->parts_small = (int)v; break;
+        case GGL_OPT_GROUP_SCHED:
+            if (v != 0.0 && v != 1.0 && v != 2.0 && v != 3.0 && v != 12.0 && v != 13.0)
+                return fail(GGL_E_ARG, "bad argument: GGL_OPT_GROUP_SCHED is 0, 1, 2, 3, 12 or 13");
+            c->group_sched = (int)v;
+            break;
         case GGL_OPT_PARTS_BIAS: c->parts_bias = (int)v; break;
         case GGL_OPT_PARTS_ORDER: c->parts_order = (int)v; break;
         case GGL_OPT_DOWNLOAD_THREADS: c->download_threads = std::min(std::max((int)v, 1), 64); break;
@@ -760,6 +787,7 @@ extern "C" int ggl_ctx_get_option(ggl_ctx* c, int opt, double* value)
         case GGL_OPT_PIPELINE: *value = c->pipeline; break;
         case GGL_OPT_FUSED_START: *value = c->fused_start; break;
         case GGL_OPT_PARTS_SMALL: *value = c->parts_small; break;
+        case GGL_OPT_GROUP_SCHED: *value = c->group_sched; break;
         case GGL_OPT_PARTS_BIAS: *value = c->parts_bias; break;
         case GGL_OPT_PARTS_ORDER: *value = c->parts_order; break;
         case GGL_OPT_DOWNLOAD_THREADS: *value = c->download_threads; break;
@@ -1441,6 +1469,47 @@ static void trace_host(ggl_ctx* c, int tag)
 }
 static void trace_symm_hook(hipStream_t st, int kind, void* arg) { trace_mark((ggl_ctx*)arg, st, 10 + kind); }
 
+// GGL_OPT_GROUP_SCHED: contiguous groups of a batch whose instances need different product counts (ns_group_partition).
+// cb[k] >= lambda_max(A'_k), beta_k = nk/rho.  Returns the number of groups (1: the batch stays whole, Kh / k0h untouched).
+static int omega_groups(const ggl_ctx* c, const double* cb, const double* beta_h, int K, int* Kh, int* k0h, int* gunits)
+{
+    if (!c->group_sched || K < 2 || c->ns_force == 2 || c->chain_mode || c->comm) return 1;
+    std::vector<int> u(K);
+    for (int k = 0; k < K; ++k) {
+        double ck = cb[k] * (1.0 + 1e-10);
+        if (!(ck > 0.0) || !std::isfinite(ck) || !(beta_h[k] > 0.0)) return 1;
+        if (ck < 4.0 * beta_h[k]) ck = 4.0 * beta_h[k];
+        u[k] = ns_units_query(std::sqrt(4.0 * beta_h[k] / ck), c->ns_degrees, c->ns_tol);
+        if (u[k] < 0) return 1;                      // (an instance for the stable schedule: the whole batch as one sequence)
+    }
+    int len[ggl_ctx::MAX_PARTS];
+    // 12 / 13 (tests): up to 2 / 3 groups wherever the product counts differ -- the time model as if the launches were large
+    const bool force = c->group_sched >= 10;
+    const int gmax = force ? c->group_sched - 10 : (c->group_sched >= 2 ? c->group_sched : 3);
+    const int G = ns_group_partition(u.data(), K, force ? 20000 : c->p, std::min(gmax, (int)ggl_ctx::MAX_PARTS - 1), len);
+    if (G <= 1) return 1;
+    for (int g = 0, k0 = 0; g < G; ++g) {
+        Kh[g] = len[g];
+        k0h[g] = k0;
+        gunits[g] = 0;
+        for (int k = k0; k < k0 + len[g]; ++k) gunits[g] = std::max(gunits[g], u[k]);
+        k0 += len[g];
+    }
+    return G;
+}
+
+static void note_groups(ggl_ctx* c, int G, const int* Kh, const NsPlan* plans)
+{
+    c->last_groups = G;
+    if (G <= 1) return;
+    c->group_steps += 1;
+    for (int g = 0; g < ggl_ctx::MAX_PARTS; ++g) {
+        c->last_group_len[g] = g < G ? Kh[g] : 0;
+        c->last_group_units[g] = g < G ? plans[g].units : 0;
+        if (g < G) c->group_units_sum[g] += plans[g].units;
+    }
+}
+
 // Omega-step with beta_k in parameter slot 0 (already on the device, or part of the pending transfer)
 static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec, bool only_spec)
 {
@@ -1500,23 +1569,6 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         // (K = 8, p = 500: +2 %; K = 16 on the 32x32 kernel: -13 %, K = 4: -16 % -- so only the narrow band below 16)
         if (nh == 1 && c->parts_small && K >= c->parts_small && K < 16 && c->p >= 384 && c->ns_parts >= 2) nh = 2;
         nh = std::max(nh, 1);
-        int Kh[ggl_ctx::MAX_PARTS], k0h[ggl_ctx::MAX_PARTS];
-        for (int h = 0, k0 = 0; h < nh; ++h) {
-            Kh[h] = K / nh + (h < K % nh ? 1 : 0);
-            if (nh == 2 && c->parts_bias && std::abs(c->parts_bias) < K / 2) Kh[h] += h == 0 ? c->parts_bias : -c->parts_bias;
-            k0h[h] = k0;
-            k0 += Kh[h];
-        }
-        const size_t pp = (size_t)c->p * c->p;
-        const int nbb = norm_bounds_blocks(c->p);
-        // concurrent parts of a large batch: the 3-stage 64x64 DMA kernel; parts of a small batch: the size rule
-        const int var_parts = (c->symm_variant < 0 && nh > 1 && K >= 16) ? 17 : c->symm_variant;
-        c->last_parts = nh;
-        c->last_variant = var_parts >= 0 ? var_parts : symm_auto_variant(Kh[0], c->p);
-        const size_t region = (size_t)(NS_MAX_LAUNCHES - 4) / nh * NS_SLOT(K);      // coefficient slots per part
-        NsPlan plans[ggl_ctx::MAX_PARTS];
-        double* start_base_h = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
-        double* start_base_d = c->coef + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
         // Speculation: same beta as the last validated step => its bounds, inflated by 2 %, are very likely still
         // bounds (W moves little between ADMM iterations and the spectrum usually shrinks); the schedule is built
         // from them NOW and the products follow the bound kernels without the host round trip.
@@ -1524,6 +1576,40 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         if (allow_spec && !only_spec && c->spec_cool > 0) c->spec_cool -= 1;      // one tick per iteration, not per attempt
         for (int k = 0; spec && k < K; ++k) spec = (c->par_h[k] == c->spec_beta[k]);
         if (resume) spec = true;
+        int Kh[ggl_ctx::MAX_PARTS], k0h[ggl_ctx::MAX_PARTS];
+        bool grouped = false;
+        int gunits[ggl_ctx::MAX_PARTS] = {};
+        if (resume) {
+            nh = c->early.nh;
+            for (int h = 0; h < nh; ++h) { Kh[h] = c->early.Kh[h]; k0h[h] = c->early.k0h[h]; }
+        } else {
+            for (int h = 0, k0 = 0; h < nh; ++h) {
+                Kh[h] = K / nh + (h < K % nh ? 1 : 0);
+                if (nh == 2 && c->parts_bias && std::abs(c->parts_bias) < K / 2) Kh[h] += h == 0 ? c->parts_bias : -c->parts_bias;
+                k0h[h] = k0;
+                k0 += Kh[h];
+            }
+            if (spec && nh == 1) {
+                // instances that need different product counts: contiguous groups with their own schedules
+                std::vector<double> cb(K);
+                for (int k = 0; k < K; ++k) cb[k] = c->spec_c[k] * c->spec_factor;
+                const int G = omega_groups(c, cb.data(), c->par_h, K, Kh, k0h, gunits);
+                if (G > 1) { nh = G; grouped = true; }
+            }
+        }
+        const size_t pp = (size_t)c->p * c->p;
+        const int nbb = norm_bounds_blocks(c->p);
+        // concurrent parts of a large batch: the 3-stage 64x64 DMA kernel; parts of a small batch: the size rule
+        // (groups of different sizes: ONE kernel instance for all of them -- the bound partials of the parts are laid out
+        // by the tile size, and the size rule could pick 32x32 tiles for a small group next to 64x64 for a large one)
+        const int var_parts = grouped ? (c->symm_variant >= 0 ? c->symm_variant : (K >= 16 ? 17 : symm_auto_variant(K, c->p)))
+                                      : ((c->symm_variant < 0 && nh > 1 && K >= 16) ? 17 : c->symm_variant);
+        c->last_parts = nh;
+        c->last_variant = symm_effective_variant(var_parts >= 0 ? var_parts : symm_auto_variant(Kh[0], c->p), c->p);
+        const size_t region = (size_t)(NS_MAX_LAUNCHES - 4) / nh * NS_SLOT(K);      // coefficient slots per part
+        NsPlan plans[ggl_ctx::MAX_PARTS];
+        double* start_base_h = c->coef_h + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
+        double* start_base_d = c->coef + (size_t)(NS_MAX_LAUNCHES - 3) * NS_SLOT(K);
         double* fused[ggl_ctx::MAX_PARTS] = {};      // speculative step: the first step's start as 2nd output of the B' launch
         bool cw_written = false;                     // this step's bound pass left a Collatz-Wielandt vector behind
         if (c->flags_dirty) {
@@ -1622,7 +1708,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         // ---- the whole product chain as ONE persistent launch with per-instance dependencies (k_omega_chain) ----------
         if (spec && !want_A && !resume && c->chain_mode && c->fused_start && c->fused_bounds && (c->symm_variant < 0 || c->symm_variant == 17) &&
             chain_tile(K, c->p, c->chain_mode == 2) == 64) {
-            if (!c->nsNX) HIPCHK(malloc_filled(&c->nsNX, 2 * c->n * sizeof(double), c->stream));
+            if (!c->nsNX) HIPCHK(malloc_filled(&c->nsNX, 2 * c->n * sizeof(double) + STACK_SLACK, c->stream));
             if (!c->chain_cnt) HIPCHK(hipMalloc(&c->chain_cnt, (size_t)K * CHAIN_CNT_STRIDE * sizeof(unsigned)));
             for (int k = 0; k < K; ++k) c->cuse_h[k] = c->spec_c[k] * c->spec_factor;
             NsPlan& pl = plans[0];
@@ -1899,7 +1985,8 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         }
         HIPCHK(hipGetLastError());
         if (want_A) {
-            for (int h = 0; h < nh; ++h) { c->early.plans[h] = plans[h]; c->early.fused[h] = fused[h]; }
+            for (int h = 0; h < nh; ++h) { c->early.plans[h] = plans[h]; c->early.fused[h] = fused[h]; c->early.Kh[h] = Kh[h]; c->early.k0h[h] = k0h[h]; }
+            c->early.nh = nh;
             memcpy(c->early.beta, c->par_h, K * sizeof(double));
             c->early.valid = true;
             c->early_launched += 1;
@@ -1925,6 +2012,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             c->ns_steps_total = (long long)(c->ns_steps_frac + 0.5);
             c->ns_calls += 1;
             c->spec_calls += 1;
+            note_groups(c, grouped ? nh : 1, Kh, plans);
             c->spec_pending = true;        // validated by the caller after its stream sync (finish_norms)
             c->cw_pending = cw_written;
             if (c->info_dirty) { memset(c->info_h, 0, K * sizeof(int)); c->info_dirty = false; }
@@ -1939,9 +2027,25 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         c->spec_have = true;
         if (cw_written) { c->cw_cur ^= 1; c->cw_have = true; }
         bool any_stable = false;
+        size_t region_b = region;
+        int var_b = var_parts;
+        if (nh == 1) {
+            // phase A ran as one launch sequence; the products may still run as groups with their own schedules
+            const int G = omega_groups(c, c->bounds_h, c->par_h, K, Kh, k0h, gunits);
+            if (G > 1) {
+                nh = G;
+                grouped = true;
+                region_b = (size_t)(NS_MAX_LAUNCHES - 4) / nh * NS_SLOT(K);
+                var_b = c->symm_variant >= 0 ? c->symm_variant : (K >= 16 ? 17 : symm_auto_variant(K, c->p));
+                if (!c->parts_probed) {
+                    rc = probe_part_streams(c);
+                    if (rc) return rc;
+                }
+            }
+        }
         for (int h = 0; h < nh; ++h) {
             const int k0 = k0h[h];
-            const int prc = ns_plan(c->bounds_h + k0, c->par_h + k0, Kh[h], c->coef_h + h * region, start_base_h + 5 * k0,
+            const int prc = ns_plan(c->bounds_h + k0, c->par_h + k0, Kh[h], c->coef_h + h * region_b, start_base_h + 5 * k0,
                                     &plans[h], c->ns_force, c->ns_degrees, c->ns_tol);
             if (prc == -1) return fail(GGL_E_SOLVER, "Newton-Schulz Omega-step: non-finite W (diverged iterate?)");
             if (prc == -2) {
@@ -1963,8 +2067,9 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
         const int nrun = (nh > 1 && !any_stable) ? nh : 1;
         if (nrun == 1) { Kh[0] = K; k0h[0] = 0; }
         c->last_parts = nrun;
-        c->last_variant = (nrun > 1 && var_parts >= 0) ? var_parts
-                          : (c->symm_variant >= 0 ? c->symm_variant : symm_auto_variant(Kh[0], c->p));
+        c->last_variant = symm_effective_variant((nrun > 1 && var_b >= 0) ? var_b
+                          : (c->symm_variant >= 0 ? c->symm_variant : symm_auto_variant(Kh[0], c->p)), c->p);
+        note_groups(c, (grouped && nrun > 1) ? nrun : 1, Kh, plans);
         PB(c, GGL_PH_EIG_OMEGA2);
         for (int h = 0; h < nrun; ++h) {
             const int Kr = Kh[h], k0 = k0h[h];
@@ -1973,15 +2078,15 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
             up.add(start_base_d + 5 * (size_t)k0, start_base_h + 5 * (size_t)k0, (size_t)Kr * 5 * sizeof(double));
             const int nb_launch = plans[h].products - 2;     // launches of phase B
             if (nb_launch > 0)
-                up.add(c->coef + h * region, c->coef_h + h * region, (size_t)nb_launch * NS_SLOT(Kr) * sizeof(double));
+                up.add(c->coef + h * region_b, c->coef_h + h * region_b, (size_t)nb_launch * NS_SLOT(Kr) * sizeof(double));
             if (h == 0 && c->info_dirty) up.add(c->info, nullptr, K * sizeof(int));   // no eigensolver ran: info = 0
             launch_copy_small(sh, up);
-            ns_run(sh, plans[h], c->coef + h * region, start_base_d + 5 * k0,
+            ns_run(sh, plans[h], c->coef + h * region_b, start_base_d + 5 * k0,
                    c->W + k0 * pp, c->nsYP[0] + k0 * pp, c->nsYP[1] + k0 * pp, c->nsT + k0 * pp, c->Om[nxt] + k0 * pp, Kr,
                    c->p,
                    // tile choice by the work of the WHOLE batch: the other parts share the chip (measured +6.7 %);
                    // with parts, the 3-stage DMA pipeline is 2.8 % ahead of the double buffer (4 % behind without)
-                   nrun > 1 ? var_parts : c->symm_variant, nrun > 1 ? c->n : 0);
+                   nrun > 1 ? var_b : c->symm_variant, nrun > 1 ? c->n : 0);
             c->ns_stable_calls += plans[h].stable ? 1 : 0;
             c->ns_launches_total += plans[h].products;
             // algorithmic work in units of (whole-stack) K p^3 flop
@@ -2102,7 +2207,22 @@ static int finish_norms(ggl_ctx* c, int rows, double* out_norms, int group = 0)
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
+        if (waited && dn.n == 0 && c->stamp_want == want) {
+            // the row itself carries the sequence number behind its sums (k_reduce_partials, red_rider_body): seen only with them
+            const volatile double* stamp = c->norms_h + GGL_NNORM;
+            for (unsigned spin = 1; *stamp != (double)want; ++spin) {
+                __builtin_ia32_pause();
+                if ((spin & 0xfff) == 0 &&
+                    std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(GGL_SPIN_LIMIT_MS)) {
+                    c->spin_timeouts += 1;
+                    waited = false;
+                    break;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
     }
+    c->stamp_want = 0;
     c->seq_wait = 0;
     if (!waited || c->prof_on) HIPCHK(hipStreamSynchronize(c->stream));
     if (want != 0 && (dn.n == 0 || dn_seq) && !waited && *(const volatile unsigned long long*)c->seq_h != want)
@@ -2142,7 +2262,7 @@ static int rank_step(ggl_ctx* c)
         // keep C for ggl_finalize_L: W is scratch that every step forms anew, so the two stacks swap names (the stream was
         // synchronised by the step's checks; a latent step neither speculates nor pre-launches, nothing in flight holds W)
         if (!c->Ckeep) {
-            HIPCHK(malloc_filled(&c->Ckeep_alloc, c->n * sizeof(double), c->stream));
+            HIPCHK(malloc_filled(&c->Ckeep_alloc, c->n * sizeof(double) + STACK_SLACK, c->stream));
             c->Ckeep = c->Ckeep_alloc;
             c->Ckeep_beta = (double*)malloc(c->K * sizeof(double));
         }
@@ -2241,7 +2361,7 @@ static int rank_step_impl(ggl_ctx* c)
         int nh = (K >= 16 && ntile >= 600 && ntile <= c->parts_max_tiles) ? std::min(c->ns_parts, K / 8) : 1;
         nh = std::max(nh, 1);
         c->last_parts = nh;
-        c->last_variant = (c->symm_variant >= 0) ? c->symm_variant : (nh > 1 ? 17 : symm_auto_variant(K, c->p));
+        c->last_variant = symm_effective_variant((c->symm_variant >= 0) ? c->symm_variant : (nh > 1 ? 17 : symm_auto_variant(K, c->p)), c->p);
         if (nh > 1) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
             for (int h = 1; h < nh; ++h) HIPCHK(hipStreamWaitEvent(c->streamx[h - 1], c->ev_fork, 0));
@@ -2511,7 +2631,7 @@ static int ggl_step_finish_impl(ggl_ctx* c, double rho, double lambda1, double l
         PE(c, GGL_PH_THETA);
         if (!latent) {
             PB(c, GGL_PH_REDUCE);
-            if (!defer_norms && c->seq_h && c->spin_wait) c->seq_wait = ++c->seq_next;
+            if (!defer_norms && c->seq_h && c->spin_wait) c->stamp_want = c->seq_wait = ++c->seq_next;
             // GGL_OPT_REDUCE_RIDER: the early first part of the next chain follows and its first launch is A' (W written by the
             // Theta kernel above): the reduction rides in that launch (RedRider) -- maybe_early below hands it over, and
             // launches it after all if no A' came
@@ -3083,6 +3203,8 @@ struct BatchRun {
     ggl_ctx* snap_ctx; const int* snap_index; int stop_after;
 };
 
+static int snapshot_many(ggl_ctx* c, const int* kd, ggl_ctx* src, const int* ks, int n, bool with_state);
+
 // after one iteration's step (sums in sq): decisions, rescale, snapshots; *stop = the call should return now
 static int batch_after_step(ggl_ctx* c, const BatchRun& b, const double* sq, int it, bool last_iter, bool* stop)
 {
@@ -3097,24 +3219,30 @@ static int batch_after_step(ggl_ctx* c, const BatchRun& b, const double* sq, int
     int rc = batch_rescale(c, fac.data(), b.n, b.group);
     if (rc) return rc;
     int finished = 0;
+    std::vector<int> kd, ks;
     for (int g = 0; g < b.n; ++g) {
         if (ev[g] != 0) {
             b.status[g] = ev[g];
             b.fin_iter[g] = b.it_base + it + 1;
-            if (b.snap_ctx) {
+            if (b.snap_ctx)
                 for (int k = 0; k < b.group; ++k) {
-                    const int s = g * b.group + k;
-                    rc = ggl_snapshot_state_from(b.snap_ctx, b.snap_index[s], c, s);
-                    if (rc) return rc;
+                    ks.push_back(g * b.group + k);
+                    kd.push_back(b.snap_index[g * b.group + k]);
                 }
-                if (ev[g] == 2)
-                    for (int k = 0; k < b.group; ++k) {
-                        rc = ggl_reset_instance(c, g * b.group + k);
-                        if (rc) return rc;
-                    }
-            }
         }
         finished += b.status[g] != 0 ? 1 : 0;
+    }
+    if (!ks.empty()) {
+        // every point that finishes in this iteration in ONE hand-over, the converged ones together with the failed ones and
+        // before those are parked (collecting reads what the ctx knows about the last L-step of the WHOLE batch)
+        rc = snapshot_many(b.snap_ctx, kd.data(), c, ks.data(), (int)ks.size(), true);
+        if (rc) return rc;
+        for (int g = 0; g < b.n; ++g)
+            if (ev[g] == 2)
+                for (int k = 0; k < b.group; ++k) {
+                    rc = ggl_reset_instance(c, g * b.group + k);
+                    if (rc) return rc;
+                }
     }
     *stop = last_iter || finished == b.n || (events > 0 && (!b.snap_ctx || (b.stop_after > 0 && finished >= b.stop_after)));
     if (*stop) HIPCHK(hipStreamSynchronize(c->stream));       // (the caller reads the state / rewrites the pinned slots next)
@@ -3261,6 +3389,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->symm_variant = src->symm_variant; c->spin_wait = src->spin_wait; c->fused_bounds = src->fused_bounds;
     c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->parts_bias = src->parts_bias; c->parts_order = src->parts_order; c->download_threads = src->download_threads; c->ns_tol = src->ns_tol;
     c->cw_warm = src->cw_warm; c->chain_mode = src->chain_mode; c->rank_l0 = src->rank_l0; c->rank_l0_coarse = src->rank_l0_coarse;
+    c->group_sched = src->group_sched;
     c->isolate = src->isolate; c->fused_cw = src->fused_cw; c->lds_omega = src->lds_omega; c->lds_waves = src->lds_waves; c->early_part = src->early_part; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
     int* didx = nullptr;
     hipError_t e = hipMalloc(&didx, m * sizeof(int));
@@ -3286,7 +3415,7 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     if (src->l_ns && src->Ckeep && src->Ckeep_beta) {
         // the kept input of the last (sign-iteration) L-step moves along: a point collected from the new ctx before its
         // first L-step there (max_iter right after a compaction) is still rebuilt by ggl_finalize_L
-        e = hipMalloc(&c->Ckeep_alloc, c->n * sizeof(double));
+        e = hipMalloc(&c->Ckeep_alloc, c->n * sizeof(double) + STACK_SLACK);
         if (e != hipSuccess) { (void)hipFree(didx); ggl_ctx_destroy(c); return fail(GGL_E_HIP, "subset: %s", hipGetErrorString(e)); }
         c->Ckeep = c->Ckeep_alloc;
         c->Ckeep_beta = (double*)malloc(m * sizeof(double));
@@ -3370,6 +3499,32 @@ extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[16])
 
 // The LDS-resident Omega-step: { launches, launches an instance fell outside the kernel's range (step repeated on the launch
 // chain), products summed over all instances of all launches, Newton-Schulz steps likewise }.  Waits for the stream.
+// GGL_OPT_GROUP_SCHED: out = { Omega-steps that ran as groups with their own schedules, groups of the last step (1: whole),
+// lengths of its groups [4], product units (A', B' included) of their schedules [4] };
+// units_sum (may be null) [4]: the units of every group slot summed over the grouped steps.
+extern "C" int ggl_group_stats(ggl_ctx* c, long long out[10], double* units_sum)
+{
+    ARGCHK(c && out, "ctx, out");
+    out[0] = c->group_steps;
+    out[1] = c->last_groups;
+    for (int g = 0; g < 4; ++g) {
+        out[2 + g] = c->last_groups > 1 ? c->last_group_len[g] : 0;
+        out[6 + g] = c->last_groups > 1 ? c->last_group_units[g] : 0;
+        if (units_sum) units_sum[g] = c->group_units_sum[g];
+    }
+    return GGL_OK;
+}
+
+// The spectral bounds c_k >= lambda_max(W_k^2 + 4 beta_k I) and the beta_k of the last VALIDATED matrix-function Omega-step
+// (what the next step's speculative schedule is built from); returns 0 when there are none yet, 1 otherwise.
+extern "C" int ggl_spectral_bounds(ggl_ctx* c, double* c_out, double* beta_out)
+{
+    ARGCHK(c && c_out && beta_out, "ctx, c_out, beta_out");
+    if (!c->omega_ns || !c->spec_have) return 0;
+    for (int k = 0; k < c->K; ++k) { c_out[k] = c->spec_c[k]; beta_out[k] = c->spec_beta[k]; }
+    return 1;
+}
+
 extern "C" int ggl_lds_stats(ggl_ctx* c, long long out[4])
 {
     ARGCHK(c && out, "ctx, out");
@@ -3645,50 +3800,73 @@ extern "C" int ggl_exit_checks(ggl_ctx* c, int latent, double out[5])
     return GGL_OK;
 }
 
-// Snapshot of instance ks of `src` into slot kd of `c` (c == src, kd == ks: ggl_snapshot_k).  The two-ctx form serves a batch
-// that was compacted (ggl_ctx_create_subset): a point that converges in the smaller ctx is snapshotted into the ORIGINAL
-// ctx at its original index, where the selection statistics and ggl_finalize_L run over all points at once.
-extern "C" int ggl_snapshot_from(ggl_ctx* c, int kd, ggl_ctx* src, int ks)
+// Snapshots of the instances ks[0..n) of `src` into the slots kd[0..n) of `c` (c == src, kd == ks: ggl_snapshot_k).  The two-ctx
+// form serves a batch that was compacted (ggl_ctx_create_subset): a point that converges in the smaller ctx is snapshotted into
+// the ORIGINAL ctx at its original index, where the selection statistics and ggl_finalize_L run over all points at once.
+// with_state: Omega and X as well (ggl_snapshot_state_from).  ONE wait for src and one for c whatever n (the C loop hands over
+// all points that finish in an iteration together; round 5 synchronised both streams per instance -- ADVICE r5).
+static int snapshot_many(ggl_ctx* c, const int* kd, ggl_ctx* src, const int* ks, int n, bool with_state)
 {
-    ARGCHK(c && src, "ctx");
-    ARGCHK(kd >= 0 && kd < c->K && ks >= 0 && ks < src->K, "instance index");
+    ARGCHK(c && src && kd && ks && n >= 1, "ctx, indices");
+    for (int i = 0; i < n; ++i) ARGCHK(kd[i] >= 0 && kd[i] < c->K && ks[i] >= 0 && ks[i] < src->K, "instance index");
     ARGCHK(c->p == src->p && c->device == src->device, "snapshot between ctxs of different dimension / device");
     HIPCHK(hipSetDevice(c->device));
+    // (before anything is queued: a pre-launched chain of either ctx holds Omega[cur ^ 1] and scratch; what is snapshotted is
+    // the iterate the caller can observe -- ADVICE r5: the state copies used to be queued ahead of the drop)
     DROP_PRE(c);
     if (src != c) {
         int rc_ = drop_prelaunch(src);
         if (rc_) return rc_;
         HIPCHK(hipStreamSynchronize(src->stream));          // the copies below run on c's stream
     }
-    const size_t pp = (size_t)c->p * c->p, nb = pp * sizeof(double);
-    if (!c->snapT) {
-        HIPCHK(hipMalloc(&c->snapT, c->n * sizeof(double)));
-        HIPCHK(hipMemsetAsync(c->snapT, 0, c->n * sizeof(double), c->stream));
-    }
-    HIPCHK(hipMemcpyAsync(c->snapT + kd * pp, src->Theta + ks * pp, nb, hipMemcpyDeviceToDevice, c->stream));
-    if (src->step_latent) {
-        if (!c->snapL) {
-            HIPCHK(hipMalloc(&c->snapL, c->n * sizeof(double)));
-            HIPCHK(hipMemsetAsync(c->snapL, 0, c->n * sizeof(double), c->stream));
+    const size_t pp = (size_t)c->p * c->p;
+    // (fills and copies of the snapshots are ordinary kernels on c's stream, launch_copy_block: their order is the queue's)
+    auto lazy = [&](double** b) -> int {
+        if (!*b) {
+            HIPCHK(hipMalloc(b, c->n * sizeof(double)));
+            launch_copy_block(c->stream, *b, nullptr, c->n);                      // (slots never snapshotted read as zeros)
         }
-        HIPCHK(hipMemcpyAsync(c->snapL + kd * pp, src->L + ks * pp, nb, hipMemcpyDeviceToDevice, c->stream));
+        return GGL_OK;
+    };
+    int rc = lazy(&c->snapT);
+    if (rc) return rc;
+    if (with_state) {
+        if ((rc = lazy(&c->snapOm)) != GGL_OK || (rc = lazy(&c->snapX)) != GGL_OK) return rc;
+    }
+    if (src->step_latent) {
+        if ((rc = lazy(&c->snapL)) != GGL_OK) return rc;
         if (!c->snap_ns) {
             c->snap_ns = (unsigned char*)calloc(c->K, 1);
             c->snap_beta = (double*)calloc(c->K, sizeof(double));
         }
-        c->snap_ns[kd] = src->l_ns ? 1 : 0;
-        if (src->l_ns) {
-            // the sign iteration's L: keep its input C as well, ggl_finalize_L(which = 1) rebuilds the snapshot from it
-            if (!c->snapC) {
-                HIPCHK(hipMalloc(&c->snapC, c->n * sizeof(double)));
-                HIPCHK(hipMemsetAsync(c->snapC, 0, c->n * sizeof(double), c->stream));
+        if (src->l_ns && (rc = lazy(&c->snapC)) != GGL_OK) return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        const size_t od = (size_t)kd[i] * pp, os = (size_t)ks[i] * pp;
+        if (with_state) {
+            launch_copy_block(c->stream, c->snapOm + od, src->Om[src->cur] + os, pp);
+            launch_copy_block(c->stream, c->snapX + od, src->X + os, pp);
+        }
+        launch_copy_block(c->stream, c->snapT + od, src->Theta + os, pp);
+        if (src->step_latent) {
+            launch_copy_block(c->stream, c->snapL + od, src->L + os, pp);
+            c->snap_ns[kd[i]] = src->l_ns ? 1 : 0;
+            if (src->l_ns) {
+                // the sign iteration's L: keep its input C as well, ggl_finalize_L(which = 1) rebuilds the snapshot from it
+                launch_copy_block(c->stream, c->snapC + od, src->Ckeep + os, pp);
+                c->snap_beta[kd[i]] = src->Ckeep_beta[ks[i]];
             }
-            HIPCHK(hipMemcpyAsync(c->snapC + kd * pp, src->Ckeep + ks * pp, nb, hipMemcpyDeviceToDevice, c->stream));
-            c->snap_beta[kd] = src->Ckeep_beta[ks];
         }
     }
+    HIPCHK(hipGetLastError());
     if (src != c) HIPCHK(hipStreamSynchronize(c->stream));  // src may go on (or away) right after the call
     return GGL_OK;
+}
+
+extern "C" int ggl_snapshot_from(ggl_ctx* c, int kd, ggl_ctx* src, int ks)
+{
+    ARGCHK(c && src, "ctx");
+    return snapshot_many(c, &kd, src, &ks, 1, false);
 }
 
 extern "C" int ggl_snapshot_k(ggl_ctx* c, int k) { return ggl_snapshot_from(c, k, c, k); }
@@ -3699,24 +3877,7 @@ extern "C" int ggl_snapshot_k(ggl_ctx* c, int k) { return ggl_snapshot_from(c, k
 extern "C" int ggl_snapshot_state_from(ggl_ctx* c, int kd, ggl_ctx* src, int ks)
 {
     ARGCHK(c && src, "ctx");
-    ARGCHK(kd >= 0 && kd < c->K && ks >= 0 && ks < src->K, "instance index");
-    ARGCHK(c->p == src->p && c->device == src->device, "snapshot between ctxs of different dimension / device");
-    HIPCHK(hipSetDevice(c->device));
-    for (double** b : {&c->snapOm, &c->snapX}) {
-        if (!*b) {
-            HIPCHK(hipMalloc(b, c->n * sizeof(double)));
-            HIPCHK(hipMemsetAsync(*b, 0, c->n * sizeof(double), c->stream));
-        }
-    }
-    const size_t pp = (size_t)c->p * c->p, nb = pp * sizeof(double);
-    if (src != c) {
-        int rc_ = drop_prelaunch(src);
-        if (rc_) return rc_;
-        HIPCHK(hipStreamSynchronize(src->stream));          // the copies below run on c's stream
-    }
-    HIPCHK(hipMemcpyAsync(c->snapOm + kd * pp, src->Om[src->cur] + ks * pp, nb, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->snapX + kd * pp, src->X + ks * pp, nb, hipMemcpyDeviceToDevice, c->stream));
-    return ggl_snapshot_from(c, kd, src, ks);
+    return snapshot_many(c, &kd, src, &ks, 1, true);
 }
 
 /* whole snapshot stacks (K,p,p), any may be null: Omega, Theta, L, X as ggl_snapshot_state_from left them */
@@ -3777,7 +3938,8 @@ extern "C" int ggl_finalize_L(ggl_ctx* c, int which, int* rank_out)
     HIPCHK(hipMemcpyAsync(c->info_h, c->info, K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (which == 1)
         for (int k = 0; k < K; ++k)
-            if (todo[k]) HIPCHK(hipMemcpyAsync(c->snapL + k * pp, c->W + k * pp, pp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            if (todo[k]) launch_copy_block(c->stream, c->snapL + k * pp, c->W + k * pp, pp);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(slot, saved.data(), K * sizeof(double));
     HIPCHK(hipMemcpyAsync(c->par + 2 * (size_t)K, slot, K * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -3787,12 +3949,22 @@ extern "C" int ggl_finalize_L(ggl_ctx* c, int which, int* rank_out)
     for (int k = 0; k < K; ++k) {
         if (!todo[k]) continue;
         int r = 0;
-        for (int e = 0; e < p; ++e) r += d[(size_t)k * p + e] > beta_src[k] ? 1 : 0;
+        bool finite = true;
+        for (int e = 0; e < p; ++e) {
+            const double v = d[(size_t)k * p + e];
+            finite = finite && std::isfinite(v);
+            r += v > beta_src[k] ? 1 : 0;
+        }
+        // eigenvalues that are not finite: the kept C was not (a diverged instance) -- never a rank of zero that reads like a result
+        if (!finite) {
+            if (c->isolate) { mark_failed(c, k, 2, NAN); r = -1; }
+            else return fail(GGL_E_SOLVER, "final L: the eigenvalues of instance %d's L-step input are not finite", k);
+        }
         if (rank_out) rank_out[k] = r;
     }
     if (which == 0) c->l_ns = false;                  // L is an eigendecomposition's now (and Ckeep is spent)
     else memset(c->snap_ns, 0, K);                    // (snapC is spent; a later snapshot of an instance sets its flag again)
-    if (which == 1) HIPCHK(hipMemsetAsync(c->snapC, 0, c->n * sizeof(double), c->stream));
+    if (which == 1) launch_copy_block(c->stream, c->snapC, nullptr, c->n);
     c->finalize_calls += 1;
     return n_todo;
 }
@@ -4274,7 +4446,7 @@ static int ext_finish(ggl_ctx* c, double rho, const double* lambda1K, const doub
     PB(c, GGL_PH_REDUCE);
     c->norms_host = true;
     if (nprob == 1) {
-        if (c->seq_h && c->spin_wait) c->seq_wait = ++c->seq_next;
+        if (c->seq_h && c->spin_wait) c->stamp_want = c->seq_wait = ++c->seq_next;
         launch_reduce_partials(c->stream, c->partials, 1, (latent ? 1 : 2) * K * nblk, GGL_NNORM, c->norms_h,
                                c->seq_wait ? c->seq_h : nullptr, c->seq_wait);
         PE(c, GGL_PH_REDUCE);
@@ -4412,7 +4584,7 @@ namespace {
 struct DevBuf {
     double* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(double)); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(double) + STACK_SLACK); }
 };
 }  // namespace
 
@@ -5310,6 +5482,14 @@ extern "C" int ggl_dev_ns_schedule(double l, int degrees, int max_steps, int* de
     if (n < 0) return fail(GGL_E_ARG, "no schedule within %d steps", max_steps);
     return n;
 }
+
+// host only: the grouping rule of GGL_OPT_GROUP_SCHED (ns_group_partition) and the product units of a schedule
+extern "C" int ggl_dev_group_partition(const int* units, int K, int p, int max_groups, int* len_out)
+{
+    ARGCHK(units && len_out && K >= 1 && p >= 1 && max_groups >= 1 && max_groups <= 3, "units, len_out, K, p, 1 <= max_groups <= 3");
+    return ns_group_partition(units, K, p, max_groups, len_out);
+}
+extern "C" int ggl_dev_ns_units(double l, int degrees, double tol) { return ns_units_query(l, degrees, tol); }
 
 extern "C" int ggl_dev_ns_schedule_tol(double l, int degrees, double tol, int max_steps, int* deg_out, double* coef_out,
                                        int* units_out)

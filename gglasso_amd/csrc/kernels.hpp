@@ -48,6 +48,8 @@ struct CopySegs {
     void add(void* d, const void* s, size_t bytes) { dst[n] = d; src[n] = s; words[n] = (unsigned)(bytes / 4); ++n; }
 };
 void launch_copy_small(hipStream_t st, const CopySegs& segs);
+// dst[0..n) = src[0..n) (src null: zeros) as an ordinary kernel in the stream
+void launch_copy_block(hipStream_t st, double* dst, const double* src, size_t n);
 void launch_copy_small_seq(hipStream_t st, const CopySegs& segs, unsigned long long* seq, unsigned long long seq_val);
 void launch_spin_us(hipStream_t st, int us);
 // join of concurrent launch sequences through memory instead of a cross-queue event (elementwise.hip)
@@ -272,6 +274,9 @@ static constexpr int NS_NCOEF = 6;
 // variant < 0: pick by problem size.  FP64 MFMA.
 int symm_variants();
 bool symm_variant_built(int v);          // the shipped library holds the dispatched instances only (gemm_sym.hip)
+bool symm_dl_serves(int p);               // the direct-to-LDS product kernel takes this dimension (every p >= 2 unless switched off for odd p)
+void symm_set_odd_dl(bool on);            // process-wide: odd p on the direct-to-LDS kernel (default) or on the register-staged one
+int symm_effective_variant(int variant, int p);   // the kernel a variant resolves to at this p (reporting)
 int symm_auto_variant(int nprod, int p); // what variant < 0 resolves to for nprod products of p x p matrices in a launch
 // maxdev (optional, device [K], zeroed by the caller): max |C - I| per instance.
 // rowpart / fropart (optional, only where symm_bounds_tile() != 0): partial row sums of |C| per tile column,
@@ -411,6 +416,10 @@ int ns_plan(const double* cbound_h, const double* beta_h, int K, double* coef_h,
             int force_mode, int degrees = 9, double tol = NS_TOL_EXACT);
 // the schedule alone (host): returns steps, fills deg[max_steps], coef[max_steps*6] = {t0..t4,l_after}
 int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* coef, int* units, double tol = NS_TOL_EXACT);
+// products of the all-symmetric schedule for [l, 1] (A', B' included), -1 where it does not apply; contiguous groups of a
+// batch whose instances need different product counts (newton_schulz.hip)
+int ns_units_query(double l, int degrees, double tol);
+int ns_group_partition(const int* units, int K, int p, int max_groups, int* len_out);
 void ns_prepare(hipStream_t st, const double* pre0_d, const double* pre1_d, const double* W, double* Ap, double* Bp,
                 int K, int p, int variant, double* start2 = nullptr, double* rowpart = nullptr, double* fropart = nullptr);
 void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const double* start_d, const double* W,

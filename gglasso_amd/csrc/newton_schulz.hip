@@ -415,6 +415,66 @@ int ns_schedule_query(double l, int degrees, int max_steps, int* deg, double* co
     return sq.n;
 }
 
+// Products (in units of one symmetric product of the instance, A' and B' included) of the all-symmetric schedule for a
+// spectrum in [l, 1]; -1 where that schedule does not apply (condition number above NS_SYM_KAPPA_MAX, no schedule).
+int ns_units_query(double l, int degrees, double tol)
+{
+    if (!(l > 0.0) || !(l <= 1.0) || 1.0 / (l * l) > NS_SYM_KAPPA_MAX) return -1;
+    const NsSeq& sq = ns_mixed_schedule(l, degrees, tol);
+    if (sq.n < 1 || sq.n > NS_MAX_STEPS || sq.cost >= (1 << 29)) return -1;
+    return 2 + sq.cost;
+}
+
+// Contiguous groups of a batch whose instances differ in conditioning.  One launch sequence runs ONE schedule -- the degree
+// sequence is common to a launch -- so ns_plan builds it for the worst instance, and a grid of independent problems
+// (helper/model_selection.py:619-633 solves every point with its own eigh) pays the worst point's product count for all of
+// them: 10-11 products per Omega-step for the 20-point p = 1000 lambda1 grid where its well-conditioned half needs 7-8.  The
+// instances of such a grid are ordered by lambda1, i.e. by conditioning, so CONTIGUOUS groups with their own schedules --
+// the concurrent parts the engine already has -- recover most of it.  units[k]: ns_units_query of instance k.  A partition
+// into g <= max_groups runs of lengths len_i costs  sum_i U_i (F + len_i I),  U_i the largest unit count in run i,
+// I = seconds per instance and product, F = fixed seconds per launch (a deterministic model, never a clock: the decision
+// shows in the last digits of the iterates); it is taken when it beats the single schedule by at least 6 %.
+// Returns the number of groups (1: leave the batch whole) and their lengths.
+int ns_group_partition(const int* units, int K, int p, int max_groups, int* len_out)
+{
+    len_out[0] = K;
+    if (K < 2 || max_groups < 2) return 1;
+    int umin = units[0], umax = units[0];
+    for (int k = 1; k < K; ++k) { umin = std::min(umin, units[k]); umax = std::max(umax, units[k]); }
+    if (umin <= 0 || umin == umax) return 1;
+    const double I = 2.5e-14 * (double)p * p * p, F = 6.5e-6;     // 64x64 direct-to-LDS kernel: 25 us per instance-product at p = 1000
+    // the dynamic programme is O(groups K^2) host work per step: only where the step is long enough not to notice
+    if (3.0 * K * K * 4e-9 > 0.02 * umax * (F + K * I)) return 1;
+    const int G = std::min(max_groups, 3);
+    const double INF = 1e300;
+    std::vector<double> best((size_t)(G + 1) * (K + 1), INF);
+    std::vector<int> from((size_t)(G + 1) * (K + 1), -1);
+    best[0] = 0.0;
+    for (int g = 1; g <= G; ++g)
+        for (int j = g; j <= K; ++j) {
+            int u = 0;
+            for (int i = j - 1; i >= g - 1; --i) {            // run [i, j)
+                u = std::max(u, units[i]);
+                const double prev = best[(size_t)(g - 1) * (K + 1) + i];
+                if (prev >= INF) continue;
+                const double cst = prev + u * (F + (j - i) * I);
+                if (cst < best[(size_t)g * (K + 1) + j]) { best[(size_t)g * (K + 1) + j] = cst; from[(size_t)g * (K + 1) + j] = i; }
+            }
+        }
+    const double whole = best[(size_t)1 * (K + 1) + K];
+    int gbest = 1;
+    for (int g = 2; g <= G; ++g)
+        if (best[(size_t)g * (K + 1) + K] < best[(size_t)gbest * (K + 1) + K]) gbest = g;
+    if (gbest == 1 || !(best[(size_t)gbest * (K + 1) + K] <= 0.94 * whole)) return 1;
+    int j = K;
+    for (int g = gbest; g >= 1; --g) {
+        const int i = from[(size_t)g * (K + 1) + j];
+        len_out[g - 1] = j - i;
+        j = i;
+    }
+    return gbest;
+}
+
 // Start of the iteration from the unscaled A' = W^2 + 4 beta I and B' = A'^2 (both already formed as products).
 // cubic first step (mode 0/1):
 //   Y1 = a0 Y0 T0 = (1.5 a0/c) A' - (0.5 a0^3/c^2) B',   Z1 = a0 T0 = 1.5 a0 I - (0.5 a0^3/c) A'   (Y0 = A'/c)

@@ -506,6 +506,24 @@ class HipEngine:
         st["deflated_calls"], st["deflated_instances"] = int(d[0]), int(d[1])
         return st
 
+    def group_stats(self):
+        """GGL_OPT_GROUP_SCHED: {'steps': Omega-steps that ran as groups with their own schedules, 'groups': of the last step,
+        'len', 'units': of its groups, 'units_sum': per group slot over all grouped steps}."""
+        import ctypes
+        out = (ctypes.c_longlong * 10)()
+        us = np.zeros(4)
+        check(self.lib.ggl_group_stats(self.h, out, ptr(us)))
+        g = int(out[1])
+        return {'steps': int(out[0]), 'groups': g, 'len': [int(out[2 + i]) for i in range(g)] if g > 1 else [],
+                'units': [int(out[6 + i]) for i in range(g)] if g > 1 else [], 'units_sum': us.tolist()}
+
+    def spectral_bounds(self):
+        """(c, beta), K each: c_k >= lambda_max(W_k^2 + 4 beta_k I) of the last validated Omega-step, or None."""
+        cb, be = np.zeros(self.K), np.zeros(self.K)
+        if check(self.lib.ggl_spectral_bounds(self.h, ptr(cb), ptr(be))) == 0:
+            return None
+        return cb, be
+
     def lds_stats(self):
         """The LDS-resident Omega-step (p <= 64): launches, launches repeated on the launch chain, products and steps
         summed over all instances."""

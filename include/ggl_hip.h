@@ -21,7 +21,11 @@
 extern "C" {
 #endif
 
-#define GGL_VERSION 200
+/* ABI version: major * 100 + minor.  Bumped whenever an entry point changes its argument layout or an existing buffer its
+ * format -- 300 (round 6): ggl_pipeline_stats writes out[10] (was out[5]), GGL_BUF_GROUPSQ is the packed upper triangle with
+ * the flag at p (p + 1) / 2 (was (p,p) + 1), the int8 entry points live in the development library only, ggl_debug_poison
+ * takes a byte pattern.  A binding built against another major version must refuse to load (gglasso_amd/_lib.py does). */
+#define GGL_VERSION 300
 
 /* error codes */
 #define GGL_OK 0
@@ -170,6 +174,12 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_DOWNLOAD_THREADS 36 /* [8] ggl_get_state / ggl_get_snapshots of more than 32 MB: host threads that touch the pages of the caller's
                                       (typically freshly allocated) arrays before the copy -- the first touch, not the transfer, is what a
                                       download into new memory waits for; 1 = none */
+#define GGL_OPT_GROUP_SCHED 37     /* [1] a batch whose instances need different product counts for their matrix square root (a grid of
+                                      independent problems: the reference solves every point with its own eigh, helper/model_selection.py:
+                                      619-633) runs as up to 3 contiguous groups with their own Newton-Schulz schedules -- the concurrent
+                                      parts of the engine -- where the size rule would run it as one launch sequence on the worst
+                                      instance's schedule; taken when a deterministic time model gains >= 6 %.  0 off, 2 / 3 = at most
+                                      that many groups; 12 / 13 (tests) = at most 2 / 3 groups wherever the product counts differ */
 #define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
                                       2 = with the lowest stream priority (streams of another priority never share a hardware queue with
                                       the ctx's main stream) */
@@ -443,6 +453,9 @@ int ggl_finalize_L(ggl_ctx *ctx, int which, int *rank_out);
  * (0x7F: 1.4e306, 0x47: 1.5e35 -- finite garbage, which a max / min reduction or a comparison keeps where it drops a NaN).
  * tests/conftest.py switches it on for a whole session when GGL_DEBUG_POISON=<n> is set in the environment of the TEST process. */
 int ggl_debug_poison(int on);
+/* Process-wide switch: odd p on the direct-to-LDS product kernel (1, default since round 6) or on the register-staged kernel as
+ * in rounds 1-5 (0); returns the previous setting.  Same products either way (parity test of the two routes, A/B runs). */
+int ggl_set_odd_dl(int on);
 int ggl_failed_instances(ggl_ctx *ctx, int *out);
 /* Why instance k was marked (the first mark stays): out[0] = 1 a spectral or norm bound that was not finite or not positive,
  * 2 an eigensolver that did not converge, 3 a non-finite residual or trace in the L-step's sign iteration, 4 marked inside a
@@ -495,6 +508,13 @@ int ggl_ns_stats(ggl_ctx *ctx, long long out[16]);
 /* The LDS-resident Omega-step (GGL_OPT_OMEGA_LDS): out = { launches, launches repeated on the launch chain because an instance
  * fell outside the kernel's range, products summed over all instances of all launches, Newton-Schulz steps likewise }. */
 int ggl_lds_stats(ggl_ctx *ctx, long long out[4]);
+/* GGL_OPT_GROUP_SCHED: out = { Omega-steps that ran as groups with their own schedules, groups of the last step (1 = whole batch),
+ * lengths of its groups [4], product units (A', B' included) of their schedules [4] }; units_sum (4 doubles, may be NULL): the
+ * units of every group slot summed over the grouped steps. */
+int ggl_group_stats(ggl_ctx *ctx, long long out[10], double *units_sum);
+/* c_k >= lambda_max(W_k^2 + 4 beta_k I) and beta_k (K doubles each) of the last validated matrix-function Omega-step; returns 1,
+ * or 0 when there is none yet. */
+int ggl_spectral_bounds(ggl_ctx *ctx, double *c_out, double *beta_out);
 /* Pipelining across iterations (GGL_OPT_PIPELINE, ggl_admm_step): out = { whole Omega-step chains launched ahead of the caller's
  * next step (after an iteration was validated, while the caller looks at its residuals), of those forgotten because rho changed,
  * early first parts (tables, W, A', B' of the NEXT iteration's chain, put into the stream before the host waits for this
@@ -558,6 +578,11 @@ int ggl_dev_ns_schedule(double l, int degrees, int max_steps, int *deg_out, doub
 /* the same for the Omega-step at a stopping tolerance (GGL_OPT_NS_TOL; 0 = fp64 resolution, what the call above plans for) */
 int ggl_dev_ns_schedule_tol(double l, int degrees, double tol, int max_steps, int *deg_out, double *coef_out,
                             int *units_out);
+/* host only: the grouping rule of GGL_OPT_GROUP_SCHED -- units[k] = product count of instance k's schedule; returns the number of
+ * contiguous groups (1 = whole) and their lengths in len_out[3] -- and the product count (A', B' included) of the all-symmetric
+ * schedule for a spectrum in [l, 1] at the stopping tolerance tol (-1: condition number above 300, the stable schedule's range) */
+int ggl_dev_group_partition(const int *units, int K, int p, int max_groups, int *len_out);
+int ggl_dev_ns_units(double l, int degrees, double tol);
 #ifdef GGL_DEV
 /* C = A B on the INT8 matrix cores from S signed-digit slices per operand (error-free split; gemm_i8.hip), slice pairs
  * t + u <= dmax; |A| <= scaleA, |B| <= scaleB entrywise.  ms_out = {slicing both operands, one product launch, overflow flag}. */

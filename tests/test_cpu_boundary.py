@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(so, n), f"{n} declared in include/ggl_hip.h but not exported"
     assert sorted(lib.EXPORTS) == names, "ctypes signature table out of sync with the header"
-    assert lib.load().ggl_version() == 200
+    assert lib.load().ggl_version() == lib.ABI_VERSION == 300
     # the development-only entry points are declared under GGL_DEV and are NOT in the shipped library
     dev = _declared_symbols(dev=True)
     assert sorted(lib._DEV_SIGNATURES) == dev and dev
@@ -279,6 +279,55 @@ def test_newton_schulz_schedule_higher_degrees_never_cost_more(lib):
     # the headline workload's interval: two degree-nine steps, eight products
     deg, _, units = _ns_schedule(lib, 0.67, 9)
     assert deg == [9, 9] and units == 8
+
+
+def test_group_schedules_partition_rule(lib):
+    """GGL_OPT_GROUP_SCHED (host logic, no GPU): a batch of independent problems whose instances need different product counts
+    (the reference solves every grid point with its own eigh, helper/model_selection.py:619-633) is cut into contiguous groups
+    with their own schedules -- only where the deterministic time model sum_g U_g (F + len_g I(p)) gains at least 6 %."""
+    import ctypes
+    L = lib.load()
+    ip = ctypes.POINTER(ctypes.c_int)
+
+    def part(u, p, mg=3):
+        u = np.ascontiguousarray(u, dtype=np.int32)
+        out = np.zeros(3, dtype=np.int32)
+        g = L.ggl_dev_group_partition(u.ctypes.data_as(ip), len(u), int(p), int(mg), out.ctypes.data_as(ip))
+        assert g >= 1 and out[:g].sum() == len(u) and np.all(out[:g] >= 1)
+        return g, out[:g].tolist()
+
+    def model(u, lens, p):
+        I, F, t, k0 = 2.5e-14 * p ** 3, 6.5e-6, 0.0, 0
+        for n in lens:
+            t += max(u[k0:k0 + n]) * (F + n * I)
+            k0 += n
+        return t
+
+    c2 = [7] * 7 + [8] * 3 + [9] * 4 + [10] * 3 + [11] * 3                 # a lambda1 grid ordered by conditioning
+    g, lens = part(c2, 1000)
+    assert g == 3 and model(c2, lens, 1000) <= 0.94 * model(c2, [20], 1000)
+    # the optimum over all cuts into at most three runs (brute force)
+    best = min(model(c2, [i, j - i, 20 - j], 1000) for i in range(1, 19) for j in range(i + 1, 20))
+    assert abs(model(c2, lens, 1000) - best) <= 1e-12 * best
+    assert part(c2, 1000, 2)[0] == 2 and part(c2, 1000, 1) == (1, [20])
+    assert part(c2, 200) == (1, [20]) and part(c2, 500) == (1, [20])          # launches too small for a split to pay
+    assert part([7] * 32, 500) == (1, [32]) and part([8] * 20, 1000) == (1, [20])   # nothing to gain
+    assert part([7, 11], 1000) == (2, [1, 1])
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        K, p = int(rng.integers(2, 48)), int(rng.choice([300, 700, 1000, 1500]))
+        u = np.sort(rng.integers(6, 14, K)) if rng.random() < 0.7 else rng.integers(6, 14, K)
+        g, lens = part(u, p)
+        if g > 1:
+            assert model(list(u), lens, p) <= 0.94 * model(list(u), [K], p) * (1 + 1e-12)
+    # product counts of the schedules the groups are built from
+    assert L.ggl_dev_ns_units(0.72, 9, 2e-12) == 7 and L.ggl_dev_ns_units(0.3, 9, 2e-12) == 11
+    assert L.ggl_dev_ns_units(0.05, 9, 2e-12) == -1                            # condition number 400: the stable schedule's range
+    last = 0
+    for l in np.geomspace(0.99, 0.06, 60):
+        u = L.ggl_dev_ns_units(float(l), 9, 2e-12)
+        assert u >= last
+        last = u
 
 
 def test_batched_single_grid_search_matches_reference_tables(oracle_engine):

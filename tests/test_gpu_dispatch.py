@@ -146,16 +146,56 @@ def test_headline_dispatch_exact_omega_step(stats, monkeypatch):
 
 
 def test_c3_dispatch_ggl_K20_p200(stats):
+    """C3 at its real dispatch along one oracle solve: 12 iterations with the rho rule against the oracle at 1e-9, then the
+    CONVERGED solve (tol = rtol = 1e-9): the oracle's status and iteration count, |Theta - oracle|_F <= 1e-8 (VERDICT r5 item 5;
+    north_star: Theta within 1e-8 Frobenius)."""
     from gglasso_amd import solver
     S, Om0 = _problem("GGL", 20, 200, 1236)
-    kw = dict(max_iter=12, tol=1e-20, rtol=1e-20)
-    with oracle_threads():
-        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
-    out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
-    _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
+    (ref12,), ref, ref_status, ref_iters = _oracle_run(S, "GGL", 0.05, 0.01, Om0, [12], 1e-9)
+    out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, max_iter=12, tol=1e-20, rtol=1e-20)
+    _check_state(out, ref12, ("Omega", "Theta", "X"), 1e-9)
     st = stats[-1]
     assert st["last_parts"] == 1 and st["last_variant"] == 20, st
     assert st["spec_calls"] >= 1, st
+    out, info = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, tol=1e-9, rtol=1e-9, measure=True)
+    assert info["status"] == ref_status == "optimal"
+    assert len(info["residual"]) == ref_iters, (len(info["residual"]), ref_iters)
+    assert np.linalg.norm(out["Theta"] - ref["Theta"]) <= 1e-8
+    assert np.array_equal(out["Theta"], out["Theta"].transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("reg,K,p,latent,parts,variant", [("GGL", 32, 501, False, 2, 17), ("GGL", 20, 201, False, 1, 20),
+                                                          ("FGL", 5, 333, True, 1, 20), ("GGL", 3, 999, False, 1, 20)])
+def test_odd_p_runs_on_the_dma_product_kernel(stats, reg, K, p, latent, parts, variant):
+    """Odd p (the reference is indifferent to the parity of p, solver/admm_solver.py:180-187): the same
+    direct-to-LDS product kernel, split and speculation as the even neighbour -- rounds 1-5 sent every odd p to the
+    register-staged kernel (25-37 % slower per product).  Eight iterations with the rho rule against the oracle at 1e-9, exact
+    symmetry, and -- process-wide switch ggl_set_odd_dl(0) -- within 1e-10 of the register-staged route's iterates."""
+    from gglasso_amd import solver, _lib
+    S, Om0 = _problem(reg, K, p, 1300 + p)
+    mu1 = 0.5 * np.ones(K) if latent else None
+    kw = dict(max_iter=8, tol=1e-20, rtol=1e-20, latent=latent, mu1=mu1)
+    with oracle_threads():
+        ref, _ = quiet(orc.ADMM_MGL, S, 0.05, 0.01, reg, Om0, **kw)
+    names = ("Omega", "Theta", "X") + (("L",) if latent else ())
+    out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, reg, Om0, **kw)
+    _check_state(out, ref, names, 1e-9)
+    for nm in ("Omega", "Theta"):
+        assert np.array_equal(out[nm], out[nm].transpose(0, 2, 1)), nm
+    st = stats[-1]
+    assert st["last_parts"] == parts and st["last_variant"] == variant, st
+    assert st["stable_calls"] == 0 and st["eigh_fallbacks"] == 0, st
+    if not latent:
+        assert st["spec_calls"] >= 1, st
+    lib = _lib.load()
+    try:
+        lib.ggl_set_odd_dl(0)
+        old, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, reg, Om0, **kw)
+    finally:
+        lib.ggl_set_odd_dl(1)
+    assert stats[-1]["last_variant"] in (0, 9), stats[-1]
+    for nm in names:
+        assert np.abs(out[nm] - old[nm]).max() <= 1e-10 * max(1.0, np.abs(old[nm]).max()), nm
 
 
 def test_c4_dispatch_fgl_K50_p500_latent(stats):
@@ -214,20 +254,50 @@ def test_c2_dispatch_sgl_p1000_grid20():
             assert np.linalg.eigvalsh(sol["Omega"]).min() > 0, k
 
 
+def test_c2_converged_grid_with_group_schedules_and_compaction():
+    """C2 whole and CONVERGED: the 20-point lambda1 grid of the p = 1000 problem as one batch to
+    tol = rtol = 1e-8 -- the instances run as contiguous groups with their own Newton-Schulz schedules (GGL_OPT_GROUP_SCHED),
+    finished points leave through compaction, the loop runs in C -- against the oracle's ADMM_SGL from the same start
+    (Omega_0 = X_0 = I, helper/model_selection.py:595-596) on three points: the best-conditioned one (it finishes first and
+    leaves early), one from the middle and the worst-conditioned one: status, iteration count, |Theta - oracle|_F <= 1e-8."""
+    from gglasso_amd import synth
+    from gglasso_amd.batch import ADMM_SGL_batch
+    p = 1000
+    S, _ = synth.make_problem("GGL", 1, p, N=2 * p, seed=1235)
+    S = S[0]
+    lams = np.logspace(0, -2, 20)
+    eye = np.eye(p)
+    res = ADMM_SGL_batch(S, lams, Omega_0=eye, X_0=eye, tol=1e-8, rtol=1e-8)
+    its = [info["iterations"] for _, info in res]
+    assert all(info["status"] == "optimal" for _, info in res), [info["status"] for _, info in res]
+    assert max(r[1]["carried"] for r in res) > min(r[1]["carried"] for r in res)          # points did leave early
+    for k in (int(np.argmin(its)), 10, 19):
+        with oracle_threads():
+            ref, rinfo = quiet(orc.ADMM_SGL, S, lams[k], eye, X_0=eye, tol=1e-8, rtol=1e-8, measure=True)
+        sol, info = res[k]
+        assert rinfo["status"] == "optimal" and info["iterations"] == len(rinfo["residual"]), (k, info, len(rinfo["residual"]))
+        assert np.linalg.norm(sol["Theta"] - ref["Theta"]) <= 1e-8, (k, float(np.linalg.norm(sol["Theta"] - ref["Theta"])))
+        assert np.array_equal(sol["Theta"], sol["Theta"].T)
+
+
 def test_c5_slab_dispatch_ggl_K32_p1000(stats):
     """Per-GPU slab of C5 (K=256, p=1000 over 8 GPUs): 4352 tile pairs, unsplit launch sequence on the double-buffered
     64x64 DMA kernel; iteration 2 speculates.  Whole state against the oracle."""
     from gglasso_amd import solver
     S, Om0 = _problem("GGL", 32, 1000, 1238)
-    kw = dict(max_iter=2, tol=1e-20, rtol=1e-20, update_rho=False)
+    # (round 6: seven iterations WITH the rho rule -- the residual balancing acts in the first iterations from the identity
+    # start, so the run covers rho changes, dropped pre-launched chains and the speculative steps between them)
+    hist = []
+    kw = dict(max_iter=7, tol=1e-20, rtol=1e-20)
     with oracle_threads():
-        ref, _ = orc.ADMM_MGL(S, 0.05, 0.01, "GGL", Om0, **kw)
+        ref, _ = quiet(orc.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, history=hist, **kw)
+    assert len({h[4] for h in hist}) >= 2, [h[4] for h in hist]           # rho did change along the way
     out, _ = quiet(solver.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, **kw)
     _check_state(out, ref, ("Omega", "Theta", "X"), 1e-9)
     assert np.array_equal(out["Theta"], out["Theta"].transpose(0, 2, 1))
     st = stats[-1]
     assert st["last_parts"] == 1 and st["last_variant"] == 16, st
-    assert st["spec_calls"] >= 1, st          # iteration 2 (and the chain pre-launched behind it) ran speculatively
+    assert st["spec_calls"] >= 1, st          # the iterations between the rho changes ran speculatively
 
 
 def test_c5_whole_ggl_K256_p1000(stats):

@@ -193,8 +193,10 @@ def _commuting_pair(rng, K, p):
 # -1 = the size rule itself.  (16, 500) is one concurrent part of the headline batch: 576 tile pairs, > 1 round of tiles.
 @pytest.mark.parametrize("variant", [-1, 0, 9, 16, 17, 20])
 # K = 9, 11, 13, 20: whole rounds of eight instances over the XCDs plus a remainder of 1 / 3 / 5 / 4 dealt as a small batch
+# odd p (round 6: on the direct-to-LDS kernels too -- every other row starts on an 8-byte boundary, the last column is half a
+# pair): 63 / 65 / 127 / 129 around the tile edges, 333, 501, 1001
 @pytest.mark.parametrize("K,p", [(2, 40), (3, 129), (2, 200), (1, 333), (9, 70), (11, 96), (13, 130), (20, 200), (2, 500),
-                                 (16, 500), (3, 1000)])
+                                 (16, 500), (3, 1000), (5, 63), (4, 65), (3, 127), (2, 501), (9, 201), (2, 1001), (1, 3)])
 def test_symm_product_kernel(variant, K, p):
     """C = cI*I + cAcc*A*B + cE*E and C2 = dI*I + dC*C for commuting symmetric A, B (every tile shape)."""
     from gglasso_amd import _lib
@@ -365,7 +367,7 @@ def test_phiplus_newton_schulz_extreme_scaling_falls_back(ops):
 
 
 @pytest.mark.parametrize("variant", [16, 17, 20])
-@pytest.mark.parametrize("K,p", [(2, 40), (3, 130), (9, 70), (2, 500), (16, 500), (2, 1000)])
+@pytest.mark.parametrize("K,p", [(2, 40), (3, 130), (9, 70), (2, 500), (16, 500), (2, 1000), (3, 129), (4, 65), (2, 501), (9, 201)])
 def test_product_epilogue_bound_partials(variant, K, p):
     """The spectral bound of the Omega-step without a norm pass over B': the product kernel's epilogue leaves the row
     sums of |C| per tile column and the tiles' Frobenius shares (every tile shape, diagonal tiles from their upper

@@ -148,6 +148,64 @@ def test_rank_of_the_solvers_latent_component(p):
             assert solver.latent_rank(low_n[j, m]) == want[j, m]
 
 
+def test_latent_grid_rank_table_is_reproducible_under_ctx_churn():
+    """The p = 500 latent lambda x mu grid of the test above, 30 times, with ctxs of other shapes created, stepped and destroyed in
+    between so that pooled arenas and streams change hands (the arena sizes of the grid's own ctx and of its compacted subsets
+    among them; latent FGL steps; a batch of small problems; a p = 1000 slab) -- the second half of the repetitions with every
+    new ctx's buffers filled with 0x7F bytes (1.4e306: finite garbage, which a max reduction or a comparison keeps where it
+    drops a NaN) and then 0xFF bytes instead of zeros.  The reference's walk (helper/model_selection.py:619-660, rank at :638)
+    returns the same RANK table every time; round 5 saw `[[0,0,63],[0,0,108]]` for `[[160,78,6],[160,79,9]]` once in thirteen runs
+    of the suite.  Every repetition: no point ends as 'solver error' (a RuntimeWarning is an error here), the table is the
+    eigendecomposition route's, every L within 1e-7 of it."""
+    import warnings
+    from gglasso_amd import solver, synth, batch, _lib
+    p = 500
+    S, _ = synth.make_problem("GGL", 1, p, seed=3)
+    lam6, mu6 = np.repeat([0.1, 0.2], 3), np.tile([0.5, 1.0, 2.0], 2)
+    eye = np.eye(p)
+
+    def grid():
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)
+            res = batch.ADMM_SGL_batch(S[0], lam6, Omega_0=eye, X_0=eye, tol=1e-8, rtol=1e-8, latent=True, mu1=mu6,
+                                       selection_stats=True)
+        assert [info['status'] for _, info in res] == ['optimal'] * 6, [info for _, info in res]
+        return np.array([info['selection']['rank'] for _, info in res]).reshape(2, 3), np.stack([sol['L'] for sol, _ in res])
+
+    def churn(r):
+        kinds = [("GGL", 6, p), ("GGL", 4, p), ("FGL", 3, p), ("GGL", 2, p), ("GGL", 40, 48), ("GGL", 8, 1000)]
+        reg, K, q = kinds[r % len(kinds)]
+        Sb, _ = synth.make_problem(reg, K, q, seed=5 + r)
+        I = np.stack([np.eye(q)] * K)
+        eng = solver.HipEngine(Sb, I, I, np.zeros_like(Sb))
+        try:
+            lat = (r % 4 == 2)
+            for _ in range(3):
+                eng.step(1.0, 0.05, 0.01, reg, lat, np.full(K, 0.3) if lat else None, np.ones(K))
+        finally:
+            eng.close()
+
+    saved = dict(solver.ENGINE_OPTIONS)
+    lib = _lib.load()
+    try:
+        solver.ENGINE_OPTIONS["rank_eig"] = 1.0
+        want, low_e = grid()
+        solver.ENGINE_OPTIONS.clear()
+        solver.ENGINE_OPTIONS.update(saved)
+        assert np.array_equal(want, [[np.linalg.matrix_rank(low_e[3 * j + m], hermitian=True) for m in range(3)] for j in range(2)])
+        assert want.max() > 100 and want.min() > 0, want
+        for r in range(30):
+            lib.ggl_debug_poison(0 if r < 15 else (127 if r < 23 else 1))
+            churn(r)
+            ranks, L = grid()
+            assert np.array_equal(ranks, want), (r, ranks.tolist(), want.tolist())
+            assert np.abs(L - low_e).max() <= 1e-7, (r, float(np.abs(L - low_e).max()))
+    finally:
+        lib.ggl_debug_poison(0)
+        solver.ENGINE_OPTIONS.clear()
+        solver.ENGINE_OPTIONS.update(saved)
+
+
 def test_single_grid_search_thresholding_tables_from_the_device():
     """single_grid_search(thresholding=True) at p = 200: TAU, the thresholded estimates and the AIC / eBIC tables built from
     ``ggl_threshold_scan`` against tune_threshold (helper/model_selection.py:707-737) run on the host over the returned,
