@@ -1302,6 +1302,7 @@ __global__ __launch_bounds__(256) void k_symm_sk(const double* __restrict__ A, c
 
 #endif   // GGL_DEV (k_symm_sk)
 
+#ifdef GGL_DEV      // (round 6: the persistent chain is an option of the development library only -- measured slower)
 // ---------------------------------------------------------------------------------------------
 // k_omega_chain: the WHOLE product chain of an Omega-step (A', B', the Newton-Schulz products, Omega) of a batch in ONE
 // persistent launch, with the dependencies kept where they are: per INSTANCE.  Product s+1 of instance k needs product s of
@@ -1442,16 +1443,13 @@ int launch_omega_chain(hipStream_t st, const ChainProg& P, unsigned* state, int*
         slots = std::min(per_cu, 3) * prop.multiProcessorCount;
         slots -= slots % NXCD;
     }
-#ifdef GGL_DEV
     if (aux == 0) hipLaunchKernelGGL((k_omega_chain<16, 3, 64, 0>), dim3(slots), dim3(256), 0, st, P, state);   // measurement only
     else
-#endif
     hipLaunchKernelGGL((k_omega_chain<16, 3, 64, 16>), dim3(slots), dim3(256), 0, st, P, state);
     hipLaunchKernelGGL(k_chain_check, dim3(1), dim3(64), 0, st, state, P.K, (unsigned)P.begin[P.nops], flag, flag_h);
     return slots;
 }
 
-#ifdef GGL_DEV
 // ---- persistent-chain probe: nprod DEPENDENT products X <- X * X of a K-batch inside ONE cooperative
 // launch, a grid-wide barrier between products, against the same chain as nprod launches.  What it prices is exactly the
 // trade a persistent Omega-chain kernel would make: a kernel boundary (drain, launch, L2 write-back/invalidate by the

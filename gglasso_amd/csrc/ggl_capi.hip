@@ -104,7 +104,15 @@ struct ggl_ctx {
     int symm_variant = -1;
     double *nsYP[2] = {nullptr, nullptr}, *nsT = nullptr;   // [Y|Z] scratch pairs (2 stacks each), T
     // the Omega-step's product chain as ONE persistent launch with per-instance dependencies (k_omega_chain, gemm_sym.hip)
-    int chain_mode = 0;                        // GGL_OPT_CHAIN: 0 never (default: measured slower), 1 where chain_tile() says so, 2 wherever it can run
+    // Measured-and-rejected alternatives (each built, bit-identical or parity-tested, and slower or
+    // within noise) are options of the DEVELOPMENT library only (round 6): in the product build the switches are constants,
+    // the compiler drops their branches, and ggl_ctx_set_option refuses them.  GGL_DEV_OPT(type, name): a field there, 0 here.
+#ifdef GGL_DEV
+#define GGL_DEV_OPT(type, name) type name = 0
+#else
+#define GGL_DEV_OPT(type, name) static constexpr type name = 0
+#endif
+    GGL_DEV_OPT(int, chain_mode);              // GGL_OPT_CHAIN: 0 never, 1 where chain_tile() says so, 2 wherever it can run
     double* nsNX = nullptr;                    // third [Y|Z] pair: the chain leaves A', B' intact for the bound kernels (lazy)
     unsigned* chain_cnt = nullptr;             // per-instance completion / ticket words, one 128-byte line each (lazy)
     long long chain_calls = 0;
@@ -117,7 +125,7 @@ struct ggl_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS - 1] = {};   // Newton-Schulz launch sequences concurrently
     // GGL_OPT_BOUND_SIDE: the bound kernels that validate a speculative step's assumed bound run on a side stream beside the
     // chain's first products (per part: fork after B', join before the first launch that overwrites B')
-    int bound_side = 0;                        // 0 off, 1 on, 2 by regime (two concurrent parts of a large batch)
+    GGL_DEV_OPT(int, bound_side);              // 0 off, 1 on, 2 by regime (two concurrent parts of a large batch)
     // GGL_OPT_JOIN_FLAG: the parts of a speculative chain are joined through flag words in device memory (k_set_flag /
     // k_wait_flags) instead of a cross-queue event wait
     bool join_flag = true;
@@ -142,8 +150,8 @@ struct ggl_ctx {
     double* pre_beta = nullptr;                // host: beta the pre-launched chain was built for (K)
     long long pre_launched = 0, pre_dropped = 0;
     int download_threads = 8;                  // GGL_OPT_DOWNLOAD_THREADS: host threads that touch a download's destination pages first
-    int parts_order = 0;                       // GGL_OPT_PARTS_ORDER
-    int parts_bias = 0;                        // GGL_OPT_PARTS_BIAS: two concurrent parts take K/2 + bias and K/2 - bias instances
+    GGL_DEV_OPT(int, parts_order);             // GGL_OPT_PARTS_ORDER
+    GGL_DEV_OPT(int, parts_bias);              // GGL_OPT_PARTS_BIAS: two concurrent parts take K/2 + bias and K/2 - bias instances
     // GGL_OPT_GROUP_SCHED: a batch whose instances need different product counts (a grid of independent problems) runs as up
     // to three contiguous groups with their own schedules (ns_group_partition, newton_schulz.hip) where the size rule would
     // run it as one launch sequence
@@ -164,7 +172,7 @@ struct ggl_ctx {
     long long lds_calls = 0, lds_misses = 0;
     int lds_cool = 0, lds_cool_next = 4;       // launches to sit out after an instance fell outside the kernel's range (doubles per miss)
     bool lds_last = false;                     // the Omega-step launched last was the LDS kernel
-    bool fused_cw = false;                     // k_bound_rows + k_cw_final as ONE launch (GGL_OPT_FUSED_CW): measured, no gain
+    GGL_DEV_OPT(bool, fused_cw);               // k_bound_rows + k_cw_final as ONE launch (GGL_OPT_FUSED_CW): measured, no gain
                                                // (K=4: 4654 / 4892 vs 4602 / 4774 it/s; headline -6 %): opt-in, DESIGN 9.7
     int theta_flat = 2;                        // GGL Theta-step for symmetric states: 0 tile pairs, 1 per-element kernel, 2 per-element with the K-column over four waves
     bool state_symmetric = true;               // X and L exactly symmetric (checked when the state is set)
@@ -198,7 +206,7 @@ struct ggl_ctx {
         int nh = 0, Kh[4] = {}, k0h[4] = {};          // the split the part was launched with (the rest must use the same)
     } early;
     bool early_part = true;                           // GGL_OPT_EARLY_PART
-    int part_priority = 0;                            // GGL_OPT_PART_PRIORITY
+    GGL_DEV_OPT(int, part_priority);                  // GGL_OPT_PART_PRIORITY
     bool parts_probed = false;                        // streamx[0] has been checked to run concurrently with the main stream
     int parts_replaced = 0;                           // candidates tried by that check (0: the stream was fine)
     bool early_caller = false;                        // set by ggl_admm_step around its Theta-step: the early part may be launched
@@ -270,7 +278,8 @@ struct ggl_ctx {
     // |C C| for a vector carried across ADMM iterations (lazy buffers, one pair)
     double* cwvecL[2] = {nullptr, nullptr};
     int cwL_cur = 0;
-    bool cwL_have = false, rank_cw = false;      // (measured at C4: no gain, see include/ggl_hip.h -- off)
+    bool cwL_have = false;
+    GGL_DEV_OPT(bool, rank_cw);                  // GGL_OPT_RANK_CW (measured at C4: no gain, see include/ggl_hip.h)
     // bound partials written by the epilogue of the B' product launch (no norm pass over B'): row sums per tile column,
     // Frobenius shares per tile, block maxima of the row sums; merge cells of the Collatz-Wielandt kernel
     double *rowpart = nullptr, *fropart = nullptr, *infpart = nullptr;
@@ -707,23 +716,32 @@ static int set_option(ggl_ctx* c, int opt, double v)
                 return fail(GGL_E_ARG, "bad argument: GGL_OPT_GROUP_SCHED is 0, 1, 2, 3, 12 or 13");
             c->group_sched = (int)v;
             break;
+#ifdef GGL_DEV
         case GGL_OPT_PARTS_BIAS: c->parts_bias = (int)v; break;
         case GGL_OPT_PARTS_ORDER: c->parts_order = (int)v; break;
+        case GGL_OPT_CHAIN: c->chain_mode = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
+        case GGL_OPT_FUSED_CW: c->fused_cw = v != 0.0; break;
+        case GGL_OPT_RANK_CW: c->rank_cw = v != 0.0; break;
+        case GGL_OPT_BOUND_SIDE: c->bound_side = (int)v; break;
+#else
+        case GGL_OPT_PARTS_BIAS: case GGL_OPT_PARTS_ORDER: case GGL_OPT_CHAIN: case GGL_OPT_FUSED_CW: case GGL_OPT_RANK_CW:
+        case GGL_OPT_BOUND_SIDE: case GGL_OPT_PART_PRIORITY:
+            if (v == 0.0) break;                 // (the default, which is what the product library runs)
+            return fail(GGL_E_ARG, "bad argument: option %d is a measured-and-rejected alternative that only the development "
+                        "library (libggl_hip_dev.so, python -m gglasso_amd.build --dev) carries", opt);
+#endif
         case GGL_OPT_DOWNLOAD_THREADS: c->download_threads = std::min(std::max((int)v, 1), 64); break;
         case GGL_OPT_CW_WARM: c->cw_warm = v != 0.0; break;
-        case GGL_OPT_CHAIN: c->chain_mode = (v == 2.0) ? 2 : (v != 0.0 ? 1 : 0); break;
         case GGL_OPT_ISOLATE: c->isolate = v != 0.0; break;
-        case GGL_OPT_FUSED_CW: c->fused_cw = v != 0.0; break;
         case GGL_OPT_OMEGA_LDS: c->lds_omega = v != 0.0; c->lds_waves = (v == 4.0 || v == 8.0) ? (int)v : 0; break;
         case GGL_OPT_EARLY_PART: c->early_part = v != 0.0; break;
         case GGL_OPT_FUSED_W: c->fused_w = v != 0.0; break;
-        case GGL_OPT_RANK_CW: c->rank_cw = v != 0.0; break;
-        case GGL_OPT_BOUND_SIDE: c->bound_side = (int)v; break;
         case GGL_OPT_LDS_PINNED: c->lds_pinned = v != 0.0; break;
         case GGL_OPT_JOIN_FLAG: c->join_flag = v != 0.0; break;
         case GGL_OPT_CW_RIDER: c->cw_rider = (int)v; break;
         case GGL_OPT_COPY_RIDER: c->copy_rider = (int)v; break;
         case GGL_OPT_REDUCE_RIDER: c->red_rider = (int)v; break;
+#ifdef GGL_DEV
         case GGL_OPT_PART_PRIORITY: {
             if (v != 0.0 && v != 1.0 && v != 2.0) return fail(GGL_E_ARG, "bad argument: GGL_OPT_PART_PRIORITY is 0, 1 or 2");
             if (!c->omega_ns || (int)v == c->part_priority) break;
@@ -742,6 +760,7 @@ static int set_option(ggl_ctx* c, int opt, double v)
             c->parts_probed = false;
             break;
         }
+#endif
         case GGL_OPT_RANK_DEFLATE: c->rank_deflate = v != 0.0; break;
         case GGL_OPT_RANK_L0_DEFLATE:
             if (!(v > 0.0) || v > 0.1) return fail(GGL_E_ARG, "bad argument: GGL_OPT_RANK_L0_DEFLATE is in (0, 0.1]");
@@ -1705,6 +1724,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 for (int h = 0; h < ggl_ctx::MAX_PARTS; ++h) c->spec_flag_h[h] = 0;
             }
         }
+#ifdef GGL_DEV
         // ---- the whole product chain as ONE persistent launch with per-instance dependencies (k_omega_chain) ----------
         if (spec && !want_A && !resume && c->chain_mode && c->fused_start && c->fused_bounds && (c->symm_variant < 0 || c->symm_variant == 17) &&
             chain_tile(K, c->p, c->chain_mode == 2) == 64) {
@@ -1776,6 +1796,7 @@ static int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec
                 return GGL_OK;
             }
         }
+#endif   // GGL_DEV (GGL_OPT_CHAIN)
         if (resume) {
             for (int h = 0; h < nh; ++h) { plans[h] = c->early.plans[h]; fused[h] = c->early.fused[h]; }
             c->early_used += 1;
@@ -3387,10 +3408,10 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->ns_degrees = src->ns_degrees; c->theta_flat = src->theta_flat; c->rank_eig = src->rank_eig;
     c->rank_ns = c->omega_ns && !c->rank_eig; c->ns_parts = src->ns_parts; c->parts_max_tiles = src->parts_max_tiles;
     c->symm_variant = src->symm_variant; c->spin_wait = src->spin_wait; c->fused_bounds = src->fused_bounds;
-    c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->parts_bias = src->parts_bias; c->parts_order = src->parts_order; c->download_threads = src->download_threads; c->ns_tol = src->ns_tol;
-    c->cw_warm = src->cw_warm; c->chain_mode = src->chain_mode; c->rank_l0 = src->rank_l0; c->rank_l0_coarse = src->rank_l0_coarse;
+    c->pipeline = src->pipeline; c->fused_start = src->fused_start; c->parts_small = src->parts_small; c->download_threads = src->download_threads; c->ns_tol = src->ns_tol;
+    c->cw_warm = src->cw_warm; c->rank_l0 = src->rank_l0; c->rank_l0_coarse = src->rank_l0_coarse;
     c->group_sched = src->group_sched;
-    c->isolate = src->isolate; c->fused_cw = src->fused_cw; c->lds_omega = src->lds_omega; c->lds_waves = src->lds_waves; c->early_part = src->early_part; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
+    c->isolate = src->isolate; c->lds_omega = src->lds_omega; c->lds_waves = src->lds_waves; c->early_part = src->early_part; c->rank_deflate = src->rank_deflate; c->rank_l0_deflate = src->rank_l0_deflate;
     int* didx = nullptr;
     hipError_t e = hipMalloc(&didx, m * sizeof(int));
     if (e == hipSuccess) e = hipMemcpyAsync(didx, idx, m * sizeof(int), hipMemcpyHostToDevice, src->stream);
@@ -3403,8 +3424,10 @@ extern "C" int ggl_ctx_create_subset(ggl_ctx* src, const int* idx, int m, ggl_ct
     c->state_symmetric = src->state_symmetric;
     c->S_symmetric = src->S_symmetric;
     c->fused_w = src->fused_w;
-    c->rank_cw = src->rank_cw;
-    c->bound_side = src->bound_side;
+#ifdef GGL_DEV
+    c->parts_bias = src->parts_bias; c->parts_order = src->parts_order; c->chain_mode = src->chain_mode; c->fused_cw = src->fused_cw;
+    c->rank_cw = src->rank_cw; c->bound_side = src->bound_side;
+#endif
     c->lds_pinned = src->lds_pinned;
     c->join_flag = src->join_flag;
     c->cw_rider = src->cw_rider;

@@ -746,6 +746,7 @@ void ns_run(hipStream_t st, const NsPlan& plan, const double* coef_d, const doub
     }
 }
 
+#ifdef GGL_DEV
 // The launches of ns_prepare + ns_run (all-symmetric schedule, first step's start fused into the B' launch) as a list of
 // product descriptors for k_omega_chain (gemm_sym.hip) -- same operands, same coefficient slots, same order, hence the same
 // bits.  One difference in WHERE things live: the iteration ping-pongs between YP and the extra pair NX instead of YP and
@@ -800,6 +801,7 @@ int ns_chain_ops(const NsPlan& plan, const double* pre0_d, const double* pre1_d,
     }
     return ok ? no : 0;
 }
+#endif   // GGL_DEV (ns_chain_ops)
 
 // ---------------------------------------------------------------------------------------------
 // L-step without an eigendecomposition:  L = (C - mu I)_+ = (C - mu I)(I + sign(C - mu I))/2

@@ -1103,10 +1103,15 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4v(double* __restrict
     const int kb = wid * KQ;
     double acc[GGL_NNORM] = {0, 0, 0, 0, 0};
     const size_t e = ((size_t)blockIdx.x * 64 + lane) * 2;
-    const bool live = e < pp;                  // pp even: e + 1 < pp as well
+    // p even: e + 1 < pp as well, in the same row, and every pair is 16-byte aligned.  Odd p (round 6; rounds 2-5 ran the
+    // one-element kernel there, 0.54-0.70x the access rate): the pairs of every other instance start on an 8-byte boundary
+    // (the hardware takes that), a pair may straddle two rows, and the last element of a matrix has no partner -- that one
+    // lane moves single elements and its second half counts as zero everywhere.
+    const bool live = e < pp, live1 = e + 1 < pp;
     double2 om[KQ], x[KQ], u[KQ];
     double2 ss = {0.0, 0.0};
-    auto ld2 = [](const double* q) { return *reinterpret_cast<const double2*>(q); };
+    auto ld2 = [live1](const double* q) { return live1 ? *reinterpret_cast<const double2*>(q) : double2{*q, 0.0}; };
+    auto st2 = [live1](double* q, const double2 v) { if (live1) *reinterpret_cast<double2*>(q) = v; else *q = v.x; };
     if (live) {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
@@ -1134,8 +1139,9 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4v(double* __restrict
         double2 tot;
         if (gsq) {
             const int gi = (int)(e / p), gj = (int)(e - (size_t)gi * p);
+            const int gj1 = (gj + 1 == p) ? 0 : gj + 1, gi1 = (gj + 1 == p) ? gi + 1 : gi;
             tot.x = gsq[tri_index(gi, gj, p)];
-            tot.y = gsq[tri_index(gi, gj + 1, p)];
+            tot.y = live1 ? gsq[tri_index(gi1, gj1, p)] : 0.0;
         } else {
             double sx[NW], sy[NW];
 #pragma unroll
@@ -1147,7 +1153,8 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4v(double* __restrict
         const double m0 = a0 - l2, m1 = a1 - l2;
         const int i0 = (int)(e / p), j0 = (int)(e - (size_t)i0 * p);
         const bool off0 = (i0 != j0);
-        const bool off1 = (i0 != j0 + 1);          // p even and e even: e + 1 is the next column of the same row
+        // (p even and e even: e + 1 is the next column of the same row; odd p: possibly the first column of the next one)
+        const bool off1 = (j0 + 1 == p) || (i0 != j0 + 1);       // (element (i0 + 1, 0) is never on the diagonal)
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             if (kb + q < K) {
@@ -1155,19 +1162,19 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4v(double* __restrict
                 double2 th;
                 th.x = off0 ? soft(u[q].x, l1) * m0 / a0 : u[q].x;
                 th.y = off1 ? soft(u[q].y, l1) * m1 / a1 : u[q].y;
-                *reinterpret_cast<double2*>(Theta + o) = th;
+                st2(Theta + o, th);
                 if (FUSE_DUAL) {
                     double2 xn;
                     xn.x = x[q].x + (om[q].x - th.x);
                     xn.y = x[q].y + (om[q].y - th.y);
-                    *reinterpret_cast<double2*>(X + o) = xn;
+                    st2(X + o, xn);
                     if (wn.S) {
                         const double2 sv = ld2(wn.S + o);
                         const double bk = wn.beta[kb + q];
                         double2 wv;
                         wv.x = (th.x - xn.x) - bk * sv.x;
                         wv.y = (th.y - xn.y) - bk * sv.y;
-                        *reinterpret_cast<double2*>(C + o) = wv;
+                        st2(C + o, wv);
                     }
                     const double2 op = ld2(OmegaPrev + o);
                     const double d0 = om[q].x - op.x, d1 = om[q].y - op.y;
@@ -1180,7 +1187,7 @@ __global__ __launch_bounds__(NW * 64) void k_theta_ggl_flat4v(double* __restrict
                     double2 cv;
                     cv.x = (th.x - x[q].x) - om[q].x;
                     cv.y = (th.y - x[q].y) - om[q].y;
-                    *reinterpret_cast<double2*>(C + o) = cv;
+                    st2(C + o, cv);
                 }
             }
         }
@@ -1329,7 +1336,7 @@ static void launch_flat4(hipStream_t st, double* Theta, double* X, double* C, co
 {
     dim3 grid(flat4_blocks(p), G), blk(NW * 64);
     if constexpr (VEC_OK) {
-        if ((p & 1) == 0) {          // p^2 even: two consecutive elements per lane, 16-byte accesses
+        {                            // two consecutive elements per lane, 16-byte accesses (any p since round 6)
             if (fuse_dual)
                 hipLaunchKernelGGL((k_theta_ggl_flat4v<KQ, true, NW>), grid, blk, 0, st, Theta, X, C, Omega, OmegaPrev, L, l1, l2, partials, K, p, skip, l1G, l2G, gsq, wn);
             else

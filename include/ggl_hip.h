@@ -94,6 +94,9 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
  * tools/ -- additionally maps the environment variables GGL_SPECULATE, GGL_SPEC_FACTOR, GGL_NS_MODE, GGL_NS_DEGREES,
  * GGL_THETA_FLAT, GGL_RANK_EIG, GGL_TWO_STREAM, GGL_PARTS_MAX_TILES, GGL_SYMM_VARIANT, GGL_SPIN_WAIT,
  * GGL_FUSED_BOUNDS, GGL_PIPELINE, GGL_FUSED_START, GGL_PARTS_SMALL onto them.) */
+/* Options marked DEV are the measured-and-rejected alternatives of rounds 2-5 (each built, bit-identical or parity-tested, and
+ * slower or within noise: DESIGN.md 8.1, 9.7, 9.10, 10.7).  Since round 6 they exist in the development library only
+ * (libggl_hip_dev.so); the product library accepts the value 0 for them and refuses anything else with GGL_E_ARG. */
 #define GGL_OPT_SPECULATE 1        /* [1] speculative Omega-step (schedule from the previous iteration's bounds)     */
 #define GGL_OPT_SPEC_FACTOR 2      /* [1.02] inflation of the previous bounds; < 1 forces validation misses (tests)  */
 #define GGL_OPT_NS_MODE 3          /* [0] as GGL_EIG_NS_MODE                                                          */
@@ -118,7 +121,7 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_CW_WARM 16         /* [1] the Collatz-Wielandt weight vector of the spectral bound is carried from one iteration to
                                     * the next (a power iteration at no extra pass; the bound stays rigorous and tightens
                                     * towards the Perron root of |B'|); 0: the row sums of |B'| every time                  */
-#define GGL_OPT_CHAIN 17           /* [0] 1: speculative Omega-steps of batches that cover the XCDs (K >= 8, even p, >= 1100 64x64 tile
+#define GGL_OPT_CHAIN 17           /* DEV [0] 1: speculative Omega-steps of batches that cover the XCDs (K >= 8, even p, >= 1100 64x64 tile
                                     * pairs) run their whole product chain as ONE persistent launch with per-instance
                                     * dependencies (k_omega_chain, csrc/gemm_sym.hip) instead of one launch per product in
                                     * concurrent parts; 2: wherever it can run (any K >= 8, even p).  Same products, same bits
@@ -127,7 +130,7 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_RANK_DEFLATE 20    /* [1] L-step (sign iteration): after a first pass at GGL_OPT_RANK_L0_DEFLATE the eigenvalues next to the
                                       threshold are deflated (range of I - X^2, exact small problem) instead of iterated down */
 #define GGL_OPT_RANK_L0_DEFLATE 21 /* [2e-3] resolution of that first pass */
-#define GGL_OPT_FUSED_CW 22        /* [0] the bound validation of a speculative Omega-step (row sums + Collatz-Wielandt pass) as ONE launch:
+#define GGL_OPT_FUSED_CW 22        /* DEV [0] the bound validation of a speculative Omega-step (row sums + Collatz-Wielandt pass) as ONE launch:
                                       built in round 4 for the small slabs, measured equal there and slower at the headline */
 #define GGL_OPT_OMEGA_LDS 23       /* [1] p <= 64: the whole Omega-step as ONE launch, one workgroup per instance, the Newton-Schulz chain
                                       resident in LDS, bound and per-instance schedule chosen on the device (omega_lds.hip); an instance
@@ -140,13 +143,13 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_FUSED_W 26         /* [1] with GGL_OPT_EARLY_PART, GGL, exactly symmetric state and S: the Theta kernel that precedes an early
                                       first part also writes that part's W = Theta - X - beta S (admm_solver.py:180) from the values it
                                       holds -- one pass over three stacks and one launch per part less (round 5) */
-#define GGL_OPT_RANK_CW 27         /* [0] L-step (sign iteration): the norm bound |C|_2 from a Collatz-Wielandt pass over C C with a vector
+#define GGL_OPT_RANK_CW 27         /* DEV [0] L-step (sign iteration): the norm bound |C|_2 from a Collatz-Wielandt pass over C C with a vector
                                       carried across ADMM iterations (as the Omega-step's bound) instead of sqrt(min(|C C|_inf, |C C|_F)).
                                       Built and measured in round 5 (FGL K=50, p=500, latent): the schedule is a step function of the
                                       resolution -- 22.0 products with either bound at GGL_OPT_RANK_L0_DEFLATE = 2e-3, 21.4 / 20.8 at
                                       4e-3 where 3-4x as many instances need the continuation -- and the pass costs 25 us: 211 it/s
                                       without, 202 with.  Off. */
-#define GGL_OPT_BOUND_SIDE 28      /* [0] speculative Omega-step: the two kernels that validate the assumed bound run on a side stream beside the
+#define GGL_OPT_BOUND_SIDE 28      /* DEV [0] speculative Omega-step: the two kernels that validate the assumed bound run on a side stream beside the
                                       chain's first products, joined before B' is overwritten (round 5).  0 off, 1 on, 2 only for two
                                       concurrent parts of a large batch.  Bitwise the in-chain order; measured: the small launch-bound
                                       sequences lose 2-5 % to the cross-stream waits, the headline gains 0.8 % over nine A/B pairs
@@ -168,9 +171,9 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
 #define GGL_OPT_REDUCE_RIDER 33    /* [2] the norm reduction behind a Theta-step rides in the A' launch of the next chain's early first part (one extra
                                       workgroup; same sums in the same order) when that launch follows it in the stream anyway: one dependent
                                       launch less per iteration.  1 = single launch sequences, 2 = always, 0 = never */
-#define GGL_OPT_PARTS_BIAS 34      /* [0] two concurrent parts of an Omega-step take K/2 + bias and K/2 - bias instances (the second part starts and
+#define GGL_OPT_PARTS_BIAS 34      /* DEV [0] two concurrent parts of an Omega-step take K/2 + bias and K/2 - bias instances (the second part starts and
                                       ends ~40 us after the first) */
-#define GGL_OPT_PARTS_ORDER 35     /* [0] two concurrent parts: 1 = the part on the ctx's main stream is queued after the other one */
+#define GGL_OPT_PARTS_ORDER 35     /* DEV [0] two concurrent parts: 1 = the part on the ctx's main stream is queued after the other one */
 #define GGL_OPT_DOWNLOAD_THREADS 36 /* [8] ggl_get_state / ggl_get_snapshots of more than 32 MB: host threads that touch the pages of the caller's
                                       (typically freshly allocated) arrays before the copy -- the first touch, not the transfer, is what a
                                       download into new memory waits for; 1 = none */
@@ -180,7 +183,7 @@ void *ggl_device_ptr(ggl_ctx *ctx, int which);
                                       parts of the engine -- where the size rule would run it as one launch sequence on the worst
                                       instance's schedule; taken when a deterministic time model gains >= 6 %.  0 off, 2 / 3 = at most
                                       that many groups; 12 / 13 (tests) = at most 2 / 3 groups wherever the product counts differ */
-#define GGL_OPT_PART_PRIORITY 25   /* [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
+#define GGL_OPT_PART_PRIORITY 25   /* DEV [0] streams of the concurrent parts of an Omega-step: 0 = created like any stream, 1 = with the highest,
                                       2 = with the lowest stream priority (streams of another priority never share a hardware queue with
                                       the ctx's main stream) */
 #define GGL_OPT_ISOLATE 19         /* [0] batches of independent problems: an instance whose data turn non-finite or whose eigensolver

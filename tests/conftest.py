@@ -29,6 +29,19 @@ def pytest_configure(config):
             solver.ENGINE_OPTIONS[name.strip()] = float(value)
 
 
+@pytest.fixture()
+def dev_library(monkeypatch):
+    """Tests of the measured-and-rejected alternatives (GGL_OPT_CHAIN, GGL_OPT_BOUND_SIDE, ...: options of the development
+    library only since round 6): every engine of the test is created in libggl_hip_dev.so (python -m gglasso_amd.build --dev),
+    which carries everything the product library does.  Skipped when that library has not been built."""
+    from gglasso_amd import _lib
+    if not os.path.exists(_lib.DEV_LIB_PATH):
+        pytest.skip("libggl_hip_dev.so is not built (python -m gglasso_amd.build --dev)")
+    dev = _lib.load_dev()
+    monkeypatch.setattr(_lib, "_lib", dev)
+    return dev
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

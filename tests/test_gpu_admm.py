@@ -728,7 +728,7 @@ def test_shared_start_arrays_are_replicated_on_the_device():
 
 
 @pytest.mark.parametrize("K,p", [(4, 300), (8, 400), (20, 200)])
-def test_bound_validation_on_a_side_stream_is_bitwise(sol, K, p):
+def test_bound_validation_on_a_side_stream_is_bitwise(sol, dev_library, K, p):
     """GGL_OPT_BOUND_SIDE: the kernels that validate a speculative Omega-step's assumed bound run on a side stream beside the
     chain's first products and are joined before B' is overwritten -- the same kernels on the same data, so the iterates
     are bitwise those of the in-chain order (one part, two concurrent parts at K = 8, a three-step schedule at (20,200));

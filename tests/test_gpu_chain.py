@@ -14,7 +14,7 @@ import pytest
 
 from oracle import ggl_oracle as orc
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("dev_library")]      # GGL_OPT_CHAIN: development library only
 
 
 def quiet(fn, *a, **k):

@@ -285,10 +285,10 @@ def test_c5_slab_dispatch_ggl_K32_p1000(stats):
     64x64 DMA kernel; iteration 2 speculates.  Whole state against the oracle."""
     from gglasso_amd import solver
     S, Om0 = _problem("GGL", 32, 1000, 1238)
-    # (round 6: seven iterations WITH the rho rule -- the residual balancing acts in the first iterations from the identity
-    # start, so the run covers rho changes, dropped pre-launched chains and the speculative steps between them)
+    # (round 6: seven iterations WITH the rho rule from rho_0 = 4 -- the residual balancing halves rho twice on the way
+    # (4, 4, 2, 2, 2, 1, 1), so the run covers rho changes, dropped pre-launched chains and the speculative steps between them)
     hist = []
-    kw = dict(max_iter=7, tol=1e-20, rtol=1e-20)
+    kw = dict(max_iter=7, tol=1e-20, rtol=1e-20, rho=4.0)
     with oracle_threads():
         ref, _ = quiet(orc.ADMM_MGL, S, 0.05, 0.01, "GGL", Om0, history=hist, **kw)
     assert len({h[4] for h in hist}) >= 2, [h[4] for h in hist]           # rho did change along the way
