@@ -157,6 +157,7 @@ struct ggl_ctx {
     // run it as one launch sequence
     int group_sched = 1;
     long long group_steps = 0;                 // Omega-steps that ran as such groups
+    long long group_changes = 0;               // ... whose split differed from the previous grouped step's
     int last_groups = 1, last_group_len[MAX_PARTS] = {}, last_group_units[MAX_PARTS] = {};
     double group_units_sum[MAX_PARTS] = {};    // per group slot: product units summed over the grouped steps
     int parts_small = 8;                       // smallest K (< 16, p >= 384) that is split into two concurrent parts; 0 = never
@@ -1519,8 +1520,12 @@ static int omega_groups(const ggl_ctx* c, const double* cb, const double* beta_h
 
 static void note_groups(ggl_ctx* c, int G, const int* Kh, const NsPlan* plans)
 {
+    const int G_prev = c->last_groups;
     c->last_groups = G;
     if (G <= 1) return;
+    bool same = (G_prev == G);
+    for (int g = 0; same && g < G; ++g) same = (c->last_group_len[g] == Kh[g]);
+    if (c->group_steps > 0 && !same) c->group_changes += 1;
     c->group_steps += 1;
     for (int g = 0; g < ggl_ctx::MAX_PARTS; ++g) {
         c->last_group_len[g] = g < G ? Kh[g] : 0;
@@ -3523,11 +3528,13 @@ extern "C" int ggl_ns_stats(ggl_ctx* c, long long out[16])
 // The LDS-resident Omega-step: { launches, launches an instance fell outside the kernel's range (step repeated on the launch
 // chain), products summed over all instances of all launches, Newton-Schulz steps likewise }.  Waits for the stream.
 // GGL_OPT_GROUP_SCHED: out = { Omega-steps that ran as groups with their own schedules, groups of the last step (1: whole),
-// lengths of its groups [4], product units (A', B' included) of their schedules [4] };
+// lengths of its groups [4], product units (A', B' included) of their schedules [4], grouped steps whose split differed from
+// the grouped step before };
 // units_sum (may be null) [4]: the units of every group slot summed over the grouped steps.
-extern "C" int ggl_group_stats(ggl_ctx* c, long long out[10], double* units_sum)
+extern "C" int ggl_group_stats(ggl_ctx* c, long long out[11], double* units_sum)
 {
     ARGCHK(c && out, "ctx, out");
+    out[10] = c->group_changes;
     out[0] = c->group_steps;
     out[1] = c->last_groups;
     for (int g = 0; g < 4; ++g) {

@@ -510,11 +510,11 @@ class HipEngine:
         """GGL_OPT_GROUP_SCHED: {'steps': Omega-steps that ran as groups with their own schedules, 'groups': of the last step,
         'len', 'units': of its groups, 'units_sum': per group slot over all grouped steps}."""
         import ctypes
-        out = (ctypes.c_longlong * 10)()
+        out = (ctypes.c_longlong * 11)()
         us = np.zeros(4)
         check(self.lib.ggl_group_stats(self.h, out, ptr(us)))
         g = int(out[1])
-        return {'steps': int(out[0]), 'groups': g, 'len': [int(out[2 + i]) for i in range(g)] if g > 1 else [],
+        return {'steps': int(out[0]), 'groups': g, 'changes': int(out[10]), 'len': [int(out[2 + i]) for i in range(g)] if g > 1 else [],
                 'units': [int(out[6 + i]) for i in range(g)] if g > 1 else [], 'units_sum': us.tolist()}
 
     def spectral_bounds(self):

@@ -512,9 +512,9 @@ int ggl_ns_stats(ggl_ctx *ctx, long long out[16]);
  * fell outside the kernel's range, products summed over all instances of all launches, Newton-Schulz steps likewise }. */
 int ggl_lds_stats(ggl_ctx *ctx, long long out[4]);
 /* GGL_OPT_GROUP_SCHED: out = { Omega-steps that ran as groups with their own schedules, groups of the last step (1 = whole batch),
- * lengths of its groups [4], product units (A', B' included) of their schedules [4] }; units_sum (4 doubles, may be NULL): the
- * units of every group slot summed over the grouped steps. */
-int ggl_group_stats(ggl_ctx *ctx, long long out[10], double *units_sum);
+ * lengths of its groups [4], product units (A', B' included) of their schedules [4], grouped steps whose split differed from
+ * the previous grouped step's }; units_sum (4 doubles, may be NULL): the units of every group slot summed over the grouped steps. */
+int ggl_group_stats(ggl_ctx *ctx, long long out[11], double *units_sum);
 /* c_k >= lambda_max(W_k^2 + 4 beta_k I) and beta_k (K doubles each) of the last validated matrix-function Omega-step; returns 1,
  * or 0 when there is none yet. */
 int ggl_spectral_bounds(ggl_ctx *ctx, double *c_out, double *beta_out);
