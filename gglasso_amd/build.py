@@ -15,8 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libggl_hip.so")
-SOURCES = ["elementwise.hip", "theta_pair.hip", "ext_group.hip", "eig_jacobi.hip", "recon_gemm.hip", "gemm_sym.hip", "gemm_i8.hip", "deflate.hip", "omega_lds.hip", "newton_schulz.hip", "ggl_capi.hip", "ggl_comm.hip", "probes_dev.hip"]
-HEADERS = ["common.hpp", "kernels.hpp", "ggl_comm.hpp", os.path.join("..", "..", "include", "ggl_hip.h")]
+SOURCES = ["elementwise.hip", "theta_pair.hip", "ext_group.hip", "eig_jacobi.hip", "recon_gemm.hip", "gemm_sym.hip", "gemm_i8.hip", "deflate.hip", "omega_lds.hip", "newton_schulz.hip", "ggl_comm.hip", "probes_dev.hip",
+           # the C ABI, by subject (csrc/capi_internal.hpp has the map)
+           "capi_ctx.hip", "capi_omega.hip", "capi_lstep.hip", "capi_batch.hip", "capi_snapshots.hip", "capi_checks.hip",
+           "capi_stats.hip", "capi_comm.hip", "capi_ext.hip", "capi_ops.hip"]
+HEADERS = ["common.hpp", "kernels.hpp", "ggl_comm.hpp", "capi_internal.hpp", os.path.join("..", "..", "include", "ggl_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs; without it hipcc 7.2 shuttles the f64
 # accumulators VGPR<->AGPR around every k-slab (64 extra moves + a full matrix-pipe drain per slab)

@@ -53,7 +53,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch)
     __syncthreads();
 }
 
-// Speculative Omega-step (ggl_capi.hip): the kernels that overwrite the iterate take the validation flags of the
+// Speculative Omega-step (capi_omega.hip): the kernels that overwrite the iterate take the validation flags of the
 // step's parts and do nothing when any is set -- the host then repeats the iteration without speculation.
 __device__ __forceinline__ bool spec_failed(const int* __restrict__ skip)
 {

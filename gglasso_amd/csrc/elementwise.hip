@@ -327,7 +327,7 @@ void launch_wait_flags(hipStream_t st, const unsigned long long* f, int n, unsig
     hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, st, f, n, v, skip, skip_host, slot, (long long)(timeout_ms * 1e5));
 }
 
-// one wave that does nothing for `us` microseconds (100 MHz wall clock): the stream-concurrency probe of ggl_capi.hip
+// one wave that does nothing for `us` microseconds (100 MHz wall clock): the stream-concurrency probe of capi_omega.hip
 __global__ void k_spin_us(long long us)
 {
     const long long t0 = (long long)wall_clock64();

@@ -1982,7 +1982,7 @@ int symm_auto_variant(int nprod, int p)
 }
 
 // Two independent products in one launch: C = coef[k]-affine(A*B) for k < K and C1 = coef[K+k]-scaled(A1*B1).
-// Launch hook of the event timeline (ggl_trace_*, ggl_capi.hip): called after every product launch with its stream.
+// Launch hook of the event timeline (ggl_trace_*, capi_stats.hip): called after every product launch with its stream.
 static void (*g_symm_hook)(hipStream_t, int, void*) = nullptr;
 static void* g_symm_hook_arg = nullptr;
 void symm_set_launch_hook(void (*fn)(hipStream_t, int, void*), void* arg) { g_symm_hook = fn; g_symm_hook_arg = arg; }

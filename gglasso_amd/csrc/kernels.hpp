@@ -126,7 +126,7 @@ void launch_group_partial(hipStream_t st, double* sq, const double* Omega, const
                           const double* X, double l1, int K, int p);
 // out(p,p) = sum_c sq[c], mirrored into the FULL symmetric matrix (diagonal 0)
 void launch_sum_chunks(hipStream_t st, double* out, const double* sq, int nsq, int p, const int* flags);
-// GROUPSQ of a K-sharded run (theta_pair.hip, ggl_capi.hip): the sums of squares sum_k u^2 are symmetric, so what the ranks
+// GROUPSQ of a K-sharded run (theta_pair.hip, capi_comm.hip): the sums of squares sum_k u^2 are symmetric, so what the ranks
 // exchange is the PACKED upper triangle, row-major with the diagonal -- p (p + 1) / 2 doubles -- followed by one double for
 // the speculation flag.  Element (i,j) in either order:
 __host__ __device__ __forceinline__ size_t tri_index(int i, int j, int p)
