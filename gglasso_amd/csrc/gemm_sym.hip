@@ -523,6 +523,9 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
         asm volatile("" ::: "memory");
         if (s + NSTG - 1 < S) issue(s + NSTG - 1, (buf + NSTG - 1) % NSTG);
         if (!dead_wave) {
+#if defined(GGL_EXP_SETPRIO) && GGL_EXP_SETPRIO == 1
+            __builtin_amdgcn_s_setprio(1);                    // experiment (tools/r6_e.sh): the matrix segment of a wave outranks the epilogues of its SIMD
+#endif
             const int nq = min(BK / 4, (valid + 3) / 4);      // k-quads inside the matrix (last slab: 1 of 4 at p = 500)
             // (The exit check between the k-quads stays even for slabs that lie inside the matrix.  Straight-line code --
             // with the compiler's own order, ds_read2st64 pairs ahead of 8 back-to-back MFMAs, or with a scheduling barrier
@@ -552,6 +555,9 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
                         }
                 }
             }
+#if defined(GGL_EXP_SETPRIO) && GGL_EXP_SETPRIO == 1
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
     };
     auto stages = [&](const int s0, auto... bufs) {
@@ -565,6 +571,9 @@ __device__ __forceinline__ void symm_dl_tile(const double* __restrict__ A, const
         else stages(s0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
     }
     __syncthreads();     // all fragment reads done before the slabs are reused as the mirror tile
+#if defined(GGL_EXP_SETPRIO) && GGL_EXP_SETPRIO == 2
+    __builtin_amdgcn_s_setprio(2);                                       // experiment: the epilogue outranks the other workgroups' slab loops
+#endif
     if (ABL == 4) {                                                      // timing ablation: no epilogue
         double keepalive = 0.0;
 #pragma unroll

@@ -13,14 +13,16 @@ def _problem(K, p, seed):
     return S
 
 
-def _run(S, rhos, lams, iters, options, idx=None):
+def _run(S, rhos, lams, iters, options, idx=None, start=None):
     """`iters` batched SGL iterations of the instances idx (default all) from the grid start Omega_0 = X_0 = I
-    (helper/model_selection.py:595-596); returns the state, per-iteration sums and the engine's statistics."""
+    (helper/model_selection.py:595-596) or from the state ``start``; returns the state, per-iteration sums and the engine's
+    statistics."""
     from gglasso_amd import solver
     idx = np.arange(len(S)) if idx is None else np.asarray(idx)
     K, p = len(idx), S.shape[-1]
     eye = np.repeat(np.eye(p)[None], K, axis=0)
-    eng = solver.HipEngine(np.ascontiguousarray(S[idx]), eye, eye, eye.copy(), options=options)
+    Om0, Th0, X0 = (eye, eye, eye.copy()) if start is None else (np.ascontiguousarray(start[nm][idx]) for nm in ("Omega", "Theta", "X"))
+    eng = solver.HipEngine(np.ascontiguousarray(S[idx]), Om0, Th0, X0, options=options)
     try:
         sums = [eng.sgl_batch_step(rhos[idx], lams[idx], False, None).copy() for _ in range(iters)]
         st = eng.state()
@@ -30,21 +32,24 @@ def _run(S, rhos, lams, iters, options, idx=None):
 
 
 def test_grouped_schedules_are_the_sub_batches_own_schedules():
-    """Eight single problems at p = 256 in three classes of conditioning (rho = 1, 4, 16 on copies of one covariance matrix, so
-    the instances of a class need the same product count in every iteration): with grouping forced (13) the batch runs as
-    three contiguous groups, the same split in every step; every instance's iterate is BITWISE the one it has in a batch that
-    holds its group alone under one schedule, within the Omega-step's tolerance of the single-schedule batch, and within 1e-9
-    of the oracle."""
+    """Eight single problems at p = 256 in three classes of conditioning (rho = 0.5, 1.5, 16 on copies of one covariance matrix:
+    the instances of a class are identical), iterated to near their fixed points so that every instance's product count stays
+    what it is: with grouping forced (13) the batch then runs as contiguous groups, the SAME split in every step; every
+    instance's iterate is BITWISE the one it has in a batch that holds its group alone under one schedule, within the
+    Omega-step's tolerance of the single-schedule batch, and within 1e-9 of the oracle."""
     from oracle import ggl_oracle as orc
-    K, p, iters = 8, 256, 6
+    K, p, warm, iters = 8, 256, 30, 5
     S = np.repeat(_problem(1, p, 41), K, axis=0)
-    rhos = np.array([1.0, 1.0, 1.0, 4.0, 4.0, 16.0, 16.0, 16.0])
+    rhos = np.array([0.5, 0.5, 0.5, 1.5, 1.5, 16.0, 16.0, 16.0])
     lams = np.full(K, 0.08)
     base = {"symm_variant": 17.0}
-    st_g, sums_g, gs, _, cb = _run(S, rhos, lams, iters, {**base, "group_sched": 13.0})
-    assert gs['steps'] >= iters - 1 and gs['len'] == [3, 2, 3] and gs['changes'] == 0, gs
-    assert len(set(gs['units'])) == 3, gs                                      # three different schedules
-    st_1, sums_1, gs1, _, _ = _run(S, rhos, lams, iters, {**base, "group_sched": 0.0})
+    st_w, _, _, _, cb = _run(S, rhos, lams, warm, {**base, "group_sched": 0.0})
+    st_g, sums_g, gs, _, _ = _run(S, rhos, lams, iters, {**base, "group_sched": 13.0}, start=st_w)
+    assert gs['steps'] == iters and gs['groups'] >= 2 and gs['changes'] == 0, gs
+    assert sum(gs['len']) == K and len(set(gs['units'])) == len(gs['units']), gs      # different schedules, or no group
+    cuts = np.cumsum(gs['len'])[:-1].tolist()
+    assert set(cuts) <= {3, 5}, gs                                              # the groups are whole classes
+    st_1, sums_1, gs1, _, _ = _run(S, rhos, lams, iters, {**base, "group_sched": 0.0}, start=st_w)
     assert gs1['steps'] == 0
     for nm in ("Omega", "Theta", "X"):
         assert np.abs(st_g[nm] - st_1[nm]).max() <= 1e-10, nm
@@ -52,14 +57,14 @@ def test_grouped_schedules_are_the_sub_batches_own_schedules():
     k0 = 0
     for n in gs['len']:
         idx = np.arange(k0, k0 + n)
-        st_s, sums_s, gss, _, _ = _run(S, rhos, lams, iters, {**base, "group_sched": 0.0}, idx)
+        st_s, sums_s, gss, _, _ = _run(S, rhos, lams, iters, {**base, "group_sched": 0.0}, idx, start=st_w)
         for nm in ("Omega", "Theta", "X"):
             assert np.array_equal(st_g[nm][idx], st_s[nm]), (nm, k0, n)
         assert np.array_equal(sums_g[:, idx], sums_s)
         k0 += n
-    # and the reference's iteration (single_admm_solver.py:157-214), point by point
+    # and the reference's iteration (single_admm_solver.py:157-214), point by point, over all warm + iters iterations
     for k in (0, 3, 7):
-        ref, _ = orc.ADMM_SGL(S[k], lams[k], np.eye(p), X_0=np.eye(p), rho=rhos[k], max_iter=iters, tol=1e-20, rtol=1e-20,
+        ref, _ = orc.ADMM_SGL(S[k], lams[k], np.eye(p), X_0=np.eye(p), rho=rhos[k], max_iter=warm + iters, tol=1e-20, rtol=1e-20,
                               update_rho=False)
         for nm in ("Omega", "Theta", "X"):
             assert np.abs(st_g[nm][k] - ref[nm]).max() <= 1e-9, (k, nm)

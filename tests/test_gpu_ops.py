@@ -413,17 +413,16 @@ def _rank_ex(W, beta, l0_coarse, degrees=0):
 
 def _with_gaps(rng, p, beta, gaps, scale=1.0):
     """Symmetric C with eigenvalues spread over [-scale, scale] and, for every g of ``gaps``, one eigenvalue at a distance
-    g * nb from the L-step's threshold beta, nb = sqrt(min(|C^2|_inf, |C^2|_F)) + beta (min(|C|_inf, |C|_F) + beta for odd p) being the norm
+    g * nb from the L-step's threshold beta, nb = sqrt(min(|C^2|_inf, |C^2|_F)) + beta being the norm
     bound the sign iteration scales with (its resolutions are relative to nb)."""
     Q, _ = np.linalg.qr(rng.standard_normal((p, p)))
     d = rng.uniform(-scale, scale, p)
     d[np.abs(d - beta) < 0.05 * scale] += 0.1 * scale            # nothing else near the threshold
     C = (Q * d) @ Q.T
-    if p % 2 == 0:        # the product kernel's epilogue leaves the partials of C^2: the bound comes from there
-        C2 = C @ C
-        nb = np.sqrt(min(np.abs(C2).sum(axis=1).max(), np.linalg.norm(C2))) + beta
-    else:                 # odd p runs the register-staged kernels: the bound is that of C itself
-        nb = min(np.abs(C).sum(axis=1).max(), np.linalg.norm(C)) + beta
+    # the product kernel's epilogue leaves the partials of C^2: the bound comes from there (round 6: for odd p too -- the
+    # direct-to-LDS kernel serves every p; rounds 3-5 took min(|C|_inf, |C|_F) at odd p)
+    C2 = C @ C
+    nb = np.sqrt(min(np.abs(C2).sum(axis=1).max(), np.linalg.norm(C2))) + beta
     for i, g in enumerate(gaps):
         d[i] = beta + g * nb
     C = (Q * d) @ Q.T
