@@ -126,6 +126,7 @@ _SIGNATURES = {
     "ggl_ns_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_rank_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_deflate_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
+    "ggl_finalize_stats": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_eig_info": ([_vp, ctypes.POINTER(_i)], _i),
     "ggl_last_dispatch": ([_vp, ctypes.POINTER(ctypes.c_longlong)], _i),
     "ggl_eigh_batched": ([_i, _i, _dp, _dp, _dp, _i], _i),

@@ -262,6 +262,7 @@ struct ggl_ctx {
     double* snap_beta = nullptr;               // host (K)
     unsigned char* snap_ns = nullptr;          // host (K): snapshot k's L is a sign-iteration L (snapC_k, snap_beta[k] valid)
     long long finalize_calls = 0;              // eigendecompositions ggl_finalize_L ran
+    long long finalize_retries = 0;            // ... that had to be repeated (eigenvalues that did not add up to the trace)
     // GGL_OPT_ISOLATE (batches of independent problems): an instance whose data turn non-finite (a NaN in its S, a diverged
     // iterate) or whose eigensolver does not converge is MARKED instead of failing the call for the whole batch
     // (helper/model_selection.py:208-224 walks the grid point by point and never loses it to one point); the host reads the

@@ -344,11 +344,37 @@ extern "C" int ggl_finalize_L(ggl_ctx* c, int which, int* rank_out)
     HIPCHK(hipMemcpyAsync(c->par + 2 * (size_t)K, slot, K * sizeof(double), hipMemcpyHostToDevice, c->stream));
     double* Csrc = which == 0 ? c->Ckeep : c->snapC;
     double* out = which == 0 ? c->L : c->W;
-    int rc = eig_recon(c, Csrc, out, c->DvL, MAP_RANK, c->par + 2 * (size_t)K);      // (destroys Csrc)
-    if (rc) return rc;
-    std::vector<double> d(kp);
-    HIPCHK(hipMemcpyAsync(d.data(), c->DvL, kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->info_h, c->info, K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // The ONE eigendecomposition a solve's returned L (and its rank) rests on is checked: trace(C_k) = the sum of the eigenvalues,
+    // taken before the eigensolver overwrites C_k.  An eigensolver that returns something else (reading (B) of round 5's
+    // intermittent RANK table) is run a second time on a kept copy of C; if that fails too the instance is
+    // marked / the call fails -- never a count that reads like a result.
+    std::vector<double> tr(K), d(kp);
+    launch_trace(c->stream, Csrc, K, p, 0.0, c->norms);
+    HIPCHK(hipMemcpyAsync(tr.data(), c->norms, K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    double* keep = c->nsT;                                 // (scratch of the matrix-function steps: free between steps)
+    if (keep) launch_copy_block(c->stream, keep, Csrc, c->n);
+    std::vector<unsigned char> wrong(K, 0);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc = eig_recon(c, Csrc, out, c->DvL, MAP_RANK, c->par + 2 * (size_t)K);      // (destroys Csrc)
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(d.data(), c->DvL, kp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->info_h, c->info, K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        bool any_wrong = false;
+        for (int k = 0; k < K; ++k) {
+            wrong[k] = 0;
+            if (!todo[k]) continue;
+            double sum = 0.0, mag = 0.0;
+            for (int e = 0; e < p; ++e) { sum += d[(size_t)k * p + e]; mag += std::fabs(d[(size_t)k * p + e]); }
+            if (!std::isfinite(sum) || !std::isfinite(tr[k]) || !(std::fabs(sum - tr[k]) <= 1e-8 * std::max(mag, 1e-300))) {
+                wrong[k] = 1;
+                any_wrong = true;
+            }
+        }
+        if (!any_wrong || attempt == 1 || !keep) break;
+        c->finalize_retries += 1;
+        launch_copy_block(c->stream, Csrc, keep, c->n);
+    }
     if (which == 1)
         for (int k = 0; k < K; ++k)
             if (todo[k]) launch_copy_block(c->stream, c->snapL + k * pp, c->W + k * pp, pp);
@@ -357,7 +383,7 @@ extern "C" int ggl_finalize_L(ggl_ctx* c, int which, int* rank_out)
     memcpy(slot, saved.data(), K * sizeof(double));
     HIPCHK(hipMemcpyAsync(c->par + 2 * (size_t)K, slot, K * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    rc = check_info(c, "final L");
+    int rc = check_info(c, "final L");
     if (rc) return rc;
     for (int k = 0; k < K; ++k) {
         if (!todo[k]) continue;
@@ -368,10 +394,12 @@ extern "C" int ggl_finalize_L(ggl_ctx* c, int which, int* rank_out)
             finite = finite && std::isfinite(v);
             r += v > beta_src[k] ? 1 : 0;
         }
-        // eigenvalues that are not finite: the kept C was not (a diverged instance) -- never a rank of zero that reads like a result
-        if (!finite) {
+        // eigenvalues that are not finite or do not add up to trace(C_k): the kept C was not finite (a diverged instance) or the
+        // eigensolver failed twice -- never a rank of zero that reads like a result
+        if (!finite || wrong[k]) {
             if (c->isolate) { mark_failed(c, k, 2, NAN); r = -1; }
-            else return fail(GGL_E_SOLVER, "final L: the eigenvalues of instance %d's L-step input are not finite", k);
+            else return fail(GGL_E_SOLVER, "final L: the eigenvalues of instance %d's L-step input are not finite or do not add up "
+                             "to its trace", k);
         }
         if (rank_out) rank_out[k] = r;
     }

@@ -191,6 +191,15 @@ extern "C" int ggl_last_dispatch(ggl_ctx* c, long long out[4])
 }
 
 // L-step calls whose first pass was followed by the deflation, and the instances that had something to deflate
+// ggl_finalize_L: out = { eigendecompositions run, of those repeated because the eigenvalues did not add up to trace(C) }
+extern "C" int ggl_finalize_stats(ggl_ctx* c, long long out[2])
+{
+    ARGCHK(c && out, "ctx, out");
+    out[0] = c->finalize_calls;
+    out[1] = c->finalize_retries;
+    return GGL_OK;
+}
+
 extern "C" int ggl_deflate_stats(ggl_ctx* c, long long out[2])
 {
     ARGCHK(c && out, "ctx, out");

@@ -533,6 +533,10 @@ int ggl_pipeline_stats(ggl_ctx *ctx, long long out[10]);
 int ggl_rank_stats(ggl_ctx *ctx, long long out[4]);
 /* out = { L-step calls whose first pass was followed by the deflation, instances that had directions to deflate } */
 int ggl_deflate_stats(ggl_ctx *ctx, long long out[2]);
+/* ggl_finalize_L checks its eigendecomposition (the eigenvalues of every rebuilt instance add up to the trace of its L-step input,
+ * taken before the eigensolver overwrites it) and repeats it once on a kept copy if they do not: out = { eigendecompositions
+ * run, of those repeated }. */
+int ggl_finalize_stats(ggl_ctx *ctx, long long out[2]);
 /* What ran last: out = { concurrent parts and product-kernel variant of the last matrix-function step (as in ggl_ns_stats),
  * code of the Theta kernel of the process's last Theta-step (0 GGL tile pairs; 100+KMAX per-element kernel with the K-column
  * in one thread; 100*KQ+NW per-element kernel with the K-column over NW waves: 404, 408, 808, 816, 1616; 2000+tile FGL
