@@ -271,6 +271,12 @@ void trace_symm_hook(hipStream_t st, int kind, void* arg) { trace_mark((ggl_ctx*
 static int omega_groups(const ggl_ctx* c, const double* cb, const double* beta_h, int K, int* Kh, int* k0h, int* gunits)
 {
     if (!c->group_sched || K < 2 || c->ns_force == 2 || c->chain_mode || c->comm) return 1;
+    {
+        // the K planner queries below cost ~0.1 us each on the host, in front of the chain's launches: only where a step is
+        // long enough not to notice (a step is >= 7 launches of F + K I seconds; same constants as ns_group_partition)
+        const double I = 2.5e-14 * (double)c->p * c->p * c->p, F = 6.5e-6;
+        if (c->group_sched < 10 && (double)K * 1e-7 > 0.01 * 7.0 * (F + K * I)) return 1;
+    }
     std::vector<int> u(K);
     for (int k = 0; k < K; ++k) {
         double ck = cb[k] * (1.0 + 1e-10);
