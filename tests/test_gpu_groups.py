@@ -109,3 +109,26 @@ def test_grouped_mgl_step_with_early_part_is_consistent():
     ref, _ = orc.ADMM_MGL(S, 0.05, 0.02, "GGL", eye, max_iter=iters, tol=1e-20, rtol=1e-20, update_rho=False)
     for nm in ("Omega", "Theta", "X"):
         assert np.abs(out["grouped"][0][nm] - ref[nm]).max() <= 1e-9, nm
+
+
+def test_product_library_refuses_the_development_only_options():
+    """Round 6: the measured-and-rejected alternatives are options of libggl_hip_dev.so only; the product
+    library accepts their default (0) and refuses anything else with GGL_E_ARG (an AssertionError in the Python binding), and
+    reports 0 for them."""
+    from gglasso_amd import solver
+    K, p = 2, 40
+    S = _problem(K, p, 51)
+    eye = np.repeat(np.eye(p)[None], K, axis=0)
+    eng = solver.HipEngine(S, eye, eye, np.zeros_like(S))
+    try:
+        for name in ("chain", "fused_cw", "part_priority", "rank_cw", "bound_side", "parts_bias", "parts_order"):
+            eng.set_option(name, 0)
+            with pytest.raises(AssertionError, match="development"):
+                eng.set_option(name, 1)
+            assert eng.get_option(name) == 0.0
+        eng.set_option("group_sched", 2)
+        assert eng.get_option("group_sched") == 2.0
+        with pytest.raises(AssertionError):
+            eng.set_option("group_sched", 7)
+    finally:
+        eng.close()
