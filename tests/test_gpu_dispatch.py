@@ -71,7 +71,13 @@ def _oracle_run(S, reg, l1, l2, Om0, checkpoints, tol, latent=False, mu1=None, m
     along ONE solve: the state after each of ``checkpoints`` iterations (tol = rtol = 1e-20 up to there, which is what a
     fixed-length run does) and then the solve continued to tol = rtol = ``tol``.  Returns ([states], converged state,
     status, total iterations).  The oracle's eigh is the expensive side of these tests; this way a converged full-size solve
-    costs its own iterations once."""
+    costs its own iterations once.
+    NOTE what this pins: the ARITHMETIC of every iteration is the oracle's (NumPy eigh + the C prox twins), the LOOP CONTROL
+    around it (rho rule, stopping rule, status strings) is the product's own ``solver._run_admm`` -- so status / iteration
+    count agreement here is product loop against product loop on different arithmetic.  The loop control itself is pinned
+    against the real reference by fixtures G8 / G9 (tests/test_oracle_golden.py, tests/test_gpu_admm.py) and, where a test
+    calls ``orc.ADMM_MGL`` / ``orc.ADMM_SGL`` directly (the third leg of the headline test, C2 converged, the odd-p and
+    slab tests), by the oracle's own restatement of admm_solver.py:172-281."""
     from gglasso_amd import solver
     from oracle_engine import OracleEngine
     K, p, _ = S.shape
