@@ -156,6 +156,7 @@ _DEV_SIGNATURES = {
     "ggl_dev_chain_run": ([_i, _i, _i, _i, _dp], _i),
     "ggl_dev_switch_bench": ([_i, _i, _i, _i, _i, _dp], _i),
     "ggl_dev_vendor_bench": ([_i, _i, _i, _i, _dp], _i),
+    "ggl_dev_fill_copy_probe": ([_i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_longlong)], _i),
 }
 
 ABI_VERSION = 300      # include/ggl_hip.h GGL_VERSION: argument layouts and buffer formats this binding was written against

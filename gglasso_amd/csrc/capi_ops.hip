@@ -220,6 +220,48 @@ extern "C" int ggl_dev_switch_bench(int K, int p, int variant, int iters, int mo
     return GGL_OK;
 }
 
+// Two probes for the readings of round 5's intermittent RANK table.
+// (A) ggl_dev_fill_copy_probe: what the snapshots of a batch used to do with the runtime's own operations -- hipMalloc a stack,
+//     hipMemsetAsync it to zero, hipMemcpyAsync device-to-device `slices` instances into it on the SAME stream (with `gap_us` of
+//     kernel work queued between the fill and the copies when > 0), synchronise, count the slices that came out zero.
+//     out = { repetitions, slices lost }.
+extern "C" int ggl_dev_fill_copy_probe(int reps, int K, int p, int slices, int gap_us, long long out[2])
+{
+    ARGCHK(reps >= 1 && K >= 1 && p >= 1 && slices >= 1 && slices <= K && out, "arguments");
+    const size_t pp = (size_t)p * p, n = (size_t)K * pp;
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    DevBuf src, flag;
+    HIPCHK(src.alloc(n));
+    HIPCHK(flag.alloc(K));
+    std::vector<double> ones(n, 1.0), got(K);
+    UP(src.p, ones.data(), n);
+    long long lost = 0;
+    for (int r = 0; r < reps; ++r) {
+        double* dst = nullptr;
+        HIPCHK(hipMalloc(&dst, n * sizeof(double)));
+        HIPCHK(hipMemsetAsync(dst, 0, n * sizeof(double), st));
+        if (gap_us > 0) launch_spin_us(st, gap_us);
+        for (int i = 0; i < slices; ++i) {
+            const int k = (i * 7 + r) % K;
+            HIPCHK(hipMemcpyAsync(dst + (size_t)k * pp, src.p + (size_t)k * pp, pp * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        // one element of every slot, read back after the stream has drained
+        HIPCHK(hipStreamSynchronize(st));
+        for (int i = 0; i < slices; ++i) {
+            const int k = (i * 7 + r) % K;
+            double v = -1.0;
+            HIPCHK(hipMemcpy(&v, dst + (size_t)k * pp + pp / 2, sizeof(double), hipMemcpyDeviceToHost));
+            if (v != 1.0) lost += 1;
+        }
+        HIPCHK(hipFree(dst));
+    }
+    (void)hipStreamDestroy(st);
+    out[0] = reps;
+    out[1] = lost;
+    return GGL_OK;
+}
+
 // A yardstick for the product kernel: what the vendor's FP64 GEMM reaches on this chip at the same shapes.
 // mode 0: rocblas_dgemm_strided_batched C = A B (N,N);  1: C = A^T B (the operand layout of k_symm_tn / k_symm_dl);
 // 2: rocblas_dsyrk_strided_batched C = A A^T, one triangle (p^3 flop per instance, like a symmetric product);

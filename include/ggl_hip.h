@@ -622,6 +622,10 @@ int ggl_dev_switch_bench(int K, int p, int variant, int iters, int mode, double 
  * rocblas_dgemm_strided_batched (N,N), 1 (T,N), 2 rocblas_dsyrk_strided_batched (one triangle), 3 rocblas_dsyrkx_strided_batched
  * (one triangle of A B^T: the library's form of a symmetric product), 4 the product kernel itself.  ms per call. */
 int ggl_dev_vendor_bench(int K, int p, int mode, int iters, double *ms_out);
+/* Probe for reading (A) of round 5's intermittent RANK table: hipMalloc + hipMemsetAsync of a (K,p,p) stack and
+ * hipMemcpyAsync device-to-device copies of `slices` instances into it on one stream, `reps` times; out = { repetitions, slices
+ * that came out zero }. */
+int ggl_dev_fill_copy_probe(int reps, int K, int p, int slices, int gap_us, long long out[2]);
 int ggl_dev_symm_timeline(int K, int p, long long *out, int max_blocks, int *nblocks_out);
 /* persistent-chain probe: nprod dependent products X <- X X of a K-batch as nprod launches (out[0], ms) and as ONE cooperative
  * launch with grid-wide barriers between the products (out[1], ms); out[2] grid of the latter, out[3] max |difference| of
