@@ -409,7 +409,10 @@ int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec, bool 
         // concurrent parts of a large batch: the 3-stage 64x64 DMA kernel; parts of a small batch: the size rule
         // (groups of different sizes: ONE kernel instance for all of them -- the bound partials of the parts are laid out
         // by the tile size, and the size rule could pick 32x32 tiles for a small group next to 64x64 for a large one)
-        const int var_parts = grouped ? (c->symm_variant >= 0 ? c->symm_variant : (K >= 16 ? 17 : symm_auto_variant(K, c->p)))
+        // (the instance the WHOLE batch would take -- the groups share the chip -- with three DMA stages where that is the
+        // 64x64 kernel, as for any concurrent parts)
+        const int var_grouped = c->symm_variant >= 0 ? c->symm_variant : (symm_auto_variant(K, c->p) == 16 ? 17 : symm_auto_variant(K, c->p));
+        const int var_parts = grouped ? var_grouped
                                       : ((c->symm_variant < 0 && nh > 1 && K >= 16) ? 17 : c->symm_variant);
         c->last_parts = nh;
         c->last_variant = symm_effective_variant(var_parts >= 0 ? var_parts : symm_auto_variant(Kh[0], c->p), c->p);
@@ -845,7 +848,7 @@ int omega_step(ggl_ctx* c, int latent, CopySegs* pending, bool allow_spec, bool 
                 nh = G;
                 grouped = true;
                 region_b = (size_t)(NS_MAX_LAUNCHES - 4) / nh * NS_SLOT(K);
-                var_b = c->symm_variant >= 0 ? c->symm_variant : (K >= 16 ? 17 : symm_auto_variant(K, c->p));
+                var_b = var_grouped;
                 if (!c->parts_probed) {
                     rc = probe_part_streams(c);
                     if (rc) return rc;
