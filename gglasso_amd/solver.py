@@ -381,6 +381,14 @@ class HipEngine:
         n = check(self.lib.ggl_finalize_L(self.h, int(which), rk.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
         return int(n), rk
 
+    def finalize_stats(self):
+        """{'calls': eigendecompositions ggl_finalize_L ran on this ctx, 'retries': of those repeated because their eigenvalues
+        did not add up to trace(C)} (the check of round 6)."""
+        import ctypes
+        out = (ctypes.c_longlong * 2)()
+        check(self.lib.ggl_finalize_stats(self.h, out))
+        return {'calls': int(out[0]), 'retries': int(out[1])}
+
     def snapshot_L_k(self, k):
         L = np.empty((self.p, self.p))
         check(self.lib.ggl_get_snapshot_k(self.h, int(k), None, ptr(L)))
