@@ -11,7 +11,8 @@
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+# (a grid point that ends as 'solver error' warns -- batch._warn_failures -- and no test of this module expects one: an error here)
+pytestmark = [pytest.mark.gpu, pytest.mark.filterwarnings("error::RuntimeWarning")]
 
 
 def _spd_with_small_entries(rng, p):
