@@ -1,0 +1,184 @@
+"""Randomised parity cases shared by tests/test_gpu_fuzz.py and tools/fuzz_parity.py: ADMM_MGL / ADMM_SGL through the C ABI against
+the CPU oracle (test infrastructure) on shapes and parameters the fixed tests do not visit -- p in 1 .. 130 (one case in ten
+191 .. 300) around every tile / pair / wave boundary, K in 1 .. 9, both penalties, latent on / off, penalty masks, N < p (singular
+S), lambda from "nothing shrinks" to "everything does", rho over three decades, rho updates on / off, fixed-length runs at
+tol = 1e-20 and runs to a realistic tolerance.
+Reference behaviour: solver/admm_solver.py:13-313 (ADMM_MGL), solver/single_admm_solver.py:15-275 (ADMM_SGL)."""
+import contextlib
+import io
+import os
+import time
+import warnings
+
+import numpy as np
+
+P = [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 23, 31, 32, 33, 47, 63, 64, 65, 66, 95, 97, 127, 128, 129, 130]
+PBIG = [191, 200, 255, 256, 257, 300]          # (one case in ten)
+TOL = 1e-9                                     # relative to max(1, |reference|_max), every array of the solution
+LAST = {}                                      # the inputs of the case under way: written out when it is off
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return fn(*a, **k)
+
+
+def one(i, rng):
+    from gglasso_amd import solver, synth
+    from oracle import ggl_oracle as orc
+    p = int(rng.choice(PBIG)) if rng.random() < 0.1 else int(rng.choice(P))
+    single = rng.random() < 0.3
+    reg = "GGL" if rng.random() < 0.5 else "FGL"
+    K = 1 if single else int(rng.integers(2, 10))
+    latent = rng.random() < 0.4
+    lam1 = float(10.0 ** rng.uniform(-3, 0.3))
+    lam2 = float(10.0 ** rng.uniform(-3, 0.0))
+    mu1 = float(10.0 ** rng.uniform(-1, 1))
+    rho = float(10.0 ** rng.uniform(-1.5, 1.5))
+    upd = bool(rng.random() < 0.5)
+    iters = int(rng.integers(1, 25))
+    conv = bool(rng.random() < 0.3)                           # a run to a realistic tolerance instead of a fixed length
+    tol, rtol = (float(10.0 ** rng.uniform(-9, -5)), float(10.0 ** rng.uniform(-8, -4))) if conv else (1e-20, 1e-20)
+    if conv:
+        iters = 400
+    S, _ = synth.make_problem(reg, K, p, N=int(rng.integers(max(2, p // 2), 3 * p + 3)), seed=int(rng.integers(1 << 30)))
+    # (N < p: a singular S, as the reference meets it in high-dimensional use)
+    tag = dict(i=i, p=p, K=K, reg=reg if not single else "SGL", latent=latent, lam1=round(lam1, 5), lam2=round(lam2, 5),
+               mu1=round(mu1, 4), rho=round(rho, 4), upd=upd, iters=iters, tol=tol, rtol=rtol)
+    kw = dict(max_iter=iters, tol=tol, rtol=rtol, rho=rho, update_rho=upd, latent=latent, measure=True)
+    LAST.clear()
+    LAST.update(S=S, lam1=lam1, lam2=lam2, single=single, reg=reg, **{k: v for k, v in kw.items() if k != "measure"})
+    if latent:
+        kw["mu1"] = mu1
+    if single:
+        eye = np.eye(p)
+        if rng.random() < 0.3:                                  # an entrywise penalty mask (single_admm_solver.py:68-73)
+            M = rng.random((p, p)) < 0.6
+            kw["lambda1_mask"] = ((M | M.T) * rng.uniform(0.5, 2.0)).astype(float)
+            tag["mask"] = True
+        ref, rinfo = quiet(orc.ADMM_SGL, S[0], lam1, eye, **kw)
+        got, ginfo = quiet(solver.ADMM_SGL, S[0], lam1, eye, **kw)
+    else:
+        eye = np.repeat(np.eye(p)[None], K, axis=0)
+        ref, rinfo = quiet(orc.ADMM_MGL, S, lam1, lam2, reg, eye, **kw)
+        got, ginfo = quiet(solver.ADMM_MGL, S, lam1, lam2, reg, eye, **kw)
+    worst = 0.0
+    # past convergence with tol = 1e-20 the residuals are rounding noise and so are the rho updates they decide (r > 10 s or
+    # s > 10 r, admm_solver.py:186-195): the two runs then scale the dual differently -- X = (unscaled dual) / rho is compared
+    # only while the residuals still mean something
+    last = np.abs(np.asarray(rinfo["residual"][-1], dtype=float))
+    noise = (not conv) and upd and float(np.max(last)) < 1e-11 * max(1.0, float(np.abs(np.asarray(ref["Theta"])).max()))
+    if noise:
+        tag["rho_by_noise"] = True
+    for nm in ("Omega", "Theta") + (() if noise else ("X",)) + (("L",) if latent else ()):
+        a, b = np.asarray(got[nm]), np.asarray(ref[nm])
+        if a.shape != b.shape:
+            return tag, float("inf"), f"shape {nm} {a.shape} vs {b.shape}"
+        if not np.all(np.isfinite(a)):
+            return tag, float("inf"), f"non-finite {nm}"
+        worst = max(worst, float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max())))
+    note = ""
+    nit_g, nit_r = len(ginfo["residual"]), len(rinfo["residual"])
+    if conv and nit_g != nit_r:
+        # a stopping test decided by the last bits of a residual: one iteration apart is the same solve, the iterates then
+        # differ by about the tolerance
+        return tag, (0.0 if abs(nit_g - nit_r) <= 1 else float("inf")), f"iterations {nit_g} vs {nit_r}"
+    if ginfo["status"] != rinfo["status"]:
+        # with tol = rtol = 1e-20 only a residual that is EXACTLY zero in one of the two passes its test: a last-bit matter
+        exact0 = not conv
+        note = f"status {ginfo['status']!r} vs {rinfo['status']!r}" + (" (exact-zero residual)" if exact0 else "")
+    return tag, worst, note
+
+
+
+def one_batch(i, rng):
+    """A grid of G points through ADMM_SGL_batch / ADMM_MGL_batch (per-point rho, stopping decision, snapshot at the iteration a
+    point converges, compaction of the stack) against the oracle's independent solve of every point (what the reference's grid
+    walks do one point after the other, helper/model_selection.py:208-224, 619-633)."""
+    from gglasso_amd import batch, synth
+    from oracle import ggl_oracle as orc
+    p = int(rng.choice([q for q in P if q >= 2]))
+    single = rng.random() < 0.5
+    reg = "GGL" if rng.random() < 0.5 else "FGL"
+    K = 1 if single else int(rng.integers(2, 6))
+    G = int(rng.integers(1, 13))
+    latent = rng.random() < 0.4
+    lam1 = 10.0 ** rng.uniform(-2.5, 0.0, G)
+    lam2 = 10.0 ** rng.uniform(-2.5, -0.3, G)
+    mu = 10.0 ** rng.uniform(-0.7, 0.7, G)
+    upd = bool(rng.random() < 0.7)
+    tol, rtol = float(10.0 ** rng.uniform(-9, -6)), float(10.0 ** rng.uniform(-8, -5))
+    max_iter = int(rng.choice([15, 60, 400]))               # (15: most points end at the iteration limit)
+    compact = bool(rng.random() < 0.7)
+    S, _ = synth.make_problem(reg, K, p, N=int(rng.integers(max(2, p // 2), 3 * p + 3)), seed=int(rng.integers(1 << 30)))
+    tag = dict(i=i, kind="batch", p=p, K=K, G=G, reg=reg if not single else "SGL", latent=latent, upd=upd, tol=tol, rtol=rtol,
+               max_iter=max_iter, compact=compact)
+    LAST.clear()
+    LAST.update(S=S, lam1=lam1, lam2=lam2, mu=mu, single=single, reg=reg, latent=latent, upd=upd, tol=tol, rtol=rtol,
+                max_iter=max_iter, compact=compact)
+    kw = dict(tol=tol, rtol=rtol, update_rho=upd, max_iter=max_iter, latent=latent)
+    if single:
+        eye = np.eye(p)
+        res = quiet(batch.ADMM_SGL_batch, S[0], lam1, Omega_0=eye, X_0=np.zeros((p, p)), mu1=mu if latent else None,
+                    compact=compact, **kw)
+    else:
+        eye = np.repeat(np.eye(p)[None], K, axis=0)
+        res = quiet(batch.ADMM_MGL_batch, S, lam1, lam2, reg, Omega_0=eye, mu1=np.repeat(mu[:, None], K, axis=1) if latent else None,
+                    compact=compact, **kw)
+    worst, note = 0.0, ""
+    for g in range(G):
+        okw = dict(kw)
+        if latent:
+            okw["mu1"] = float(mu[g]) if single else np.full(K, mu[g])
+        if single:
+            ref, rinfo = quiet(orc.ADMM_SGL, S[0], float(lam1[g]), eye, X_0=np.zeros((p, p)), **okw)
+        else:
+            ref, rinfo = quiet(orc.ADMM_MGL, S, float(lam1[g]), float(lam2[g]), reg, eye, **okw)
+        sol, info = res[g]
+        if info["iterations"] != rinfo["iterations"]:
+            # a stopping test decided by the last bits of a residual: one iteration apart is the same solve
+            if abs(info["iterations"] - rinfo["iterations"]) > 1:
+                return tag, float("inf"), f"point {g}: iterations {info['iterations']} vs {rinfo['iterations']}"
+            note = f"point {g}: iterations {info['iterations']} vs {rinfo['iterations']}"
+            continue
+        if info["status"] != rinfo["status"]:
+            return tag, float("inf"), f"point {g}: status {info['status']!r} vs {rinfo['status']!r}"
+        for nm in ("Omega", "Theta", "X") + (("L",) if latent else ()):
+            a, b = np.asarray(sol[nm]), np.asarray(ref[nm])
+            if a.shape != b.shape or not np.all(np.isfinite(a)):
+                return tag, float("inf"), f"point {g}: {nm} shape {a.shape} vs {b.shape} or not finite"
+            worst = max(worst, float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max())))
+    return tag, worst, note
+
+
+def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
+    """Runs ``cases`` cases of the stream ``seed``; returns (cases off, last-bit stopping notes, largest deviation of the rest).
+    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind`` "batch": the grid cases of one_batch."""
+    global PBIG
+    rng = np.random.default_rng(seed)
+    keep, bad, notes, mx = PBIG, 0, 0, 0.0
+    if not big:
+        PBIG = P
+    try:
+        for i in range(cases):
+            try:
+                tag, worst, note = (one_batch if kind == "batch" else one)(i, rng)
+            except Exception as e:                                      # a crash is a finding too
+                out(f"case {i}: raised {type(e).__name__}: {e}")
+                bad += 1
+                continue
+            if worst > TOL or (note and "exact-zero" not in note and "iterations" not in note):
+                bad += 1
+                out(f"OFF {worst:.3e} {note} {tag}")
+                if dump_dir:
+                    os.makedirs(dump_dir, exist_ok=True)
+                    np.savez(os.path.join(dump_dir, f"case_seed{seed}_{i}.npz"), **{k: v for k, v in LAST.items() if v is not None})
+            else:
+                mx = max(mx, worst)
+                if note:
+                    notes += 1
+                    out(f"note {worst:.3e} {note} {tag}")
+    finally:
+        PBIG = keep
+    return bad, notes, mx

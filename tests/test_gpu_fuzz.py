@@ -1,0 +1,26 @@
+"""A quick pass of the randomised parity cases (tests/fuzz_checks.py; tools/fuzz_parity.py runs as many as asked for -- round 6:
+1 700 cases over six streams, profiles/r6_fuzz_parity.txt): ADMM_MGL / ADMM_SGL through the C ABI against the oracle at shapes
+around every tile / pair / wave boundary (p = 1 .. 130), K = 1 .. 9, both penalties, latent on / off, masks, singular S, rho
+updates.  Reference: solver/admm_solver.py:13-313, solver/single_admm_solver.py:15-275."""
+import pytest
+
+import fuzz_checks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_shapes_and_parameters_against_the_oracle(seed):
+    lines = []
+    bad, notes, worst = fuzz_checks.run_cases(40, seed, out=lines.append, big=False)
+    assert bad == 0, "\n".join(lines)
+    assert worst <= fuzz_checks.TOL
+
+
+def test_random_grids_through_the_batch_drivers_against_the_oracle():
+    """ADMM_SGL_batch / ADMM_MGL_batch on random grids (G = 1 .. 12 points of random lambda / mu, per-point rho and stopping,
+    iteration limits that cut most points off, compaction on / off) against the oracle's independent solve of every point."""
+    lines = []
+    bad, notes, worst = fuzz_checks.run_cases(24, 31, out=lines.append, kind="batch")
+    assert bad == 0, "\n".join(lines)
+    assert worst <= fuzz_checks.TOL
