@@ -152,9 +152,128 @@ def one_batch(i, rng):
     return tag, worst, note
 
 
+def one_block(i, rng):
+    """block_SGL (solver/single_admm_solver.py:326-475): a covariance matrix with planted components of random sizes (singletons,
+    pairs, blocks of very different size in one problem), lambda1 between the planted cross-block level and the in-block
+    correlations, optional mask; all components solved together on the GPU against the oracle's component-by-component loop."""
+    from gglasso_amd import solver
+    from oracle import ggl_oracle as orc
+    nb = int(rng.integers(1, 7))
+    sizes = [int(rng.choice([1, 1, 2, 3, 5, 8, 13, 21, 40, 70])) for _ in range(nb)]
+    p = int(sum(sizes))
+    blocks = []
+    for n in sizes:
+        A = rng.standard_normal((n, 3 * n + 2))
+        blocks.append(A @ A.T / (3 * n + 2))
+    from scipy.linalg import block_diag
+    S = block_diag(*blocks)
+    noise = rng.standard_normal((p, p)) * 1e-3
+    S = S + (noise + noise.T) / 2 * (S == 0)                     # cross-block entries far below any lambda1 drawn here
+    perm = rng.permutation(p)
+    S = np.ascontiguousarray(S[np.ix_(perm, perm)])
+    lam1 = float(10.0 ** rng.uniform(-1.7, -0.3))
+    tol, rtol = float(10.0 ** rng.uniform(-9, -6)), float(10.0 ** rng.uniform(-8, -4))
+    upd = bool(rng.random() < 0.7)
+    rho = float(10.0 ** rng.uniform(-0.5, 0.5))
+    max_iter = int(rng.choice([20, 500]))
+    kw = dict(tol=tol, rtol=rtol, update_rho=upd, rho=rho, max_iter=max_iter)
+    tag = dict(i=i, kind="block", p=p, sizes=sizes, lam1=round(lam1, 5), **kw)
+    if rng.random() < 0.3:
+        M = rng.random((p, p)) < 0.7
+        kw["lambda1_mask"] = ((M | M.T) * 1.0 + 0.5).astype(float)
+        tag["mask"] = True
+    LAST.clear()
+    LAST.update(S=S, lam1=lam1, **kw)
+    ref = quiet(orc.block_SGL, S, lam1, np.eye(p), **kw)
+    got = quiet(solver.block_SGL, S, lam1, np.eye(p), **kw)
+    worst = 0.0
+    for nm in ("Omega", "Theta", "X"):
+        a, b = np.asarray(got[nm]), np.asarray(ref[nm])
+        if a.shape != b.shape or not np.all(np.isfinite(a)):
+            return tag, float("inf"), f"{nm}: shape {a.shape} vs {b.shape} or not finite"
+        worst = max(worst, float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max())))
+    # (a component whose stopping test is decided by the last bits ends one iteration apart: about the tolerance, not 1e-9)
+    note = ""
+    if worst > TOL and worst <= 50 * max(tol, rtol):
+        note, worst = f"iterations: one component differs by {worst:.1e} <= 50 max(tol, rtol)", 0.0
+    return tag, worst, note
+
+
+def _nonconforming(rng, universe, sizes, prob=0.08):
+    """Instances observing random subsets of a common variable set; G like helper/ext_admm_helper.py:104-144 (one group per
+    pair of variables present together in >= 2 instances)."""
+    members = [np.sort(rng.choice(universe, size=n, replace=False)) for n in sizes]
+    A = rng.standard_normal((universe, universe)) * (rng.random((universe, universe)) < prob)
+    Sig = np.linalg.inv(A @ A.T + np.eye(universe))
+    S = {}
+    for k, ix in enumerate(members):
+        X = rng.multivariate_normal(np.zeros(universe), Sig, size=3 * len(ix) + 2).T[ix]
+        S[k] = np.atleast_2d(np.cov(X, bias=True))
+    K = len(sizes)
+    loc = -np.ones((universe, K), dtype=int)
+    for k, ix in enumerate(members):
+        loc[ix, k] = np.arange(len(ix))
+    rows = []
+    for a in range(universe):
+        for b in range(a + 1, universe):
+            both = (loc[a] >= 0) & (loc[b] >= 0)
+            if both.sum() >= 2:
+                rows.append((np.where(both, np.minimum(loc[a], loc[b]), -1), np.where(both, np.maximum(loc[a], loc[b]), -1)))
+    if not rows:
+        return None
+    G = np.stack([np.stack([r[0] for r in rows]), np.stack([r[1] for r in rows])]).astype(int)
+    return S, G, np.array([len(ix) for ix in members])
+
+
+def one_ext(i, rng):
+    """ext_ADMM_MGL (solver/ext_admm_solver.py:18-323): K = 2 .. 5 instances of DIFFERENT dimension over a common variable set,
+    random group structure, per-instance lambda1 / mu1, latent on / off, fixed lengths and runs to a tolerance."""
+    from gglasso_amd.ext_solver import ext_ADMM_MGL
+    from oracle import ggl_oracle as orc
+    K = int(rng.integers(2, 6))
+    universe = int(rng.choice([6, 9, 14, 20, 33, 48, 70]))
+    sizes = [int(rng.integers(max(2, universe // 3), universe + 1)) for _ in range(K)]
+    made = _nonconforming(rng, universe, sizes, prob=float(rng.uniform(0.05, 0.3)))
+    tag = dict(i=i, kind="ext", K=K, universe=universe, sizes=sizes)
+    if made is None:
+        return tag, 0.0, ""
+    S, G, p = made
+    orc.check_G(G, p)
+    latent = rng.random() < 0.4
+    lam1 = 10.0 ** rng.uniform(-2.0, -0.5, K)
+    lam2 = float(10.0 ** rng.uniform(-2.5, -0.5))
+    rho = float(10.0 ** rng.uniform(-0.7, 0.7))
+    conv = bool(rng.random() < 0.3)
+    tol, rtol = (float(10.0 ** rng.uniform(-8, -5)), float(10.0 ** rng.uniform(-7, -4))) if conv else (1e-20, 1e-20)
+    iters = 300 if conv else int(rng.integers(1, 16))
+    kw = dict(max_iter=iters, tol=tol, rtol=rtol, rho=rho, latent=latent, measure=True)
+    if latent:
+        kw["mu1"] = 10.0 ** rng.uniform(-0.7, 0.5, K)
+    tag.update(latent=latent, lam2=round(lam2, 5), rho=round(rho, 4), iters=iters, tol=tol, rtol=rtol, groups=int(G.shape[1]))
+    LAST.clear()
+    LAST.update(G=G, lam1=lam1, lam2=lam2, **{f"S_{k}": S[k] for k in range(K)}, **{k: v for k, v in kw.items() if k != "measure"})
+    Om0 = {k: np.eye(p[k]) for k in range(K)}
+    ref, rinfo = quiet(orc.ext_ADMM_MGL, S, lam1, lam2, 'GGL', {k: v.copy() for k, v in Om0.items()}, G, **kw)
+    got, ginfo = quiet(ext_ADMM_MGL, S, lam1, lam2, 'GGL', {k: v.copy() for k, v in Om0.items()}, G, **kw)
+    nit_g, nit_r = len(ginfo["residual"]), len(rinfo["residual"])
+    if nit_g != nit_r:
+        return tag, (0.0 if conv and abs(nit_g - nit_r) <= 1 else float("inf")), f"iterations {nit_g} vs {nit_r}"
+    note = ""
+    if ginfo["status"] != rinfo["status"]:
+        note = f"status {ginfo['status']!r} vs {rinfo['status']!r}" + ("" if conv else " (exact-zero residual)")
+    worst = 0.0
+    for nm in ("Omega", "Theta", "X0", "X1") + (("L",) if latent else ()):
+        for k in range(K):
+            a, b = np.asarray(got[nm][k]), np.asarray(ref[nm][k])
+            if a.shape != b.shape or not np.all(np.isfinite(a)):
+                return tag, float("inf"), f"{nm}[{k}]: shape {a.shape} vs {b.shape} or not finite"
+            worst = max(worst, float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max())))
+    return tag, worst, note
+
+
 def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     """Runs ``cases`` cases of the stream ``seed``; returns (cases off, last-bit stopping notes, largest deviation of the rest).
-    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind`` "batch": the grid cases of one_batch."""
+    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind``: "solver" (one), "batch" (one_batch), "block" (one_block), "ext" (one_ext)."""
     global PBIG
     rng = np.random.default_rng(seed)
     keep, bad, notes, mx = PBIG, 0, 0, 0.0
@@ -163,7 +282,7 @@ def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     try:
         for i in range(cases):
             try:
-                tag, worst, note = (one_batch if kind == "batch" else one)(i, rng)
+                tag, worst, note = {"batch": one_batch, "block": one_block, "ext": one_ext}.get(kind, one)(i, rng)
             except Exception as e:                                      # a crash is a finding too
                 out(f"case {i}: raised {type(e).__name__}: {e}")
                 bad += 1

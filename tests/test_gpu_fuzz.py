@@ -24,3 +24,14 @@ def test_random_grids_through_the_batch_drivers_against_the_oracle():
     bad, notes, worst = fuzz_checks.run_cases(24, 31, out=lines.append, kind="batch")
     assert bad == 0, "\n".join(lines)
     assert worst <= fuzz_checks.TOL
+
+
+@pytest.mark.parametrize("kind,cases,seed", [("block", 60, 43), ("ext", 40, 53)])
+def test_random_block_and_nonconforming_problems_against_the_oracle(kind, cases, seed):
+    """block_SGL on covariance matrices with planted components of very different size (singletons to 70, all solved together
+    on the GPU; solver/single_admm_solver.py:326-475) and ext_ADMM_MGL on K = 2 .. 5 instances of different dimension with a
+    random group structure (solver/ext_admm_solver.py:18-323), each against the oracle."""
+    lines = []
+    bad, notes, worst = fuzz_checks.run_cases(cases, seed, out=lines.append, kind=kind)
+    assert bad == 0, "\n".join(lines)
+    assert worst <= fuzz_checks.TOL
