@@ -14,7 +14,8 @@ import numpy as np
 
 P = [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 23, 31, 32, 33, 47, 63, 64, 65, 66, 95, 97, 127, 128, 129, 130]
 PBIG = [191, 200, 255, 256, 257, 300]          # (one case in ten)
-TOL = 1e-9                                     # relative to max(1, |reference|_max), every array of the solution
+TOL = float(os.environ.get("GGL_FUZZ_TOL", 1e-9))    # relative to max(1, |reference|_max), every array of the solution (the
+                                               # variable: a tighter bar lists the cases nearest to it)
 LAST = {}                                      # the inputs of the case under way: written out when it is off
 
 
@@ -271,9 +272,80 @@ def one_ext(i, rng):
     return tag, worst, note
 
 
+def _spectrum(rng, p):
+    """Eigenvalues with what a random matrix never has: wide ranges, clusters, exact repeats, zeros, one sign only."""
+    kind = int(rng.integers(0, 6))
+    if kind == 0:
+        d = rng.standard_normal(p) * 10.0 ** rng.uniform(-2, 2)
+    elif kind == 1:
+        d = 10.0 ** rng.uniform(-4, 3, p) * rng.choice([-1.0, 1.0], p)           # seven decades, both signs
+    elif kind == 2:
+        d = np.repeat(rng.standard_normal(max(1, p // 8 + 1)), 8)[:p] * 10.0 ** rng.uniform(-1, 1)   # exact repeats
+    elif kind == 3:
+        d = 1.0 + 1e-9 * rng.standard_normal(p)                                # one cluster
+    elif kind == 4:
+        d = np.abs(rng.standard_normal(p)) * (rng.random(p) < 0.5)             # semidefinite, many exact zeros
+    else:
+        d = -np.abs(rng.standard_normal(p)) * 10.0 ** rng.uniform(-1, 2)       # negative definite
+    return d
+
+
+def one_ops(i, rng):
+    """The operators on their own (solver/ggl_helper.py:16-36, 190-207, 280-303; solver/fgl_helper.py:11-68) at inputs ADMM iterates
+    rarely are: phiplus and prox_rank_norm from the MATRIX (the Omega- / L-step the solver runs, method by the size rule) on
+    stacks whose instances have engineered spectra of very different conditioning, prox_p with ties and exact zeros across K."""
+    from gglasso_amd import ops
+    from oracle import ggl_oracle as orc
+    which = int(rng.integers(0, 3))
+    K = int(rng.integers(1, 9))
+    tag = dict(i=i, kind="ops", K=K)
+    if which < 2:
+        p = int(rng.choice([q for q in P + [200, 257, 300] if q >= 2]))
+        W = np.empty((K, p, p))
+        for k in range(K):
+            Q, _ = np.linalg.qr(rng.standard_normal((p, p)))
+            W[k] = (Q * _spectrum(rng, p)) @ Q.T
+            W[k] = 0.5 * (W[k] + W[k].T)
+        beta = 10.0 ** rng.uniform(-3, 1.5, K)
+        tag.update(op="phiplus" if which == 0 else "rank", p=p, beta=[float(f"{b:.3g}") for b in beta])
+        LAST.clear()
+        LAST.update(W=W, beta=beta, which=which)
+        if which == 0:
+            ref, _ = orc.phiplus_stack(W, beta)
+            out = ops.phiplus_matrix(W, beta)
+        else:
+            ref = orc.rank_stack(W, beta)
+            out = ops.rank_matrix(W, beta)
+        if not np.all(np.isfinite(out)):
+            return tag, float("inf"), "not finite"
+        # per instance: relative to the larger of 1, the result and the input (an eigenvalue-wise map: its error scales with |W|)
+        worst = max(float(np.abs(out[k] - ref[k]).max()) / max(1.0, float(np.abs(ref[k]).max()), float(np.abs(W[k]).max()))
+                    for k in range(K))
+        if not np.array_equal(out, out.transpose(0, 2, 1)):
+            return tag, float("inf"), "result not bitwise symmetric"
+        return tag, worst, ""
+    p = int(rng.choice(P))
+    reg = "GGL" if rng.random() < 0.5 else "FGL"
+    K = max(K, 2)
+    X = rng.standard_normal((K, p, p))
+    style = int(rng.integers(0, 3))
+    if style == 1:
+        X = np.round(X * 2) / 2                                    # ties across K and exact zeros
+    elif style == 2:
+        X = np.repeat(X[:1], K, axis=0) + (rng.random((K, 1, 1)) < 0.3) * 1e-14   # (almost) constant across K
+    X = 0.5 * (X + X.transpose(0, 2, 1))
+    l1, l2 = float(10.0 ** rng.uniform(-3, 0.5)), float(10.0 ** rng.uniform(-3, 0.5))
+    tag.update(op="prox_p", reg=reg, p=p, K=K, style=style, l1=l1, l2=l2)
+    LAST.clear()
+    LAST.update(X=X, l1=l1, l2=l2, reg=reg)
+    ref = orc.prox_p(X, l1, l2, reg)
+    out = ops.prox_p(X, l1, l2, reg)
+    return tag, float(np.abs(out - ref).max()) / max(1.0, float(np.abs(ref).max())), ""
+
+
 def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     """Runs ``cases`` cases of the stream ``seed``; returns (cases off, last-bit stopping notes, largest deviation of the rest).
-    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind``: "solver" (one), "batch" (one_batch), "block" (one_block), "ext" (one_ext)."""
+    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind``: "solver" (one), "batch" (one_batch), "block" (one_block), "ext" (one_ext), "ops" (one_ops)."""
     global PBIG
     rng = np.random.default_rng(seed)
     keep, bad, notes, mx = PBIG, 0, 0, 0.0
@@ -282,7 +354,7 @@ def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     try:
         for i in range(cases):
             try:
-                tag, worst, note = {"batch": one_batch, "block": one_block, "ext": one_ext}.get(kind, one)(i, rng)
+                tag, worst, note = {"batch": one_batch, "block": one_block, "ext": one_ext, "ops": one_ops}.get(kind, one)(i, rng)
             except Exception as e:                                      # a crash is a finding too
                 out(f"case {i}: raised {type(e).__name__}: {e}")
                 bad += 1
