@@ -412,11 +412,16 @@ def _final_L(eng, sols, per_sol):
                 L = eng.snapshot_L_k(i)
                 q = sol['L'].shape[-1]                 # (instances of a padded batch are returned un-padded)
                 L = np.ascontiguousarray(L[:q, :q])
-                # the rebuilt L IS the iteration's L up to the sign iteration's residual (~1e-13 |L|): anything else means the
-                # kept input of that L-step is not what the step saw (round 5's intermittent RANK table [[0,0,63],[0,0,108]]
-                # was of this kind) -- the point is reported, never returned as if it were a result
+                # the rebuilt L IS the iteration's L up to the sign iteration's residual: anything else means the kept input of that
+                # L-step is not what the step saw (round 5's intermittent RANK table [[0,0,63],[0,0,108]] was of this kind) -- the
+                # point is reported, never returned as if it were a result.  The residual is relative to the step's INPUT
+                # C = Omega - Theta - X (~1e-13 |C|), not to L: an L that is exactly zero (every eigenvalue below the threshold)
+                # comes out of the sign iteration as noise of that size (4e-12 seen at p = 16, tools/fuzz_parity.py ... stats), so
+                # the floor scales with the iterate.  A lost input is off by the size of L itself, orders above either term.
                 nrm = float(np.abs(L_it).max())
-                if not (np.all(np.isfinite(L)) and float(np.abs(L - L_it).max()) <= 1e-6 * max(nrm, 1e-300) + 1e-12):
+                scale = max([1.0] + [float(np.abs(sol[nm] if single else sol[nm][k]).max()) for nm in ('Omega', 'Theta', 'X')
+                                     if nm in sol and np.all(np.isfinite(sol[nm] if single else sol[nm][k]))])
+                if not (np.all(np.isfinite(L)) and float(np.abs(L - L_it).max()) <= 1e-6 * nrm + 1e-8 * scale):
                     bad.append(g)
                     continue
                 if single:

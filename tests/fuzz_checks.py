@@ -343,9 +343,70 @@ def one_ops(i, rng):
     return tag, float(np.abs(out - ref).max()) / max(1.0, float(np.abs(ref).max())), ""
 
 
+def one_stats(i, rng):
+    """What the AIC / eBIC / rank tables of model selection are made of (helper/model_selection.py:619-660, 698-737, 884-894):
+    <S,Theta>, log det Theta, count_nonzero(Theta), lambda_min(Theta), matrix_rank(L) and the same statistics of the estimate
+    thresholded at every tau, computed on the device beside a random grid -- against numpy on the solutions the grid returns."""
+    from gglasso_amd import batch, synth
+    p = int(rng.choice([q for q in P if q >= 3]))
+    G = int(rng.integers(1, 10))
+    latent = rng.random() < 0.5
+    lam = 10.0 ** rng.uniform(-2.0, 0.0, G)
+    mu = 10.0 ** rng.uniform(-0.5, 0.7, G)
+    with_tau = rng.random() < 0.5
+    tau = np.sort(10.0 ** rng.uniform(-8, -0.5, int(rng.integers(1, 8)))) if with_tau else None
+    tol = float(10.0 ** rng.uniform(-9, -6))
+    S, _ = synth.make_problem("GGL", 1, p, N=int(rng.integers(p, 3 * p + 3)), seed=int(rng.integers(1 << 30)))
+    S = S[0]
+    tag = dict(i=i, kind="stats", p=p, G=G, latent=latent, ntau=0 if tau is None else len(tau), tol=tol)
+    LAST.clear()
+    LAST.update(S=S, lam=lam, mu=mu, latent=latent, tau=tau, tol=tol)
+    res = quiet(batch.ADMM_SGL_batch, S, lam, Omega_0=np.eye(p), X_0=np.zeros((p, p)), tol=tol, rtol=tol, max_iter=500,
+                latent=latent, mu1=mu if latent else None, selection_stats=True, tau_range=tau)
+    worst = 0.0
+
+    def stats_of(T):
+        d = np.linalg.eigvalsh(T)
+        return float(np.sum(S * T)), float(np.linalg.slogdet(T)[1]), int(np.count_nonzero(T)), float(d.min())
+
+    def cmp(got4, T, what):
+        nonlocal worst
+        sd, ld, nz, lm = stats_of(T)
+        if int(got4[2]) != nz:
+            return f"{what}: nnz {int(got4[2])} vs {nz}"
+        worst = max(worst, abs(got4[0] - sd) / max(1.0, abs(sd)), abs(got4[3] - lm) / max(1.0, np.abs(T).max()))
+        if lm > 1e-9:                                  # (log det of a matrix that is not definite is -inf / nan by convention)
+            if not np.isfinite(got4[1]):
+                return f"{what}: log det {got4[1]} for a definite matrix (lambda_min {lm:.3e})"
+            worst = max(worst, abs(got4[1] - ld) / max(1.0, abs(ld)))
+        return ""
+
+    for g, (sol, info) in enumerate(res):
+        if info["status"] == "solver error":
+            return tag, float("inf"), f"point {g}: solver error {info.get('error')}"
+        sel = info["selection"]
+        bad = cmp([sel["Sdot"], sel["logdet"], sel["nnz"], sel["lambda_min"]], sol["Theta"], f"point {g}")
+        if bad:
+            return tag, float("inf"), bad
+        if latent:
+            sv = np.linalg.svd(sol["L"], compute_uv=False)
+            cut = sv.max() * p * np.finfo(float).eps if sv.size else 0.0
+            clear = not np.any((sv > cut / 30) & (sv < cut * 30))       # (a singular value AT numpy's cut is anybody's call)
+            if clear and int(sel["rank"]) != int(np.linalg.matrix_rank(sol["L"])):
+                return tag, float("inf"), f"point {g}: rank {sel['rank']} vs {np.linalg.matrix_rank(sol['L'])}"
+        if tau is not None:
+            tab = np.asarray(sel["threshold"])
+            for t in range(len(tau)):
+                Tt = sol["Theta"] * ((np.abs(sol["Theta"]) > tau[t]) | np.eye(p, dtype=bool))
+                bad = cmp(tab[t], Tt, f"point {g}, tau {tau[t]:.3g}")
+                if bad:
+                    return tag, float("inf"), bad
+    return tag, worst, ""
+
+
 def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     """Runs ``cases`` cases of the stream ``seed``; returns (cases off, last-bit stopping notes, largest deviation of the rest).
-    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind``: "solver" (one), "batch" (one_batch), "block" (one_block), "ext" (one_ext), "ops" (one_ops)."""
+    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind``: "solver" (one), "batch" (one_batch), "block" (one_block), "ext" (one_ext), "ops" (one_ops), "stats" (one_stats)."""
     global PBIG
     rng = np.random.default_rng(seed)
     keep, bad, notes, mx = PBIG, 0, 0, 0.0
@@ -354,7 +415,7 @@ def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     try:
         for i in range(cases):
             try:
-                tag, worst, note = {"batch": one_batch, "block": one_block, "ext": one_ext, "ops": one_ops}.get(kind, one)(i, rng)
+                tag, worst, note = {"batch": one_batch, "block": one_block, "ext": one_ext, "ops": one_ops, "stats": one_stats}.get(kind, one)(i, rng)
             except Exception as e:                                      # a crash is a finding too
                 out(f"case {i}: raised {type(e).__name__}: {e}")
                 bad += 1

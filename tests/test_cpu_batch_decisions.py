@@ -195,3 +195,16 @@ def test_a_rebuilt_latent_component_that_differs_from_the_iterations_is_reported
 
     rk2, bad2 = batch._final_L(Eng2(), sols2, 1)
     assert bad2 == [0] and rk2.tolist() == [-1]
+    # an L that is exactly zero comes out of the sign iteration as noise relative to the step's INPUT, not to L (found by the
+    # randomised sweep, tools/fuzz_parity.py 200 71 stats, case 142: 3.9e-12 at p = 16): consistent, and replaced by the zeros
+    sols3 = [{'L': 4e-12 * (noise[0] + noise[0].T) / 1e-13, 'Theta': 30.0 * np.eye(p)}]
+
+    class Eng3:
+        def finalize_L(self, which):
+            return 1, np.array([0], dtype=np.int32)
+
+        def snapshot_L_k(self, i):
+            return np.zeros((p, p))
+
+    rk3, bad3 = batch._final_L(Eng3(), sols3, 1)
+    assert bad3 == [] and rk3.tolist() == [0] and not sols3[0]['L'].any()

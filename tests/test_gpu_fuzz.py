@@ -26,13 +26,15 @@ def test_random_grids_through_the_batch_drivers_against_the_oracle():
     assert worst <= fuzz_checks.TOL
 
 
-@pytest.mark.parametrize("kind,cases,seed", [("block", 60, 43), ("ext", 40, 53), ("ops", 60, 63)])
+@pytest.mark.parametrize("kind,cases,seed", [("block", 60, 43), ("ext", 40, 53), ("ops", 60, 63), ("stats", 40, 73)])
 def test_random_block_and_nonconforming_problems_against_the_oracle(kind, cases, seed):
     """block_SGL on covariance matrices with planted components of very different size (singletons to 70, all solved together
     on the GPU; solver/single_admm_solver.py:326-475) and ext_ADMM_MGL on K = 2 .. 5 instances of different dimension with a
     random group structure (solver/ext_admm_solver.py:18-323), each against the oracle; the operators on their own (phiplus /
     prox_rank_norm from the matrix on stacks with engineered spectra -- seven decades, exact repeats, zeros, one sign, instances of
-    very different conditioning in one stack -- and prox_p with ties and exact zeros across K; solver/ggl_helper.py)."""
+    very different conditioning in one stack -- and prox_p with ties and exact zeros across K; solver/ggl_helper.py); the device's selection statistics
+    (<S,Theta>, log det, count_nonzero, lambda_min, rank of L, the thresholded tables; helper/model_selection.py:619-660, 698-737)
+    against numpy on the solutions a random latent / non-latent grid returns."""
     lines = []
     bad, notes, worst = fuzz_checks.run_cases(cases, seed, out=lines.append, kind=kind)
     assert bad == 0, "\n".join(lines)
