@@ -404,9 +404,203 @@ def one_stats(i, rng):
     return tag, worst, ""
 
 
+def one_grid(i, rng):
+    """single_grid_search (helper/model_selection.py:505-692) on a random (lambda1, mu1) grid -- all points one batch, tables from
+    the device statistics -- against the same tables built on the host (numpy formulas of _grid_tables' point-by-point branch)
+    from the oracle's independent solve of every point from the reference's start Omega_0 = X_0 = I (:595-596)."""
+    from gglasso_amd import model_selection as ms, synth
+    from oracle import ggl_oracle as orc
+    p = int(rng.choice([q for q in P if 3 <= q <= 97]))
+    nl, latent = int(rng.integers(1, 6)), bool(rng.random() < 0.5)
+    nm = int(rng.integers(1, 4)) if latent else 1
+    lam = np.sort(10.0 ** rng.uniform(-1.8, -0.2, nl))[::-1].copy()
+    mu = np.sort(10.0 ** rng.uniform(-0.3, 0.8, nm))[::-1].copy() if latent else None
+    method = "eBIC" if rng.random() < 0.6 else "AIC"
+    gamma = float(rng.choice([0.1, 0.3, 0.5, 0.7, 0.25]))
+    thr = bool(rng.random() < 0.4)
+    tol = float(10.0 ** rng.uniform(-9, -7))
+    Ns = int(rng.integers(p, 4 * p + 5))
+    S, _ = synth.make_problem("GGL", 1, p, N=Ns, seed=int(rng.integers(1 << 30)))
+    S = S[0]
+    tag = dict(i=i, kind="grid", p=p, nl=nl, nm=nm, latent=latent, method=method, gamma=gamma, thresholding=thr, tol=tol, N=Ns)
+    LAST.clear()
+    LAST.update(S=S, lam=lam, mu=mu, latent=latent, method=method, gamma=gamma, thr=thr, tol=tol, N=Ns)
+    best, est, low, st = quiet(ms.single_grid_search, S, lam, Ns, method=method, gamma=gamma, latent=latent, mu_range=mu,
+                               thresholding=thr, tol=tol, rtol=tol)
+    sols = []
+    eye = np.eye(p)
+    for j in range(nl):
+        for m in range(nm):
+            kw = dict(latent=True, mu1=float(mu[m])) if latent else {}
+            sol, _ = quiet(orc.ADMM_SGL, S, float(lam[j]), eye, X_0=eye, tol=tol, rtol=tol, max_iter=1000, **kw)
+            sols.append(sol)
+    mu_r = mu if latent else np.array([0])
+    gammas = sorted(set(ms.DEFAULT_GAMMAS) | {gamma})
+    rbest, rest, rlow, rst = ms._grid_tables(S, Ns, sols, None, lam, mu_r, latent, method, gamma, gammas, True, None, thr)
+    loose = max(TOL, 100 * tol)                       # (a point that stops one iteration apart is off by about its tolerance)
+    d_est = float(np.abs(est - rest).max()) / max(1.0, float(np.abs(rest).max()))
+    if d_est > loose:
+        return tag, float("inf"), f"estimates differ by {d_est:.2e}"
+    if latent:
+        d_low = float(np.abs(low - rlow).max()) / max(1.0, float(np.abs(rest).max()))
+        if d_low > loose:
+            return tag, float("inf"), f"lowrank differs by {d_low:.2e}"
+    if thr and not np.array_equal(st["TAU"], rst["TAU"]):
+        return tag, 0.0, "iterations: another threshold chosen at a point (scores of two candidates within the solve's tolerance)"
+    if not np.array_equal(st["SP"], rst["SP"]):
+        return tag, 0.0, "iterations: zero pattern differs at a point (an entry at the threshold to the last bits)"
+    worst = 0.0
+    for a, b, nm_ in [(st["AIC"], rst["AIC"], "AIC")] + [(st["BIC"][g], rst["BIC"][g], f"BIC[{g}]") for g in gammas]:
+        if not np.array_equal(np.isnan(a), np.isnan(b)):
+            return tag, float("inf"), f"{nm_}: NaN pattern differs"
+        ok = ~np.isnan(b)
+        if ok.any():
+            # (the fit term N (<S,Theta> - log det Theta) inherits the solve's tolerance times N p)
+            worst_t = float(np.max(np.abs(a[ok] - b[ok]) / np.maximum(1.0, np.abs(b[ok]))))
+            if worst_t > max(1e-7, 1e3 * tol):
+                return tag, float("inf"), f"{nm_} differs by {worst_t:.2e}"
+    if latent and not np.array_equal(st["RANK"], rst["RANK"]):
+        # numpy's rule on a singular value at its cut is anybody's call; anything else is a finding
+        for j in range(nl):
+            for m in range(nm):
+                if st["RANK"][j, m] != rst["RANK"][j, m]:
+                    sv = np.linalg.svd(rlow[j, m], compute_uv=False)
+                    cut = sv.max() * p * np.finfo(float).eps
+                    if not np.any((sv > cut / 1e3) & (sv < cut * 1e3)):
+                        return tag, float("inf"), f"RANK[{j},{m}] {st['RANK'][j, m]} vs {rst['RANK'][j, m]}"
+        return tag, 0.0, "iterations: rank differs at a singular value within 1e3 of numpy's cut"
+    if [float(st["BEST"]["lambda1"]), float(st["BEST"]["mu1"])] != [float(rst["BEST"]["lambda1"]), float(rst["BEST"]["mu1"])]:
+        tab = rst["AIC"] if method == "AIC" else rst["BIC"][gamma]
+        two = np.sort(tab[~np.isnan(tab)])[:2]
+        if len(two) == 2 and abs(two[1] - two[0]) <= 1e-6 * max(1.0, abs(two[0])):
+            return tag, 0.0, "iterations: best point differs between two scores that tie"
+        return tag, float("inf"), f"BEST {st['BEST']} vs {rst['BEST']}"
+    d_best = float(np.abs(best["Theta"] - rbest["Theta"]).max()) / max(1.0, float(np.abs(rbest["Theta"]).max()))
+    if d_best > loose or set(best) != set(rbest):
+        return tag, float("inf"), f"best_sol differs by {d_best:.2e} or in its keys {sorted(best)} vs {sorted(rbest)}"
+    return tag, min(d_est, TOL), ""
+
+
+def one_isolate(i, rng):
+    """A grid in which some points' data are not finite (a NaN / Inf somewhere in their S, as a failed upstream estimate leaves
+    it): those points end as 'solver error', and every OTHER point's result is what the grid without them returns (to rounding: the
+    Omega-step's schedule is planned per batch, so the two runs differ in the last bits) -- the reference's sequential walk would
+    lose the bad point only (helper/model_selection.py:619-633).  Latent on / off, compaction on / off."""
+    from gglasso_amd import batch, synth
+    p = int(rng.choice([q for q in P if 2 <= q <= 97]))
+    single, K, reg = True, 1, "GGL"       # (the multiple-graph drivers share one S between the points: nothing to poison per point)
+    G = int(rng.integers(2, 9))
+    latent = bool(rng.random() < 0.5)
+    lam1 = 10.0 ** rng.uniform(-2.0, 0.0, G)
+    mu = 10.0 ** rng.uniform(-0.5, 0.7, G)
+    tol = float(10.0 ** rng.uniform(-8, -6))
+    compact = bool(rng.random() < 0.7)
+    nbad = int(rng.integers(1, max(2, G // 2 + 1)))
+    bad = np.sort(rng.choice(G, size=nbad, replace=False))
+    good = np.array([g for g in range(G) if g not in set(bad.tolist())])
+    tag = dict(i=i, kind="isolate", p=p, K=K, G=G, latent=latent, reg=reg if not single else "SGL", bad=bad.tolist(), compact=compact)
+    if single:
+        Sg = np.repeat(synth.make_problem("GGL", 1, p, seed=int(rng.integers(1 << 30)))[0], G, axis=0)        # (G,p,p), one S per point
+        Sp = Sg.copy()
+        for g in bad:
+            a, b = int(rng.integers(p)), int(rng.integers(p))
+            Sp[g, a, b] = Sp[g, b, a] = rng.choice([np.nan, np.inf, -np.inf])
+        LAST.clear()
+        LAST.update(S=Sp, lam1=lam1, mu=mu, latent=latent, tol=tol, compact=compact)
+        kw = dict(Omega_0=np.eye(p), X_0=np.zeros((p, p)), tol=tol, rtol=tol, max_iter=300, latent=latent, compact=compact)
+        res = quiet(batch.ADMM_SGL_batch, Sp, lam1, mu1=mu if latent else None, **kw)
+        ref = quiet(batch.ADMM_SGL_batch, Sg[good], lam1[good], mu1=mu[good] if latent else None, **kw) if len(good) else []
+    worst, note = 0.0, ""
+    for g in bad:
+        if res[g][1]["status"] != "solver error":
+            return tag, float("inf"), f"poisoned point {g} ended as {res[g][1]['status']!r}"
+    for n, g in enumerate(good):
+        (sol, info), (rsol, rinfo) = res[g], ref[n]
+        if info["iterations"] != rinfo["iterations"]:
+            if abs(info["iterations"] - rinfo["iterations"]) > 1:
+                return tag, float("inf"), f"point {g}: {info['iterations']} iterations vs {rinfo['iterations']}"
+            note = f"iterations {info['iterations']} vs {rinfo['iterations']} at point {g}"
+            continue
+        if info["status"] != rinfo["status"]:
+            return tag, float("inf"), f"point {g}: {info['status']!r} vs {rinfo['status']!r}"
+        for nm in rsol:
+            a, b = np.asarray(sol[nm]), np.asarray(rsol[nm])
+            if not np.all(np.isfinite(a)):
+                return tag, float("inf"), f"point {g}: {nm} not finite"
+            worst = max(worst, float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max())))
+    return tag, worst, note
+
+
+def one_mgrid(i, rng):
+    """grid_search (helper/model_selection.py:55-298) for the multiple-graph problems: the whole lambda1 x lambda2 grid as one
+    batch with the device's statistics, against the same function walking the grid point by point with the criteria on the host
+    and the ORACLE's ADMM_MGL as its solver -- started from the identity at every point like the batch (the reference's warm
+    start, :224, is another path to the same optimum: it moves a point by up to 1e4 x the stopping tolerance where ADMM
+    converges slowly, which would hide everything this comparison is for)."""
+    from gglasso_amd import model_selection as ms, solver, synth
+    from oracle import ggl_oracle as orc
+    p = int(rng.choice([5, 8, 9, 15, 16, 17, 23, 31, 33, 47]))
+    K = int(rng.integers(2, 5))
+    reg = "GGL" if rng.random() < 0.5 else "FGL"
+    n1, n2 = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    l1 = np.sort(10.0 ** rng.uniform(-1.5, -0.3, n1))[::-1].copy()
+    use_w2 = bool(rng.random() < 0.5)
+    l2 = None if use_w2 else np.sort(10.0 ** rng.uniform(-2.0, -0.5, n2))[::-1].copy()
+    w2 = np.sort(rng.uniform(0.05, 0.6, n2)) if use_w2 else None
+    latent = bool(rng.random() < 0.4)
+    thr = bool(rng.random() < 0.3)
+    method = "eBIC" if rng.random() < 0.6 else "AIC"
+    gamma = float(rng.choice([0.1, 0.3, 0.5]))
+    tol = float(10.0 ** rng.uniform(-9, -7))
+    Nk = rng.integers(p, 4 * p + 5, K)
+    S, _ = synth.make_problem(reg, K, p, N=int(Nk.max()), seed=int(rng.integers(1 << 30)))
+    kw = dict(method=method, gamma=gamma, latent=latent, thresholding=thr, tol=tol, rtol=tol)
+    if latent:
+        nmu = int(rng.integers(1, 4))
+        kw["mu_range"] = np.sort(10.0 ** rng.uniform(-0.3, 0.7, nmu))[::-1].copy()
+        kw["ix_mu"] = rng.integers(0, nmu, (K, n1))          # one mu1 per instance and lambda1 column (model_selection.py:96-99)
+    tag = dict(i=i, kind="mgrid", p=p, K=K, reg=reg, n1=n1, n2=n2, w2=use_w2, latent=latent, thresholding=thr, method=method,
+               gamma=gamma, tol=tol)
+    LAST.clear()
+    LAST.update(S=S, N=Nk, l1=l1, l2=l2, w2=w2, reg=reg, **{k: v for k, v in kw.items()})
+    st, ix, best = quiet(ms.grid_search, solver.ADMM_MGL, S, Nk, p, reg, l1, l2=l2, w2=w2, **kw)
+    eyeK = np.repeat(np.eye(p)[None], K, axis=0)
+
+    def cold(**a):
+        a["Omega_0"] = eyeK.copy()
+        return orc.ADMM_MGL(**a)
+
+    rst, rix, rbest = quiet(ms.grid_search, cold, S, Nk, p, reg, l1, l2=l2, w2=w2, batched=False, **kw)
+    loose = max(TOL, 100 * tol)            # (a point that stops one iteration apart is off by about its tolerance)
+    if thr and not np.array_equal(st["TAU"], rst["TAU"]):
+        return tag, 0.0, "iterations: another threshold chosen at a point"
+    if not np.array_equal(st["SP"], rst["SP"]):
+        return tag, 0.0, "iterations: zero pattern differs at a point"
+    for nm_ in ["AIC"] + [("BIC", g) for g in sorted(rst["BIC"])]:
+        a = st[nm_] if isinstance(nm_, str) else st[nm_[0]][nm_[1]]
+        b = rst[nm_] if isinstance(nm_, str) else rst[nm_[0]][nm_[1]]
+        if not np.array_equal(np.isnan(a), np.isnan(b)):
+            return tag, float("inf"), f"{nm_}: NaN pattern differs"
+        ok = ~np.isnan(b)
+        if ok.any() and float(np.max(np.abs(a[ok] - b[ok]) / np.maximum(1.0, np.abs(b[ok])))) > max(1e-6, 1e4 * tol):
+            return tag, float("inf"), f"{nm_} differs by {float(np.max(np.abs(a[ok] - b[ok]) / np.maximum(1.0, np.abs(b[ok])))):.2e}"
+    if latent and not np.array_equal(st["RANK"], rst["RANK"]):
+        return tag, 0.0, "iterations: rank differs at a point (an eigenvalue of L at the cut to the solve's tolerance)"
+    if tuple(np.atleast_1d(ix).tolist()) != tuple(np.atleast_1d(rix).tolist()):
+        tab = rst["AIC"] if method == "AIC" else rst["BIC"][gamma]
+        two = np.sort(tab[~np.isnan(tab)])[:2]
+        if len(two) == 2 and abs(two[1] - two[0]) <= 1e-5 * max(1.0, abs(two[0])):
+            return tag, 0.0, "iterations: best point differs between two scores that tie"
+        return tag, float("inf"), f"best index {ix} vs {rix}"
+    d = float(np.abs(best["Theta"] - rbest["Theta"]).max()) / max(1.0, float(np.abs(rbest["Theta"]).max()))
+    if d > loose:
+        return tag, float("inf"), f"best Theta differs by {d:.2e}"
+    return tag, min(d, TOL), ""
+
+
 def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     """Runs ``cases`` cases of the stream ``seed``; returns (cases off, last-bit stopping notes, largest deviation of the rest).
-    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind``: "solver" (one), "batch" (one_batch), "block" (one_block), "ext" (one_ext), "ops" (one_ops), "stats" (one_stats)."""
+    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind``: "solver" (one), "batch" (one_batch), "block" (one_block), "ext" (one_ext), "ops" (one_ops), "stats" (one_stats), "grid" (one_grid), "isolate" (one_isolate), "mgrid" (one_mgrid)."""
     global PBIG
     rng = np.random.default_rng(seed)
     keep, bad, notes, mx = PBIG, 0, 0, 0.0
@@ -415,7 +609,7 @@ def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     try:
         for i in range(cases):
             try:
-                tag, worst, note = {"batch": one_batch, "block": one_block, "ext": one_ext, "ops": one_ops, "stats": one_stats}.get(kind, one)(i, rng)
+                tag, worst, note = {"batch": one_batch, "block": one_block, "ext": one_ext, "ops": one_ops, "stats": one_stats, "grid": one_grid, "isolate": one_isolate, "mgrid": one_mgrid}.get(kind, one)(i, rng)
             except Exception as e:                                      # a crash is a finding too
                 out(f"case {i}: raised {type(e).__name__}: {e}")
                 bad += 1

@@ -26,7 +26,8 @@ def test_random_grids_through_the_batch_drivers_against_the_oracle():
     assert worst <= fuzz_checks.TOL
 
 
-@pytest.mark.parametrize("kind,cases,seed", [("block", 60, 43), ("ext", 40, 53), ("ops", 60, 63), ("stats", 40, 73)])
+@pytest.mark.parametrize("kind,cases,seed", [("block", 60, 43), ("ext", 40, 53), ("ops", 60, 63), ("stats", 40, 73), ("grid", 25, 83),
+                                              ("isolate", 40, 93), ("mgrid", 40, 103)])
 def test_random_block_and_nonconforming_problems_against_the_oracle(kind, cases, seed):
     """block_SGL on covariance matrices with planted components of very different size (singletons to 70, all solved together
     on the GPU; solver/single_admm_solver.py:326-475) and ext_ADMM_MGL on K = 2 .. 5 instances of different dimension with a
@@ -34,7 +35,9 @@ def test_random_block_and_nonconforming_problems_against_the_oracle(kind, cases,
     prox_rank_norm from the matrix on stacks with engineered spectra -- seven decades, exact repeats, zeros, one sign, instances of
     very different conditioning in one stack -- and prox_p with ties and exact zeros across K; solver/ggl_helper.py); the device's selection statistics
     (<S,Theta>, log det, count_nonzero, lambda_min, rank of L, the thresholded tables; helper/model_selection.py:619-660, 698-737)
-    against numpy on the solutions a random latent / non-latent grid returns."""
+    against numpy on the solutions a random latent / non-latent grid returns; single_grid_search and grid_search
+    (helper/model_selection.py:505-692, 55-298) on random grids against the host tables of the oracle's point-by-point solves;
+    grids with poisoned points (NaN / Inf in their S): those end as 'solver error', the others are the grid's without them."""
     lines = []
     bad, notes, worst = fuzz_checks.run_cases(cases, seed, out=lines.append, kind=kind)
     assert bad == 0, "\n".join(lines)
