@@ -48,6 +48,21 @@ def one(i, rng):
     tag = dict(i=i, p=p, K=K, reg=reg if not single else "SGL", latent=latent, lam1=round(lam1, 5), lam2=round(lam2, 5),
                mu1=round(mu1, 4), rho=round(rho, 4), upd=upd, iters=iters, tol=tol, rtol=rtol)
     kw = dict(max_iter=iters, tol=tol, rtol=rtol, rho=rho, update_rho=upd, latent=latent, measure=True)
+    # a third of the cases start from somewhere else: Omega_0 positive definite, Theta_0 another matrix, X_0 a symmetric dual
+    warm = bool(rng.random() < 0.33)
+    starts = None
+    if warm:
+        def spd():
+            A = rng.standard_normal((K, p, p + 2))
+            return A @ A.transpose(0, 2, 1) / (p + 2) + 0.1 * np.eye(p)
+        X0 = rng.standard_normal((K, p, p)) * 0.1
+        starts = (spd(), spd(), 0.5 * (X0 + X0.transpose(0, 2, 1)))
+        tag["warm"] = True
+    # (the KKT criterion: eta_A <= tol decides, admm_solver.py:197-204 / single_admm_solver.py:199-206)
+    if conv and rng.random() < 0.3:
+        kw["stopping_criterion"] = "kkt"
+        kw["tol"] = tol = float(10.0 ** rng.uniform(-6, -3))
+        tag.update(kkt=True, tol=tol)
     LAST.clear()
     LAST.update(S=S, lam1=lam1, lam2=lam2, single=single, reg=reg, **{k: v for k, v in kw.items() if k != "measure"})
     if latent:
@@ -58,12 +73,19 @@ def one(i, rng):
             M = rng.random((p, p)) < 0.6
             kw["lambda1_mask"] = ((M | M.T) * rng.uniform(0.5, 2.0)).astype(float)
             tag["mask"] = True
-        ref, rinfo = quiet(orc.ADMM_SGL, S[0], lam1, eye, **kw)
-        got, ginfo = quiet(solver.ADMM_SGL, S[0], lam1, eye, **kw)
+        if warm:
+            eye, kw["Theta_0"], kw["X_0"] = starts[0][0], starts[1][0], starts[2][0]
+        ref, rinfo = quiet(orc.ADMM_SGL, S[0], lam1, eye.copy(), **{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+        got, ginfo = quiet(solver.ADMM_SGL, S[0], lam1, eye.copy(), **{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
     else:
         eye = np.repeat(np.eye(p)[None], K, axis=0)
-        ref, rinfo = quiet(orc.ADMM_MGL, S, lam1, lam2, reg, eye, **kw)
-        got, ginfo = quiet(solver.ADMM_MGL, S, lam1, lam2, reg, eye, **kw)
+        if warm:
+            eye, kw["Theta_0"], kw["X_0"] = starts
+        if rng.random() < 0.3:
+            kw["n_samples"] = rng.integers(5, 500, K)               # the weights of the log-likelihood terms (admm_solver.py:127-134)
+            tag["n_samples"] = True
+        ref, rinfo = quiet(orc.ADMM_MGL, S, lam1, lam2, reg, eye.copy(), **{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+        got, ginfo = quiet(solver.ADMM_MGL, S, lam1, lam2, reg, eye.copy(), **{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
     worst = 0.0
     # past convergence with tol = 1e-20 the residuals are rounding noise and so are the rho updates they decide (r > 10 s or
     # s > 10 r, admm_solver.py:186-195): the two runs then scale the dual differently -- X = (unscaled dual) / rho is compared
