@@ -426,6 +426,19 @@ def one_stats(i, rng):
     return tag, worst, ""
 
 
+def _pattern_note(aic, raic, what="zero pattern"):
+    """Two tables whose zero patterns differ: a last-bit matter only if the fit terms agree, i.e. the AIC tables differ by
+    whole edges (an entry whose prox input sits AT the threshold -- a weakly active entry, e.g. of a group the group
+    penalty has zeroed in ext_ADMM_MGL, where ADMM's dual ends on the boundary of its feasible set -- is +-1 ulp in one
+    evaluation and exactly zero in another: 2^-58 .. 2^-56 seen).  Anything else is a finding."""
+    ok = ~(np.isnan(aic) | np.isnan(raic))
+    d = 2.0 * (aic[ok] - raic[ok])          # in half edges: the oracle's Theta (like the reference's) is not bitwise symmetric -- its
+    # Omega is Q diag Q^T from a matrix product -- so ONE of a pair (i,j), (j,i) can pass the threshold by an ulp; ours is symmetric
+    if np.all(np.abs(d - np.round(d)) <= 2e-5 * np.maximum(1.0, np.abs(raic[ok]))):
+        return 0.0, f"iterations: {what} differs by entries at the threshold (last bit): {int(np.abs(np.round(d)).sum())} entries in the table"
+    return float("inf"), f"{what} differs and the AIC tables are not whole entries apart (max fractional part {float(np.max(np.abs(d - np.round(d)))) / 2:.2e})"
+
+
 def one_grid(i, rng):
     """single_grid_search (helper/model_selection.py:505-692) on a random (lambda1, mu1) grid -- all points one batch, tables from
     the device statistics -- against the same tables built on the host (numpy formulas of _grid_tables' point-by-point branch)
@@ -470,7 +483,7 @@ def one_grid(i, rng):
     if thr and not np.array_equal(st["TAU"], rst["TAU"]):
         return tag, 0.0, "iterations: another threshold chosen at a point (scores of two candidates within the solve's tolerance)"
     if not np.array_equal(st["SP"], rst["SP"]):
-        return tag, 0.0, "iterations: zero pattern differs at a point (an entry at the threshold to the last bits)"
+        return (tag,) + _pattern_note(st["AIC"], rst["AIC"])
     worst = 0.0
     for a, b, nm_ in [(st["AIC"], rst["AIC"], "AIC")] + [(st["BIC"][g], rst["BIC"][g], f"BIC[{g}]") for g in gammas]:
         if not np.array_equal(np.isnan(a), np.isnan(b)):
@@ -597,7 +610,7 @@ def one_mgrid(i, rng):
     if thr and not np.array_equal(st["TAU"], rst["TAU"]):
         return tag, 0.0, "iterations: another threshold chosen at a point"
     if not np.array_equal(st["SP"], rst["SP"]):
-        return tag, 0.0, "iterations: zero pattern differs at a point"
+        return (tag,) + _pattern_note(st["AIC"], rst["AIC"])
     for nm_ in ["AIC"] + [("BIC", g) for g in sorted(rst["BIC"])]:
         a = st[nm_] if isinstance(nm_, str) else st[nm_[0]][nm_[1]]
         b = rst[nm_] if isinstance(nm_, str) else rst[nm_[0]][nm_[1]]
@@ -620,9 +633,149 @@ def one_mgrid(i, rng):
     return tag, min(d, TOL), ""
 
 
+def one_kgrid(i, rng):
+    """K_single_grid (helper/model_selection.py:300-503): K independent single problems on one (lambda1, mu1) grid, all K x L x M
+    points one batch -- against the host tables of the oracle's point-by-point solves and the selection rules (:443-466)
+    restated here: best mu1 per instance and lambda1, then the best lambda1 uniformly and per instance."""
+    from gglasso_amd import model_selection as ms, synth
+    from oracle import ggl_oracle as orc
+    p = int(rng.choice([q for q in P if 3 <= q <= 66]))
+    K = int(rng.integers(2, 5))
+    nl, latent = int(rng.integers(1, 5)), bool(rng.random() < 0.5)
+    nm = int(rng.integers(1, 4)) if latent else 1
+    lam = np.sort(10.0 ** rng.uniform(-1.8, -0.2, nl))[::-1].copy()
+    mu = np.sort(10.0 ** rng.uniform(-0.3, 0.8, nm))[::-1].copy() if latent else None
+    method = "eBIC" if rng.random() < 0.6 else "AIC"
+    gamma = float(rng.choice([0.1, 0.3, 0.5]))
+    thr = bool(rng.random() < 0.3)
+    tol = float(10.0 ** rng.uniform(-9, -7))
+    Nk = rng.integers(p, 4 * p + 5, K)
+    S, _ = synth.make_problem("GGL", K, p, N=int(Nk.max()), seed=int(rng.integers(1 << 30)))
+    tag = dict(i=i, kind="kgrid", p=p, K=K, nl=nl, nm=nm, latent=latent, method=method, gamma=gamma, thresholding=thr, tol=tol)
+    LAST.clear()
+    LAST.update(S=S, N=Nk, lam=lam, mu=mu, latent=latent, method=method, gamma=gamma, thr=thr, tol=tol)
+    est_u, est_i, st = quiet(ms.K_single_grid, S, lam, Nk, method=method, gamma=gamma, latent=latent, mu_range=mu,
+                             thresholding=thr, tol=tol, rtol=tol)
+    mu_r = mu if latent else np.array([0])
+    gammas = sorted(set(ms.DEFAULT_GAMMAS) | {gamma})
+    eye = np.eye(p)
+    tabs, ests, lows, bests = [], [], [], []
+    for k in range(K):
+        sols = []
+        for j in range(nl):
+            for m in range(nm):
+                kw = dict(latent=True, mu1=float(mu[m])) if latent else {}
+                sols.append(quiet(orc.ADMM_SGL, S[k], float(lam[j]), eye, X_0=eye, tol=tol, rtol=tol, max_iter=1000, **kw)[0])
+        rb, re, rl, rs = ms._grid_tables(S[k], Nk[k], sols, None, lam, mu_r, latent, method, gamma, gammas, True, None, thr)
+        tabs.append(rs); ests.append(re); lows.append(rl); bests.append(rb)
+    if not np.array_equal(st["SP"], np.stack([t["SP"] for t in tabs])):
+        if thr:                 # (another threshold chosen between two candidates that score alike moves the fit terms too)
+            return tag, 0.0, "iterations: zero pattern or chosen threshold differs at a point"
+        return (tag,) + _pattern_note(st["AIC"], np.stack([t["AIC"] for t in tabs]))
+    for nm_, ref in (("AIC", np.stack([t["AIC"] for t in tabs])), ("BIC", np.stack([t["BIC"][gamma] for t in tabs]))):
+        a = st[nm_]
+        if not np.array_equal(np.isnan(a), np.isnan(ref)):
+            return tag, float("inf"), f"{nm_}: NaN pattern differs"
+        ok = ~np.isnan(ref)
+        dev = float(np.max(np.abs(a[ok] - ref[ok]) / np.maximum(1.0, np.abs(ref[ok])))) if ok.any() else 0.0
+        if dev > max(1e-7, 1e3 * tol):
+            return tag, float("inf"), f"{nm_} differs by {dev:.2e}"
+    if latent and not np.array_equal(st["RANK"], np.stack([t["RANK"] for t in tabs])):
+        return tag, 0.0, "iterations: rank differs at a point (a singular value at numpy's cut)"
+    # the selection (:443-466) from the REFERENCE tables; a tie (two scores within 1e-6) makes the index anybody's call
+    table = np.stack([t["AIC"] if method == "AIC" else t["BIC"][gamma] for t in tabs])
+    ix_mu = np.array([[np.nanargmin(table[k, j]) for j in range(nl)] for k in range(K)])
+    score = np.take_along_axis(table, ix_mu[:, :, None], axis=2)[:, :, 0]
+
+    def tied(v):
+        w = np.sort(v[~np.isnan(v)])
+        return len(w) > 1 and abs(w[1] - w[0]) <= 1e-6 * max(1.0, abs(w[0]))
+
+    if any(tied(table[k, j]) for k in range(K) for j in range(nl)) or tied(score.sum(axis=0)) or any(tied(score[k]) for k in range(K)):
+        return tag, 0.0, "iterations: a selection between two scores that tie"
+    if not (np.array_equal(st["ix_mu"], ix_mu) and int(st["ix_uniform"]) == int(np.nanargmin(score.sum(axis=0)))
+            and np.array_equal(st["ix_indv"], np.nanargmin(score, axis=1))):
+        return tag, float("inf"), f"selection differs: ix_mu {st['ix_mu'].tolist()} ix_uniform {st['ix_uniform']} ix_indv {st['ix_indv'].tolist()}"
+    loose = max(TOL, 100 * tol)
+    ju = int(st["ix_uniform"])
+    worst = 0.0
+    for k in range(K):
+        ru = ests[k][ju, ix_mu[k, ju]]
+        worst = max(worst, float(np.abs(est_u["Theta"][k] - ru).max()) / max(1.0, float(np.abs(ru).max())),
+                    float(np.abs(est_i["Theta"][k] - bests[k]["Theta"]).max()) / max(1.0, float(np.abs(bests[k]["Theta"]).max())))
+        if latent:
+            worst = max(worst, float(np.abs(est_u["L"][k] - lows[k][ju, ix_mu[k, ju]]).max()), float(np.abs(est_i["L"][k] - bests[k]["L"]).max()))
+    if worst > loose:
+        return tag, float("inf"), f"estimates differ by {worst:.2e}"
+    return tag, min(worst, TOL), ""
+
+
+def one_egrid(i, rng):
+    """grid_search with ext_ADMM_MGL (instances of different dimension, helper/model_selection.py:55-298 with dict S and G): the
+    grid as one padded batch (ext_ADMM_MGL_batch) against the point-by-point walk with the ORACLE's ext_ADMM_MGL from the identity
+    start at every point."""
+    from gglasso_amd import model_selection as ms
+    from gglasso_amd.ext_solver import ext_ADMM_MGL
+    from oracle import ggl_oracle as orc
+    K = int(rng.integers(2, 5))
+    universe = int(rng.choice([6, 9, 14, 20, 30]))
+    sizes = [int(rng.integers(max(2, universe // 2), universe + 1)) for _ in range(K)]
+    made = _nonconforming(rng, universe, sizes, prob=float(rng.uniform(0.05, 0.3)))
+    tag = dict(i=i, kind="egrid", K=K, universe=universe, sizes=sizes)
+    if made is None:
+        return tag, 0.0, ""
+    S, G, p = made
+    n1, n2 = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    l1 = np.sort(10.0 ** rng.uniform(-1.5, -0.3, n1))[::-1].copy()
+    l2 = np.sort(10.0 ** rng.uniform(-2.0, -0.5, n2))[::-1].copy()
+    latent = bool(rng.random() < 0.4)
+    method = "eBIC" if rng.random() < 0.6 else "AIC"
+    gamma = float(rng.choice([0.1, 0.3, 0.5]))
+    tol = float(10.0 ** rng.uniform(-8, -6))
+    Nk = np.array([3 * n + 2 for n in p])
+    kw = dict(method=method, gamma=gamma, latent=latent, tol=tol, rtol=tol, G=G)
+    if latent:
+        nmu = int(rng.integers(1, 3))
+        kw["mu_range"] = np.sort(10.0 ** rng.uniform(-0.3, 0.7, nmu))[::-1].copy()
+        kw["ix_mu"] = rng.integers(0, nmu, (K, n1))
+    tag.update(n1=n1, n2=n2, latent=latent, method=method, gamma=gamma, tol=tol)
+    LAST.clear()
+    LAST.update(G=G, N=Nk, l1=l1, l2=l2, **{f"S_{k}": S[k] for k in range(K)}, **{k: v for k, v in kw.items() if k != "G"})
+
+    def cold(**a):
+        a["Omega_0"] = {k: np.eye(p[k]) for k in range(K)}
+        return orc.ext_ADMM_MGL(**a)
+
+    st, ix, best = quiet(ms.grid_search, ext_ADMM_MGL, S, Nk, p, "GGL", l1, l2=l2, **kw)
+    rst, rix, rbest = quiet(ms.grid_search, cold, S, Nk, p, "GGL", l1, l2=l2, batched=False, **kw)
+    if not np.array_equal(st["SP"], rst["SP"]):
+        return (tag,) + _pattern_note(st["AIC"], rst["AIC"])
+    for nm_ in ["AIC"] + [("BIC", g) for g in sorted(rst["BIC"])]:
+        a = st[nm_] if isinstance(nm_, str) else st[nm_[0]][nm_[1]]
+        b = rst[nm_] if isinstance(nm_, str) else rst[nm_[0]][nm_[1]]
+        if not np.array_equal(np.isnan(a), np.isnan(b)):
+            return tag, float("inf"), f"{nm_}: NaN pattern differs"
+        ok = ~np.isnan(b)
+        dev = float(np.max(np.abs(a[ok] - b[ok]) / np.maximum(1.0, np.abs(b[ok])))) if ok.any() else 0.0
+        if dev > max(1e-6, 1e4 * tol):
+            return tag, float("inf"), f"{nm_} differs by {dev:.2e}"
+    if latent and not np.array_equal(st["RANK"], rst["RANK"]):
+        return tag, 0.0, "iterations: rank differs at a point"
+    if tuple(np.atleast_1d(ix).tolist()) != tuple(np.atleast_1d(rix).tolist()):
+        tab = rst["AIC"] if method == "AIC" else rst["BIC"][gamma]
+        two = np.sort(tab[~np.isnan(tab)])[:2]
+        if len(two) == 2 and abs(two[1] - two[0]) <= 1e-5 * max(1.0, abs(two[0])):
+            return tag, 0.0, "iterations: best point differs between two scores that tie"
+        return tag, float("inf"), f"best index {ix} vs {rix}"
+    worst = max(float(np.abs(best["Theta"][k] - rbest["Theta"][k]).max()) / max(1.0, float(np.abs(rbest["Theta"][k]).max())) for k in range(K))
+    if worst > max(TOL, 100 * tol):
+        return tag, float("inf"), f"best Theta differs by {worst:.2e}"
+    return tag, min(worst, TOL), ""
+
+
 def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     """Runs ``cases`` cases of the stream ``seed``; returns (cases off, last-bit stopping notes, largest deviation of the rest).
-    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind``: "solver" (one), "batch" (one_batch), "block" (one_block), "ext" (one_ext), "ops" (one_ops), "stats" (one_stats), "grid" (one_grid), "isolate" (one_isolate), "mgrid" (one_mgrid)."""
+    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind``: "solver" (one), "batch" (one_batch), "block" (one_block), "ext" (one_ext), "ops" (one_ops), "stats" (one_stats), "grid" (one_grid), "isolate" (one_isolate), "mgrid" (one_mgrid), "kgrid" (one_kgrid), "egrid" (one_egrid)."""
     global PBIG
     rng = np.random.default_rng(seed)
     keep, bad, notes, mx = PBIG, 0, 0, 0.0
@@ -631,7 +784,7 @@ def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     try:
         for i in range(cases):
             try:
-                tag, worst, note = {"batch": one_batch, "block": one_block, "ext": one_ext, "ops": one_ops, "stats": one_stats, "grid": one_grid, "isolate": one_isolate, "mgrid": one_mgrid}.get(kind, one)(i, rng)
+                tag, worst, note = {"batch": one_batch, "block": one_block, "ext": one_ext, "ops": one_ops, "stats": one_stats, "grid": one_grid, "isolate": one_isolate, "mgrid": one_mgrid, "kgrid": one_kgrid, "egrid": one_egrid}.get(kind, one)(i, rng)
             except Exception as e:                                      # a crash is a finding too
                 out(f"case {i}: raised {type(e).__name__}: {e}")
                 bad += 1

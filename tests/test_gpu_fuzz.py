@@ -27,7 +27,7 @@ def test_random_grids_through_the_batch_drivers_against_the_oracle():
 
 
 @pytest.mark.parametrize("kind,cases,seed", [("block", 60, 43), ("ext", 40, 53), ("ops", 60, 63), ("stats", 40, 73), ("grid", 25, 83),
-                                              ("isolate", 40, 93), ("mgrid", 40, 103)])
+                                              ("isolate", 40, 93), ("mgrid", 40, 103), ("kgrid", 25, 113), ("egrid", 12, 123)])
 def test_random_block_and_nonconforming_problems_against_the_oracle(kind, cases, seed):
     """block_SGL on covariance matrices with planted components of very different size (singletons to 70, all solved together
     on the GPU; solver/single_admm_solver.py:326-475) and ext_ADMM_MGL on K = 2 .. 5 instances of different dimension with a
@@ -36,7 +36,8 @@ def test_random_block_and_nonconforming_problems_against_the_oracle(kind, cases,
     very different conditioning in one stack -- and prox_p with ties and exact zeros across K; solver/ggl_helper.py); the device's selection statistics
     (<S,Theta>, log det, count_nonzero, lambda_min, rank of L, the thresholded tables; helper/model_selection.py:619-660, 698-737)
     against numpy on the solutions a random latent / non-latent grid returns; single_grid_search and grid_search
-    (helper/model_selection.py:505-692, 55-298) on random grids against the host tables of the oracle's point-by-point solves;
+    (helper/model_selection.py:505-692, 55-298; the latter also with ext_ADMM_MGL on instances of different dimension) and
+    K_single_grid (:300-503) on random grids against the host tables of the oracle's point-by-point solves;
     grids with poisoned points (NaN / Inf in their S): those end as 'solver error', the others are the grid's without them."""
     lines = []
     bad, notes, worst = fuzz_checks.run_cases(cases, seed, out=lines.append, kind=kind)

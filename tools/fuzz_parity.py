@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU (the cases of tests/fuzz_checks.py, as many as asked for): ADMM_MGL / ADMM_SGL through the C
 ABI against the CPU oracle on shapes and parameters the fixed tests do not visit.
-    python tools/fuzz_parity.py [cases] [seed] [solver|batch|block|ext|ops|stats|grid|isolate|mgrid]     -- prints every case that is off by more than 1e-9 (inputs -> gpurun_out/fuzz/)
+    python tools/fuzz_parity.py [cases] [seed] [solver|batch|block|ext|ops|stats|grid|isolate|mgrid|kgrid|egrid]     -- prints every case that is off by more than 1e-9 (inputs -> gpurun_out/fuzz/)
                                                       and a summary line"""
 import os
 import sys
