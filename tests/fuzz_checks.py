@@ -17,6 +17,7 @@ PBIG = [191, 200, 255, 256, 257, 300]          # (one case in ten)
 TOL = float(os.environ.get("GGL_FUZZ_TOL", 1e-9))    # relative to max(1, |reference|_max), every array of the solution (the
                                                # variable: a tighter bar lists the cases nearest to it)
 LAST = {}                                      # the inputs of the case under way: written out when it is off
+GROUPED = []                                   # one_bigbatch: (grouping forced, Omega-steps that ran as groups) per case
 
 
 def quiet(fn, *a, **k):
@@ -773,9 +774,75 @@ def one_egrid(i, rng):
     return tag, min(worst, TOL), ""
 
 
+def one_bigbatch(i, rng):
+    """A lambda (x mu) grid at the sizes where a batch runs as groups with their own Newton-Schulz schedules, concurrent parts,
+    compaction and the C loop (p = 256 .. 500, 6 .. 20 points over two decades of lambda1: instances of very different
+    conditioning) -- every point against the oracle's own solve; in half of the cases grouping is FORCED (GGL_OPT_GROUP_SCHED =
+    13) through a subclass of the engine, so that the split is exercised whatever the size rule says."""
+    from gglasso_amd import batch, solver, synth
+    from oracle import ggl_oracle as orc
+    p = int(rng.choice([256, 300, 333, 400, 500]))
+    G = int(rng.integers(6, 21))
+    latent = bool(rng.random() < 0.3)
+    lam = 10.0 ** rng.uniform(-2.0, 0.0, G)
+    mu = 10.0 ** rng.uniform(-0.3, 0.7, G)
+    tol = float(10.0 ** rng.uniform(-8, -6))
+    force = bool(rng.random() < 0.5)
+    max_iter = int(rng.choice([25, 400]))
+    S, _ = synth.make_problem("GGL", 1, p, N=int(rng.integers(p, 3 * p)), seed=int(rng.integers(1 << 30)))
+    S = S[0]
+    tag = dict(i=i, kind="bigbatch", p=p, G=G, latent=latent, tol=tol, forced_groups=force, max_iter=max_iter)
+    LAST.clear()
+    LAST.update(S=S, lam=lam, mu=mu, latent=latent, tol=tol, force=force, max_iter=max_iter)
+    keep = solver.ENGINE
+    seen = {}
+
+    class Forced(keep):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.set_option("group_sched", 13 if force else 1)
+
+        def close(self):
+            try:
+                gs = self.group_stats()
+                seen["steps"] = seen.get("steps", 0) + gs["steps"]
+            except Exception:
+                pass
+            return super().close()
+
+    solver.ENGINE = Forced
+    try:
+        res = quiet(batch.ADMM_SGL_batch, S, lam, Omega_0=np.eye(p), X_0=np.zeros((p, p)), tol=tol, rtol=tol, max_iter=max_iter,
+                    latent=latent, mu1=mu if latent else None)
+    finally:
+        solver.ENGINE = keep
+    tag["grouped_steps"] = seen.get("steps")
+    worst, note = 0.0, ""
+    for g in range(G):
+        kw = dict(latent=True, mu1=float(mu[g])) if latent else {}
+        ref, rinfo = quiet(orc.ADMM_SGL, S, float(lam[g]), np.eye(p), X_0=np.zeros((p, p)), tol=tol, rtol=tol, max_iter=max_iter, **kw)
+        sol, info = res[g]
+        if info["iterations"] != rinfo["iterations"]:
+            if abs(info["iterations"] - rinfo["iterations"]) > 1:
+                return tag, float("inf"), f"point {g}: iterations {info['iterations']} vs {rinfo['iterations']}"
+            note = f"point {g}: iterations {info['iterations']} vs {rinfo['iterations']}"
+            continue
+        if info["status"] != rinfo["status"]:
+            return tag, float("inf"), f"point {g}: status {info['status']!r} vs {rinfo['status']!r}"
+        for nm in ("Omega", "Theta", "X") + (("L",) if latent else ()):
+            a, b = np.asarray(sol[nm]), np.asarray(ref[nm])
+            if not np.all(np.isfinite(a)):
+                return tag, float("inf"), f"point {g}: {nm} not finite"
+            worst = max(worst, float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max())))
+    # (forced grouping still yields to the rules that keep a batch whole: one schedule for all when an instance needs the stable
+    # iteration (kappa > 300), equal product counts, a K-sharded ctx -- so 'grouped_steps' is reported, not required)
+    GROUPED.append((force, seen.get("steps", 0)))
+    return tag, worst, note
+
+
 def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     """Runs ``cases`` cases of the stream ``seed``; returns (cases off, last-bit stopping notes, largest deviation of the rest).
-    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind``: "solver" (one), "batch" (one_batch), "block" (one_block), "ext" (one_ext), "ops" (one_ops), "stats" (one_stats), "grid" (one_grid), "isolate" (one_isolate), "mgrid" (one_mgrid), "kgrid" (one_kgrid), "egrid" (one_egrid)."""
+    ``big`` False keeps p <= 130 (the suite's quick pass); ``kind``: "solver" (one), "batch" (one_batch), "block" (one_block), "ext" (one_ext), "ops" (one_ops), "stats" (one_stats), "grid" (one_grid), "isolate" (one_isolate), "mgrid" (one_mgrid), "kgrid" (one_kgrid), "egrid" (one_egrid), "bigbatch" (one_bigbatch)."""
     global PBIG
     rng = np.random.default_rng(seed)
     keep, bad, notes, mx = PBIG, 0, 0, 0.0
@@ -784,7 +851,7 @@ def run_cases(cases, seed, out=print, dump_dir=None, big=True, kind="solver"):
     try:
         for i in range(cases):
             try:
-                tag, worst, note = {"batch": one_batch, "block": one_block, "ext": one_ext, "ops": one_ops, "stats": one_stats, "grid": one_grid, "isolate": one_isolate, "mgrid": one_mgrid, "kgrid": one_kgrid, "egrid": one_egrid}.get(kind, one)(i, rng)
+                tag, worst, note = {"batch": one_batch, "block": one_block, "ext": one_ext, "ops": one_ops, "stats": one_stats, "grid": one_grid, "isolate": one_isolate, "mgrid": one_mgrid, "kgrid": one_kgrid, "egrid": one_egrid, "bigbatch": one_bigbatch}.get(kind, one)(i, rng)
             except Exception as e:                                      # a crash is a finding too
                 out(f"case {i}: raised {type(e).__name__}: {e}")
                 bad += 1
