@@ -12,6 +12,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import fuzz_checks  # noqa: E402
 
+if os.environ.get("GGL_DEBUG_POISON", "") not in ("", "0"):
+    # every ctx of this process starts from buffers filled with that byte instead of zeros (1 = 0xFF: NaN; 127 / 71: finite garbage)
+    from gglasso_amd import _lib
+    _lib.load().ggl_debug_poison(int(os.environ["GGL_DEBUG_POISON"]))
+    print("ctx buffers pre-filled with byte", int(os.environ["GGL_DEBUG_POISON"]))
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 kind = sys.argv[3] if len(sys.argv) > 3 else "solver"
