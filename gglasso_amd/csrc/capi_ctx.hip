@@ -695,7 +695,8 @@ static int upload_stack(ggl_ctx* c, double* dst, const double* src, int period)
 {
     // period 0: the host array holds all K instances; P > 0: it holds P, and instance k is its instance k % P
     const size_t pp = (size_t)c->p * c->p;
-    if (period <= 0 || period >= c->K) {
+    ARGCHK(period >= 0 && period <= c->K, "period: 0 (all K) or a divisor of K");
+    if (period == 0 || period == c->K) {
         HIPCHK(hipMemcpyAsync(dst, src, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         return GGL_OK;
     }

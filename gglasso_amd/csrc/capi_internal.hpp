@@ -38,8 +38,11 @@ using namespace ggl;
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess)                                                                          \
+        if (e_ != hipSuccess) {                                                                        \
+            (void)hipGetLastError();   /* the runtime keeps a failed call's code as the thread's "last error": taken here, or  \
+                                          the next launch check of an unrelated, valid call reports it (tools/abi_misuse.py) */ \
             return fail(GGL_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                              \
     } while (0)
 
 #define ARGCHK(cond, msg)                                       \

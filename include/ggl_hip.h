@@ -84,7 +84,7 @@ int ggl_device_count(void);
  * Replaces the NumPy temporaries ADMM_MGL allocates per call (admm_solver.py:142-154).
  * stream: an existing hipStream_t or NULL to create one (see GGL_CTX_STREAM_GIVEN for the NULL stream itself). */
 int ggl_ctx_create(int device, int K, int p, int flags, void *stream, ggl_ctx **out);
-int ggl_ctx_destroy(ggl_ctx *ctx);
+int ggl_ctx_destroy(ggl_ctx *ctx);          /* (NULL: a no-op that succeeds, like free) */
 int ggl_ctx_sync(ggl_ctx *ctx);
 void *ggl_device_ptr(ggl_ctx *ctx, int which);
 
@@ -208,8 +208,8 @@ int ggl_set_S(ggl_ctx *ctx, const double *S_host);
 int ggl_set_state(ggl_ctx *ctx, const double *Omega, const double *Theta, const double *L,
                   const double *X);
 /* The same with arrays SHARED by the instances of a batch: `period` / periods[0..3] (Omega, Theta, L, X; NULL = all 0) is the
- * number of instances the host array holds -- 0: all K; P > 0 (a divisor of K): P, and instance k of the ctx is its instance
- * k % P.  P = 1: one (p,p) matrix for all (the grid of single_grid_search starts every instance from the same S, Omega_0, X_0);
+ * number of instances the host array holds -- 0: all K; P > 0 (a divisor of K, anything else is GGL_E_ARG): P, and instance k of the
+ * ctx is its instance k % P.  P = 1: one (p,p) matrix for all (the grid of single_grid_search starts every instance from the same S, Omega_0, X_0);
  * P = K': the stack of ONE multiple-graph problem for each of the G grid points of grid_search.  Uploaded once, replicated on
  * the device. */
 int ggl_set_S_ex(ggl_ctx *ctx, const double *S_host, int period);
