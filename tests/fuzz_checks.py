@@ -17,6 +17,7 @@ PBIG = [191, 200, 255, 256, 257, 300]          # (one case in ten)
 TOL = float(os.environ.get("GGL_FUZZ_TOL", 1e-9))    # relative to max(1, |reference|_max), every array of the solution (the
                                                # variable: a tighter bar lists the cases nearest to it)
 LAST = {}                                      # the inputs of the case under way: written out when it is off
+N_SAMPLES_INT = False                          # see one(): True in tests/golden/fuzz_oracle_vs_reference.py
 GROUPED = []                                   # one_bigbatch: (grouping forced, Omega-steps that ran as groups) per case
 
 
@@ -83,7 +84,9 @@ def one(i, rng):
         if warm:
             eye, kw["Theta_0"], kw["X_0"] = starts
         if rng.random() < 0.3:
-            kw["n_samples"] = rng.integers(5, 500, K)               # the weights of the log-likelihood terms (admm_solver.py:127-134)
+            # the weights of the log-likelihood terms (admm_solver.py:127-139): an array (K,) -- or one int for all where the
+            # REFERENCE itself is on the other side (its array branch cannot be reached: `n_samples == None` on an array raises)
+            kw["n_samples"] = int(rng.integers(5, 500)) if N_SAMPLES_INT else rng.integers(5, 500, K)
             tag["n_samples"] = True
         ref, rinfo = quiet(orc.ADMM_MGL, S, lam1, lam2, reg, eye.copy(), **{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
         got, ginfo = quiet(solver.ADMM_MGL, S, lam1, lam2, reg, eye.copy(), **{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
