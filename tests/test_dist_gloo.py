@@ -88,6 +88,95 @@ def test_k_sharded_ggl_equals_single_process(tmp_path, K, world, miss, latent):
     assert covered == K
 
 
+def _random_cases(seed, n):
+    """n drawn K-sharded problems (same on every rank and in the checker): K, p, lambdas, rho, rho updates, latent, n_samples,
+    tolerance or a fixed length, and a script of speculation misses."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        K, p = int(rng.integers(2, 10)), int(rng.choice([3, 8, 16, 17, 24]))
+        c = dict(K=K, p=p, seed=int(rng.integers(1 << 30)), lam1=float(10.0 ** rng.uniform(-2, -0.3)),
+                 lam2=float(10.0 ** rng.uniform(-2.5, -0.5)), rho=float(10.0 ** rng.uniform(-0.7, 0.7)), upd=bool(rng.random() < 0.6),
+                 latent=bool(rng.random() < 0.4), mu=10.0 ** rng.uniform(-0.5, 0.5, K),
+                 nk=(rng.integers(5, 300, K) if rng.random() < 0.3 else None))
+        if rng.random() < 0.5:
+            c.update(tol=1e-20, rtol=1e-20, max_iter=int(rng.integers(1, 14)))
+        else:
+            c.update(tol=float(10.0 ** rng.uniform(-9, -6)), rtol=float(10.0 ** rng.uniform(-8, -5)), max_iter=400)
+        c["miss"] = ",".join(f"{int(rng.integers(2))}:{int(rng.integers(1, 12))}" for _ in range(int(rng.integers(0, 4)))) \
+            if rng.random() < 0.5 else ""
+        cases.append(c)
+    return cases
+
+
+def _random_worker(rank, world, port, seed, n, out_dir):
+    import contextlib
+    import io
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gglasso_amd import solver, synth
+    from gglasso_amd.dist import ADMM_MGL_sharded, TorchComm, shard_bounds
+    from oracle_engine import OracleEngine, SpeculatingOracleEngine
+    out = {}
+    for i, c in enumerate(_random_cases(seed, n)):
+        S, _ = synth.make_problem("GGL", c["K"], c["p"], seed=c["seed"])
+        k0, k1 = shard_bounds(c["K"], world, rank)
+        comm = TorchComm()
+        solver.ENGINE = OracleEngine
+        os.environ["GGL_TEST_MISS"] = c["miss"]
+        if c["miss"]:
+            comm.device_norms = True
+            solver.ENGINE = SpeculatingOracleEngine
+        extra = dict(latent=True, mu1=c["mu"][k0:k1]) if c["latent"] else {}
+        if c["nk"] is not None:
+            extra["n_samples"] = c["nk"][k0:k1]
+        with contextlib.redirect_stdout(io.StringIO()):
+            sol, info = ADMM_MGL_sharded(S[k0:k1], c["lam1"], c["lam2"], "GGL", np.repeat(np.eye(c["p"])[None], k1 - k0, axis=0), c["K"],
+                                         comm, tol=c["tol"], rtol=c["rtol"], max_iter=c["max_iter"], rho=c["rho"], update_rho=c["upd"],
+                                         measure=True, **extra)
+        out[f"{i}_status"] = info["status"]
+        out[f"{i}_iters"] = len(info["residual"])
+        for nm in sol:
+            out[f"{i}_{nm}"] = sol[nm]
+    np.savez(os.path.join(out_dir, f"random_rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed", [77, 78])
+def test_k_sharded_random_cases_equal_the_unsharded_solve(tmp_path, seed):
+    """Twenty-four drawn problems (K = 2 .. 9 over two ranks -- uneven slabs, a rank with ONE instance --, p = 3 .. 24, rho updates,
+    latent variables with per-instance mu1, n_samples weights, fixed lengths and runs to a tolerance, scripted speculation misses on
+    either rank) through the real driver loop on two gloo ranks: every rank's slab equals the oracle's unsharded ADMM_MGL
+    (solver/admm_solver.py:13-313), same status, same iteration count."""
+    import torch.multiprocessing as mp
+    from oracle import ggl_oracle as orc
+    from gglasso_amd import synth
+    from gglasso_amd.dist import shard_bounds
+    n, world = 24, 2
+    port = _free_port()
+    mp.spawn(_random_worker, args=(world, port, seed, n, str(tmp_path)), nprocs=world, join=True)
+    z = [np.load(os.path.join(str(tmp_path), f"random_rank{r}.npz")) for r in range(world)]
+    for i, c in enumerate(_random_cases(seed, n)):
+        S, _ = synth.make_problem("GGL", c["K"], c["p"], seed=c["seed"])
+        extra = dict(latent=True, mu1=c["mu"]) if c["latent"] else {}
+        if c["nk"] is not None:
+            extra["n_samples"] = c["nk"]
+        ref, rinfo = orc.ADMM_MGL(S, c["lam1"], c["lam2"], "GGL", np.repeat(np.eye(c["p"])[None], c["K"], axis=0), tol=c["tol"],
+                                  rtol=c["rtol"], max_iter=c["max_iter"], rho=c["rho"], update_rho=c["upd"], **extra)
+        for r in range(world):
+            k0, k1 = shard_bounds(c["K"], world, r)
+            assert int(z[r][f"{i}_iters"]) == rinfo["iterations"], (i, c, r)
+            if c["tol"] > 1e-19:          # (at tol = 1e-20 the closing status test passes only for an exactly-zero residual)
+                assert str(z[r][f"{i}_status"]) == rinfo["status"], (i, c, r)
+            for nm in ("Omega", "Theta", "X") + (("L",) if c["latent"] else ()):
+                assert np.abs(z[r][f"{i}_{nm}"] - ref[nm][k0:k1]).max() <= 1e-9 * max(1.0, np.abs(ref[nm]).max()), (i, c, r, nm)
+
+
 def test_shard_helpers():
     from gglasso_amd.dist import shard_bounds, shard_grid
     for K in (1, 7, 32, 256):
