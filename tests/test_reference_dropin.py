@@ -114,6 +114,46 @@ def test_seam2_glasso_problem_with_patched_solvers(ref, ours, monkeypatch):
         assert np.abs(P1.solution.precision_ - P0.solution.precision_).max() <= 1e-8
 
 
+def test_seam2_glasso_problem_on_drawn_configurations(ref, monkeypatch):
+    """The real glasso_problem class (problem.py) on sixty drawn configurations -- single / GGL / FGL, K = 2 .. 5, p = 6 .. 24, latent
+    on / off, do_scaling on / off (the class scales S to correlations and the solution back, problem.py:239-262), drawn reg_params
+    -- once with its own solvers, once with ours swapped in at the by-name imports (problem.py:10-11): same status, same
+    precision_ (and lowrank_)."""
+    dg, problem, ms = ref["dg"], ref["problem"], ref["ms"]
+    from gglasso_amd import solver
+    from oracle_engine import OracleEngine
+    rng = np.random.default_rng(4242)
+    for trial in range(60):
+        single = bool(rng.random() < 0.35)
+        K, p, N = int(rng.integers(2, 6)), int(rng.choice([6, 10, 16, 24])), int(rng.integers(60, 400))
+        reg = None if single else ("GGL" if rng.random() < 0.5 else "FGL")
+        latent, scaling = bool(rng.random() < 0.4), bool(rng.random() < 0.5)
+        from gglasso_amd import synth
+        Sk, _ = synth.make_problem(reg or "GGL", 1 if single else K, p, N=N, seed=int(rng.integers(1 << 30)))
+        S = Sk[0] if single else Sk
+        params = {'lambda1': float(10.0 ** rng.uniform(-1.6, -0.5)), 'lambda2': float(10.0 ** rng.uniform(-2.0, -0.7)),
+                  'mu1': float(10.0 ** rng.uniform(-0.7, 0.3))}
+        tag = dict(trial=trial, single=single, K=K, p=p, N=N, reg=reg, latent=latent, scaling=scaling, **params)
+
+        def solve():
+            P = problem.glasso_problem(S, N, reg=reg, reg_params=dict(params), latent=latent, do_scaling=scaling)
+            quiet(P.solve, tol=1e-9, rtol=1e-9)
+            return P
+
+        monkeypatch.undo()
+        P0 = solve()
+        monkeypatch.setattr(solver, "ENGINE", OracleEngine)
+        monkeypatch.setattr(problem, "ADMM_MGL", solver.ADMM_MGL)
+        monkeypatch.setattr(problem, "ADMM_SGL", solver.ADMM_SGL)
+        monkeypatch.setattr(problem, "block_SGL", solver.block_SGL)
+        P1 = solve()
+        # (the non-latent single problem goes through block_SGL, which returns no info: problem.py:443-450)
+        assert P1.solver_info.get('status') == P0.solver_info.get('status'), tag
+        assert np.abs(P1.solution.precision_ - P0.solution.precision_).max() <= 1e-8 * max(1.0, np.abs(P0.solution.precision_).max()), tag
+        if latent:
+            assert np.abs(P1.solution.lowrank_ - P0.solution.lowrank_).max() <= 1e-8 * max(1.0, np.abs(P0.solution.precision_).max()), tag
+
+
 def test_seam2_model_selection_single(ref, ours, monkeypatch):
     """single_grid_search (model_selection.py:505) drives block_SGL / ADMM_SGL imported at :13."""
     dg, problem, ms = ref["dg"], ref["problem"], ref["ms"]
