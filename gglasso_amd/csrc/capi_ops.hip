@@ -843,9 +843,24 @@ extern "C" int ggl_dev_mfma_f64_peak(double* tflops_out)
 }
 #endif   // GGL_DEV
 
+// the eigensolver selector of the stateless entry points (low byte; GGL_EIG_NS_MODE / _DEGREES above it are checked by the ctx)
+static bool eig_selector_ok(int eig_method)
+{
+    const int e = eig_method & 0xff;
+    return e == GGL_EIG_AUTO || e == GGL_EIG_JACOBI || e == GGL_EIG_ROCSOLVER || e == GGL_EIG_NEWTON_SCHULZ;
+}
+// beta of the log-det prox (n_k / rho, admm_solver.py:180-187): positive and finite for every instance
+static bool betas_ok(const double* beta, int K)
+{
+    for (int k = 0; k < K; ++k)
+        if (!(beta[k] > 0.0) || !std::isfinite(beta[k])) return false;
+    return true;
+}
+
 extern "C" int ggl_eigh_batched(int K, int p, const double* A, double* D, double* Q, int eig_method)
 {
     ARGCHK(D, "D");
+    ARGCHK(eig_selector_ok(eig_method), "eigensolver selector");
     return eig_common(K, p, A, nullptr, D, Q, nullptr, MAP_IDENT, eig_method & 0xff);
 }
 
@@ -853,6 +868,8 @@ extern "C" int ggl_phiplus_matrix(int K, int p, const double* beta, const double
 {
     ARGCHK(beta && out && W, "beta, W, out");
     ARGCHK(K >= 1 && p >= 1, "K, p");
+    ARGCHK(eig_selector_ok(eig_method), "eigensolver selector");
+    ARGCHK(betas_ok(beta, K), "beta must be positive and finite");
     if (use_ns(eig_method & 0xff, p)) {
         // run the Omega-step of a scratch ctx with Theta = W, X = S = 0, nk = beta, rho = 1
         ggl_ctx* c = nullptr;
@@ -894,6 +911,7 @@ static int rank_matrix_impl(int K, int p, const double* beta, const double* C, d
 {
     ARGCHK(beta && out && C, "beta, C, out");
     ARGCHK(K >= 1 && p >= 1, "K, p");
+    ARGCHK(eig_selector_ok(eig_method), "eigensolver selector");
     if (stats) for (int i = 0; i < nstats; ++i) stats[i] = 0;
     if (use_ns(eig_method & 0xff, p)) {
         // the L-step of a scratch ctx: C into the work stack, beta into the mu/rho parameter slot
@@ -930,6 +948,7 @@ extern "C" int ggl_rank_matrix(int K, int p, const double* beta, const double* C
 static int recon_common(int K, int p, const double* beta, const double* D, const double* Q, double* out, int map)
 {
     ARGCHK(K >= 1 && p >= 1 && beta && D && Q && out, "arguments");
+    ARGCHK(map != MAP_PHIPLUS || betas_ok(beta, K), "beta must be positive and finite");
     const size_t n = (size_t)K * p * p, kp = (size_t)K * p;
     // Q has eigenvectors in columns; the kernel wants them in rows
     std::vector<double> R(n);

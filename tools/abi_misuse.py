@@ -97,5 +97,51 @@ rc = step(1.0, 0.1, 0.05, 0)
 print("valid ggl_admm_step after the probes: rc", rc, last() if rc else "", "norms finite", bool(np.all(np.isfinite(norms[:5]))))
 bad += 0 if rc == 0 and np.all(np.isfinite(norms[:5])) else 1
 lib.ggl_ctx_destroy(h)
+
+# ---- the stateless operators (the seam solver/admm_solver.py:11 imports) and the batch / snapshot / subset entry points ----
+A = np.eye(6)
+out6 = np.zeros((1, 6, 6))
+b1 = np.ones(1)
+expect_error("ggl_phiplus_matrix(K=0)", lib.ggl_phiplus_matrix(0, 6, ptr(b1), ptr(A), ptr(out6), 0))
+expect_error("ggl_phiplus_matrix(p=-2)", lib.ggl_phiplus_matrix(1, -2, ptr(b1), ptr(A), ptr(out6), 0))
+expect_error("ggl_phiplus_matrix(W=NULL)", lib.ggl_phiplus_matrix(1, 6, ptr(b1), None, ptr(out6), 0))
+expect_error("ggl_phiplus_matrix(eig_method=77)", lib.ggl_phiplus_matrix(1, 6, ptr(b1), ptr(A), ptr(out6), 77))
+expect_error("ggl_phiplus_matrix(beta=0)", lib.ggl_phiplus_matrix(1, 6, ptr(np.zeros(1)), ptr(A), ptr(out6), 0))
+expect_error("ggl_phiplus_matrix(beta=nan)", lib.ggl_phiplus_matrix(1, 6, ptr(np.full(1, np.nan)), ptr(A), ptr(out6), 0))
+expect_error("ggl_rank_matrix(eig_method=200)", lib.ggl_rank_matrix(1, 6, ptr(b1), ptr(A), ptr(out6), 200))
+expect_error("ggl_phiplus(beta=-1)", lib.ggl_phiplus(1, 6, ptr(-b1), ptr(np.ones(6)), ptr(A), ptr(out6)))
+expect_error("ggl_rank_matrix(out=NULL)", lib.ggl_rank_matrix(1, 6, ptr(b1), ptr(A), None, 0))
+expect_error("ggl_eigh_batched(A=NULL)", lib.ggl_eigh_batched(1, 6, None, ptr(np.zeros(6)), ptr(out6), 0))
+X6 = np.stack([A, A])
+expect_error("ggl_prox_p(l1=0)", lib.ggl_prox_p(2, 6, ptr(X6), ctypes.c_double(0.0), ctypes.c_double(0.1), 0, ptr(np.zeros_like(X6))))
+expect_error("ggl_prox_p(reg=5)", lib.ggl_prox_p(2, 6, ptr(X6), ctypes.c_double(0.1), ctypes.c_double(0.1), 5, ptr(np.zeros_like(X6))))
+expect_error("ggl_prox_p(X=NULL)", lib.ggl_prox_p(2, 6, None, ctypes.c_double(0.1), ctypes.c_double(0.1), 0, ptr(np.zeros_like(X6))))
+expect_error("ggl_prox_tv(K=0)", lib.ggl_prox_tv(3, 0, ptr(np.zeros(3)), ctypes.c_double(0.1), ptr(np.zeros(3))))
+expect_error("ggl_prox_tv(n=-1)", lib.ggl_prox_tv(-1, 3, ptr(np.zeros(3)), ctypes.c_double(0.1), ptr(np.zeros(3))))
+expect_error("ggl_prox_od_1norm(A=NULL)", lib.ggl_prox_od_1norm(6, None, ctypes.c_double(0.1), None, ptr(out6)))
+rc, h = ctx(4, 8)
+assert rc == 0, last()
+S4 = np.stack([np.eye(8)] * 4)
+assert lib.ggl_set_S(h, ptr(S4)) == 0 and lib.ggl_set_state(h, ptr(S4), ptr(S4), None, ptr(np.zeros_like(S4))) == 0, last()
+r4, l4, o20 = np.ones(4), np.full(4, 0.1), np.zeros(20)
+expect_error("ggl_mgl_batch_step(G=3 of K=4)", lib.ggl_mgl_batch_step(h, 3, ptr(r4), ptr(l4), ptr(l4), 0, 0, None, None, ptr(o20)))
+expect_error("ggl_mgl_batch_step(G=0)", lib.ggl_mgl_batch_step(h, 0, ptr(r4), ptr(l4), ptr(l4), 0, 0, None, None, ptr(o20)))
+sub = ctypes.c_void_p()
+expect_error("ggl_ctx_create_subset(idx out of range)", lib.ggl_ctx_create_subset(h, (ctypes.c_int * 2)(1, 9), 2, ctypes.byref(sub)))
+expect_error("ggl_ctx_create_subset(m=0)", lib.ggl_ctx_create_subset(h, (ctypes.c_int * 2)(1, 2), 0, ctypes.byref(sub)))
+expect_error("ggl_ctx_create_subset(idx=NULL)", lib.ggl_ctx_create_subset(h, None, 2, ctypes.byref(sub)))
+expect_error("ggl_get_snapshot_k(k=4 of K=4)", lib.ggl_get_snapshot_k(h, 4, ptr(S4), None))
+expect_error("ggl_reset_instance(k=-1)", lib.ggl_reset_instance(h, -1))
+expect_error("ggl_failed_reason(k=7)", lib.ggl_failed_reason(h, 7, ptr(np.zeros(2))))
+expect_error("ggl_selection_stats(out=NULL)", lib.ggl_selection_stats(h, None))
+expect_error("ggl_objective(reg=9)", lib.ggl_objective(h, ctypes.c_double(0.1), ctypes.c_double(0.1), 9, ptr(np.zeros(3))))
+expect_error("ggl_trace_start(max_events=-5)", lib.ggl_trace_start(h, -5))
+expect_error("ggl_comm_init(nranks=0)", lib.ggl_comm_init(h, 0, 0, ctypes.create_string_buffer(128)))
+expect_error("ggl_comm_init(rank >= nranks)", lib.ggl_comm_init(h, 3, 2, ctypes.create_string_buffer(128)))
+expect_error("ggl_allreduce_norms without a communicator", lib.ggl_allreduce_norms(h))
+rc = lib.ggl_sgl_batch_step(h, ptr(r4), ptr(l4), 0, None, ptr(o20))
+print("valid ggl_sgl_batch_step after the probes: rc", rc, last() if rc else "", "sums finite", bool(np.all(np.isfinite(o20))))
+bad += 0 if rc == 0 and np.all(np.isfinite(o20)) else 1
+lib.ggl_ctx_destroy(h)
 print("ok" if bad == 0 else f"{bad} probes misbehaved")
 sys.exit(0 if bad == 0 else 1)
