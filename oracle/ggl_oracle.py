@@ -12,7 +12,7 @@ checks every function below against those vectors (operators <= 1e-12, 10-iterat
 <= 1e-10, converged Theta <= 1e-8) plus the reference's own known-answer test (lambda1_mask = 0
 => Theta = inv(S), tests/test_solvers.py:191-216).  Round 6: also on DRAWN inputs -- ``tests/golden/fuzz_oracle_vs_reference.py``
 runs the real reference against this module with the case generators of ``tests/fuzz_checks.py`` (ADMM_MGL / ADMM_SGL, block_SGL,
-ext_ADMM_MGL, the operators on engineered spectra; 4 240 cases, <= 3e-12; profiles/r6_oracle_pinned_on_random_inputs.txt).
+ext_ADMM_MGL, the operators on engineered spectra; 9 040 cases, <= 3e-12; profiles/r6_oracle_pinned_on_random_inputs.txt).
 
 Third-party arithmetic: the reference calls ``numpy.linalg.eigh`` (LAPACK dsyevd via NumPy; pin
 ``numpy>=1.17.3,<2.0.0`` in pyproject.toml:37, NumPy 2.2.6/OpenBLAS 0.3.29 in this image) at
